@@ -1,0 +1,186 @@
+/* mgx.h — C ABI of the MI355X-native GBP message-passing engine.
+ *
+ * Drop-in boundary for the factor-graph inner loop of AU-Master-Thesis/magics.
+ * The reference has no FFI seam; the seam is the public Rust API of `FactorGraph`
+ * (crates/magics/src/factorgraph/factorgraph.rs:76) as driven by
+ * crates/magics/src/planner/robot.rs.  Because GPU execution is batched over all
+ * robots, the ABI is world-level: one `mgx_world` owns every robot's factor graph
+ * (device resident, SoA) and each entry point names the reference call it replaces.
+ *
+ * Conventions: plain C, caller owns every buffer it passes, the library owns all
+ * device memory.  Every call returns an `int` status (MGX_OK == 0, negative =
+ * error, never aborts).  A world is thread-compatible (external synchronisation).
+ * All floating point is f64 (crates/gbp_linalg/src/lib.rs:31), DOFS = 4
+ * (crates/magics/src/factorgraph/mod.rs:21).  Matrices are row-major.
+ *
+ * There is NO CPU fallback: every compute entry point fails with
+ * MGX_ERR_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef MGX_H
+#define MGX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGX_DOFS 4
+
+/* status codes */
+#define MGX_OK 0
+#define MGX_ERR_INVALID (-1)   /* bad argument (null pointer, index out of range, K < 2 ...) */
+#define MGX_ERR_NO_DEVICE (-2) /* no usable HIP device / HIP runtime error at init */
+#define MGX_ERR_HIP (-3)       /* HIP runtime call failed (see mgx_last_error) */
+#define MGX_ERR_STATE (-4)     /* call not valid in the current state */
+#define MGX_ERR_NOMEM (-5)
+
+/* factor kinds, bit positions of mgx_params.enable_mask
+ * (gbp_config FactorsEnabledSection, crates/gbp_config/src/lib.rs:454-494) */
+#define MGX_FACTOR_DYNAMIC 1u
+#define MGX_FACTOR_INTERROBOT 2u
+#define MGX_FACTOR_OBSTACLE 4u
+#define MGX_FACTOR_TRACKING 8u
+
+/* one schedule step, bits of the uint8 passed to mgx_iterate
+ * (gbp_schedule::GbpScheduleAtIteration, crates/gbp_schedule/src/schedules/mod.rs:59-63) */
+#define MGX_STEP_INTERNAL 1u
+#define MGX_STEP_EXTERNAL 2u
+
+/* schedule kinds (crates/gbp_schedule/src/schedules/ *.rs) */
+#define MGX_SCHEDULE_CENTERED 0
+#define MGX_SCHEDULE_SOON_AS_POSSIBLE 1
+#define MGX_SCHEDULE_LATE_AS_POSSIBLE 2
+#define MGX_SCHEDULE_INTERLEAVE_EVENLY 3
+#define MGX_SCHEDULE_HALF_BEGINNING_HALF_END 4
+
+typedef struct mgx_world mgx_world;
+
+/* World-wide GBP parameters: the values `RobotBundle::new` and
+ * `create_interrobot_factors` read from `Config` (robot.rs:1134-1356,1441-1586).
+ * Sigmas are the f32 config values already widened to f64 (`Float::from(f32)`). */
+typedef struct mgx_params {
+    double sigma_dynamics;           /* config.gbp.sigma_factor_dynamics   */
+    double sigma_interrobot;         /* config.gbp.sigma_factor_interrobot */
+    double sigma_obstacle;           /* config.gbp.sigma_factor_obstacle   */
+    double sigma_tracking;           /* config.gbp.sigma_factor_tracking   */
+    double safety_multiplier;        /* config.robot.inter_robot_safety_distance_multiplier */
+    double tracking_switch_padding;  /* config.gbp.tracking.switch_padding (f32 widened)      */
+    double tracking_attraction_distance; /* config.gbp.tracking.attraction_distance          */
+    uint32_t enable_mask;            /* MGX_FACTOR_* bits: config.gbp.factors_enabled        */
+    uint32_t reserved;
+} mgx_params;
+
+/* One robot = one reference `FactorGraph` built by `RobotBundle::new`
+ * (robot.rs:1134-1356): K variables, K-1 dynamic factors, K-2 obstacle factors and
+ * K-2 tracking factors (on variables 1..K-2). */
+typedef struct mgx_robot_desc {
+    uint32_t K;               /* number of variables (>= 2)                                  */
+    uint32_t n_path;          /* tracking polyline points (0 = none)                         */
+    const double *mean0;      /* [K][4] initial variable means (robot.rs:1187-1218)          */
+    const double *prior_diag; /* [K] diagonal of the prior precision; non-finite => 0
+                                 (variable.rs:146-148); the reference uses 1e30 / +inf      */
+    const double *dt;         /* [K-1] dynamic-factor delta_t (robot.rs:1232,1240)           */
+    const float *path_xy;     /* [n_path][2] f32 waypoints for the tracking factors or NULL  */
+    double radius;            /* robot radius; d_safe = safety_multiplier * radius           */
+    uint64_t order_key;       /* total order of graphs = Bevy Entity order (id.rs:19-117);
+                                 must be unique per world (across ranks when sharded)       */
+    uint32_t ghost;           /* 1 = halo copy of a robot owned by another rank: only its
+                                 variable->factor snapshots exist, filled by mgx_halo_unpack */
+    uint32_t reserved;
+} mgx_robot_desc;
+
+/* ---- lifecycle ------------------------------------------------------------------- */
+int mgx_world_create(const mgx_params *params, mgx_world **out);
+int mgx_world_destroy(mgx_world *w);
+/* text of the last error on this thread (never NULL) */
+const char *mgx_last_error(void);
+/* HIP stream every kernel / copy of this world is enqueued on (NULL = default stream) */
+int mgx_set_stream(mgx_world *w, void *hip_stream);
+int mgx_synchronize(mgx_world *w);
+
+/* Obstacle "SDF" image sampled by ObstacleFactor::measure (factor/obstacle.rs:141-188):
+ * interleaved RGB u8, row-major, `world_w x world_h` world units (robot.rs:1259-1264).
+ * Only the red channel is kept on the device. */
+int mgx_world_set_sdf(mgx_world *w, const uint8_t *rgb, uint32_t width, uint32_t height,
+                      double world_w, double world_h);
+
+/* ---- topology (FactorGraph::add_variable/add_factor/add_*_edge, robot.rs) ---------- */
+/* RobotBundle::new (robot.rs:1134-1356). */
+int mgx_robot_add(mgx_world *w, const mgx_robot_desc *desc, int32_t *robot_id);
+/* create_interrobot_factors for ONE direction (robot.rs:1500-1585): `owner` creates
+ * K-1 InterRobotFactors towards `other`, variable i <-> variable i, i = 1..K-1, with
+ * robot_number = first_robot_number + (i-1) (robot.rs:1527, interrobot.rs:75).
+ * The reference calls this for (a,b) and (b,a) in the same system run. */
+int mgx_ir_connect(mgx_world *w, int32_t owner, int32_t other, uint64_t first_robot_number);
+/* delete_interrobot_factors (robot.rs:1386-1439): removes a->b and b->a factors and
+ * both sides' inbox entries (factorgraph.rs:380-436). */
+int mgx_ir_disconnect(mgx_world *w, int32_t a, int32_t b);
+
+/* RadioAntenna.active (robot.rs:1593-1601) and Mission.state.idle() gates of
+ * iterate_gbp_v2 (robot.rs:1794,1806,1822,1835,1851). */
+int mgx_set_antenna(mgx_world *w, int32_t robot, int32_t active);
+int mgx_set_idle(mgx_world *w, int32_t robot, int32_t idle);
+
+/* ---- the hot path ------------------------------------------------------------------ */
+/* iterate_gbp_v2 (robot.rs:1769-1861): runs `n` schedule steps, step i doing the
+ * internal phase if steps[i] & MGX_STEP_INTERNAL and the external phase if
+ * steps[i] & MGX_STEP_EXTERNAL.  Asynchronous on the world's stream. */
+int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n);
+
+/* The launch primitive the calls above and below are built on: one device pass per robot
+ * that runs the external phases in `external_phases` (bit0 = external factor sweep + routing,
+ * bit1 = external variable sweep + routing) and then `n_internal` internal iterations of the
+ * phases in `internal_phases` (bit0 = internal factor sweep, bit1 = internal variable sweep;
+ * n_internal > 1 needs both).  A sharded driver uses it to place its halo exchange between
+ * an internal and the following external phase.  robot = -1: all robots. */
+int mgx_sweep(mgx_world *w, int32_t robot, uint32_t external_phases, uint32_t internal_phases,
+              uint32_t n_internal);
+
+/* Fine-grained mirrors of FactorGraph::{internal_factor_iteration,
+ * internal_variable_iteration, external_factor_iteration, external_variable_iteration}
+ * (factorgraph.rs:688-826).  robot = -1 runs the sweep for every robot.  The external
+ * sweeps include the message routing the reference's caller performs
+ * (robot.rs:1813-1858) and are only available world-wide (robot must be -1). */
+int mgx_internal_factor_iteration(mgx_world *w, int32_t robot);
+int mgx_internal_variable_iteration(mgx_world *w, int32_t robot);
+int mgx_external_factor_iteration(mgx_world *w, int32_t robot);
+int mgx_external_variable_iteration(mgx_world *w, int32_t robot);
+
+/* FactorGraph::change_prior_of_variable + the caller's routing to external factors
+ * (factorgraph.rs:494-528, variable.rs:203-230, robot.rs:2262-2282). */
+int mgx_change_prior(mgx_world *w, int32_t robot, uint32_t var_ix, const double mean[4]);
+/* batched form: n triples (robot[i], var_ix[i], means[i][4]) in one launch */
+int mgx_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, const uint32_t *var_ix,
+                      const double *means);
+
+/* ---- read-back ----------------------------------------------------------------------- */
+/* VariableNode.belief (variable.rs:40-54).  Any output pointer may be NULL. */
+int mgx_get_belief(mgx_world *w, int32_t robot, uint32_t var_ix, double eta[4], double lam[16],
+                   double mean[4], double cov[16], int32_t *valid);
+/* bulk: robots in id order, variables in index order; ghosts are skipped.
+ * means [sum K][4]; eta [sum K][4]; lam [sum K][16].  Any pointer may be NULL. */
+int mgx_read_beliefs(mgx_world *w, double *eta, double *lam, double *means);
+int mgx_num_robots(mgx_world *w, uint32_t *n_robots, uint32_t *n_variables);
+
+/* ---- multi-GPU halo (one exchange per external iteration) ----------------- */
+/* Number of f64 words of one robot's halo record with K variables. */
+uint32_t mgx_halo_words(uint32_t K);
+/* Pack the variable->own-factor snapshots of `n` local robots into `dev_buf`
+ * (device pointer, n records back to back), resp. unpack `n` records into ghost robots. */
+int mgx_halo_pack(mgx_world *w, uint32_t n, const int32_t *robots, void *dev_buf);
+int mgx_halo_unpack(mgx_world *w, uint32_t n, const int32_t *ghosts, const void *dev_buf);
+
+/* ---- host helpers (no device needed) --------------------------------------------------- */
+/* gbp_schedule: fills steps[max(n_int,n_ext)] with MGX_STEP_* bits. Returns the count
+ * or a negative status. (crates/gbp_schedule/src/schedules/ *.rs) */
+int mgx_schedule(int32_t kind, uint8_t n_internal, uint8_t n_external, uint8_t *steps,
+                 uint32_t capacity);
+/* get_variable_timesteps (crates/magics/src/utils.rs:35-75). Returns the count. */
+int mgx_variable_timesteps(uint32_t lookahead_horizon, uint32_t lookahead_multiple,
+                           uint32_t *timesteps, uint32_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_H */

@@ -1,0 +1,795 @@
+// mgx_world.hip — host side of the C ABI (include/mgx.h): world arena, topology -> slot tables,
+// device buffers, launch sequencing.  No CPU compute path exists: every compute entry point
+// needs a HIP device.
+//
+// Host keeps a per-robot / per-connection mirror of all mutable state only to (re)build the
+// device arrays when the topology changes (`commit`): device is the source of truth between
+// commits; `pull` downloads it first so that added robots / inter-robot connections never
+// disturb existing state (the reference mutates its graphs in place,
+// factorgraph.rs:190-226,304-353,380-436).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mgx.h"
+#include "gbp_math.h"
+#include "mgx_dev.h"
+
+namespace mgx {
+size_t sweep_lds_bytes(int K);
+int sweep_block(int K);
+hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, uint32_t int_mask, int n_int,
+                              int snap_out, hipStream_t stream);
+hipError_t launch_change_prior(const DevWorld &w, int n, const int32_t *robots, const uint32_t *vars, const double *means,
+                               hipStream_t stream);
+hipError_t launch_halo_pack(const DevWorld &w, int n, const int32_t *robots, double *buf, hipStream_t stream);
+hipError_t launch_halo_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *buf, hipStream_t stream);
+}  // namespace mgx
+
+using namespace mgx;
+
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(MGX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));    \
+    } while (0)
+
+namespace {
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = cap = 0;
+    }
+    // (re)allocates only when growing; the copy is enqueued on `s` from pageable memory, so the
+    // caller synchronises before `h` dies
+    hipError_t upload(const std::vector<T> &h, hipStream_t s) {
+        const size_t want = h.size() ? h.size() : 1;
+        if (want > cap) {
+            release();
+            hipError_t e = hipMalloc((void **)&p, sizeof(T) * want);
+            if (e != hipSuccess) return e;
+            cap = want;
+        }
+        n = h.size();
+        if (n) return hipMemcpyAsync(p, h.data(), sizeof(T) * n, hipMemcpyHostToDevice, s);
+        return hipSuccess;
+    }
+    hipError_t download(std::vector<T> &h, hipStream_t s) const {
+        h.resize(n);
+        if (!n) return hipSuccess;
+        return hipMemcpyAsync(h.data(), p, sizeof(T) * n, hipMemcpyDeviceToHost, s);
+    }
+};
+
+// mutable state of one robot, item-major (AoS) on the host
+struct Robot {
+    int K = 0;
+    bool ghost = false;
+    double radius = 1.0;
+    uint64_t order_key = 0;
+    uint8_t antenna = 1, idle = 0;
+    std::vector<double> prior_eta, prior_lam, bel_eta, bel_lam, bel_mu, bel_cov;  // [K][4|16]
+    std::vector<int32_t> valid;                                                   // [K]
+    std::vector<double> snap;                                                     // [K][24]
+    std::vector<uint32_t> epoch;                                                  // [K]
+    std::vector<double> fv_eta, fv_lam;                                           // [E][4|16]
+    std::vector<double> dyn_m;                                                    // [K-1][16]
+    std::vector<int32_t> trk_record;                                              // [K-2]
+    std::vector<float> trk_last_pos;                                              // [K-2][2]
+    std::vector<double> trk_last_val;                                             // [K-2]
+    std::vector<float> path;                                                      // [n_path][2]
+    int32_t iter_factor = 0;
+};
+
+struct IrEdge {  // one InterRobotFactor, kept at its target variable
+    double fv_eta[4] = {0, 0, 0, 0}, fv_lam[16] = {0}, bmu[4] = {0, 0, 0, 0};
+    uint32_t created = 0;
+    bool fresh = true;  // created since the last commit: state is initialised at commit
+};
+struct IrConn {  // K-1 factors owner -> other
+    int owner, other;
+    uint64_t first_number;
+    std::vector<IrEdge> edges;  // index i-1 for variable i
+};
+
+}  // namespace
+
+struct mgx_world {
+    mgx_params p{};
+    std::vector<Robot> robots;  // ids = indices; ghosts may interleave on the host, device order below
+    std::vector<IrConn> conns;
+    std::vector<uint8_t> sdf_red;
+    uint32_t sdf_w = 0, sdf_h = 0;
+    double world_w = 1.0, world_h = 1.0;
+    int K = 0;
+
+    hipStream_t stream = nullptr;
+    bool dirty = true;       // topology / flags changed since the device arrays were built
+    bool flags_dirty = true;
+    bool dev_valid = false;  // device arrays hold live state
+    DevWorld d{};
+    std::vector<int> dev_of;     // robot id -> device robot index (locals first, then ghosts)
+    std::vector<int> robot_of;   // device robot index -> robot id
+    std::vector<int> edge_conn, edge_i;  // device ir edge -> (conn index, i-1)
+
+    DevBuf<double> prior_eta, prior_lam, bel_eta, bel_lam, bel_mu, bel_cov, snap0, snap1, fv_eta, fv_lam, dyn_m,
+        trk_last_val, ir_dsafe, ir_off, ir_fv_eta, ir_fv_lam, ir_bmu;
+    DevBuf<int32_t> bel_valid, trk_record, path_ptr, iter_factor, ir_var_ptr, ir_src_var, ir_dst_var, ir_src_robot;
+    DevBuf<uint32_t> epoch0, epoch1, ir_created;
+    DevBuf<float> trk_last_pos, path_xy;
+    DevBuf<uint8_t> ir_dst_slot, antenna, idle, sdf;
+    // scratch for change_prior / halo index lists
+    DevBuf<int32_t> tmp_i32;
+    DevBuf<uint32_t> tmp_u32;
+    DevBuf<double> tmp_f64;
+};
+
+static bool device_ok() {
+    static int state = 0;  // 0 unknown, 1 ok, -1 none
+    if (state == 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        state = (e == hipSuccess && n > 0) ? 1 : -1;
+    }
+    return state == 1;
+}
+
+// ---- SoA helpers --------------------------------------------------------------------------------
+template <class T>
+static void scatter(std::vector<T> &dst, size_t stride, size_t item, const T *src, int comps) {
+    for (int c = 0; c < comps; c++) dst[(size_t)c * stride + item] = src[c];
+}
+template <class T>
+static void gather(const std::vector<T> &src, size_t stride, size_t item, T *dst, int comps) {
+    for (int c = 0; c < comps; c++) dst[c] = src[(size_t)c * stride + item];
+}
+
+// J^T Q J of a dynamic factor in the reference's evaluation order (dynamic.rs:22-52,
+// factor/mod.rs:391-394), compacted to the 4x4 M with lam_p = M (x) I2.
+static void dynamic_potential(double dt, double sigma, double *M /*16*/) {
+    const double qc = 1.0 / (sigma * sigma);
+    const double q11 = 12.0 * (1.0 / (dt * dt * dt)) * qc, q12 = -6.0 * (1.0 / (dt * dt)) * qc, q22 = (4.0 / dt) * qc;
+    double Q[16] = {0}, J[32] = {0};
+    for (int a = 0; a < 2; a++) {
+        Q[a * 4 + a] = q11;
+        Q[a * 4 + a + 2] = q12;
+        Q[(a + 2) * 4 + a] = q12;
+        Q[(a + 2) * 4 + a + 2] = q22;
+        J[a * 8 + a] = 1.0;
+        J[a * 8 + a + 2] = dt;
+        J[a * 8 + a + 4] = -1.0;
+        J[(a + 2) * 8 + a + 2] = 1.0;
+        J[(a + 2) * 8 + a + 6] = -1.0;
+    }
+    double JtQ[32], L[64];
+    for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += J[k * 8 + i] * Q[k * 4 + j];
+            JtQ[i * 4 + j] = s;
+        }
+    for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 8; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += JtQ[i * 4 + k] * J[k * 8 + j];
+            L[i * 8 + j] = s;
+        }
+    for (int a = 0; a < 4; a++)
+        for (int b = 0; b < 4; b++) M[a * 4 + b] = L[(2 * a) * 8 + (2 * b)];
+}
+
+// ---- pull: device -> host mirror ----------------------------------------------------------------
+static int pull(mgx_world *w) {
+    if (!w->dev_valid) return MGX_OK;
+    const int K = w->K, E = 4 * K - 6;
+    const size_t V = (size_t)w->d.V, EI = (size_t)w->d.EI, NT = (size_t)w->d.NT, NI = (size_t)w->d.NI;
+    std::vector<double> pe, pl, be, bl, bm, bc, sn, fe, fl, tlv, ife, ifl, ibm;
+    std::vector<int32_t> bv, trc, itf;
+    std::vector<uint32_t> ep;
+    std::vector<float> tlp;
+    hipStream_t s = w->stream;
+    HIP_TRY(w->prior_eta.download(pe, s));
+    HIP_TRY(w->prior_lam.download(pl, s));
+    HIP_TRY(w->bel_eta.download(be, s));
+    HIP_TRY(w->bel_lam.download(bl, s));
+    HIP_TRY(w->bel_mu.download(bm, s));
+    HIP_TRY(w->bel_cov.download(bc, s));
+    HIP_TRY(w->bel_valid.download(bv, s));
+    HIP_TRY((w->d.cur ? w->snap1 : w->snap0).download(sn, s));
+    HIP_TRY((w->d.cur ? w->epoch1 : w->epoch0).download(ep, s));
+    HIP_TRY(w->fv_eta.download(fe, s));
+    HIP_TRY(w->fv_lam.download(fl, s));
+    HIP_TRY(w->trk_record.download(trc, s));
+    HIP_TRY(w->trk_last_pos.download(tlp, s));
+    HIP_TRY(w->trk_last_val.download(tlv, s));
+    HIP_TRY(w->iter_factor.download(itf, s));
+    HIP_TRY(w->ir_fv_eta.download(ife, s));
+    HIP_TRY(w->ir_fv_lam.download(ifl, s));
+    HIP_TRY(w->ir_bmu.download(ibm, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t dr = 0; dr < w->robot_of.size(); dr++) {
+        Robot &rb = w->robots[(size_t)w->robot_of[dr]];
+        for (int i = 0; i < K; i++) {
+            const size_t v = dr * K + i;
+            gather(pe, V, v, &rb.prior_eta[4 * i], 4);
+            gather(pl, V, v, &rb.prior_lam[16 * i], 16);
+            gather(be, V, v, &rb.bel_eta[4 * i], 4);
+            gather(bl, V, v, &rb.bel_lam[16 * i], 16);
+            gather(bm, V, v, &rb.bel_mu[4 * i], 4);
+            gather(bc, V, v, &rb.bel_cov[16 * i], 16);
+            gather(sn, V, v, &rb.snap[24 * i], 24);
+            rb.valid[i] = bv[v];
+            rb.epoch[i] = ep[v];
+        }
+        if (rb.ghost) continue;
+        for (int e = 0; e < E; e++) {
+            gather(fe, EI, dr * E + e, &rb.fv_eta[4 * e], 4);
+            gather(fl, EI, dr * E + e, &rb.fv_lam[16 * e], 16);
+        }
+        for (int j = 0; j < K - 2; j++) {
+            const size_t t = dr * (K - 2) + j;
+            rb.trk_record[j] = trc[t];
+            rb.trk_last_pos[2 * j] = tlp[t];
+            rb.trk_last_pos[2 * j + 1] = tlp[NT + t];
+            rb.trk_last_val[j] = tlv[t];
+        }
+        rb.iter_factor = itf[dr];
+    }
+    for (size_t e = 0; e < NI; e++) {
+        IrEdge &ed = w->conns[(size_t)w->edge_conn[e]].edges[(size_t)w->edge_i[e]];
+        gather(ife, NI, e, ed.fv_eta, 4);
+        gather(ifl, NI, e, ed.fv_lam, 16);
+        gather(ibm, NI, e, ed.bmu, 4);
+    }
+    return MGX_OK;
+}
+
+// ---- commit: host mirror -> device arrays ---------------------------------------------------------
+static int upload_flags(mgx_world *w) {
+    std::vector<uint8_t> an(w->robot_of.size()), id(w->robot_of.size());
+    for (size_t dr = 0; dr < w->robot_of.size(); dr++) {
+        an[dr] = w->robots[(size_t)w->robot_of[dr]].antenna;
+        id[dr] = w->robots[(size_t)w->robot_of[dr]].idle;
+    }
+    HIP_TRY(w->antenna.upload(an, w->stream));
+    HIP_TRY(w->idle.upload(id, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));  // `an`/`id` are pageable temporaries
+    w->d.antenna = w->antenna.p;
+    w->d.idle = w->idle.p;
+    w->flags_dirty = false;
+    return MGX_OK;
+}
+
+static int commit(mgx_world *w) {
+    if (!device_ok()) return fail(MGX_ERR_NO_DEVICE, "no usable HIP device (this library has no CPU path)");
+    if (!w->dirty) {
+        if (w->flags_dirty) return upload_flags(w);
+        return MGX_OK;
+    }
+    if (w->robots.empty()) return fail(MGX_ERR_STATE, "world has no robots");
+    int rc = pull(w);
+    if (rc != MGX_OK) return rc;
+    const int K = w->K, E = 4 * K - 6;
+    if (sweep_lds_bytes(K) > 64 * 1024 || sweep_block(K) > 256) return fail(MGX_ERR_INVALID, "K = %d too large", K);
+
+    // device robot order: locals (id order), then ghosts
+    w->robot_of.clear();
+    w->dev_of.assign(w->robots.size(), -1);
+    for (size_t r = 0; r < w->robots.size(); r++)
+        if (!w->robots[r].ghost) { w->dev_of[r] = (int)w->robot_of.size(); w->robot_of.push_back((int)r); }
+    const int R_local = (int)w->robot_of.size();
+    for (size_t r = 0; r < w->robots.size(); r++)
+        if (w->robots[r].ghost) { w->dev_of[r] = (int)w->robot_of.size(); w->robot_of.push_back((int)r); }
+    const int R_total = (int)w->robot_of.size();
+    const size_t V = (size_t)R_total * K, EI = (size_t)std::max(R_local, 1) * E, ND = (size_t)std::max(R_local, 1) * (K - 1),
+                 NT = (size_t)std::max(R_local, 1) * std::max(K - 2, 1);
+
+    // initialise fresh inter-robot edges from the (pulled) current state: created epoch of the
+    // owner's variable (its inbox slot stays empty until the owner's next delivery) and the target
+    // variable's current belief mean (robot.rs:1549-1585)
+    for (IrConn &c : w->conns)
+        for (size_t j = 0; j < c.edges.size(); j++) {
+            IrEdge &ed = c.edges[j];
+            if (!ed.fresh) continue;
+            const Robot &ow = w->robots[(size_t)c.owner], &ot = w->robots[(size_t)c.other];
+            ed.created = ow.epoch[j + 1];
+            for (int q = 0; q < 4; q++) ed.bmu[q] = ot.bel_mu[4 * (j + 1) + q];
+            ed.fresh = false;
+        }
+
+    // inter-robot edges grouped by LOCAL target variable, ordered by the owner's order key
+    struct Ref { int conn, j; uint64_t key; };
+    std::vector<std::vector<Ref>> per_var((size_t)R_local * K);
+    for (size_t ci = 0; ci < w->conns.size(); ci++) {
+        const IrConn &c = w->conns[ci];
+        if (w->robots[(size_t)c.other].ghost) continue;  // target lives on another rank
+        const int dt = w->dev_of[(size_t)c.other];
+        for (size_t j = 0; j < c.edges.size(); j++)
+            per_var[(size_t)dt * K + j + 1].push_back({(int)ci, (int)j, w->robots[(size_t)c.owner].order_key});
+    }
+    std::vector<int32_t> var_ptr((size_t)R_local * K + 1, 0), src_var, dst_var, src_robot;
+    std::vector<double> dsafe, off, ife, ifl, ibm;
+    std::vector<uint8_t> dslot;
+    std::vector<uint32_t> created;
+    w->edge_conn.clear();
+    w->edge_i.clear();
+    size_t NI = 0;
+    for (auto &pv : per_var) NI += pv.size();
+    const size_t NIs = std::max<size_t>(NI, 1);
+    ife.assign(4 * NIs, 0.0);
+    ifl.assign(16 * NIs, 0.0);
+    ibm.assign(4 * NIs, 0.0);
+    size_t e = 0;
+    for (size_t v = 0; v < per_var.size(); v++) {
+        var_ptr[v] = (int32_t)e;
+        auto &pv = per_var[v];
+        std::sort(pv.begin(), pv.end(), [](const Ref &a, const Ref &b) { return a.key < b.key; });
+        for (const Ref &rf : pv) {
+            const IrConn &c = w->conns[(size_t)rf.conn];
+            const Robot &ow = w->robots[(size_t)c.owner], &ot = w->robots[(size_t)c.other];
+            const IrEdge &ed = c.edges[(size_t)rf.j];
+            src_var.push_back(w->dev_of[(size_t)c.owner] * K + rf.j + 1);
+            dst_var.push_back((int32_t)v);
+            src_robot.push_back(w->dev_of[(size_t)c.owner]);
+            dsafe.push_back(w->p.safety_multiplier * ow.radius);  // interrobot.rs:64
+            off.push_back((double)1e-6f * (double)(c.first_number + (uint64_t)rf.j));  // interrobot.rs:52,75
+            dslot.push_back(ot.order_key > ow.order_key ? 1 : 0);
+            created.push_back(ed.created);
+            scatter(ife, NIs, e, ed.fv_eta, 4);
+            scatter(ifl, NIs, e, ed.fv_lam, 16);
+            scatter(ibm, NIs, e, ed.bmu, 4);
+            w->edge_conn.push_back(rf.conn);
+            w->edge_i.push_back(rf.j);
+            e++;
+        }
+    }
+    var_ptr[per_var.size()] = (int32_t)e;
+
+    std::vector<double> pe(4 * V), pl(16 * V), be(4 * V), bl(16 * V), bm(4 * V), bc(16 * V), sn(24 * V), fe(4 * EI, 0.0),
+        fl(16 * EI, 0.0), dm(16 * ND, 0.0), tlv(NT, 0.0);
+    std::vector<int32_t> bv(V), trc(NT, 0), pptr((size_t)R_local + 1, 0), itf((size_t)std::max(R_local, 1), 0);
+    std::vector<uint32_t> ep(V);
+    std::vector<float> tlp(2 * NT, 0.f), pxy;
+    for (int dr = 0; dr < R_total; dr++) {
+        const Robot &rb = w->robots[(size_t)w->robot_of[(size_t)dr]];
+        for (int i = 0; i < K; i++) {
+            const size_t v = (size_t)dr * K + i;
+            scatter(pe, V, v, &rb.prior_eta[4 * i], 4);
+            scatter(pl, V, v, &rb.prior_lam[16 * i], 16);
+            scatter(be, V, v, &rb.bel_eta[4 * i], 4);
+            scatter(bl, V, v, &rb.bel_lam[16 * i], 16);
+            scatter(bm, V, v, &rb.bel_mu[4 * i], 4);
+            scatter(bc, V, v, &rb.bel_cov[16 * i], 16);
+            scatter(sn, V, v, &rb.snap[24 * i], 24);
+            bv[v] = rb.valid[i];
+            ep[v] = rb.epoch[i];
+        }
+        if (rb.ghost) continue;
+        for (int ed = 0; ed < E; ed++) {
+            scatter(fe, EI, (size_t)dr * E + ed, &rb.fv_eta[4 * ed], 4);
+            scatter(fl, EI, (size_t)dr * E + ed, &rb.fv_lam[16 * ed], 16);
+        }
+        for (int f = 0; f < K - 1; f++) scatter(dm, ND, (size_t)dr * (K - 1) + f, &rb.dyn_m[16 * f], 16);
+        for (int j = 0; j < K - 2; j++) {
+            const size_t t = (size_t)dr * (K - 2) + j;
+            trc[t] = rb.trk_record[j];
+            tlp[t] = rb.trk_last_pos[2 * j];
+            tlp[NT + t] = rb.trk_last_pos[2 * j + 1];
+            tlv[t] = rb.trk_last_val[j];
+        }
+        pptr[(size_t)dr] = (int32_t)(pxy.size() / 2);
+        pxy.insert(pxy.end(), rb.path.begin(), rb.path.end());
+        pptr[(size_t)dr + 1] = (int32_t)(pxy.size() / 2);
+        itf[(size_t)dr] = rb.iter_factor;
+    }
+    if (pxy.empty()) pxy.assign(2, 0.f);
+    if (src_var.empty()) {
+        src_var.assign(1, 0); dst_var.assign(1, 0); src_robot.assign(1, 0); dsafe.assign(1, 0.0); off.assign(1, 0.0);
+        dslot.assign(1, 0); created.assign(1, 0);
+    }
+    if (w->sdf_red.empty()) {  // no image: every lookup is "outside" => h = 0
+        w->sdf_red.assign(1, 255);
+        w->sdf_w = w->sdf_h = 0;
+    }
+
+    hipStream_t s = w->stream;
+    HIP_TRY(w->prior_eta.upload(pe, s));
+    HIP_TRY(w->prior_lam.upload(pl, s));
+    HIP_TRY(w->bel_eta.upload(be, s));
+    HIP_TRY(w->bel_lam.upload(bl, s));
+    HIP_TRY(w->bel_mu.upload(bm, s));
+    HIP_TRY(w->bel_cov.upload(bc, s));
+    HIP_TRY(w->bel_valid.upload(bv, s));
+    HIP_TRY(w->snap0.upload(sn, s));
+    HIP_TRY(w->snap1.upload(sn, s));
+    HIP_TRY(w->epoch0.upload(ep, s));
+    HIP_TRY(w->epoch1.upload(ep, s));
+    HIP_TRY(w->fv_eta.upload(fe, s));
+    HIP_TRY(w->fv_lam.upload(fl, s));
+    HIP_TRY(w->dyn_m.upload(dm, s));
+    HIP_TRY(w->trk_record.upload(trc, s));
+    HIP_TRY(w->trk_last_pos.upload(tlp, s));
+    HIP_TRY(w->trk_last_val.upload(tlv, s));
+    HIP_TRY(w->path_ptr.upload(pptr, s));
+    HIP_TRY(w->path_xy.upload(pxy, s));
+    HIP_TRY(w->iter_factor.upload(itf, s));
+    HIP_TRY(w->ir_var_ptr.upload(var_ptr, s));
+    HIP_TRY(w->ir_src_var.upload(src_var, s));
+    HIP_TRY(w->ir_dst_var.upload(dst_var, s));
+    HIP_TRY(w->ir_src_robot.upload(src_robot, s));
+    HIP_TRY(w->ir_dsafe.upload(dsafe, s));
+    HIP_TRY(w->ir_off.upload(off, s));
+    HIP_TRY(w->ir_dst_slot.upload(dslot, s));
+    HIP_TRY(w->ir_created.upload(created, s));
+    HIP_TRY(w->ir_fv_eta.upload(ife, s));
+    HIP_TRY(w->ir_fv_lam.upload(ifl, s));
+    HIP_TRY(w->ir_bmu.upload(ibm, s));
+    HIP_TRY(w->sdf.upload(w->sdf_red, s));
+    HIP_TRY(hipStreamSynchronize(s));  // host staging vectors die at scope exit
+
+    DevWorld &d = w->d;
+    d.R_local = R_local; d.R_total = R_total; d.K = K; d.E = E;
+    d.V = (int)V; d.EI = (int)EI; d.ND = (int)ND; d.NT = (int)NT; d.NI = (int)NIs;
+    d.cur = 0;
+    d.enable = w->p.enable_mask;
+    d.prior_eta = w->prior_eta.p; d.prior_lam = w->prior_lam.p;
+    d.bel_eta = w->bel_eta.p; d.bel_lam = w->bel_lam.p; d.bel_mu = w->bel_mu.p; d.bel_cov = w->bel_cov.p;
+    d.bel_valid = w->bel_valid.p;
+    d.snap[0] = w->snap0.p; d.snap[1] = w->snap1.p;
+    d.snap_epoch[0] = w->epoch0.p; d.snap_epoch[1] = w->epoch1.p;
+    d.fv_eta = w->fv_eta.p; d.fv_lam = w->fv_lam.p; d.dyn_m = w->dyn_m.p;
+    d.trk_record = w->trk_record.p; d.trk_last_pos = w->trk_last_pos.p; d.trk_last_val = w->trk_last_val.p;
+    d.path_ptr = w->path_ptr.p; d.path_xy = w->path_xy.p; d.iter_factor = w->iter_factor.p;
+    d.ir_var_ptr = w->ir_var_ptr.p; d.ir_src_var = w->ir_src_var.p; d.ir_dst_var = w->ir_dst_var.p;
+    d.ir_src_robot = w->ir_src_robot.p; d.ir_dsafe = w->ir_dsafe.p; d.ir_off = w->ir_off.p;
+    d.ir_dst_slot = w->ir_dst_slot.p; d.ir_created = w->ir_created.p;
+    d.ir_fv_eta = w->ir_fv_eta.p; d.ir_fv_lam = w->ir_fv_lam.p; d.ir_bmu = w->ir_bmu.p;
+    d.sdf = w->sdf.p; d.sdf_w = w->sdf_w; d.sdf_h = w->sdf_h; d.world_w = w->world_w; d.world_h = w->world_h;
+    // ObstacleFactor::new jacobian_delta (obstacle.rs:98-102)
+    d.obs_delta = (w->sdf_w && w->sdf_h) ? (w->world_w / (double)w->sdf_w + w->world_h / (double)w->sdf_h) / 2.0 : 1.0;
+    d.inv_s2_obs = 1.0 / (w->p.sigma_obstacle * w->p.sigma_obstacle);    // FactorState::new, factor/mod.rs:631-632
+    d.inv_s2_ir = 1.0 / (w->p.sigma_interrobot * w->p.sigma_interrobot);
+    d.inv_s2_trk = 1.0 / (w->p.sigma_tracking * w->p.sigma_tracking);
+    d.trk_pad = w->p.tracking_switch_padding;
+    d.trk_attr = w->p.tracking_attraction_distance;
+    w->dirty = false;
+    w->dev_valid = true;
+    return upload_flags(w);
+}
+
+// ---- launches -----------------------------------------------------------------------------------------
+static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_mask, int n_int) {
+    int rc = commit(w);
+    if (rc != MGX_OK) return rc;
+    const bool writes_snap = (int_mask & PH_INT_VARIABLE) && n_int > 0;
+    if (robot < 0) {
+        const int out = writes_snap ? 1 - w->d.cur : -1;
+        HIP_TRY(launch_robot_sweep(w->d, 0, w->d.R_local, ext_mask, int_mask, n_int, out, w->stream));
+        if (writes_snap) w->d.cur ^= 1;
+    } else {
+        if ((size_t)robot >= w->robots.size() || w->robots[(size_t)robot].ghost) return fail(MGX_ERR_INVALID, "bad robot id %d", robot);
+        if (ext_mask) return fail(MGX_ERR_INVALID, "external sweeps are world-wide (robot must be -1)");
+        // single workgroup: nobody else reads the snapshot buffer concurrently => update in place
+        HIP_TRY(launch_robot_sweep(w->d, w->dev_of[(size_t)robot], 1, 0, int_mask, n_int, writes_snap ? w->d.cur : -1, w->stream));
+    }
+    return MGX_OK;
+}
+
+// =========================================================================================================
+//                                            C ABI
+// =========================================================================================================
+extern "C" {
+
+const char *mgx_last_error(void) { return g_err.c_str(); }
+
+int mgx_world_create(const mgx_params *params, mgx_world **out) {
+    if (!params || !out) return fail(MGX_ERR_INVALID, "null argument");
+    if (!(params->sigma_dynamics > 0) || !(params->sigma_interrobot > 0) || !(params->sigma_obstacle > 0) ||
+        !(params->sigma_tracking > 0) || !(params->safety_multiplier > 0))
+        return fail(MGX_ERR_INVALID, "sigmas and safety multiplier must be positive");
+    if (!device_ok()) return fail(MGX_ERR_NO_DEVICE, "no usable HIP device (this library has no CPU path)");
+    mgx_world *w = new (std::nothrow) mgx_world();
+    if (!w) return fail(MGX_ERR_NOMEM, "out of memory");
+    w->p = *params;
+    *out = w;
+    return MGX_OK;
+}
+
+int mgx_world_destroy(mgx_world *w) {
+    if (!w) return MGX_OK;
+    if (w->dev_valid) (void)hipStreamSynchronize(w->stream);
+    delete w;
+    return MGX_OK;
+}
+
+int mgx_set_stream(mgx_world *w, void *hip_stream) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    if (w->dev_valid) HIP_TRY(hipStreamSynchronize(w->stream));
+    w->stream = (hipStream_t)hip_stream;
+    return MGX_OK;
+}
+
+int mgx_synchronize(mgx_world *w) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    if (!device_ok()) return fail(MGX_ERR_NO_DEVICE, "no usable HIP device");
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    return MGX_OK;
+}
+
+int mgx_world_set_sdf(mgx_world *w, const uint8_t *rgb, uint32_t width, uint32_t height, double world_w, double world_h) {
+    if (!w || !rgb || !width || !height || !(world_w > 0) || !(world_h > 0)) return fail(MGX_ERR_INVALID, "bad sdf arguments");
+    w->sdf_red.resize((size_t)width * height);
+    for (size_t i = 0; i < w->sdf_red.size(); i++) w->sdf_red[i] = rgb[3 * i];  // pixel[0], obstacle.rs:178
+    w->sdf_w = width; w->sdf_h = height; w->world_w = world_w; w->world_h = world_h;
+    w->dirty = true;
+    return MGX_OK;
+}
+
+int mgx_robot_add(mgx_world *w, const mgx_robot_desc *d, int32_t *robot_id) {
+    if (!w || !d || !d->mean0 || !d->prior_diag || !d->dt) return fail(MGX_ERR_INVALID, "null argument");
+    if (d->K < 3) return fail(MGX_ERR_INVALID, "K must be >= 3");
+    if (w->K && (int)d->K != w->K) return fail(MGX_ERR_INVALID, "all robots of a world share K (%d), got %u", w->K, d->K);
+    if (!(d->radius > 0)) return fail(MGX_ERR_INVALID, "radius must be positive");
+    for (const Robot &o : w->robots)
+        if (o.order_key == d->order_key) return fail(MGX_ERR_INVALID, "duplicate order_key");
+    const int K = (int)d->K, E = 4 * K - 6;
+    Robot rb;
+    rb.K = K; rb.ghost = d->ghost != 0; rb.radius = d->radius; rb.order_key = d->order_key;
+    rb.prior_eta.assign(4 * K, 0.0); rb.prior_lam.assign(16 * K, 0.0);
+    rb.bel_eta.assign(4 * K, 0.0); rb.bel_lam.assign(16 * K, 0.0); rb.bel_mu.assign(4 * K, 0.0); rb.bel_cov.assign(16 * K, 0.0);
+    rb.valid.assign(K, 1); rb.snap.assign(24 * K, 0.0); rb.epoch.assign(K, 0);
+    rb.fv_eta.assign(4 * E, 0.0); rb.fv_lam.assign(16 * E, 0.0); rb.dyn_m.assign(16 * (K - 1), 0.0);
+    rb.trk_record.assign(K - 2, 0); rb.trk_last_pos.assign(2 * (K - 2), 0.f); rb.trk_last_val.assign(K - 2, 0.0);
+    for (int i = 0; i < K; i++) {  // VariableNode::new, variable.rs:140-166
+        double pd = d->prior_diag[i];
+        if (!std::isfinite(pd)) pd = 0.0;  // :146-148
+        double lam[16] = {0}, cov[16] = {0};
+        for (int a = 0; a < 4; a++) lam[a * 5] = pd;
+        const double *m = d->mean0 + 4 * i;
+        for (int a = 0; a < 4; a++) {
+            double s = 0.0;
+            for (int b = 0; b < 4; b++) s += lam[a * 4 + b] * m[b];
+            rb.prior_eta[4 * i + a] = s;
+            rb.bel_eta[4 * i + a] = s;
+            rb.bel_mu[4 * i + a] = m[a];
+        }
+        memcpy(&rb.prior_lam[16 * i], lam, sizeof lam);
+        memcpy(&rb.bel_lam[16 * i], lam, sizeof lam);
+        if (!inv4(lam, cov)) memset(cov, 0, sizeof cov);  // :152-154
+        memcpy(&rb.bel_cov[16 * i], cov, sizeof cov);
+        bool fin = true;
+        for (double c : cov) fin = fin && std::isfinite(c);
+        rb.valid[i] = fin;
+        // what prepare_message() would send (variable.rs:234-240): seeds the tracking factor inbox
+        // (factorgraph.rs:315-317); all other inboxes start empty (epoch 0)
+        memcpy(&rb.snap[24 * i], &rb.bel_eta[4 * i], 4 * sizeof(double));
+        memcpy(&rb.snap[24 * i + 4], lam, sizeof lam);
+        memcpy(&rb.snap[24 * i + 20], m, 4 * sizeof(double));
+    }
+    for (int f = 0; f < K - 1; f++) {
+        if (!(d->dt[f] > 0)) return fail(MGX_ERR_INVALID, "dt must be positive");
+        dynamic_potential(d->dt[f], w->p.sigma_dynamics, &rb.dyn_m[16 * f]);
+    }
+    for (int j = 0; j < K - 2; j++) {  // new_tracking_factor, factor/mod.rs:269-274
+        rb.trk_last_pos[2 * j] = (float)d->mean0[4 * (j + 1)];
+        rb.trk_last_pos[2 * j + 1] = (float)d->mean0[4 * (j + 1) + 1];
+    }
+    if (d->n_path && d->path_xy) rb.path.assign(d->path_xy, d->path_xy + 2 * (size_t)d->n_path);
+    w->robots.push_back(std::move(rb));
+    w->K = K;
+    w->dirty = true;
+    if (robot_id) *robot_id = (int32_t)w->robots.size() - 1;
+    return MGX_OK;
+}
+
+int mgx_ir_connect(mgx_world *w, int32_t owner, int32_t other, uint64_t first_robot_number) {
+    if (!w || owner < 0 || other < 0 || (size_t)owner >= w->robots.size() || (size_t)other >= w->robots.size() || owner == other)
+        return fail(MGX_ERR_INVALID, "bad robot ids");
+    if (first_robot_number == 0) return fail(MGX_ERR_INVALID, "robot_number is NonZeroUsize");
+    for (const IrConn &c : w->conns)
+        if (c.owner == owner && c.other == other) return fail(MGX_ERR_STATE, "already connected");
+    IrConn c;
+    c.owner = owner; c.other = other; c.first_number = first_robot_number;
+    c.edges.resize((size_t)w->K - 1);
+    w->conns.push_back(std::move(c));
+    w->dirty = true;
+    return MGX_OK;
+}
+
+int mgx_ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
+    if (!w || a < 0 || b < 0 || (size_t)a >= w->robots.size() || (size_t)b >= w->robots.size() || a == b)
+        return fail(MGX_ERR_INVALID, "bad robot ids");
+    int rc = pull(w);  // keep the other connections' live state
+    if (rc != MGX_OK) return rc;
+    w->dev_valid = false;
+    size_t before = w->conns.size();
+    w->conns.erase(std::remove_if(w->conns.begin(), w->conns.end(),
+                                  [&](const IrConn &c) { return (c.owner == a && c.other == b) || (c.owner == b && c.other == a); }),
+                   w->conns.end());
+    w->dirty = true;
+    (void)before;
+    return MGX_OK;
+}
+
+int mgx_set_antenna(mgx_world *w, int32_t robot, int32_t active) {
+    if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
+    w->robots[(size_t)robot].antenna = active ? 1 : 0;
+    w->flags_dirty = true;
+    return MGX_OK;
+}
+int mgx_set_idle(mgx_world *w, int32_t robot, int32_t idle) {
+    if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
+    w->robots[(size_t)robot].idle = idle ? 1 : 0;
+    w->flags_dirty = true;
+    return MGX_OK;
+}
+
+int mgx_sweep(mgx_world *w, int32_t robot, uint32_t external_phases, uint32_t internal_phases, uint32_t n_internal) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    if ((external_phases & ~3u) || (internal_phases & ~3u)) return fail(MGX_ERR_INVALID, "bad phase mask");
+    if (n_internal > 1 && internal_phases != 3u) return fail(MGX_ERR_INVALID, "fused iterations need both internal phases");
+    return sweep(w, robot, external_phases, internal_phases << 2, internal_phases ? (int)n_internal : 0);
+}
+
+int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n) {
+    if (!w || (!steps && n)) return fail(MGX_ERR_INVALID, "null argument");
+    // flatten to phases I / E (robot.rs:1787-1860: internal first, then external, per step) and
+    // group them into launches of the form [E] I* (one workgroup-resident pass each)
+    std::vector<uint8_t> ph;
+    for (uint32_t i = 0; i < n; i++) {
+        if (steps[i] & MGX_STEP_INTERNAL) ph.push_back('I');
+        if (steps[i] & MGX_STEP_EXTERNAL) ph.push_back('E');
+    }
+    size_t i = 0;
+    while (i < ph.size()) {
+        uint32_t ext = 0;
+        if (ph[i] == 'E') { ext = PH_EXT_FACTOR | PH_EXT_VARIABLE; i++; }
+        int n_int = 0;
+        while (i < ph.size() && ph[i] == 'I') { n_int++; i++; }
+        int rc = sweep(w, -1, ext, n_int ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, n_int);
+        if (rc != MGX_OK) return rc;
+    }
+    return MGX_OK;
+}
+
+int mgx_internal_factor_iteration(mgx_world *w, int32_t robot) { return w ? sweep(w, robot, 0, PH_INT_FACTOR, 1) : fail(MGX_ERR_INVALID, "null world"); }
+int mgx_internal_variable_iteration(mgx_world *w, int32_t robot) { return w ? sweep(w, robot, 0, PH_INT_VARIABLE, 1) : fail(MGX_ERR_INVALID, "null world"); }
+int mgx_external_factor_iteration(mgx_world *w, int32_t robot) { return w ? sweep(w, robot, PH_EXT_FACTOR, 0, 0) : fail(MGX_ERR_INVALID, "null world"); }
+int mgx_external_variable_iteration(mgx_world *w, int32_t robot) { return w ? sweep(w, robot, PH_EXT_VARIABLE, 0, 0) : fail(MGX_ERR_INVALID, "null world"); }
+
+int mgx_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, const uint32_t *var_ix, const double *means) {
+    if (!w || !robots || !var_ix || !means) return fail(MGX_ERR_INVALID, "null argument");
+    if (n == 0) return MGX_OK;
+    std::vector<int32_t> dr(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size() || w->robots[(size_t)robots[i]].ghost || (int)var_ix[i] >= w->K)
+            return fail(MGX_ERR_INVALID, "bad (robot, variable) at %u", i);
+    }
+    int rc = commit(w);
+    if (rc != MGX_OK) return rc;
+    for (uint32_t i = 0; i < n; i++) dr[i] = w->dev_of[(size_t)robots[i]];
+    std::vector<uint32_t> vv(var_ix, var_ix + n);
+    std::vector<double> mm(means, means + 4 * (size_t)n);
+    HIP_TRY(hipStreamSynchronize(w->stream));  // previous users of the scratch buffers
+    HIP_TRY(w->tmp_i32.upload(dr, w->stream));
+    HIP_TRY(w->tmp_u32.upload(vv, w->stream));
+    HIP_TRY(w->tmp_f64.upload(mm, w->stream));
+    HIP_TRY(launch_change_prior(w->d, (int)n, w->tmp_i32.p, w->tmp_u32.p, w->tmp_f64.p, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    return MGX_OK;
+}
+int mgx_change_prior(mgx_world *w, int32_t robot, uint32_t var_ix, const double mean[4]) {
+    return mgx_change_priors(w, 1, &robot, &var_ix, mean);
+}
+
+int mgx_num_robots(mgx_world *w, uint32_t *n_robots, uint32_t *n_variables) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    uint32_t nr = 0;
+    for (const Robot &r : w->robots) nr += r.ghost ? 0 : 1;
+    if (n_robots) *n_robots = nr;
+    if (n_variables) *n_variables = nr * (uint32_t)w->K;
+    return MGX_OK;
+}
+
+int mgx_read_beliefs(mgx_world *w, double *eta, double *lam, double *means) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    int rc = commit(w);
+    if (rc != MGX_OK) return rc;
+    const int K = w->K;
+    const size_t V = (size_t)w->d.V, nloc = (size_t)w->d.R_local * K;
+    std::vector<double> be, bl, bm;
+    if (eta) HIP_TRY(w->bel_eta.download(be, w->stream));
+    if (lam) HIP_TRY(w->bel_lam.download(bl, w->stream));
+    if (means) HIP_TRY(w->bel_mu.download(bm, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    // device local order == id order of non-ghost robots
+    for (size_t v = 0; v < nloc; v++) {
+        if (eta) gather(be, V, v, eta + 4 * v, 4);
+        if (lam) gather(bl, V, v, lam + 16 * v, 16);
+        if (means) gather(bm, V, v, means + 4 * v, 4);
+    }
+    return MGX_OK;
+}
+
+int mgx_get_belief(mgx_world *w, int32_t robot, uint32_t var_ix, double eta[4], double lam[16], double mean[4], double cov[16],
+                   int32_t *valid) {
+    if (!w || robot < 0 || (size_t)robot >= w->robots.size() || (int)var_ix >= w->K) return fail(MGX_ERR_INVALID, "bad (robot, variable)");
+    int rc = commit(w);
+    if (rc != MGX_OK) return rc;
+    const size_t V = (size_t)w->d.V, v = (size_t)w->dev_of[(size_t)robot] * w->K + var_ix;
+    auto fetch = [&](const double *base, double *out, int comps) -> hipError_t {
+        for (int c = 0; c < comps; c++) {
+            hipError_t e = hipMemcpyAsync(out + c, base + (size_t)c * V + v, sizeof(double), hipMemcpyDeviceToHost, w->stream);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    };
+    if (eta) HIP_TRY(fetch(w->bel_eta.p, eta, 4));
+    if (lam) HIP_TRY(fetch(w->bel_lam.p, lam, 16));
+    if (mean) HIP_TRY(fetch(w->bel_mu.p, mean, 4));
+    if (cov) HIP_TRY(fetch(w->bel_cov.p, cov, 16));
+    if (valid) HIP_TRY(hipMemcpyAsync(valid, w->bel_valid.p + v, sizeof(int32_t), hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    return MGX_OK;
+}
+
+uint32_t mgx_halo_words(uint32_t K) { return (SNAP_W + 1) * K; }
+
+int mgx_halo_pack(mgx_world *w, uint32_t n, const int32_t *robots, void *dev_buf) {
+    if (!w || (n && (!robots || !dev_buf))) return fail(MGX_ERR_INVALID, "null argument");
+    int rc = commit(w);
+    if (rc != MGX_OK) return rc;
+    if (!n) return MGX_OK;
+    std::vector<int32_t> dr(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
+        dr[i] = w->dev_of[(size_t)robots[i]];
+    }
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    HIP_TRY(w->tmp_i32.upload(dr, w->stream));
+    HIP_TRY(launch_halo_pack(w->d, (int)n, w->tmp_i32.p, (double *)dev_buf, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    return MGX_OK;
+}
+int mgx_halo_unpack(mgx_world *w, uint32_t n, const int32_t *ghosts, const void *dev_buf) {
+    if (!w || (n && (!ghosts || !dev_buf))) return fail(MGX_ERR_INVALID, "null argument");
+    int rc = commit(w);
+    if (rc != MGX_OK) return rc;
+    if (!n) return MGX_OK;
+    std::vector<int32_t> dr(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (ghosts[i] < 0 || (size_t)ghosts[i] >= w->robots.size() || !w->robots[(size_t)ghosts[i]].ghost)
+            return fail(MGX_ERR_INVALID, "not a ghost robot");
+        dr[i] = w->dev_of[(size_t)ghosts[i]];
+    }
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    HIP_TRY(w->tmp_i32.upload(dr, w->stream));
+    HIP_TRY(launch_halo_unpack(w->d, (int)n, w->tmp_i32.p, (const double *)dev_buf, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    return MGX_OK;
+}
+
+}  // extern "C"

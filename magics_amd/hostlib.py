@@ -1,0 +1,131 @@
+"""ctypes loader of the C-ABI library ``libmgx.so`` (include/mgx.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  Loading it
+needs no GPU; every *compute* entry point fails loudly (``MgxError``) when no HIP device is
+usable — there is no CPU path in the product.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmgx.so")
+
+SCHEDULE_CENTERED = 0
+SCHEDULE_SOON_AS_POSSIBLE = 1
+SCHEDULE_LATE_AS_POSSIBLE = 2
+SCHEDULE_INTERLEAVE_EVENLY = 3
+SCHEDULE_HALF_BEGINNING_HALF_END = 4
+
+STEP_INTERNAL = 1
+STEP_EXTERNAL = 2
+
+c_double_p = C.POINTER(C.c_double)
+
+
+class MgxError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("sigma_dynamics", C.c_double),
+        ("sigma_interrobot", C.c_double),
+        ("sigma_obstacle", C.c_double),
+        ("sigma_tracking", C.c_double),
+        ("safety_multiplier", C.c_double),
+        ("tracking_switch_padding", C.c_double),
+        ("tracking_attraction_distance", C.c_double),
+        ("enable_mask", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class RobotDesc(C.Structure):
+    _fields_ = [
+        ("K", C.c_uint32),
+        ("n_path", C.c_uint32),
+        ("mean0", c_double_p),
+        ("prior_diag", c_double_p),
+        ("dt", c_double_p),
+        ("path_xy", C.POINTER(C.c_float)),
+        ("radius", C.c_double),
+        ("order_key", C.c_uint64),
+        ("ghost", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+# every symbol include/mgx.h declares: name -> (restype, argtypes)
+_V = C.c_void_p
+SYMBOLS = {
+    "mgx_world_create": (C.c_int, [C.POINTER(Params), C.POINTER(_V)]),
+    "mgx_world_destroy": (C.c_int, [_V]),
+    "mgx_last_error": (C.c_char_p, []),
+    "mgx_set_stream": (C.c_int, [_V, _V]),
+    "mgx_synchronize": (C.c_int, [_V]),
+    "mgx_world_set_sdf": (C.c_int, [_V, _V, C.c_uint32, C.c_uint32, C.c_double, C.c_double]),
+    "mgx_robot_add": (C.c_int, [_V, C.POINTER(RobotDesc), C.POINTER(C.c_int32)]),
+    "mgx_ir_connect": (C.c_int, [_V, C.c_int32, C.c_int32, C.c_uint64]),
+    "mgx_ir_disconnect": (C.c_int, [_V, C.c_int32, C.c_int32]),
+    "mgx_set_antenna": (C.c_int, [_V, C.c_int32, C.c_int32]),
+    "mgx_set_idle": (C.c_int, [_V, C.c_int32, C.c_int32]),
+    "mgx_iterate": (C.c_int, [_V, C.c_char_p, C.c_uint32]),
+    "mgx_sweep": (C.c_int, [_V, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "mgx_internal_factor_iteration": (C.c_int, [_V, C.c_int32]),
+    "mgx_internal_variable_iteration": (C.c_int, [_V, C.c_int32]),
+    "mgx_external_factor_iteration": (C.c_int, [_V, C.c_int32]),
+    "mgx_external_variable_iteration": (C.c_int, [_V, C.c_int32]),
+    "mgx_change_prior": (C.c_int, [_V, C.c_int32, C.c_uint32, c_double_p]),
+    "mgx_change_priors": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), c_double_p]),
+    "mgx_get_belief": (C.c_int, [_V, C.c_int32, C.c_uint32, c_double_p, c_double_p, c_double_p, c_double_p,
+                                 C.POINTER(C.c_int32)]),
+    "mgx_read_beliefs": (C.c_int, [_V, c_double_p, c_double_p, c_double_p]),
+    "mgx_num_robots": (C.c_int, [_V, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "mgx_halo_words": (C.c_uint32, [C.c_uint32]),
+    "mgx_halo_pack": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), _V]),
+    "mgx_halo_unpack": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), _V]),
+    "mgx_schedule": (C.c_int, [C.c_int32, C.c_uint8, C.c_uint8, C.c_char_p, C.c_uint32]),
+    "mgx_variable_timesteps": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library; raises ``MgxError`` when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MgxError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise MgxError(f"mgx error {rc}: {lib().mgx_last_error().decode(errors='replace')}")
+    return rc
+
+
+def schedule(kind, n_internal, n_external):
+    """GbpSchedule::schedule — list of step bytes (STEP_INTERNAL | STEP_EXTERNAL)."""
+    buf = C.create_string_buffer(256)
+    n = lib().mgx_schedule(int(kind), int(n_internal), int(n_external), buf, 256)
+    if n < 0:
+        raise ValueError("bad schedule arguments")
+    return list(buf.raw[:n])
+
+
+def variable_timesteps(lookahead_horizon, lookahead_multiple):
+    """get_variable_timesteps (crates/magics/src/utils.rs:35-75)."""
+    buf = (C.c_uint32 * 4096)()
+    n = lib().mgx_variable_timesteps(int(lookahead_horizon), int(lookahead_multiple), buf, 4096)
+    if n < 0:
+        raise ValueError("bad arguments")
+    return list(buf[:n])

@@ -1,0 +1,177 @@
+"""Analytic known-answer tests pinning the CPU oracle where the reference holds no vectors
+(SURVEY.md §8c): (i) a dynamics-only chain is a tree, so GBP beliefs converge to the dense
+solve of the joint information form; (ii) Schur marginalisation vs numpy; (iii) inter-robot
+factor symmetry; plus the exact quirks of the message-passing semantics."""
+import numpy as np
+import pytest
+
+import oracle
+from magics_amd import scenarios as S
+
+dp = oracle.binding._dp
+
+
+def _chain_world(K=8, enable=S.EN_DYN, sigma=0.5, seed=1):
+    rng = np.random.default_rng(seed)
+    params = dict(S.JUNCTION_PARAMS, enable_mask=enable, sigma_dynamics=sigma)
+    w = oracle.OracleWorld(params)
+    mean0 = rng.normal(size=(K, 4))
+    prior = np.full(K, np.inf)
+    prior[0] = prior[-1] = 1e3  # moderate anchors keep the dense system well conditioned
+    dt = rng.uniform(0.1, 0.4, size=K - 1)
+    w.set_sdf(np.full((8, 8, 3), 255, np.uint8), 100.0, 100.0)
+    w.add_robot(mean0, prior, dt, 1.0)
+    return w, mean0, prior, dt, sigma
+
+
+def _dense_chain_solution(mean0, prior, dt, sigma):
+    K = len(mean0)
+    L = np.zeros((4 * K, 4 * K))
+    eta = np.zeros(4 * K)
+    for i in (0, K - 1):
+        L[4 * i:4 * i + 4, 4 * i:4 * i + 4] += prior[i] * np.eye(4)
+        eta[4 * i:4 * i + 4] += prior[i] * mean0[i]
+    I2, Z2 = np.eye(2), np.zeros((2, 2))
+    for i in range(K - 1):
+        d = dt[i]
+        qc = 1.0 / sigma ** 2
+        Q = np.block([[12 / d ** 3 * qc * I2, -6 / d ** 2 * qc * I2], [-6 / d ** 2 * qc * I2, 4 / d * qc * I2]])
+        J = np.block([[I2, d * I2, -I2, Z2], [Z2, I2, Z2, -I2]])
+        L[4 * i:4 * i + 8, 4 * i:4 * i + 8] += J.T @ Q @ J
+    cov = np.linalg.inv(L)
+    mu = cov @ eta
+    return mu.reshape(K, 4), cov
+
+
+def test_chain_gbp_equals_dense_solve():
+    w, mean0, prior, dt, sigma = _chain_world()
+    w.iterate([1] * 40)  # tree => exact after <= diameter sweeps
+    mu_dense, cov = _dense_chain_solution(mean0, prior, dt, sigma)
+    _, lam, mu = w.read_beliefs()
+    np.testing.assert_allclose(mu, mu_dense, rtol=1e-7, atol=1e-9)
+    for i in range(len(mean0)):
+        marg = np.linalg.inv(cov[4 * i:4 * i + 4, 4 * i:4 * i + 4])
+        np.testing.assert_allclose(lam[i], marg, rtol=1e-6, atol=1e-6 * np.abs(marg).max())
+
+
+def test_inv4_matches_numpy_and_flags_singular():
+    L = oracle.lib()
+    rng = np.random.default_rng(3)
+    for _ in range(100):
+        a = rng.normal(size=(4, 4))
+        m = a @ a.T + 0.1 * np.eye(4)
+        out = np.zeros((4, 4))
+        assert L.orc_inv4(dp(m), dp(out)) == 1
+        np.testing.assert_allclose(out, np.linalg.inv(m), rtol=1e-9, atol=1e-12)
+    out = np.zeros((4, 4))
+    assert L.orc_inv4(dp(np.zeros((4, 4))), dp(out)) == 0          # det == 0 => None
+    g = np.zeros((4, 4)); g[:2, :2] = np.outer([0.3, -0.7], [0.3, -0.7])  # rank-1 block
+    assert L.orc_inv4(dp(g), dp(out)) == 0
+    big = 1e30 * np.eye(4)
+    assert L.orc_inv4(dp(big), dp(out)) == 1 and np.allclose(np.diag(out), 1e-30)
+
+
+def test_schur_vs_dense_inverse():
+    # marginalising block b of N(eta, lam) == inverting the joint, cutting block a, inverting back
+    L = oracle.lib()
+    rng = np.random.default_rng(5)
+    for idx in (0, 4):
+        a = rng.normal(size=(8, 8))
+        lam = a @ a.T + np.eye(8)
+        eta = rng.normal(size=8)
+        oe, ol, om = np.zeros(4), np.zeros((4, 4)), np.zeros(4)
+        assert L.orc_marginalise(dp(eta), dp(lam), 8, idx, dp(oe), dp(ol), dp(om)) == 1
+        cov = np.linalg.inv(lam)
+        sl = slice(idx, idx + 4)
+        np.testing.assert_allclose(ol, np.linalg.inv(cov[sl, sl]), rtol=1e-9)
+        np.testing.assert_allclose(np.linalg.solve(ol, oe), (cov @ eta)[sl], rtol=1e-9)
+
+
+def _pair_world(pa, pb, first=(1, 16), K=4, swap_keys=False, enable=S.EN_DYN | S.EN_IR):
+    params = dict(S.JUNCTION_PARAMS, enable_mask=enable)
+    w = oracle.OracleWorld(params)
+    w.set_sdf(np.full((8, 8, 3), 255, np.uint8), 100.0, 100.0)
+    prior = np.full(K, np.inf); prior[0] = prior[-1] = 1e30
+    dt = np.full(K - 1, 0.1)
+    ids = []
+    for k, p in enumerate((pa, pb)):
+        mean0 = np.tile(np.array([p[0], p[1], 0.3, -0.2]), (K, 1)) + np.arange(K)[:, None] * 0.01
+        key = (1 - k) if swap_keys else k
+        ids.append(w.add_robot(mean0, prior, dt, 1.0, order_key=key))
+    w.ir_connect(ids[0], ids[1], first[0])
+    w.ir_connect(ids[1], ids[0], first[1])
+    return w, ids
+
+
+def test_interrobot_only_sends_to_the_other_robot_and_is_symmetric():
+    # two robots 1 m apart (< d_safe = 2.5): after [I, E] both get messages on variables 1..K-1
+    # from the OTHER robot's factors only; their own factors' inbox slots stay empty forever
+    # (factorgraph.rs:745-754)
+    w, ids = _pair_world((0.0, 0.0), (1.0, 0.2))
+    w.iterate([3, 3, 3])
+    for r, o in ((0, 1), (1, 0)):
+        for i in range(1, 4):
+            box = w.variable_inbox(ids[r], i)
+            own_ir = [b for b in box if b[0] == ids[r] and b[1] >= 4 + 3 + 2 + 2]
+            foreign = [b for b in box if b[0] == ids[o]]
+            assert len(own_ir) == 1 and not own_ir[0][2]
+            assert len(foreign) == 1 and foreign[0][2]
+    # mirror symmetry: swapping which robot has the lower order key mirrors the problem
+    # (up to the tiny offsets, 1e-6 * robot_number)
+    w2, ids2 = _pair_world((0.0, 0.0), (1.0, 0.2), swap_keys=True)
+    w2.iterate([3, 3, 3])
+    _, _, mu = w.read_beliefs()
+    _, _, mu2 = w2.read_beliefs()
+    np.testing.assert_allclose(mu, mu2, rtol=0, atol=2e-3)
+
+
+def test_interrobot_skipped_beyond_safety_distance():
+    w, ids = _pair_world((0.0, 0.0), (3.0, 0.0))  # 3 m > d_safe
+    w.iterate([3, 3])
+    for i in range(1, 4):
+        assert not any(b[2] for b in w.variable_inbox(ids[0], i) if b[0] == ids[1])
+
+
+def test_variable_new_resets_non_finite_prior_and_change_prior_semantics():
+    w, mean0, prior, dt, sigma = _chain_world(K=5)
+    b = w.get_belief(0, 2)
+    assert (b["lam"] == 0).all() and (b["cov"] == 0).all() and b["valid"]  # variable.rs:146-154
+    w.iterate([1] * 6)
+    before = w.get_belief(0, 4)
+    new_mean = np.array([9.0, -9.0, 1.0, 2.0])
+    w.change_prior(0, 4, new_mean)
+    after = w.get_belief(0, 4)
+    # belief eta / lam are NOT recomputed, mean is overwritten (variable.rs:203-230)
+    assert (after["eta"] == before["eta"]).all() and (after["lam"] == before["lam"]).all()
+    assert (after["mean"] == new_mean).all()
+    assert not any(b[2] for b in w.variable_inbox(0, 4))  # inbox wiped to empty
+
+
+def test_obstacle_measure_pixel_rule():
+    # obstacle.rs:141-188: px = ((x + W/2) * w/W) as u32 (saturating), py from -y, outside => 0
+    params = dict(S.JUNCTION_PARAMS)
+    w = oracle.OracleWorld(params)
+    img = np.full((4, 8, 3), 255, np.uint8)
+    img[1, 6, 0] = 0      # black pixel at column 6, row 1
+    img[0, 0, 0] = 51
+    w.set_sdf(img, 8.0, 4.0)  # 1 px per world unit
+    L = oracle.lib()
+    f = lambda x, y: L.orc_obstacle_measure(w._w, dp(np.array([x, y, 0.0, 0.0])))
+    assert f(2.5, 0.5) == 1.0          # px = 6, py = (-0.5 + 2) = 1
+    assert f(2.0, 0.999) == 1.0
+    assert f(1.99, 0.5) == 0.0         # neighbouring white pixel
+    assert f(-4.0, 1.99) == pytest.approx(1 - 51 / 255)
+    assert f(-400.0, 1.99) == pytest.approx(1 - 51 / 255)  # negative saturates to pixel 0
+    assert f(4.0, 0.0) == 0.0          # x pixel 8 is outside => 0
+    assert f(0.0, -2.5) == 0.0         # y pixel 4 outside
+
+
+def test_tracking_factor_waits_ten_factor_sweeps():
+    sc = S.grid_scenario(1, 10, tracking=True, obstacles=False)
+    w = oracle.OracleWorld(sc["params"])
+    S.populate(w, sc)
+    trk = lambda: [b for b in w.variable_inbox(0, 3) if b[1] >= 10 + 9 + 8]
+    w.iterate([1] * 10)
+    assert not trk()[0][2]       # iteration_count.factor < 10 for the first ten sweeps
+    w.iterate([1])
+    assert trk()[0][2]
