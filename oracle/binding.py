@@ -46,7 +46,7 @@ def build(native=False, out_dir=None):
     if native:
         out_dir = out_dir or _HERE
         out = os.path.join(out_dir, "libgbp_oracle_native.so")
-        cmd = ["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
+        cmd = ["gcc", "-O3", "-fno-tree-slp-vectorize", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
                "-fPIC", "-shared", "-o", out, os.path.join(_HERE, "gbp_oracle.c"), "-lm"]
         subprocess.run(cmd, check=True, capture_output=True)
         return out
