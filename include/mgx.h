@@ -166,10 +166,15 @@ int mgx_num_robots(mgx_world *w, uint32_t *n_robots, uint32_t *n_variables);
 /* ---- multi-GPU halo (one exchange per external iteration) ----------------- */
 /* Number of f64 words of one robot's halo record with K variables. */
 uint32_t mgx_halo_words(uint32_t K);
-/* Pack the variable->own-factor snapshots of `n` local robots into `dev_buf`
- * (device pointer, n records back to back), resp. unpack `n` records into ghost robots. */
-int mgx_halo_pack(mgx_world *w, uint32_t n, const int32_t *robots, void *dev_buf);
-int mgx_halo_unpack(mgx_world *w, uint32_t n, const int32_t *ghosts, const void *dev_buf);
+/* Register the exchange lists once: the local robots whose snapshot records are written
+ * to the send buffer (in this order) and the ghost robots filled from the receive buffer. */
+int mgx_halo_plan(mgx_world *w, uint32_t n_send, const int32_t *send_robots, uint32_t n_recv,
+                  const int32_t *recv_ghosts);
+/* Pack the planned robots' variable->own-factor snapshots (what their inter-robot factors on
+ * other ranks read) into `dev_buf` (device pointer, n_send records of mgx_halo_words(K) f64),
+ * resp. unpack n_recv records into the ghost robots.  Asynchronous on the world's stream. */
+int mgx_halo_pack(mgx_world *w, void *dev_buf);
+int mgx_halo_unpack(mgx_world *w, const void *dev_buf);
 
 /* ---- host helpers (no device needed) --------------------------------------------------- */
 /* gbp_schedule: fills steps[max(n_int,n_ext)] with MGX_STEP_* bits. Returns the count

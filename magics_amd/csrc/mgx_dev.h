@@ -43,6 +43,7 @@ struct DevWorld {
 
     // inter-robot edges (at the target variable)
     const int32_t *ir_var_ptr;    // [R_local * K + 1]
+    const int32_t *ir_var_mid;    // [R_local * K] first edge whose owner has a HIGHER graph key
     const int32_t *ir_src_var;    // [NI] snapshot index of the owner's variable
     const int32_t *ir_dst_var;    // [NI] target variable
     const int32_t *ir_src_robot;  // [NI]

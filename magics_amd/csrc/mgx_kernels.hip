@@ -35,18 +35,13 @@ __device__ __forceinline__ void st_soa16(double *base, int stride, int item, con
     for (int c = 0; c < 16; c++) base[(size_t)c * stride + item] = o[c];
 }
 
-// sum of the inter-robot messages in variable v's inbox
-__device__ __forceinline__ void ir_sum(const DevWorld &w, int v, double (&se)[4], double (&sl)[16]) {
-#pragma unroll
-    for (int c = 0; c < 4; c++) se[c] = 0.0;
-#pragma unroll
-    for (int c = 0; c < 16; c++) sl[c] = 0.0;
-    const int e0 = w.ir_var_ptr[v], e1 = w.ir_var_ptr[v + 1];
+// adds the inter-robot messages [e0, e1) of a variable's inbox to (eta, lam), in inbox order
+__device__ __forceinline__ void ir_accumulate(const DevWorld &w, int e0, int e1, double (&eta)[4], double (&lam)[16]) {
     for (int e = e0; e < e1; e++) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) se[c] += w.ir_fv_eta[(size_t)c * w.NI + e];
+        for (int c = 0; c < 4; c++) eta[c] += w.ir_fv_eta[(size_t)c * w.NI + e];
 #pragma unroll
-        for (int c = 0; c < 16; c++) sl[c] += w.ir_fv_lam[(size_t)c * w.NI + e];
+        for (int c = 0; c < 16; c++) lam[c] += w.ir_fv_lam[(size_t)c * w.NI + e];
     }
 }
 
@@ -69,7 +64,8 @@ __global__ void __launch_bounds__(256) k_robot_sweep(DevWorld w, int robot0, uin
     const bool is_var = lane < K;
 
     // ---- per-variable register state ------------------------------------------------------
-    double p_eta[4], p_lam[16], mu[4], cov[16], irs_e[4], irs_l[16];
+    double p_eta[4], p_lam[16], mu[4], cov[16];
+    int ir_e0 = 0, ir_mid = 0, ir_e1 = 0;  // inbox entries of foreign factors with a lower / higher graph key
     int valid = 0;
     uint32_t epoch = 0;
     if (is_var) {
@@ -89,7 +85,9 @@ __global__ void __launch_bounds__(256) k_robot_sweep(DevWorld w, int robot0, uin
         for (int c = 0; c < 4; c++) s_bel[(20 + c) * K + lane] = mu[c];
 #pragma unroll
         for (int c = 0; c < SNAP_W; c++) s_snap[c * K + lane] = w.snap[w.cur][(size_t)c * w.V + v];
-        ir_sum(w, v, irs_e, irs_l);
+        ir_e0 = w.ir_var_ptr[v];
+        ir_mid = w.ir_var_mid[v];
+        ir_e1 = w.ir_var_ptr[v + 1];
     }
     for (int e = lane; e < E; e += T) {
 #pragma unroll
@@ -180,7 +178,6 @@ __global__ void __launch_bounds__(256) k_robot_sweep(DevWorld w, int robot0, uin
         }
         if (radio) itf += 1;  // iteration_count.factor of B's own external sweep (factorgraph.rs:757)
         __syncthreads();
-        if (is_var) ir_sum(w, v0 + lane, irs_e, irs_l);
     }
 
     // internal-edge slots of variable `lane`
@@ -196,6 +193,10 @@ __global__ void __launch_bounds__(256) k_robot_sweep(DevWorld w, int robot0, uin
         for (int c = 0; c < 4; c++) eta[c] = p_eta[c];
 #pragma unroll
         for (int c = 0; c < 16; c++) lam[c] = p_lam[c];
+        // inbox order of the reference (BTreeMap<FactorId, _>, id.rs:19-54): factors of graphs with a
+        // lower key, own factors by node index (dynamic i-1, dynamic i, obstacle, tracking; own
+        // inter-robot factors are forever empty), then factors of graphs with a higher key
+        ir_accumulate(w, ir_e0, ir_mid, eta, lam);
         const int es[4] = {e_left, e_right, e_obs, e_trk};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -205,10 +206,7 @@ __global__ void __launch_bounds__(256) k_robot_sweep(DevWorld w, int robot0, uin
 #pragma unroll
             for (int c = 0; c < 16; c++) lam[c] += s_fv[(4 + c) * E + es[q]];
         }
-#pragma unroll
-        for (int c = 0; c < 4; c++) eta[c] += irs_e[c];
-#pragma unroll
-        for (int c = 0; c < 16; c++) lam[c] += irs_l[c];
+        ir_accumulate(w, ir_mid, ir_e1, eta, lam);
         belief_from_information(eta, lam, mu, cov, valid);
 #pragma unroll
         for (int c = 0; c < 4; c++) s_bel[c * K + lane] = eta[c];

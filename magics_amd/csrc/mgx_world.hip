@@ -137,7 +137,7 @@ struct mgx_world {
 
     DevBuf<double> prior_eta, prior_lam, bel_eta, bel_lam, bel_mu, bel_cov, snap0, snap1, fv_eta, fv_lam, dyn_m,
         trk_last_val, ir_dsafe, ir_off, ir_fv_eta, ir_fv_lam, ir_bmu;
-    DevBuf<int32_t> bel_valid, trk_record, path_ptr, iter_factor, ir_var_ptr, ir_src_var, ir_dst_var, ir_src_robot;
+    DevBuf<int32_t> bel_valid, trk_record, path_ptr, iter_factor, ir_var_ptr, ir_var_mid, ir_src_var, ir_dst_var, ir_src_robot;
     DevBuf<uint32_t> epoch0, epoch1, ir_created;
     DevBuf<float> trk_last_pos, path_xy;
     DevBuf<uint8_t> ir_dst_slot, antenna, idle, sdf;
@@ -145,6 +145,10 @@ struct mgx_world {
     DevBuf<int32_t> tmp_i32;
     DevBuf<uint32_t> tmp_u32;
     DevBuf<double> tmp_f64;
+    // halo plan: local robots whose snapshots are sent / ghost robots that receive, in buffer order
+    std::vector<int32_t> halo_send, halo_recv;
+    DevBuf<int32_t> halo_send_dev, halo_recv_dev;
+    bool halo_dirty = false;
 };
 
 static bool device_ok() {
@@ -258,7 +262,7 @@ static int pull(mgx_world *w) {
         }
         rb.iter_factor = itf[dr];
     }
-    for (size_t e = 0; e < NI; e++) {
+    for (size_t e = 0; e < w->edge_conn.size(); e++) {
         IrEdge &ed = w->conns[(size_t)w->edge_conn[e]].edges[(size_t)w->edge_i[e]];
         gather(ife, NI, e, ed.fv_eta, 4);
         gather(ifl, NI, e, ed.fv_lam, 16);
@@ -330,7 +334,7 @@ static int commit(mgx_world *w) {
         for (size_t j = 0; j < c.edges.size(); j++)
             per_var[(size_t)dt * K + j + 1].push_back({(int)ci, (int)j, w->robots[(size_t)c.owner].order_key});
     }
-    std::vector<int32_t> var_ptr((size_t)R_local * K + 1, 0), src_var, dst_var, src_robot;
+    std::vector<int32_t> var_ptr((size_t)R_local * K + 1, 0), var_mid((size_t)R_local * K, 0), src_var, dst_var, src_robot;
     std::vector<double> dsafe, off, ife, ifl, ibm;
     std::vector<uint8_t> dslot;
     std::vector<uint32_t> created;
@@ -347,6 +351,10 @@ static int commit(mgx_world *w) {
         var_ptr[v] = (int32_t)e;
         auto &pv = per_var[v];
         std::sort(pv.begin(), pv.end(), [](const Ref &a, const Ref &b) { return a.key < b.key; });
+        const uint64_t own_key = w->robots[(size_t)w->robot_of[v / (size_t)K]].order_key;
+        var_mid[v] = (int32_t)(e + pv.size());
+        for (size_t q = 0; q < pv.size(); q++)
+            if (pv[q].key > own_key) { var_mid[v] = (int32_t)(e + q); break; }
         for (const Ref &rf : pv) {
             const IrConn &c = w->conns[(size_t)rf.conn];
             const Robot &ow = w->robots[(size_t)c.owner], &ot = w->robots[(size_t)c.other];
@@ -437,6 +445,7 @@ static int commit(mgx_world *w) {
     HIP_TRY(w->path_xy.upload(pxy, s));
     HIP_TRY(w->iter_factor.upload(itf, s));
     HIP_TRY(w->ir_var_ptr.upload(var_ptr, s));
+    HIP_TRY(w->ir_var_mid.upload(var_mid, s));
     HIP_TRY(w->ir_src_var.upload(src_var, s));
     HIP_TRY(w->ir_dst_var.upload(dst_var, s));
     HIP_TRY(w->ir_src_robot.upload(src_robot, s));
@@ -463,7 +472,7 @@ static int commit(mgx_world *w) {
     d.fv_eta = w->fv_eta.p; d.fv_lam = w->fv_lam.p; d.dyn_m = w->dyn_m.p;
     d.trk_record = w->trk_record.p; d.trk_last_pos = w->trk_last_pos.p; d.trk_last_val = w->trk_last_val.p;
     d.path_ptr = w->path_ptr.p; d.path_xy = w->path_xy.p; d.iter_factor = w->iter_factor.p;
-    d.ir_var_ptr = w->ir_var_ptr.p; d.ir_src_var = w->ir_src_var.p; d.ir_dst_var = w->ir_dst_var.p;
+    d.ir_var_ptr = w->ir_var_ptr.p; d.ir_var_mid = w->ir_var_mid.p; d.ir_src_var = w->ir_src_var.p; d.ir_dst_var = w->ir_dst_var.p;
     d.ir_src_robot = w->ir_src_robot.p; d.ir_dsafe = w->ir_dsafe.p; d.ir_off = w->ir_off.p;
     d.ir_dst_slot = w->ir_dst_slot.p; d.ir_created = w->ir_created.p;
     d.ir_fv_eta = w->ir_fv_eta.p; d.ir_fv_lam = w->ir_fv_lam.p; d.ir_bmu = w->ir_bmu.p;
@@ -477,6 +486,7 @@ static int commit(mgx_world *w) {
     d.trk_attr = w->p.tracking_attraction_distance;
     w->dirty = false;
     w->dev_valid = true;
+    w->halo_dirty = true;
     return upload_flags(w);
 }
 
@@ -758,37 +768,50 @@ int mgx_get_belief(mgx_world *w, int32_t robot, uint32_t var_ix, double eta[4], 
 
 uint32_t mgx_halo_words(uint32_t K) { return (SNAP_W + 1) * K; }
 
-int mgx_halo_pack(mgx_world *w, uint32_t n, const int32_t *robots, void *dev_buf) {
-    if (!w || (n && (!robots || !dev_buf))) return fail(MGX_ERR_INVALID, "null argument");
-    int rc = commit(w);
-    if (rc != MGX_OK) return rc;
-    if (!n) return MGX_OK;
-    std::vector<int32_t> dr(n);
-    for (uint32_t i = 0; i < n; i++) {
-        if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
-        dr[i] = w->dev_of[(size_t)robots[i]];
-    }
-    HIP_TRY(hipStreamSynchronize(w->stream));
-    HIP_TRY(w->tmp_i32.upload(dr, w->stream));
-    HIP_TRY(launch_halo_pack(w->d, (int)n, w->tmp_i32.p, (double *)dev_buf, w->stream));
-    HIP_TRY(hipStreamSynchronize(w->stream));
+int mgx_halo_plan(mgx_world *w, uint32_t n_send, const int32_t *send_robots, uint32_t n_recv, const int32_t *recv_ghosts) {
+    if (!w || (n_send && !send_robots) || (n_recv && !recv_ghosts)) return fail(MGX_ERR_INVALID, "null argument");
+    for (uint32_t i = 0; i < n_send; i++)
+        if (send_robots[i] < 0 || (size_t)send_robots[i] >= w->robots.size() || w->robots[(size_t)send_robots[i]].ghost)
+            return fail(MGX_ERR_INVALID, "send list entry %u is not a local robot", i);
+    for (uint32_t i = 0; i < n_recv; i++)
+        if (recv_ghosts[i] < 0 || (size_t)recv_ghosts[i] >= w->robots.size() || !w->robots[(size_t)recv_ghosts[i]].ghost)
+            return fail(MGX_ERR_INVALID, "receive list entry %u is not a ghost robot", i);
+    w->halo_send.assign(send_robots, send_robots + n_send);
+    w->halo_recv.assign(recv_ghosts, recv_ghosts + n_recv);
+    w->halo_dirty = true;
     return MGX_OK;
 }
-int mgx_halo_unpack(mgx_world *w, uint32_t n, const int32_t *ghosts, const void *dev_buf) {
-    if (!w || (n && (!ghosts || !dev_buf))) return fail(MGX_ERR_INVALID, "null argument");
+
+static int halo_commit(mgx_world *w) {
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
-    if (!n) return MGX_OK;
-    std::vector<int32_t> dr(n);
-    for (uint32_t i = 0; i < n; i++) {
-        if (ghosts[i] < 0 || (size_t)ghosts[i] >= w->robots.size() || !w->robots[(size_t)ghosts[i]].ghost)
-            return fail(MGX_ERR_INVALID, "not a ghost robot");
-        dr[i] = w->dev_of[(size_t)ghosts[i]];
-    }
+    if (!w->halo_dirty) return MGX_OK;
+    std::vector<int32_t> a(w->halo_send.size()), b(w->halo_recv.size());
+    for (size_t i = 0; i < a.size(); i++) a[i] = w->dev_of[(size_t)w->halo_send[i]];
+    for (size_t i = 0; i < b.size(); i++) b[i] = w->dev_of[(size_t)w->halo_recv[i]];
+    HIP_TRY(w->halo_send_dev.upload(a, w->stream));
+    HIP_TRY(w->halo_recv_dev.upload(b, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
-    HIP_TRY(w->tmp_i32.upload(dr, w->stream));
-    HIP_TRY(launch_halo_unpack(w->d, (int)n, w->tmp_i32.p, (const double *)dev_buf, w->stream));
-    HIP_TRY(hipStreamSynchronize(w->stream));
+    w->halo_dirty = false;
+    return MGX_OK;
+}
+
+int mgx_halo_pack(mgx_world *w, void *dev_buf) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    int rc = halo_commit(w);
+    if (rc != MGX_OK) return rc;
+    if (w->halo_send.empty()) return MGX_OK;
+    if (!dev_buf) return fail(MGX_ERR_INVALID, "null buffer");
+    HIP_TRY(launch_halo_pack(w->d, (int)w->halo_send.size(), w->halo_send_dev.p, (double *)dev_buf, w->stream));
+    return MGX_OK;
+}
+int mgx_halo_unpack(mgx_world *w, const void *dev_buf) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    int rc = halo_commit(w);
+    if (rc != MGX_OK) return rc;
+    if (w->halo_recv.empty()) return MGX_OK;
+    if (!dev_buf) return fail(MGX_ERR_INVALID, "null buffer");
+    HIP_TRY(launch_halo_unpack(w->d, (int)w->halo_recv.size(), w->halo_recv_dev.p, (const double *)dev_buf, w->stream));
     return MGX_OK;
 }
 

@@ -9,6 +9,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmgx.so")
+# The product library is built with -ffp-contract=off: GBP on these graphs is numerically chaotic
+# while beliefs form (rank-deficient precisions inverted next to rounding noise), so the kernels
+# keep the reference's scalar f64 operation order and never fuse a*b+c — results are then bit
+# identical to the CPU restatement (tests/test_gpu_parity.py).  libmgx_fma.so is the same source
+# with FMA contraction, kept only to measure what that costs (MGX_FMA=1 selects it).
+FMA_LIB_PATH = os.path.join(_HERE, "lib", "libmgx_fma.so")
 
 SCHEDULE_CENTERED = 0
 SCHEDULE_SOON_AS_POSSIBLE = 1
@@ -82,34 +88,38 @@ SYMBOLS = {
     "mgx_read_beliefs": (C.c_int, [_V, c_double_p, c_double_p, c_double_p]),
     "mgx_num_robots": (C.c_int, [_V, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mgx_halo_words": (C.c_uint32, [C.c_uint32]),
-    "mgx_halo_pack": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), _V]),
-    "mgx_halo_unpack": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), _V]),
+    "mgx_halo_plan": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_int32)]),
+    "mgx_halo_pack": (C.c_int, [_V, _V]),
+    "mgx_halo_unpack": (C.c_int, [_V, _V]),
     "mgx_schedule": (C.c_int, [C.c_int32, C.c_uint8, C.c_uint8, C.c_char_p, C.c_uint32]),
     "mgx_variable_timesteps": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]),
 }
 
-_lib = None
+_libs = {}
 
 
-def lib():
+def lib(fma=None):
     """The loaded C-ABI library; raises ``MgxError`` when it has not been built."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise MgxError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    if fma is None:
+        fma = os.environ.get("MGX_FMA", "0") == "1"
+    key = bool(fma)
+    if key not in _libs:
+        path = FMA_LIB_PATH if key else LIB_PATH
+        if not os.path.exists(path):
+            raise MgxError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = L
-    return _lib
+        _libs[key] = L
+    return _libs[key]
 
 
-def check(rc):
+def check(rc, L=None):
     if rc < 0:
-        raise MgxError(f"mgx error {rc}: {lib().mgx_last_error().decode(errors='replace')}")
+        raise MgxError(f"mgx error {rc}: {(L or lib()).mgx_last_error().decode(errors='replace')}")
     return rc
 
 

@@ -10,7 +10,8 @@ import ctypes as C
 import numpy as np
 
 from . import hostlib
-from .hostlib import Params, RobotDesc, c_double_p, check
+from .hostlib import Params, RobotDesc, c_double_p
+from .hostlib import check as _check
 
 
 def _dp(a):
@@ -33,11 +34,14 @@ def make_params(p):
 
 
 class World:
-    def __init__(self, params, stream=None):
-        self._L = hostlib.lib()
+    def _chk(self, rc):
+        return _check(rc, self._L)
+
+    def __init__(self, params, stream=None, fma=None):
+        self._L = hostlib.lib(fma)
         self._p = make_params(params)
         h = C.c_void_p()
-        check(self._L.mgx_world_create(C.byref(self._p), C.byref(h)))
+        self._chk(self._L.mgx_world_create(C.byref(self._p), C.byref(h)))
         self._w = h
         self._next_key = 0
         if stream is not None:
@@ -57,10 +61,10 @@ class World:
 
     def set_stream(self, stream):
         """``stream``: raw hipStream_t value (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
-        check(self._L.mgx_set_stream(self._w, C.c_void_p(int(stream))))
+        self._chk(self._L.mgx_set_stream(self._w, C.c_void_p(int(stream))))
 
     def synchronize(self):
-        check(self._L.mgx_synchronize(self._w))
+        self._chk(self._L.mgx_synchronize(self._w))
 
     # -- topology --------------------------------------------------------------------------
     def set_sdf(self, rgb, world_w, world_h):
@@ -68,7 +72,7 @@ class World:
         if rgb.ndim != 3 or rgb.shape[2] != 3:
             raise ValueError("rgb must be HxWx3 u8")
         h, w, _ = rgb.shape
-        check(self._L.mgx_world_set_sdf(self._w, rgb.ctypes.data, w, h, float(world_w), float(world_h)))
+        self._chk(self._L.mgx_world_set_sdf(self._w, rgb.ctypes.data, w, h, float(world_w), float(world_h)))
 
     def add_robot(self, mean0, prior_diag, dt, radius, path=None, order_key=None, ghost=False):
         mean0 = _f64(mean0)
@@ -89,68 +93,68 @@ class World:
         d.order_key = int(order_key)
         d.ghost = 1 if ghost else 0
         rid = C.c_int32(-1)
-        check(self._L.mgx_robot_add(self._w, C.byref(d), C.byref(rid)))
+        self._chk(self._L.mgx_robot_add(self._w, C.byref(d), C.byref(rid)))
         return rid.value
 
     def ir_connect(self, owner, other, first_robot_number):
-        check(self._L.mgx_ir_connect(self._w, owner, other, int(first_robot_number)))
+        self._chk(self._L.mgx_ir_connect(self._w, owner, other, int(first_robot_number)))
 
     def ir_disconnect(self, a, b):
-        check(self._L.mgx_ir_disconnect(self._w, a, b))
+        self._chk(self._L.mgx_ir_disconnect(self._w, a, b))
 
     def set_antenna(self, robot, active):
-        check(self._L.mgx_set_antenna(self._w, robot, int(bool(active))))
+        self._chk(self._L.mgx_set_antenna(self._w, robot, int(bool(active))))
 
     def set_idle(self, robot, idle):
-        check(self._L.mgx_set_idle(self._w, robot, int(bool(idle))))
+        self._chk(self._L.mgx_set_idle(self._w, robot, int(bool(idle))))
 
     # -- hot path ----------------------------------------------------------------------------
     def iterate(self, steps):
         steps = bytes(bytearray(int(s) for s in steps))
-        check(self._L.mgx_iterate(self._w, steps, len(steps)))
+        self._chk(self._L.mgx_iterate(self._w, steps, len(steps)))
 
     def sweep(self, external_phases, internal_phases, n_internal=1, robot=-1):
-        check(self._L.mgx_sweep(self._w, robot, external_phases, internal_phases, n_internal))
+        self._chk(self._L.mgx_sweep(self._w, robot, external_phases, internal_phases, n_internal))
 
     def internal_factor_iteration(self, robot=-1):
-        check(self._L.mgx_internal_factor_iteration(self._w, robot))
+        self._chk(self._L.mgx_internal_factor_iteration(self._w, robot))
 
     def internal_variable_iteration(self, robot=-1):
-        check(self._L.mgx_internal_variable_iteration(self._w, robot))
+        self._chk(self._L.mgx_internal_variable_iteration(self._w, robot))
 
     def external_factor_iteration(self, robot=-1):
-        check(self._L.mgx_external_factor_iteration(self._w, robot))
+        self._chk(self._L.mgx_external_factor_iteration(self._w, robot))
 
     def external_variable_iteration(self, robot=-1):
-        check(self._L.mgx_external_variable_iteration(self._w, robot))
+        self._chk(self._L.mgx_external_variable_iteration(self._w, robot))
 
     def change_prior(self, robot, var_ix, mean):
         mean = _f64(mean, (4,))
-        check(self._L.mgx_change_prior(self._w, robot, var_ix, _dp(mean)))
+        self._chk(self._L.mgx_change_prior(self._w, robot, var_ix, _dp(mean)))
 
     def change_priors(self, robots, var_ix, means):
         robots = np.ascontiguousarray(robots, dtype=np.int32)
         var_ix = np.ascontiguousarray(var_ix, dtype=np.uint32)
         means = _f64(means, (len(robots), 4))
-        check(self._L.mgx_change_priors(self._w, len(robots), robots.ctypes.data_as(C.POINTER(C.c_int32)),
+        self._chk(self._L.mgx_change_priors(self._w, len(robots), robots.ctypes.data_as(C.POINTER(C.c_int32)),
                                         var_ix.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(means)))
 
     # -- read-back -----------------------------------------------------------------------------
     def get_belief(self, robot, var_ix):
         eta, lam, mean, cov = np.zeros(4), np.zeros((4, 4)), np.zeros(4), np.zeros((4, 4))
         valid = C.c_int32()
-        check(self._L.mgx_get_belief(self._w, robot, var_ix, _dp(eta), _dp(lam), _dp(mean), _dp(cov), C.byref(valid)))
+        self._chk(self._L.mgx_get_belief(self._w, robot, var_ix, _dp(eta), _dp(lam), _dp(mean), _dp(cov), C.byref(valid)))
         return {"eta": eta, "lam": lam, "mean": mean, "cov": cov, "valid": bool(valid.value)}
 
     def num_robots(self):
         a, b = C.c_uint32(), C.c_uint32()
-        check(self._L.mgx_num_robots(self._w, C.byref(a), C.byref(b)))
+        self._chk(self._L.mgx_num_robots(self._w, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def read_beliefs(self):
         _, nv = self.num_robots()
         eta, lam, means = np.zeros((nv, 4)), np.zeros((nv, 4, 4)), np.zeros((nv, 4))
-        check(self._L.mgx_read_beliefs(self._w, _dp(eta), _dp(lam), _dp(means)))
+        self._chk(self._L.mgx_read_beliefs(self._w, _dp(eta), _dp(lam), _dp(means)))
         return eta, lam, means
 
     # -- halo ------------------------------------------------------------------------------------
@@ -158,13 +162,17 @@ class World:
     def halo_words(K):
         return hostlib.lib().mgx_halo_words(K)
 
-    def halo_pack(self, robots, dev_ptr):
-        robots = np.ascontiguousarray(robots, dtype=np.int32)
-        check(self._L.mgx_halo_pack(self._w, len(robots), robots.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(dev_ptr)))
+    def halo_plan(self, send_robots, recv_ghosts):
+        a = np.ascontiguousarray(send_robots, dtype=np.int32)
+        b = np.ascontiguousarray(recv_ghosts, dtype=np.int32)
+        ip = C.POINTER(C.c_int32)
+        self._chk(self._L.mgx_halo_plan(self._w, len(a), a.ctypes.data_as(ip), len(b), b.ctypes.data_as(ip)))
 
-    def halo_unpack(self, ghosts, dev_ptr):
-        ghosts = np.ascontiguousarray(ghosts, dtype=np.int32)
-        check(self._L.mgx_halo_unpack(self._w, len(ghosts), ghosts.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(dev_ptr)))
+    def halo_pack(self, dev_ptr):
+        self._chk(self._L.mgx_halo_pack(self._w, C.c_void_p(dev_ptr)))
+
+    def halo_unpack(self, dev_ptr):
+        self._chk(self._L.mgx_halo_unpack(self._w, C.c_void_p(dev_ptr)))
 
     def factorgraph(self, robot):
         return FactorGraph(self, robot)

@@ -1,6 +1,14 @@
 """Parity of the HIP engine (through the C ABI) with the CPU oracle on identical factor graphs —
-the first gate.  Tolerance: 1e-5 relative on belief means and precisions (BASELINE.json); the
-engine uses FMA contraction and a different summation order, so results are not bit-identical.
+the first gate.
+
+BASELINE.json asks for 1e-5 relative on belief means / precisions.  GBP on these graphs is
+numerically chaotic while beliefs form (a rank-1 obstacle / inter-robot precision is inverted
+next to the rounding residue of rank-deficient Schur complements), so two implementations that
+differ in the last bit diverge by O(1) for a while (test_fma_build_* below shows it).  The
+product kernels therefore keep the reference's scalar f64 operation order with no FMA
+contraction, and the bar here is stronger than the tolerance: beliefs BIT-IDENTICAL to the oracle
+in every regime.  The FMA build of the same sources is held to the 1e-5 tolerance where the
+problem is well conditioned.
 """
 import numpy as np
 import pytest
@@ -8,7 +16,7 @@ import pytest
 from magics_amd import scenarios as S
 from magics_amd import hostlib
 
-from parity import TOL, assert_parity, both, errors, make_pair
+from parity import TOL, assert_identical, assert_parity, both, errors, make_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -18,7 +26,7 @@ def test_config2_small_dynamics_obstacles():
     eng, ref = make_pair(sc)
     for tick in range(3):
         both(eng, ref, lambda w: w.iterate(sc["steps"]))
-        assert_parity(eng, ref, what=f"config2 64x16 tick {tick}")
+        assert_identical(eng, ref, what=f"config2 64x16 tick {tick}")
 
 
 def test_first_iterations_one_by_one():
@@ -28,10 +36,7 @@ def test_first_iterations_one_by_one():
     eng, ref = make_pair(sc)
     for it in range(12):
         both(eng, ref, lambda w: w.iterate([3]))
-        eta_e, lam_e, mu_e = eng.read_beliefs()
-        eta_r, lam_r, mu_r = ref.read_beliefs()
-        np.testing.assert_allclose(mu_e, mu_r, rtol=0, atol=TOL * max(1.0, np.abs(mu_r).max()), err_msg=f"iteration {it}")
-    assert_parity(eng, ref, what="first 12 iterations")
+        assert_identical(eng, ref, what=f"iteration {it}")
 
 
 def test_config3_small_interrobot():
@@ -39,7 +44,7 @@ def test_config3_small_interrobot():
     eng, ref = make_pair(sc)
     for tick in range(3):
         both(eng, ref, lambda w: w.iterate(sc["steps"]))
-        assert_parity(eng, ref, what=f"config3 64x16+ir tick {tick}")
+        assert_identical(eng, ref, what=f"config3 64x16+ir tick {tick}")
 
 
 def test_dense_interrobot_interactions():
@@ -48,7 +53,7 @@ def test_dense_interrobot_interactions():
     eng, ref = make_pair(sc)
     for tick in range(2):
         both(eng, ref, lambda w: w.iterate(sc["steps"]))
-        assert_parity(eng, ref, what=f"dense ir tick {tick}")
+        assert_identical(eng, ref, what=f"dense ir tick {tick}")
 
 
 def test_config1_circle():
@@ -56,7 +61,7 @@ def test_config1_circle():
     eng, ref = make_pair(sc)
     assert len(sc["steps"]) == 50
     both(eng, ref, lambda w: w.iterate(sc["steps"]))
-    assert_parity(eng, ref, what="circle 10x10, 50/10 interleave-evenly")
+    assert_identical(eng, ref, what="circle 10x10, 50/10 interleave-evenly")
 
 
 @pytest.mark.parametrize("kind", range(5))
@@ -65,7 +70,7 @@ def test_uneven_schedules(kind):
     steps = hostlib.schedule(kind, 7, 3) + hostlib.schedule(kind, 2, 6)
     eng, ref = make_pair(sc)
     both(eng, ref, lambda w: w.iterate(steps))
-    assert_parity(eng, ref, what=f"schedule kind {kind}")
+    assert_identical(eng, ref, what=f"schedule kind {kind}")
 
 
 def test_fine_grained_sweeps():
@@ -87,7 +92,7 @@ def test_fine_grained_sweeps():
         w.external_variable_iteration()
         w.iterate([3, 1, 2])
     both(eng, ref, script)
-    assert_parity(eng, ref, what="fine-grained sweeps")
+    assert_identical(eng, ref, what="fine-grained sweeps")
 
 
 def _tick(w, sc, rng_seed, n=4):
@@ -114,7 +119,7 @@ def test_ticks_with_change_prior():
     # beliefs feed back into the scripted priors, so drive each world with its own beliefs
     _tick(eng, sc, 7)
     _tick(ref, sc, 7)
-    assert_parity(eng, ref, what="4 ticks with change_prior")
+    assert_identical(eng, ref, what="4 ticks with change_prior")
 
 
 def test_change_prior_before_first_iteration():
@@ -125,7 +130,7 @@ def test_change_prior_before_first_iteration():
         w.change_prior(2, 0, np.array([0.0, 0.1, 0.5, 0.5]))
         w.iterate([3, 3, 3, 3, 3])
     both(eng, ref, script)
-    assert_parity(eng, ref, what="change_prior first")
+    assert_identical(eng, ref, what="change_prior first")
 
 
 def test_antenna_and_idle_gating():
@@ -146,7 +151,7 @@ def test_antenna_and_idle_gating():
             w.set_idle(r, False)
         w.iterate([3, 3, 3])
     both(eng, ref, script)
-    assert_parity(eng, ref, what="antenna / idle gating")
+    assert_identical(eng, ref, what="antenna / idle gating")
 
 
 def test_tracking_factors():
@@ -154,15 +159,15 @@ def test_tracking_factors():
     eng, ref = make_pair(sc)
     for tick in range(3):
         both(eng, ref, lambda w: w.iterate(sc["steps"]))
-        assert_parity(eng, ref, what=f"tracking tick {tick}")
+        assert_identical(eng, ref, what=f"tracking tick {tick}")
 
 
 def test_K32_tracking_config5_shape():
-    sc = S.grid_scenario(12, 32, interrobot=True, tracking=True, pitch=3.0, comm_radius=6.0)
+    sc = S.grid_scenario(12, 32, interrobot=True, tracking=True, pitch=5.0, comm_radius=8.0)
     eng, ref = make_pair(sc)
     for tick in range(2):
         both(eng, ref, lambda w: w.iterate(sc["steps"]))
-        assert_parity(eng, ref, what=f"K=32 + tracking tick {tick}")
+        assert_identical(eng, ref, what=f"K=32 + tracking tick {tick}")
 
 
 def test_connect_and_disconnect_mid_run():
@@ -182,11 +187,11 @@ def test_connect_and_disconnect_mid_run():
         w.iterate([3, 3, 3])
     # inter-robot factors must be enabled in the params for the late connections to act
     both(eng, ref, script)
-    assert_parity(eng, ref, what="connect / disconnect (ir disabled => no effect)")
+    assert_identical(eng, ref, what="connect / disconnect (ir disabled => no effect)")
     sc2 = dict(sc, params=dict(sc["params"], enable_mask=sc["params"]["enable_mask"] | S.EN_IR))
     eng, ref = make_pair(sc2)
     both(eng, ref, script)
-    assert_parity(eng, ref, what="connect / disconnect mid-run")
+    assert_identical(eng, ref, what="connect / disconnect mid-run")
 
 
 def test_get_belief_matches_bulk_read():
@@ -197,8 +202,7 @@ def test_get_belief_matches_bulk_read():
     b = eng.get_belief(2, 5)
     assert (b["mean"] == mu[2 * 10 + 5]).all() and (b["lam"] == lam[2 * 10 + 5]).all() and (b["eta"] == eta[2 * 10 + 5]).all()
     rb = ref.get_belief(2, 5)
-    np.testing.assert_allclose(b["cov"], rb["cov"], rtol=1e-6, atol=1e-9 * np.abs(rb["cov"]).max())
-    assert b["valid"] == rb["valid"]
+    assert np.array_equal(b["cov"], rb["cov"]) and b["valid"] == rb["valid"]
 
 
 def test_chain_gbp_equals_dense_solve_on_gpu():
@@ -242,11 +246,34 @@ def test_config2_full_size():
     eng, ref = make_pair(sc)
     for tick in range(2):
         both(eng, ref, lambda w: w.iterate(sc["steps"]))
-    assert_parity(eng, ref, what="config2 1000x16, 20 iterations")
+    assert_identical(eng, ref, what="config2 1000x16, 20 iterations")
 
 
 def test_config3_full_size():
     sc = S.grid_scenario(1000, 16, interrobot=True)
     eng, ref = make_pair(sc)
     both(eng, ref, lambda w: w.iterate(sc["steps"]))
-    assert_parity(eng, ref, what="config3 1000x16 + ir, 10 iterations")
+    assert_identical(eng, ref, what="config3 1000x16 + ir, 10 iterations")
+
+
+# ---- the FMA build of the same sources: tolerance parity where the problem is well conditioned ----
+def test_fma_build_within_tolerance_when_well_conditioned():
+    # no obstacle gradients: every precision that forms is full rank
+    sc = S.grid_scenario(64, 16, interrobot=False, obstacles=False)
+    eng, ref = make_pair(sc, fma=True)
+    for tick in range(4):
+        both(eng, ref, lambda w: w.iterate(sc["steps"]))
+        assert_parity(eng, ref, tol=TOL, what=f"fma build, white image, tick {tick}")
+
+
+def test_fma_build_shows_the_chaotic_transient():
+    # with obstacle gradients the forming beliefs amplify last-bit differences: the FMA build is
+    # far outside 1e-5 after two sweeps although it agrees again (here) once beliefs have formed —
+    # the reason the product build does not contract
+    sc = S.grid_scenario(4, 10, interrobot=False, obstacles=True)
+    eng, ref = make_pair(sc, fma=True)
+    both(eng, ref, lambda w: w.iterate([1, 1]))
+    e_mu, _, _ = errors(eng, ref)
+    assert e_mu > 1e-3
+    both(eng, ref, lambda w: w.iterate([1] * 8))
+    assert_parity(eng, ref, tol=TOL, what="fma build after the transient")
