@@ -98,6 +98,31 @@ SYMBOLS = {
 _libs = {}
 
 
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  If
+    libmgx.so pulled in the system copy first, a later `import torch` would load a SECOND HIP
+    runtime into the process (its DT_NEEDED is spelled without the version, so the loader does
+    not match it to the loaded SONAME) and one of the two then sees no GPU.  Loading torch's
+    copy first makes both libmgx.so and torch resolve to the same runtime.  Without torch the
+    system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib(fma=None):
     """The loaded C-ABI library; raises ``MgxError`` when it has not been built."""
     if fma is None:
@@ -108,6 +133,7 @@ def lib(fma=None):
         if not os.path.exists(path):
             raise MgxError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _preload_hip_runtime()
         L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)

@@ -1,0 +1,242 @@
+"""Robots sharded over the GPUs of one node, one process per GPU.
+
+Robots are independent during internal sweeps; they couple only through inter-robot factors,
+once per external iteration (robot.rs:1803-1859).  Every inter-robot factor F_AB (owned by A,
+attached to B's variable) is evaluated on the rank that owns its only consumer B
+(factorgraph.rs:745-754 discards its message to A), which needs nothing from A but the
+belief A's variable sends to its own factors — A's *snapshot record*.  So the whole exchange is
+ONE all-to-all-v of snapshot records of boundary robots per external iteration, placed right
+before the launch that runs the external phase; no other collective exists on the path.
+
+``ShardedWorld`` builds the rank-local world (local robots + ghost copies of remote neighbours),
+the send / receive lists and drives ``mgx_sweep`` segments with the exchange in between.  The
+communicator is injected: ``TorchDistComm`` (RCCL via torch.distributed "nccl"; "gloo" in the CPU
+tests) or a ``LocalCluster`` that runs several ranks inside one process (single-GPU tests).
+"""
+import numpy as np
+
+from . import hostlib
+
+PH_FACTOR, PH_VARIABLE = 1, 2
+
+
+def partition_strips(positions, world_size):
+    """Owner rank of every robot: contiguous strips in (y, x) order with equal robot counts —
+    spatial blocks keep cross-rank neighbour pairs few."""
+    positions = np.asarray(positions)
+    order = np.lexsort((positions[:, 0], positions[:, 1]))
+    owner = np.empty(len(positions), dtype=np.int64)
+    n = len(positions)
+    for k in range(world_size):
+        owner[order[k * n // world_size:(k + 1) * n // world_size]] = k
+    return owner
+
+
+def segments(steps):
+    """Schedule steps -> launches [(external?, n_internal)]: phases in reference order (internal
+    then external per step, robot.rs:1787-1860) grouped as an optional external phase followed by
+    the internal iterations that follow it (the same grouping as mgx_iterate)."""
+    ph = []
+    for s in steps:
+        if s & hostlib.STEP_INTERNAL:
+            ph.append("I")
+        if s & hostlib.STEP_EXTERNAL:
+            ph.append("E")
+    out, i = [], 0
+    while i < len(ph):
+        ext = ph[i] == "E"
+        if ext:
+            i += 1
+        n = 0
+        while i < len(ph) and ph[i] == "I":
+            n += 1
+            i += 1
+        out.append((ext, n))
+    return out
+
+
+class ShardPlan:
+    """Pure host logic (numpy only): who owns what, which robots are ghosts here, what is sent
+    where, in which order.  Identical code on every rank; no communication needed to build it."""
+
+    def __init__(self, sc, rank, world_size, owner=None):
+        self.rank, self.world_size = rank, world_size
+        n = len(sc["robots"])
+        self.owner = np.asarray(owner) if owner is not None else partition_strips(sc["positions"], world_size)
+        assert len(self.owner) == n
+        self.local = [r for r in range(n) if self.owner[r] == rank]
+        ghosts, send = set(), [set() for _ in range(world_size)]
+        self.connections = []
+        for a, b, n0 in sc["ir"]:
+            oa, ob = self.owner[a], self.owner[b]
+            if ob == rank:
+                self.connections.append((a, b, n0))  # evaluated here (target is local)
+                if oa != rank:
+                    ghosts.add(a)
+            elif oa == rank:
+                send[ob].add(a)  # b's rank evaluates F_ab and needs a's snapshots
+        self.ghosts = sorted(ghosts)
+        self.send_lists = [sorted(s) for s in send]
+        self.recv_lists = [[g for g in self.ghosts if self.owner[g] == p] for p in range(world_size)]
+        self.K = sc["K"]
+
+
+class ShardedWorld:
+    def __init__(self, sc, rank, world_size, world_factory, comm=None, owner=None, tensor_factory=None):
+        self.sc, self.plan, self.comm = sc, ShardPlan(sc, rank, world_size, owner), comm
+        plan = self.plan
+        self.world = world_factory(sc["params"])
+        w = self.world
+        w.set_sdf(sc["sdf"]["rgb"], sc["sdf"]["world_w"], sc["sdf"]["world_h"])
+        self.lid = {}
+        for g in plan.local:
+            rb = sc["robots"][g]
+            self.lid[g] = w.add_robot(rb["mean0"], rb["prior_diag"], rb["dt"], rb["radius"], path=rb["path"],
+                                      order_key=rb["order_key"])
+        for g in plan.ghosts:
+            rb = sc["robots"][g]
+            self.lid[g] = w.add_robot(rb["mean0"], rb["prior_diag"], rb["dt"], rb["radius"], path=None,
+                                      order_key=rb["order_key"], ghost=True)
+        for a, b, n0 in plan.connections:
+            w.ir_connect(self.lid[a], self.lid[b], n0)
+        words = w.halo_words(plan.K)
+        self.send_counts = [len(l) * words for l in plan.send_lists]
+        self.recv_counts = [len(l) * words for l in plan.recv_lists]
+        send_flat = [self.lid[g] for l in plan.send_lists for g in l]
+        recv_flat = [self.lid[g] for l in plan.recv_lists for g in l]
+        w.halo_plan(send_flat, recv_flat)
+        make = tensor_factory or _torch_tensor_factory
+        self.send_buf = make(max(1, sum(self.send_counts)))
+        self.recv_buf = make(max(1, sum(self.recv_counts)))
+
+    # -- exchange pieces (a LocalCluster drives them itself) ---------------------------------------
+    def pack(self):
+        self.world.halo_pack(self.send_buf.data_ptr())
+
+    def unpack(self):
+        self.world.halo_unpack(self.recv_buf.data_ptr())
+
+    def exchange(self):
+        if self.plan.world_size == 1:
+            return
+        self.pack()
+        self.comm.all_to_all(self.recv_buf, self.send_buf, self.recv_counts, self.send_counts)
+        self.unpack()
+
+    def sweep_segment(self, ext, n_int):
+        self.world.sweep(PH_FACTOR | PH_VARIABLE if ext else 0, PH_FACTOR | PH_VARIABLE if n_int else 0, n_int)
+
+    # -- World-like interface over global robot ids -------------------------------------------------
+    def iterate(self, steps):
+        for ext, n_int in segments(steps):
+            if ext:
+                self.exchange()
+            self.sweep_segment(ext, n_int)
+
+    def set_antenna(self, robot, active):
+        if robot in self.lid:
+            self.world.set_antenna(self.lid[robot], active)
+
+    def set_idle(self, robot, idle):
+        if robot in self.lid:
+            self.world.set_idle(self.lid[robot], idle)
+
+    def change_prior(self, robot, var_ix, mean):
+        if self.plan.owner[robot] == self.plan.rank:
+            self.world.change_prior(self.lid[robot], var_ix, mean)
+
+    def read_beliefs(self):
+        """(global robot ids of the local robots, eta, lam, means) of this rank."""
+        eta, lam, mu = self.world.read_beliefs()
+        return list(self.plan.local), eta, lam, mu
+
+    def synchronize(self):
+        self.world.synchronize()
+
+
+def _torch_tensor_factory(n):
+    """device buffers of the halo exchange (torch is the allocator / collective plumbing)"""
+    import torch
+    if not torch.cuda.is_available():
+        raise hostlib.MgxError("halo buffers need a GPU (pass tensor_factory explicitly for host-side tests)")
+    return torch.zeros(n, dtype=torch.float64, device="cuda")
+
+
+class TorchDistComm:
+    """all-to-all-v over torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" on CPU)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+
+    def all_to_all(self, recv, send, recv_counts, send_counts):
+        n_r, n_s = sum(recv_counts), sum(send_counts)
+        self.dist.all_to_all_single(recv[:n_r], send[:n_s], output_split_sizes=list(recv_counts),
+                                    input_split_sizes=list(send_counts), group=self.group)
+
+
+class LocalCluster:
+    """All ranks of a sharded world inside ONE process (one GPU): used by the tests to check the
+    ghost / halo numerics against the unsharded world without a multi-GPU node."""
+
+    def __init__(self, sc, world_size, world_factory, owner=None, tensor_factory=None):
+        self.ranks = [ShardedWorld(sc, r, world_size, world_factory, comm=None, owner=owner,
+                                   tensor_factory=tensor_factory) for r in range(world_size)]
+        self.n_robots, self.K = len(sc["robots"]), sc["K"]
+
+    def _exchange(self):
+        for sw in self.ranks:
+            sw.pack()
+        for sw in self.ranks:
+            sw.synchronize()
+        for dst in self.ranks:  # the all-to-all-v, by hand
+            off_r = 0
+            for p, src in enumerate(self.ranks):
+                cnt = dst.recv_counts[p]
+                off_s = sum(src.send_counts[:dst.plan.rank])
+                assert cnt == src.send_counts[dst.plan.rank]
+                if cnt:
+                    dst.recv_buf[off_r:off_r + cnt].copy_(src.send_buf[off_s:off_s + cnt])
+                off_r += cnt
+        _sync_tensors(self.ranks)
+        for sw in self.ranks:
+            sw.unpack()
+
+    def iterate(self, steps):
+        for ext, n_int in segments(steps):
+            if ext and len(self.ranks) > 1:
+                self._exchange()
+            for sw in self.ranks:
+                sw.sweep_segment(ext, n_int)
+
+    def set_antenna(self, robot, active):
+        for sw in self.ranks:
+            sw.set_antenna(robot, active)
+
+    def set_idle(self, robot, idle):
+        for sw in self.ranks:
+            sw.set_idle(robot, idle)
+
+    def change_prior(self, robot, var_ix, mean):
+        for sw in self.ranks:
+            sw.change_prior(robot, var_ix, mean)
+
+    def read_beliefs(self):
+        K = self.K
+        eta, lam, mu = np.zeros((self.n_robots * K, 4)), np.zeros((self.n_robots * K, 4, 4)), np.zeros((self.n_robots * K, 4))
+        for sw in self.ranks:
+            ids, e, l, m = sw.read_beliefs()
+            for j, g in enumerate(ids):
+                eta[g * K:(g + 1) * K] = e[j * K:(j + 1) * K]
+                lam[g * K:(g + 1) * K] = l[j * K:(j + 1) * K]
+                mu[g * K:(g + 1) * K] = m[j * K:(j + 1) * K]
+        return eta, lam, mu
+
+
+def _sync_tensors(ranks):
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except ImportError:
+        pass

@@ -1,0 +1,46 @@
+"""Sharded execution on the GPU: several ranks of a sharded world driven inside one process
+(LocalCluster: ghosts + halo pack / all-to-all-v / unpack per external iteration) must give the
+beliefs of the single-world CPU oracle bit for bit."""
+import numpy as np
+import pytest
+
+from magics_amd import World, scenarios as S, sharded
+
+import oracle
+from parity import assert_identical
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world_size", [2, 4])
+def test_local_cluster_equals_oracle(world_size):
+    sc = S.grid_scenario(64, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
+    cluster = sharded.LocalCluster(sc, world_size, World)
+    assert any(sw.plan.ghosts for sw in cluster.ranks)
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    steps = sc["steps"] + [1, 1, 2, 3, 2]
+    for tick in range(2):
+        cluster.iterate(steps)
+        ref.iterate(steps)
+        assert_identical(cluster, ref, what=f"{world_size} ranks, tick {tick}")
+
+
+def test_local_cluster_gating_and_prior_changes():
+    sc = S.grid_scenario(36, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
+    cluster = sharded.LocalCluster(sc, 3, World)
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    boundary = sorted({g for sw in cluster.ranks for g in sw.plan.ghosts})
+    def script(w):
+        w.iterate([3, 3, 3])
+        w.set_antenna(boundary[0], False)
+        w.set_idle(boundary[1], True)
+        w.change_prior(boundary[2], 9, np.array([0.5, 0.25, 1.0, -1.0]))
+        w.iterate([3, 3, 3])
+        w.set_antenna(boundary[0], True)
+        w.set_idle(boundary[1], False)
+        w.iterate([3, 3])
+    script(cluster)
+    script(ref)
+    assert_identical(cluster, ref, what="3 ranks, gating + change_prior on boundary robots")
