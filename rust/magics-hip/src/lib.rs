@@ -1,0 +1,131 @@
+//! `FactorGraph`-shaped shim over the MI355X GBP engine (libmgx.so).
+//!
+//! Mirrors the part of `crates/magics/src/factorgraph/factorgraph.rs` that
+//! `crates/magics/src/planner/robot.rs` calls.  Graphs live on the device inside one `World`;
+//! a `FactorGraph` is `(world, robot id)`.  Messages are routed on the device, so the methods
+//! that return `Vec<…Message>` in the reference return empty vectors here.
+//! NOTE: delivered as source; the build image has no Rust toolchain.
+pub mod sys;
+
+use std::ffi::CStr;
+use std::sync::Arc;
+
+#[derive(Debug)]
+pub struct MgxError(pub i32, pub String);
+
+fn check(rc: i32) -> Result<(), MgxError> {
+    if rc >= 0 {
+        return Ok(());
+    }
+    let msg = unsafe { CStr::from_ptr(sys::mgx_last_error()) }.to_string_lossy().into_owned();
+    Err(MgxError(rc, msg))
+}
+
+pub struct World {
+    raw: *mut sys::mgx_world,
+}
+unsafe impl Send for World {}
+unsafe impl Sync for World {} // thread-compatible: callers serialise access, like Bevy's exclusive `&mut`
+
+impl World {
+    pub fn new(params: sys::mgx_params) -> Result<Arc<Self>, MgxError> {
+        let mut raw = std::ptr::null_mut();
+        check(unsafe { sys::mgx_world_create(&params, &mut raw) })?;
+        Ok(Arc::new(Self { raw }))
+    }
+    pub fn set_sdf(&self, rgb: &[u8], width: u32, height: u32, world_w: f64, world_h: f64) -> Result<(), MgxError> {
+        assert_eq!(rgb.len(), (width * height * 3) as usize);
+        check(unsafe { sys::mgx_world_set_sdf(self.raw, rgb.as_ptr(), width, height, world_w, world_h) })
+    }
+    /// `RobotBundle::new` (robot.rs:1134-1356)
+    #[allow(clippy::too_many_arguments)]
+    pub fn add_robot(self: &Arc<Self>, mean0: &[[f64; 4]], prior_diag: &[f64], dt: &[f64], radius: f64,
+                     path: Option<&[[f32; 2]]>, order_key: u64) -> Result<FactorGraph, MgxError> {
+        let k = mean0.len();
+        assert!(prior_diag.len() == k && dt.len() + 1 == k);
+        let desc = sys::mgx_robot_desc {
+            k: k as u32,
+            n_path: path.map_or(0, |p| p.len() as u32),
+            mean0: mean0.as_ptr().cast(),
+            prior_diag: prior_diag.as_ptr(),
+            dt: dt.as_ptr(),
+            path_xy: path.map_or(std::ptr::null(), |p| p.as_ptr().cast()),
+            radius,
+            order_key,
+            ghost: 0,
+            reserved: 0,
+        };
+        let mut id = -1;
+        check(unsafe { sys::mgx_robot_add(self.raw, &desc, &mut id) })?;
+        Ok(FactorGraph { world: self.clone(), robot: id })
+    }
+    /// `create_interrobot_factors`, one direction (robot.rs:1500-1585)
+    pub fn ir_connect(&self, owner: &FactorGraph, other: &FactorGraph, first_robot_number: u64) -> Result<(), MgxError> {
+        check(unsafe { sys::mgx_ir_connect(self.raw, owner.robot, other.robot, first_robot_number) })
+    }
+    /// `delete_interrobot_factors` (robot.rs:1386-1439)
+    pub fn ir_disconnect(&self, a: &FactorGraph, b: &FactorGraph) -> Result<(), MgxError> {
+        check(unsafe { sys::mgx_ir_disconnect(self.raw, a.robot, b.robot) })
+    }
+    /// `iterate_gbp_v2` (robot.rs:1769-1861): `steps[i]` = internal | external << 1
+    pub fn iterate(&self, steps: &[u8]) -> Result<(), MgxError> {
+        check(unsafe { sys::mgx_iterate(self.raw, steps.as_ptr(), steps.len() as u32) })
+    }
+    /// `update_prior_of_horizon_state` + `update_prior_of_current_state_v3` batched (robot.rs:2182-2338)
+    pub fn change_priors(&self, robots: &[i32], vars: &[u32], means: &[[f64; 4]]) -> Result<(), MgxError> {
+        assert!(robots.len() == vars.len() && vars.len() == means.len());
+        check(unsafe { sys::mgx_change_priors(self.raw, robots.len() as u32, robots.as_ptr(), vars.as_ptr(), means.as_ptr().cast()) })
+    }
+}
+
+impl Drop for World {
+    fn drop(&mut self) {
+        unsafe { sys::mgx_world_destroy(self.raw) };
+    }
+}
+
+/// Stand-in for the reference's `FactorGraph` component.
+pub struct FactorGraph {
+    world: Arc<World>,
+    robot: i32,
+}
+
+pub struct Belief {
+    pub information_vector: [f64; 4],
+    pub precision_matrix: [f64; 16],
+    pub mean: [f64; 4],
+    pub covariance_matrix: [f64; 16],
+    pub valid: bool,
+}
+
+impl FactorGraph {
+    pub fn id(&self) -> i32 { self.robot }
+    pub fn internal_factor_iteration(&mut self) -> Result<(), MgxError> {
+        check(unsafe { sys::mgx_internal_factor_iteration(self.world.raw, self.robot) })
+    }
+    pub fn internal_variable_iteration(&mut self) -> Result<(), MgxError> {
+        check(unsafe { sys::mgx_internal_variable_iteration(self.world.raw, self.robot) })
+    }
+    /// factorgraph.rs:494-528; the returned vector is empty because routing happens on the device
+    pub fn change_prior_of_variable(&mut self, variable_index: u32, new_mean: [f64; 4]) -> Result<Vec<()>, MgxError> {
+        check(unsafe { sys::mgx_change_prior(self.world.raw, self.robot, variable_index, new_mean.as_ptr()) })?;
+        Ok(Vec::new())
+    }
+    pub fn set_antenna(&mut self, active: bool) -> Result<(), MgxError> {
+        check(unsafe { sys::mgx_set_antenna(self.world.raw, self.robot, active as i32) })
+    }
+    pub fn set_idle(&mut self, idle: bool) -> Result<(), MgxError> {
+        check(unsafe { sys::mgx_set_idle(self.world.raw, self.robot, idle as i32) })
+    }
+    /// `VariableNode.belief` (variable.rs:40-54)
+    pub fn belief(&self, variable_index: u32) -> Result<Belief, MgxError> {
+        let mut b = Belief { information_vector: [0.0; 4], precision_matrix: [0.0; 16], mean: [0.0; 4], covariance_matrix: [0.0; 16], valid: false };
+        let mut valid = 0;
+        check(unsafe {
+            sys::mgx_get_belief(self.world.raw, self.robot, variable_index, b.information_vector.as_mut_ptr(),
+                                b.precision_matrix.as_mut_ptr(), b.mean.as_mut_ptr(), b.covariance_matrix.as_mut_ptr(), &mut valid)
+        })?;
+        b.valid = valid != 0;
+        Ok(b)
+    }
+}

@@ -1,0 +1,65 @@
+//! Raw bindings of include/mgx.h (kept in sync by hand; `bindgen include/mgx.h` gives the same).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct mgx_world { _private: [u8; 0] }
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct mgx_params {
+    pub sigma_dynamics: f64,
+    pub sigma_interrobot: f64,
+    pub sigma_obstacle: f64,
+    pub sigma_tracking: f64,
+    pub safety_multiplier: f64,
+    pub tracking_switch_padding: f64,
+    pub tracking_attraction_distance: f64,
+    pub enable_mask: u32,
+    pub reserved: u32,
+}
+
+#[repr(C)]
+pub struct mgx_robot_desc {
+    pub k: u32,
+    pub n_path: u32,
+    pub mean0: *const f64,
+    pub prior_diag: *const f64,
+    pub dt: *const f64,
+    pub path_xy: *const f32,
+    pub radius: f64,
+    pub order_key: u64,
+    pub ghost: u32,
+    pub reserved: u32,
+}
+
+extern "C" {
+    pub fn mgx_world_create(params: *const mgx_params, out: *mut *mut mgx_world) -> c_int;
+    pub fn mgx_world_destroy(w: *mut mgx_world) -> c_int;
+    pub fn mgx_last_error() -> *const c_char;
+    pub fn mgx_set_stream(w: *mut mgx_world, hip_stream: *mut c_void) -> c_int;
+    pub fn mgx_synchronize(w: *mut mgx_world) -> c_int;
+    pub fn mgx_world_set_sdf(w: *mut mgx_world, rgb: *const u8, width: u32, height: u32, world_w: f64, world_h: f64) -> c_int;
+    pub fn mgx_robot_add(w: *mut mgx_world, desc: *const mgx_robot_desc, robot_id: *mut i32) -> c_int;
+    pub fn mgx_ir_connect(w: *mut mgx_world, owner: i32, other: i32, first_robot_number: u64) -> c_int;
+    pub fn mgx_ir_disconnect(w: *mut mgx_world, a: i32, b: i32) -> c_int;
+    pub fn mgx_set_antenna(w: *mut mgx_world, robot: i32, active: i32) -> c_int;
+    pub fn mgx_set_idle(w: *mut mgx_world, robot: i32, idle: i32) -> c_int;
+    pub fn mgx_iterate(w: *mut mgx_world, steps: *const u8, n: u32) -> c_int;
+    pub fn mgx_sweep(w: *mut mgx_world, robot: i32, external_phases: u32, internal_phases: u32, n_internal: u32) -> c_int;
+    pub fn mgx_internal_factor_iteration(w: *mut mgx_world, robot: i32) -> c_int;
+    pub fn mgx_internal_variable_iteration(w: *mut mgx_world, robot: i32) -> c_int;
+    pub fn mgx_external_factor_iteration(w: *mut mgx_world, robot: i32) -> c_int;
+    pub fn mgx_external_variable_iteration(w: *mut mgx_world, robot: i32) -> c_int;
+    pub fn mgx_change_prior(w: *mut mgx_world, robot: i32, var_ix: u32, mean: *const f64) -> c_int;
+    pub fn mgx_change_priors(w: *mut mgx_world, n: u32, robots: *const i32, var_ix: *const u32, means: *const f64) -> c_int;
+    pub fn mgx_get_belief(w: *mut mgx_world, robot: i32, var_ix: u32, eta: *mut f64, lam: *mut f64, mean: *mut f64, cov: *mut f64, valid: *mut i32) -> c_int;
+    pub fn mgx_read_beliefs(w: *mut mgx_world, eta: *mut f64, lam: *mut f64, means: *mut f64) -> c_int;
+    pub fn mgx_num_robots(w: *mut mgx_world, n_robots: *mut u32, n_variables: *mut u32) -> c_int;
+    pub fn mgx_halo_words(k: u32) -> u32;
+    pub fn mgx_halo_plan(w: *mut mgx_world, n_send: u32, send_robots: *const i32, n_recv: u32, recv_ghosts: *const i32) -> c_int;
+    pub fn mgx_halo_pack(w: *mut mgx_world, dev_buf: *mut c_void) -> c_int;
+    pub fn mgx_halo_unpack(w: *mut mgx_world, dev_buf: *const c_void) -> c_int;
+    pub fn mgx_schedule(kind: i32, n_internal: u8, n_external: u8, steps: *mut u8, capacity: u32) -> c_int;
+    pub fn mgx_variable_timesteps(lookahead_horizon: u32, lookahead_multiple: u32, timesteps: *mut u32, capacity: u32) -> c_int;
+}
