@@ -63,27 +63,34 @@ MGX_HD bool any_inf16(const double (&a)[16]) {
 }
 
 // Belief update of VariableNode::update_belief_and_create_factor_responses
-// (variable.rs:273-297) given the already summed (eta, lam).  mu / cov / valid keep their
-// previous values when the precision is "zero" (no element > 1e-6) or singular.
-MGX_HD void belief_from_information(const double (&eta)[4], const double (&lam)[16], double (&mu)[4],
-                                    double (&cov)[16], int &valid) {
+// (variable.rs:273-297) given the already summed (eta, lam).  Returns false — mu / cov / valid keep
+// their previous values — when the precision is "zero" (no element > 1e-6) or singular; otherwise
+// cov is replaced, valid recomputed, and mu replaced iff the covariance is finite.
+MGX_HD bool belief_update(const double (&eta)[4], const double (&lam)[16], double (&mu)[4], double (&cov)[16],
+                          int &valid) {
     bool not_zero = false;
 #pragma unroll
     for (int i = 0; i < 16; i++) not_zero = not_zero || (lam[i] - 1e-6 > 0.0);
-    if (!not_zero) return;
-    double c[16];
-    if (!inv4(lam, c)) return;
+    if (!not_zero) return false;
+    if (!inv4(lam, cov)) return false;
     bool fin = true;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        cov[i] = c[i];
-        fin = fin && std::isfinite(c[i]);
-    }
+    for (int i = 0; i < 16; i++) fin = fin && std::isfinite(cov[i]);
     valid = fin ? 1 : 0;
     if (fin) {
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            mu[r] = ((c[r * 4 + 0] * eta[0] + c[r * 4 + 1] * eta[1]) + c[r * 4 + 2] * eta[2]) + c[r * 4 + 3] * eta[3];
+            mu[r] = ((cov[r * 4 + 0] * eta[0] + cov[r * 4 + 1] * eta[1]) + cov[r * 4 + 2] * eta[2]) + cov[r * 4 + 3] * eta[3];
+    }
+    return true;
+}
+
+MGX_HD void belief_from_information(const double (&eta)[4], const double (&lam)[16], double (&mu)[4],
+                                    double (&cov)[16], int &valid) {
+    double c[16];
+    if (belief_update(eta, lam, mu, c, valid)) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) cov[i] = c[i];
     }
 }
 
@@ -185,15 +192,27 @@ MGX_HD uint32_t sat_u32(double v) {
 struct SdfView {
     const uint8_t *red;  // single channel (red of the reference's Rgb<u8> image), row-major
     uint32_t w, h;
-    double world_w, world_h;
+    // ObstacleFactor::measure recomputes these four from (world size, image size) on every call
+    // (obstacle.rs:147-150); they are loop invariants, evaluated once with the same f64 operations
+    double x_off, y_off, x_scale, y_scale;
 };
+
+MGX_HD SdfView make_sdf_view(const uint8_t *red, uint32_t w, uint32_t h, double world_w, double world_h) {
+    SdfView s;
+    s.red = red;
+    s.w = w;
+    s.h = h;
+    s.x_off = world_w / 2.0;
+    s.y_off = world_h / 2.0;
+    s.x_scale = (double)w / world_w;
+    s.y_scale = (double)h / world_h;
+    return s;
+}
 
 // pixel index of ObstacleFactor::measure, or -1 when outside the image (=> h = 0)
 MGX_HD long long sdf_index(const SdfView &s, double x, double y) {
-    const double x_off = s.world_w / 2.0, y_off = s.world_h / 2.0;
-    const double x_scale = (double)s.w / s.world_w, y_scale = (double)s.h / s.world_h;
-    const uint32_t xp = sat_u32((x + x_off) * x_scale);
-    const uint32_t yp = sat_u32((-y + y_off) * y_scale);
+    const uint32_t xp = sat_u32((x + s.x_off) * s.x_scale);
+    const uint32_t yp = sat_u32((-y + s.y_off) * s.y_scale);
     if (!(xp < s.w && yp < s.h)) return -1;
     return (long long)yp * s.w + xp;
 }

@@ -27,7 +27,8 @@ struct DevWorld {
     double *prior_eta, *prior_lam;
     double *bel_eta, *bel_lam, *bel_mu, *bel_cov;
     int32_t *bel_valid;
-    double *snap[2];          // [24][V] variable -> own-factor snapshot (eta, lam, mu)
+    double *snap[2];          // [V][24] variable -> own-factor snapshot (eta, lam, mu), one 192-B record per
+                              // variable: other robots' workgroups gather whole records
     uint32_t *snap_epoch[2];  // [V] number of deliveries (internal sweeps + prior changes)
 
     // internal factor -> variable messages
@@ -60,6 +61,7 @@ struct DevWorld {
     const uint8_t *sdf;
     uint32_t sdf_w, sdf_h;
     double world_w, world_h, obs_delta;
+    int ir_max_edges;  // largest number of inter-robot edges attached to one robot (LDS staging size)
 
     double inv_s2_obs, inv_s2_ir, inv_s2_trk, trk_pad, trk_attr;
 };

@@ -23,8 +23,8 @@
 #include "mgx_dev.h"
 
 namespace mgx {
-size_t sweep_lds_bytes(int K);
-int sweep_block(int K);
+size_t sweep_lds_bytes(int K, int ir_edges);
+bool sweep_supports(int K);
 hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, uint32_t int_mask, int n_int,
                               int snap_out, hipStream_t stream);
 hipError_t launch_change_prior(const DevWorld &w, int n, const int32_t *robots, const uint32_t *vars, const double *means,
@@ -244,7 +244,7 @@ static int pull(mgx_world *w) {
             gather(bl, V, v, &rb.bel_lam[16 * i], 16);
             gather(bm, V, v, &rb.bel_mu[4 * i], 4);
             gather(bc, V, v, &rb.bel_cov[16 * i], 16);
-            gather(sn, V, v, &rb.snap[24 * i], 24);
+            memcpy(&rb.snap[24 * i], &sn[v * 24], 24 * sizeof(double));
             rb.valid[i] = bv[v];
             rb.epoch[i] = ep[v];
         }
@@ -297,7 +297,7 @@ static int commit(mgx_world *w) {
     int rc = pull(w);
     if (rc != MGX_OK) return rc;
     const int K = w->K, E = 4 * K - 6;
-    if (sweep_lds_bytes(K) > 64 * 1024 || sweep_block(K) > 256) return fail(MGX_ERR_INVALID, "K = %d too large", K);
+    if (!sweep_supports(K) || sweep_lds_bytes(K, 0) > 60 * 1024) return fail(MGX_ERR_INVALID, "K = %d not supported (3 <= K <= 33)", K);
 
     // device robot order: locals (id order), then ghosts
     w->robot_of.clear();
@@ -375,6 +375,9 @@ static int commit(mgx_world *w) {
         }
     }
     var_ptr[per_var.size()] = (int32_t)e;
+    int ir_max_edges = 0;
+    for (int dr = 0; dr < R_local; dr++)
+        ir_max_edges = std::max(ir_max_edges, (int)(var_ptr[(size_t)(dr + 1) * K] - var_ptr[(size_t)dr * K]));
 
     std::vector<double> pe(4 * V), pl(16 * V), be(4 * V), bl(16 * V), bm(4 * V), bc(16 * V), sn(24 * V), fe(4 * EI, 0.0),
         fl(16 * EI, 0.0), dm(16 * ND, 0.0), tlv(NT, 0.0);
@@ -391,7 +394,7 @@ static int commit(mgx_world *w) {
             scatter(bl, V, v, &rb.bel_lam[16 * i], 16);
             scatter(bm, V, v, &rb.bel_mu[4 * i], 4);
             scatter(bc, V, v, &rb.bel_cov[16 * i], 16);
-            scatter(sn, V, v, &rb.snap[24 * i], 24);
+            memcpy(&sn[v * 24], &rb.snap[24 * i], 24 * sizeof(double));
             bv[v] = rb.valid[i];
             ep[v] = rb.epoch[i];
         }
@@ -463,6 +466,7 @@ static int commit(mgx_world *w) {
     d.R_local = R_local; d.R_total = R_total; d.K = K; d.E = E;
     d.V = (int)V; d.EI = (int)EI; d.ND = (int)ND; d.NT = (int)NT; d.NI = (int)NIs;
     d.cur = 0;
+    d.ir_max_edges = ir_max_edges;
     d.enable = w->p.enable_mask;
     d.prior_eta = w->prior_eta.p; d.prior_lam = w->prior_lam.p;
     d.bel_eta = w->bel_eta.p; d.bel_lam = w->bel_lam.p; d.bel_mu = w->bel_mu.p; d.bel_cov = w->bel_cov.p;

@@ -40,7 +40,7 @@ int h_interrobot_message(const double *xlo, const double *xhi, double dsafe, dou
 }
 void h_obstacle(const unsigned char *red, unsigned w, unsigned h, double ww, double wh, double delta, double inv_s2,
                 const double *x0, double *oe, double *ol) {
-    mgx::SdfView s{red, w, h, ww, wh};
+    mgx::SdfView s = mgx::make_sdf_view(red, w, h, ww, wh);
     long long idx[4];
     double x[4], hv[4], re[4], rl[16];
     for (int i = 0; i < 4; i++) x[i] = x0[i];
