@@ -64,6 +64,8 @@ struct DevWorld {
     int ir_max_edges;  // largest number of inter-robot edges attached to one robot (LDS staging size)
 
     double inv_s2_obs, inv_s2_ir, inv_s2_trk, trk_pad, trk_attr;
+    // diagnostic builds only (-DMGX_STAMPS, tools/stamps.py): per-workgroup phase cycle sums
+    unsigned long long *dbg;
 };
 
 // phases of one launch

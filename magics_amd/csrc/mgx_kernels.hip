@@ -1,27 +1,27 @@
 // mgx_kernels.hip — gfx950 kernels of the GBP engine.
 //
-// k_robot_sweep: ONE 128-THREAD WORKGROUP PER ROBOT, TWO ROLE-SPECIALISED WAVES.
-// The robot's whole factor graph (variable->factor snapshots, priors, factor->variable messages,
-// the inter-robot messages attached to its variables) is staged in LDS once per launch and stays
+// k_robot_sweep: ONE 128-THREAD WORKGROUP PER GROUP OF RPB ROBOTS, TWO ROLE-SPECIALISED WAVES.
+// The robots' whole factor graphs (variable->factor snapshots, priors, factor->variable messages,
+// the inter-robot messages attached to their variables) are staged in LDS once per launch and stay
 // there for every phase the launch runs: an optional external phase
 // (external_factor_iteration + routing + external_variable_iteration,
 // factorgraph.rs:719-760,794-826, robot.rs:1803-1859) followed by `n_int` internal iterations
 // (internal_factor_iteration + internal_variable_iteration, factorgraph.rs:688-714,762-790).
 //
-//   wave 0 (DYN)  factor phase: one lane per dynamic-factor MESSAGE (2(K-1) lanes), one 4x4
+//   wave 0 (DYN)  factor phase: one lane per dynamic-factor MESSAGE (RPB * 2(K-1) lanes), one 4x4
 //                 Schur complement each
 //   wave 1 (UV)   factor phase: one lane per obstacle / tracking factor;
 //                 variable phase: one lane per variable (inbox sum, 4x4 inverse, belief)
 //   both waves    external factor sweep: one lane per incoming inter-robot edge ("pull" form:
 //                 every factor F_AB is evaluated by the workgroup of its only consumer B)
 //
-// At 1000 robots the chip holds every workgroup at once (4 per CU = 2 waves per SIMD from
-// different robots), so the long dependent f64 chains of one wave are partly hidden behind another
-// robot's wave.  All per-variable state lives in LDS, not registers, so each wave stays within the
-// 256 VGPRs that two waves per SIMD allow.  Each phase is a Jacobi sweep separated by workgroup
-// barriers only.  Robots couple only through the inter-robot edges, which gather the OTHER robot's
-// 192-byte snapshot records from buffer `cur` in HBM while this launch writes buffer `1 - cur`:
-// no inter-workgroup synchronisation inside a launch.
+// RPB (robots per workgroup) packs as many robots as fit the 64 lanes of each role (2 at K = 16):
+// the per-message instruction streams are long dependent f64 chains, so a wave costs the same
+// whether 30 or 60 of its lanes are live.  All per-variable state lives in LDS, not registers, so
+// each wave stays within 256 VGPRs.  Each phase is a Jacobi sweep separated by workgroup barriers
+// only.  Robots couple only through the inter-robot edges, which gather the OTHER robot's 192-byte
+// snapshot records from buffer `cur` in HBM while this launch writes buffer `1 - cur`: no
+// inter-workgroup synchronisation inside a launch.
 //
 // Arithmetic: gbp_math.h, compiled with -ffp-contract=off so that results are bit-identical to
 // the scalar f64 reference semantics.
@@ -54,81 +54,122 @@ __device__ __forceinline__ void st_soa16(double *base, int stride, int item, con
 
 extern __shared__ double lds[];
 
+// In-kernel cycle stamps exist only in the diagnostic build (never in libmgx.so): they go to a
+// buffer of their own and no output value depends on them.
+#ifdef MGX_STAMPS
+#define STAMP(var) unsigned long long var = __builtin_readcyclecounter()
+#define STAMP_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(acc, a, b)
+#endif
+
 // STAGE_IR: the robot's incoming inter-robot messages are kept in LDS ([20][n_edges]); otherwise
 // (a robot with too many edges for LDS) they are read from HBM / L2 in every variable sweep.
 // KT: horizon length K as a compile-time constant (0 = read it from the world): with K fixed every
 // LDS access is base + immediate offset, which keeps the address arithmetic out of the VGPR budget.
 constexpr int IR_STRIDE = 21;  // one staged inter-robot message: 20 f64 + 1 pad (bank spread)
 
-template <int KT, bool STAGE_IR>
-__global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int robot0, uint32_t ext_mask, uint32_t int_mask,
-                                                             int n_int, int snap_out) {
-    const int r = robot0 + blockIdx.x;
+// robots per workgroup: every role must fit one 64-lane wave
+#ifndef MGX_RPB_MAX
+#define MGX_RPB_MAX 1
+#endif
+constexpr int rpb_for(int K) {
+    int n = 64 / (2 * (K - 1));
+    return n < 1 ? 1 : (n > MGX_RPB_MAX ? MGX_RPB_MAX : n);
+}
+
+template <int KT, int RPB, bool STAGE_IR>
+__global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int robot0, int robot_end, uint32_t ext_mask,
+                                                             uint32_t int_mask, int n_int, int snap_out) {
+    STAMP(t_k0);
+    const int r0 = robot0 + blockIdx.x * RPB;                       // first robot of this workgroup
+    const int n_sub = (robot_end - r0) < RPB ? (robot_end - r0) : RPB;  // robots actually present
     const int tid = threadIdx.x;
     const int role = tid >> 6, lane = tid & 63;
     const int K = KT > 0 ? KT : w.K, E = 4 * K - 6;
-    double *s_snap = lds;                              // [24][K] variable -> own-factor snapshots
-    double *s_prior = s_snap + SNAP_W * K;             // [20][K] prior eta, lam
-    double *s_cov = s_prior + 20 * K;                  // [16][K] belief covariance
-    double *s_mu = s_cov + 16 * K;                     // [4][K]  belief mean
-    double *s_fv = s_mu + 4 * K;                       // [20][E] factor -> variable messages
-    uint32_t *s_epoch = (uint32_t *)(s_fv + 20 * E);   // [K] deliveries
-    int32_t *s_valid = (int32_t *)(s_epoch + K);       // [K]
-    double *s_ir = (double *)(s_valid + K);            // [ne][IR_STRIDE] inter-robot messages (STAGE_IR)
+    const int KK = RPB * K, EE = RPB * E + 1;                      // LDS column counts (+1: an all-zero
+                                                                   // message column for absent edges)
+    const int nK = n_sub * K, nE = n_sub * E;                      // live columns
+    const int ZCOL = EE - 1;
+    double *s_snap = lds;                              // [24][KK] variable -> own-factor snapshots
+    double *s_prior = s_snap + SNAP_W * KK;            // [20][KK] prior eta, lam
+    double *s_cov = s_prior + 20 * KK;                 // [16][KK] belief covariance
+    double *s_mu = s_cov + 16 * KK;                    // [4][KK]  belief mean
+    double *s_fv = s_mu + 4 * KK;                      // [20][EE] factor -> variable messages
+    uint32_t *s_epoch = (uint32_t *)(s_fv + 20 * EE);  // [KK] deliveries
+    int32_t *s_valid = (int32_t *)(s_epoch + KK);      // [KK]
+    double *s_ir = (double *)(s_valid + KK);           // [ne][IR_STRIDE] inter-robot messages (STAGE_IR)
 
-    const bool idle = w.idle[r] != 0;
-    const bool radio = (w.antenna[r] != 0) && !idle;
-    const int v0 = r * K, eb = r * E;
-    const int ie0 = w.ir_var_ptr[v0], ie1 = w.ir_var_ptr[v0 + K], ne = ie1 - ie0;
+    const int v0 = r0 * K, eb = r0 * E;
+    const int ie0 = w.ir_var_ptr[v0], ie1 = w.ir_var_ptr[v0 + nK], ne = ie1 - ie0;
     const bool ir_on = (w.enable & 2u) != 0;
-    const int n_dyn = 2 * (K - 1);
+    const int n_dyn = 2 * (K - 1), n_una = 2 * (K - 2);
 
-    // ---- stage the robot in LDS (all 256 threads, coalesced) ----------------------------------
+    // ---- stage the robots in LDS (all 128 threads, coalesced; consecutive robots are contiguous) --
     {
         const double *src = w.snap[w.cur] + (size_t)v0 * SNAP_W;
-        for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = src[t];
-        for (int t = tid; t < 20 * E; t += SWEEP_BLOCK) {
-            const int c = t / E, e = t - c * E;
-            s_fv[t] = (c < 4) ? w.fv_eta[(size_t)c * w.EI + eb + e] : w.fv_lam[(size_t)(c - 4) * w.EI + eb + e];
+        for (int t = tid; t < SNAP_W * nK; t += SWEEP_BLOCK) s_snap[(t % SNAP_W) * KK + (t / SNAP_W)] = src[t];
+        for (int t = tid; t < 20 * nE; t += SWEEP_BLOCK) {
+            const int c = t / nE, e = t - c * nE;
+            s_fv[c * EE + e] = (c < 4) ? w.fv_eta[(size_t)c * w.EI + eb + e] : w.fv_lam[(size_t)(c - 4) * w.EI + eb + e];
         }
+        if (tid < 20) s_fv[tid * EE + ZCOL] = 0.0;
         if (STAGE_IR)
             for (int t = tid; t < 20 * ne; t += SWEEP_BLOCK) {
                 const int c = t / ne, j = t - c * ne;
                 s_ir[j * IR_STRIDE + c] = (c < 4) ? w.ir_fv_eta[(size_t)c * w.NI + ie0 + j] : w.ir_fv_lam[(size_t)(c - 4) * w.NI + ie0 + j];
             }
-        for (int t = tid; t < 20 * K; t += SWEEP_BLOCK) {
-            const int c = t / K, i = t - c * K;
-            s_prior[t] = (c < 4) ? w.prior_eta[(size_t)c * w.V + v0 + i] : w.prior_lam[(size_t)(c - 4) * w.V + v0 + i];
+        for (int t = tid; t < 20 * nK; t += SWEEP_BLOCK) {
+            const int c = t / nK, i = t - c * nK;
+            s_prior[c * KK + i] = (c < 4) ? w.prior_eta[(size_t)c * w.V + v0 + i] : w.prior_lam[(size_t)(c - 4) * w.V + v0 + i];
         }
-        for (int t = tid; t < 16 * K; t += SWEEP_BLOCK) s_cov[t] = w.bel_cov[(size_t)(t / K) * w.V + v0 + (t % K)];
-        for (int t = tid; t < 4 * K; t += SWEEP_BLOCK) s_mu[t] = w.bel_mu[(size_t)(t / K) * w.V + v0 + (t % K)];
-        for (int t = tid; t < K; t += SWEEP_BLOCK) {
+        for (int t = tid; t < 16 * nK; t += SWEEP_BLOCK) s_cov[(t / nK) * KK + (t % nK)] = w.bel_cov[(size_t)(t / nK) * w.V + v0 + (t % nK)];
+        for (int t = tid; t < 4 * nK; t += SWEEP_BLOCK) s_mu[(t / nK) * KK + (t % nK)] = w.bel_mu[(size_t)(t / nK) * w.V + v0 + (t % nK)];
+        for (int t = tid; t < nK; t += SWEEP_BLOCK) {
             s_epoch[t] = w.snap_epoch[w.cur][v0 + t];
             s_valid[t] = w.bel_valid[v0 + t];
         }
     }
-    int itf = w.iter_factor[r];
 
-    // ---- UV wave, variable phase: lane = variable ------------------------------------------------
-    const bool is_var = role == ROLE_UV && lane < K;
+    // ---- this lane's robot in each of its roles ---------------------------------------------------
+    // DYN wave: lane -> (robot sd, message l); UV wave: unary lane -> (su, factor l), variable lane -> (sv, i)
+    const int sd = lane / n_dyn, ld = lane - sd * n_dyn;
+    const int su = lane / n_una, lu = lane - su * n_una;
+    const int sv = lane / K, iv = lane - sv * K;
+    const bool is_dyn = role == ROLE_DYN && lane < n_sub * n_dyn;
+    const bool is_una = role == ROLE_UV && lane < n_sub * n_una;
+    const bool is_obs = is_una && lu < K - 2;
+    const bool is_trk = is_una && lu >= K - 2;
+    const bool is_var = role == ROLE_UV && lane < nK;
+    // the robot whose flags / counters this lane follows (edge lanes look theirs up per edge)
+    const int my_sub = role == ROLE_DYN ? (is_dyn ? sd : 0) : (is_una ? su : (is_var ? sv : 0));
+    const bool idle_u = w.idle[r0 + (is_una ? su : 0)] != 0;      // unary-factor lane's robot
+    const bool idle_v = w.idle[r0 + (is_var ? sv : 0)] != 0;      // variable lane's robot
+    const bool idle_d = w.idle[r0 + (is_dyn ? sd : 0)] != 0;      // dynamic-message lane's robot
+    const bool radio_v = (w.antenna[r0 + (is_var ? sv : 0)] != 0) && !idle_v;
+    // iteration_count.factor of the robot this lane follows (every lane applies the same increments
+    // as its robot: one per internal factor sweep if not idle, one per external factor sweep if on air)
+    int itf = w.iter_factor[r0 + my_sub];
+    const bool my_idle = w.idle[r0 + my_sub] != 0;
+    const bool my_radio = (w.antenna[r0 + my_sub] != 0) && !my_idle;
+
     int ir_e0 = 0, ir_mid = 0, ir_e1 = 0;
     if (is_var) {
         ir_e0 = w.ir_var_ptr[v0 + lane];
         ir_mid = w.ir_var_mid[v0 + lane];
         ir_e1 = w.ir_var_ptr[v0 + lane + 1];
     }
-    // which variable sweep of this launch is the last one (it writes the belief to HBM)
-    const bool has_int_var = (int_mask & PH_INT_VARIABLE) && n_int > 0 && !idle;
-    const bool any_var_sweep = has_int_var || ((ext_mask & PH_EXT_VARIABLE) && radio);
+    // which variable sweep of this launch is the last one for this lane's robot (its belief goes out)
+    const bool has_int_var = (int_mask & PH_INT_VARIABLE) && n_int > 0 && !idle_v;
 
-    // ---- DYN wave: constant potential blocks of this lane's message -----------------------------
-    const bool is_dyn = role == ROLE_DYN && lane < n_dyn;
+    // ---- DYN wave: constant potential blocks of this lane's message -------------------------------
     double maa[4], mab[4], mba[4], mbb[4];
-    int dyn_other_var = 0, dyn_other_edge = 0;
+    int dyn_other_var = 0, dyn_other_edge = 0, dyn_edge = 0;
     if (is_dyn) {
-        const int f = lane % (K - 1), slot = lane / (K - 1);
+        const int f = ld % (K - 1), slot = ld / (K - 1);
         const int a2 = 2 * slot, b2 = 2 * (1 - slot);
-        const int it = r * (K - 1) + f;
+        const int it = (r0 + sd) * (K - 1) + f;
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -138,19 +179,18 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 mba[i * 2 + j] = w.dyn_m[(size_t)((b2 + i) * 4 + (a2 + j)) * w.ND + it];
                 mbb[i * 2 + j] = w.dyn_m[(size_t)((b2 + i) * 4 + (b2 + j)) * w.ND + it];
             }
-        dyn_other_var = f + 1 - slot;
-        dyn_other_edge = (1 - slot) * (K - 1) + f;
+        dyn_other_var = sd * K + f + 1 - slot;
+        dyn_other_edge = sd * E + (1 - slot) * (K - 1) + f;
+        dyn_edge = sd * E + ld;
     }
 
-    // ---- UV wave, factor phase: obstacle lanes [0, K-2), tracking lanes [K-2, 2(K-2)) -----------
-    const bool is_obs = role == ROLE_UV && lane < K - 2;
-    const bool is_trk = role == ROLE_UV && lane >= K - 2 && lane < 2 * (K - 2);
-    const int uvar = (is_trk ? lane - (K - 2) : lane) + 1;          // variable of the unary factor
-    const int uedge = n_dyn + lane;                                 // its internal-edge slot
+    // ---- UV wave, factor phase: per robot obstacle lanes [0, K-2), tracking lanes [K-2, 2(K-2)) ----
+    const int uvar = su * K + (is_trk ? lu - (K - 2) : lu) + 1;     // LDS column of the factor's variable
+    const int uedge = su * E + n_dyn + lu;                          // its internal-edge column
     int trk_rec = 0;
     float trk_lp[2] = {0.f, 0.f};
     double trk_lv = 0.0;
-    const int trk_item = r * (K - 2) + (uvar - 1);
+    const int trk_item = (r0 + su) * (K - 2) + (lu - (K - 2));
     if (is_trk) {
         trk_rec = w.trk_record[trk_item];
         trk_lp[0] = w.trk_last_pos[trk_item];
@@ -158,14 +198,17 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         trk_lv = w.trk_last_val[trk_item];
     }
     __syncthreads();
+    STAMP(t_staged);
 
     // ======================= external factor sweep (pull form) ================================
     // factorgraph.rs:745-754 keeps only the message to the other graph's variable, so F_AB is
     // evaluated here, at B, from A's snapshot record and B's last response mean.
     if (ext_mask & PH_EXT_FACTOR) {
-        if (radio && ir_on) {
+        if (ir_on) {
             for (int j = tid; j < ne; j += SWEEP_BLOCK) {
                 const int e = ie0 + j;
+                const int B = w.ir_dst_var[e] / K;  // target robot (device index)
+                if (!(w.antenna[B] != 0 && w.idle[B] == 0)) continue;  // B cannot receive
                 const int A = w.ir_src_robot[e];
                 if (!(w.antenna[A] != 0 && w.idle[A] == 0)) continue;  // A did not run its sweep
                 const int s = w.ir_src_var[e];
@@ -209,15 +252,18 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 }
             }
         }
-        if (radio) itf += 1;  // iteration_count.factor of B's own external sweep (factorgraph.rs:757)
+        if (my_radio) itf += 1;  // iteration_count.factor of the robot's own external sweep (factorgraph.rs:757)
         __syncthreads();
     }
 
-    // internal-edge slots of variable `lane`
-    const int e_left = (lane >= 1) ? (K - 1) + (lane - 1) : -1;   // dynamic factor lane-1 -> slot 1
-    const int e_right = (lane <= K - 2) ? lane : -1;               // dynamic factor lane   -> slot 0
-    const int e_obs = (lane >= 1 && lane <= K - 2) ? n_dyn + (lane - 1) : -1;
-    const int e_trk = (lane >= 1 && lane <= K - 2) ? n_dyn + (K - 2) + (lane - 1) : -1;
+    // internal-edge columns of this lane's variable
+    const int eoff = sv * E;
+    // (absent edges read the all-zero column: x + 0.0 == x exactly, and a running sum that starts from
+    // the prior is never -0.0, so this equals skipping the entry as the reference's inbox does)
+    const int e_left = (iv >= 1) ? eoff + (K - 1) + (iv - 1) : ZCOL;   // dynamic factor i-1 -> slot 1
+    const int e_right = (iv <= K - 2) ? eoff + iv : ZCOL;               // dynamic factor i   -> slot 0
+    const int e_obs = (iv >= 1 && iv <= K - 2) ? eoff + n_dyn + (iv - 1) : ZCOL;
+    const int e_trk = (iv >= 1 && iv <= K - 2) ? eoff + n_dyn + (K - 2) + (iv - 1) : ZCOL;
 
     auto ir_accumulate = [&](int e_from, int e_to, double (&eta)[4], double (&lam)[16]) {
         for (int e = e_from; e < e_to; e++) {
@@ -236,13 +282,18 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         }
     };
 
-    auto variable_sweep = [&](bool deliver_internal, bool last) {
-        // VariableNode::update_belief_and_create_factor_responses, variable.rs:251-342
-        double b_eta[4], b_lam[16], mu[4], cov[16];
+    // VariableNode::update_belief_and_create_factor_responses (variable.rs:251-342) in two halves:
+    //  variable_sum:    eta / lam = prior + inbox (:254-271) and, for an internal sweep, the (eta, lam)
+    //                   part of the responses to own-graph factors (:301-330, factorgraph.rs:771-786);
+    //  variable_finish: covariance, validity and mean from (eta, lam) (:273-297) and the mean part of
+    //                   the responses.
+    // Dynamic factors never read a mean, so in the internal loop the finish of sweep t runs in the UV
+    // wave NEXT TO the dynamic messages of sweep t+1 in the DYN wave instead of in front of them.
+    auto variable_sum = [&](bool deliver_internal, bool last, double (&b_eta)[4], double (&b_lam)[16]) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) b_eta[c] = s_prior[c * K + lane];
+        for (int c = 0; c < 4; c++) b_eta[c] = s_prior[c * KK + lane];
 #pragma unroll
-        for (int c = 0; c < 16; c++) b_lam[c] = s_prior[(4 + c) * K + lane];
+        for (int c = 0; c < 16; c++) b_lam[c] = s_prior[(4 + c) * KK + lane];
         // inbox order of the reference (BTreeMap<FactorId, _>, id.rs:19-54): factors of graphs with a
         // lower key, own factors by node index (dynamic i-1, dynamic i, obstacle, tracking; own
         // inter-robot factors are forever empty), then factors of graphs with a higher key
@@ -250,79 +301,155 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         const int es[4] = {e_left, e_right, e_obs, e_trk};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            if (es[q] < 0) continue;
 #pragma unroll
-            for (int c = 0; c < 4; c++) b_eta[c] += s_fv[c * E + es[q]];
+            for (int c = 0; c < 4; c++) b_eta[c] += s_fv[c * EE + es[q]];
 #pragma unroll
-            for (int c = 0; c < 16; c++) b_lam[c] += s_fv[(4 + c) * E + es[q]];
+            for (int c = 0; c < 16; c++) b_lam[c] += s_fv[(4 + c) * EE + es[q]];
         }
         ir_accumulate(ir_mid, ir_e1, b_eta, b_lam);
+        if (deliver_internal) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) mu[c] = s_mu[c * K + lane];
-        int valid = s_valid[lane];
-        if (belief_update(b_eta, b_lam, mu, cov, valid)) {  // covariance (and maybe mean) changed
+            for (int c = 0; c < 4; c++) s_snap[c * KK + lane] = b_eta[c];
 #pragma unroll
-            for (int c = 0; c < 16; c++) s_cov[c * K + lane] = cov[c];
-#pragma unroll
-            for (int c = 0; c < 4; c++) s_mu[c * K + lane] = mu[c];
-            s_valid[lane] = valid;
-        }
-        if (deliver_internal) {  // responses to own-graph factors (factorgraph.rs:771-786)
-#pragma unroll
-            for (int c = 0; c < 4; c++) s_snap[c * K + lane] = b_eta[c];
-#pragma unroll
-            for (int c = 0; c < 16; c++) s_snap[(4 + c) * K + lane] = b_lam[c];
-#pragma unroll
-            for (int c = 0; c < 4; c++) s_snap[(20 + c) * K + lane] = mu[c];
+            for (int c = 0; c < 16; c++) s_snap[(4 + c) * KK + lane] = b_lam[c];
             s_epoch[lane] += 1;
         }
         if (last) {  // the prior is not needed again in this launch: its LDS column carries the
                      // belief (eta, lam) of the last sweep to the coalesced write-back
 #pragma unroll
-            for (int c = 0; c < 4; c++) s_prior[c * K + lane] = b_eta[c];
+            for (int c = 0; c < 4; c++) s_prior[c * KK + lane] = b_eta[c];
 #pragma unroll
-            for (int c = 0; c < 16; c++) s_prior[(4 + c) * K + lane] = b_lam[c];
+            for (int c = 0; c < 16; c++) s_prior[(4 + c) * KK + lane] = b_lam[c];
         }
+    };
+    // Internal-sweep sums, one lane per (variable, row): lane (col, r) accumulates eta[r] and lam[r][0..3]
+    // in inbox order — each element sees exactly the additions of the per-variable form.  All 128
+    // threads take part (the DYN wave has nothing else to do in the variable phase).
+    auto variable_sum_rows = [&](bool last) {
+        for (int t = tid; t < 4 * nK; t += SWEEP_BLOCK) {
+            const int col = t >> 2, rr = t & 3;
+            const int sub = col / K, i = col - sub * K;
+            if (w.idle[r0 + sub] != 0) continue;
+            const int eo = sub * E;
+            const int es[4] = {(i >= 1) ? eo + (K - 1) + (i - 1) : ZCOL, (i <= K - 2) ? eo + i : ZCOL,
+                               (i >= 1 && i <= K - 2) ? eo + n_dyn + (i - 1) : ZCOL,
+                               (i >= 1 && i <= K - 2) ? eo + n_dyn + (K - 2) + (i - 1) : ZCOL};
+            double acc[5];  // eta[rr], lam[rr][0..3]
+            acc[0] = s_prior[rr * KK + col];
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[1 + c] = s_prior[(4 + rr * 4 + c) * KK + col];
+            const int x0 = w.ir_var_ptr[v0 + col], xm = w.ir_var_mid[v0 + col], x1 = w.ir_var_ptr[v0 + col + 1];
+            auto ir_rows = [&](int e_from, int e_to) {
+                for (int e = e_from; e < e_to; e++) {
+                    if (STAGE_IR) {
+                        const double *m = s_ir + (e - ie0) * IR_STRIDE;
+                        acc[0] += m[rr];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) acc[1 + c] += m[4 + rr * 4 + c];
+                    } else {
+                        acc[0] += w.ir_fv_eta[(size_t)rr * w.NI + e];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) acc[1 + c] += w.ir_fv_lam[(size_t)(rr * 4 + c) * w.NI + e];
+                    }
+                }
+            };
+            ir_rows(x0, xm);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                acc[0] += s_fv[rr * EE + es[q]];
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[1 + c] += s_fv[(4 + rr * 4 + c) * EE + es[q]];
+            }
+            ir_rows(xm, x1);
+            s_snap[rr * KK + col] = acc[0];
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_snap[(4 + rr * 4 + c) * KK + col] = acc[1 + c];
+            if (rr == 0) s_epoch[col] += 1;
+            if (last) {
+                s_prior[rr * KK + col] = acc[0];
+#pragma unroll
+                for (int c = 0; c < 4; c++) s_prior[(4 + rr * 4 + c) * KK + col] = acc[1 + c];
+            }
+        }
+    };
+    auto variable_finish = [&](bool deliver_internal, const double (&b_eta)[4], const double (&b_lam)[16]) {
+        double mu[4], cov[16];
+#pragma unroll
+        for (int c = 0; c < 4; c++) mu[c] = s_mu[c * KK + lane];
+        int valid = s_valid[lane];
+        if (belief_update(b_eta, b_lam, mu, cov, valid)) {  // covariance (and maybe mean) changed
+#pragma unroll
+            for (int c = 0; c < 16; c++) s_cov[c * KK + lane] = cov[c];
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_mu[c * KK + lane] = mu[c];
+            s_valid[lane] = valid;
+        }
+        if (deliver_internal) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_snap[(20 + c) * KK + lane] = mu[c];
+        }
+    };
+    // finish of an internal sweep whose sums are in the snapshot columns (they ARE the responses)
+    auto variable_finish_from_snapshot = [&]() {
+        double b_eta[4], b_lam[16];
+#pragma unroll
+        for (int c = 0; c < 4; c++) b_eta[c] = s_snap[c * KK + lane];
+#pragma unroll
+        for (int c = 0; c < 16; c++) b_lam[c] = s_snap[(4 + c) * KK + lane];
+        variable_finish(true, b_eta, b_lam);
     };
 
     // ======================= external variable sweep ==========================================
     if (ext_mask & PH_EXT_VARIABLE) {
-        if (radio) {
-            if (is_var) variable_sweep(false, !has_int_var);
-            __syncthreads();
-            if (ir_on) {
-                // responses to the foreign factors attached to our variables, routed to their inbox
-                // (robot.rs:1842-1858): only the mean of that inbox entry is ever used (it sets the
-                // linearisation point; eta / lam of the target side never reach the kept message)
-                for (int j = tid; j < ne; j += SWEEP_BLOCK) {
-                    const int e = ie0 + j;
-                    const int A = w.ir_src_robot[e];
-                    if (!(w.antenna[A] != 0 && w.idle[A] == 0)) continue;  // A cannot receive
-                    const int i = w.ir_dst_var[e] - v0;
+        if (is_var && radio_v) {
+            double b_eta[4], b_lam[16];
+            variable_sum(false, !has_int_var, b_eta, b_lam);
+            variable_finish(false, b_eta, b_lam);
+        }
+        __syncthreads();
+        if (ir_on) {
+            // responses to the foreign factors attached to our variables, routed to their inbox
+            // (robot.rs:1842-1858): only the mean of that inbox entry is ever used (it sets the
+            // linearisation point; eta / lam of the target side never reach the kept message)
+            for (int j = tid; j < ne; j += SWEEP_BLOCK) {
+                const int e = ie0 + j;
+                const int col = w.ir_dst_var[e] - v0;
+                const int B = r0 + col / K;
+                if (!(w.antenna[B] != 0 && w.idle[B] == 0)) continue;  // B did not run its sweep
+                const int A = w.ir_src_robot[e];
+                if (!(w.antenna[A] != 0 && w.idle[A] == 0)) continue;  // A cannot receive
 #pragma unroll
-                    for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = s_mu[c * K + i] - 0.0;
-                }
+                for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = s_mu[c * KK + col] - 0.0;
             }
         }
         __syncthreads();
     }
 
     // ======================= internal iterations ==============================================
-    if (!idle) {
+    {
         const SdfView sdf = make_sdf_view(w.sdf, w.sdf_w, w.sdf_h, w.world_w, w.world_h);
+#ifdef MGX_STAMPS
+        unsigned long long c_f = 0, c_fb = 0, c_v = 0, c_vb = 0;
+#endif
+        STAMP(t_loop0);
+#ifdef MGX_STAMPS
+        const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        bool pending = false;  // this variable lane's last internal sums still await their finish
         for (int it = 0; it < n_int; it++) {
+            STAMP(t0);
             if (int_mask & PH_INT_FACTOR) {
                 // The two messages of one dynamic factor read each other's previous value; both lanes
                 // sit in the SAME wave, whose LDS reads all issue before its LDS writes, so no barrier
                 // is needed between reading the old and writing the new messages.
-                if (is_dyn && (w.enable & 1u)) {
+                if (is_dyn && !idle_d && (w.enable & 1u)) {
                     double me[4], ml[16], oe[4], ol[16];
                     const int o = dyn_other_var, oe_ix = dyn_other_edge;
                     if (s_epoch[o] > 0) {  // other variable has answered: belief - our last message
 #pragma unroll
-                        for (int c = 0; c < 4; c++) me[c] = s_snap[c * K + o] - s_fv[c * E + oe_ix];
+                        for (int c = 0; c < 4; c++) me[c] = s_snap[c * KK + o] - s_fv[c * EE + oe_ix];
 #pragma unroll
-                        for (int c = 0; c < 16; c++) ml[c] = s_snap[(4 + c) * K + o] - s_fv[(4 + c) * E + oe_ix];
+                        for (int c = 0; c < 16; c++) ml[c] = s_snap[(4 + c) * KK + o] - s_fv[(4 + c) * EE + oe_ix];
                     } else {
 #pragma unroll
                         for (int c = 0; c < 4; c++) me[c] = 0.0;
@@ -336,15 +463,21 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                         for (int c = 0; c < 16; c++) ol[c] = 0.0;
                     }
 #pragma unroll
-                    for (int c = 0; c < 4; c++) s_fv[c * E + lane] = oe[c];
+                    for (int c = 0; c < 4; c++) s_fv[c * EE + dyn_edge] = oe[c];
 #pragma unroll
-                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * E + lane] = ol[c];
+                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * EE + dyn_edge] = ol[c];
                 }
-                if (is_obs && (w.enable & 4u)) {
+                // UV wave: first the belief of the previous sweep (mean, covariance) that the unary
+                // factors linearise at — same wave, so its LDS writes precede their LDS reads
+                if (pending) {
+                    variable_finish_from_snapshot();
+                    pending = false;
+                }
+                if (is_obs && !idle_u && (w.enable & 4u)) {
                     double x0[4], oe[4], ol[16];
                     const bool pres = s_epoch[uvar] > 0;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) x0[c] = pres ? s_snap[(20 + c) * K + uvar] : 0.0;
+                    for (int c = 0; c < 4; c++) x0[c] = pres ? s_snap[(20 + c) * KK + uvar] : 0.0;
                     long long idx[4];
                     obstacle_taps(sdf, x0[0], x0[1], w.obs_delta, idx);
                     double h[4];
@@ -352,15 +485,15 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     for (int q = 0; q < 4; q++) h[q] = (idx[q] >= 0) ? sdf_value(w.sdf[idx[q]]) : 0.0;
                     obstacle_message(h, w.obs_delta, w.inv_s2_obs, x0, oe, ol);
 #pragma unroll
-                    for (int c = 0; c < 4; c++) s_fv[c * E + uedge] = oe[c];
+                    for (int c = 0; c < 4; c++) s_fv[c * EE + uedge] = oe[c];
 #pragma unroll
-                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * E + uedge] = ol[c];
+                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * EE + uedge] = ol[c];
                 }
-                if (is_trk && (w.enable & 8u) && itf >= 10) {  // factorgraph.rs:701
+                if (is_trk && !idle_u && (w.enable & 8u) && itf >= 10) {  // factorgraph.rs:701
                     double x0[4], oe[4], ol[16];
 #pragma unroll
-                    for (int c = 0; c < 4; c++) x0[c] = s_snap[(20 + c) * K + uvar];
-                    const int p0 = w.path_ptr[r], np = w.path_ptr[r + 1] - p0;
+                    for (int c = 0; c < 4; c++) x0[c] = s_snap[(20 + c) * KK + uvar];
+                    const int p0 = w.path_ptr[r0 + su], np = w.path_ptr[r0 + su + 1] - p0;
                     if (!tracking_message(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, trk_rec,
                                           trk_lp, trk_lv, oe, ol)) {
 #pragma unroll
@@ -369,53 +502,86 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                         for (int c = 0; c < 16; c++) ol[c] = 0.0;
                     }
 #pragma unroll
-                    for (int c = 0; c < 4; c++) s_fv[c * E + uedge] = oe[c];
+                    for (int c = 0; c < 4; c++) s_fv[c * EE + uedge] = oe[c];
 #pragma unroll
-                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * E + uedge] = ol[c];
+                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * EE + uedge] = ol[c];
                 }
-                itf += 1;
+                if (!my_idle) itf += 1;
+                STAMP(t1);
                 __syncthreads();
+                STAMP(t2);
+                STAMP_ADD(c_f, t0, t1);
+                STAMP_ADD(c_fb, t1, t2);
             }
+            STAMP(t3);
             if (int_mask & PH_INT_VARIABLE) {
-                if (is_var) variable_sweep(true, it == n_int - 1);
+                variable_sum_rows(it == n_int - 1);
+                if (is_var && !idle_v) pending = true;
+                STAMP(t4);
                 __syncthreads();
+                STAMP(t5);
+                STAMP_ADD(c_v, t3, t4);
+                STAMP_ADD(c_vb, t4, t5);
             }
         }
+        if (pending) variable_finish_from_snapshot();
+        __syncthreads();
+#ifdef MGX_STAMPS
+        if (w.dbg && lane == 0) {  // per wave: cycles in factor phase, its barrier, variable phase, its barrier
+            unsigned long long *d = w.dbg + ((size_t)blockIdx.x * 2 + role) * 8;
+            d[0] = c_f; d[1] = c_fb; d[2] = c_v; d[3] = c_vb; d[4] = __builtin_readcyclecounter() - t_loop0;
+            d[5] = __builtin_amdgcn_s_memrealtime() - rt0;  // 100 MHz ticks over the same span
+            d[6] = t_staged - t_k0;
+            d[7] = t_loop0 - t_staged;
+        }
+#endif
     }
 
     // ---- write back (coalesced) ------------------------------------------------------------------
-    for (int t = tid; t < 20 * E; t += SWEEP_BLOCK) {
-        const int c = t / E, e = t - c * E;
+    for (int t = tid; t < 20 * nE; t += SWEEP_BLOCK) {
+        const int c = t / nE, e = t - c * nE;
         if (c < 4)
-            w.fv_eta[(size_t)c * w.EI + eb + e] = s_fv[t];
+            w.fv_eta[(size_t)c * w.EI + eb + e] = s_fv[c * EE + e];
         else
-            w.fv_lam[(size_t)(c - 4) * w.EI + eb + e] = s_fv[t];
+            w.fv_lam[(size_t)(c - 4) * w.EI + eb + e] = s_fv[c * EE + e];
     }
     if (snap_out >= 0) {
         double *dst = w.snap[snap_out] + (size_t)v0 * SNAP_W;
-        for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) dst[t] = s_snap[(t % SNAP_W) * K + (t / SNAP_W)];
+        for (int t = tid; t < SNAP_W * nK; t += SWEEP_BLOCK) dst[t] = s_snap[(t % SNAP_W) * KK + (t / SNAP_W)];
+        for (int t = tid; t < nK; t += SWEEP_BLOCK) w.snap_epoch[snap_out][v0 + t] = s_epoch[t];
     }
-    if (any_var_sweep) {  // beliefs: s_prior columns now hold (eta, lam) of the last sweep
-        for (int t = tid; t < 20 * K; t += SWEEP_BLOCK) {
-            const int c = t / K, i = t - c * K;
-            if (c < 4)
-                w.bel_eta[(size_t)c * w.V + v0 + i] = s_prior[t];
-            else
-                w.bel_lam[(size_t)(c - 4) * w.V + v0 + i] = s_prior[t];
-        }
-        for (int t = tid; t < 16 * K; t += SWEEP_BLOCK) w.bel_cov[(size_t)(t / K) * w.V + v0 + (t % K)] = s_cov[t];
-        for (int t = tid; t < 4 * K; t += SWEEP_BLOCK) w.bel_mu[(size_t)(t / K) * w.V + v0 + (t % K)] = s_mu[t];
-        for (int t = tid; t < K; t += SWEEP_BLOCK) w.bel_valid[v0 + t] = s_valid[t];
+    // beliefs: the s_prior columns of robots that ran a variable sweep now hold (eta, lam) of their last sweep
+    const bool any_int_var = (int_mask & PH_INT_VARIABLE) && n_int > 0;
+    const bool any_ext_var = (ext_mask & PH_EXT_VARIABLE) != 0;
+    auto swept = [&](int col) {
+        const int rr = r0 + col / K;
+        const bool idl = w.idle[rr] != 0;
+        return (any_int_var && !idl) || (any_ext_var && w.antenna[rr] != 0 && !idl);
+    };
+    for (int t = tid; t < 20 * nK; t += SWEEP_BLOCK) {
+        const int c = t / nK, i = t - c * nK;
+        if (!swept(i)) continue;
+        if (c < 4)
+            w.bel_eta[(size_t)c * w.V + v0 + i] = s_prior[c * KK + i];
+        else
+            w.bel_lam[(size_t)(c - 4) * w.V + v0 + i] = s_prior[c * KK + i];
     }
-    if (snap_out >= 0)
-        for (int t = tid; t < K; t += SWEEP_BLOCK) w.snap_epoch[snap_out][v0 + t] = s_epoch[t];
+    for (int t = tid; t < 16 * nK; t += SWEEP_BLOCK)
+        if (swept(t % nK)) w.bel_cov[(size_t)(t / nK) * w.V + v0 + (t % nK)] = s_cov[(t / nK) * KK + (t % nK)];
+    for (int t = tid; t < 4 * nK; t += SWEEP_BLOCK)
+        if (swept(t % nK)) w.bel_mu[(size_t)(t / nK) * w.V + v0 + (t % nK)] = s_mu[(t / nK) * KK + (t % nK)];
+    for (int t = tid; t < nK; t += SWEEP_BLOCK)
+        if (swept(t)) w.bel_valid[v0 + t] = s_valid[t];
     if (is_trk) {
         w.trk_record[trk_item] = trk_rec;
         w.trk_last_pos[trk_item] = trk_lp[0];
         w.trk_last_pos[(size_t)w.NT + trk_item] = trk_lp[1];
         w.trk_last_val[trk_item] = trk_lv;
     }
-    if (tid == 0) w.iter_factor[r] = itf;
+    if (is_dyn && ld == 0) w.iter_factor[r0 + sd] = itf;  // one lane per robot carries its counter out
+#ifdef MGX_STAMPS
+    if (w.dbg && lane == 0) w.dbg[((size_t)blockIdx.x * 2 + role) * 8 + 7] = __builtin_readcyclecounter() - t_k0;  // whole kernel
+#endif
 }
 
 // VariableNode::change_prior + routing (variable.rs:203-230, factorgraph.rs:494-528,
@@ -490,35 +656,38 @@ __global__ void k_halo_unpack(DevWorld w, int n, const int32_t *ghosts, const do
 }
 
 // ---- launch wrappers (called from mgx_world.hip) -------------------------------------------------
-size_t sweep_lds_bytes(int K, int ir_edges) {
+size_t sweep_lds_bytes(int K, int rpb, int ir_edges) {
     const int E = 4 * K - 6;
-    return sizeof(double) * (size_t)((SNAP_W + 20 + 16 + 4) * K + 20 * E + IR_STRIDE * ir_edges) + 8 * (size_t)K;
+    return sizeof(double) * (size_t)(rpb * ((SNAP_W + 20 + 16 + 4) * K + 20 * E) + 20 + IR_STRIDE * ir_edges) + 8 * (size_t)(rpb * K);
 }
 bool sweep_supports(int K) { return K >= 3 && 2 * (K - 1) <= 64; }
+int sweep_rpb(int K) { return rpb_for(K); }
 
-template <int KT>
+template <int KT, int RPB>
 static void launch_k(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, uint32_t int_mask, int n_int, int snap_out,
                      hipStream_t stream) {
-    // 4 workgroups per CU need <= 40 KB each; beyond 48 KB fall back to reading the messages from L2
-    const size_t staged = sweep_lds_bytes(w.K, w.ir_max_edges);
-    if (staged <= 48 * 1024)
-        hipLaunchKernelGGL((k_robot_sweep<KT, true>), dim3(n_robots), dim3(SWEEP_BLOCK), staged, stream, w, robot0, ext_mask,
-                           int_mask, n_int, snap_out);
+    const int blocks = (n_robots + RPB - 1) / RPB;
+    // LDS: staging the inter-robot messages needs IR_STRIDE f64 per edge of the workgroup's robots;
+    // beyond 64 KB fall back to reading them from L2 in every variable sweep
+    const size_t staged = sweep_lds_bytes(w.K, RPB, RPB * w.ir_max_edges);
+    if (staged <= 64 * 1024)
+        hipLaunchKernelGGL((k_robot_sweep<KT, RPB, true>), dim3(blocks), dim3(SWEEP_BLOCK), staged, stream, w, robot0,
+                           robot0 + n_robots, ext_mask, int_mask, n_int, snap_out);
     else
-        hipLaunchKernelGGL((k_robot_sweep<KT, false>), dim3(n_robots), dim3(SWEEP_BLOCK), sweep_lds_bytes(w.K, 0), stream, w,
-                           robot0, ext_mask, int_mask, n_int, snap_out);
+        hipLaunchKernelGGL((k_robot_sweep<KT, RPB, false>), dim3(blocks), dim3(SWEEP_BLOCK), sweep_lds_bytes(w.K, RPB, 0), stream, w,
+                           robot0, robot0 + n_robots, ext_mask, int_mask, n_int, snap_out);
 }
 
 hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, uint32_t int_mask, int n_int,
                               int snap_out, hipStream_t stream) {
     if (n_robots <= 0) return hipSuccess;
     switch (w.K) {  // horizon lengths of BASELINE.json / the reference scenarios get constant-K code
-    case 10: launch_k<10>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
-    case 12: launch_k<12>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
-    case 16: launch_k<16>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
-    case 21: launch_k<21>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
-    case 32: launch_k<32>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
-    default: launch_k<0>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
+    case 10: launch_k<10, rpb_for(10)>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
+    case 12: launch_k<12, rpb_for(12)>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
+    case 16: launch_k<16, rpb_for(16)>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
+    case 21: launch_k<21, rpb_for(21)>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
+    case 32: launch_k<32, rpb_for(32)>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
+    default: launch_k<0, 1>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
     }
     return hipGetLastError();
 }

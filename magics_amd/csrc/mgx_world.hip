@@ -23,7 +23,8 @@
 #include "mgx_dev.h"
 
 namespace mgx {
-size_t sweep_lds_bytes(int K, int ir_edges);
+size_t sweep_lds_bytes(int K, int rpb, int ir_edges);
+int sweep_rpb(int K);
 bool sweep_supports(int K);
 hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, uint32_t int_mask, int n_int,
                               int snap_out, hipStream_t stream);
@@ -145,6 +146,7 @@ struct mgx_world {
     DevBuf<int32_t> tmp_i32;
     DevBuf<uint32_t> tmp_u32;
     DevBuf<double> tmp_f64;
+    DevBuf<unsigned long long> dbg;  // diagnostic builds only
     // halo plan: local robots whose snapshots are sent / ghost robots that receive, in buffer order
     std::vector<int32_t> halo_send, halo_recv;
     DevBuf<int32_t> halo_send_dev, halo_recv_dev;
@@ -297,7 +299,7 @@ static int commit(mgx_world *w) {
     int rc = pull(w);
     if (rc != MGX_OK) return rc;
     const int K = w->K, E = 4 * K - 6;
-    if (!sweep_supports(K) || sweep_lds_bytes(K, 0) > 60 * 1024) return fail(MGX_ERR_INVALID, "K = %d not supported (3 <= K <= 33)", K);
+    if (!sweep_supports(K) || sweep_lds_bytes(K, sweep_rpb(K), 0) > 60 * 1024) return fail(MGX_ERR_INVALID, "K = %d not supported (3 <= K <= 33)", K);
 
     // device robot order: locals (id order), then ghosts
     w->robot_of.clear();
@@ -488,6 +490,16 @@ static int commit(mgx_world *w) {
     d.inv_s2_trk = 1.0 / (w->p.sigma_tracking * w->p.sigma_tracking);
     d.trk_pad = w->p.tracking_switch_padding;
     d.trk_attr = w->p.tracking_attraction_distance;
+#ifdef MGX_STAMPS
+    {
+        std::vector<unsigned long long> z((size_t)(R_local + 4) * 16, 0ull);
+        HIP_TRY(w->dbg.upload(z, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        d.dbg = w->dbg.p;
+    }
+#else
+    d.dbg = nullptr;
+#endif
     w->dirty = false;
     w->dev_valid = true;
     w->halo_dirty = true;
@@ -818,5 +830,17 @@ int mgx_halo_unpack(mgx_world *w, const void *dev_buf) {
     HIP_TRY(launch_halo_unpack(w->d, (int)w->halo_recv.size(), w->halo_recv_dev.p, (const double *)dev_buf, w->stream));
     return MGX_OK;
 }
+
+#ifdef MGX_STAMPS
+// diagnostic build only: copy the per-wave phase cycle sums to the host
+int mgx_debug_read_stamps(mgx_world *w, unsigned long long *out, uint32_t n) {
+    if (!w || !out) return fail(MGX_ERR_INVALID, "null argument");
+    std::vector<unsigned long long> h;
+    HIP_TRY(w->dbg.download(h, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    for (uint32_t i = 0; i < n && i < h.size(); i++) out[i] = h[i];
+    return (int)h.size();
+}
+#endif
 
 }  // extern "C"

@@ -129,7 +129,7 @@ def lib(fma=None):
         fma = os.environ.get("MGX_FMA", "0") == "1"
     key = bool(fma)
     if key not in _libs:
-        path = FMA_LIB_PATH if key else LIB_PATH
+        path = FMA_LIB_PATH if key else os.environ.get("MGX_LIB", LIB_PATH)  # MGX_LIB: experiments only
         if not os.path.exists(path):
             raise MgxError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")

@@ -1,0 +1,43 @@
+"""Diagnostic: builds libmgx_stamps.so (-DMGX_STAMPS, never shipped) and prints where the sweep
+kernel's waves spend their cycles per internal iteration (factor phase, barrier, variable phase,
+barrier).  Run on the GPU box:  python tools/stamps.py [--rpb-note]"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from magics_amd import hostlib, scenarios as S  # noqa: E402
+from magics_amd.world import World  # noqa: E402
+
+out = os.path.join(ROOT, "gpurun_out", "libmgx_stamps.so")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+srcs = [os.path.join(ROOT, "magics_amd", "csrc", f) for f in ("mgx_kernels.hip", "mgx_world.hip", "mgx_host.cpp")]
+subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                "-DMGX_STAMPS", "-o", out] + srcs, check=True)
+hostlib.LIB_PATH = out
+hostlib._libs.clear()
+n_iter = 10
+for name, kw in (("config2", dict(interrobot=False)), ("config3", dict(interrobot=True))):
+    sc = S.grid_scenario(1000, 16, **kw)
+    w = World(sc["params"])
+    S.populate(w, sc)
+    steps = [1] * n_iter if name == "config2" else sc["steps"]
+    for _ in range(3):
+        w.iterate(steps)
+    w.synchronize()
+    L = hostlib.lib()
+    L.mgx_debug_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32]
+    buf = (C.c_ulonglong * (1004 * 16))()
+    n = L.mgx_debug_read_stamps(w._w, buf, len(buf))
+    a = np.array(buf[:n], dtype=np.float64).reshape(-1, 2, 8)
+    a = a[a[:, 0, 4] > 0]
+    it = n_iter if name == "config2" else 1
+    for role, rn in ((0, "DYN"), (1, "UV ")):
+        f, fb, v, vb, tot = (a[:, role, k].mean() / it for k in range(5))
+        clk = a[:, role, 4].mean() / (a[:, role, 5].mean() / 100e6) / 1e9
+        print(f"{name} {rn}: staging {a[:, role, 6].mean():.0f} cycles, whole kernel {a[:, role, 7].mean():.0f} cycles, loop total {a[:, role, 4].mean():.0f}")
+        print(f"{name} {rn}: clock {clk:.2f} GHz; per iteration cycles  factor {f:8.0f}  barrier {fb:8.0f}  variable {v:8.0f}  barrier {vb:8.0f}  loop {tot:8.0f}   ({len(a)} workgroups)")
