@@ -68,9 +68,12 @@ MGX_HD bool any_inf16(const double (&a)[16]) {
 // cov is replaced, valid recomputed, and mu replaced iff the covariance is finite.
 MGX_HD bool belief_update(const double (&eta)[4], const double (&lam)[16], double (&mu)[4], double (&cov)[16],
                           int &valid) {
+    // variable.rs:276 tests `x - 1e-6 > 0.0`; for every double x that is the same predicate as
+    // `x > 1e-6` (the subtraction is exact within a factor 2 of 1e-6 — Sterbenz — and cannot change
+    // sign outside it; NaN fails both), so the subtraction is not performed
     bool not_zero = false;
 #pragma unroll
-    for (int i = 0; i < 16; i++) not_zero = not_zero || (lam[i] - 1e-6 > 0.0);
+    for (int i = 0; i < 16; i++) not_zero = not_zero || (lam[i] > 1e-6);
     if (!not_zero) return false;
     if (!inv4(lam, cov)) return false;
     bool fin = true;

@@ -17,22 +17,41 @@ namespace mgx {
 
 constexpr int SNAP_W = 24;  // eta(4) lam(16) mu(4)
 
+// Blob of one robot (f64 words; K variables, E = 4K-6 internal edges, component-major rows):
+//   prior  [20][K]    prior eta(4), lam(16)                          read-only for the sweep kernel
+//   bel    [20][K]    belief eta, lam of the last variable sweep     output
+//   cov    [16][K]    belief covariance                              in/out   \
+//   mu     [4][K]     belief mean                                    in/out    | one contiguous
+//   fv     [20][E+1]  factor -> variable messages (eta 4, lam 16);   in/out    | in/out region
+//                     column E is all zeros (absent edges)                     |
+//   valid  [K] int32  (occupies K f64 slots)                         in/out   /
+struct BlobLayout {
+    int K, E1;  // E1 = E + 1
+    __host__ __device__ constexpr BlobLayout(int k) : K(k), E1(4 * k - 6 + 1) {}
+    __host__ __device__ constexpr int prior() const { return 0; }
+    __host__ __device__ constexpr int bel() const { return 20 * K; }
+    __host__ __device__ constexpr int cov() const { return 40 * K; }
+    __host__ __device__ constexpr int mu() const { return 56 * K; }
+    __host__ __device__ constexpr int fv() const { return 60 * K; }
+    __host__ __device__ constexpr int valid() const { return 60 * K + 20 * E1; }
+    __host__ __device__ constexpr int inout_words() const { return 16 * K + 4 * K + 20 * E1 + K; }  // cov..valid
+    __host__ __device__ constexpr int words() const { return 61 * K + 20 * E1; }
+};
+
 struct DevWorld {
     int R_local, R_total, K, E;
     int V, EI, ND, NT, NI;
     int cur;  // snapshot buffer read by this launch; the other one is written
     uint32_t enable;
 
-    // variables
-    double *prior_eta, *prior_lam;
-    double *bel_eta, *bel_lam, *bel_mu, *bel_cov;
-    int32_t *bel_valid;
-    double *snap[2];          // [V][24] variable -> own-factor snapshot (eta, lam, mu), one 192-B record per
-                              // variable: other robots' workgroups gather whole records
+    // Per-robot private state: one contiguous blob per robot, laid out exactly like the workgroup's
+    // LDS image so that staging / write-back are straight wide copies (see blob_layout below).
+    double *blob;
+    int BS;  // blob stride (f64 words per robot)
+    // Snapshot exchange buffers — the only state OTHER robots' workgroups read: one 192-byte record
+    // (eta, lam, mu) per variable, double buffered (a launch reads `cur`, writes `1 - cur`).
+    double *snap[2];          // [V][24]
     uint32_t *snap_epoch[2];  // [V] number of deliveries (internal sweeps + prior changes)
-
-    // internal factor -> variable messages
-    double *fv_eta, *fv_lam;  // [4][EI], [16][EI]
     double *dyn_m;            // [16][ND] compact J^T Q J of each dynamic factor
     // tracking factor state
     int32_t *trk_record;      // [NT]

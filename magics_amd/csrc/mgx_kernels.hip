@@ -1,27 +1,29 @@
 // mgx_kernels.hip — gfx950 kernels of the GBP engine.
 //
-// k_robot_sweep: ONE 128-THREAD WORKGROUP PER GROUP OF RPB ROBOTS, TWO ROLE-SPECIALISED WAVES.
-// The robots' whole factor graphs (variable->factor snapshots, priors, factor->variable messages,
-// the inter-robot messages attached to their variables) are staged in LDS once per launch and stay
-// there for every phase the launch runs: an optional external phase
+// k_robot_sweep: ONE 128-THREAD WORKGROUP PER ROBOT, TWO ROLE-SPECIALISED WAVES.
+// The robot's whole factor graph (its private state blob: priors, beliefs, factor->variable
+// messages; its snapshot records; the inter-robot messages attached to its variables) is staged in
+// LDS once per launch by straight 16-byte copies and stays there for every phase the launch runs: an optional external phase
 // (external_factor_iteration + routing + external_variable_iteration,
 // factorgraph.rs:719-760,794-826, robot.rs:1803-1859) followed by `n_int` internal iterations
 // (internal_factor_iteration + internal_variable_iteration, factorgraph.rs:688-714,762-790).
 //
-//   wave 0 (DYN)  factor phase: one lane per dynamic-factor MESSAGE (RPB * 2(K-1) lanes), one 4x4
-//                 Schur complement each
-//   wave 1 (UV)   factor phase: one lane per obstacle / tracking factor;
-//                 variable phase: one lane per variable (inbox sum, 4x4 inverse, belief)
-//   both waves    external factor sweep: one lane per incoming inter-robot edge ("pull" form:
-//                 every factor F_AB is evaluated by the workgroup of its only consumer B)
+//   wave 0 (DYN)  factor phase: one lane per dynamic-factor MESSAGE (2(K-1) lanes), one 4x4 Schur
+//                 complement each
+//   wave 1 (UV)   factor phase: mean / covariance of the previous sweep (one lane per variable: 4x4
+//                 inverse), then one lane per obstacle / tracking factor
+//   both waves    variable phase: inbox sums, one lane per (variable, row);
+//                 external factor sweep: one lane per incoming inter-robot edge ("pull" form: every
+//                 factor F_AB is evaluated by the workgroup of its only consumer B)
 //
-// RPB (robots per workgroup) packs as many robots as fit the 64 lanes of each role (2 at K = 16):
-// the per-message instruction streams are long dependent f64 chains, so a wave costs the same
-// whether 30 or 60 of its lanes are live.  All per-variable state lives in LDS, not registers, so
-// each wave stays within 256 VGPRs.  Each phase is a Jacobi sweep separated by workgroup barriers
-// only.  Robots couple only through the inter-robot edges, which gather the OTHER robot's 192-byte
-// snapshot records from buffer `cur` in HBM while this launch writes buffer `1 - cur`: no
-// inter-workgroup synchronisation inside a launch.
+// A dynamic factor never reads a mean, so the expensive half of a variable update (inverse, mean) of
+// sweep t runs in the UV wave NEXT TO the dynamic messages of sweep t+1 in the DYN wave.  One wave
+// alone issues an f64 VALU instruction only every ~8 cycles, so what bounds an iteration is the
+// longest dependent instruction stream per robot, not lane count: the design shortens that stream.
+// All per-variable state lives in LDS, not registers, so each wave stays within 256 VGPRs.  Each
+// phase is a Jacobi sweep separated by workgroup barriers only.  Robots couple only through the
+// inter-robot edges, which gather the OTHER robot's 192-byte snapshot records from buffer `cur` in
+// HBM while this launch writes buffer `1 - cur`: no inter-workgroup synchronisation inside a launch.
 //
 // Arithmetic: gbp_math.h, compiled with -ffp-contract=off so that results are bit-identical to
 // the scalar f64 reference semantics.
@@ -70,106 +72,80 @@ extern __shared__ double lds[];
 // LDS access is base + immediate offset, which keeps the address arithmetic out of the VGPR budget.
 constexpr int IR_STRIDE = 21;  // one staged inter-robot message: 20 f64 + 1 pad (bank spread)
 
-// robots per workgroup: every role must fit one 64-lane wave
-#ifndef MGX_RPB_MAX
-#define MGX_RPB_MAX 1
-#endif
-constexpr int rpb_for(int K) {
-    int n = 64 / (2 * (K - 1));
-    return n < 1 ? 1 : (n > MGX_RPB_MAX ? MGX_RPB_MAX : n);
+// straight copies between a robot's blob in HBM and its LDS image, 16 bytes per lane
+__device__ __forceinline__ void copy_words(double *dst, const double *src, int n, int tid) {
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    double2 *d2 = reinterpret_cast<double2 *>(dst);
+    for (int t = tid; t < (n >> 1); t += SWEEP_BLOCK) d2[t] = s2[t];
+    if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
 }
 
-template <int KT, int RPB, bool STAGE_IR>
-__global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int robot0, int robot_end, uint32_t ext_mask,
-                                                             uint32_t int_mask, int n_int, int snap_out) {
+template <int KT, bool STAGE_IR>
+__global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int robot0, uint32_t ext_mask, uint32_t int_mask,
+                                                             int n_int, int snap_out) {
     STAMP(t_k0);
-    const int r0 = robot0 + blockIdx.x * RPB;                       // first robot of this workgroup
-    const int n_sub = (robot_end - r0) < RPB ? (robot_end - r0) : RPB;  // robots actually present
+    const int r = robot0 + blockIdx.x;
     const int tid = threadIdx.x;
     const int role = tid >> 6, lane = tid & 63;
-    const int K = KT > 0 ? KT : w.K, E = 4 * K - 6;
-    const int KK = RPB * K, EE = RPB * E + 1;                      // LDS column counts (+1: an all-zero
-                                                                   // message column for absent edges)
-    const int nK = n_sub * K, nE = n_sub * E;                      // live columns
-    const int ZCOL = EE - 1;
-    double *s_snap = lds;                              // [24][KK] variable -> own-factor snapshots
-    double *s_prior = s_snap + SNAP_W * KK;            // [20][KK] prior eta, lam
-    double *s_cov = s_prior + 20 * KK;                 // [16][KK] belief covariance
-    double *s_mu = s_cov + 16 * KK;                    // [4][KK]  belief mean
-    double *s_fv = s_mu + 4 * KK;                      // [20][EE] factor -> variable messages
-    uint32_t *s_epoch = (uint32_t *)(s_fv + 20 * EE);  // [KK] deliveries
-    int32_t *s_valid = (int32_t *)(s_epoch + KK);      // [KK]
-    double *s_ir = (double *)(s_valid + KK);           // [ne][IR_STRIDE] inter-robot messages (STAGE_IR)
+    const int K = KT > 0 ? KT : w.K, E = 4 * K - 6, E1 = E + 1;
+    const BlobLayout L(K);
+    const int ZCOL = E;  // all-zero message column (absent edges)
+    double *s_snap = lds;                                 // [24][K] variable -> own-factor snapshots
+    double *s_prior = s_snap + SNAP_W * K;                // [20][K] prior eta, lam (belief after the last sweep)
+    double *s_tmp = s_prior + 20 * K;                     // [20][K] scratch sums (external sweep)
+    double *s_io = s_tmp + 20 * K;                        // image of the blob's in/out region:
+    double *s_cov = s_io;                                 //   [16][K] belief covariance
+    double *s_mu = s_io + 16 * K;                         //   [4][K]  belief mean
+    double *s_fv = s_io + 20 * K;                         //   [20][E1] factor -> variable messages
+    int32_t *s_valid = (int32_t *)(s_io + 20 * K + 20 * E1);  // [K]
+    uint32_t *s_epoch = (uint32_t *)(s_io + L.inout_words() + (L.inout_words() & 1));  // [K] deliveries
+    int32_t *s_irp = (int32_t *)(s_epoch + ((K + 1) & ~1));  // [3][K+1] inbox ranges of foreign factors
+    double *s_ir = (double *)(s_irp + ((3 * (K + 1) + 1) & ~1));  // [ne][IR_STRIDE] inter-robot messages (STAGE_IR)
 
-    const int v0 = r0 * K, eb = r0 * E;
-    const int ie0 = w.ir_var_ptr[v0], ie1 = w.ir_var_ptr[v0 + nK], ne = ie1 - ie0;
+    double *blob = w.blob + (size_t)r * w.BS;
+    const int v0 = r * K;
+    const int ie0 = w.ir_var_ptr[v0], ie1 = w.ir_var_ptr[v0 + K], ne = ie1 - ie0;
     const bool ir_on = (w.enable & 2u) != 0;
-    const int n_dyn = 2 * (K - 1), n_una = 2 * (K - 2);
+    const int n_dyn = 2 * (K - 1);
+    const bool idle = w.idle[r] != 0;
+    const bool radio = (w.antenna[r] != 0) && !idle;
 
-    // ---- stage the robots in LDS (all 128 threads, coalesced; consecutive robots are contiguous) --
+    // ---- stage the robot in LDS (all 128 threads) -----------------------------------------------
+    copy_words(s_prior, blob + L.prior(), 20 * K, tid);
+    copy_words(s_io, blob + L.cov(), L.inout_words(), tid);
     {
         const double *src = w.snap[w.cur] + (size_t)v0 * SNAP_W;
-        for (int t = tid; t < SNAP_W * nK; t += SWEEP_BLOCK) s_snap[(t % SNAP_W) * KK + (t / SNAP_W)] = src[t];
-        for (int t = tid; t < 20 * nE; t += SWEEP_BLOCK) {
-            const int c = t / nE, e = t - c * nE;
-            s_fv[c * EE + e] = (c < 4) ? w.fv_eta[(size_t)c * w.EI + eb + e] : w.fv_lam[(size_t)(c - 4) * w.EI + eb + e];
+        for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = src[t];
+        for (int t = tid; t < K; t += SWEEP_BLOCK) {
+            s_epoch[t] = w.snap_epoch[w.cur][v0 + t];
+            s_irp[t] = w.ir_var_ptr[v0 + t];
+            s_irp[(K + 1) + t] = w.ir_var_mid[v0 + t];
+            s_irp[2 * (K + 1) + t] = w.ir_var_ptr[v0 + t + 1];
         }
-        if (tid < 20) s_fv[tid * EE + ZCOL] = 0.0;
         if (STAGE_IR)
             for (int t = tid; t < 20 * ne; t += SWEEP_BLOCK) {
                 const int c = t / ne, j = t - c * ne;
                 s_ir[j * IR_STRIDE + c] = (c < 4) ? w.ir_fv_eta[(size_t)c * w.NI + ie0 + j] : w.ir_fv_lam[(size_t)(c - 4) * w.NI + ie0 + j];
             }
-        for (int t = tid; t < 20 * nK; t += SWEEP_BLOCK) {
-            const int c = t / nK, i = t - c * nK;
-            s_prior[c * KK + i] = (c < 4) ? w.prior_eta[(size_t)c * w.V + v0 + i] : w.prior_lam[(size_t)(c - 4) * w.V + v0 + i];
-        }
-        for (int t = tid; t < 16 * nK; t += SWEEP_BLOCK) s_cov[(t / nK) * KK + (t % nK)] = w.bel_cov[(size_t)(t / nK) * w.V + v0 + (t % nK)];
-        for (int t = tid; t < 4 * nK; t += SWEEP_BLOCK) s_mu[(t / nK) * KK + (t % nK)] = w.bel_mu[(size_t)(t / nK) * w.V + v0 + (t % nK)];
-        for (int t = tid; t < nK; t += SWEEP_BLOCK) {
-            s_epoch[t] = w.snap_epoch[w.cur][v0 + t];
-            s_valid[t] = w.bel_valid[v0 + t];
-        }
     }
+    int itf = w.iter_factor[r];  // iteration_count.factor (every lane applies the same increments)
 
-    // ---- this lane's robot in each of its roles ---------------------------------------------------
-    // DYN wave: lane -> (robot sd, message l); UV wave: unary lane -> (su, factor l), variable lane -> (sv, i)
-    const int sd = lane / n_dyn, ld = lane - sd * n_dyn;
-    const int su = lane / n_una, lu = lane - su * n_una;
-    const int sv = lane / K, iv = lane - sv * K;
-    const bool is_dyn = role == ROLE_DYN && lane < n_sub * n_dyn;
-    const bool is_una = role == ROLE_UV && lane < n_sub * n_una;
-    const bool is_obs = is_una && lu < K - 2;
-    const bool is_trk = is_una && lu >= K - 2;
-    const bool is_var = role == ROLE_UV && lane < nK;
-    // the robot whose flags / counters this lane follows (edge lanes look theirs up per edge)
-    const int my_sub = role == ROLE_DYN ? (is_dyn ? sd : 0) : (is_una ? su : (is_var ? sv : 0));
-    const bool idle_u = w.idle[r0 + (is_una ? su : 0)] != 0;      // unary-factor lane's robot
-    const bool idle_v = w.idle[r0 + (is_var ? sv : 0)] != 0;      // variable lane's robot
-    const bool idle_d = w.idle[r0 + (is_dyn ? sd : 0)] != 0;      // dynamic-message lane's robot
-    const bool radio_v = (w.antenna[r0 + (is_var ? sv : 0)] != 0) && !idle_v;
-    // iteration_count.factor of the robot this lane follows (every lane applies the same increments
-    // as its robot: one per internal factor sweep if not idle, one per external factor sweep if on air)
-    int itf = w.iter_factor[r0 + my_sub];
-    const bool my_idle = w.idle[r0 + my_sub] != 0;
-    const bool my_radio = (w.antenna[r0 + my_sub] != 0) && !my_idle;
+    // ---- roles ------------------------------------------------------------------------------------
+    const bool is_dyn = role == ROLE_DYN && lane < n_dyn;
+    const bool is_obs = role == ROLE_UV && lane < K - 2;
+    const bool is_trk = role == ROLE_UV && lane >= K - 2 && lane < 2 * (K - 2);
+    const bool is_var = role == ROLE_UV && lane < K;
+    // which variable sweep of this launch is the robot's last one (its belief goes out)
+    const bool has_int_var = (int_mask & PH_INT_VARIABLE) && n_int > 0 && !idle;
+    const bool any_sweep = has_int_var || ((ext_mask & PH_EXT_VARIABLE) && radio);
 
-    int ir_e0 = 0, ir_mid = 0, ir_e1 = 0;
-    if (is_var) {
-        ir_e0 = w.ir_var_ptr[v0 + lane];
-        ir_mid = w.ir_var_mid[v0 + lane];
-        ir_e1 = w.ir_var_ptr[v0 + lane + 1];
-    }
-    // which variable sweep of this launch is the last one for this lane's robot (its belief goes out)
-    const bool has_int_var = (int_mask & PH_INT_VARIABLE) && n_int > 0 && !idle_v;
-
-    // ---- DYN wave: constant potential blocks of this lane's message -------------------------------
+    // DYN wave: constant potential blocks of this lane's message
     double maa[4], mab[4], mba[4], mbb[4];
-    int dyn_other_var = 0, dyn_other_edge = 0, dyn_edge = 0;
+    int dyn_other_var = 0, dyn_other_edge = 0;
     if (is_dyn) {
-        const int f = ld % (K - 1), slot = ld / (K - 1);
+        const int f = lane % (K - 1), slot = lane / (K - 1);
         const int a2 = 2 * slot, b2 = 2 * (1 - slot);
-        const int it = (r0 + sd) * (K - 1) + f;
+        const int it = r * (K - 1) + f;
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -179,18 +155,16 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 mba[i * 2 + j] = w.dyn_m[(size_t)((b2 + i) * 4 + (a2 + j)) * w.ND + it];
                 mbb[i * 2 + j] = w.dyn_m[(size_t)((b2 + i) * 4 + (b2 + j)) * w.ND + it];
             }
-        dyn_other_var = sd * K + f + 1 - slot;
-        dyn_other_edge = sd * E + (1 - slot) * (K - 1) + f;
-        dyn_edge = sd * E + ld;
+        dyn_other_var = f + 1 - slot;
+        dyn_other_edge = (1 - slot) * (K - 1) + f;
     }
-
-    // ---- UV wave, factor phase: per robot obstacle lanes [0, K-2), tracking lanes [K-2, 2(K-2)) ----
-    const int uvar = su * K + (is_trk ? lu - (K - 2) : lu) + 1;     // LDS column of the factor's variable
-    const int uedge = su * E + n_dyn + lu;                          // its internal-edge column
+    // UV wave, factor phase: obstacle lanes [0, K-2), tracking lanes [K-2, 2(K-2))
+    const int uvar = (is_trk ? lane - (K - 2) : lane) + 1;  // variable of the unary factor
+    const int uedge = n_dyn + lane;                         // its internal-edge column
     int trk_rec = 0;
     float trk_lp[2] = {0.f, 0.f};
     double trk_lv = 0.0;
-    const int trk_item = (r0 + su) * (K - 2) + (lu - (K - 2));
+    const int trk_item = r * (K - 2) + (uvar - 1);
     if (is_trk) {
         trk_rec = w.trk_record[trk_item];
         trk_lp[0] = w.trk_last_pos[trk_item];
@@ -198,17 +172,16 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         trk_lv = w.trk_last_val[trk_item];
     }
     __syncthreads();
+    uint32_t my_epoch = (tid < 4 * K) ? s_epoch[tid >> 2] : 0u;  // deliveries of the variable this thread sums
     STAMP(t_staged);
 
     // ======================= external factor sweep (pull form) ================================
     // factorgraph.rs:745-754 keeps only the message to the other graph's variable, so F_AB is
     // evaluated here, at B, from A's snapshot record and B's last response mean.
     if (ext_mask & PH_EXT_FACTOR) {
-        if (ir_on) {
+        if (radio && ir_on) {
             for (int j = tid; j < ne; j += SWEEP_BLOCK) {
                 const int e = ie0 + j;
-                const int B = w.ir_dst_var[e] / K;  // target robot (device index)
-                if (!(w.antenna[B] != 0 && w.idle[B] == 0)) continue;  // B cannot receive
                 const int A = w.ir_src_robot[e];
                 if (!(w.antenna[A] != 0 && w.idle[A] == 0)) continue;  // A did not run its sweep
                 const int s = w.ir_src_var[e];
@@ -252,93 +225,42 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 }
             }
         }
-        if (my_radio) itf += 1;  // iteration_count.factor of the robot's own external sweep (factorgraph.rs:757)
+        if (radio) itf += 1;  // iteration_count.factor of the robot's own external sweep (factorgraph.rs:757)
         __syncthreads();
     }
 
-    // internal-edge columns of this lane's variable
-    const int eoff = sv * E;
-    // (absent edges read the all-zero column: x + 0.0 == x exactly, and a running sum that starts from
-    // the prior is never -0.0, so this equals skipping the entry as the reference's inbox does)
-    const int e_left = (iv >= 1) ? eoff + (K - 1) + (iv - 1) : ZCOL;   // dynamic factor i-1 -> slot 1
-    const int e_right = (iv <= K - 2) ? eoff + iv : ZCOL;               // dynamic factor i   -> slot 0
-    const int e_obs = (iv >= 1 && iv <= K - 2) ? eoff + n_dyn + (iv - 1) : ZCOL;
-    const int e_trk = (iv >= 1 && iv <= K - 2) ? eoff + n_dyn + (K - 2) + (iv - 1) : ZCOL;
-
-    auto ir_accumulate = [&](int e_from, int e_to, double (&eta)[4], double (&lam)[16]) {
-        for (int e = e_from; e < e_to; e++) {
-            if (STAGE_IR) {
-                const double *m = s_ir + (e - ie0) * IR_STRIDE;
+    // Inbox sums of a variable sweep, one lane per (variable, row): lane (i, rr) accumulates eta[rr] and
+    // lam[rr][0..3] in the reference's inbox order (BTreeMap<FactorId, _>, id.rs:19-54): factors of
+    // graphs with a lower key, own factors by node index (dynamic i-1, dynamic i, obstacle, tracking;
+    // own inter-robot factors are forever empty), then factors of graphs with a higher key — each
+    // element sees exactly the additions of VariableNode::update_belief... (variable.rs:254-271).
+    // Absent edges read the all-zero column: x + 0.0 == x exactly and a running sum that starts from
+    // the prior is never -0.0, so this equals skipping the entry.  For an internal sweep the sums are
+    // also the (eta, lam) of the responses to own-graph factors (:301-330, factorgraph.rs:771-786).
+    // s_out receives the sums ([20][K] image: the snapshot for internal sweeps).
+    auto variable_sums = [&](double *s_out, bool internal, bool last) {
+        for (int t = tid; t < 4 * K; t += SWEEP_BLOCK) {
+            const int i = t >> 2, rr = t & 3;
+            uint32_t epoch_reg = (4 * K <= SWEEP_BLOCK) ? my_epoch : s_epoch[i];
+            const int es[4] = {(i >= 1) ? (K - 1) + (i - 1) : ZCOL, (i <= K - 2) ? i : ZCOL,
+                               (i >= 1 && i <= K - 2) ? n_dyn + (i - 1) : ZCOL,
+                               (i >= 1 && i <= K - 2) ? n_dyn + (K - 2) + (i - 1) : ZCOL};
+            // all 25 LDS operands of the own-graph part are fetched before the first add: one LDS
+            // round trip instead of one per message
+            double pr[5], ms[4][5];
+            pr[0] = s_prior[rr * K + i];
 #pragma unroll
-                for (int c = 0; c < 4; c++) eta[c] += m[c];
+            for (int c = 0; c < 4; c++) pr[1 + c] = s_prior[(4 + rr * 4 + c) * K + i];
 #pragma unroll
-                for (int c = 0; c < 16; c++) lam[c] += m[4 + c];
-            } else {
+            for (int q = 0; q < 4; q++) {
+                ms[q][0] = s_fv[rr * E1 + es[q]];
 #pragma unroll
-                for (int c = 0; c < 4; c++) eta[c] += w.ir_fv_eta[(size_t)c * w.NI + e];
-#pragma unroll
-                for (int c = 0; c < 16; c++) lam[c] += w.ir_fv_lam[(size_t)c * w.NI + e];
+                for (int c = 0; c < 4; c++) ms[q][1 + c] = s_fv[(4 + rr * 4 + c) * E1 + es[q]];
             }
-        }
-    };
-
-    // VariableNode::update_belief_and_create_factor_responses (variable.rs:251-342) in two halves:
-    //  variable_sum:    eta / lam = prior + inbox (:254-271) and, for an internal sweep, the (eta, lam)
-    //                   part of the responses to own-graph factors (:301-330, factorgraph.rs:771-786);
-    //  variable_finish: covariance, validity and mean from (eta, lam) (:273-297) and the mean part of
-    //                   the responses.
-    // Dynamic factors never read a mean, so in the internal loop the finish of sweep t runs in the UV
-    // wave NEXT TO the dynamic messages of sweep t+1 in the DYN wave instead of in front of them.
-    auto variable_sum = [&](bool deliver_internal, bool last, double (&b_eta)[4], double (&b_lam)[16]) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) b_eta[c] = s_prior[c * KK + lane];
-#pragma unroll
-        for (int c = 0; c < 16; c++) b_lam[c] = s_prior[(4 + c) * KK + lane];
-        // inbox order of the reference (BTreeMap<FactorId, _>, id.rs:19-54): factors of graphs with a
-        // lower key, own factors by node index (dynamic i-1, dynamic i, obstacle, tracking; own
-        // inter-robot factors are forever empty), then factors of graphs with a higher key
-        ir_accumulate(ir_e0, ir_mid, b_eta, b_lam);
-        const int es[4] = {e_left, e_right, e_obs, e_trk};
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-#pragma unroll
-            for (int c = 0; c < 4; c++) b_eta[c] += s_fv[c * EE + es[q]];
-#pragma unroll
-            for (int c = 0; c < 16; c++) b_lam[c] += s_fv[(4 + c) * EE + es[q]];
-        }
-        ir_accumulate(ir_mid, ir_e1, b_eta, b_lam);
-        if (deliver_internal) {
-#pragma unroll
-            for (int c = 0; c < 4; c++) s_snap[c * KK + lane] = b_eta[c];
-#pragma unroll
-            for (int c = 0; c < 16; c++) s_snap[(4 + c) * KK + lane] = b_lam[c];
-            s_epoch[lane] += 1;
-        }
-        if (last) {  // the prior is not needed again in this launch: its LDS column carries the
-                     // belief (eta, lam) of the last sweep to the coalesced write-back
-#pragma unroll
-            for (int c = 0; c < 4; c++) s_prior[c * KK + lane] = b_eta[c];
-#pragma unroll
-            for (int c = 0; c < 16; c++) s_prior[(4 + c) * KK + lane] = b_lam[c];
-        }
-    };
-    // Internal-sweep sums, one lane per (variable, row): lane (col, r) accumulates eta[r] and lam[r][0..3]
-    // in inbox order — each element sees exactly the additions of the per-variable form.  All 128
-    // threads take part (the DYN wave has nothing else to do in the variable phase).
-    auto variable_sum_rows = [&](bool last) {
-        for (int t = tid; t < 4 * nK; t += SWEEP_BLOCK) {
-            const int col = t >> 2, rr = t & 3;
-            const int sub = col / K, i = col - sub * K;
-            if (w.idle[r0 + sub] != 0) continue;
-            const int eo = sub * E;
-            const int es[4] = {(i >= 1) ? eo + (K - 1) + (i - 1) : ZCOL, (i <= K - 2) ? eo + i : ZCOL,
-                               (i >= 1 && i <= K - 2) ? eo + n_dyn + (i - 1) : ZCOL,
-                               (i >= 1 && i <= K - 2) ? eo + n_dyn + (K - 2) + (i - 1) : ZCOL};
             double acc[5];  // eta[rr], lam[rr][0..3]
-            acc[0] = s_prior[rr * KK + col];
 #pragma unroll
-            for (int c = 0; c < 4; c++) acc[1 + c] = s_prior[(4 + rr * 4 + c) * KK + col];
-            const int x0 = w.ir_var_ptr[v0 + col], xm = w.ir_var_mid[v0 + col], x1 = w.ir_var_ptr[v0 + col + 1];
+            for (int c = 0; c < 5; c++) acc[c] = pr[c];
+            const int x0 = s_irp[i], xm = s_irp[(K + 1) + i], x1 = s_irp[2 * (K + 1) + i];
             auto ir_rows = [&](int e_from, int e_to) {
                 for (int e = e_from; e < e_to; e++) {
                     if (STAGE_IR) {
@@ -355,71 +277,70 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             };
             ir_rows(x0, xm);
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                acc[0] += s_fv[rr * EE + es[q]];
+            for (int q = 0; q < 4; q++)
 #pragma unroll
-                for (int c = 0; c < 4; c++) acc[1 + c] += s_fv[(4 + rr * 4 + c) * EE + es[q]];
-            }
+                for (int c = 0; c < 5; c++) acc[c] += ms[q][c];
             ir_rows(xm, x1);
-            s_snap[rr * KK + col] = acc[0];
+            s_out[rr * K + i] = acc[0];
 #pragma unroll
-            for (int c = 0; c < 4; c++) s_snap[(4 + rr * 4 + c) * KK + col] = acc[1 + c];
-            if (rr == 0) s_epoch[col] += 1;
-            if (last) {
-                s_prior[rr * KK + col] = acc[0];
+            for (int c = 0; c < 4; c++) s_out[(4 + rr * 4 + c) * K + i] = acc[1 + c];
+            if (internal && rr == 0) {
+                s_epoch[i] = ++epoch_reg;  // register copy when each thread owns one (variable, row)
+                if (4 * K <= SWEEP_BLOCK) my_epoch = epoch_reg;
+            }
+            if (last && s_out != s_prior) {  // the prior is not needed again in this launch: its LDS image
+                                             // carries the belief (eta, lam) to the write-back
+                s_prior[rr * K + i] = acc[0];
 #pragma unroll
-                for (int c = 0; c < 4; c++) s_prior[(4 + rr * 4 + c) * KK + col] = acc[1 + c];
+                for (int c = 0; c < 4; c++) s_prior[(4 + rr * 4 + c) * K + i] = acc[1 + c];
             }
         }
     };
-    auto variable_finish = [&](bool deliver_internal, const double (&b_eta)[4], const double (&b_lam)[16]) {
-        double mu[4], cov[16];
+    // Second half of the variable update: covariance, validity and mean from (eta, lam)
+    // (variable.rs:273-297), one lane per variable; for an internal sweep the mean also completes the
+    // snapshot (the responses' mean, :317).
+    auto variable_finish = [&](const double *s_in, bool internal) {
+        double b_eta[4], b_lam[16], mu[4], cov[16];
 #pragma unroll
-        for (int c = 0; c < 4; c++) mu[c] = s_mu[c * KK + lane];
+        for (int c = 0; c < 4; c++) b_eta[c] = s_in[c * K + lane];
+#pragma unroll
+        for (int c = 0; c < 16; c++) b_lam[c] = s_in[(4 + c) * K + lane];
+#pragma unroll
+        for (int c = 0; c < 4; c++) mu[c] = s_mu[c * K + lane];
         int valid = s_valid[lane];
         if (belief_update(b_eta, b_lam, mu, cov, valid)) {  // covariance (and maybe mean) changed
 #pragma unroll
-            for (int c = 0; c < 16; c++) s_cov[c * KK + lane] = cov[c];
+            for (int c = 0; c < 16; c++) s_cov[c * K + lane] = cov[c];
 #pragma unroll
-            for (int c = 0; c < 4; c++) s_mu[c * KK + lane] = mu[c];
+            for (int c = 0; c < 4; c++) s_mu[c * K + lane] = mu[c];
             s_valid[lane] = valid;
         }
-        if (deliver_internal) {
+        if (internal) {
 #pragma unroll
-            for (int c = 0; c < 4; c++) s_snap[(20 + c) * KK + lane] = mu[c];
+            for (int c = 0; c < 4; c++) s_snap[(20 + c) * K + lane] = mu[c];
         }
-    };
-    // finish of an internal sweep whose sums are in the snapshot columns (they ARE the responses)
-    auto variable_finish_from_snapshot = [&]() {
-        double b_eta[4], b_lam[16];
-#pragma unroll
-        for (int c = 0; c < 4; c++) b_eta[c] = s_snap[c * KK + lane];
-#pragma unroll
-        for (int c = 0; c < 16; c++) b_lam[c] = s_snap[(4 + c) * KK + lane];
-        variable_finish(true, b_eta, b_lam);
     };
 
     // ======================= external variable sweep ==========================================
     if (ext_mask & PH_EXT_VARIABLE) {
-        if (is_var && radio_v) {
-            double b_eta[4], b_lam[16];
-            variable_sum(false, !has_int_var, b_eta, b_lam);
-            variable_finish(false, b_eta, b_lam);
-        }
+        // beliefs are recomputed, nothing is delivered to own factors (factorgraph.rs:794-826): the
+        // sums go to the belief image if this is the robot's last sweep of the launch, else to scratch
+        double *s_sum = has_int_var ? s_tmp : s_prior;
+        if (radio) variable_sums(s_sum, false, false);
         __syncthreads();
-        if (ir_on) {
+        if (radio && is_var) variable_finish(s_sum, false);
+        __syncthreads();
+        if (radio && ir_on) {
             // responses to the foreign factors attached to our variables, routed to their inbox
             // (robot.rs:1842-1858): only the mean of that inbox entry is ever used (it sets the
             // linearisation point; eta / lam of the target side never reach the kept message)
             for (int j = tid; j < ne; j += SWEEP_BLOCK) {
                 const int e = ie0 + j;
-                const int col = w.ir_dst_var[e] - v0;
-                const int B = r0 + col / K;
-                if (!(w.antenna[B] != 0 && w.idle[B] == 0)) continue;  // B did not run its sweep
                 const int A = w.ir_src_robot[e];
                 if (!(w.antenna[A] != 0 && w.idle[A] == 0)) continue;  // A cannot receive
+                const int i = w.ir_dst_var[e] - v0;
 #pragma unroll
-                for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = s_mu[c * KK + col] - 0.0;
+                for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = s_mu[c * K + i] - 0.0;
             }
         }
         __syncthreads();
@@ -430,26 +351,24 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         const SdfView sdf = make_sdf_view(w.sdf, w.sdf_w, w.sdf_h, w.world_w, w.world_h);
 #ifdef MGX_STAMPS
         unsigned long long c_f = 0, c_fb = 0, c_v = 0, c_vb = 0;
-#endif
-        STAMP(t_loop0);
-#ifdef MGX_STAMPS
         const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        bool pending = false;  // this variable lane's last internal sums still await their finish
-        for (int it = 0; it < n_int; it++) {
+        STAMP(t_loop0);
+        bool pending = false;  // the last internal sums still await their finish (mean, covariance)
+        for (int it = 0; it < n_int && !idle; it++) {
             STAMP(t0);
             if (int_mask & PH_INT_FACTOR) {
                 // The two messages of one dynamic factor read each other's previous value; both lanes
                 // sit in the SAME wave, whose LDS reads all issue before its LDS writes, so no barrier
                 // is needed between reading the old and writing the new messages.
-                if (is_dyn && !idle_d && (w.enable & 1u)) {
+                if (is_dyn && (w.enable & 1u)) {
                     double me[4], ml[16], oe[4], ol[16];
                     const int o = dyn_other_var, oe_ix = dyn_other_edge;
                     if (s_epoch[o] > 0) {  // other variable has answered: belief - our last message
 #pragma unroll
-                        for (int c = 0; c < 4; c++) me[c] = s_snap[c * KK + o] - s_fv[c * EE + oe_ix];
+                        for (int c = 0; c < 4; c++) me[c] = s_snap[c * K + o] - s_fv[c * E1 + oe_ix];
 #pragma unroll
-                        for (int c = 0; c < 16; c++) ml[c] = s_snap[(4 + c) * KK + o] - s_fv[(4 + c) * EE + oe_ix];
+                        for (int c = 0; c < 16; c++) ml[c] = s_snap[(4 + c) * K + o] - s_fv[(4 + c) * E1 + oe_ix];
                     } else {
 #pragma unroll
                         for (int c = 0; c < 4; c++) me[c] = 0.0;
@@ -463,21 +382,19 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                         for (int c = 0; c < 16; c++) ol[c] = 0.0;
                     }
 #pragma unroll
-                    for (int c = 0; c < 4; c++) s_fv[c * EE + dyn_edge] = oe[c];
+                    for (int c = 0; c < 4; c++) s_fv[c * E1 + lane] = oe[c];
 #pragma unroll
-                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * EE + dyn_edge] = ol[c];
+                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + lane] = ol[c];
                 }
                 // UV wave: first the belief of the previous sweep (mean, covariance) that the unary
                 // factors linearise at — same wave, so its LDS writes precede their LDS reads
-                if (pending) {
-                    variable_finish_from_snapshot();
-                    pending = false;
-                }
-                if (is_obs && !idle_u && (w.enable & 4u)) {
+                if (pending && is_var) variable_finish(s_snap, true);
+                pending = false;
+                if (is_obs && (w.enable & 4u)) {
                     double x0[4], oe[4], ol[16];
                     const bool pres = s_epoch[uvar] > 0;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) x0[c] = pres ? s_snap[(20 + c) * KK + uvar] : 0.0;
+                    for (int c = 0; c < 4; c++) x0[c] = pres ? s_snap[(20 + c) * K + uvar] : 0.0;
                     long long idx[4];
                     obstacle_taps(sdf, x0[0], x0[1], w.obs_delta, idx);
                     double h[4];
@@ -485,15 +402,15 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     for (int q = 0; q < 4; q++) h[q] = (idx[q] >= 0) ? sdf_value(w.sdf[idx[q]]) : 0.0;
                     obstacle_message(h, w.obs_delta, w.inv_s2_obs, x0, oe, ol);
 #pragma unroll
-                    for (int c = 0; c < 4; c++) s_fv[c * EE + uedge] = oe[c];
+                    for (int c = 0; c < 4; c++) s_fv[c * E1 + uedge] = oe[c];
 #pragma unroll
-                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * EE + uedge] = ol[c];
+                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + uedge] = ol[c];
                 }
-                if (is_trk && !idle_u && (w.enable & 8u) && itf >= 10) {  // factorgraph.rs:701
+                if (is_trk && (w.enable & 8u) && itf >= 10) {  // factorgraph.rs:701
                     double x0[4], oe[4], ol[16];
 #pragma unroll
-                    for (int c = 0; c < 4; c++) x0[c] = s_snap[(20 + c) * KK + uvar];
-                    const int p0 = w.path_ptr[r0 + su], np = w.path_ptr[r0 + su + 1] - p0;
+                    for (int c = 0; c < 4; c++) x0[c] = s_snap[(20 + c) * K + uvar];
+                    const int p0 = w.path_ptr[r], np = w.path_ptr[r + 1] - p0;
                     if (!tracking_message(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, trk_rec,
                                           trk_lp, trk_lv, oe, ol)) {
 #pragma unroll
@@ -502,11 +419,11 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                         for (int c = 0; c < 16; c++) ol[c] = 0.0;
                     }
 #pragma unroll
-                    for (int c = 0; c < 4; c++) s_fv[c * EE + uedge] = oe[c];
+                    for (int c = 0; c < 4; c++) s_fv[c * E1 + uedge] = oe[c];
 #pragma unroll
-                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * EE + uedge] = ol[c];
+                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + uedge] = ol[c];
                 }
-                if (!my_idle) itf += 1;
+                itf += 1;
                 STAMP(t1);
                 __syncthreads();
                 STAMP(t2);
@@ -515,8 +432,8 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             }
             STAMP(t3);
             if (int_mask & PH_INT_VARIABLE) {
-                variable_sum_rows(it == n_int - 1);
-                if (is_var && !idle_v) pending = true;
+                variable_sums(s_snap, true, it == n_int - 1);
+                pending = true;
                 STAMP(t4);
                 __syncthreads();
                 STAMP(t5);
@@ -524,7 +441,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 STAMP_ADD(c_vb, t4, t5);
             }
         }
-        if (pending) variable_finish_from_snapshot();
+        if (pending && is_var) variable_finish(s_snap, true);
         __syncthreads();
 #ifdef MGX_STAMPS
         if (w.dbg && lane == 0) {  // per wave: cycles in factor phase, its barrier, variable phase, its barrier
@@ -532,53 +449,25 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             d[0] = c_f; d[1] = c_fb; d[2] = c_v; d[3] = c_vb; d[4] = __builtin_readcyclecounter() - t_loop0;
             d[5] = __builtin_amdgcn_s_memrealtime() - rt0;  // 100 MHz ticks over the same span
             d[6] = t_staged - t_k0;
-            d[7] = t_loop0 - t_staged;
         }
 #endif
     }
 
-    // ---- write back (coalesced) ------------------------------------------------------------------
-    for (int t = tid; t < 20 * nE; t += SWEEP_BLOCK) {
-        const int c = t / nE, e = t - c * nE;
-        if (c < 4)
-            w.fv_eta[(size_t)c * w.EI + eb + e] = s_fv[c * EE + e];
-        else
-            w.fv_lam[(size_t)(c - 4) * w.EI + eb + e] = s_fv[c * EE + e];
-    }
+    // ---- write back: straight copies of the LDS images ----------------------------------------------
+    copy_words(blob + L.cov(), s_io, L.inout_words(), tid);
+    if (any_sweep) copy_words(blob + L.bel(), s_prior, 20 * K, tid);
     if (snap_out >= 0) {
         double *dst = w.snap[snap_out] + (size_t)v0 * SNAP_W;
-        for (int t = tid; t < SNAP_W * nK; t += SWEEP_BLOCK) dst[t] = s_snap[(t % SNAP_W) * KK + (t / SNAP_W)];
-        for (int t = tid; t < nK; t += SWEEP_BLOCK) w.snap_epoch[snap_out][v0 + t] = s_epoch[t];
+        for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) dst[t] = s_snap[(t % SNAP_W) * K + (t / SNAP_W)];
+        for (int t = tid; t < K; t += SWEEP_BLOCK) w.snap_epoch[snap_out][v0 + t] = s_epoch[t];
     }
-    // beliefs: the s_prior columns of robots that ran a variable sweep now hold (eta, lam) of their last sweep
-    const bool any_int_var = (int_mask & PH_INT_VARIABLE) && n_int > 0;
-    const bool any_ext_var = (ext_mask & PH_EXT_VARIABLE) != 0;
-    auto swept = [&](int col) {
-        const int rr = r0 + col / K;
-        const bool idl = w.idle[rr] != 0;
-        return (any_int_var && !idl) || (any_ext_var && w.antenna[rr] != 0 && !idl);
-    };
-    for (int t = tid; t < 20 * nK; t += SWEEP_BLOCK) {
-        const int c = t / nK, i = t - c * nK;
-        if (!swept(i)) continue;
-        if (c < 4)
-            w.bel_eta[(size_t)c * w.V + v0 + i] = s_prior[c * KK + i];
-        else
-            w.bel_lam[(size_t)(c - 4) * w.V + v0 + i] = s_prior[c * KK + i];
-    }
-    for (int t = tid; t < 16 * nK; t += SWEEP_BLOCK)
-        if (swept(t % nK)) w.bel_cov[(size_t)(t / nK) * w.V + v0 + (t % nK)] = s_cov[(t / nK) * KK + (t % nK)];
-    for (int t = tid; t < 4 * nK; t += SWEEP_BLOCK)
-        if (swept(t % nK)) w.bel_mu[(size_t)(t / nK) * w.V + v0 + (t % nK)] = s_mu[(t / nK) * KK + (t % nK)];
-    for (int t = tid; t < nK; t += SWEEP_BLOCK)
-        if (swept(t)) w.bel_valid[v0 + t] = s_valid[t];
     if (is_trk) {
         w.trk_record[trk_item] = trk_rec;
         w.trk_last_pos[trk_item] = trk_lp[0];
         w.trk_last_pos[(size_t)w.NT + trk_item] = trk_lp[1];
         w.trk_last_val[trk_item] = trk_lv;
     }
-    if (is_dyn && ld == 0) w.iter_factor[r0 + sd] = itf;  // one lane per robot carries its counter out
+    if (tid == 0) w.iter_factor[r] = itf;
 #ifdef MGX_STAMPS
     if (w.dbg && lane == 0) w.dbg[((size_t)blockIdx.x * 2 + role) * 8 + 7] = __builtin_readcyclecounter() - t_k0;  // whole kernel
 #endif
@@ -589,18 +478,24 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 __global__ void k_change_prior(DevWorld w, int n, const int32_t *robots, const uint32_t *vars, const double *means) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    const int r = robots[t], i = (int)vars[t], K = w.K, E = w.E;
+    const int r = robots[t], i = (int)vars[t], K = w.K, E = w.E, E1 = E + 1;
+    const BlobLayout L(K);
+    double *b = w.blob + (size_t)r * w.BS;
     const int v = r * K + i;
     double m[4], pl[16], be[4], bl[16];
 #pragma unroll
     for (int c = 0; c < 4; c++) m[c] = means[4 * t + c];
-    ld_soa16(w.prior_lam, w.V, v, pl);
+#pragma unroll
+    for (int c = 0; c < 16; c++) pl[c] = b[L.prior() + (4 + c) * K + i];
 #pragma unroll
     for (int a = 0; a < 4; a++)  // prior eta = prior lam . mean (:204)
-        w.prior_eta[(size_t)a * w.V + v] = ((pl[a * 4 + 0] * m[0] + pl[a * 4 + 1] * m[1]) + pl[a * 4 + 2] * m[2]) + pl[a * 4 + 3] * m[3];
-    st_soa4(w.bel_mu, w.V, v, m);  // :206
-    ld_soa4(w.bel_eta, w.V, v, be);
-    ld_soa16(w.bel_lam, w.V, v, bl);
+        b[L.prior() + a * K + i] = ((pl[a * 4 + 0] * m[0] + pl[a * 4 + 1] * m[1]) + pl[a * 4 + 2] * m[2]) + pl[a * 4 + 3] * m[3];
+#pragma unroll
+    for (int c = 0; c < 4; c++) b[L.mu() + c * K + i] = m[c];  // :206
+#pragma unroll
+    for (int c = 0; c < 4; c++) be[c] = b[L.bel() + c * K + i];
+#pragma unroll
+    for (int c = 0; c < 16; c++) bl[c] = b[L.bel() + (4 + c) * K + i];
     // the (stale eta, stale lam, new mean) belief goes to every connected factor (:210-221):
     //   own-graph factors read it from the snapshot record ...
     double *rec = w.snap[w.cur] + (size_t)v * SNAP_W;
@@ -626,11 +521,8 @@ __global__ void k_change_prior(DevWorld w, int n, const int32_t *robots, const u
                        (i >= 1 && i <= K - 2) ? n_dyn + (K - 2) + (i - 1) : -1};
     for (int q = 0; q < 4; q++) {
         if (es[q] < 0) continue;
-        const int e = r * E + es[q];
 #pragma unroll
-        for (int c = 0; c < 4; c++) w.fv_eta[(size_t)c * w.EI + e] = 0.0;
-#pragma unroll
-        for (int c = 0; c < 16; c++) w.fv_lam[(size_t)c * w.EI + e] = 0.0;
+        for (int c = 0; c < 20; c++) b[L.fv() + c * E1 + es[q]] = 0.0;
     }
 }
 
@@ -656,38 +548,38 @@ __global__ void k_halo_unpack(DevWorld w, int n, const int32_t *ghosts, const do
 }
 
 // ---- launch wrappers (called from mgx_world.hip) -------------------------------------------------
-size_t sweep_lds_bytes(int K, int rpb, int ir_edges) {
-    const int E = 4 * K - 6;
-    return sizeof(double) * (size_t)(rpb * ((SNAP_W + 20 + 16 + 4) * K + 20 * E) + 20 + IR_STRIDE * ir_edges) + 8 * (size_t)(rpb * K);
+size_t sweep_lds_bytes(int K, int ir_edges) {
+    const BlobLayout L(K);
+    const int io = L.inout_words() + (L.inout_words() & 1);
+    return sizeof(double) * (size_t)((SNAP_W + 20 + 20) * K + io + IR_STRIDE * ir_edges) + 4 * (size_t)(((K + 1) & ~1) + ((3 * (K + 1) + 1) & ~1));
 }
 bool sweep_supports(int K) { return K >= 3 && 2 * (K - 1) <= 64; }
-int sweep_rpb(int K) { return rpb_for(K); }
+int blob_words(int K) { const BlobLayout L(K); return (L.words() + 1) & ~1; }
 
-template <int KT, int RPB>
+template <int KT>
 static void launch_k(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, uint32_t int_mask, int n_int, int snap_out,
                      hipStream_t stream) {
-    const int blocks = (n_robots + RPB - 1) / RPB;
-    // LDS: staging the inter-robot messages needs IR_STRIDE f64 per edge of the workgroup's robots;
-    // beyond 64 KB fall back to reading them from L2 in every variable sweep
-    const size_t staged = sweep_lds_bytes(w.K, RPB, RPB * w.ir_max_edges);
+    // staging the inter-robot messages needs IR_STRIDE f64 per edge; beyond 64 KB of LDS fall back to
+    // reading them from L2 in every variable sweep
+    const size_t staged = sweep_lds_bytes(w.K, w.ir_max_edges);
     if (staged <= 64 * 1024)
-        hipLaunchKernelGGL((k_robot_sweep<KT, RPB, true>), dim3(blocks), dim3(SWEEP_BLOCK), staged, stream, w, robot0,
-                           robot0 + n_robots, ext_mask, int_mask, n_int, snap_out);
+        hipLaunchKernelGGL((k_robot_sweep<KT, true>), dim3(n_robots), dim3(SWEEP_BLOCK), staged, stream, w, robot0, ext_mask,
+                           int_mask, n_int, snap_out);
     else
-        hipLaunchKernelGGL((k_robot_sweep<KT, RPB, false>), dim3(blocks), dim3(SWEEP_BLOCK), sweep_lds_bytes(w.K, RPB, 0), stream, w,
-                           robot0, robot0 + n_robots, ext_mask, int_mask, n_int, snap_out);
+        hipLaunchKernelGGL((k_robot_sweep<KT, false>), dim3(n_robots), dim3(SWEEP_BLOCK), sweep_lds_bytes(w.K, 0), stream, w,
+                           robot0, ext_mask, int_mask, n_int, snap_out);
 }
 
 hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, uint32_t int_mask, int n_int,
                               int snap_out, hipStream_t stream) {
     if (n_robots <= 0) return hipSuccess;
     switch (w.K) {  // horizon lengths of BASELINE.json / the reference scenarios get constant-K code
-    case 10: launch_k<10, rpb_for(10)>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
-    case 12: launch_k<12, rpb_for(12)>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
-    case 16: launch_k<16, rpb_for(16)>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
-    case 21: launch_k<21, rpb_for(21)>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
-    case 32: launch_k<32, rpb_for(32)>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
-    default: launch_k<0, 1>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
+    case 10: launch_k<10>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
+    case 12: launch_k<12>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
+    case 16: launch_k<16>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
+    case 21: launch_k<21>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
+    case 32: launch_k<32>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
+    default: launch_k<0>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
     }
     return hipGetLastError();
 }

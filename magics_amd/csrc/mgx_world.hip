@@ -23,8 +23,8 @@
 #include "mgx_dev.h"
 
 namespace mgx {
-size_t sweep_lds_bytes(int K, int rpb, int ir_edges);
-int sweep_rpb(int K);
+size_t sweep_lds_bytes(int K, int ir_edges);
+int blob_words(int K);
 bool sweep_supports(int K);
 hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, uint32_t int_mask, int n_int,
                               int snap_out, hipStream_t stream);
@@ -136,9 +136,8 @@ struct mgx_world {
     std::vector<int> robot_of;   // device robot index -> robot id
     std::vector<int> edge_conn, edge_i;  // device ir edge -> (conn index, i-1)
 
-    DevBuf<double> prior_eta, prior_lam, bel_eta, bel_lam, bel_mu, bel_cov, snap0, snap1, fv_eta, fv_lam, dyn_m,
-        trk_last_val, ir_dsafe, ir_off, ir_fv_eta, ir_fv_lam, ir_bmu;
-    DevBuf<int32_t> bel_valid, trk_record, path_ptr, iter_factor, ir_var_ptr, ir_var_mid, ir_src_var, ir_dst_var, ir_src_robot;
+    DevBuf<double> blob, snap0, snap1, dyn_m, trk_last_val, ir_dsafe, ir_off, ir_fv_eta, ir_fv_lam, ir_bmu;
+    DevBuf<int32_t> trk_record, path_ptr, iter_factor, ir_var_ptr, ir_var_mid, ir_src_var, ir_dst_var, ir_src_robot;
     DevBuf<uint32_t> epoch0, epoch1, ir_created;
     DevBuf<float> trk_last_pos, path_xy;
     DevBuf<uint8_t> ir_dst_slot, antenna, idle, sdf;
@@ -207,27 +206,69 @@ static void dynamic_potential(double dt, double sigma, double *M /*16*/) {
         for (int b = 0; b < 4; b++) M[a * 4 + b] = L[(2 * a) * 8 + (2 * b)];
 }
 
+// ---- blob <-> host mirror -----------------------------------------------------------------------------
+// rows of a robot's blob are component-major ([c][K] / [c][E+1]); the host mirror is item-major
+static void blob_pack(const Robot &rb, double *b) {
+    const int K = rb.K, E = 4 * K - 6, E1 = E + 1;
+    const BlobLayout L(K);
+    for (int i = 0; i < K; i++) {
+        for (int c = 0; c < 4; c++) {
+            b[L.prior() + c * K + i] = rb.prior_eta[4 * i + c];
+            b[L.bel() + c * K + i] = rb.bel_eta[4 * i + c];
+            b[L.mu() + c * K + i] = rb.bel_mu[4 * i + c];
+        }
+        for (int c = 0; c < 16; c++) {
+            b[L.prior() + (4 + c) * K + i] = rb.prior_lam[16 * i + c];
+            b[L.bel() + (4 + c) * K + i] = rb.bel_lam[16 * i + c];
+            b[L.cov() + c * K + i] = rb.bel_cov[16 * i + c];
+        }
+    }
+    for (int c = 0; c < 20; c++) b[L.fv() + c * E1 + E] = 0.0;  // the all-zero column
+    if (!rb.ghost)
+        for (int e = 0; e < E; e++) {
+            for (int c = 0; c < 4; c++) b[L.fv() + c * E1 + e] = rb.fv_eta[4 * e + c];
+            for (int c = 0; c < 16; c++) b[L.fv() + (4 + c) * E1 + e] = rb.fv_lam[16 * e + c];
+        }
+    int32_t *valid = reinterpret_cast<int32_t *>(b + L.valid());
+    for (int i = 0; i < K; i++) valid[i] = rb.valid[i];
+}
+static void blob_unpack(Robot &rb, const double *b) {
+    const int K = rb.K, E = 4 * K - 6, E1 = E + 1;
+    const BlobLayout L(K);
+    for (int i = 0; i < K; i++) {
+        for (int c = 0; c < 4; c++) {
+            rb.prior_eta[4 * i + c] = b[L.prior() + c * K + i];
+            rb.bel_eta[4 * i + c] = b[L.bel() + c * K + i];
+            rb.bel_mu[4 * i + c] = b[L.mu() + c * K + i];
+        }
+        for (int c = 0; c < 16; c++) {
+            rb.prior_lam[16 * i + c] = b[L.prior() + (4 + c) * K + i];
+            rb.bel_lam[16 * i + c] = b[L.bel() + (4 + c) * K + i];
+            rb.bel_cov[16 * i + c] = b[L.cov() + c * K + i];
+        }
+    }
+    if (!rb.ghost)
+        for (int e = 0; e < E; e++) {
+            for (int c = 0; c < 4; c++) rb.fv_eta[4 * e + c] = b[L.fv() + c * E1 + e];
+            for (int c = 0; c < 16; c++) rb.fv_lam[16 * e + c] = b[L.fv() + (4 + c) * E1 + e];
+        }
+    const int32_t *valid = reinterpret_cast<const int32_t *>(b + L.valid());
+    for (int i = 0; i < K; i++) rb.valid[i] = valid[i];
+}
+
 // ---- pull: device -> host mirror ----------------------------------------------------------------
 static int pull(mgx_world *w) {
     if (!w->dev_valid) return MGX_OK;
-    const int K = w->K, E = 4 * K - 6;
-    const size_t V = (size_t)w->d.V, EI = (size_t)w->d.EI, NT = (size_t)w->d.NT, NI = (size_t)w->d.NI;
-    std::vector<double> pe, pl, be, bl, bm, bc, sn, fe, fl, tlv, ife, ifl, ibm;
-    std::vector<int32_t> bv, trc, itf;
+    const int K = w->K;
+    const size_t NT = (size_t)w->d.NT, NI = (size_t)w->d.NI, BS = (size_t)w->d.BS;
+    std::vector<double> bl, sn, tlv, ife, ifl, ibm;
+    std::vector<int32_t> trc, itf;
     std::vector<uint32_t> ep;
     std::vector<float> tlp;
     hipStream_t s = w->stream;
-    HIP_TRY(w->prior_eta.download(pe, s));
-    HIP_TRY(w->prior_lam.download(pl, s));
-    HIP_TRY(w->bel_eta.download(be, s));
-    HIP_TRY(w->bel_lam.download(bl, s));
-    HIP_TRY(w->bel_mu.download(bm, s));
-    HIP_TRY(w->bel_cov.download(bc, s));
-    HIP_TRY(w->bel_valid.download(bv, s));
+    HIP_TRY(w->blob.download(bl, s));
     HIP_TRY((w->d.cur ? w->snap1 : w->snap0).download(sn, s));
     HIP_TRY((w->d.cur ? w->epoch1 : w->epoch0).download(ep, s));
-    HIP_TRY(w->fv_eta.download(fe, s));
-    HIP_TRY(w->fv_lam.download(fl, s));
     HIP_TRY(w->trk_record.download(trc, s));
     HIP_TRY(w->trk_last_pos.download(tlp, s));
     HIP_TRY(w->trk_last_val.download(tlv, s));
@@ -238,23 +279,13 @@ static int pull(mgx_world *w) {
     HIP_TRY(hipStreamSynchronize(s));
     for (size_t dr = 0; dr < w->robot_of.size(); dr++) {
         Robot &rb = w->robots[(size_t)w->robot_of[dr]];
+        blob_unpack(rb, &bl[dr * BS]);
         for (int i = 0; i < K; i++) {
             const size_t v = dr * K + i;
-            gather(pe, V, v, &rb.prior_eta[4 * i], 4);
-            gather(pl, V, v, &rb.prior_lam[16 * i], 16);
-            gather(be, V, v, &rb.bel_eta[4 * i], 4);
-            gather(bl, V, v, &rb.bel_lam[16 * i], 16);
-            gather(bm, V, v, &rb.bel_mu[4 * i], 4);
-            gather(bc, V, v, &rb.bel_cov[16 * i], 16);
             memcpy(&rb.snap[24 * i], &sn[v * 24], 24 * sizeof(double));
-            rb.valid[i] = bv[v];
             rb.epoch[i] = ep[v];
         }
         if (rb.ghost) continue;
-        for (int e = 0; e < E; e++) {
-            gather(fe, EI, dr * E + e, &rb.fv_eta[4 * e], 4);
-            gather(fl, EI, dr * E + e, &rb.fv_lam[16 * e], 16);
-        }
         for (int j = 0; j < K - 2; j++) {
             const size_t t = dr * (K - 2) + j;
             rb.trk_record[j] = trc[t];
@@ -299,7 +330,7 @@ static int commit(mgx_world *w) {
     int rc = pull(w);
     if (rc != MGX_OK) return rc;
     const int K = w->K, E = 4 * K - 6;
-    if (!sweep_supports(K) || sweep_lds_bytes(K, sweep_rpb(K), 0) > 60 * 1024) return fail(MGX_ERR_INVALID, "K = %d not supported (3 <= K <= 33)", K);
+    if (!sweep_supports(K) || sweep_lds_bytes(K, 0) > 60 * 1024) return fail(MGX_ERR_INVALID, "K = %d not supported (3 <= K <= 33)", K);
 
     // device robot order: locals (id order), then ghosts
     w->robot_of.clear();
@@ -381,30 +412,20 @@ static int commit(mgx_world *w) {
     for (int dr = 0; dr < R_local; dr++)
         ir_max_edges = std::max(ir_max_edges, (int)(var_ptr[(size_t)(dr + 1) * K] - var_ptr[(size_t)dr * K]));
 
-    std::vector<double> pe(4 * V), pl(16 * V), be(4 * V), bl(16 * V), bm(4 * V), bc(16 * V), sn(24 * V), fe(4 * EI, 0.0),
-        fl(16 * EI, 0.0), dm(16 * ND, 0.0), tlv(NT, 0.0);
-    std::vector<int32_t> bv(V), trc(NT, 0), pptr((size_t)R_local + 1, 0), itf((size_t)std::max(R_local, 1), 0);
+    const size_t BS = (size_t)blob_words(K);
+    std::vector<double> blb(BS * (size_t)R_total, 0.0), sn(24 * V), dm(16 * ND, 0.0), tlv(NT, 0.0);
+    std::vector<int32_t> trc(NT, 0), pptr((size_t)R_local + 1, 0), itf((size_t)std::max(R_local, 1), 0);
     std::vector<uint32_t> ep(V);
     std::vector<float> tlp(2 * NT, 0.f), pxy;
     for (int dr = 0; dr < R_total; dr++) {
         const Robot &rb = w->robots[(size_t)w->robot_of[(size_t)dr]];
+        blob_pack(rb, &blb[(size_t)dr * BS]);
         for (int i = 0; i < K; i++) {
             const size_t v = (size_t)dr * K + i;
-            scatter(pe, V, v, &rb.prior_eta[4 * i], 4);
-            scatter(pl, V, v, &rb.prior_lam[16 * i], 16);
-            scatter(be, V, v, &rb.bel_eta[4 * i], 4);
-            scatter(bl, V, v, &rb.bel_lam[16 * i], 16);
-            scatter(bm, V, v, &rb.bel_mu[4 * i], 4);
-            scatter(bc, V, v, &rb.bel_cov[16 * i], 16);
             memcpy(&sn[v * 24], &rb.snap[24 * i], 24 * sizeof(double));
-            bv[v] = rb.valid[i];
             ep[v] = rb.epoch[i];
         }
         if (rb.ghost) continue;
-        for (int ed = 0; ed < E; ed++) {
-            scatter(fe, EI, (size_t)dr * E + ed, &rb.fv_eta[4 * ed], 4);
-            scatter(fl, EI, (size_t)dr * E + ed, &rb.fv_lam[16 * ed], 16);
-        }
         for (int f = 0; f < K - 1; f++) scatter(dm, ND, (size_t)dr * (K - 1) + f, &rb.dyn_m[16 * f], 16);
         for (int j = 0; j < K - 2; j++) {
             const size_t t = (size_t)dr * (K - 2) + j;
@@ -429,19 +450,11 @@ static int commit(mgx_world *w) {
     }
 
     hipStream_t s = w->stream;
-    HIP_TRY(w->prior_eta.upload(pe, s));
-    HIP_TRY(w->prior_lam.upload(pl, s));
-    HIP_TRY(w->bel_eta.upload(be, s));
-    HIP_TRY(w->bel_lam.upload(bl, s));
-    HIP_TRY(w->bel_mu.upload(bm, s));
-    HIP_TRY(w->bel_cov.upload(bc, s));
-    HIP_TRY(w->bel_valid.upload(bv, s));
+    HIP_TRY(w->blob.upload(blb, s));
     HIP_TRY(w->snap0.upload(sn, s));
     HIP_TRY(w->snap1.upload(sn, s));
     HIP_TRY(w->epoch0.upload(ep, s));
     HIP_TRY(w->epoch1.upload(ep, s));
-    HIP_TRY(w->fv_eta.upload(fe, s));
-    HIP_TRY(w->fv_lam.upload(fl, s));
     HIP_TRY(w->dyn_m.upload(dm, s));
     HIP_TRY(w->trk_record.upload(trc, s));
     HIP_TRY(w->trk_last_pos.upload(tlp, s));
@@ -470,12 +483,10 @@ static int commit(mgx_world *w) {
     d.cur = 0;
     d.ir_max_edges = ir_max_edges;
     d.enable = w->p.enable_mask;
-    d.prior_eta = w->prior_eta.p; d.prior_lam = w->prior_lam.p;
-    d.bel_eta = w->bel_eta.p; d.bel_lam = w->bel_lam.p; d.bel_mu = w->bel_mu.p; d.bel_cov = w->bel_cov.p;
-    d.bel_valid = w->bel_valid.p;
+    d.blob = w->blob.p; d.BS = (int)BS;
     d.snap[0] = w->snap0.p; d.snap[1] = w->snap1.p;
     d.snap_epoch[0] = w->epoch0.p; d.snap_epoch[1] = w->epoch1.p;
-    d.fv_eta = w->fv_eta.p; d.fv_lam = w->fv_lam.p; d.dyn_m = w->dyn_m.p;
+    d.dyn_m = w->dyn_m.p;
     d.trk_record = w->trk_record.p; d.trk_last_pos = w->trk_last_pos.p; d.trk_last_val = w->trk_last_val.p;
     d.path_ptr = w->path_ptr.p; d.path_xy = w->path_xy.p; d.iter_factor = w->iter_factor.p;
     d.ir_var_ptr = w->ir_var_ptr.p; d.ir_var_mid = w->ir_var_mid.p; d.ir_src_var = w->ir_src_var.p; d.ir_dst_var = w->ir_dst_var.p;
@@ -745,18 +756,28 @@ int mgx_read_beliefs(mgx_world *w, double *eta, double *lam, double *means) {
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
     const int K = w->K;
-    const size_t V = (size_t)w->d.V, nloc = (size_t)w->d.R_local * K;
-    std::vector<double> be, bl, bm;
-    if (eta) HIP_TRY(w->bel_eta.download(be, w->stream));
-    if (lam) HIP_TRY(w->bel_lam.download(bl, w->stream));
-    if (means) HIP_TRY(w->bel_mu.download(bm, w->stream));
+    const BlobLayout L(K);
+    const size_t BS = (size_t)w->d.BS, R = (size_t)w->d.R_local;
+    // strided device -> host copies of the belief (eta, lam) and mean rows of every local blob
+    std::vector<double> bel(R * 20 * K), mu(R * 4 * K);
+    if (eta || lam)
+        HIP_TRY(hipMemcpy2DAsync(bel.data(), 20 * K * sizeof(double), w->blob.p + L.bel(), BS * sizeof(double),
+                                 20 * K * sizeof(double), R, hipMemcpyDeviceToHost, w->stream));
+    if (means)
+        HIP_TRY(hipMemcpy2DAsync(mu.data(), 4 * K * sizeof(double), w->blob.p + L.mu(), BS * sizeof(double),
+                                 4 * K * sizeof(double), R, hipMemcpyDeviceToHost, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
     // device local order == id order of non-ghost robots
-    for (size_t v = 0; v < nloc; v++) {
-        if (eta) gather(be, V, v, eta + 4 * v, 4);
-        if (lam) gather(bl, V, v, lam + 16 * v, 16);
-        if (means) gather(bm, V, v, means + 4 * v, 4);
-    }
+    for (size_t r = 0; r < R; r++)
+        for (int i = 0; i < K; i++) {
+            const size_t v = r * K + i;
+            if (eta)
+                for (int c = 0; c < 4; c++) eta[4 * v + c] = bel[r * 20 * K + c * K + i];
+            if (lam)
+                for (int c = 0; c < 16; c++) lam[16 * v + c] = bel[r * 20 * K + (4 + c) * K + i];
+            if (means)
+                for (int c = 0; c < 4; c++) means[4 * v + c] = mu[r * 4 * K + c * K + i];
+        }
     return MGX_OK;
 }
 
@@ -765,20 +786,21 @@ int mgx_get_belief(mgx_world *w, int32_t robot, uint32_t var_ix, double eta[4], 
     if (!w || robot < 0 || (size_t)robot >= w->robots.size() || (int)var_ix >= w->K) return fail(MGX_ERR_INVALID, "bad (robot, variable)");
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
-    const size_t V = (size_t)w->d.V, v = (size_t)w->dev_of[(size_t)robot] * w->K + var_ix;
-    auto fetch = [&](const double *base, double *out, int comps) -> hipError_t {
-        for (int c = 0; c < comps; c++) {
-            hipError_t e = hipMemcpyAsync(out + c, base + (size_t)c * V + v, sizeof(double), hipMemcpyDeviceToHost, w->stream);
-            if (e != hipSuccess) return e;
-        }
-        return hipSuccess;
-    };
-    if (eta) HIP_TRY(fetch(w->bel_eta.p, eta, 4));
-    if (lam) HIP_TRY(fetch(w->bel_lam.p, lam, 16));
-    if (mean) HIP_TRY(fetch(w->bel_mu.p, mean, 4));
-    if (cov) HIP_TRY(fetch(w->bel_cov.p, cov, 16));
-    if (valid) HIP_TRY(hipMemcpyAsync(valid, w->bel_valid.p + v, sizeof(int32_t), hipMemcpyDeviceToHost, w->stream));
+    const int K = w->K, i = (int)var_ix;
+    const BlobLayout L(K);
+    std::vector<double> b((size_t)w->d.BS);
+    HIP_TRY(hipMemcpyAsync(b.data(), w->blob.p + (size_t)w->dev_of[(size_t)robot] * w->d.BS, sizeof(double) * b.size(),
+                           hipMemcpyDeviceToHost, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
+    if (eta)
+        for (int c = 0; c < 4; c++) eta[c] = b[L.bel() + c * K + i];
+    if (lam)
+        for (int c = 0; c < 16; c++) lam[c] = b[L.bel() + (4 + c) * K + i];
+    if (mean)
+        for (int c = 0; c < 4; c++) mean[c] = b[L.mu() + c * K + i];
+    if (cov)
+        for (int c = 0; c < 16; c++) cov[c] = b[L.cov() + c * K + i];
+    if (valid) *valid = reinterpret_cast<const int32_t *>(b.data() + L.valid())[i];
     return MGX_OK;
 }
 
