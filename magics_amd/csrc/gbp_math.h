@@ -254,6 +254,31 @@ MGX_HD void obstacle_message(const double (&h)[4], double delta, double inv_sigm
     }
 }
 
+// Row-split form of the two functions above for four cooperating lanes (q = 0..3): lane q samples
+// tap q, and, given all four samples, produces row q of the message.  Every element is computed by
+// the same operations as in obstacle_message.
+MGX_HD long long obstacle_tap(const SdfView &s, double x, double y, double delta, int q) {
+    const double xr = (x + delta) - delta, yr = (y + delta) - delta;
+    const double tx = (q == 0) ? x : (q == 1 ? x + delta : xr);
+    const double ty = (q <= 1) ? y : (q == 2 ? y + delta : yr);
+    return sdf_index(s, tx, ty);
+}
+MGX_HD void obstacle_message_row(const double (&h)[4], double delta, double inv_sigma2, const double (&x0)[4], int q,
+                                 double &eta_q, double (&lam_q)[4]) {
+    double J[4];
+    J[0] = (h[1] - h[0]) / delta;
+    J[1] = (h[2] - h[0]) / delta;
+    J[2] = (h[3] - h[0]) / delta;
+    J[3] = J[2];
+    const double jq = (q == 0) ? J[0] : (q == 1 ? J[1] : J[2]);
+    const double jl = jq * inv_sigma2;
+    const double jx = ((J[0] * x0[0] + J[1] * x0[1]) + J[2] * x0[2]) + J[3] * x0[3];
+    const double rhs = jx + (0.0 - h[0]);
+    eta_q = jl * rhs;
+#pragma unroll
+    for (int j = 0; j < 4; j++) lam_q[j] = jl * J[j];
+}
+
 // ---------------------------------------------------------------------------------------
 // Inter-robot factor (factor/interrobot.rs:91-226, factor/mod.rs:334-454).
 // x_lo / x_hi: linearisation-point halves of slot 0 / slot 1 (the graph with the lower /

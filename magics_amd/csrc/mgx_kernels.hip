@@ -158,7 +158,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         dyn_other_var = f + 1 - slot;
         dyn_other_edge = (1 - slot) * (K - 1) + f;
     }
-    // UV wave, factor phase: obstacle lanes [0, K-2), tracking lanes [K-2, 2(K-2))
+    // obstacle factors: four lanes per factor when they fit one wave and no tracking lanes are needed
+    const bool obs_rows = (4 * (K - 2) <= 64) && !(w.enable & 8u);
+    // UV wave, factor phase (otherwise): obstacle lanes [0, K-2), tracking lanes [K-2, 2(K-2))
     const int uvar = (is_trk ? lane - (K - 2) : lane) + 1;  // variable of the unary factor
     const int uedge = n_dyn + lane;                         // its internal-edge column
     int trk_rec = 0;
@@ -390,7 +392,26 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 // factors linearise at — same wave, so its LDS writes precede their LDS reads
                 if (pending && is_var) variable_finish(s_snap, true);
                 pending = false;
-                if (is_obs && (w.enable & 4u)) {
+                if (obs_rows) {
+                    // four lanes per obstacle factor: lane q samples tap q and writes row q of the message
+                    if (role == ROLE_UV && lane < 4 * (K - 2) && (w.enable & 4u)) {
+                        const int j = lane >> 2, q = lane & 3, var = j + 1, col = n_dyn + j;
+                        double x0[4];
+                        const bool pres = s_epoch[var] > 0;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) x0[c] = pres ? s_snap[(20 + c) * K + var] : 0.0;
+                        const long long idx = obstacle_tap(sdf, x0[0], x0[1], w.obs_delta, q);
+                        const double hq = (idx >= 0) ? sdf_value(w.sdf[idx]) : 0.0;
+                        double h[4];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) h[t] = __shfl(hq, (lane & ~3) + t, 64);
+                        double eta_q, lam_q[4];
+                        obstacle_message_row(h, w.obs_delta, w.inv_s2_obs, x0, q, eta_q, lam_q);
+                        s_fv[q * E1 + col] = eta_q;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) s_fv[(4 + q * 4 + c) * E1 + col] = lam_q[c];
+                    }
+                } else if (is_obs && (w.enable & 4u)) {
                     double x0[4], oe[4], ol[16];
                     const bool pres = s_epoch[uvar] > 0;
 #pragma unroll
