@@ -121,6 +121,17 @@ def cpu_baseline(sc, seconds):
     }
 
 
+def measured_traffic(key):
+    """HBM bytes per dispatch from the committed PMC passes (profiles/traffic_r01.json): FETCH_SIZE
+    doubled (gfx950 correction for wide streaming reads) + WRITE_SIZE; None when absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_r01.json")) as f:
+            t = json.load(f)[key]
+        return int((2 * t["fetch_kib"] + t["write_kib"]) * 1024)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     a = parse()
     import torch
@@ -172,7 +183,7 @@ def main():
             "bound": "hbm", "kernel": "k_robot_sweep",
             "achieved": round(bytes_iter * a.steps / dev / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(bytes_iter * a.steps / dev / 1e9 / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": measured_traffic("config2") if (n_loc, K) == (1000, 16) else None,
             "algorithmic_bytes_per_launch": bytes_iter * SCHEDULE_LEN,
             "avg_launch_us": round(dev / n_launch * 1e6, 3),
             "note": "algorithmic bytes = SURVEY §8d model (38 656 B per robot-iteration); the launch keeps each "
@@ -182,37 +193,54 @@ def main():
     w.synchronize()
 
     # ---- secondary: configs[2]/[3], + inter-robot factors, robots sharded with halo exchange ------
+    sc2 = None
     if not a.no_secondary:
+        # Every rank first builds its shard; the ranks then agree that all of them succeeded BEFORE the
+        # first collective, so a failure on one rank can never leave the others waiting in RCCL.
         n_tot = n_loc * world_size
-        sc2 = S.grid_scenario(n_tot, K, interrobot=True, seed=805)
-        comm = sharded.TorchDistComm() if multi else None
-        sw = sharded.ShardedWorld(sc2, rank, world_size, lambda p: World(p, stream=stream, fma=a.fma), comm=comm)
-        steps2 = sc2["steps"]
-        n2, w2 = max(SCHEDULE_LEN, a.steps // 4), max(SCHEDULE_LEN, a.warmup // 4)
-        wall2, dev2 = timed(torch, dist, sw.iterate, steps2, n2, w2, multi)
-        D = len(sc2["ir"]) / n_tot
-        bytes2 = S.algorithmic_bytes_per_robot_iter(K, D) * n_loc
-        line["secondary"] = {
-            "value": round(n2 / wall2, 2), "unit": f"GBP iterations/s (one iteration over all {n_tot} robots)",
-            "steps": n2, "ms_per_step": wall2 / n2 * 1e3,
-            "config": {"workload": f"BASELINE configs[2]/[3]: synthetic {n_tot} robots x {K} horizon + inter-robot "
-                                   f"factors (comm radius 8, {D:.2f} neighbours/robot), sharded {world_size} way(s)",
-                       "parallelism": f"robots sharded over {world_size} GPU(s), one RCCL all-to-all-v of boundary "
-                                      "snapshots per external iteration" if multi else "1 GPU, no collective",
-                       "ghost_robots_this_rank": len(sw.plan.ghosts)},
-            "roofline": {"bound": "hbm", "kernel": "k_robot_sweep",
-                         "achieved": round(bytes2 * n2 / dev2 / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(bytes2 * n2 / dev2 / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": bytes2, "avg_launch_us": round(dev2 / (n2 + n2 // SCHEDULE_LEN) * 1e6, 3)},
-        }
-        sw.synchronize()
+        sw, err = None, ""
+        try:
+            sc2 = S.grid_scenario(n_tot, K, interrobot=True, seed=805)
+            comm = sharded.TorchDistComm() if multi else None
+            sw = sharded.ShardedWorld(sc2, rank, world_size, lambda p: World(p, stream=stream, fma=a.fma), comm=comm)
+            sw.world.sweep(0, 0, 0)  # commit: device arrays built, no phase run
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+        if multi:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0]) == 1:
+            steps2 = sc2["steps"]
+            n2, w2 = max(SCHEDULE_LEN, a.steps // 4), max(SCHEDULE_LEN, a.warmup // 4)
+            wall2, dev2 = timed(torch, dist, sw.iterate, steps2, n2, w2, multi)
+            D = len(sc2["ir"]) / n_tot
+            bytes2 = S.algorithmic_bytes_per_robot_iter(K, D) * n_loc
+            line["secondary"] = {
+                "value": round(n2 / wall2, 2), "unit": f"GBP iterations/s (one iteration over all {n_tot} robots)",
+                "steps": n2, "ms_per_step": wall2 / n2 * 1e3,
+                "config": {"workload": f"BASELINE configs[2]/[3]: synthetic {n_tot} robots x {K} horizon + inter-robot "
+                                       f"factors (comm radius 8, {D:.2f} neighbours/robot), sharded {world_size} way(s)",
+                           "parallelism": (f"robots sharded over {world_size} GPUs, one RCCL all-to-all-v of boundary "
+                                           "snapshots per external iteration") if multi else "1 GPU, no collective",
+                           "ghost_robots_this_rank": len(sw.plan.ghosts)},
+                "roofline": {"bound": "hbm", "kernel": "k_robot_sweep",
+                             "achieved": round(bytes2 * n2 / dev2 / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(bytes2 * n2 / dev2 / 1e9 / HBM_PEAK_GBS, 4),
+                             "traffic": measured_traffic("config3") if (n_loc, K, world_size) == (1000, 16, 1) else None,
+                             "algorithmic_bytes_per_launch": bytes2,
+                             "avg_launch_us": round(dev2 / (n2 + -(-n2 // SCHEDULE_LEN)) * 1e6, 3)},
+            }
+            sw.synchronize()
+        else:
+            line["secondary"] = {"error": err or "another rank failed to build its shard"}
+            sc2 = None
 
     # ---- CPU baseline: rank 0, N = 1 only ---------------------------------------------------------
     if rank == 0 and not multi and not a.no_cpu_baseline:
         cb = cpu_baseline(sc, a.cpu_seconds)
         line["cpu_baseline"] = cb
         line["speedup_vs_cpu_baseline"] = round(line["value"] / cb["value"], 1)
-        if "secondary" in line:
+        if sc2 is not None and "value" in line.get("secondary", {}):
             cb2 = cpu_baseline(sc2, a.cpu_seconds)
             line["secondary"]["cpu_baseline"] = cb2
             line["secondary"]["speedup_vs_cpu_baseline"] = round(line["secondary"]["value"] / cb2["value"], 1)

@@ -123,9 +123,14 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             s_irp[2 * (K + 1) + t] = w.ir_var_ptr[v0 + t + 1];
         }
         if (STAGE_IR)
-            for (int t = tid; t < 20 * ne; t += SWEEP_BLOCK) {
-                const int c = t / ne, j = t - c * ne;
-                s_ir[j * IR_STRIDE + c] = (c < 4) ? w.ir_fv_eta[(size_t)c * w.NI + ie0 + j] : w.ir_fv_lam[(size_t)(c - 4) * w.NI + ie0 + j];
+            for (int j = tid; j < ne; j += SWEEP_BLOCK) {  // 20 independent loads in flight per lane
+                double m[20];
+#pragma unroll
+                for (int c = 0; c < 4; c++) m[c] = w.ir_fv_eta[(size_t)c * w.NI + ie0 + j];
+#pragma unroll
+                for (int c = 0; c < 16; c++) m[4 + c] = w.ir_fv_lam[(size_t)c * w.NI + ie0 + j];
+#pragma unroll
+                for (int c = 0; c < 20; c++) s_ir[j * IR_STRIDE + c] = m[c];
             }
     }
     int itf = w.iter_factor[r];  // iteration_count.factor (every lane applies the same increments)
@@ -323,6 +328,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         }
     };
 
+    STAMP(t_extf);
     // ======================= external variable sweep ==========================================
     if (ext_mask & PH_EXT_VARIABLE) {
         // beliefs are recomputed, nothing is delivered to own factors (factorgraph.rs:794-826): the
@@ -348,6 +354,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         __syncthreads();
     }
 
+    STAMP(t_extv);
     // ======================= internal iterations ==============================================
     {
         const SdfView sdf = make_sdf_view(w.sdf, w.sdf_w, w.sdf_h, w.world_w, w.world_h);
@@ -470,6 +477,8 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             d[0] = c_f; d[1] = c_fb; d[2] = c_v; d[3] = c_vb; d[4] = __builtin_readcyclecounter() - t_loop0;
             d[5] = __builtin_amdgcn_s_memrealtime() - rt0;  // 100 MHz ticks over the same span
             d[6] = t_staged - t_k0;
+            d[0] = (d[0] & 0xffffffffull) | ((t_extf - t_staged) << 32);  // external factor sweep (high word)
+            d[1] = (d[1] & 0xffffffffull) | ((t_extv - t_extf) << 32);    // external variable sweep (high word)
         }
 #endif
     }

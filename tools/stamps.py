@@ -33,8 +33,13 @@ for name, kw in (("config2", dict(interrobot=False)), ("config3", dict(interrobo
     L.mgx_debug_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32]
     buf = (C.c_ulonglong * (1004 * 16))()
     n = L.mgx_debug_read_stamps(w._w, buf, len(buf))
-    a = np.array(buf[:n], dtype=np.float64).reshape(-1, 2, 8)
-    a = a[a[:, 0, 4] > 0]
+    raw = np.array(buf[:n], dtype=np.uint64).reshape(-1, 2, 8)
+    ext_f, ext_v = (raw[:, :, 0] >> np.uint64(32)).astype(np.float64), (raw[:, :, 1] >> np.uint64(32)).astype(np.float64)
+    raw[:, :, 0] &= np.uint64(0xffffffff)
+    raw[:, :, 1] &= np.uint64(0xffffffff)
+    a = raw.astype(np.float64)
+    print(f"{name}: external factor sweep {ext_f[ext_f > 0].mean() if (ext_f > 0).any() else 0:.0f} cycles, external variable sweep {ext_v[ext_v > 0].mean() if (ext_v > 0).any() else 0:.0f} cycles")
+    a = a[a[:, 0, 7] > 0]
     it = n_iter if name == "config2" else 1
     for role, rn in ((0, "DYN"), (1, "UV ")):
         f, fb, v, vb, tot = (a[:, role, k].mean() / it for k in range(5))
