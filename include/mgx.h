@@ -133,9 +133,13 @@ int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n);
  * bit1 = external variable sweep + routing) and then `n_internal` internal iterations of the
  * phases in `internal_phases` (bit0 = internal factor sweep, bit1 = internal variable sweep;
  * n_internal > 1 needs both).  A sharded driver uses it to place its halo exchange between
- * an internal and the following external phase.  robot = -1: all robots. */
+ * an internal and the following external phase.  robot = -1: all robots.
+ * hints: MGX_HINT_NEXT_STARTS_EXTERNAL — a promise that the next sweep of this world starts with an
+ * external factor sweep and that no flag / topology / prior change happens in between; the
+ * inter-robot messages computed here are then not stored to HBM (they are recomputed first). */
+#define MGX_HINT_NEXT_STARTS_EXTERNAL 1u
 int mgx_sweep(mgx_world *w, int32_t robot, uint32_t external_phases, uint32_t internal_phases,
-              uint32_t n_internal);
+              uint32_t n_internal, uint32_t hints);
 
 /* Fine-grained mirrors of FactorGraph::{internal_factor_iteration,
  * internal_variable_iteration, external_factor_iteration, external_variable_iteration}

@@ -38,6 +38,16 @@ struct BlobLayout {
     __host__ __device__ constexpr int words() const { return 61 * K + 20 * E1; }
 };
 
+// One inter-robot factor F_AB as seen from its target variable B.var_i.
+struct IrEdgeRec {
+    int32_t src_var;    // snapshot index of the owner's variable A.var_i
+    int32_t src_robot;  // device index of A
+    uint32_t created;   // epoch of A.var_i when the factor was created (its inbox slot is empty until then)
+    int32_t dst;        // local index i of the target variable | (1 << 16 if B has the higher order key)
+    double d_safe;      // safety distance of the OWNER (interrobot.rs:64)
+    double offset;      // tiny offset 1e-6f * robot_number (interrobot.rs:52,75)
+};
+
 struct DevWorld {
     int R_local, R_total, K, E;
     int V, EI, ND, NT, NI;
@@ -64,12 +74,9 @@ struct DevWorld {
     // inter-robot edges (at the target variable)
     const int32_t *ir_var_ptr;    // [R_local * K + 1]
     const int32_t *ir_var_mid;    // [R_local * K] first edge whose owner has a HIGHER graph key
-    const int32_t *ir_src_var;    // [NI] snapshot index of the owner's variable
-    const int32_t *ir_dst_var;    // [NI] target variable
-    const int32_t *ir_src_robot;  // [NI]
-    const double *ir_dsafe, *ir_off;
-    const uint8_t *ir_dst_slot;   // 1 if the target graph has the higher order key
-    const uint32_t *ir_created;   // epoch of the owner's variable when the factor was created
+    const IrEdgeRec *ir_rec;      // [NI] constants of each edge (one 32-byte load)
+    const uint8_t *ir_gate;       // [NI] 1 iff the OWNER robot is on air (antenna on, not idle): refreshed with
+                                  //      the flags so that the edge lane needs no dependent flag loads
     double *ir_fv_eta, *ir_fv_lam;  // [4][NI],[16][NI] factor -> target variable
     double *ir_bmu;                 // [4][NI] mean of the target variable -> factor message (the
                                     // only part of that inbox entry the kept output depends on)
@@ -92,5 +99,8 @@ constexpr uint32_t PH_EXT_FACTOR = 1u;    // external_factor_iteration (+ routin
 constexpr uint32_t PH_EXT_VARIABLE = 2u;  // external_variable_iteration (+ routing)
 constexpr uint32_t PH_INT_FACTOR = 4u;    // internal_factor_iteration
 constexpr uint32_t PH_INT_VARIABLE = 8u;  // internal_variable_iteration
+
+// launch hints
+constexpr uint32_t HINT_IR_DEAD = 1u;  // the next sweep recomputes every inter-robot message this one computes
 
 }  // namespace mgx

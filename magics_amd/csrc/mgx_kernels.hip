@@ -82,7 +82,7 @@ __device__ __forceinline__ void copy_words(double *dst, const double *src, int n
 
 template <int KT, bool STAGE_IR>
 __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int robot0, uint32_t ext_mask, uint32_t int_mask,
-                                                             int n_int, int snap_out) {
+                                                             int n_int, int snap_out, uint32_t hints) {
     STAMP(t_k0);
     const int r = robot0 + blockIdx.x;
     const int tid = threadIdx.x;
@@ -122,8 +122,12 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             s_irp[(K + 1) + t] = w.ir_var_mid[v0 + t];
             s_irp[2 * (K + 1) + t] = w.ir_var_ptr[v0 + t + 1];
         }
+        // messages that this launch's external factor sweep recomputes before anyone reads them are
+        // not fetched
+        const bool recompute = (ext_mask & PH_EXT_FACTOR) && radio && ir_on;
         if (STAGE_IR)
             for (int j = tid; j < ne; j += SWEEP_BLOCK) {  // 20 independent loads in flight per lane
+                if (recompute && w.ir_gate[ie0 + j]) continue;
                 double m[20];
 #pragma unroll
                 for (int c = 0; c < 4; c++) m[c] = w.ir_fv_eta[(size_t)c * w.NI + ie0 + j];
@@ -189,13 +193,13 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         if (radio && ir_on) {
             for (int j = tid; j < ne; j += SWEEP_BLOCK) {
                 const int e = ie0 + j;
-                const int A = w.ir_src_robot[e];
-                if (!(w.antenna[A] != 0 && w.idle[A] == 0)) continue;  // A did not run its sweep
-                const int s = w.ir_src_var[e];
+                if (!w.ir_gate[e]) continue;  // the owner did not run its external factor sweep
+                const IrEdgeRec er = w.ir_rec[e];
                 double ao_eta[4], ao_lam[16], a_mu[4], b_mu[4];
-                const bool a_present = w.snap_epoch[w.cur][s] > w.ir_created[e];
+                ld_soa4(w.ir_bmu, w.NI, e, b_mu);
+                const bool a_present = w.snap_epoch[w.cur][er.src_var] > er.created;
                 if (a_present) {
-                    const double *rec = w.snap[w.cur] + (size_t)s * SNAP_W;
+                    const double *rec = w.snap[w.cur] + (size_t)er.src_var * SNAP_W;
 #pragma unroll
                     for (int c = 0; c < 4; c++) ao_eta[c] = rec[c];
 #pragma unroll
@@ -208,22 +212,26 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #pragma unroll
                     for (int c = 0; c < 16; c++) ao_lam[c] = 0.0;
                 }
-                ld_soa4(w.ir_bmu, w.NI, e, b_mu);
-                const int dslot = w.ir_dst_slot[e];
+                const int dslot = er.dst >> 16;
                 double oe[4], ol[16];
                 bool ok;
                 if (dslot)
-                    ok = interrobot_message(a_mu, b_mu, w.ir_dsafe[e], w.ir_off[e], w.inv_s2_ir, 1, ao_eta, ao_lam, oe, ol);
+                    ok = interrobot_message(a_mu, b_mu, er.d_safe, er.offset, w.inv_s2_ir, 1, ao_eta, ao_lam, oe, ol);
                 else
-                    ok = interrobot_message(b_mu, a_mu, w.ir_dsafe[e], w.ir_off[e], w.inv_s2_ir, 0, ao_eta, ao_lam, oe, ol);
+                    ok = interrobot_message(b_mu, a_mu, er.d_safe, er.offset, w.inv_s2_ir, 0, ao_eta, ao_lam, oe, ol);
                 if (!ok) {
 #pragma unroll
                     for (int c = 0; c < 4; c++) oe[c] = 0.0;
 #pragma unroll
                     for (int c = 0; c < 16; c++) ol[c] = 0.0;
                 }
-                st_soa4(w.ir_fv_eta, w.NI, e, oe);
-                st_soa16(w.ir_fv_lam, w.NI, e, ol);
+                // HINT_IR_DEAD: the caller's next sweep recomputes these messages before reading them
+                // (it starts with an external factor sweep under the same flags), and this launch
+                // reads them from LDS — then the HBM copy is dead and not stored
+                if (!(STAGE_IR && (hints & HINT_IR_DEAD))) {
+                    st_soa4(w.ir_fv_eta, w.NI, e, oe);
+                    st_soa16(w.ir_fv_lam, w.NI, e, ol);
+                }
                 if (STAGE_IR) {
 #pragma unroll
                     for (int c = 0; c < 4; c++) s_ir[j * IR_STRIDE + c] = oe[c];
@@ -269,17 +277,29 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             for (int c = 0; c < 5; c++) acc[c] = pr[c];
             const int x0 = s_irp[i], xm = s_irp[(K + 1) + i], x1 = s_irp[2 * (K + 1) + i];
             auto ir_rows = [&](int e_from, int e_to) {
-                for (int e = e_from; e < e_to; e++) {
-                    if (STAGE_IR) {
-                        const double *m = s_ir + (e - ie0) * IR_STRIDE;
-                        acc[0] += m[rr];
+                // foreign messages are added in inbox order; four at a time are fetched before the adds
+                for (int e = e_from; e < e_to; e += 4) {
+                    double m[4][5];
 #pragma unroll
-                        for (int c = 0; c < 4; c++) acc[1 + c] += m[4 + rr * 4 + c];
-                    } else {
-                        acc[0] += w.ir_fv_eta[(size_t)rr * w.NI + e];
+                    for (int u = 0; u < 4; u++) {
+                        const int ee = (e + u < e_to) ? e + u : e;  // clamp: the value is not added
+                        if (STAGE_IR) {
+                            const double *p = s_ir + (ee - ie0) * IR_STRIDE;
+                            m[u][0] = p[rr];
 #pragma unroll
-                        for (int c = 0; c < 4; c++) acc[1 + c] += w.ir_fv_lam[(size_t)(rr * 4 + c) * w.NI + e];
+                            for (int c = 0; c < 4; c++) m[u][1 + c] = p[4 + rr * 4 + c];
+                        } else {
+                            m[u][0] = w.ir_fv_eta[(size_t)rr * w.NI + ee];
+#pragma unroll
+                            for (int c = 0; c < 4; c++) m[u][1 + c] = w.ir_fv_lam[(size_t)(rr * 4 + c) * w.NI + ee];
+                        }
                     }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (e + u < e_to) {
+#pragma unroll
+                            for (int c = 0; c < 5; c++) acc[c] += m[u][c];
+                        }
                 }
             };
             ir_rows(x0, xm);
@@ -344,9 +364,8 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             // linearisation point; eta / lam of the target side never reach the kept message)
             for (int j = tid; j < ne; j += SWEEP_BLOCK) {
                 const int e = ie0 + j;
-                const int A = w.ir_src_robot[e];
-                if (!(w.antenna[A] != 0 && w.idle[A] == 0)) continue;  // A cannot receive
-                const int i = w.ir_dst_var[e] - v0;
+                if (!w.ir_gate[e]) continue;  // the owner cannot receive
+                const int i = w.ir_rec[e].dst & 0xffff;
 #pragma unroll
                 for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = s_mu[c * K + i] - 0.0;
             }
@@ -588,28 +607,28 @@ int blob_words(int K) { const BlobLayout L(K); return (L.words() + 1) & ~1; }
 
 template <int KT>
 static void launch_k(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, uint32_t int_mask, int n_int, int snap_out,
-                     hipStream_t stream) {
+                     uint32_t hints, hipStream_t stream) {
     // staging the inter-robot messages needs IR_STRIDE f64 per edge; beyond 64 KB of LDS fall back to
     // reading them from L2 in every variable sweep
     const size_t staged = sweep_lds_bytes(w.K, w.ir_max_edges);
     if (staged <= 64 * 1024)
         hipLaunchKernelGGL((k_robot_sweep<KT, true>), dim3(n_robots), dim3(SWEEP_BLOCK), staged, stream, w, robot0, ext_mask,
-                           int_mask, n_int, snap_out);
+                           int_mask, n_int, snap_out, hints);
     else
         hipLaunchKernelGGL((k_robot_sweep<KT, false>), dim3(n_robots), dim3(SWEEP_BLOCK), sweep_lds_bytes(w.K, 0), stream, w,
-                           robot0, ext_mask, int_mask, n_int, snap_out);
+                           robot0, ext_mask, int_mask, n_int, snap_out, hints);
 }
 
 hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, uint32_t int_mask, int n_int,
-                              int snap_out, hipStream_t stream) {
+                              int snap_out, uint32_t hints, hipStream_t stream) {
     if (n_robots <= 0) return hipSuccess;
     switch (w.K) {  // horizon lengths of BASELINE.json / the reference scenarios get constant-K code
-    case 10: launch_k<10>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
-    case 12: launch_k<12>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
-    case 16: launch_k<16>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
-    case 21: launch_k<21>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
-    case 32: launch_k<32>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
-    default: launch_k<0>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, stream); break;
+    case 10: launch_k<10>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;
+    case 12: launch_k<12>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;
+    case 16: launch_k<16>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;
+    case 21: launch_k<21>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;
+    case 32: launch_k<32>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;
+    default: launch_k<0>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;
     }
     return hipGetLastError();
 }

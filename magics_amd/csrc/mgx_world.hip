@@ -27,7 +27,7 @@ size_t sweep_lds_bytes(int K, int ir_edges);
 int blob_words(int K);
 bool sweep_supports(int K);
 hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, uint32_t int_mask, int n_int,
-                              int snap_out, hipStream_t stream);
+                              int snap_out, uint32_t hints, hipStream_t stream);
 hipError_t launch_change_prior(const DevWorld &w, int n, const int32_t *robots, const uint32_t *vars, const double *means,
                                hipStream_t stream);
 hipError_t launch_halo_pack(const DevWorld &w, int n, const int32_t *robots, double *buf, hipStream_t stream);
@@ -136,11 +136,13 @@ struct mgx_world {
     std::vector<int> robot_of;   // device robot index -> robot id
     std::vector<int> edge_conn, edge_i;  // device ir edge -> (conn index, i-1)
 
-    DevBuf<double> blob, snap0, snap1, dyn_m, trk_last_val, ir_dsafe, ir_off, ir_fv_eta, ir_fv_lam, ir_bmu;
-    DevBuf<int32_t> trk_record, path_ptr, iter_factor, ir_var_ptr, ir_var_mid, ir_src_var, ir_dst_var, ir_src_robot;
-    DevBuf<uint32_t> epoch0, epoch1, ir_created;
+    DevBuf<double> blob, snap0, snap1, dyn_m, trk_last_val, ir_fv_eta, ir_fv_lam, ir_bmu;
+    DevBuf<IrEdgeRec> ir_rec;
+    std::vector<int32_t> edge_src_robot;  // device robot index of each edge's owner (for the gates)
+    DevBuf<int32_t> trk_record, path_ptr, iter_factor, ir_var_ptr, ir_var_mid;
+    DevBuf<uint32_t> epoch0, epoch1;
     DevBuf<float> trk_last_pos, path_xy;
-    DevBuf<uint8_t> ir_dst_slot, antenna, idle, sdf;
+    DevBuf<uint8_t> ir_gate, antenna, idle, sdf;
     // scratch for change_prior / halo index lists
     DevBuf<int32_t> tmp_i32;
     DevBuf<uint32_t> tmp_u32;
@@ -311,11 +313,18 @@ static int upload_flags(mgx_world *w) {
         an[dr] = w->robots[(size_t)w->robot_of[dr]].antenna;
         id[dr] = w->robots[(size_t)w->robot_of[dr]].idle;
     }
+    std::vector<uint8_t> gate(std::max<size_t>(w->edge_src_robot.size(), 1), 0);
+    for (size_t e = 0; e < w->edge_src_robot.size(); e++) {
+        const size_t a = (size_t)w->edge_src_robot[e];
+        gate[e] = (an[a] && !id[a]) ? 1 : 0;
+    }
     HIP_TRY(w->antenna.upload(an, w->stream));
     HIP_TRY(w->idle.upload(id, w->stream));
+    HIP_TRY(w->ir_gate.upload(gate, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));  // `an`/`id` are pageable temporaries
     w->d.antenna = w->antenna.p;
     w->d.idle = w->idle.p;
+    w->d.ir_gate = w->ir_gate.p;
     w->flags_dirty = false;
     return MGX_OK;
 }
@@ -367,10 +376,10 @@ static int commit(mgx_world *w) {
         for (size_t j = 0; j < c.edges.size(); j++)
             per_var[(size_t)dt * K + j + 1].push_back({(int)ci, (int)j, w->robots[(size_t)c.owner].order_key});
     }
-    std::vector<int32_t> var_ptr((size_t)R_local * K + 1, 0), var_mid((size_t)R_local * K, 0), src_var, dst_var, src_robot;
-    std::vector<double> dsafe, off, ife, ifl, ibm;
-    std::vector<uint8_t> dslot;
-    std::vector<uint32_t> created;
+    std::vector<int32_t> var_ptr((size_t)R_local * K + 1, 0), var_mid((size_t)R_local * K, 0);
+    std::vector<IrEdgeRec> recs;
+    std::vector<double> ife, ifl, ibm;
+    w->edge_src_robot.clear();
     w->edge_conn.clear();
     w->edge_i.clear();
     size_t NI = 0;
@@ -392,13 +401,15 @@ static int commit(mgx_world *w) {
             const IrConn &c = w->conns[(size_t)rf.conn];
             const Robot &ow = w->robots[(size_t)c.owner], &ot = w->robots[(size_t)c.other];
             const IrEdge &ed = c.edges[(size_t)rf.j];
-            src_var.push_back(w->dev_of[(size_t)c.owner] * K + rf.j + 1);
-            dst_var.push_back((int32_t)v);
-            src_robot.push_back(w->dev_of[(size_t)c.owner]);
-            dsafe.push_back(w->p.safety_multiplier * ow.radius);  // interrobot.rs:64
-            off.push_back((double)1e-6f * (double)(c.first_number + (uint64_t)rf.j));  // interrobot.rs:52,75
-            dslot.push_back(ot.order_key > ow.order_key ? 1 : 0);
-            created.push_back(ed.created);
+            IrEdgeRec rec;
+            rec.src_var = w->dev_of[(size_t)c.owner] * K + rf.j + 1;
+            rec.src_robot = w->dev_of[(size_t)c.owner];
+            rec.created = ed.created;
+            rec.dst = (int32_t)(v % (size_t)K) | ((ot.order_key > ow.order_key) ? (1 << 16) : 0);
+            rec.d_safe = w->p.safety_multiplier * ow.radius;                            // interrobot.rs:64
+            rec.offset = (double)1e-6f * (double)(c.first_number + (uint64_t)rf.j);    // interrobot.rs:52,75
+            recs.push_back(rec);
+            w->edge_src_robot.push_back(rec.src_robot);
             scatter(ife, NIs, e, ed.fv_eta, 4);
             scatter(ifl, NIs, e, ed.fv_lam, 16);
             scatter(ibm, NIs, e, ed.bmu, 4);
@@ -440,10 +451,7 @@ static int commit(mgx_world *w) {
         itf[(size_t)dr] = rb.iter_factor;
     }
     if (pxy.empty()) pxy.assign(2, 0.f);
-    if (src_var.empty()) {
-        src_var.assign(1, 0); dst_var.assign(1, 0); src_robot.assign(1, 0); dsafe.assign(1, 0.0); off.assign(1, 0.0);
-        dslot.assign(1, 0); created.assign(1, 0);
-    }
+    if (recs.empty()) recs.push_back(IrEdgeRec{0, 0, 0, 0, 0.0, 0.0});
     if (w->sdf_red.empty()) {  // no image: every lookup is "outside" => h = 0
         w->sdf_red.assign(1, 255);
         w->sdf_w = w->sdf_h = 0;
@@ -464,13 +472,7 @@ static int commit(mgx_world *w) {
     HIP_TRY(w->iter_factor.upload(itf, s));
     HIP_TRY(w->ir_var_ptr.upload(var_ptr, s));
     HIP_TRY(w->ir_var_mid.upload(var_mid, s));
-    HIP_TRY(w->ir_src_var.upload(src_var, s));
-    HIP_TRY(w->ir_dst_var.upload(dst_var, s));
-    HIP_TRY(w->ir_src_robot.upload(src_robot, s));
-    HIP_TRY(w->ir_dsafe.upload(dsafe, s));
-    HIP_TRY(w->ir_off.upload(off, s));
-    HIP_TRY(w->ir_dst_slot.upload(dslot, s));
-    HIP_TRY(w->ir_created.upload(created, s));
+    HIP_TRY(w->ir_rec.upload(recs, s));
     HIP_TRY(w->ir_fv_eta.upload(ife, s));
     HIP_TRY(w->ir_fv_lam.upload(ifl, s));
     HIP_TRY(w->ir_bmu.upload(ibm, s));
@@ -489,9 +491,7 @@ static int commit(mgx_world *w) {
     d.dyn_m = w->dyn_m.p;
     d.trk_record = w->trk_record.p; d.trk_last_pos = w->trk_last_pos.p; d.trk_last_val = w->trk_last_val.p;
     d.path_ptr = w->path_ptr.p; d.path_xy = w->path_xy.p; d.iter_factor = w->iter_factor.p;
-    d.ir_var_ptr = w->ir_var_ptr.p; d.ir_var_mid = w->ir_var_mid.p; d.ir_src_var = w->ir_src_var.p; d.ir_dst_var = w->ir_dst_var.p;
-    d.ir_src_robot = w->ir_src_robot.p; d.ir_dsafe = w->ir_dsafe.p; d.ir_off = w->ir_off.p;
-    d.ir_dst_slot = w->ir_dst_slot.p; d.ir_created = w->ir_created.p;
+    d.ir_var_ptr = w->ir_var_ptr.p; d.ir_var_mid = w->ir_var_mid.p; d.ir_rec = w->ir_rec.p;
     d.ir_fv_eta = w->ir_fv_eta.p; d.ir_fv_lam = w->ir_fv_lam.p; d.ir_bmu = w->ir_bmu.p;
     d.sdf = w->sdf.p; d.sdf_w = w->sdf_w; d.sdf_h = w->sdf_h; d.world_w = w->world_w; d.world_h = w->world_h;
     // ObstacleFactor::new jacobian_delta (obstacle.rs:98-102)
@@ -518,19 +518,19 @@ static int commit(mgx_world *w) {
 }
 
 // ---- launches -----------------------------------------------------------------------------------------
-static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_mask, int n_int) {
+static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_mask, int n_int, uint32_t hints = 0) {
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
     const bool writes_snap = (int_mask & PH_INT_VARIABLE) && n_int > 0;
     if (robot < 0) {
         const int out = writes_snap ? 1 - w->d.cur : -1;
-        HIP_TRY(launch_robot_sweep(w->d, 0, w->d.R_local, ext_mask, int_mask, n_int, out, w->stream));
+        HIP_TRY(launch_robot_sweep(w->d, 0, w->d.R_local, ext_mask, int_mask, n_int, out, hints, w->stream));
         if (writes_snap) w->d.cur ^= 1;
     } else {
         if ((size_t)robot >= w->robots.size() || w->robots[(size_t)robot].ghost) return fail(MGX_ERR_INVALID, "bad robot id %d", robot);
         if (ext_mask) return fail(MGX_ERR_INVALID, "external sweeps are world-wide (robot must be -1)");
         // single workgroup: nobody else reads the snapshot buffer concurrently => update in place
-        HIP_TRY(launch_robot_sweep(w->d, w->dev_of[(size_t)robot], 1, 0, int_mask, n_int, writes_snap ? w->d.cur : -1, w->stream));
+        HIP_TRY(launch_robot_sweep(w->d, w->dev_of[(size_t)robot], 1, 0, int_mask, n_int, writes_snap ? w->d.cur : -1, 0, w->stream));
     }
     return MGX_OK;
 }
@@ -684,11 +684,14 @@ int mgx_set_idle(mgx_world *w, int32_t robot, int32_t idle) {
     return MGX_OK;
 }
 
-int mgx_sweep(mgx_world *w, int32_t robot, uint32_t external_phases, uint32_t internal_phases, uint32_t n_internal) {
+int mgx_sweep(mgx_world *w, int32_t robot, uint32_t external_phases, uint32_t internal_phases, uint32_t n_internal,
+              uint32_t hints) {
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if ((external_phases & ~3u) || (internal_phases & ~3u)) return fail(MGX_ERR_INVALID, "bad phase mask");
+    if (hints & ~MGX_HINT_NEXT_STARTS_EXTERNAL) return fail(MGX_ERR_INVALID, "bad hints");
     if (n_internal > 1 && internal_phases != 3u) return fail(MGX_ERR_INVALID, "fused iterations need both internal phases");
-    return sweep(w, robot, external_phases, internal_phases << 2, internal_phases ? (int)n_internal : 0);
+    const uint32_t h = ((hints & MGX_HINT_NEXT_STARTS_EXTERNAL) && (external_phases & 1u)) ? HINT_IR_DEAD : 0u;
+    return sweep(w, robot, external_phases, internal_phases << 2, internal_phases ? (int)n_internal : 0, h);
 }
 
 int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n) {
@@ -706,7 +709,10 @@ int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n) {
         if (ph[i] == 'E') { ext = PH_EXT_FACTOR | PH_EXT_VARIABLE; i++; }
         int n_int = 0;
         while (i < ph.size() && ph[i] == 'I') { n_int++; i++; }
-        int rc = sweep(w, -1, ext, n_int ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, n_int);
+        // the next launch of this call (if any) starts with an external phase: the inter-robot messages
+        // this launch computes are recomputed before anything reads their HBM copy
+        const uint32_t hints = (ext && i < ph.size()) ? HINT_IR_DEAD : 0u;
+        int rc = sweep(w, -1, ext, n_int ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, n_int, hints);
         if (rc != MGX_OK) return rc;
     }
     return MGX_OK;

@@ -123,15 +123,17 @@ class ShardedWorld:
         self.comm.all_to_all(self.recv_buf, self.send_buf, self.recv_counts, self.send_counts)
         self.unpack()
 
-    def sweep_segment(self, ext, n_int):
-        self.world.sweep(PH_FACTOR | PH_VARIABLE if ext else 0, PH_FACTOR | PH_VARIABLE if n_int else 0, n_int)
+    def sweep_segment(self, ext, n_int, next_ext=False):
+        hints = hostlib.HINT_NEXT_STARTS_EXTERNAL if (ext and next_ext) else 0
+        self.world.sweep(PH_FACTOR | PH_VARIABLE if ext else 0, PH_FACTOR | PH_VARIABLE if n_int else 0, n_int, hints=hints)
 
     # -- World-like interface over global robot ids -------------------------------------------------
     def iterate(self, steps):
-        for ext, n_int in segments(steps):
+        segs = segments(steps)
+        for k, (ext, n_int) in enumerate(segs):
             if ext:
                 self.exchange()
-            self.sweep_segment(ext, n_int)
+            self.sweep_segment(ext, n_int, next_ext=k + 1 < len(segs) and segs[k + 1][0])
 
     def set_antenna(self, robot, active):
         if robot in self.lid:
@@ -203,11 +205,12 @@ class LocalCluster:
             sw.unpack()
 
     def iterate(self, steps):
-        for ext, n_int in segments(steps):
+        segs = segments(steps)
+        for k, (ext, n_int) in enumerate(segs):
             if ext and len(self.ranks) > 1:
                 self._exchange()
             for sw in self.ranks:
-                sw.sweep_segment(ext, n_int)
+                sw.sweep_segment(ext, n_int, next_ext=k + 1 < len(segs) and segs[k + 1][0])
 
     def set_antenna(self, robot, active):
         for sw in self.ranks:

@@ -113,8 +113,8 @@ class World:
         steps = bytes(bytearray(int(s) for s in steps))
         self._chk(self._L.mgx_iterate(self._w, steps, len(steps)))
 
-    def sweep(self, external_phases, internal_phases, n_internal=1, robot=-1):
-        self._chk(self._L.mgx_sweep(self._w, robot, external_phases, internal_phases, n_internal))
+    def sweep(self, external_phases, internal_phases, n_internal=1, robot=-1, hints=0):
+        self._chk(self._L.mgx_sweep(self._w, robot, external_phases, internal_phases, n_internal, hints))
 
     def internal_factor_iteration(self, robot=-1):
         self._chk(self._L.mgx_internal_factor_iteration(self._w, robot))

@@ -46,7 +46,7 @@ extern "C" {
     pub fn mgx_set_antenna(w: *mut mgx_world, robot: i32, active: i32) -> c_int;
     pub fn mgx_set_idle(w: *mut mgx_world, robot: i32, idle: i32) -> c_int;
     pub fn mgx_iterate(w: *mut mgx_world, steps: *const u8, n: u32) -> c_int;
-    pub fn mgx_sweep(w: *mut mgx_world, robot: i32, external_phases: u32, internal_phases: u32, n_internal: u32) -> c_int;
+    pub fn mgx_sweep(w: *mut mgx_world, robot: i32, external_phases: u32, internal_phases: u32, n_internal: u32, hints: u32) -> c_int;
     pub fn mgx_internal_factor_iteration(w: *mut mgx_world, robot: i32) -> c_int;
     pub fn mgx_internal_variable_iteration(w: *mut mgx_world, robot: i32) -> c_int;
     pub fn mgx_external_factor_iteration(w: *mut mgx_world, robot: i32) -> c_int;

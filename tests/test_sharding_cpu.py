@@ -63,7 +63,7 @@ class FakeWorld:
             assert (buf[j * w + 2:(j + 1) * w] == self.robots[r]["key"]).all()
             self.robots[r]["version"] = int(buf[j * w + 1])
 
-    def sweep(self, ext, internal, n_int):
+    def sweep(self, ext, internal, n_int, hints=0):
         if ext:
             for a, b in self.conns:  # every factor evaluated here sees its owner's latest snapshot
                 assert self.robots[a]["version"] == self.version, (self.robots[a], self.version)
