@@ -190,6 +190,21 @@ def main():
                     "robot's graph in LDS for its 10 iterations, so real HBM traffic is far below it",
         },
     }
+    # whole driver ticks: prior updates of the current and horizon state of every robot
+    # (one launch, robot.rs:2182-2338) + the 10-step schedule; includes the host-side argument upload
+    tk = S.tick_inputs(sc)
+    n_ticks = max(10, a.steps // 20)
+    for _ in range(5):
+        w.update_priors(**tk)
+        w.iterate(steps)
+    w.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_ticks):
+        w.update_priors(**tk)
+        w.iterate(steps)
+    w.synchronize()
+    line["tick"] = {"value": round(n_ticks / (time.perf_counter() - t0), 1), "unit": "driver ticks/s per GPU",
+                    "what": "update_prior_of_horizon_state + update_prior_of_current_state_v3 for all robots, then 10 GBP iterations"}
     w.synchronize()
 
     # ---- secondary: configs[2]/[3], + inter-robot factors, robots sharded with halo exchange ------

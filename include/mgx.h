@@ -158,6 +158,16 @@ int mgx_change_prior(mgx_world *w, int32_t robot, uint32_t var_ix, const double 
 int mgx_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, const uint32_t *var_ix,
                       const double *means);
 
+/* The driver's per-tick prior updates, batched over robots in one launch:
+ *   what[i] & 1: update_prior_of_horizon_state (robot.rs:2182-2283) — the last variable of robots[i]
+ *                moves towards waypoints_xy[i] at min(max_speed, distance) for delta_t seconds;
+ *   what[i] & 2: update_prior_of_current_state_v3 (robot.rs:2286-2338) — variable 0 moves by
+ *                time_scale[i] * (mean_1 - mean_0), time_scale = fixed_dt / t0 (an f32 quotient widened).
+ * Each ends in change_prior of that variable.  The caller lists the robots the reference's systems would
+ * not skip (not idle / not finished / with a next waypoint) and keeps the mission logic. */
+int mgx_update_priors(mgx_world *w, uint32_t n, const int32_t *robots, const double *waypoints_xy,
+                      const double *time_scale, const uint8_t *what, double max_speed, double delta_t);
+
 /* ---- read-back ----------------------------------------------------------------------- */
 /* VariableNode.belief (variable.rs:40-54).  Any output pointer may be NULL. */
 int mgx_get_belief(mgx_world *w, int32_t robot, uint32_t var_ix, double eta[4], double lam[16],

@@ -523,17 +523,13 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 }
 
 // VariableNode::change_prior + routing (variable.rs:203-230, factorgraph.rs:494-528,
-// robot.rs:2262-2282).  One thread per (robot, variable, mean) triple.
-__global__ void k_change_prior(DevWorld w, int n, const int32_t *robots, const uint32_t *vars, const double *means) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const int r = robots[t], i = (int)vars[t], K = w.K, E = w.E, E1 = E + 1;
+// robot.rs:2262-2282) for variable i of robot r.
+__device__ void apply_change_prior(const DevWorld &w, int r, int i, const double (&m)[4]) {
+    const int K = w.K, E = w.E, E1 = E + 1;
     const BlobLayout L(K);
     double *b = w.blob + (size_t)r * w.BS;
     const int v = r * K + i;
-    double m[4], pl[16], be[4], bl[16];
-#pragma unroll
-    for (int c = 0; c < 4; c++) m[c] = means[4 * t + c];
+    double pl[16], be[4], bl[16];
 #pragma unroll
     for (int c = 0; c < 16; c++) pl[c] = b[L.prior() + (4 + c) * K + i];
 #pragma unroll
@@ -572,6 +568,53 @@ __global__ void k_change_prior(DevWorld w, int n, const int32_t *robots, const u
         if (es[q] < 0) continue;
 #pragma unroll
         for (int c = 0; c < 20; c++) b[L.fv() + c * E1 + es[q]] = 0.0;
+    }
+}
+
+// One thread per (robot, variable, mean) triple.
+__global__ void k_change_prior(DevWorld w, int n, const int32_t *robots, const uint32_t *vars, const double *means) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double m[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) m[c] = means[4 * t + c];
+    apply_change_prior(w, robots[t], (int)vars[t], m);
+}
+
+// The per-tick prior updates of the driver, one thread per listed robot:
+//   what & 1: update_prior_of_horizon_state (robot.rs:2182-2283): the last variable moves towards the
+//             waypoint at min(max_speed, distance);
+//   what & 2: update_prior_of_current_state_v3 (robot.rs:2286-2338): variable 0 moves by
+//             time_scale * (mean_1 - mean_0).
+// Both end in change_prior of that variable.  The reference runs the horizon system for every robot
+// before the current-state system; for K >= 3 the two touch disjoint state of a robot.
+__global__ void k_update_priors(DevWorld w, int n, const int32_t *robots, const double *waypoints, const double *time_scale,
+                                const uint8_t *what, double max_speed, double delta_t) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int r = robots[t], K = w.K;
+    const BlobLayout L(K);
+    const double *b = w.blob + (size_t)r * w.BS;
+    if (what[t] & 1u) {
+        const int i = K - 1;
+        const double ex = b[L.mu() + 0 * K + i], ey = b[L.mu() + 1 * K + i];  // estimated position (:2242)
+        double hx = waypoints[2 * t] - ex, hy = waypoints[2 * t + 1] - ey;     // horizon2waypoint
+        const double dist = std::sqrt(hx * hx + hy * hy);                       // euclidean_norm
+        double nx = hx, ny = hy;                                                 // .normalized(): unchanged if |.| is 0 / inf
+        if (!(dist == 0.0 || std::isinf(dist))) { nx = hx / dist; ny = hy / dist; }
+        const double sp = (max_speed < dist || dist != dist) ? max_speed : dist;  // Float::min(max_speed, dist)
+        const double vx = sp * nx, vy = sp * ny;                                 // new_velocity
+        const double m[4] = {ex + vx * delta_t, ey + vy * delta_t, vx, vy};      // (:2253-2256)
+        apply_change_prior(w, r, i, m);
+    }
+    if (what[t] & 2u) {
+        double m[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const double m0 = b[L.mu() + c * K + 0], m1 = b[L.mu() + c * K + 1];
+            m[c] = m0 + time_scale[t] * (m1 - m0);  // (:2309-2316)
+        }
+        apply_change_prior(w, r, 0, m);
     }
 }
 
@@ -636,6 +679,13 @@ hipError_t launch_change_prior(const DevWorld &w, int n, const int32_t *robots, 
                                hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_change_prior, dim3((n + 63) / 64), dim3(64), 0, stream, w, n, robots, vars, means);
+    return hipGetLastError();
+}
+hipError_t launch_update_priors(const DevWorld &w, int n, const int32_t *robots, const double *waypoints, const double *time_scale,
+                                const uint8_t *what, double max_speed, double delta_t, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_update_priors, dim3((n + 63) / 64), dim3(64), 0, stream, w, n, robots, waypoints, time_scale, what, max_speed,
+                       delta_t);
     return hipGetLastError();
 }
 hipError_t launch_halo_pack(const DevWorld &w, int n, const int32_t *robots, double *buf, hipStream_t stream) {

@@ -30,6 +30,8 @@ hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint3
                               int snap_out, uint32_t hints, hipStream_t stream);
 hipError_t launch_change_prior(const DevWorld &w, int n, const int32_t *robots, const uint32_t *vars, const double *means,
                                hipStream_t stream);
+hipError_t launch_update_priors(const DevWorld &w, int n, const int32_t *robots, const double *waypoints, const double *time_scale,
+                                const uint8_t *what, double max_speed, double delta_t, hipStream_t stream);
 hipError_t launch_halo_pack(const DevWorld &w, int n, const int32_t *robots, double *buf, hipStream_t stream);
 hipError_t launch_halo_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *buf, hipStream_t stream);
 }  // namespace mgx
@@ -146,7 +148,8 @@ struct mgx_world {
     // scratch for change_prior / halo index lists
     DevBuf<int32_t> tmp_i32;
     DevBuf<uint32_t> tmp_u32;
-    DevBuf<double> tmp_f64;
+    DevBuf<double> tmp_f64, tmp_f64b;
+    DevBuf<uint8_t> tmp_u8;
     DevBuf<unsigned long long> dbg;  // diagnostic builds only
     // halo plan: local robots whose snapshots are sent / ghost robots that receive, in buffer order
     std::vector<int32_t> halo_send, halo_recv;
@@ -744,6 +747,30 @@ int mgx_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, const uin
     HIP_TRY(hipStreamSynchronize(w->stream));
     return MGX_OK;
 }
+int mgx_update_priors(mgx_world *w, uint32_t n, const int32_t *robots, const double *waypoints_xy, const double *time_scale,
+                      const uint8_t *what, double max_speed, double delta_t) {
+    if (!w || !robots || !waypoints_xy || !time_scale || !what) return fail(MGX_ERR_INVALID, "null argument");
+    if (n == 0) return MGX_OK;
+    if (w->K < 3) return fail(MGX_ERR_INVALID, "needs K >= 3");
+    for (uint32_t i = 0; i < n; i++)
+        if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size() || w->robots[(size_t)robots[i]].ghost || (what[i] & ~3u))
+            return fail(MGX_ERR_INVALID, "bad entry %u", i);
+    int rc = commit(w);
+    if (rc != MGX_OK) return rc;
+    std::vector<int32_t> dr(n);
+    for (uint32_t i = 0; i < n; i++) dr[i] = w->dev_of[(size_t)robots[i]];
+    std::vector<double> wp(waypoints_xy, waypoints_xy + 2 * (size_t)n), ts(time_scale, time_scale + n);
+    std::vector<uint8_t> wh(what, what + n);
+    HIP_TRY(hipStreamSynchronize(w->stream));  // previous users of the scratch buffers
+    HIP_TRY(w->tmp_i32.upload(dr, w->stream));
+    HIP_TRY(w->tmp_f64.upload(wp, w->stream));
+    HIP_TRY(w->tmp_f64b.upload(ts, w->stream));
+    HIP_TRY(w->tmp_u8.upload(wh, w->stream));
+    HIP_TRY(launch_update_priors(w->d, (int)n, w->tmp_i32.p, w->tmp_f64.p, w->tmp_f64b.p, w->tmp_u8.p, max_speed, delta_t, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    return MGX_OK;
+}
+
 int mgx_change_prior(mgx_world *w, int32_t robot, uint32_t var_ix, const double mean[4]) {
     return mgx_change_priors(w, 1, &robot, &var_ix, mean);
 }

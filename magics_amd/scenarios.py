@@ -181,14 +181,14 @@ def grid_scenario(n_robots, K=16, interrobot=False, comm_radius=8.0, obstacles=T
             d = (g - s) / np.linalg.norm(g - s)
             path = np.array([s, s + 30.0 * d, s + 60.0 * d], dtype=F32)
         robots.append(dict(mean0=mean0, prior_diag=prior, dt=dt, radius=radius, path=path, order_key=r,
-                           pos=pos[r]))
+                           pos=pos[r], goal=np.array(goals[r][:2]), t0=F32(radius) / F32(2.0) / F32(target_speed)))
     pairs = []
     if interrobot:
         pairs = neighbour_pairs(pos, comm_radius)
     ir = number_ir_pairs(pairs, K)
     n_ext = n_external if n_external is not None else (n_internal if interrobot else 0)
     steps = hostlib.schedule(schedule_kind, n_internal, n_ext)
-    return dict(params=params, sdf=sdf, robots=robots, ir=ir, steps=steps, K=K, positions=pos,
+    return dict(params=params, sdf=sdf, robots=robots, ir=ir, steps=steps, K=K, positions=pos, target_speed=target_speed,
                 name=f"grid{total}x{K}{'+ir' if interrobot else ''}{'+trk' if tracking else ''}")
 
 
@@ -240,7 +240,7 @@ def circle_scenario(n_robots=10, K=10, circle_radius=50.0, seed=805, n_internal=
         radius = f32w(rng.uniform(2.0, 3.0))
         mean0, prior, dt = robot_initial_state((x, y, vx, vy), (-x, -y, vx, vy), ts, radius, target_speed, 3.0)
         robots.append(dict(mean0=mean0, prior_diag=prior, dt=dt, radius=radius, path=None, order_key=r,
-                           pos=np.array([x, y])))
+                           pos=np.array([x, y]), goal=np.array([-x, -y]), t0=F32(radius) / F32(2.0) / F32(target_speed)))
         pos.append((x, y))
     pos = np.array(pos)
     world = 4 * circle_radius
@@ -249,7 +249,17 @@ def circle_scenario(n_robots=10, K=10, circle_radius=50.0, seed=805, n_internal=
     ir = number_ir_pairs(neighbour_pairs(pos, circle_radius), K)
     steps = hostlib.schedule(hostlib.SCHEDULE_INTERLEAVE_EVENLY, n_internal, n_external)
     return dict(params=params, sdf=sdf, robots=robots, ir=ir, steps=steps, K=K, positions=pos,
-                name=f"circle{n_robots}x{K}")
+                name=f"circle{n_robots}x{K}", target_speed=target_speed)
+
+
+def tick_inputs(sc, hz=10.0):
+    """Arguments of `update_priors` for one driver tick at `hz` (FixedUpdate, config.simulation.hz):
+    every robot heads for its goal; time_scale = fixed_dt / t0 as an f32 quotient (robot.rs:2309)."""
+    n = len(sc["robots"])
+    dt32 = F32(1.0) / F32(hz)
+    return dict(robots=np.arange(n, dtype=np.int32), waypoints_xy=np.array([rb["goal"] for rb in sc["robots"]], dtype=np.float64),
+                time_scale=np.array([float(dt32 / rb["t0"]) for rb in sc["robots"]]), what=np.full(n, 3, dtype=np.uint8),
+                max_speed=f32w(sc["target_speed"]), delta_t=float(dt32))
 
 
 def populate(world, sc, robots=None):

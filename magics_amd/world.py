@@ -139,6 +139,17 @@ class World:
         self._chk(self._L.mgx_change_priors(self._w, len(robots), robots.ctypes.data_as(C.POINTER(C.c_int32)),
                                         var_ix.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(means)))
 
+    def update_priors(self, robots, waypoints_xy, time_scale, what, max_speed, delta_t):
+        """update_prior_of_horizon_state (what & 1) / update_prior_of_current_state_v3 (what & 2) for the
+        listed robots (robot.rs:2182-2338)."""
+        robots = np.ascontiguousarray(robots, dtype=np.int32)
+        n = len(robots)
+        wp = _f64(waypoints_xy, (n, 2))
+        ts = _f64(time_scale, (n,))
+        what = np.ascontiguousarray(what, dtype=np.uint8)
+        self._chk(self._L.mgx_update_priors(self._w, n, robots.ctypes.data_as(C.POINTER(C.c_int32)), _dp(wp), _dp(ts),
+                                            what.ctypes.data_as(C.POINTER(C.c_uint8)), float(max_speed), float(delta_t)))
+
     # -- read-back -----------------------------------------------------------------------------
     def get_belief(self, robot, var_ix):
         eta, lam, mean, cov = np.zeros(4), np.zeros((4, 4)), np.zeros(4), np.zeros((4, 4))

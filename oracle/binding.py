@@ -70,6 +70,8 @@ def _bind(path):
     for n in ("internal_factor", "internal_variable", "external_factor", "external_variable"):
         getattr(L, f"orc_{n}_iteration").argtypes = [C.c_void_p, C.c_int32]
     L.orc_change_prior.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, c_double_p]
+    L.orc_update_priors.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), c_double_p, c_double_p, C.POINTER(C.c_uint8),
+                                    C.c_double, C.c_double]
     L.orc_get_belief.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, c_double_p, c_double_p, c_double_p,
                                  c_double_p, C.POINTER(C.c_int32)]
     L.orc_read_beliefs.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p]
@@ -216,6 +218,14 @@ class OracleWorld:
         means = _f64(means)
         for r, v, m in zip(robots, var_ix, means):
             self.change_prior(int(r), int(v), m)
+
+    def update_priors(self, robots, waypoints_xy, time_scale, what, max_speed, delta_t):
+        robots = np.ascontiguousarray(robots, dtype=np.int32)
+        n = len(robots)
+        wp, ts = _f64(waypoints_xy, (n, 2)), _f64(time_scale, (n,))
+        what = np.ascontiguousarray(what, dtype=np.uint8)
+        self._chk(self._L.orc_update_priors(self._w, n, robots.ctypes.data_as(C.POINTER(C.c_int32)), _dp(wp), _dp(ts),
+                                            what.ctypes.data_as(C.POINTER(C.c_uint8)), float(max_speed), float(delta_t)))
 
     def get_belief(self, robot, var_ix):
         eta, lam, mean, cov = np.zeros(4), np.zeros((4, 4)), np.zeros(4), np.zeros((4, 4))

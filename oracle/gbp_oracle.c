@@ -1066,6 +1066,41 @@ int orc_change_prior(World *w, int32_t r, uint32_t var_ix, const double *mean) {
     return ORC_OK;
 }
 
+/* update_prior_of_horizon_state (ROBOT:2182-2283) and update_prior_of_current_state_v3
+ * (ROBOT:2286-2338) for the listed robots; the caller has already applied the systems' skip rules
+ * (finished / idle / no next waypoint).  The reference runs the first system over all robots, then
+ * the second. */
+int orc_update_priors(World *w, uint32_t n, const int32_t *robots, const double *waypoints_xy, const double *time_scale,
+                      const uint8_t *what, double max_speed, double delta_t) {
+    for (uint32_t t = 0; t < n; t++) {
+        if (!(what[t] & 1u)) continue;
+        Graph *g = &w->g[robots[t]];
+        Variable *hv = &g->nodes[g->var_indices[g->K - 1]].v; /* last_variable_mut :2239 */
+        double est[2] = {hv->mu[0], hv->mu[1]};                /* :2242 */
+        double h2w[2] = {waypoints_xy[2 * t] - est[0], waypoints_xy[2 * t + 1] - est[1]}; /* :2251 */
+        double dist = euclidean_norm(h2w, 2);                  /* :2252 */
+        double nrm[2] = {h2w[0], h2w[1]};
+        normalize(nrm, 2);
+        double sp = fmin(max_speed, dist);                      /* Float::min :2254 */
+        double vel[2] = {sp * nrm[0], sp * nrm[1]};
+        double mean[4] = {est[0] + vel[0] * delta_t, est[1] + vel[1] * delta_t, vel[0], vel[1]}; /* :2255-2258 */
+        memcpy(hv->mu, mean, sizeof mean);                      /* :2263 */
+        orc_change_prior(w, robots[t], (uint32_t)(g->K - 1), mean); /* :2266-2282 */
+    }
+    for (uint32_t t = 0; t < n; t++) {
+        if (!(what[t] & 2u)) continue;
+        Graph *g = &w->g[robots[t]];
+        const Variable *v0 = &g->nodes[g->var_indices[0]].v, *v1 = &g->nodes[g->var_indices[1]].v;
+        double mean[4];
+        for (int c = 0; c < 4; c++) { /* :2309-2316 */
+            double change = time_scale[t] * (v1->mu[c] - v0->mu[c]);
+            mean[c] = v0->mu[c] + change;
+        }
+        orc_change_prior(w, robots[t], 0u, mean); /* :2318-2322 */
+    }
+    return ORC_OK;
+}
+
 int orc_get_belief(World *w, int32_t r, uint32_t var_ix, double *eta, double *lam, double *mean,
                    double *cov, int32_t *valid) {
     if (!w || r < 0 || r >= w->n || (int)var_ix >= w->g[r].K) return ORC_ERR_INVALID;
