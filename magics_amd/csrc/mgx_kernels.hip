@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         trk_lv = w.trk_last_val[trk_item];
     }
     __syncthreads();
-    uint32_t my_epoch = (tid < 4 * K) ? s_epoch[tid >> 2] : 0u;  // deliveries of the variable this thread sums
+    uint32_t my_epoch = (tid < 4 * K) ? s_epoch[tid % K] : 0u;  // deliveries of the variable this thread sums
     STAMP(t_staged);
 
     // ======================= external factor sweep (pull form) ================================
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // s_out receives the sums ([20][K] image: the snapshot for internal sweeps).
     auto variable_sums = [&](double *s_out, bool internal, bool last) {
         for (int t = tid; t < 4 * K; t += SWEEP_BLOCK) {
-            const int i = t >> 2, rr = t & 3;
+            const int rr = t / K, i = t - rr * K;  // consecutive lanes -> consecutive variables: conflict-free LDS rows
             uint32_t epoch_reg = (4 * K <= SWEEP_BLOCK) ? my_epoch : s_epoch[i];
             const int es[4] = {(i >= 1) ? (K - 1) + (i - 1) : ZCOL, (i <= K - 2) ? i : ZCOL,
                                (i >= 1 && i <= K - 2) ? n_dyn + (i - 1) : ZCOL,
