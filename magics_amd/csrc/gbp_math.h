@@ -17,41 +17,60 @@
 
 namespace mgx {
 
-// 4x4 inverse by adjugate / determinant.  Returns false iff det == 0 exactly — the
-// `Option` contract of ndarray-inverse 0.1.9 `inv()` used at variable.rs:153,278 and
-// factor/marginalise_factor_distance.rs:79.
+// 4x4 inverse by cofactor expansion — the `Option` contract of ndarray-inverse 0.1.9 `inv()` used at
+// variable.rs:153,278 and factor/marginalise_factor_distance.rs:79: `None` iff det == 0 exactly.
+//   cofactor(i, j) = (-1)^(i+j) * det3(rows != i, columns != j),
+//   det3([[a b c],[d e f],[g h k]]) = (a (e k - f h) - b (d k - f g)) + c (d h - e g),
+//   det = ((m00 C00 + m01 C01) + m02 C02) + m03 C03,   inverse[j][i] = C(i, j) * (1 / det).
+// Every cofactor is the SAME expression of the three remaining rows, so a row of cofactors can be
+// computed by one lane from the other three rows of the matrix (the four-lane forms below) with
+// results identical to this single-lane form.
+
+// unsigned minors of the row that was removed: r0, r1, r2 are the remaining rows in ascending order
+MGX_HD void minors_of_removed_row(const double (&r0)[4], const double (&r1)[4], const double (&r2)[4], double (&mn)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int c0 = (j == 0) ? 1 : 0, c1 = (j <= 1) ? 2 : 1, c2 = (j <= 2) ? 3 : 2;
+        const double a = r0[c0], b = r0[c1], c = r0[c2];
+        const double d = r1[c0], e = r1[c1], f = r1[c2];
+        const double g = r2[c0], h = r2[c1], k = r2[c2];
+        mn[j] = (a * (e * k - f * h) - b * (d * k - f * g)) + c * (d * h - e * g);
+    }
+}
+// cofactors C(i, 0..3) of row i from the minors of that row
+MGX_HD void cofactors_from_minors(int i, const double (&mn)[4], double (&cf)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) cf[j] = ((i + j) & 1) ? -mn[j] : mn[j];
+}
+MGX_HD double det_from_row0(const double (&row0)[4], const double (&cf0)[4]) {
+    return ((row0[0] * cf0[0] + row0[1] * cf0[1]) + row0[2] * cf0[2]) + row0[3] * cf0[3];
+}
+
 MGX_HD bool inv4(const double (&m)[16], double (&o)[16]) {
-    const double s0 = m[0] * m[5] - m[4] * m[1];
-    const double s1 = m[0] * m[6] - m[4] * m[2];
-    const double s2 = m[0] * m[7] - m[4] * m[3];
-    const double s3 = m[1] * m[6] - m[5] * m[2];
-    const double s4 = m[1] * m[7] - m[5] * m[3];
-    const double s5 = m[2] * m[7] - m[6] * m[3];
-    const double c5 = m[10] * m[15] - m[14] * m[11];
-    const double c4 = m[9] * m[15] - m[13] * m[11];
-    const double c3 = m[9] * m[14] - m[13] * m[10];
-    const double c2 = m[8] * m[15] - m[12] * m[11];
-    const double c1 = m[8] * m[14] - m[12] * m[10];
-    const double c0 = m[8] * m[13] - m[12] * m[9];
-    const double det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    double cf[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double rows[3][4];
+        int n = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (r != i) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) rows[n][c] = m[r * 4 + c];
+                n++;
+            }
+        double mn[4];
+        minors_of_removed_row(rows[0], rows[1], rows[2], mn);
+        cofactors_from_minors(i, mn, cf[i]);
+    }
+    const double row0[4] = {m[0], m[1], m[2], m[3]};
+    const double det = det_from_row0(row0, cf[0]);
     if (det == 0.0) return false;
     const double id = 1.0 / det;
-    o[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * id;
-    o[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * id;
-    o[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * id;
-    o[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * id;
-    o[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * id;
-    o[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * id;
-    o[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * id;
-    o[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * id;
-    o[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * id;
-    o[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * id;
-    o[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * id;
-    o[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * id;
-    o[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * id;
-    o[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * id;
-    o[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * id;
-    o[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * id;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j * 4 + i] = cf[i][j] * id;
     return true;
 }
 

@@ -190,41 +190,36 @@ static void matvec(const double *A, const double *x, double *y, int m, int n) {
     }
 }
 
-/* ndarray-inverse 0.1.9 `Inverse::inv` for a 4x4 (Cargo.lock:4870): determinant by
- * cofactors; det == 0 => None; else adjugate / det.  (Third-party, source absent from
- * /root/reference: restated from its published contract, see header.) */
+/* ndarray-inverse 0.1.9 `Inverse::inv` for a 4x4 (Cargo.lock:4870).  Third-party, source absent
+ * from /root/reference: restated from its published contract (`None` when the determinant is
+ * exactly 0, cofactor / determinant inverse) as the plain cofactor expansion:
+ *   C(i,j) = (-1)^(i+j) det3(rows != i, cols != j),
+ *   det3([[a b c],[d e f],[g h k]]) = (a (e k - f h) - b (d k - f g)) + c (d h - e g),
+ *   det = ((m00 C00 + m01 C01) + m02 C02) + m03 C03,  inverse[j][i] = C(i,j) * (1/det). */
+static double det3(const double *r0, const double *r1, const double *r2, int j) {
+    int c0 = (j == 0) ? 1 : 0, c1 = (j <= 1) ? 2 : 1, c2 = (j <= 2) ? 3 : 2;
+    double a = r0[c0], b = r0[c1], c = r0[c2];
+    double d = r1[c0], e = r1[c1], f = r1[c2];
+    double g = r2[c0], h = r2[c1], k = r2[c2];
+    return (a * (e * k - f * h) - b * (d * k - f * g)) + c * (d * h - e * g);
+}
 static int inv4(const double *m, double *out) {
-    double s0 = m[0] * m[5] - m[4] * m[1];
-    double s1 = m[0] * m[6] - m[4] * m[2];
-    double s2 = m[0] * m[7] - m[4] * m[3];
-    double s3 = m[1] * m[6] - m[5] * m[2];
-    double s4 = m[1] * m[7] - m[5] * m[3];
-    double s5 = m[2] * m[7] - m[6] * m[3];
-    double c5 = m[10] * m[15] - m[14] * m[11];
-    double c4 = m[9] * m[15] - m[13] * m[11];
-    double c3 = m[9] * m[14] - m[13] * m[10];
-    double c2 = m[8] * m[15] - m[12] * m[11];
-    double c1 = m[8] * m[14] - m[12] * m[10];
-    double c0 = m[8] * m[13] - m[12] * m[9];
-    double det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    double cf[4][4];
+    for (int i = 0; i < 4; i++) {
+        const double *rows[3];
+        int n = 0;
+        for (int r = 0; r < 4; r++)
+            if (r != i) rows[n++] = m + 4 * r;
+        for (int j = 0; j < 4; j++) {
+            double mn = det3(rows[0], rows[1], rows[2], j);
+            cf[i][j] = ((i + j) & 1) ? -mn : mn;
+        }
+    }
+    double det = ((m[0] * cf[0][0] + m[1] * cf[0][1]) + m[2] * cf[0][2]) + m[3] * cf[0][3];
     if (det == 0.0) return 0;
     double id = 1.0 / det;
-    out[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * id;
-    out[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * id;
-    out[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * id;
-    out[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * id;
-    out[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * id;
-    out[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * id;
-    out[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * id;
-    out[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * id;
-    out[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * id;
-    out[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * id;
-    out[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * id;
-    out[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * id;
-    out[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * id;
-    out[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * id;
-    out[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * id;
-    out[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * id;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) out[j * 4 + i] = cf[i][j] * id;
     return 1;
 }
 int orc_inv4(const double *m, double *out) { return inv4(m, out); }
