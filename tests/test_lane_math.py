@@ -64,6 +64,24 @@ def test_dynamic_message_vs_dense(H):
             np.testing.assert_allclose(oe, we, rtol=1e-9, atol=1e-9 * scale)
 
 
+def test_four_lane_dynamic_message_equals_single_lane_bitwise(H):
+    # the DYN waves split one message over four lanes; every element must be the single-lane value
+    rng = np.random.default_rng(7)
+    for trial in range(200):
+        dt, sigma = rng.uniform(0.1, 0.5), rng.uniform(0.05, 1.0)
+        M = np.ascontiguousarray(_dyn_full(dt, sigma)[::2, ::2])
+        a = rng.normal(size=(4, 4))
+        lo = a @ a.T * 10 ** rng.uniform(-3, 6) if trial % 5 else np.zeros((4, 4))
+        eo = rng.normal(size=4) * 10 ** rng.uniform(-2, 4)
+        for slot in (0, 1):
+            e1, l1, e4, l4 = np.zeros(4), np.zeros((4, 4)), np.zeros(4), np.zeros((4, 4))
+            ok1 = H.h_dynamic_message(dp(M), slot, dp(eo), dp(lo), dp(e1), dp(l1))
+            ok4 = H.h_dynamic_message_4lane(dp(M), slot, dp(eo), dp(lo), dp(e4), dp(l4))
+            assert ok1 == ok4
+            if ok1:
+                assert np.array_equal(e1, e4) and np.array_equal(l1, l4)
+
+
 def test_interrobot_message_vs_dense(H):
     rng = np.random.default_rng(1)
     H.h_interrobot_message.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int,
