@@ -122,6 +122,38 @@ int mgx_ir_disconnect(mgx_world *w, int32_t a, int32_t b);
 int mgx_set_antenna(mgx_world *w, int32_t robot, int32_t active);
 int mgx_set_idle(mgx_world *w, int32_t robot, int32_t idle);
 
+/* update_failed_comms (robot.rs:1593-1601) writes every antenna once per tick: bulk form.
+ * The Bernoulli draws stay with the caller (the reference uses Bevy's GlobalEntropy<WyRand>). */
+int mgx_set_antennas(mgx_world *w, uint32_t n, const int32_t *robots, const uint8_t *active);
+
+/* ---- dynamic inter-robot topology (robot.rs:1362-1586) ----------------------------------- */
+#define MGX_NEIGHBOURS_AUTO 0u  /* all-pairs kernel below 512 robots, hash grid above */
+#define MGX_NEIGHBOURS_PAIRS 1u /* all-pairs kernel (what the reference does on the CPU) */
+#define MGX_NEIGHBOURS_GRID 2u  /* uniform hash grid, 3x3 cells of ~radius (falls back to all
+                                   pairs when radius is not positive and finite) */
+/* update_robot_neighbours (robot.rs:1362-1384): `positions_xyz` = Transform::translation of
+ * every robot of the world in id order (host, n x 3 f32).  Robot j is in range of i (j != i)
+ * unless `radius < |p_i - p_j|` in f32 (so a NaN distance is in range).  CSR result on the
+ * host: row_ptr[n+1], rows ascending in Entity order (= order_key) like the BTreeSet
+ * robots_within_comms_range.  neighbours_out may be NULL to size the call (*needed). */
+int mgx_neighbours(mgx_world *w, const float *positions_xyz, float radius, uint32_t method,
+                   int32_t *row_ptr, int32_t *neighbours_out, uint64_t capacity,
+                   uint64_t *needed);
+/* One pass of update_robot_neighbours + delete_interrobot_factors + create_interrobot_factors
+ * (robot.rs:86-99,1362-1586), including the reference's bookkeeping quirk: the pairs to delete
+ * go through a HashMap<RobotId,RobotId> (robot.rs:1391-1404), so per robot only the
+ * largest-id out-of-range peer gets its factors deleted in that pass, the rest only leave
+ * robots_connected_with (and get a second set of factors if they come back in range).
+ * `robot_number_next` is RobotNumberGenerator (robot.rs:122-140), advanced by one per created
+ * factor.  stats (optional) = {connections created (one direction each), pairs deleted}.
+ * Existing state survives: the device state is pulled to the host before the tables are
+ * rebuilt, only when something changed. */
+int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, uint32_t method,
+                        uint64_t *robot_number_next, uint32_t *stats);
+/* RobotConnections::robots_connected_with of one robot (robot.rs:515-531), ascending.
+ * others may be NULL to query the count. */
+int mgx_connections(mgx_world *w, int32_t robot, int32_t *others, uint32_t capacity, uint32_t *n);
+
 /* ---- the hot path ------------------------------------------------------------------ */
 /* iterate_gbp_v2 (robot.rs:1769-1861): runs `n` schedule steps, step i doing the
  * internal phase if steps[i] & MGX_STEP_INTERNAL and the external phase if

@@ -1,0 +1,210 @@
+// mgx_topology.hip — comms-range neighbour search on the device (update_robot_neighbours,
+// crates/magics/src/planner/robot.rs:1362-1384): for every robot the set of other robots j with
+// NOT (radius < |p_i - p_j|), f32 distance as glam's Vec3::distance.  The reference scans all
+// pairs ("TODO: use kdtree", robot.rs:1368); here a uniform hash grid of cell size ~radius
+// bounds the candidates to 3x3 cells, and an all-pairs kernel covers small worlds and the
+// degenerate inputs (non-finite positions, radius <= 0 or NaN) with the same predicate.
+//
+// Output is CSR (ptr[n+1], idx[]) with every row ascending in robot index.  Integer result:
+// identical to the all-pairs scan by construction (the grid only prunes pairs whose x or z
+// separation alone exceeds the radius).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "gbp_math.h"
+
+namespace mgx {
+
+// |a-b| as f32 Vec3::distance: sqrt((dx*dx + dy*dy) + dz*dz), each operation rounded to f32.
+// Written through f64 (53 >= 2*24+2 bits: every double rounding is innocuous) so that no
+// contraction setting can fuse the products into the sums.
+__device__ __forceinline__ bool in_comms_range(float ax, float ay, float az, float bx, float by, float bz, float radius) {
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    const float px = (float)((double)dx * (double)dx), py = (float)((double)dy * (double)dy), pz = (float)((double)dz * (double)dz);
+    const float s = (float)((double)(float)((double)px + (double)py) + (double)pz);
+    const float d = (float)sqrt((double)s);
+    return !(radius < d);
+}
+
+__device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
+
+// cell coordinate of one axis: floor(x / cell) in f64, clamped (monotone, so robots within one
+// radius of each other stay within one cell of each other)
+__device__ __forceinline__ int cell_of(float x, double inv_cell) {
+    double c = floor((double)x * inv_cell);
+    c = fmin(fmax(c, -1073741824.0), 1073741824.0);
+    return (int)c;
+}
+__device__ __forceinline__ uint32_t bucket_of(int cx, int cz, uint32_t mask) {
+    return (((uint32_t)cx * 73856093u) ^ ((uint32_t)cz * 19349663u)) & mask;
+}
+
+// ---- all pairs ------------------------------------------------------------------------------------
+// one thread per robot i, positions of j staged through LDS in tiles; FILL = second pass
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_pairs(const float *__restrict__ pos, int n, float radius, int32_t *__restrict__ cnt,
+                                                const int32_t *__restrict__ ptr, int32_t *__restrict__ idx) {
+    __shared__ float tile[256 * 3];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n;
+    const float ax = live ? pos[3 * i] : 0.f, ay = live ? pos[3 * i + 1] : 0.f, az = live ? pos[3 * i + 2] : 0.f;
+    int m = 0;
+    int32_t out = (FILL && live) ? ptr[i] : 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int nj = min(256, n - j0);
+        __syncthreads();
+        for (int q = threadIdx.x; q < 3 * nj; q += 256) tile[q] = pos[3 * j0 + q];
+        __syncthreads();
+        if (live)
+            for (int q = 0; q < nj; q++) {
+                const int j = j0 + q;
+                if (j != i && in_comms_range(ax, ay, az, tile[3 * q], tile[3 * q + 1], tile[3 * q + 2], radius)) {
+                    if (FILL) idx[out + m] = j;
+                    m++;
+                }
+            }
+    }
+    if (!FILL && live) cnt[i] = m;
+}
+
+// ---- hash grid ------------------------------------------------------------------------------------
+// bucket histogram; robots with a non-finite coordinate go to the `special` list instead
+__global__ void k_grid_hist(const float *__restrict__ pos, int n, double inv_cell, uint32_t mask, int32_t *__restrict__ bucket_cnt,
+                            int32_t *__restrict__ special, int32_t *__restrict__ n_special) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
+    if (!finite3(x, y, z)) {
+        special[atomicAdd(n_special, 1)] = i;
+        return;
+    }
+    atomicAdd(&bucket_cnt[bucket_of(cell_of(x, inv_cell), cell_of(z, inv_cell), mask)], 1);
+}
+__global__ void k_grid_scatter(const float *__restrict__ pos, int n, double inv_cell, uint32_t mask,
+                               const int32_t *__restrict__ bucket_ptr, int32_t *__restrict__ cursor, int32_t *__restrict__ members) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
+    if (!finite3(x, y, z)) return;
+    const uint32_t b = bucket_of(cell_of(x, inv_cell), cell_of(z, inv_cell), mask);
+    members[bucket_ptr[b] + atomicAdd(&cursor[b], 1)] = i;
+}
+
+// exclusive scan of a[0..n) into out[0..n], out[n] = total; one workgroup of 1024 threads
+__global__ void __launch_bounds__(1024) k_scan(const int32_t *__restrict__ a, int n, int32_t *__restrict__ out) {
+    __shared__ int32_t part[1024];
+    const int t = threadIdx.x;
+    const int chunk = (n + 1023) / 1024;
+    const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
+    int32_t s = 0;
+    for (int q = lo; q < hi; q++) s += a[q];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int32_t v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int32_t run = part[t] - s;
+    for (int q = lo; q < hi; q++) {
+        out[q] = run;
+        run += a[q];
+    }
+    if (t == 1023) out[n] = part[1023];
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_grid_query(const float *__restrict__ pos, int n, float radius, double inv_cell, uint32_t mask,
+                                                     const int32_t *__restrict__ bucket_ptr, const int32_t *__restrict__ members,
+                                                     const int32_t *__restrict__ special, const int32_t *__restrict__ n_special,
+                                                     int32_t *__restrict__ cnt, const int32_t *__restrict__ ptr,
+                                                     int32_t *__restrict__ idx) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float ax = pos[3 * i], ay = pos[3 * i + 1], az = pos[3 * i + 2];
+    const int32_t base = FILL ? ptr[i] : 0;
+    int m = 0;
+    auto test = [&](int j) {
+        if (j == i) return;
+        if (in_comms_range(ax, ay, az, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], radius)) {
+            if (FILL) idx[base + m] = j;
+            m++;
+        }
+    };
+    if (!finite3(ax, ay, az)) {  // NaN distance counts as "in range": compare with everybody
+        for (int j = 0; j < n; j++) test(j);
+    } else {
+        const int cx = cell_of(ax, inv_cell), cz = cell_of(az, inv_cell);
+        uint32_t seen[9];
+        int ns = 0;
+        for (int dz = -1; dz <= 1; dz++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const uint32_t b = bucket_of(cx + dx, cz + dz, mask);
+                bool dup = false;
+                for (int q = 0; q < ns; q++) dup |= seen[q] == b;
+                if (dup) continue;  // two of the nine cells hash to one bucket: visit it once
+                seen[ns++] = b;
+                for (int q = bucket_ptr[b]; q < bucket_ptr[b + 1]; q++) test(members[q]);
+            }
+        const int nsp = *n_special;
+        for (int q = 0; q < nsp; q++) test(special[q]);
+    }
+    if (!FILL) {
+        cnt[i] = m;
+    } else {  // rows ascending in robot index (candidates arrive in bucket order)
+        for (int a = 1; a < m; a++) {
+            const int32_t v = idx[base + a];
+            int b = a;
+            while (b > 0 && idx[base + b - 1] > v) {
+                idx[base + b] = idx[base + b - 1];
+                b--;
+            }
+            idx[base + b] = v;
+        }
+    }
+}
+
+// ---- host-side sequencing ---------------------------------------------------------------------------
+// Scratch (all device): cnt[n], bucket_cnt[M], bucket_ptr[M+1], cursor[M], members[n], special[n],
+// n_special[1].  `ptr` is [n+1].  Phase 1 leaves the row counts scanned in `ptr`; the caller
+// reads ptr[n], sizes `idx` and runs phase 2.
+hipError_t neighbours_count(const float *pos, int n, float radius, bool grid, uint32_t M, int32_t *cnt, int32_t *bucket_cnt,
+                            int32_t *bucket_ptr, int32_t *cursor, int32_t *members, int32_t *special, int32_t *n_special,
+                            int32_t *ptr, hipStream_t s) {
+    if (n <= 0) return hipMemsetAsync(ptr, 0, sizeof(int32_t), s);
+    const dim3 g256((unsigned)((n + 255) / 256));
+    if (grid) {
+        const double inv_cell = 1.0 / ((double)radius * 1.001);
+        hipError_t e = hipMemsetAsync(bucket_cnt, 0, sizeof(int32_t) * M, s);
+        if (e != hipSuccess) return e;
+        if ((e = hipMemsetAsync(cursor, 0, sizeof(int32_t) * M, s)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(n_special, 0, sizeof(int32_t), s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_grid_hist, g256, dim3(256), 0, s, pos, n, inv_cell, M - 1, bucket_cnt, special, n_special);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, bucket_cnt, (int)M, bucket_ptr);
+        hipLaunchKernelGGL(k_grid_scatter, g256, dim3(256), 0, s, pos, n, inv_cell, M - 1, bucket_ptr, cursor, members);
+        hipLaunchKernelGGL(k_grid_query<false>, g256, dim3(256), 0, s, pos, n, radius, inv_cell, M - 1, bucket_ptr, members, special,
+                           n_special, cnt, (const int32_t *)nullptr, (int32_t *)nullptr);
+    } else {
+        hipLaunchKernelGGL(k_pairs<false>, g256, dim3(256), 0, s, pos, n, radius, cnt, (const int32_t *)nullptr, (int32_t *)nullptr);
+    }
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, cnt, n, ptr);
+    return hipGetLastError();
+}
+hipError_t neighbours_fill(const float *pos, int n, float radius, bool grid, uint32_t M, const int32_t *bucket_ptr,
+                           const int32_t *members, const int32_t *special, const int32_t *n_special, const int32_t *ptr,
+                           int32_t *idx, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const dim3 g256((unsigned)((n + 255) / 256));
+    if (grid) {
+        const double inv_cell = 1.0 / ((double)radius * 1.001);
+        hipLaunchKernelGGL(k_grid_query<true>, g256, dim3(256), 0, s, pos, n, radius, inv_cell, M - 1, bucket_ptr, members, special,
+                           n_special, (int32_t *)nullptr, ptr, idx);
+    } else {
+        hipLaunchKernelGGL(k_pairs<true>, g256, dim3(256), 0, s, pos, n, radius, (int32_t *)nullptr, ptr, idx);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mgx

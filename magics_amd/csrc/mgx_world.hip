@@ -34,6 +34,13 @@ hipError_t launch_update_priors(const DevWorld &w, int n, const int32_t *robots,
                                 const uint8_t *what, double max_speed, double delta_t, hipStream_t stream);
 hipError_t launch_halo_pack(const DevWorld &w, int n, const int32_t *robots, double *buf, hipStream_t stream);
 hipError_t launch_halo_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *buf, hipStream_t stream);
+// mgx_topology.hip
+hipError_t neighbours_count(const float *pos, int n, float radius, bool grid, uint32_t M, int32_t *cnt, int32_t *bucket_cnt,
+                            int32_t *bucket_ptr, int32_t *cursor, int32_t *members, int32_t *special, int32_t *n_special,
+                            int32_t *ptr, hipStream_t s);
+hipError_t neighbours_fill(const float *pos, int n, float radius, bool grid, uint32_t M, const int32_t *bucket_ptr,
+                           const int32_t *members, const int32_t *special, const int32_t *n_special, const int32_t *ptr,
+                           int32_t *idx, hipStream_t s);
 }  // namespace mgx
 
 using namespace mgx;
@@ -80,6 +87,17 @@ struct DevBuf {
         if (n) return hipMemcpyAsync(p, h.data(), sizeof(T) * n, hipMemcpyHostToDevice, s);
         return hipSuccess;
     }
+    hipError_t reserve(size_t want) {  // contents undefined afterwards
+        if (want < 1) want = 1;
+        if (want > cap) {
+            release();
+            hipError_t e = hipMalloc((void **)&p, sizeof(T) * want);
+            if (e != hipSuccess) return e;
+            cap = want;
+        }
+        n = want;
+        return hipSuccess;
+    }
     hipError_t download(std::vector<T> &h, hipStream_t s) const {
         h.resize(n);
         if (!n) return hipSuccess;
@@ -105,6 +123,16 @@ struct Robot {
     std::vector<double> trk_last_val;                                             // [K-2]
     std::vector<float> path;                                                      // [n_path][2]
     int32_t iter_factor = 0;
+    // petgraph StableGraph node slots of this robot's graph: K variables, K-1 dynamic, K-2 obstacle
+    // and K-2 tracking factors first (robot.rs:1179-1334), inter-robot factors after; vacated slots
+    // are reused last-freed-first.  Only the ORDER of the indices matters (inbox key order).
+    int n_nodes = 0;
+    std::vector<int> free_nodes;
+    int alloc_node() {
+        if (!free_nodes.empty()) { const int ix = free_nodes.back(); free_nodes.pop_back(); return ix; }
+        return n_nodes++;
+    }
+    std::vector<int> connected;  // RobotConnections::robots_connected_with (robot.rs:515-531), ascending order key
 };
 
 struct IrEdge {  // one InterRobotFactor, kept at its target variable
@@ -116,6 +144,7 @@ struct IrConn {  // K-1 factors owner -> other
     int owner, other;
     uint64_t first_number;
     std::vector<IrEdge> edges;  // index i-1 for variable i
+    std::vector<int> node;      // node slot of each factor in the owner's graph
 };
 
 }  // namespace
@@ -155,6 +184,9 @@ struct mgx_world {
     std::vector<int32_t> halo_send, halo_recv;
     DevBuf<int32_t> halo_send_dev, halo_recv_dev;
     bool halo_dirty = false;
+    // neighbour search scratch (mgx_topology.hip)
+    DevBuf<float> nb_pos;
+    DevBuf<int32_t> nb_cnt, nb_bucket_cnt, nb_bucket_ptr, nb_cursor, nb_members, nb_special, nb_nspecial, nb_ptr, nb_idx;
 };
 
 static bool device_ok() {
@@ -370,14 +402,14 @@ static int commit(mgx_world *w) {
         }
 
     // inter-robot edges grouped by LOCAL target variable, ordered by the owner's order key
-    struct Ref { int conn, j; uint64_t key; };
+    struct Ref { int conn, j; uint64_t key; int node; };
     std::vector<std::vector<Ref>> per_var((size_t)R_local * K);
     for (size_t ci = 0; ci < w->conns.size(); ci++) {
         const IrConn &c = w->conns[ci];
         if (w->robots[(size_t)c.other].ghost) continue;  // target lives on another rank
         const int dt = w->dev_of[(size_t)c.other];
         for (size_t j = 0; j < c.edges.size(); j++)
-            per_var[(size_t)dt * K + j + 1].push_back({(int)ci, (int)j, w->robots[(size_t)c.owner].order_key});
+            per_var[(size_t)dt * K + j + 1].push_back({(int)ci, (int)j, w->robots[(size_t)c.owner].order_key, c.node[j]});
     }
     std::vector<int32_t> var_ptr((size_t)R_local * K + 1, 0), var_mid((size_t)R_local * K, 0);
     std::vector<IrEdgeRec> recs;
@@ -395,7 +427,8 @@ static int commit(mgx_world *w) {
     for (size_t v = 0; v < per_var.size(); v++) {
         var_ptr[v] = (int32_t)e;
         auto &pv = per_var[v];
-        std::sort(pv.begin(), pv.end(), [](const Ref &a, const Ref &b) { return a.key < b.key; });
+        // inbox key order: (graph, node index) — message.rs / id.rs:19-117
+        std::sort(pv.begin(), pv.end(), [](const Ref &a, const Ref &b) { return a.key != b.key ? a.key < b.key : a.node < b.node; });
         const uint64_t own_key = w->robots[(size_t)w->robot_of[v / (size_t)K]].order_key;
         var_mid[v] = (int32_t)(e + pv.size());
         for (size_t q = 0; q < pv.size(); q++)
@@ -598,6 +631,7 @@ int mgx_robot_add(mgx_world *w, const mgx_robot_desc *d, int32_t *robot_id) {
     const int K = (int)d->K, E = 4 * K - 6;
     Robot rb;
     rb.K = K; rb.ghost = d->ghost != 0; rb.radius = d->radius; rb.order_key = d->order_key;
+    rb.n_nodes = K + (K - 1) + 2 * (K - 2);
     rb.prior_eta.assign(4 * K, 0.0); rb.prior_lam.assign(16 * K, 0.0);
     rb.bel_eta.assign(4 * K, 0.0); rb.bel_lam.assign(16 * K, 0.0); rb.bel_mu.assign(4 * K, 0.0); rb.bel_cov.assign(16 * K, 0.0);
     rb.valid.assign(K, 1); rb.snap.assign(24 * K, 0.0); rb.epoch.assign(K, 0);
@@ -645,32 +679,43 @@ int mgx_robot_add(mgx_world *w, const mgx_robot_desc *d, int32_t *robot_id) {
     return MGX_OK;
 }
 
-int mgx_ir_connect(mgx_world *w, int32_t owner, int32_t other, uint64_t first_robot_number) {
+static int ir_connect(mgx_world *w, int32_t owner, int32_t other, uint64_t first_robot_number) {
     if (!w || owner < 0 || other < 0 || (size_t)owner >= w->robots.size() || (size_t)other >= w->robots.size() || owner == other)
         return fail(MGX_ERR_INVALID, "bad robot ids");
     if (first_robot_number == 0) return fail(MGX_ERR_INVALID, "robot_number is NonZeroUsize");
-    for (const IrConn &c : w->conns)
-        if (c.owner == owner && c.other == other) return fail(MGX_ERR_STATE, "already connected");
+    // no "already connected" check: the reference creates whatever its connection sets ask for, and
+    // a pair can legitimately hold two sets of factors (robot.rs:1391-1404, see mgx_update_topology)
     IrConn c;
     c.owner = owner; c.other = other; c.first_number = first_robot_number;
     c.edges.resize((size_t)w->K - 1);
+    c.node.resize((size_t)w->K - 1);
+    for (int &nd : c.node) nd = w->robots[(size_t)owner].alloc_node();  // add_factor, ascending i
     w->conns.push_back(std::move(c));
     w->dirty = true;
     return MGX_OK;
 }
 
-int mgx_ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
+static int ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
     if (!w || a < 0 || b < 0 || (size_t)a >= w->robots.size() || (size_t)b >= w->robots.size() || a == b)
         return fail(MGX_ERR_INVALID, "bad robot ids");
     int rc = pull(w);  // keep the other connections' live state
     if (rc != MGX_OK) return rc;
     w->dev_valid = false;
-    size_t before = w->conns.size();
+    // delete_interrobot_factors_connected_to on both graphs (factorgraph.rs:380-436): the node
+    // slots are vacated in ascending index order
+    for (int side = 0; side < 2; side++) {
+        const int self = side ? b : a, other = side ? a : b;
+        std::vector<int> gone;
+        for (const IrConn &c : w->conns)
+            if (c.owner == self && c.other == other) gone.insert(gone.end(), c.node.begin(), c.node.end());
+        std::sort(gone.begin(), gone.end());
+        std::vector<int> &fr = w->robots[(size_t)self].free_nodes;
+        fr.insert(fr.end(), gone.begin(), gone.end());
+    }
     w->conns.erase(std::remove_if(w->conns.begin(), w->conns.end(),
                                   [&](const IrConn &c) { return (c.owner == a && c.other == b) || (c.owner == b && c.other == a); }),
                    w->conns.end());
     w->dirty = true;
-    (void)before;
     return MGX_OK;
 }
 
@@ -684,6 +729,165 @@ int mgx_set_idle(mgx_world *w, int32_t robot, int32_t idle) {
     if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
     w->robots[(size_t)robot].idle = idle ? 1 : 0;
     w->flags_dirty = true;
+    return MGX_OK;
+}
+
+int mgx_set_antennas(mgx_world *w, uint32_t n, const int32_t *robots, const uint8_t *active) {
+    if (!w || (n && (!robots || !active))) return fail(MGX_ERR_INVALID, "null argument");
+    for (uint32_t i = 0; i < n; i++)
+        if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
+    for (uint32_t i = 0; i < n; i++) w->robots[(size_t)robots[i]].antenna = active[i] ? 1 : 0;
+    w->flags_dirty = true;
+    return MGX_OK;
+}
+
+// ---- dynamic inter-robot topology (robot.rs:1362-1586) -----------------------------------------------
+static void sort_by_key(const mgx_world *w, std::vector<int> &v) {  // BTreeSet<Entity> order
+    std::sort(v.begin(), v.end(), [&](int a, int b) { return w->robots[(size_t)a].order_key < w->robots[(size_t)b].order_key; });
+}
+
+// The fine-grained calls keep robots_connected_with in step, as create_/delete_interrobot_factors
+// do (robot.rs:1406-1408,1546), so that they can be mixed with mgx_update_topology.
+int mgx_ir_connect(mgx_world *w, int32_t owner, int32_t other, uint64_t first_robot_number) {
+    int rc = ir_connect(w, owner, other, first_robot_number);
+    if (rc != MGX_OK) return rc;
+    std::vector<int> &cw = w->robots[(size_t)owner].connected;
+    if (std::find(cw.begin(), cw.end(), other) == cw.end()) {
+        cw.push_back(other);
+        sort_by_key(w, cw);
+    }
+    return MGX_OK;
+}
+int mgx_ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
+    int rc = ir_disconnect(w, a, b);
+    if (rc != MGX_OK) return rc;
+    std::vector<int> &ca = w->robots[(size_t)a].connected, &cb = w->robots[(size_t)b].connected;
+    ca.erase(std::remove(ca.begin(), ca.end(), b), ca.end());
+    cb.erase(std::remove(cb.begin(), cb.end(), a), cb.end());
+    return MGX_OK;
+}
+
+// device neighbour search -> host CSR, rows ascending in order key
+static int neighbours(mgx_world *w, const float *pos, float radius, uint32_t method, std::vector<int32_t> &ptr,
+                      std::vector<int32_t> &idx) {
+    if (!device_ok()) return fail(MGX_ERR_NO_DEVICE, "no HIP device");
+    const int n = (int)w->robots.size();
+    for (const Robot &r : w->robots)
+        if (r.ghost) return fail(MGX_ERR_STATE, "neighbour search needs every robot on this rank (world has ghost robots)");
+    const bool usable_radius = std::isfinite(radius) && radius > 0.f;
+    bool grid = method == MGX_NEIGHBOURS_GRID || (method == MGX_NEIGHBOURS_AUTO && n >= 512);
+    if (!usable_radius) grid = false;  // radius <= 0 / NaN / inf: every pair has to see the predicate
+    uint32_t M = 64;
+    while (M < 2u * (uint32_t)std::max(n, 1)) M <<= 1;
+    hipStream_t s = w->stream;
+    HIP_TRY(w->nb_pos.reserve((size_t)3 * std::max(n, 1)));
+    HIP_TRY(w->nb_cnt.reserve((size_t)std::max(n, 1)));
+    HIP_TRY(w->nb_ptr.reserve((size_t)n + 1));
+    HIP_TRY(w->nb_members.reserve((size_t)std::max(n, 1)));
+    HIP_TRY(w->nb_special.reserve((size_t)std::max(n, 1)));
+    HIP_TRY(w->nb_nspecial.reserve(1));
+    HIP_TRY(w->nb_bucket_cnt.reserve(M));
+    HIP_TRY(w->nb_bucket_ptr.reserve((size_t)M + 1));
+    HIP_TRY(w->nb_cursor.reserve(M));
+    if (n) HIP_TRY(hipMemcpyAsync(w->nb_pos.p, pos, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    HIP_TRY(neighbours_count(w->nb_pos.p, n, radius, grid, M, w->nb_cnt.p, w->nb_bucket_cnt.p, w->nb_bucket_ptr.p, w->nb_cursor.p,
+                             w->nb_members.p, w->nb_special.p, w->nb_nspecial.p, w->nb_ptr.p, s));
+    ptr.assign((size_t)n + 1, 0);
+    HIP_TRY(hipMemcpyAsync(ptr.data(), w->nb_ptr.p, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const size_t total = (size_t)ptr[(size_t)n];
+    idx.assign(total, 0);
+    if (total) {
+        HIP_TRY(w->nb_idx.reserve(total));
+        HIP_TRY(neighbours_fill(w->nb_pos.p, n, radius, grid, M, w->nb_bucket_ptr.p, w->nb_members.p, w->nb_special.p,
+                                w->nb_nspecial.p, w->nb_ptr.p, w->nb_idx.p, s));
+        HIP_TRY(hipMemcpyAsync(idx.data(), w->nb_idx.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    bool monotone = true;  // ids ascending == keys ascending?
+    for (int r = 1; r < n && monotone; r++) monotone = w->robots[(size_t)r - 1].order_key < w->robots[(size_t)r].order_key;
+    if (!monotone)
+        for (int r = 0; r < n; r++)
+            std::sort(idx.begin() + ptr[(size_t)r], idx.begin() + ptr[(size_t)r + 1],
+                      [&](int a, int b) { return w->robots[(size_t)a].order_key < w->robots[(size_t)b].order_key; });
+    return MGX_OK;
+}
+
+int mgx_neighbours(mgx_world *w, const float *positions_xyz, float radius, uint32_t method, int32_t *row_ptr, int32_t *neighbours_out,
+                   uint64_t capacity, uint64_t *needed) {
+    if (!w || !positions_xyz || !row_ptr) return fail(MGX_ERR_INVALID, "null argument");
+    if (method > MGX_NEIGHBOURS_GRID) return fail(MGX_ERR_INVALID, "bad method");
+    std::vector<int32_t> ptr, idx;
+    int rc = neighbours(w, positions_xyz, radius, method, ptr, idx);
+    if (rc != MGX_OK) return rc;
+    memcpy(row_ptr, ptr.data(), sizeof(int32_t) * ptr.size());
+    if (needed) *needed = idx.size();
+    if (!neighbours_out) return MGX_OK;  // sizing call
+    if (idx.size() > capacity) return fail(MGX_ERR_INVALID, "neighbour list needs %zu entries, capacity %llu", idx.size(), (unsigned long long)capacity);
+    if (!idx.empty()) memcpy(neighbours_out, idx.data(), sizeof(int32_t) * idx.size());
+    return MGX_OK;
+}
+
+int mgx_connections(mgx_world *w, int32_t robot, int32_t *others, uint32_t capacity, uint32_t *n) {
+    if (!w || !n || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
+    const std::vector<int> &c = w->robots[(size_t)robot].connected;
+    *n = (uint32_t)c.size();
+    if (!others) return MGX_OK;
+    if (c.size() > capacity) return fail(MGX_ERR_INVALID, "capacity too small");
+    for (size_t i = 0; i < c.size(); i++) others[i] = c[i];
+    return MGX_OK;
+}
+
+int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, uint32_t method, uint64_t *robot_number_next,
+                        uint32_t *stats) {
+    if (!w || !positions_xyz || !robot_number_next) return fail(MGX_ERR_INVALID, "null argument");
+    if (*robot_number_next == 0) return fail(MGX_ERR_INVALID, "robot_number is NonZeroUsize");
+    if (method > MGX_NEIGHBOURS_GRID) return fail(MGX_ERR_INVALID, "bad method");
+    std::vector<int32_t> ptr, idx;
+    int rc = neighbours(w, positions_xyz, radius, method, ptr, idx);  // update_robot_neighbours, robot.rs:1362-1384
+    if (rc != MGX_OK) return rc;
+    const int n = (int)w->robots.size();
+    uint32_t created = 0, deleted = 0;
+    auto in_range = [&](int r, int o) { return std::find(idx.begin() + ptr[(size_t)r], idx.begin() + ptr[(size_t)r + 1], o) != idx.begin() + ptr[(size_t)r + 1]; };
+
+    // delete_interrobot_factors (robot.rs:1386-1439).  The pairs pass through a
+    // HashMap<RobotId, RobotId> filled with `extend` (:1391,1400-1404): one entry per robot, the
+    // LAST out-of-range id (largest key) wins; every out-of-range id leaves robots_connected_with
+    // (:1406-1408) whether or not its factors get deleted.  The map's iteration order is
+    // unspecified in the reference; ascending robot id here.
+    std::vector<int> victim((size_t)n, -1);
+    for (int r = 0; r < n; r++) {
+        std::vector<int> &cw = w->robots[(size_t)r].connected, keep;
+        for (int o : cw)
+            if (in_range(r, o)) keep.push_back(o);
+            else victim[(size_t)r] = o;
+        cw.swap(keep);
+    }
+    for (int r = 0; r < n; r++)
+        if (victim[(size_t)r] >= 0) {
+            rc = ir_disconnect(w, r, victim[(size_t)r]);
+            if (rc != MGX_OK) return rc;
+            deleted++;
+        }
+
+    // create_interrobot_factors (robot.rs:1441-1586): new = within range \ connected, ascending,
+    // snapshotted for every robot first (:1449-1461); K-1 robot numbers per connection (:1527)
+    std::vector<std::vector<int>> fresh((size_t)n);
+    for (int r = 0; r < n; r++) {
+        const std::vector<int> &cw = w->robots[(size_t)r].connected;
+        for (int32_t q = ptr[(size_t)r]; q < ptr[(size_t)r + 1]; q++)
+            if (std::find(cw.begin(), cw.end(), idx[(size_t)q]) == cw.end()) fresh[(size_t)r].push_back(idx[(size_t)q]);
+    }
+    for (int r = 0; r < n; r++)
+        for (int o : fresh[(size_t)r]) {
+            rc = ir_connect(w, r, o, *robot_number_next);
+            if (rc != MGX_OK) return rc;
+            *robot_number_next += (uint64_t)(w->K - 1);
+            w->robots[(size_t)r].connected.push_back(o);  // :1546
+            sort_by_key(w, w->robots[(size_t)r].connected);
+            created++;
+        }
+    if (stats) { stats[0] = created; stats[1] = deleted; }
     return MGX_OK;
 }
 

@@ -24,6 +24,7 @@ SCHEDULE_HALF_BEGINNING_HALF_END = 4
 
 STEP_INTERNAL = 1
 STEP_EXTERNAL = 2
+NEIGHBOURS_AUTO, NEIGHBOURS_PAIRS, NEIGHBOURS_GRID = 0, 1, 2
 HINT_NEXT_STARTS_EXTERNAL = 1
 
 c_double_p = C.POINTER(C.c_double)
@@ -76,6 +77,11 @@ SYMBOLS = {
     "mgx_ir_disconnect": (C.c_int, [_V, C.c_int32, C.c_int32]),
     "mgx_set_antenna": (C.c_int, [_V, C.c_int32, C.c_int32]),
     "mgx_set_idle": (C.c_int, [_V, C.c_int32, C.c_int32]),
+    "mgx_set_antennas": (C.c_int, [_V, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "mgx_neighbours": (C.c_int, [_V, C.c_void_p, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                 C.POINTER(C.c_uint64)]),
+    "mgx_update_topology": (C.c_int, [_V, C.c_void_p, C.c_float, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "mgx_connections": (C.c_int, [_V, C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "mgx_iterate": (C.c_int, [_V, C.c_char_p, C.c_uint32]),
     "mgx_sweep": (C.c_int, [_V, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "mgx_internal_factor_iteration": (C.c_int, [_V, C.c_int32]),

@@ -108,6 +108,41 @@ class World:
     def set_idle(self, robot, idle):
         self._chk(self._L.mgx_set_idle(self._w, robot, int(bool(idle))))
 
+    def set_antennas(self, robots, active):
+        """update_failed_comms (robot.rs:1593-1601): one write per antenna per tick."""
+        robots = np.ascontiguousarray(robots, dtype=np.int32)
+        active = np.ascontiguousarray(active, dtype=np.uint8)
+        assert robots.shape == active.shape
+        self._chk(self._L.mgx_set_antennas(self._w, robots.size, robots.ctypes.data, active.ctypes.data))
+
+    # -- dynamic inter-robot topology (robot.rs:1362-1586) --------------------------------------
+    def neighbours(self, positions, radius, method=hostlib.NEIGHBOURS_AUTO):
+        """update_robot_neighbours: CSR (row_ptr, neighbours) of robots_within_comms_range."""
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        ptr = np.zeros(pos.shape[0] + 1, dtype=np.int32)
+        need = C.c_uint64()
+        self._chk(self._L.mgx_neighbours(self._w, pos.ctypes.data, float(radius), method, ptr.ctypes.data, None, 0, C.byref(need)))
+        idx = np.zeros(max(need.value, 1), dtype=np.int32)
+        self._chk(self._L.mgx_neighbours(self._w, pos.ctypes.data, float(radius), method, ptr.ctypes.data, idx.ctypes.data,
+                                         need.value, C.byref(need)))
+        return ptr, idx[:need.value]
+
+    def update_topology(self, positions, radius, next_number, method=hostlib.NEIGHBOURS_AUTO):
+        """update_robot_neighbours + delete_/create_interrobot_factors; returns (next robot number,
+        connections created, pairs deleted)."""
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        nxt = C.c_uint64(int(next_number))
+        stats = (C.c_uint32 * 2)()
+        self._chk(self._L.mgx_update_topology(self._w, pos.ctypes.data, float(radius), method, C.byref(nxt), stats))
+        return nxt.value, stats[0], stats[1]
+
+    def connections(self, robot):
+        n = C.c_uint32()
+        self._chk(self._L.mgx_connections(self._w, robot, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.int32)
+        self._chk(self._L.mgx_connections(self._w, robot, out.ctypes.data, n.value, C.byref(n)))
+        return out[:n.value].tolist()
+
     # -- hot path ----------------------------------------------------------------------------
     def iterate(self, steps):
         steps = bytes(bytearray(int(s) for s in steps))

@@ -67,6 +67,9 @@ def _bind(path):
     L.orc_set_antenna.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     L.orc_set_idle.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     L.orc_iterate.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
+    L.orc_neighbours.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.orc_update_topology.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.orc_connections.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     for n in ("internal_factor", "internal_variable", "external_factor", "external_variable"):
         getattr(L, f"orc_{n}_iteration").argtypes = [C.c_void_p, C.c_int32]
     L.orc_change_prior.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, c_double_p]
@@ -194,6 +197,35 @@ class OracleWorld:
     def set_idle(self, robot, idle):
         self._chk(self._L.orc_set_idle(self._w, robot, int(bool(idle))))
 
+    def set_antennas(self, robots, active):
+        for r, a in zip(robots, active):
+            self.set_antenna(int(r), bool(a))
+
+    def neighbours(self, positions, radius, method=0):
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        n = pos.shape[0]
+        ptr = np.zeros(n + 1, dtype=np.int32)
+        need = C.c_uint64()
+        self._chk(self._L.orc_neighbours(self._w, pos.ctypes.data, float(radius), ptr.ctypes.data, None, 0, C.byref(need)))
+        idx = np.zeros(max(need.value, 1), dtype=np.int32)
+        self._chk(self._L.orc_neighbours(self._w, pos.ctypes.data, float(radius), ptr.ctypes.data, idx.ctypes.data,
+                                         need.value, C.byref(need)))
+        return ptr, idx[:need.value]
+
+    def update_topology(self, positions, radius, next_number, method=0):
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        nxt = C.c_uint64(int(next_number))
+        stats = (C.c_uint32 * 2)()
+        self._chk(self._L.orc_update_topology(self._w, pos.ctypes.data, float(radius), C.byref(nxt), stats))
+        return nxt.value, stats[0], stats[1]
+
+    def connections(self, robot):
+        n = C.c_uint32()
+        self._chk(self._L.orc_connections(self._w, robot, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.int32)
+        self._chk(self._L.orc_connections(self._w, robot, out.ctypes.data, n.value, C.byref(n)))
+        return out[:n.value].tolist()
+
     def iterate(self, steps):
         steps = bytes(bytearray(int(s) for s in steps))
         self._chk(self._L.orc_iterate(self._w, steps, len(steps)))
@@ -259,6 +291,11 @@ class OracleWorld:
                 return out
             out.append((fr.value, fi.value, bool(p), eta, lam))
             j += 1
+
+
+    def variable_inbox_graphs(self, robot, var_ix):
+        """White-box: the sending graph (robot id) of every inbox slot of a variable."""
+        return [e[0] for e in self.variable_inbox(robot, var_ix)]
 
 
 def schedule(kind, n_internal, n_external):

@@ -155,6 +155,8 @@ typedef struct {
     int antenna, idle;
     float *path;
     int n_path;
+    int *connected; /* RobotConnections::robots_connected_with (ROBOT:515-531), sorted by order key */
+    int n_connected, cap_connected;
 } Graph;
 
 typedef struct {
@@ -651,6 +653,7 @@ static void graph_free(Graph *g) {
     free(g->ir_indices);
     free(g->var_indices);
     free(g->path);
+    free(g->connected);
 }
 void orc_world_destroy(World *w) {
     if (!w) return;
@@ -756,7 +759,7 @@ int orc_robot_add(World *w, const orc_robot_desc *d, int32_t *robot_id) {
 }
 
 /* create_interrobot_factors, one direction — ROBOT:1500-1585 */
-int orc_ir_connect(World *w, int32_t owner, int32_t other, uint64_t first_robot_number) {
+static int ir_connect(World *w, int32_t owner, int32_t other, uint64_t first_robot_number) {
     if (!w || owner < 0 || other < 0 || owner >= w->n || other >= w->n || owner == other)
         return ORC_ERR_INVALID;
     Graph *g = &w->g[owner];
@@ -817,11 +820,164 @@ static void delete_ir_connected_to(World *w, int self, int other) {
     free(removed);
 }
 /* delete_interrobot_factors — ROBOT:1386-1439 */
-int orc_ir_disconnect(World *w, int32_t a, int32_t b) {
+static int ir_disconnect(World *w, int32_t a, int32_t b) {
     if (!w || a < 0 || b < 0 || a >= w->n || b >= w->n || a == b) return ORC_ERR_INVALID;
     delete_ir_connected_to(w, a, b);
     delete_ir_connected_to(w, b, a);
     return ORC_OK;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * dynamic inter-robot topology — the three FixedUpdate systems of ROBOT:1362-1586
+ * --------------------------------------------------------------------------------------- */
+/* update_robot_neighbours — ROBOT:1362-1384.  `pos` = Transform::translation of every robot
+ * (f32 xyz).  j is within range of i unless `radius < distance(i, j)` (so a NaN distance IS in
+ * range); glam Vec3::distance = sqrt((dx*dx + dy*dy) + dz*dz) in f32.  Result = BTreeSet per
+ * robot, i.e. ascending Entity order (= order_key), as CSR. */
+static int within_range(const float *a, const float *b, float radius) {
+    float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+    return !(radius < d);
+}
+static void sort_by_key(const World *w, int *a, int n) { /* BTreeSet<Entity> order */
+    for (int i = 1; i < n; i++) {
+        int v = a[i], j = i;
+        while (j > 0 && w->g[a[j - 1]].order_key > w->g[v].order_key) { a[j] = a[j - 1]; j--; }
+        a[j] = v;
+    }
+}
+int orc_neighbours(World *w, const float *pos, float radius, int32_t *ptr, int32_t *idx, uint64_t capacity,
+                   uint64_t *needed) {
+    if (!w || !pos || !ptr) return ORC_ERR_INVALID;
+    for (int r = 0; r < w->n; r++)
+        if (w->g[r].ghost) return ORC_ERR_INVALID;
+    uint64_t cnt = 0;
+    int *row = (int *)malloc(sizeof(int) * (size_t)(w->n > 0 ? w->n : 1));
+    for (int i = 0; i < w->n; i++) {
+        ptr[i] = (int32_t)cnt;
+        int m = 0;
+        for (int j = 0; j < w->n; j++)
+            if (j != i && within_range(pos + 3 * i, pos + 3 * j, radius)) row[m++] = j;
+        sort_by_key(w, row, m);
+        for (int k = 0; k < m; k++, cnt++)
+            if (idx && cnt < capacity) idx[cnt] = row[k];
+    }
+    ptr[w->n] = (int32_t)cnt;
+    free(row);
+    if (needed) *needed = cnt;
+    return (idx && cnt <= capacity) || !idx ? ORC_OK : ORC_ERR_INVALID;
+}
+
+static int set_contains(const int *a, int n, int v) {
+    for (int i = 0; i < n; i++)
+        if (a[i] == v) return 1;
+    return 0;
+}
+int orc_connections(World *w, int32_t r, int32_t *out, uint32_t capacity, uint32_t *n) {
+    if (!w || r < 0 || r >= w->n || !n) return ORC_ERR_INVALID;
+    Graph *g = &w->g[r];
+    *n = (uint32_t)g->n_connected;
+    if ((uint32_t)g->n_connected > capacity) return out ? ORC_ERR_INVALID : ORC_OK;
+    for (int i = 0; i < g->n_connected; i++) out[i] = g->connected[i];
+    return ORC_OK;
+}
+/* public forms keep robots_connected_with in step (ROBOT:1406-1408,1546) */
+int orc_ir_connect(World *w, int32_t owner, int32_t other, uint64_t first_robot_number) {
+    int rc = ir_connect(w, owner, other, first_robot_number);
+    if (rc != ORC_OK) return rc;
+    Graph *g = &w->g[owner];
+    if (!set_contains(g->connected, g->n_connected, other)) {
+        push_int(&g->connected, &g->n_connected, &g->cap_connected, other);
+        sort_by_key(w, g->connected, g->n_connected);
+    }
+    return ORC_OK;
+}
+static void set_remove(int *a, int *n, int v) {
+    int k = 0;
+    for (int i = 0; i < *n; i++)
+        if (a[i] != v) a[k++] = a[i];
+    *n = k;
+}
+int orc_ir_disconnect(World *w, int32_t a, int32_t b) {
+    int rc = ir_disconnect(w, a, b);
+    if (rc != ORC_OK) return rc;
+    set_remove(w->g[a].connected, &w->g[a].n_connected, b);
+    set_remove(w->g[b].connected, &w->g[b].n_connected, a);
+    return ORC_OK;
+}
+
+/* update_robot_neighbours + delete_interrobot_factors + create_interrobot_factors in the order
+ * the schedule runs them (ROBOT:86-99).  Query iteration = robot id order (spawn order).
+ * `next_number` is RobotNumberGenerator (ROBOT:122-140): one number per created factor.
+ * stats[0] = connections (one direction, K-1 factors each) created, stats[1] = robot pairs whose
+ * factors were deleted. */
+int orc_update_topology(World *w, const float *pos, float radius, uint64_t *next_number, uint32_t *stats) {
+    if (!w || !pos || !next_number || *next_number == 0) return ORC_ERR_INVALID;
+    const int n = w->n;
+    int32_t *ptr = (int32_t *)malloc(sizeof(int32_t) * ((size_t)(n > 0 ? n : 0) + 1));
+    uint64_t need = 0;
+    int rc = orc_neighbours(w, pos, radius, ptr, NULL, 0, &need);
+    if (rc != ORC_OK) { free(ptr); return rc; }
+    int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(need ? need : 1));
+    orc_neighbours(w, pos, radius, ptr, idx, need, &need);
+    uint32_t created = 0, deleted = 0;
+
+    /* delete_interrobot_factors — ROBOT:1386-1439.  The (robot -> other) pairs go through a
+     * HashMap<RobotId, RobotId> (:1391,1400-1404): `extend` keeps only the LAST pair per robot,
+     * i.e. the largest out-of-range id; the others are dropped from robots_connected_with
+     * (:1406-1408) but their factors stay unless the other side's entry names this robot.
+     * HashMap iteration order is unspecified in the reference; ascending robot id here. */
+    int *victim = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    for (int r = 0; r < n; r++) {
+        Graph *g = &w->g[r];
+        victim[r] = -1;
+        int keep = 0;
+        for (int k = 0; k < g->n_connected; k++) {
+            int o = g->connected[k];
+            if (set_contains(idx + ptr[r], ptr[r + 1] - ptr[r], o)) g->connected[keep++] = o;
+            else victim[r] = o; /* ascending key order: the last one wins */
+        }
+        g->n_connected = keep;
+    }
+    for (int r = 0; r < n; r++)
+        if (victim[r] >= 0) {
+            ir_disconnect(w, r, victim[r]);
+            deleted++;
+        }
+    free(victim);
+
+    /* create_interrobot_factors — ROBOT:1441-1586: new = within_range \ connected_with,
+     * ascending; robots in query order; K-1 numbers drawn per connection (:1527) */
+    int **fresh = (int **)calloc((size_t)(n > 0 ? n : 1), sizeof(int *));
+    int *n_fresh = (int *)calloc((size_t)(n > 0 ? n : 1), sizeof(int));
+    for (int r = 0; r < n; r++) { /* :1449-1461 snapshot before any insertion */
+        Graph *g = &w->g[r];
+        int m = ptr[r + 1] - ptr[r];
+        fresh[r] = (int *)malloc(sizeof(int) * (size_t)(m ? m : 1));
+        for (int k = 0; k < m; k++) {
+            int o = idx[ptr[r] + k];
+            if (!set_contains(g->connected, g->n_connected, o)) fresh[r][n_fresh[r]++] = o;
+        }
+    }
+    for (int r = 0; r < n && rc == ORC_OK; r++) {
+        for (int k = 0; k < n_fresh[r]; k++) {
+            int o = fresh[r][k];
+            rc = ir_connect(w, r, o, *next_number);
+            if (rc != ORC_OK) break;
+            *next_number += (uint64_t)(w->g[r].K - 1);
+            Graph *g = &w->g[r];
+            push_int(&g->connected, &g->n_connected, &g->cap_connected, o); /* :1546 */
+            sort_by_key(w, g->connected, g->n_connected);
+            created++;
+        }
+    }
+    for (int r = 0; r < n; r++) free(fresh[r]);
+    free(fresh);
+    free(n_fresh);
+    free(ptr);
+    free(idx);
+    if (stats) { stats[0] = created; stats[1] = deleted; }
+    return rc;
 }
 
 int orc_set_antenna(World *w, int32_t r, int32_t on) {

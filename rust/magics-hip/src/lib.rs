@@ -37,6 +37,20 @@ impl World {
         assert_eq!(rgb.len(), (width * height * 3) as usize);
         check(unsafe { sys::mgx_world_set_sdf(self.raw, rgb.as_ptr(), width, height, world_w, world_h) })
     }
+    /// `update_robot_neighbours` + `delete_interrobot_factors` + `create_interrobot_factors`
+    /// (robot.rs:1362-1586) in one call: `translations` are the robots' `Transform::translation`
+    /// in robot-id order, `robot_number` is the `RobotNumberGenerator` state.  Returns
+    /// (connections created, pairs deleted).
+    pub fn update_topology(&self, translations: &[[f32; 3]], radius: f32, robot_number: &mut u64) -> Result<(u32, u32), MgxError> {
+        let mut stats = [0u32; 2];
+        check(unsafe { sys::mgx_update_topology(self.raw, translations.as_ptr().cast(), radius, 0, robot_number, stats.as_mut_ptr()) })?;
+        Ok((stats[0], stats[1]))
+    }
+    /// `update_failed_comms` (robot.rs:1593-1601): the Bernoulli draws stay with the caller's PRNG
+    pub fn set_antennas(&self, robots: &[i32], active: &[u8]) -> Result<(), MgxError> {
+        assert_eq!(robots.len(), active.len());
+        check(unsafe { sys::mgx_set_antennas(self.raw, robots.len() as u32, robots.as_ptr(), active.as_ptr()) })
+    }
     /// `RobotBundle::new` (robot.rs:1134-1356)
     #[allow(clippy::too_many_arguments)]
     pub fn add_robot(self: &Arc<Self>, mean0: &[[f64; 4]], prior_diag: &[f64], dt: &[f64], radius: f64,
