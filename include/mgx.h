@@ -108,6 +108,11 @@ int mgx_world_set_sdf(mgx_world *w, const uint8_t *rgb, uint32_t width, uint32_t
 /* ---- topology (FactorGraph::add_variable/add_factor/add_*_edge, robot.rs) ---------- */
 /* RobotBundle::new (robot.rs:1134-1356). */
 int mgx_robot_add(mgx_world *w, const mgx_robot_desc *desc, int32_t *robot_id);
+/* Entity despawn (robot.rs:2172, despawn_entity_after): the robot leaves every query — never
+ * iterated again, whatever is addressed to it is dropped (robot.rs:1815,1844), invisible to
+ * mgx_neighbours.  Ids stay stable; its last beliefs remain readable.  The other robots drop
+ * their factors towards it in the following mgx_update_topology passes (or mgx_ir_disconnect). */
+int mgx_robot_remove(mgx_world *w, int32_t robot);
 /* create_interrobot_factors for ONE direction (robot.rs:1500-1585): `owner` creates
  * K-1 InterRobotFactors towards `other`, variable i <-> variable i, i = 1..K-1, with
  * robot_number = first_robot_number + (i-1) (robot.rs:1527, interrobot.rs:75).
@@ -207,6 +212,8 @@ int mgx_get_belief(mgx_world *w, int32_t robot, uint32_t var_ix, double eta[4], 
 /* bulk: robots in id order, variables in index order; ghosts are skipped.
  * means [sum K][4]; eta [sum K][4]; lam [sum K][16].  Any pointer may be NULL. */
 int mgx_read_beliefs(mgx_world *w, double *eta, double *lam, double *means);
+/* means only — what reached_waypoint (robot.rs:2125-2136) and the visualisers read per tick */
+int mgx_read_means(mgx_world *w, double *means);
 int mgx_num_robots(mgx_world *w, uint32_t *n_robots, uint32_t *n_variables);
 
 /* ---- multi-GPU halo (one exchange per external iteration) ----------------- */

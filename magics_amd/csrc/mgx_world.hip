@@ -112,6 +112,7 @@ struct Robot {
     double radius = 1.0;
     uint64_t order_key = 0;
     uint8_t antenna = 1, idle = 0;
+    bool removed = false;  // despawned: never iterated, nothing delivered, invisible to the neighbour search
     std::vector<double> prior_eta, prior_lam, bel_eta, bel_lam, bel_mu, bel_cov;  // [K][4|16]
     std::vector<int32_t> valid;                                                   // [K]
     std::vector<double> snap;                                                     // [K][24]
@@ -719,14 +720,33 @@ static int ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
     return MGX_OK;
 }
 
+// Entity despawn (robot.rs:2172 + despawn_entity_after): the graph leaves every Bevy query, so it
+// is never iterated again and whatever is addressed to it is dropped (robot.rs:1815,1844: the
+// `query.get_mut` fails) — the same dataflow as idle with the antenna off, for good.  The other
+// robots drop their factors towards it in the following topology passes.
+int mgx_robot_remove(mgx_world *w, int32_t robot) {
+    if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
+    Robot &rb = w->robots[(size_t)robot];
+    if (rb.removed) return fail(MGX_ERR_STATE, "robot %d already removed", robot);
+    if (rb.ghost) return fail(MGX_ERR_STATE, "ghost robots are removed by their owning rank");
+    rb.removed = true;
+    rb.idle = 1;
+    rb.antenna = 0;
+    rb.connected.clear();
+    w->flags_dirty = true;
+    return MGX_OK;
+}
+
 int mgx_set_antenna(mgx_world *w, int32_t robot, int32_t active) {
     if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
+    if (w->robots[(size_t)robot].removed) return fail(MGX_ERR_STATE, "robot %d was removed", robot);
     w->robots[(size_t)robot].antenna = active ? 1 : 0;
     w->flags_dirty = true;
     return MGX_OK;
 }
 int mgx_set_idle(mgx_world *w, int32_t robot, int32_t idle) {
     if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
+    if (w->robots[(size_t)robot].removed) return fail(MGX_ERR_STATE, "robot %d was removed", robot);
     w->robots[(size_t)robot].idle = idle ? 1 : 0;
     w->flags_dirty = true;
     return MGX_OK;
@@ -734,8 +754,10 @@ int mgx_set_idle(mgx_world *w, int32_t robot, int32_t idle) {
 
 int mgx_set_antennas(mgx_world *w, uint32_t n, const int32_t *robots, const uint8_t *active) {
     if (!w || (n && (!robots || !active))) return fail(MGX_ERR_INVALID, "null argument");
-    for (uint32_t i = 0; i < n; i++)
+    for (uint32_t i = 0; i < n; i++) {
         if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
+        if (w->robots[(size_t)robots[i]].removed) return fail(MGX_ERR_STATE, "robot %d was removed", robots[i]);
+    }
     for (uint32_t i = 0; i < n; i++) w->robots[(size_t)robots[i]].antenna = active[i] ? 1 : 0;
     w->flags_dirty = true;
     return MGX_OK;
@@ -771,9 +793,20 @@ int mgx_ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
 static int neighbours(mgx_world *w, const float *pos, float radius, uint32_t method, std::vector<int32_t> &ptr,
                       std::vector<int32_t> &idx) {
     if (!device_ok()) return fail(MGX_ERR_NO_DEVICE, "no HIP device");
-    const int n = (int)w->robots.size();
-    for (const Robot &r : w->robots)
-        if (r.ghost) return fail(MGX_ERR_STATE, "neighbour search needs every robot on this rank (world has ghost robots)");
+    const int n_all = (int)w->robots.size();
+    std::vector<int> alive;  // removed robots are in no query: search the others, map back
+    std::vector<float> packed;
+    for (int r = 0; r < n_all; r++) {
+        if (w->robots[(size_t)r].ghost) return fail(MGX_ERR_STATE, "neighbour search needs every robot on this rank (world has ghost robots)");
+        if (!w->robots[(size_t)r].removed) alive.push_back(r);
+    }
+    const bool compact = (int)alive.size() != n_all;
+    if (compact) {
+        packed.resize(3 * alive.size());
+        for (size_t a = 0; a < alive.size(); a++) memcpy(&packed[3 * a], pos + 3 * (size_t)alive[a], 3 * sizeof(float));
+        pos = packed.data();
+    }
+    const int n = (int)alive.size();
     const bool usable_radius = std::isfinite(radius) && radius > 0.f;
     bool grid = method == MGX_NEIGHBOURS_GRID || (method == MGX_NEIGHBOURS_AUTO && n >= 512);
     if (!usable_radius) grid = false;  // radius <= 0 / NaN / inf: every pair has to see the predicate
@@ -804,10 +837,17 @@ static int neighbours(mgx_world *w, const float *pos, float radius, uint32_t met
         HIP_TRY(hipMemcpyAsync(idx.data(), w->nb_idx.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
+    if (compact) {  // back to world robot ids, empty rows for the removed ones
+        for (int32_t &j : idx) j = alive[(size_t)j];
+        std::vector<int32_t> full((size_t)n_all + 1, 0);
+        for (int a = 0; a < n; a++) full[(size_t)alive[(size_t)a] + 1] = ptr[(size_t)a + 1] - ptr[(size_t)a];
+        for (int r = 0; r < n_all; r++) full[(size_t)r + 1] += full[(size_t)r];
+        ptr.swap(full);
+    }
     bool monotone = true;  // ids ascending == keys ascending?
-    for (int r = 1; r < n && monotone; r++) monotone = w->robots[(size_t)r - 1].order_key < w->robots[(size_t)r].order_key;
+    for (int r = 1; r < n_all && monotone; r++) monotone = w->robots[(size_t)r - 1].order_key < w->robots[(size_t)r].order_key;
     if (!monotone)
-        for (int r = 0; r < n; r++)
+        for (int r = 0; r < n_all; r++)
             std::sort(idx.begin() + ptr[(size_t)r], idx.begin() + ptr[(size_t)r + 1],
                       [&](int a, int b) { return w->robots[(size_t)a].order_key < w->robots[(size_t)b].order_key; });
     return MGX_OK;
@@ -857,6 +897,7 @@ int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, 
     // unspecified in the reference; ascending robot id here.
     std::vector<int> victim((size_t)n, -1);
     for (int r = 0; r < n; r++) {
+        if (w->robots[(size_t)r].removed) continue;  // not in the query any more
         std::vector<int> &cw = w->robots[(size_t)r].connected, keep;
         for (int o : cw)
             if (in_range(r, o)) keep.push_back(o);
@@ -935,7 +976,7 @@ int mgx_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, const uin
     if (n == 0) return MGX_OK;
     std::vector<int32_t> dr(n);
     for (uint32_t i = 0; i < n; i++) {
-        if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size() || w->robots[(size_t)robots[i]].ghost || (int)var_ix[i] >= w->K)
+        if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size() || w->robots[(size_t)robots[i]].ghost || w->robots[(size_t)robots[i]].removed || (int)var_ix[i] >= w->K)
             return fail(MGX_ERR_INVALID, "bad (robot, variable) at %u", i);
     }
     int rc = commit(w);
@@ -957,7 +998,7 @@ int mgx_update_priors(mgx_world *w, uint32_t n, const int32_t *robots, const dou
     if (n == 0) return MGX_OK;
     if (w->K < 3) return fail(MGX_ERR_INVALID, "needs K >= 3");
     for (uint32_t i = 0; i < n; i++)
-        if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size() || w->robots[(size_t)robots[i]].ghost || (what[i] & ~3u))
+        if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size() || w->robots[(size_t)robots[i]].ghost || w->robots[(size_t)robots[i]].removed || (what[i] & ~3u))
             return fail(MGX_ERR_INVALID, "bad entry %u", i);
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
@@ -987,6 +1028,13 @@ int mgx_num_robots(mgx_world *w, uint32_t *n_robots, uint32_t *n_variables) {
     if (n_variables) *n_variables = nr * (uint32_t)w->K;
     return MGX_OK;
 }
+
+// bulk read of the belief means only (what reached_waypoint and the visualisers read, robot.rs:2125-2136)
+int mgx_read_means(mgx_world *w, double *means) {
+    if (!w || !means) return fail(MGX_ERR_INVALID, "null argument");
+    return mgx_read_beliefs(w, nullptr, nullptr, means);
+}
+
 
 int mgx_read_beliefs(mgx_world *w, double *eta, double *lam, double *means) {
     if (!w) return fail(MGX_ERR_INVALID, "null world");

@@ -73,6 +73,7 @@ SYMBOLS = {
     "mgx_synchronize": (C.c_int, [_V]),
     "mgx_world_set_sdf": (C.c_int, [_V, _V, C.c_uint32, C.c_uint32, C.c_double, C.c_double]),
     "mgx_robot_add": (C.c_int, [_V, C.POINTER(RobotDesc), C.POINTER(C.c_int32)]),
+    "mgx_robot_remove": (C.c_int, [_V, C.c_int32]),
     "mgx_ir_connect": (C.c_int, [_V, C.c_int32, C.c_int32, C.c_uint64]),
     "mgx_ir_disconnect": (C.c_int, [_V, C.c_int32, C.c_int32]),
     "mgx_set_antenna": (C.c_int, [_V, C.c_int32, C.c_int32]),
@@ -95,6 +96,7 @@ SYMBOLS = {
     "mgx_get_belief": (C.c_int, [_V, C.c_int32, C.c_uint32, c_double_p, c_double_p, c_double_p, c_double_p,
                                  C.POINTER(C.c_int32)]),
     "mgx_read_beliefs": (C.c_int, [_V, c_double_p, c_double_p, c_double_p]),
+    "mgx_read_means": (C.c_int, [_V, c_double_p]),
     "mgx_num_robots": (C.c_int, [_V, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mgx_halo_words": (C.c_uint32, [C.c_uint32]),
     "mgx_halo_plan": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_int32)]),

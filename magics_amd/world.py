@@ -99,6 +99,10 @@ class World:
     def ir_connect(self, owner, other, first_robot_number):
         self._chk(self._L.mgx_ir_connect(self._w, owner, other, int(first_robot_number)))
 
+    def remove_robot(self, robot):
+        """Entity despawn (robot.rs:2172): the robot leaves every query for good."""
+        self._chk(self._L.mgx_robot_remove(self._w, robot))
+
     def ir_disconnect(self, a, b):
         self._chk(self._L.mgx_ir_disconnect(self._w, a, b))
 
@@ -196,6 +200,12 @@ class World:
         a, b = C.c_uint32(), C.c_uint32()
         self._chk(self._L.mgx_num_robots(self._w, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def read_means(self):
+        _, nv = self.num_robots()
+        means = np.zeros((nv, 4))
+        self._chk(self._L.mgx_read_means(self._w, _dp(means)))
+        return means
 
     def read_beliefs(self):
         _, nv = self.num_robots()

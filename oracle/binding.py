@@ -62,6 +62,7 @@ def _bind(path):
     L.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
     L.orc_world_set_sdf.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_double]
     L.orc_robot_add.argtypes = [C.c_void_p, C.POINTER(RobotDesc), C.POINTER(C.c_int32)]
+    L.orc_robot_remove.argtypes = [C.c_void_p, C.c_int32]
     L.orc_ir_connect.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64]
     L.orc_ir_disconnect.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     L.orc_set_antenna.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
@@ -188,6 +189,9 @@ class OracleWorld:
     def ir_connect(self, owner, other, first_robot_number):
         self._chk(self._L.orc_ir_connect(self._w, owner, other, int(first_robot_number)))
 
+    def remove_robot(self, robot):
+        self._chk(self._L.orc_robot_remove(self._w, robot))
+
     def ir_disconnect(self, a, b):
         self._chk(self._L.orc_ir_disconnect(self._w, a, b))
 
@@ -270,6 +274,9 @@ class OracleWorld:
         a, b = C.c_uint32(), C.c_uint32()
         self._L.orc_num_robots(self._w, C.byref(a), C.byref(b))
         return a.value, b.value
+
+    def read_means(self):
+        return self.read_beliefs()[2]
 
     def read_beliefs(self):
         _, nv = self.num_robots()

@@ -153,6 +153,7 @@ typedef struct {
     int *var_indices;
     int iter_factor, iter_variable; /* iteration_count */
     int antenna, idle;
+    int removed; /* entity despawned (ROBOT:2172): out of every query from now on */
     float *path;
     int n_path;
     int *connected; /* RobotConnections::robots_connected_with (ROBOT:515-531), sorted by order key */
@@ -856,8 +857,8 @@ int orc_neighbours(World *w, const float *pos, float radius, int32_t *ptr, int32
     for (int i = 0; i < w->n; i++) {
         ptr[i] = (int32_t)cnt;
         int m = 0;
-        for (int j = 0; j < w->n; j++)
-            if (j != i && within_range(pos + 3 * i, pos + 3 * j, radius)) row[m++] = j;
+        for (int j = 0; j < w->n && !w->g[i].removed; j++)
+            if (j != i && !w->g[j].removed && within_range(pos + 3 * i, pos + 3 * j, radius)) row[m++] = j;
         sort_by_key(w, row, m);
         for (int k = 0; k < m; k++, cnt++)
             if (idx && cnt < capacity) idx[cnt] = row[k];
@@ -931,6 +932,7 @@ int orc_update_topology(World *w, const float *pos, float radius, uint64_t *next
     for (int r = 0; r < n; r++) {
         Graph *g = &w->g[r];
         victim[r] = -1;
+        if (g->removed) continue; /* not in the query any more */
         int keep = 0;
         for (int k = 0; k < g->n_connected; k++) {
             int o = g->connected[k];
@@ -980,13 +982,25 @@ int orc_update_topology(World *w, const float *pos, float radius, uint64_t *next
     return rc;
 }
 
+/* Entity despawn (ROBOT:2172, despawn_entity_after): the graph leaves every query — it is never
+ * iterated again and messages addressed to it are dropped (`query.get_mut` fails, ROBOT:1815,1844);
+ * the other robots drop their factors towards it through the next topology passes. */
+int orc_robot_remove(World *w, int32_t r) {
+    if (!w || r < 0 || r >= w->n || w->g[r].removed) return ORC_ERR_INVALID;
+    w->g[r].removed = 1;
+    w->g[r].idle = 1;
+    w->g[r].antenna = 0;
+    w->g[r].n_connected = 0;
+    return ORC_OK;
+}
+
 int orc_set_antenna(World *w, int32_t r, int32_t on) {
-    if (!w || r < 0 || r >= w->n) return ORC_ERR_INVALID;
+    if (!w || r < 0 || r >= w->n || w->g[r].removed) return ORC_ERR_INVALID;
     w->g[r].antenna = on != 0;
     return ORC_OK;
 }
 int orc_set_idle(World *w, int32_t r, int32_t idle) {
-    if (!w || r < 0 || r >= w->n) return ORC_ERR_INVALID;
+    if (!w || r < 0 || r >= w->n || w->g[r].removed) return ORC_ERR_INVALID;
     w->g[r].idle = idle != 0;
     return ORC_OK;
 }
@@ -1200,7 +1214,7 @@ int orc_external_variable_iteration(World *w, int32_t robot) {
 /* VariableNode::change_prior + FactorGraph::change_prior_of_variable + caller routing
  * — FG/variable.rs:203-230, FG/factorgraph.rs:494-528, ROBOT:2262-2282 */
 int orc_change_prior(World *w, int32_t r, uint32_t var_ix, const double *mean) {
-    if (!w || r < 0 || r >= w->n || (int)var_ix >= w->g[r].K || !mean) return ORC_ERR_INVALID;
+    if (!w || r < 0 || r >= w->n || (int)var_ix >= w->g[r].K || !mean || w->g[r].removed) return ORC_ERR_INVALID;
     Graph *g = &w->g[r];
     int vix = g->var_indices[var_ix];
     Variable *v = &g->nodes[vix].v;
@@ -1223,6 +1237,8 @@ int orc_change_prior(World *w, int32_t r, uint32_t var_ix, const double *mean) {
  * the second. */
 int orc_update_priors(World *w, uint32_t n, const int32_t *robots, const double *waypoints_xy, const double *time_scale,
                       const uint8_t *what, double max_speed, double delta_t) {
+    for (uint32_t t = 0; t < n; t++)
+        if (robots[t] < 0 || robots[t] >= w->n || w->g[robots[t]].removed) return ORC_ERR_INVALID;
     for (uint32_t t = 0; t < n; t++) {
         if (!(what[t] & 1u)) continue;
         Graph *g = &w->g[robots[t]];

@@ -41,6 +41,7 @@ extern "C" {
     pub fn mgx_synchronize(w: *mut mgx_world) -> c_int;
     pub fn mgx_world_set_sdf(w: *mut mgx_world, rgb: *const u8, width: u32, height: u32, world_w: f64, world_h: f64) -> c_int;
     pub fn mgx_robot_add(w: *mut mgx_world, desc: *const mgx_robot_desc, robot_id: *mut i32) -> c_int;
+    pub fn mgx_robot_remove(w: *mut mgx_world, robot: i32) -> c_int;
     pub fn mgx_ir_connect(w: *mut mgx_world, owner: i32, other: i32, first_robot_number: u64) -> c_int;
     pub fn mgx_ir_disconnect(w: *mut mgx_world, a: i32, b: i32) -> c_int;
     pub fn mgx_set_antenna(w: *mut mgx_world, robot: i32, active: i32) -> c_int;
@@ -60,6 +61,7 @@ extern "C" {
     pub fn mgx_update_priors(w: *mut mgx_world, n: u32, robots: *const i32, waypoints_xy: *const f64, time_scale: *const f64, what: *const u8, max_speed: f64, delta_t: f64) -> c_int;
     pub fn mgx_get_belief(w: *mut mgx_world, robot: i32, var_ix: u32, eta: *mut f64, lam: *mut f64, mean: *mut f64, cov: *mut f64, valid: *mut i32) -> c_int;
     pub fn mgx_read_beliefs(w: *mut mgx_world, eta: *mut f64, lam: *mut f64, means: *mut f64) -> c_int;
+    pub fn mgx_read_means(w: *mut mgx_world, means: *mut f64) -> c_int;
     pub fn mgx_num_robots(w: *mut mgx_world, n_robots: *mut u32, n_variables: *mut u32) -> c_int;
     pub fn mgx_halo_words(k: u32) -> u32;
     pub fn mgx_halo_plan(w: *mut mgx_world, n_send: u32, send_robots: *const i32, n_recv: u32, recv_ghosts: *const i32) -> c_int;

@@ -184,3 +184,42 @@ def test_topology_calls_reject_sharded_worlds():
     w.add_robot(rb["mean0"], rb["prior_diag"], rb["dt"], rb["radius"], order_key=99, ghost=True)
     with pytest.raises(RuntimeError, match="ghost"):
         w.neighbours(np.zeros((5, 3), dtype=np.float32), 1.0)
+
+
+def test_robot_removal_between_ticks():
+    """Despawn (robot.rs:2172): removed robots stop iterating, their messages freeze until the
+    neighbours' topology passes drop them; ids and the remaining trajectories stay exact."""
+    n, K = 12, 10
+    sc = S.circle_scenario(n, K, circle_radius=20.0, n_internal=10, n_external=10)
+    sc["ir"] = []
+    eng, ref = make_pair(sc)
+    args = S.tick_inputs(sc)
+    nxt = {id(eng): 1, id(ref): 1}
+    alive = np.ones(n, dtype=bool)
+    for tick in range(40):
+        if tick in (8, 15, 16):
+            gone = {8: [3], 15: [0, 7], 16: [11]}[tick]
+            for w in (eng, ref):
+                for r in gone:
+                    w.remove_robot(r)
+            alive[gone] = False
+            keep = np.nonzero(alive)[0]
+            args = S.tick_inputs(sc)
+            args = dict(args, robots=args["robots"][keep], waypoints_xy=args["waypoints_xy"][keep],
+                        time_scale=args["time_scale"][keep], what=args["what"][keep])
+        res = []
+        for w in (eng, ref):
+            pos = positions_from_beliefs(w, n, K)
+            out = w.update_topology(pos, 25.0, nxt[id(w)])
+            nxt[id(w)] = out[0]
+            res.append(out)
+            w.update_priors(**args)
+            w.iterate(sc["steps"])
+        assert res[0] == res[1], (tick, res)
+        assert [eng.connections(r) for r in range(n)] == [ref.connections(r) for r in range(n)]
+        if tick % 4 == 3:
+            assert_identical(eng, ref, what=f"removal, tick {tick + 1}")
+    assert np.array_equal(eng.read_means(), ref.read_means())
+    assert all(eng.connections(r) == [] for r in (0, 3, 7, 11))
+    with pytest.raises(RuntimeError, match="removed"):
+        eng.set_idle(3, False)

@@ -90,3 +90,23 @@ def test_hashmap_quirk_leaves_factors_behind():
     assert created == 6
     assert w.variable_inbox_graphs(1, 1).count(0) == 2   # old and new factor 0 -> 1
     assert w.variable_inbox_graphs(2, 1).count(0) == 1
+
+
+def test_removed_robot_leaves_the_queries():
+    w, sc = small_world(4, K=10)
+    line = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0], [3, 0, 0]], dtype=np.float32)
+    nxt, created, _ = w.update_topology(line, 1.5, 1)
+    assert created == 6
+    w.remove_robot(1)
+    ptr, idx = w.neighbours(line, 1.5)
+    assert [r.tolist() for r in rows_of(ptr, idx)] == [[], [], [3], [2]]
+    nxt, created, deleted = w.update_topology(line, 1.5, nxt)
+    # 0 and 2 each drop their factors towards 1 (and the messages robot 1's factors left behind)
+    assert (created, deleted) == (0, 2)
+    assert [w.connections(r) for r in range(4)] == [[], [], [3], [2]]
+    assert w.variable_inbox_graphs(0, 1).count(1) == 0 and w.variable_inbox_graphs(2, 1).count(1) == 0
+    import pytest
+    with pytest.raises(RuntimeError):
+        w.set_antenna(1, True)
+    with pytest.raises(RuntimeError):
+        w.remove_robot(1)
