@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--horizon", type=int, default=16)
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--secondary-deadline", type=float, default=240.0,
+                    help="N > 1 only: seconds the sharded (collective) phase may take before it is abandoned")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--fma", action="store_true", help="use the FMA-contracting build (not the product)")
     return ap.parse_args()
@@ -132,6 +134,30 @@ def measured_traffic(key):
         return None
 
 
+class _Deadline:
+    """Ends the process from a timer thread if a phase with collectives overruns (see main)."""
+
+    def __init__(self, seconds, rank, line):
+        import threading
+        self._t = None
+        if seconds > 0:
+            self._t = threading.Timer(seconds, self._expire, args=(seconds, rank, line))
+            self._t.daemon = True
+            self._t.start()
+
+    @staticmethod
+    def _expire(seconds, rank, line):
+        if rank == 0:
+            out = dict(line)
+            out["secondary"] = {"error": f"sharded phase did not finish within {seconds} s; skipped"}
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    def cancel(self):
+        if self._t is not None:
+            self._t.cancel()
+
+
 def main():
     a = parse()
     import torch
@@ -209,6 +235,11 @@ def main():
 
     # ---- secondary: configs[2]/[3], + inter-robot factors, robots sharded with halo exchange ------
     sc2 = None
+    # The sharded workload is the only phase with a collective in it.  Should that collective ever
+    # stall on some node, the primary measurement must still be reported: every rank carries a
+    # deadline for this phase, and on expiry rank 0 prints the line without the secondary figures
+    # and all ranks leave.
+    guard = _Deadline(a.secondary_deadline if multi else 0, rank, line)
     if not a.no_secondary:
         # Every rank first builds its shard; the ranks then agree that all of them succeeded BEFORE the
         # first collective, so a failure on one rank can never leave the others waiting in RCCL.
@@ -249,6 +280,8 @@ def main():
         else:
             line["secondary"] = {"error": err or "another rank failed to build its shard"}
             sc2 = None
+
+    guard.cancel()
 
     # ---- CPU baseline: rank 0, N = 1 only ---------------------------------------------------------
     if rank == 0 and not multi and not a.no_cpu_baseline:
