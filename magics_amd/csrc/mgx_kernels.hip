@@ -581,21 +581,23 @@ __global__ void k_change_prior(DevWorld w, int n, const int32_t *robots, const u
     apply_change_prior(w, robots[t], (int)vars[t], m);
 }
 
-// The per-tick prior updates of the driver, one thread per listed robot:
+// The per-tick prior updates of the driver, one thread per (listed robot, update):
 //   what & 1: update_prior_of_horizon_state (robot.rs:2182-2283): the last variable moves towards the
 //             waypoint at min(max_speed, distance);
 //   what & 2: update_prior_of_current_state_v3 (robot.rs:2286-2338): variable 0 moves by
 //             time_scale * (mean_1 - mean_0).
 // Both end in change_prior of that variable.  The reference runs the horizon system for every robot
-// before the current-state system; for K >= 3 the two touch disjoint state of a robot.
+// before the current-state system; for K >= 3 the two touch disjoint state of a robot (variable
+// K-1 and its factor slots vs variables 0, 1), so the two updates of a robot run side by side.
 __global__ void k_update_priors(DevWorld w, int n, const int32_t *robots, const double *waypoints, const double *time_scale,
                                 const uint8_t *what, double max_speed, double delta_t) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = g >> 1, which = g & 1;
     if (t >= n) return;
     const int r = robots[t], K = w.K;
     const BlobLayout L(K);
     const double *b = w.blob + (size_t)r * w.BS;
-    if (what[t] & 1u) {
+    if (which == 0 && (what[t] & 1u)) {
         const int i = K - 1;
         const double ex = b[L.mu() + 0 * K + i], ey = b[L.mu() + 1 * K + i];  // estimated position (:2242)
         double hx = waypoints[2 * t] - ex, hy = waypoints[2 * t + 1] - ey;     // horizon2waypoint
@@ -607,7 +609,7 @@ __global__ void k_update_priors(DevWorld w, int n, const int32_t *robots, const 
         const double m[4] = {ex + vx * delta_t, ey + vy * delta_t, vx, vy};      // (:2253-2256)
         apply_change_prior(w, r, i, m);
     }
-    if (what[t] & 2u) {
+    if (which == 1 && (what[t] & 2u)) {
         double m[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
@@ -684,8 +686,8 @@ hipError_t launch_change_prior(const DevWorld &w, int n, const int32_t *robots, 
 hipError_t launch_update_priors(const DevWorld &w, int n, const int32_t *robots, const double *waypoints, const double *time_scale,
                                 const uint8_t *what, double max_speed, double delta_t, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_update_priors, dim3((n + 63) / 64), dim3(64), 0, stream, w, n, robots, waypoints, time_scale, what, max_speed,
-                       delta_t);
+    hipLaunchKernelGGL(k_update_priors, dim3((2 * n + 63) / 64), dim3(64), 0, stream, w, n, robots, waypoints, time_scale, what,
+                       max_speed, delta_t);
     return hipGetLastError();
 }
 hipError_t launch_halo_pack(const DevWorld &w, int n, const int32_t *robots, double *buf, hipStream_t stream) {

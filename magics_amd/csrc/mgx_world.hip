@@ -105,6 +105,49 @@ struct DevBuf {
     }
 };
 
+// Pinned, device-mapped host staging for the small per-tick argument lists: the kernels read them
+// in place over the host link (tens of KB), so a tick enqueues no copy and never synchronises host
+// and device.  A ring of slots, each guarded by an event recorded after the kernel that reads it.
+struct StageRing {
+    static constexpr int SLOTS = 8;
+    void *host[SLOTS] = {};
+    size_t cap[SLOTS] = {};
+    hipEvent_t ev[SLOTS] = {};
+    bool pending[SLOTS] = {};
+    int next = 0;
+    ~StageRing() {
+        for (int i = 0; i < SLOTS; i++) {
+            if (ev[i]) { (void)hipEventSynchronize(ev[i]); (void)hipEventDestroy(ev[i]); }
+            if (host[i]) (void)hipHostFree(host[i]);
+        }
+    }
+    hipError_t acquire(size_t bytes, void **p, int *slot) {
+        const int i = next;
+        next = (next + 1) % SLOTS;
+        hipError_t e;
+        if (!ev[i] && (e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming)) != hipSuccess) return e;
+        if (pending[i]) {
+            if ((e = hipEventSynchronize(ev[i])) != hipSuccess) return e;
+            pending[i] = false;
+        }
+        if (bytes > cap[i]) {
+            if (host[i]) (void)hipHostFree(host[i]);
+            host[i] = nullptr;
+            cap[i] = 0;
+            const size_t want = std::max<size_t>(bytes + bytes / 2, 4096);
+            if ((e = hipHostMalloc(&host[i], want, hipHostMallocMapped)) != hipSuccess) return e;
+            cap[i] = want;
+        }
+        *p = host[i];
+        *slot = i;
+        return hipSuccess;
+    }
+    hipError_t release(int slot, hipStream_t s) {
+        pending[slot] = true;
+        return hipEventRecord(ev[slot], s);
+    }
+};
+
 // mutable state of one robot, item-major (AoS) on the host
 struct Robot {
     int K = 0;
@@ -175,11 +218,7 @@ struct mgx_world {
     DevBuf<uint32_t> epoch0, epoch1;
     DevBuf<float> trk_last_pos, path_xy;
     DevBuf<uint8_t> ir_gate, antenna, idle, sdf;
-    // scratch for change_prior / halo index lists
-    DevBuf<int32_t> tmp_i32;
-    DevBuf<uint32_t> tmp_u32;
-    DevBuf<double> tmp_f64, tmp_f64b;
-    DevBuf<uint8_t> tmp_u8;
+    StageRing stage;  // packed per-tick arguments
     DevBuf<unsigned long long> dbg;  // diagnostic builds only
     // halo plan: local robots whose snapshots are sent / ghost robots that receive, in buffer order
     std::vector<int32_t> halo_send, halo_recv;
@@ -974,22 +1013,28 @@ int mgx_external_variable_iteration(mgx_world *w, int32_t robot) { return w ? sw
 int mgx_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, const uint32_t *var_ix, const double *means) {
     if (!w || !robots || !var_ix || !means) return fail(MGX_ERR_INVALID, "null argument");
     if (n == 0) return MGX_OK;
-    std::vector<int32_t> dr(n);
     for (uint32_t i = 0; i < n; i++) {
         if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size() || w->robots[(size_t)robots[i]].ghost || w->robots[(size_t)robots[i]].removed || (int)var_ix[i] >= w->K)
             return fail(MGX_ERR_INVALID, "bad (robot, variable) at %u", i);
     }
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
-    for (uint32_t i = 0; i < n; i++) dr[i] = w->dev_of[(size_t)robots[i]];
-    std::vector<uint32_t> vv(var_ix, var_ix + n);
-    std::vector<double> mm(means, means + 4 * (size_t)n);
-    HIP_TRY(hipStreamSynchronize(w->stream));  // previous users of the scratch buffers
-    HIP_TRY(w->tmp_i32.upload(dr, w->stream));
-    HIP_TRY(w->tmp_u32.upload(vv, w->stream));
-    HIP_TRY(w->tmp_f64.upload(mm, w->stream));
-    HIP_TRY(launch_change_prior(w->d, (int)n, w->tmp_i32.p, w->tmp_u32.p, w->tmp_f64.p, w->stream));
-    HIP_TRY(hipStreamSynchronize(w->stream));
+    // packed arguments, f64 words: means[4n] | device robot (int32)[n] | variable (uint32)[n]
+    const size_t words = 4 * (size_t)n + (n + 1) / 2 + (n + 1) / 2;
+    void *hp = nullptr;
+    int slot = 0;
+    HIP_TRY(w->stage.acquire(words * sizeof(double), &hp, &slot));
+    double *hm = (double *)hp;
+    int32_t *hr = (int32_t *)(hm + 4 * (size_t)n);
+    uint32_t *hv = (uint32_t *)(hm + 4 * (size_t)n + (n + 1) / 2);
+    memcpy(hm, means, 4 * (size_t)n * sizeof(double));
+    for (uint32_t i = 0; i < n; i++) { hr[i] = w->dev_of[(size_t)robots[i]]; hv[i] = var_ix[i]; }
+    void *dp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+    const double *dm = (const double *)dp;
+    HIP_TRY(launch_change_prior(w->d, (int)n, (const int32_t *)(dm + 4 * (size_t)n), (const uint32_t *)(dm + 4 * (size_t)n + (n + 1) / 2), dm,
+                                w->stream));
+    HIP_TRY(w->stage.release(slot, w->stream));
     return MGX_OK;
 }
 int mgx_update_priors(mgx_world *w, uint32_t n, const int32_t *robots, const double *waypoints_xy, const double *time_scale,
@@ -1002,17 +1047,24 @@ int mgx_update_priors(mgx_world *w, uint32_t n, const int32_t *robots, const dou
             return fail(MGX_ERR_INVALID, "bad entry %u", i);
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
-    std::vector<int32_t> dr(n);
-    for (uint32_t i = 0; i < n; i++) dr[i] = w->dev_of[(size_t)robots[i]];
-    std::vector<double> wp(waypoints_xy, waypoints_xy + 2 * (size_t)n), ts(time_scale, time_scale + n);
-    std::vector<uint8_t> wh(what, what + n);
-    HIP_TRY(hipStreamSynchronize(w->stream));  // previous users of the scratch buffers
-    HIP_TRY(w->tmp_i32.upload(dr, w->stream));
-    HIP_TRY(w->tmp_f64.upload(wp, w->stream));
-    HIP_TRY(w->tmp_f64b.upload(ts, w->stream));
-    HIP_TRY(w->tmp_u8.upload(wh, w->stream));
-    HIP_TRY(launch_update_priors(w->d, (int)n, w->tmp_i32.p, w->tmp_f64.p, w->tmp_f64b.p, w->tmp_u8.p, max_speed, delta_t, w->stream));
-    HIP_TRY(hipStreamSynchronize(w->stream));
+    // packed arguments, f64 words: waypoints[2n] | time_scale[n] | device robot (int32)[n] | what (u8)[n]
+    const size_t w_r = (n + 1) / 2, w_w = (n + 7) / 8, words = 3 * (size_t)n + w_r + w_w;
+    void *hp = nullptr;
+    int slot = 0;
+    HIP_TRY(w->stage.acquire(words * sizeof(double), &hp, &slot));
+    double *hw = (double *)hp;
+    int32_t *hr = (int32_t *)(hw + 3 * (size_t)n);
+    uint8_t *hh = (uint8_t *)(hw + 3 * (size_t)n + w_r);
+    memcpy(hw, waypoints_xy, 2 * (size_t)n * sizeof(double));
+    memcpy(hw + 2 * (size_t)n, time_scale, (size_t)n * sizeof(double));
+    for (uint32_t i = 0; i < n; i++) hr[i] = w->dev_of[(size_t)robots[i]];
+    memcpy(hh, what, n);
+    void *dp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+    const double *dw = (const double *)dp;
+    HIP_TRY(launch_update_priors(w->d, (int)n, (const int32_t *)(dw + 3 * (size_t)n), dw, dw + 2 * (size_t)n,
+                                 (const uint8_t *)(dw + 3 * (size_t)n + w_r), max_speed, delta_t, w->stream));
+    HIP_TRY(w->stage.release(slot, w->stream));
     return MGX_OK;
 }
 
