@@ -641,6 +641,12 @@ __global__ void k_halo_unpack(DevWorld w, int n, const int32_t *ghosts, const do
         w.snap_epoch[w.cur][v0 + (q - SNAP_W * w.K)] = (uint32_t)buf[t];
 }
 
+// small byte copy (flag tables from the pinned argument ring into their device arrays)
+__global__ void k_copy_bytes(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dst[t] = src[t];
+}
+
 // ---- launch wrappers (called from mgx_world.hip) -------------------------------------------------
 size_t sweep_lds_bytes(int K, int ir_edges) {
     const BlobLayout L(K);
@@ -688,6 +694,11 @@ hipError_t launch_update_priors(const DevWorld &w, int n, const int32_t *robots,
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_update_priors, dim3((2 * n + 63) / 64), dim3(64), 0, stream, w, n, robots, waypoints, time_scale, what,
                        max_speed, delta_t);
+    return hipGetLastError();
+}
+hipError_t launch_copy_bytes(uint8_t *dst, const uint8_t *src, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_copy_bytes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, src, n);
     return hipGetLastError();
 }
 hipError_t launch_halo_pack(const DevWorld &w, int n, const int32_t *robots, double *buf, hipStream_t stream) {

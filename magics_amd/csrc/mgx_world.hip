@@ -34,6 +34,7 @@ hipError_t launch_update_priors(const DevWorld &w, int n, const int32_t *robots,
                                 const uint8_t *what, double max_speed, double delta_t, hipStream_t stream);
 hipError_t launch_halo_pack(const DevWorld &w, int n, const int32_t *robots, double *buf, hipStream_t stream);
 hipError_t launch_halo_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *buf, hipStream_t stream);
+hipError_t launch_copy_bytes(uint8_t *dst, const uint8_t *src, size_t n, hipStream_t stream);
 // mgx_topology.hip
 hipError_t neighbours_count(const float *pos, int n, float radius, bool grid, uint32_t M, int32_t *cnt, int32_t *bucket_cnt,
                             int32_t *bucket_ptr, int32_t *cursor, int32_t *members, int32_t *special, int32_t *n_special,
@@ -383,20 +384,32 @@ static int pull(mgx_world *w) {
 
 // ---- commit: host mirror -> device arrays ---------------------------------------------------------
 static int upload_flags(mgx_world *w) {
-    std::vector<uint8_t> an(w->robot_of.size()), id(w->robot_of.size());
-    for (size_t dr = 0; dr < w->robot_of.size(); dr++) {
+    // antenna[R] | idle[R] | gate[NI], staged in one pinned block and moved by a copy kernel: no
+    // blocking copy, no synchronisation (update_failed_comms rewrites every antenna each tick)
+    const size_t R = w->robot_of.size(), NE = std::max<size_t>(w->edge_src_robot.size(), 1);
+    void *hp = nullptr;
+    int slot = 0;
+    HIP_TRY(w->stage.acquire(2 * R + NE, &hp, &slot));
+    uint8_t *an = (uint8_t *)hp, *id = an + R, *gate = id + R;
+    for (size_t dr = 0; dr < R; dr++) {
         an[dr] = w->robots[(size_t)w->robot_of[dr]].antenna;
         id[dr] = w->robots[(size_t)w->robot_of[dr]].idle;
     }
-    std::vector<uint8_t> gate(std::max<size_t>(w->edge_src_robot.size(), 1), 0);
+    gate[0] = 0;
     for (size_t e = 0; e < w->edge_src_robot.size(); e++) {
         const size_t a = (size_t)w->edge_src_robot[e];
         gate[e] = (an[a] && !id[a]) ? 1 : 0;
     }
-    HIP_TRY(w->antenna.upload(an, w->stream));
-    HIP_TRY(w->idle.upload(id, w->stream));
-    HIP_TRY(w->ir_gate.upload(gate, w->stream));
-    HIP_TRY(hipStreamSynchronize(w->stream));  // `an`/`id` are pageable temporaries
+    HIP_TRY(w->antenna.reserve(R));
+    HIP_TRY(w->idle.reserve(R));
+    HIP_TRY(w->ir_gate.reserve(NE));
+    void *dp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+    const uint8_t *src = (const uint8_t *)dp;
+    HIP_TRY(launch_copy_bytes(w->antenna.p, src, R, w->stream));
+    HIP_TRY(launch_copy_bytes(w->idle.p, src + R, R, w->stream));
+    HIP_TRY(launch_copy_bytes(w->ir_gate.p, src + 2 * R, NE, w->stream));
+    HIP_TRY(w->stage.release(slot, w->stream));
     w->d.antenna = w->antenna.p;
     w->d.idle = w->idle.p;
     w->d.ir_gate = w->ir_gate.p;
