@@ -229,6 +229,47 @@ int mgx_halo_plan(mgx_world *w, uint32_t n_send, const int32_t *send_robots, uin
 int mgx_halo_pack(mgx_world *w, void *dev_buf);
 int mgx_halo_unpack(mgx_world *w, const void *dev_buf);
 
+/* ---- direct halo exchange: peer-mapped stores instead of the collective -------
+ * Same dataflow as pack -> all-to-all-v -> unpack, without a collective and without host work
+ * per exchange: each producer's kernel stores its boundary records straight into the consumer
+ * rank's receive area over xGMI and then bumps an arrival counter there; the consumer's kernel
+ * waits for the counters of all its producers and fills its ghost robots.  Once connected, every
+ * world-wide launch that starts with the external factor phase (mgx_iterate, mgx_sweep,
+ * mgx_external_factor_iteration) runs the exchange first, asynchronously on the world's stream.
+ * All ranks must issue the same sequence of such launches (they do: one schedule).
+ *
+ * Wiring, after mgx_halo_plan (send list grouped by consumer, receive list grouped by producer):
+ *   1. mgx_halo_direct_setup: allocates this rank's receive area (2 x n_recv records, fine-grained
+ *      device memory) and n_sources arrival counters; returns their device addresses.
+ *   2. the ranks swap these addresses — mgx_ipc_export / mgx_ipc_open across processes (hipIpc*),
+ *      raw pointers inside one process — together with, per producer, the record offset of its
+ *      segment in the consumer's area and the address of its counter (flag_base + 8 * index of the
+ *      producer among the consumer's sources).
+ *   3. mgx_halo_direct_connect with, per consumer p (send-list segment send_first[p] ..
+ *      send_first[p+1]): the consumer's area, its size in records, the offset of this rank's
+ *      segment in it and this rank's counter there.  Producers and consumers of a rank must be the
+ *      same set of peers (inter-robot factors come in pairs, robot.rs:1490-1541).
+ * A wait that exceeds MGX_HALO_TIMEOUT_MS (default 5000) gives up, leaves the ghosts untouched
+ * and is reported by mgx_halo_direct_status (never a hung GPU). */
+int mgx_halo_direct_setup(mgx_world *w, uint32_t n_sources, void **recv_base, void **flag_base);
+int mgx_halo_direct_connect(mgx_world *w, uint32_t n_peers, const uint32_t *send_first,
+                            void *const *peer_recv_base, const uint64_t *peer_recv_records,
+                            const uint64_t *peer_record_offset, void *const *peer_flag_slot);
+/* The exchange by hand: MGX_HALO_PUSH sends this rank's records for the next exchange,
+ * MGX_HALO_WAIT fills the ghosts once every producer has done so; both = what the launches do by
+ * themselves.  A launch that finds its exchange already pushed only waits — ranks that share one
+ * process (and possibly a hardware queue) push all of them before the first one waits. */
+#define MGX_HALO_PUSH 1u
+#define MGX_HALO_WAIT 2u
+int mgx_halo_direct_exchange(mgx_world *w, uint32_t what);
+int mgx_halo_direct_status(mgx_world *w, uint64_t *exchanges, uint64_t *failed_exchange);
+int mgx_halo_direct_disconnect(mgx_world *w);
+/* hipIpcGetMemHandle / hipIpcOpenMemHandle / hipIpcCloseMemHandle on the addresses above
+ * (64-byte handles), so the host side needs no HIP binding of its own. */
+int mgx_ipc_export(const void *dev_ptr, uint8_t handle[64]);
+int mgx_ipc_open(const uint8_t handle[64], void **dev_ptr);
+int mgx_ipc_close(void *dev_ptr);
+
 /* ---- host helpers (no device needed) --------------------------------------------------- */
 /* gbp_schedule: fills steps[max(n_int,n_ext)] with MGX_STEP_* bits. Returns the count
  * or a negative status. (crates/gbp_schedule/src/schedules/ *.rs) */

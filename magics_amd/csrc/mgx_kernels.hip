@@ -641,6 +641,71 @@ __global__ void k_halo_unpack(DevWorld w, int n, const int32_t *ghosts, const do
         w.snap_epoch[w.cur][v0 + (q - SNAP_W * w.K)] = (uint32_t)buf[t];
 }
 
+// ---- direct halo exchange: peer-mapped stores over xGMI -----------------------------
+// The receive areas and arrival counters are fine-grained device memory of the CONSUMER rank,
+// mapped into this process (hipIpc*, or the same address space when the ranks share a process).
+// Every access to them is a system-scope atomic, so no cache of either GPU can hold them stale.
+//
+// push: the snapshot records of this rank's boundary robots go straight into every consumer's
+// receive area (dst[rr] = address of the record of sent robot rr, for this exchange's parity);
+// the last workgroup to finish then publishes the exchange number in every consumer's counter.
+__global__ void __launch_bounds__(256) k_halo_push(DevWorld w, int n, const int32_t *robots, const unsigned long long *dst, int n_peers,
+                                                   const unsigned long long *peer_flags, unsigned long long seq, unsigned int *done) {
+    const int words = (SNAP_W + 1) * w.K;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n * words) {
+        const int rr = t / words, q = t % words;
+        const int v0 = robots[rr] * w.K;
+        const double val = (q < SNAP_W * w.K) ? w.snap[w.cur][(size_t)v0 * SNAP_W + q] : (double)w.snap_epoch[w.cur][v0 + (q - SNAP_W * w.K)];
+        double *d = reinterpret_cast<double *>(dst[rr]);
+        __hip_atomic_store(&d[q], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int prev = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {  // every workgroup's records are out
+            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            for (int p = 0; p < n_peers; p++)
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(peer_flags[p]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+// wait + unpack: every workgroup waits until all producers have published exchange `seq` (bounded:
+// after `timeout_ticks` of the 100 MHz wall clock it records the failure and leaves), then moves
+// the received records into the ghost robots' snapshot buffers.
+__global__ void __launch_bounds__(256) k_halo_wait_unpack(DevWorld w, int n, const int32_t *ghosts, const double *recv, int n_sources,
+                                                          const unsigned long long *flags, unsigned long long seq,
+                                                          unsigned long long *err, long long timeout_ticks) {
+    __shared__ int ok;
+    if (threadIdx.x == 0) ok = 1;
+    __syncthreads();
+    for (int j = threadIdx.x; j < n_sources; j += blockDim.x) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(&flags[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            if (wall_clock64() - t0 > timeout_ticks) {
+                ok = 0;
+                __hip_atomic_store(err, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    __syncthreads();
+    if (!ok) return;
+    const int words = (SNAP_W + 1) * w.K;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * words) return;
+    const int rr = t / words, q = t % words;
+    const int v0 = ghosts[rr] * w.K;
+    const double val = __hip_atomic_load(&recv[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (q < SNAP_W * w.K)
+        w.snap[w.cur][(size_t)v0 * SNAP_W + q] = val;
+    else
+        w.snap_epoch[w.cur][v0 + (q - SNAP_W * w.K)] = (uint32_t)val;
+}
+
 // small byte copy (flag tables from the pinned argument ring into their device arrays)
 __global__ void k_copy_bytes(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, size_t n) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -694,6 +759,22 @@ hipError_t launch_update_priors(const DevWorld &w, int n, const int32_t *robots,
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_update_priors, dim3((2 * n + 63) / 64), dim3(64), 0, stream, w, n, robots, waypoints, time_scale, what,
                        max_speed, delta_t);
+    return hipGetLastError();
+}
+hipError_t launch_halo_push(const DevWorld &w, int n, const int32_t *robots, const unsigned long long *dst, int n_peers,
+                            const unsigned long long *peer_flags, unsigned long long seq, unsigned int *done, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const int total = n * (SNAP_W + 1) * w.K;
+    hipLaunchKernelGGL(k_halo_push, dim3((total + 255) / 256), dim3(256), 0, stream, w, n, robots, dst, n_peers, peer_flags, seq, done);
+    return hipGetLastError();
+}
+hipError_t launch_halo_wait_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *recv, int n_sources,
+                                   const unsigned long long *flags, unsigned long long seq, unsigned long long *err,
+                                   long long timeout_ticks, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const int total = n * (SNAP_W + 1) * w.K;
+    hipLaunchKernelGGL(k_halo_wait_unpack, dim3((total + 255) / 256), dim3(256), 0, stream, w, n, ghosts, recv, n_sources, flags, seq,
+                       err, timeout_ticks);
     return hipGetLastError();
 }
 hipError_t launch_copy_bytes(uint8_t *dst, const uint8_t *src, size_t n, hipStream_t stream) {

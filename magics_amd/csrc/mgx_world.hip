@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -35,6 +36,11 @@ hipError_t launch_update_priors(const DevWorld &w, int n, const int32_t *robots,
 hipError_t launch_halo_pack(const DevWorld &w, int n, const int32_t *robots, double *buf, hipStream_t stream);
 hipError_t launch_halo_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *buf, hipStream_t stream);
 hipError_t launch_copy_bytes(uint8_t *dst, const uint8_t *src, size_t n, hipStream_t stream);
+hipError_t launch_halo_push(const DevWorld &w, int n, const int32_t *robots, const unsigned long long *dst, int n_peers,
+                            const unsigned long long *peer_flags, unsigned long long seq, unsigned int *done, hipStream_t stream);
+hipError_t launch_halo_wait_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *recv, int n_sources,
+                                   const unsigned long long *flags, unsigned long long seq, unsigned long long *err,
+                                   long long timeout_ticks, hipStream_t stream);
 // mgx_topology.hip
 hipError_t neighbours_count(const float *pos, int n, float radius, bool grid, uint32_t M, int32_t *cnt, int32_t *bucket_cnt,
                             int32_t *bucket_ptr, int32_t *cursor, int32_t *members, int32_t *special, int32_t *n_special,
@@ -225,6 +231,20 @@ struct mgx_world {
     std::vector<int32_t> halo_send, halo_recv;
     DevBuf<int32_t> halo_send_dev, halo_recv_dev;
     bool halo_dirty = false;
+    // direct halo exchange (peer-mapped stores): this rank's receive area and arrival counters are
+    // fine-grained device memory that the producers write; `dst` / `peer_flags` are addresses inside
+    // the consumers' areas
+    struct DirectHalo {
+        double *recv = nullptr;               // [2][recv_words]
+        unsigned long long *flags = nullptr;  // [n_sources] arrival counters, then one error word
+        size_t recv_words = 0;
+        int n_sources = 0, n_peers = 0;
+        bool connected = false;
+        unsigned long long seq = 0, push_seq = 0;  // exchanges waited for / pushed
+        long long timeout_ticks = 500000000ll;  // 5 s of the 100 MHz wall clock
+        DevBuf<unsigned long long> dst[2], peer_flags;
+        DevBuf<unsigned int> done;
+    } direct;
     // neighbour search scratch (mgx_topology.hip)
     DevBuf<float> nb_pos;
     DevBuf<int32_t> nb_cnt, nb_bucket_cnt, nb_bucket_ptr, nb_cursor, nb_members, nb_special, nb_nspecial, nb_ptr, nb_idx;
@@ -607,11 +627,16 @@ static int commit(mgx_world *w) {
 }
 
 // ---- launches -----------------------------------------------------------------------------------------
+static int direct_exchange(mgx_world *w);
 static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_mask, int n_int, uint32_t hints = 0) {
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
     const bool writes_snap = (int_mask & PH_INT_VARIABLE) && n_int > 0;
     if (robot < 0) {
+        if (w->direct.connected && (ext_mask & PH_EXT_FACTOR)) {  // the inter-robot factors read the ghosts' snapshots
+            rc = direct_exchange(w);
+            if (rc != MGX_OK) return rc;
+        }
         const int out = writes_snap ? 1 - w->d.cur : -1;
         HIP_TRY(launch_robot_sweep(w->d, 0, w->d.R_local, ext_mask, int_mask, n_int, out, hints, w->stream));
         if (writes_snap) w->d.cur ^= 1;
@@ -647,6 +672,8 @@ int mgx_world_create(const mgx_params *params, mgx_world **out) {
 int mgx_world_destroy(mgx_world *w) {
     if (!w) return MGX_OK;
     if (w->dev_valid) (void)hipStreamSynchronize(w->stream);
+    if (w->direct.recv) (void)hipFree(w->direct.recv);
+    if (w->direct.flags) (void)hipFree(w->direct.flags);
     delete w;
     return MGX_OK;
 }
@@ -1181,6 +1208,161 @@ static int halo_commit(mgx_world *w) {
     HIP_TRY(w->halo_recv_dev.upload(b, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
     w->halo_dirty = false;
+    return MGX_OK;
+}
+
+}  // extern "C" (helpers below have C++ linkage)
+
+// push: this rank's boundary records go to the consumers (exchange number push_seq + 1);
+// wait: the ghosts are filled once every producer has published exchange seq + 1.
+static int direct_push(mgx_world *w) {
+    int rc = halo_commit(w);
+    if (rc != MGX_OK) return rc;
+    mgx_world::DirectHalo &dh = w->direct;
+    if (dh.push_seq != dh.seq) return fail(MGX_ERR_STATE, "exchange %llu is already pushed and not yet waited for", dh.push_seq);
+    dh.push_seq += 1;
+    const int par = (int)(dh.push_seq & 1ull);
+    HIP_TRY(launch_halo_push(w->d, (int)w->halo_send.size(), w->halo_send_dev.p, dh.dst[par].p, dh.n_peers, dh.peer_flags.p, dh.push_seq,
+                             dh.done.p, w->stream));
+    return MGX_OK;
+}
+static int direct_wait(mgx_world *w) {
+    int rc = halo_commit(w);
+    if (rc != MGX_OK) return rc;
+    mgx_world::DirectHalo &dh = w->direct;
+    if (dh.push_seq != dh.seq + 1) return fail(MGX_ERR_STATE, "nothing pushed for exchange %llu", dh.seq + 1);
+    dh.seq += 1;
+    const int par = (int)(dh.seq & 1ull);
+    HIP_TRY(launch_halo_wait_unpack(w->d, (int)w->halo_recv.size(), w->halo_recv_dev.p, dh.recv + (size_t)par * dh.recv_words,
+                                    dh.n_sources, dh.flags, dh.seq, dh.flags + dh.n_sources, dh.timeout_ticks, w->stream));
+    return MGX_OK;
+}
+static int direct_exchange(mgx_world *w) {
+    if (w->direct.push_seq == w->direct.seq) {  // not pushed ahead by the caller
+        int rc = direct_push(w);
+        if (rc != MGX_OK) return rc;
+    }
+    return direct_wait(w);
+}
+
+extern "C" {
+
+// ---- direct halo exchange (peer-mapped stores) ---------------------------------------------
+int mgx_halo_direct_setup(mgx_world *w, uint32_t n_sources, void **recv_base, void **flag_base) {
+    if (!w || !recv_base || !flag_base) return fail(MGX_ERR_INVALID, "null argument");
+    int rc = halo_commit(w);
+    if (rc != MGX_OK) return rc;
+    mgx_world::DirectHalo &dh = w->direct;
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    dh.connected = false;
+    if (dh.recv) { (void)hipFree(dh.recv); dh.recv = nullptr; }
+    if (dh.flags) { (void)hipFree(dh.flags); dh.flags = nullptr; }
+    dh.recv_words = w->halo_recv.size() * (size_t)mgx_halo_words((uint32_t)w->K);
+    dh.n_sources = (int)n_sources;
+    const size_t rb = std::max<size_t>(2 * dh.recv_words, 1) * sizeof(double), fb = ((size_t)n_sources + 1) * sizeof(unsigned long long);
+    // fine-grained: coherent with stores arriving from other GPUs / processes while kernels run
+    HIP_TRY(hipExtMallocWithFlags((void **)&dh.recv, rb, hipDeviceMallocFinegrained));
+    HIP_TRY(hipExtMallocWithFlags((void **)&dh.flags, fb, hipDeviceMallocFinegrained));
+    HIP_TRY(hipMemsetAsync(dh.recv, 0, rb, w->stream));
+    HIP_TRY(hipMemsetAsync(dh.flags, 0, fb, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    dh.seq = dh.push_seq = 0;
+    if (const char *ms = getenv("MGX_HALO_TIMEOUT_MS")) {
+        const long long v = atoll(ms);
+        if (v > 0) dh.timeout_ticks = v * 100000ll;
+    }
+    *recv_base = dh.recv;
+    *flag_base = dh.flags;
+    return MGX_OK;
+}
+
+int mgx_halo_direct_connect(mgx_world *w, uint32_t n_peers, const uint32_t *send_first, void *const *peer_recv_base,
+                            const uint64_t *peer_recv_records, const uint64_t *peer_record_offset, void *const *peer_flag_slot) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    mgx_world::DirectHalo &dh = w->direct;
+    if (!dh.flags) return fail(MGX_ERR_STATE, "mgx_halo_direct_setup first");
+    if (n_peers && (!send_first || !peer_recv_base || !peer_recv_records || !peer_record_offset || !peer_flag_slot))
+        return fail(MGX_ERR_INVALID, "null argument");
+    if ((int)n_peers != dh.n_sources)
+        return fail(MGX_ERR_INVALID, "%u consumers but %d producers: the exchange must be symmetric (every peer both sends and receives)",
+                    n_peers, dh.n_sources);
+    const size_t n_send = w->halo_send.size(), words = (size_t)mgx_halo_words((uint32_t)w->K);
+    if (n_peers && (send_first[0] != 0 || send_first[n_peers] != n_send)) return fail(MGX_ERR_INVALID, "send_first does not cover the send list");
+    std::vector<unsigned long long> d0(std::max<size_t>(n_send, 1), 0ull), d1(std::max<size_t>(n_send, 1), 0ull), pf(std::max<size_t>(n_peers, 1), 0ull);
+    for (uint32_t p = 0; p < n_peers; p++) {
+        if (send_first[p + 1] <= send_first[p]) return fail(MGX_ERR_INVALID, "peer %u receives nothing", p);
+        if (!peer_recv_base[p] || !peer_flag_slot[p]) return fail(MGX_ERR_INVALID, "peer %u: null address", p);
+        const uint64_t cnt = send_first[p + 1] - send_first[p];
+        if (peer_record_offset[p] + cnt > peer_recv_records[p]) return fail(MGX_ERR_INVALID, "peer %u: segment exceeds its receive area", p);
+        for (uint32_t i = send_first[p]; i < send_first[p + 1]; i++) {
+            const unsigned long long base = (unsigned long long)(uintptr_t)peer_recv_base[p];
+            const unsigned long long rec = peer_record_offset[p] + (i - send_first[p]);
+            d0[i] = base + (0ull * peer_recv_records[p] + rec) * words * sizeof(double);
+            d1[i] = base + (1ull * peer_recv_records[p] + rec) * words * sizeof(double);
+        }
+        pf[p] = (unsigned long long)(uintptr_t)peer_flag_slot[p];
+    }
+    std::vector<unsigned int> zero(1, 0u);
+    HIP_TRY(dh.dst[0].upload(d0, w->stream));
+    HIP_TRY(dh.dst[1].upload(d1, w->stream));
+    HIP_TRY(dh.peer_flags.upload(pf, w->stream));
+    HIP_TRY(dh.done.upload(zero, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    dh.n_peers = (int)n_peers;
+    dh.seq = dh.push_seq = 0;
+    dh.connected = true;
+    return MGX_OK;
+}
+
+int mgx_halo_direct_exchange(mgx_world *w, uint32_t what) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    if (!w->direct.connected) return fail(MGX_ERR_STATE, "direct halo exchange is not connected");
+    if (what == MGX_HALO_PUSH) return direct_push(w);
+    if (what == MGX_HALO_WAIT) return direct_wait(w);
+    if (what == (MGX_HALO_PUSH | MGX_HALO_WAIT)) return direct_exchange(w);
+    return fail(MGX_ERR_INVALID, "bad phase mask");
+}
+
+int mgx_halo_direct_status(mgx_world *w, uint64_t *exchanges, uint64_t *failed_exchange) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    mgx_world::DirectHalo &dh = w->direct;
+    if (!dh.flags) return fail(MGX_ERR_STATE, "direct halo exchange is not set up");
+    unsigned long long err = 0;
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    HIP_TRY(hipMemcpy(&err, dh.flags + dh.n_sources, sizeof err, hipMemcpyDeviceToHost));
+    if (exchanges) *exchanges = dh.seq;
+    if (failed_exchange) *failed_exchange = err;
+    if (err) return fail(MGX_ERR_STATE, "halo exchange %llu timed out waiting for a peer", err);
+    return MGX_OK;
+}
+
+int mgx_halo_direct_disconnect(mgx_world *w) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    w->direct.connected = false;
+    return MGX_OK;
+}
+
+// hipIpc* wrappers so that a host language needs no HIP binding of its own to share the areas
+int mgx_ipc_export(const void *dev_ptr, uint8_t handle[64]) {
+    if (!dev_ptr || !handle) return fail(MGX_ERR_INVALID, "null argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, const_cast<void *>(dev_ptr)));
+    memcpy(handle, &h, 64);
+    return MGX_OK;
+}
+int mgx_ipc_open(const uint8_t handle[64], void **dev_ptr) {
+    if (!handle || !dev_ptr) return fail(MGX_ERR_INVALID, "null argument");
+    if (!device_ok()) return fail(MGX_ERR_NO_DEVICE, "no HIP device");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, 64);
+    HIP_TRY(hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return MGX_OK;
+}
+int mgx_ipc_close(void *dev_ptr) {
+    if (!dev_ptr) return MGX_OK;
+    HIP_TRY(hipIpcCloseMemHandle(dev_ptr));
     return MGX_OK;
 }
 

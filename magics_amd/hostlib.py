@@ -25,6 +25,7 @@ SCHEDULE_HALF_BEGINNING_HALF_END = 4
 STEP_INTERNAL = 1
 STEP_EXTERNAL = 2
 NEIGHBOURS_AUTO, NEIGHBOURS_PAIRS, NEIGHBOURS_GRID = 0, 1, 2
+HALO_PUSH, HALO_WAIT = 1, 2
 HINT_NEXT_STARTS_EXTERNAL = 1
 
 c_double_p = C.POINTER(C.c_double)
@@ -97,6 +98,14 @@ SYMBOLS = {
                                  C.POINTER(C.c_int32)]),
     "mgx_read_beliefs": (C.c_int, [_V, c_double_p, c_double_p, c_double_p]),
     "mgx_read_means": (C.c_int, [_V, c_double_p]),
+    "mgx_halo_direct_setup": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "mgx_halo_direct_connect": (C.c_int, [_V, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgx_halo_direct_exchange": (C.c_int, [_V, C.c_uint32]),
+    "mgx_halo_direct_status": (C.c_int, [_V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "mgx_halo_direct_disconnect": (C.c_int, [_V]),
+    "mgx_ipc_export": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "mgx_ipc_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "mgx_ipc_close": (C.c_int, [C.c_void_p]),
     "mgx_num_robots": (C.c_int, [_V, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mgx_halo_words": (C.c_uint32, [C.c_uint32]),
     "mgx_halo_plan": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_int32)]),
@@ -158,6 +167,23 @@ def check(rc, L=None):
     if rc < 0:
         raise MgxError(f"mgx error {rc}: {(L or lib()).mgx_last_error().decode(errors='replace')}")
     return rc
+
+
+def ipc_export(dev_ptr):
+    """64-byte hipIpc handle of a device allocation (mgx_ipc_export)."""
+    buf = C.create_string_buffer(64)
+    check(lib().mgx_ipc_export(C.c_void_p(dev_ptr), buf))
+    return buf.raw
+
+
+def ipc_open(handle):
+    out = C.c_void_p()
+    check(lib().mgx_ipc_open(handle, C.byref(out)))
+    return out.value
+
+
+def ipc_close(dev_ptr):
+    check(lib().mgx_ipc_close(C.c_void_p(dev_ptr)))
 
 
 def schedule(kind, n_internal, n_external):

@@ -12,6 +12,11 @@ before the launch that runs the external phase; no other collective exists on th
 the send / receive lists and drives ``mgx_sweep`` segments with the exchange in between.  The
 communicator is injected: ``TorchDistComm`` (RCCL via torch.distributed "nccl"; "gloo" in the CPU
 tests) or a ``LocalCluster`` that runs several ranks inside one process (single-GPU tests).
+
+``connect_direct`` replaces the collective by peer-mapped stores (include/mgx.h, "direct halo
+exchange"): producers write their boundary records straight into the consumers' receive areas
+(hipIpc-mapped across processes) and the engine waits for them on the device, so an external
+iteration costs no host work beyond the launches and ``iterate`` is one C call per tick.
 """
 import numpy as np
 
@@ -109,6 +114,55 @@ class ShardedWorld:
         self.send_buf = make(max(1, sum(self.send_counts)))
         self.recv_buf = make(max(1, sum(self.recv_counts)))
 
+        self.direct = False
+
+    # -- direct exchange wiring ----------------------------------------------------------------------
+    def direct_setup(self, export_ipc):
+        """Allocate this rank's receive area; returns what the peers need to know about it."""
+        plan, ws = self.plan, self.plan.world_size
+        sources = [p for p in range(ws) if plan.recv_lists[p]]
+        recv, flags = self.world.halo_direct_setup(len(sources))
+        offsets, acc = [], 0
+        for p in range(ws):
+            offsets.append(acc)
+            acc += len(plan.recv_lists[p])
+        info = dict(rank=plan.rank, n_records=acc, offsets=offsets, slot={p: j for j, p in enumerate(sources)})
+        if export_ipc:
+            info["recv_handle"], info["flags_handle"] = hostlib.ipc_export(recv), hostlib.ipc_export(flags)
+        else:
+            info["recv_ptr"], info["flags_ptr"] = recv, flags
+        return info
+
+    def direct_connect(self, infos):
+        """infos[q]: what rank q published in direct_setup (handles are opened here)."""
+        plan, ws = self.plan, self.plan.world_size
+        consumers = [q for q in range(ws) if plan.send_lists[q]]
+        first, base, nrec, off, slot = [0], [], [], [], []
+        self._opened = getattr(self, "_opened", [])
+        for q in consumers:
+            inf = infos[q]
+            if "recv_ptr" in inf:
+                r, f = inf["recv_ptr"], inf["flags_ptr"]
+            else:
+                r, f = hostlib.ipc_open(inf["recv_handle"]), hostlib.ipc_open(inf["flags_handle"])
+                self._opened += [r, f]
+            first.append(first[-1] + len(plan.send_lists[q]))
+            base.append(r)
+            nrec.append(inf["n_records"])
+            off.append(inf["offsets"][plan.rank])
+            slot.append(f + 8 * inf["slot"][plan.rank])
+        self.world.halo_direct_connect(first, base, nrec, off, slot)
+        self.direct = True
+
+    def direct_close(self):
+        """Call on every rank, after a barrier: nobody may still be pushing into a closed area."""
+        if self.direct:
+            self.world.halo_direct_disconnect()
+            self.direct = False
+        for ptr in getattr(self, "_opened", []):
+            hostlib.ipc_close(ptr)
+        self._opened = []
+
     # -- exchange pieces (a LocalCluster drives them itself) ---------------------------------------
     def pack(self):
         self.world.halo_pack(self.send_buf.data_ptr())
@@ -117,7 +171,7 @@ class ShardedWorld:
         self.world.halo_unpack(self.recv_buf.data_ptr())
 
     def exchange(self):
-        if self.plan.world_size == 1:
+        if self.plan.world_size == 1 or self.direct:  # direct: the engine exchanges inside the launch sequence
             return
         self.pack()
         self.comm.all_to_all(self.recv_buf, self.send_buf, self.recv_counts, self.send_counts)
@@ -129,6 +183,9 @@ class ShardedWorld:
 
     # -- World-like interface over global robot ids -------------------------------------------------
     def iterate(self, steps):
+        if self.direct or self.plan.world_size == 1:
+            self.world.iterate(steps)  # one C call: launches (and exchanges) are sequenced by the engine
+            return
         segs = segments(steps)
         for k, (ext, n_int) in enumerate(segs):
             if ext:
@@ -164,6 +221,16 @@ def _torch_tensor_factory(n):
     return torch.zeros(n, dtype=torch.float64, device="cuda")
 
 
+def connect_direct(sw, comm):
+    """Wire the direct exchange of a multi-process run: one all-gather of the (tiny) area
+    descriptions over the control-plane communicator, then every rank maps its consumers' areas."""
+    if sw.plan.world_size == 1:
+        return
+    infos = comm.all_gather_object(sw.direct_setup(export_ipc=True))
+    sw.direct_connect({inf["rank"]: inf for inf in infos})
+    comm.barrier()
+
+
 class TorchDistComm:
     """all-to-all-v over torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" on CPU)."""
 
@@ -176,15 +243,30 @@ class TorchDistComm:
         self.dist.all_to_all_single(recv[:n_r], send[:n_s], output_split_sizes=list(recv_counts),
                                     input_split_sizes=list(send_counts), group=self.group)
 
+    def all_gather_object(self, obj):
+        out = [None] * self.dist.get_world_size(self.group)
+        self.dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
 
 class LocalCluster:
     """All ranks of a sharded world inside ONE process (one GPU): used by the tests to check the
     ghost / halo numerics against the unsharded world without a multi-GPU node."""
 
-    def __init__(self, sc, world_size, world_factory, owner=None, tensor_factory=None):
+    def __init__(self, sc, world_size, world_factory, owner=None, tensor_factory=None, direct=False):
+        """direct=True: the ranks exchange through peer-mapped stores (same address space, no IPC);
+        `world_factory` must then give every rank its OWN stream — a rank's wait kernel would block
+        a shared stream before the other rank's stores are even enqueued."""
         self.ranks = [ShardedWorld(sc, r, world_size, world_factory, comm=None, owner=owner,
                                    tensor_factory=tensor_factory) for r in range(world_size)]
         self.n_robots, self.K = len(sc["robots"]), sc["K"]
+        if direct and world_size > 1:
+            infos = {sw.plan.rank: sw.direct_setup(export_ipc=False) for sw in self.ranks}
+            for sw in self.ranks:
+                sw.direct_connect(infos)
 
     def _exchange(self):
         for sw in self.ranks:
@@ -208,7 +290,13 @@ class LocalCluster:
         segs = segments(steps)
         for k, (ext, n_int) in enumerate(segs):
             if ext and len(self.ranks) > 1:
-                self._exchange()
+                if self.ranks[0].direct:
+                    # all pushes before the first wait: the ranks' streams may share a hardware queue
+                    # here, and a waiting kernel must never sit in front of the stores it waits for
+                    for sw in self.ranks:
+                        sw.world.halo_direct_exchange(hostlib.HALO_PUSH)
+                else:
+                    self._exchange()
             for sw in self.ranks:
                 sw.sweep_segment(ext, n_int, next_ext=k + 1 < len(segs) and segs[k + 1][0])
 

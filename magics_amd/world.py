@@ -218,6 +218,34 @@ class World:
     def halo_words(K):
         return hostlib.lib().mgx_halo_words(K)
 
+    # direct halo exchange (peer-mapped stores; see include/mgx.h)
+    def halo_direct_setup(self, n_sources):
+        recv, flags = C.c_void_p(), C.c_void_p()
+        self._chk(self._L.mgx_halo_direct_setup(self._w, n_sources, C.byref(recv), C.byref(flags)))
+        return recv.value, flags.value
+
+    def halo_direct_connect(self, send_first, peer_recv_base, peer_recv_records, peer_record_offset, peer_flag_slot):
+        n = len(peer_recv_base)
+        a = np.ascontiguousarray(send_first, dtype=np.uint32)
+        b = np.ascontiguousarray(peer_recv_base, dtype=np.uint64)
+        c = np.ascontiguousarray(peer_recv_records, dtype=np.uint64)
+        d = np.ascontiguousarray(peer_record_offset, dtype=np.uint64)
+        e = np.ascontiguousarray(peer_flag_slot, dtype=np.uint64)
+        assert a.size == n + 1 and b.size == c.size == d.size == e.size == n
+        self._chk(self._L.mgx_halo_direct_connect(self._w, n, a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, e.ctypes.data))
+
+    def halo_direct_exchange(self, what=hostlib.HALO_PUSH | hostlib.HALO_WAIT):
+        self._chk(self._L.mgx_halo_direct_exchange(self._w, what))
+
+    def halo_direct_status(self):
+        """Number of exchanges so far; raises if one of them timed out waiting for a peer."""
+        n, bad = C.c_uint64(), C.c_uint64()
+        self._chk(self._L.mgx_halo_direct_status(self._w, C.byref(n), C.byref(bad)))
+        return n.value
+
+    def halo_direct_disconnect(self):
+        self._chk(self._L.mgx_halo_direct_disconnect(self._w))
+
     def halo_plan(self, send_robots, recv_ghosts):
         a = np.ascontiguousarray(send_robots, dtype=np.int32)
         b = np.ascontiguousarray(recv_ghosts, dtype=np.int32)

@@ -1,0 +1,42 @@
+"""One rank of the multi-process direct-halo test (tests/test_gpu_direct_halo_mp.py): every rank
+is its own process on cuda:0, the control plane is gloo, the data plane is hipIpc-mapped
+peer stores.  usage: direct_halo_worker.py RANK WORLD_SIZE PORT OUT.npz"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, ws, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(ws))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    torch.cuda.set_device(0)
+    from magics_amd import World, scenarios as S, sharded
+    sc = S.grid_scenario(64, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
+    comm = sharded.TorchDistComm()
+    sw = sharded.ShardedWorld(sc, rank, ws, World, comm=comm)
+    sharded.connect_direct(sw, comm)
+    steps = sc["steps"] + [1, 1, 2, 3, 2]
+    boundary = sorted({g for r in range(ws) for g in sharded.ShardPlan(sc, r, ws).ghosts})
+    for tick in range(3):
+        if tick == 1:
+            sw.set_antenna(boundary[0], False)
+            sw.change_prior(boundary[2], 9, np.array([0.5, 0.25, 1.0, -1.0]))
+        if tick == 2:
+            sw.set_antenna(boundary[0], True)
+        sw.iterate(steps)
+    ids, eta, lam, mu = sw.read_beliefs()
+    n = sw.world.halo_direct_status()
+    np.savez(out, ids=np.array(ids), eta=eta, lam=lam, mu=mu, n=n)
+    dist.barrier()
+    sw.direct_close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,67 @@
+"""Direct halo exchange across PROCESSES: two / three ranks, each its own process on the one GPU
+of the test box, map each other's receive areas with hipIpc and exchange through peer stores and
+device-side arrival counters.  The assembled beliefs must equal the single-world oracle's."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from magics_amd import scenarios as S, sharded
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
+@pytest.mark.parametrize("world_size", [2, 3])
+def test_ranks_in_separate_processes(world_size, tmp_path):
+    port = _free_port()
+    outs = [str(tmp_path / f"rank{r}.npz") for r in range(world_size)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MGX_HALO_TIMEOUT_MS="20000")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "direct_halo_worker.py"), str(r), str(world_size), port, outs[r]],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world_size)]
+    logs = []
+    try:
+        for p in procs:
+            logs.append(p.communicate(timeout=240)[0].decode(errors="replace"))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+
+    sc = S.grid_scenario(64, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
+    K = sc["K"]
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    steps = sc["steps"] + [1, 1, 2, 3, 2]
+    boundary = sorted({g for r in range(world_size) for g in sharded.ShardPlan(sc, r, world_size).ghosts})
+    for tick in range(3):
+        if tick == 1:
+            ref.set_antenna(boundary[0], False)
+            ref.change_prior(boundary[2], 9, np.array([0.5, 0.25, 1.0, -1.0]))
+        if tick == 2:
+            ref.set_antenna(boundary[0], True)
+        ref.iterate(steps)
+    eta_r, lam_r, mu_r = ref.read_beliefs()
+    n_ext = 3 * sum(1 for s in steps if s & 2)
+    seen = 0
+    for o in outs:
+        d = np.load(o)
+        assert int(d["n"]) == n_ext
+        for j, g in enumerate(d["ids"]):
+            sl, dl = slice(g * K, (g + 1) * K), slice(j * K, (j + 1) * K)
+            assert np.array_equal(d["eta"][dl], eta_r[sl]) and np.array_equal(d["lam"][dl], lam_r[sl]) and np.array_equal(d["mu"][dl], mu_r[sl]), (o, g)
+            seen += 1
+    assert seen == len(sc["robots"])

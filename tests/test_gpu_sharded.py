@@ -44,3 +44,68 @@ def test_local_cluster_gating_and_prior_changes():
     script(cluster)
     script(ref)
     assert_identical(cluster, ref, what="3 ranks, gating + change_prior on boundary robots")
+
+
+def _own_stream_factory():
+    """Every rank of a direct-exchange cluster needs its own stream (see LocalCluster)."""
+    import torch
+    streams = []
+
+    def make(params):
+        st = torch.cuda.Stream()
+        streams.append(st)
+        return World(params, stream=st.cuda_stream)
+    return make, streams
+
+
+@pytest.mark.parametrize("world_size", [2, 3])
+def test_direct_exchange_equals_oracle(world_size):
+    """Peer-mapped stores + device-side arrival counters instead of the all-to-all-v."""
+    sc = S.grid_scenario(64, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
+    make, streams = _own_stream_factory()
+    cluster = sharded.LocalCluster(sc, world_size, make, direct=True)
+    assert all(sw.direct for sw in cluster.ranks)
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    steps = sc["steps"] + [1, 1, 2, 3, 2]
+    n_ext = sum(1 for s in steps if s & 2)
+    for tick in range(3):
+        cluster.iterate(steps)
+        ref.iterate(steps)
+        assert_identical(cluster, ref, what=f"direct exchange, {world_size} ranks, tick {tick}")
+    for sw in cluster.ranks:
+        assert sw.world.halo_direct_status() == 3 * n_ext
+
+
+def test_direct_exchange_gating_and_prior_changes():
+    sc = S.grid_scenario(36, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
+    make, streams = _own_stream_factory()
+    cluster = sharded.LocalCluster(sc, 3, make, direct=True)
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    boundary = sorted({g for sw in cluster.ranks for g in sw.plan.ghosts})
+
+    def script(w):
+        w.iterate([3, 3, 3])
+        w.set_antenna(boundary[0], False)
+        w.set_idle(boundary[1], True)
+        w.change_prior(boundary[2], 9, np.array([0.5, 0.25, 1.0, -1.0]))
+        w.iterate([3, 3, 3])
+        w.set_antenna(boundary[0], True)
+        w.set_idle(boundary[1], False)
+        w.iterate([3, 3])
+    script(cluster)
+    script(ref)
+    assert_identical(cluster, ref, what="direct exchange, gating + change_prior on boundary robots")
+
+
+def test_direct_exchange_reports_a_missing_peer(monkeypatch):
+    """A producer that never shows up must end in a reported timeout, not in a hung GPU."""
+    monkeypatch.setenv("MGX_HALO_TIMEOUT_MS", "200")
+    sc = S.grid_scenario(36, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
+    make, streams = _own_stream_factory()
+    cluster = sharded.LocalCluster(sc, 2, make, direct=True)
+    lonely = cluster.ranks[0]
+    lonely.iterate([3])            # rank 1 never runs its side of the exchange
+    with pytest.raises(RuntimeError, match="timed out"):
+        lonely.world.halo_direct_status()
