@@ -18,6 +18,7 @@ boundary snapshots per external iteration.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -38,10 +39,13 @@ def parse():
     ap.add_argument("--horizon", type=int, default=16)
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-direct", action="store_true", help="N > 1: skip the direct-exchange child measurement")
     ap.add_argument("--secondary-deadline", type=float, default=240.0,
                     help="N > 1 only: seconds the sharded (collective) phase may take before it is abandoned")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--fma", action="store_true", help="use the FMA-contracting build (not the product)")
+    ap.add_argument("--role", default="main", choices=["main", "direct-child"],
+                    help="direct-child: one rank of the isolated direct-exchange measurement (spawned by the main role)")
     return ap.parse_args()
 
 
@@ -134,6 +138,120 @@ def measured_traffic(key):
         return None
 
 
+def direct_child(a):
+    """One rank of the sharded inter-robot workload with the DIRECT halo exchange (peer-mapped
+    stores over xGMI, include/mgx.h) — run as a child process of each bench rank so that nothing
+    it does can take the main measurement down.  Control plane: gloo; no RCCL in this process."""
+    import torch
+    import torch.distributed as dist
+    rank, world_size = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(int(os.environ.get("MGX_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    dist.init_process_group("gloo")
+    from magics_amd import World, scenarios as S, sharded
+    stream = torch.cuda.current_stream().cuda_stream
+    n_loc, K = a.robots_per_gpu, a.horizon
+    n_tot = n_loc * world_size
+
+    def agree(ok):  # every rank succeeded so far?
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t[0]) == 1
+
+    out, sw, err = {}, None, ""
+    try:
+        sc2 = S.grid_scenario(n_tot, K, interrobot=True, seed=805)
+        comm = sharded.TorchDistComm()
+        sw = sharded.ShardedWorld(sc2, rank, world_size, lambda p: World(p, stream=stream, fma=a.fma), comm=comm)
+        sw.world.sweep(0, 0, 0)
+        info = sw.direct_setup(export_ipc=True)
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    if not agree(not err):
+        out = {"error": err or "another rank failed to set up"}
+    else:
+        infos = comm.all_gather_object(info)
+        try:
+            sw.direct_connect({i["rank"]: i for i in infos})
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        if not agree(not err):
+            out = {"error": err or "another rank failed to map its peers"}
+    if not out:
+        steps2 = sc2["steps"]
+        n2, w2 = max(SCHEDULE_LEN, a.steps // 4), max(SCHEDULE_LEN, a.warmup // 4)
+        run_steps(sw.iterate, w2, steps2)
+        try:
+            sw.world.halo_direct_status()  # synchronises; raises if a wait timed out
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        if not agree(not err):
+            out = {"error": err or "another rank timed out in the warm-up"}
+    if not out:
+        dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        run_steps(sw.iterate, n2, steps2)
+        ev1.record()
+        torch.cuda.synchronize()
+        dist.barrier()
+        wall = time.perf_counter() - t0
+        t = torch.tensor([wall, ev0.elapsed_time(ev1) * 1e-3], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev = float(t[0]), float(t[1])
+        try:
+            n_ex = sw.world.halo_direct_status()
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        if not agree(not err):
+            out = {"error": err or "another rank timed out"}
+        else:
+            D = len(sc2["ir"]) / n_tot
+            bytes2 = S.algorithmic_bytes_per_robot_iter(K, D) * n_loc
+            out = {"value": round(n2 / wall, 2), "unit": f"GBP iterations/s (one iteration over all {n_tot} robots)",
+                   "steps": n2, "ms_per_step": wall / n2 * 1e3, "exchanges": n_ex,
+                   "exchange": "direct: peer-mapped stores into the consumers' receive areas (hipIpc) + device-side arrival "
+                               "counters, one C call per tick, no collective",
+                   "ghost_robots_this_rank": len(sw.plan.ghosts),
+                   "roofline": {"bound": "hbm", "achieved": round(bytes2 * n2 / dev / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(bytes2 * n2 / dev / 1e9 / HBM_PEAK_GBS, 4)}}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    if sw is not None:
+        sw.direct_close()
+    dist.destroy_process_group()
+
+
+def run_direct_children(a, rank, local_rank, world_size):
+    """Spawn this rank's direct-exchange child and wait for it (bounded).  Returns the child's JSON
+    (rank 0) or a description of what went wrong; never raises."""
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world_size),
+               MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 23),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.setdefault("MGX_HALO_TIMEOUT_MS", "2000")
+    cmd = [sys.executable, os.path.abspath(__file__), "--role", "direct-child", "--gpus", str(world_size), "--steps", str(a.steps),
+           "--warmup", str(a.warmup), "--robots-per-gpu", str(a.robots_per_gpu), "--horizon", str(a.horizon)] + (["--fma"] if a.fma else [])
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=a.secondary_deadline)
+    except subprocess.TimeoutExpired:
+        return {"error": f"direct-exchange child did not finish within {a.secondary_deadline} s"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+    if rank != 0:
+        return None
+    for ln in reversed(r.stdout.decode(errors="replace").splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                pass
+    return {"error": f"child exit code {r.returncode}: {r.stderr.decode(errors='replace')[-400:]}"}
+
+
 class _Deadline:
     """Ends the process from a timer thread if a phase with collectives overruns (see main)."""
 
@@ -160,6 +278,8 @@ class _Deadline:
 
 def main():
     a = parse()
+    if a.role == "direct-child":
+        return direct_child(a)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -282,6 +402,12 @@ def main():
             sc2 = None
 
     guard.cancel()
+
+    # ---- the same sharded workload with the direct exchange, isolated in child processes ---------
+    if multi and not a.no_secondary and not a.no_direct:
+        res = run_direct_children(a, rank, local_rank, world_size)
+        if rank == 0 and isinstance(line.get("secondary"), dict):
+            line["secondary"]["direct_exchange"] = res
 
     # ---- CPU baseline: rank 0, N = 1 only ---------------------------------------------------------
     if rank == 0 and not multi and not a.no_cpu_baseline:

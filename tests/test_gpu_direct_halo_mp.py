@@ -65,3 +65,31 @@ def test_ranks_in_separate_processes(world_size, tmp_path):
             assert np.array_equal(d["eta"][dl], eta_r[sl]) and np.array_equal(d["lam"][dl], lam_r[sl]) and np.array_equal(d["mu"][dl], mu_r[sl]), (o, g)
             seen += 1
     assert seen == len(sc["robots"])
+
+
+def test_bench_direct_child_role(tmp_path):
+    """bench.py's isolated direct-exchange measurement (what every bench rank spawns at N > 1),
+    here two ranks on the one GPU of the box."""
+    import json
+    port = _free_port()
+    bench = os.path.join(os.path.dirname(HERE), "bench.py")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   MGX_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", MGX_HALO_TIMEOUT_MS="20000")
+        procs.append(subprocess.Popen([sys.executable, bench, "--role", "direct-child", "--gpus", "2", "--steps", "80", "--warmup", "20",
+                                       "--robots-per-gpu", "100", "--horizon", "10"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=240))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, outs[r][1].decode(errors="replace")[-3000:]
+    res = json.loads([ln for ln in outs[0][0].decode().splitlines() if ln.startswith("{")][-1])
+    assert "error" not in res, res
+    assert res["value"] > 0 and res["exchanges"] > 0 and res["ghost_robots_this_rank"] > 0
