@@ -58,7 +58,7 @@ def run_steps(iterate, n, steps_one_tick):
         iterate(steps_one_tick[:rem])
 
 
-def timed(torch, dist, iterate, steps_one_tick, n_steps, n_warm, multi):
+def timed(torch, dist, iterate, steps_one_tick, n_steps, n_warm, multi, red_dev="cuda"):
     """W warm-up steps, then exactly K steps between barrier + synchronize; returns
     (wall seconds MAX over ranks, device seconds between HIP events on the launch stream)."""
     run_steps(iterate, n_warm, steps_one_tick)
@@ -76,7 +76,7 @@ def timed(torch, dist, iterate, steps_one_tick, n_steps, n_warm, multi):
     wall = time.perf_counter() - t0
     dev = ev0.elapsed_time(ev1) * 1e-3
     if multi:
-        t = torch.tensor([wall, dev], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, dev], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev = float(t[0]), float(t[1])
     return wall, dev
@@ -227,7 +227,10 @@ def direct_child(a):
 def run_direct_children(a, rank, local_rank, world_size):
     """Spawn this rank's direct-exchange child and wait for it (bounded).  Returns the child's JSON
     (rank 0) or a description of what went wrong; never raises."""
-    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world_size),
+    # the children rendezvous among themselves: nothing of the launcher's elastic agent may leak in
+    # (with TORCHELASTIC_USE_AGENT_STORE set, rank 0 would not host the store on the new port)
+    base = {k: v for k, v in os.environ.items() if not k.startswith(("TORCHELASTIC_", "GROUP_", "ROLE_"))}
+    env = dict(base, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world_size),
                MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
                MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 23),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -293,12 +296,20 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the engine has no CPU path", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
+    # MGX_BENCH_BACKEND=gloo + MGX_BENCH_DEVICE=0 is the dry-run mode of the N > 1 control flow on a
+    # one-GPU box (collectives staged through the host); the measured configuration is nccl = RCCL.
+    backend = os.environ.get("MGX_BENCH_BACKEND", "nccl")
+    device_index = int(os.environ.get("MGX_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(device_index)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     from magics_amd import World, scenarios as S, sharded
     stream = torch.cuda.current_stream().cuda_stream
@@ -310,7 +321,7 @@ def main():
     S.populate(w, sc)
     steps = sc["steps"]
     assert len(steps) == SCHEDULE_LEN
-    wall, dev = timed(torch, dist, w.iterate, steps, a.steps, a.warmup, multi)
+    wall, dev = timed(torch, dist, w.iterate, steps, a.steps, a.warmup, multi, red_dev)
     bytes_iter = S.algorithmic_bytes_per_robot_iter(K, 0.0) * n_loc  # per GPU per iteration
     n_launch = -(-a.steps // SCHEDULE_LEN)
     line = {
@@ -367,18 +378,18 @@ def main():
         sw, err = None, ""
         try:
             sc2 = S.grid_scenario(n_tot, K, interrobot=True, seed=805)
-            comm = sharded.TorchDistComm() if multi else None
+            comm = sharded.TorchDistComm(stage_through_host=backend != "nccl") if multi else None
             sw = sharded.ShardedWorld(sc2, rank, world_size, lambda p: World(p, stream=stream, fma=a.fma), comm=comm)
             sw.world.sweep(0, 0, 0)  # commit: device arrays built, no phase run
         except Exception as e:  # noqa: BLE001
             err = f"{type(e).__name__}: {e}"
-        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=red_dev)
         if multi:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok[0]) == 1:
             steps2 = sc2["steps"]
             n2, w2 = max(SCHEDULE_LEN, a.steps // 4), max(SCHEDULE_LEN, a.warmup // 4)
-            wall2, dev2 = timed(torch, dist, sw.iterate, steps2, n2, w2, multi)
+            wall2, dev2 = timed(torch, dist, sw.iterate, steps2, n2, w2, multi, red_dev)
             D = len(sc2["ir"]) / n_tot
             bytes2 = S.algorithmic_bytes_per_robot_iter(K, D) * n_loc
             line["secondary"] = {

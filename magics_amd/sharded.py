@@ -234,12 +234,20 @@ def connect_direct(sw, comm):
 class TorchDistComm:
     """all-to-all-v over torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" on CPU)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, stage_through_host=False):
+        """stage_through_host: device buffers travel through host copies (a backend without device
+        support, i.e. gloo with GPU worlds: dry runs only)."""
         import torch.distributed as dist
-        self.dist, self.group = dist, group
+        self.dist, self.group, self.stage = dist, group, stage_through_host
 
     def all_to_all(self, recv, send, recv_counts, send_counts):
         n_r, n_s = sum(recv_counts), sum(send_counts)
+        if self.stage and recv.is_cuda:
+            r, s_ = recv[:n_r].cpu(), send[:n_s].cpu()
+            self.dist.all_to_all_single(r, s_, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts),
+                                        group=self.group)
+            recv[:n_r].copy_(r)
+            return
         self.dist.all_to_all_single(recv[:n_r], send[:n_s], output_split_sizes=list(recv_counts),
                                     input_split_sizes=list(send_counts), group=self.group)
 

@@ -93,3 +93,25 @@ def test_bench_direct_child_role(tmp_path):
     res = json.loads([ln for ln in outs[0][0].decode().splitlines() if ln.startswith("{")][-1])
     assert "error" not in res, res
     assert res["value"] > 0 and res["exchanges"] > 0 and res["ghost_robots_this_rank"] > 0
+
+
+def test_bench_two_rank_control_flow_dry_run():
+    """bench.py as the driver launches it at N = 2 (torch.distributed.run, one process per rank),
+    in its dry-run mode for one-GPU boxes: both ranks on cuda:0, gloo instead of RCCL.  Checks the
+    control flow end to end: one JSON line, whole-job aggregate, sharded secondary, and the
+    direct-exchange measurement from the child processes."""
+    import json
+    bench = os.path.join(os.path.dirname(HERE), "bench.py")
+    env = dict(os.environ, MGX_BENCH_BACKEND="gloo", MGX_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MGX_HALO_TIMEOUT_MS="20000")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), bench, "--gpus", "2", "--steps", "60", "--warmup", "20", "--robots-per-gpu", "144",
+           "--horizon", "10", "--secondary-deadline", "150"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert d["secondary"]["value"] > 0 and d["secondary"]["config"]["ghost_robots_this_rank"] > 0
+    assert d["secondary"]["direct_exchange"].get("value", 0) > 0, d["secondary"]["direct_exchange"]
