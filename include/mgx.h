@@ -215,6 +215,13 @@ int mgx_read_beliefs(mgx_world *w, double *eta, double *lam, double *means);
 /* means only — what reached_waypoint (robot.rs:2125-2136) and the visualisers read per tick */
 int mgx_read_means(mgx_world *w, double *means);
 int mgx_num_robots(mgx_world *w, uint32_t *n_robots, uint32_t *n_variables);
+/* FactorGraph::messages_sent() / messages_received() (factorgraph.rs:876-890; MessageCount,
+ * factorgraph/mod.rs:29-137) of one robot's graph, as exported by export.rs:434-439:
+ * counts = {sent internal, sent external, received internal, received external}, summed over the
+ * nodes the graph holds now (a deleted inter-robot factor takes its counts with it).  The counts
+ * depend only on topology, enabled kinds, antenna / idle flags and iteration counts, so they are
+ * kept on the host (launches are logged, no device work).  Unsharded worlds only. */
+int mgx_message_counts(mgx_world *w, int32_t robot, uint64_t counts[4]);
 
 /* ---- multi-GPU halo (one exchange per external iteration) ----------------- */
 /* Number of f64 words of one robot's halo record with K variables. */

@@ -184,6 +184,11 @@ struct Robot {
         return n_nodes++;
     }
     std::vector<int> connected;  // RobotConnections::robots_connected_with (robot.rs:515-531), ascending order key
+    // MessageCount of the graph's permanent nodes (variables, dynamic / obstacle / tracking factors):
+    // sent internal, sent external, received internal, received external (factorgraph/mod.rs:29-137)
+    uint64_t cnt[4] = {0, 0, 0, 0};
+    int64_t cnt_itf = 0;  // iteration_count.factor as far as the counters have been advanced
+    std::vector<uint32_t> slot_uses;  // per node slot: entries of interrobot_factor_indices naming it
 };
 
 struct IrEdge {  // one InterRobotFactor, kept at its target variable
@@ -196,6 +201,12 @@ struct IrConn {  // K-1 factors owner -> other
     uint64_t first_number;
     std::vector<IrEdge> edges;  // index i-1 for variable i
     std::vector<int> node;      // node slot of each factor in the owner's graph
+    uint64_t cnt[4] = {0, 0, 0, 0};  // MessageCount summed over the K-1 factors
+    // Sum over the factors of how often each one's node slot occurs in the owner's
+    // interrobot_factor_indices: that list is never pruned (factorgraph.rs:729-733), so a factor in a
+    // re-used slot is updated once per occurrence in every external sweep — same message, but every
+    // update counts as sent / received.
+    uint64_t updates_per_sweep = 0;
 };
 
 }  // namespace
@@ -226,6 +237,11 @@ struct mgx_world {
     DevBuf<float> trk_last_pos, path_xy;
     DevBuf<uint8_t> ir_gate, antenna, idle, sdf;
     StageRing stage;  // packed per-tick arguments
+    // message counters are advanced lazily: launches and prior changes are only logged here
+    struct CountEntry { uint8_t ext, in; int n_int, robot; uint64_t times; };
+    std::vector<CountEntry> clog;
+    std::vector<uint32_t> cp_pending;  // [robot * K + variable] change_prior calls not yet counted
+    std::vector<uint32_t> cp_dirty;
     DevBuf<unsigned long long> dbg;  // diagnostic builds only
     // halo plan: local robots whose snapshots are sent / ghost robots that receive, in buffer order
     std::vector<int32_t> halo_send, halo_recv;
@@ -403,6 +419,110 @@ static int pull(mgx_world *w) {
 }
 
 // ---- commit: host mirror -> device arrays ---------------------------------------------------------
+// ---- message counters (factorgraph/mod.rs:29-137, factorgraph.rs:876-890) ----------------------------
+// Every count is structural: who sends to whom is fixed by the topology, the enabled kinds, the
+// antenna / idle flags and (for tracking factors) iteration_count.factor — never by message
+// contents (a skipped factor still "sends" its empty messages, factor/mod.rs:353-367).  So the
+// launches are only logged, and the counters are brought up to date whenever one of those inputs
+// is about to change or a count is asked for.
+static void flush_counts(mgx_world *w) {
+    if (w->clog.empty() && w->cp_dirty.empty()) return;
+    const int K = w->K;
+    const size_t n = w->robots.size();
+    const uint32_t en = w->p.enable_mask;
+    const uint64_t dynf = (en & 1u) ? 2ull * (K - 1) : 0, obsf = (en & 4u) ? (uint64_t)(K - 2) : 0, trkf = (en & 8u) ? (uint64_t)(K - 2) : 0;
+    std::vector<uint64_t> own(n, 0), foreign(n, 0), nIv(n, 0), nEf(n, 0), nEv(n, 0);
+    for (const IrConn &c : w->conns) { own[(size_t)c.owner]++; foreign[(size_t)c.other]++; }
+    for (size_t r = 0; r < n; r++) {
+        Robot &rb = w->robots[r];
+        if (rb.ghost) continue;
+        const bool idle = rb.idle != 0, radio = rb.antenna && !idle;
+        uint64_t nIf = 0, trk = 0;
+        int64_t itf = rb.cnt_itf;
+        for (const mgx_world::CountEntry &e : w->clog) {
+            if (e.robot >= 0 && (size_t)e.robot != r) continue;
+            // one repetition = [external factor][external variable] n_int x ([internal factor][internal variable])
+            const uint64_t fac_per_rep = ((e.ext & 1u) && radio ? 1u : 0u) + ((e.in & 1u) && !idle ? (uint64_t)e.n_int : 0u);
+            uint64_t rep = 0;
+            for (; rep < e.times && itf < 10 && fac_per_rep; rep++) {  // tracking gate still closed: step by step
+                if ((e.ext & 1u) && radio) { nEf[r]++; itf++; }
+                if ((e.ext & 2u) && radio) nEv[r]++;
+                if (!idle)
+                    for (int q = 0; q < e.n_int; q++) {
+                        if (e.in & 1u) { nIf++; if (itf >= 10) trk++; itf++; }
+                        if (e.in & 2u) nIv[r]++;
+                    }
+            }
+            const uint64_t left = e.times - rep;
+            if ((e.ext & 1u) && radio) { nEf[r] += left; itf += (int64_t)left; }
+            if ((e.ext & 2u) && radio) nEv[r] += left;
+            if (!idle) {
+                if (e.in & 1u) { const uint64_t k = left * (uint64_t)e.n_int; nIf += k; if (fac_per_rep) trk += k; itf += (int64_t)k; }
+                if (e.in & 2u) nIv[r] += left * (uint64_t)e.n_int;
+            }
+        }
+        rb.cnt_itf = itf;
+        const uint64_t s_int = 2ull * (K - 1) + 2ull * (K - 2) + (uint64_t)(K - 1) * own[r], s_ext = (uint64_t)(K - 1) * foreign[r];
+        // internal factor sweeps: one message per inbox key of every updated factor, received by the variables
+        rb.cnt[0] += nIf * (dynf + obsf) + trk * trkf;
+        rb.cnt[2] += nIf * (dynf + obsf) + trk * trkf;
+        // variable sweeps answer every inbox key; only own-graph, enabled factors receive (internal sweeps)
+        rb.cnt[0] += (nIv[r] + nEv[r]) * s_int;
+        rb.cnt[1] += (nIv[r] + nEv[r]) * s_ext;
+        rb.cnt[2] += nIv[r] * (dynf + obsf + trkf);
+    }
+    if (en & 2u)
+        for (IrConn &c : w->conns) {
+            const Robot &a = w->robots[(size_t)c.owner], &b = w->robots[(size_t)c.other];
+            const bool radio_a = a.antenna && !a.idle, radio_b = b.antenna && !b.idle;
+            c.cnt[2] += nIv[(size_t)c.owner] * (uint64_t)(K - 1);            // own variables' responses (internal sweeps)
+            c.cnt[0] += nEf[(size_t)c.owner] * c.updates_per_sweep;          // external factor sweep: one message per key,
+            c.cnt[1] += nEf[(size_t)c.owner] * c.updates_per_sweep;          //   the own and the foreign variable
+            if (radio_b) w->robots[(size_t)c.other].cnt[3] += nEf[(size_t)c.owner] * c.updates_per_sweep;  // delivered (robot.rs:1813-1831)
+            if (radio_a) c.cnt[3] += nEv[(size_t)c.other] * (uint64_t)(K - 1);  // the foreign variables' responses (robot.rs:1842-1858)
+        }
+    // change_prior (variable.rs:203-230): its sends stay in a local counter; the connected factors receive
+    if (!w->cp_dirty.empty()) {
+        std::vector<std::vector<int>> own_of(n), foreign_of(n);
+        if (en & 2u)
+            for (size_t ci = 0; ci < w->conns.size(); ci++) {
+                own_of[(size_t)w->conns[ci].owner].push_back((int)ci);
+                foreign_of[(size_t)w->conns[ci].other].push_back((int)ci);
+            }
+        for (uint32_t key : w->cp_dirty) {
+            const size_t r = key / (uint32_t)K;
+            const int i = (int)(key % (uint32_t)K);
+            const uint64_t c = w->cp_pending[key];
+            w->cp_pending[key] = 0;
+            Robot &rb = w->robots[r];
+            const uint64_t dyn_here = (uint64_t)((i >= 1) + (i <= K - 2));
+            rb.cnt[2] += c * (((en & 1u) ? dyn_here : 0) + ((i >= 1 && i <= K - 2) ? (uint64_t)(((en & 4u) != 0) + ((en & 8u) != 0)) : 0));
+            if (i >= 1) {  // one inter-robot factor per connection hangs on this variable
+                for (int ci : own_of[r]) w->conns[(size_t)ci].cnt[2] += c;
+                for (int ci : foreign_of[r]) w->conns[(size_t)ci].cnt[3] += c;
+            }
+        }
+        w->cp_dirty.clear();
+    }
+    w->clog.clear();
+}
+static void log_launch(mgx_world *w, int robot, uint32_t ext_mask, uint32_t int_mask, int n_int) {
+    const uint8_t ext = (uint8_t)((ext_mask & PH_EXT_FACTOR ? 1 : 0) | (ext_mask & PH_EXT_VARIABLE ? 2 : 0));
+    const uint8_t in = (uint8_t)((int_mask & PH_INT_FACTOR ? 1 : 0) | (int_mask & PH_INT_VARIABLE ? 2 : 0));
+    if (!ext && (!in || n_int <= 0)) return;
+    if (!w->clog.empty()) {
+        mgx_world::CountEntry &b = w->clog.back();
+        if (b.ext == ext && b.in == in && b.n_int == n_int && b.robot == robot) { b.times++; return; }
+    }
+    w->clog.push_back({ext, in, in ? n_int : 0, robot, 1});
+    if (w->clog.size() > 4096) flush_counts(w);
+}
+static void log_change_prior(mgx_world *w, int robot, int var) {
+    const size_t key = (size_t)robot * (size_t)w->K + (size_t)var;
+    if (w->cp_pending.size() <= key) w->cp_pending.resize(w->robots.size() * (size_t)w->K, 0);
+    if (w->cp_pending[key]++ == 0) w->cp_dirty.push_back((uint32_t)key);
+}
+
 static int upload_flags(mgx_world *w) {
     // antenna[R] | idle[R] | gate[NI], staged in one pinned block and moved by a copy kernel: no
     // blocking copy, no synchronisation (update_failed_comms rewrites every antenna each tick)
@@ -640,11 +760,13 @@ static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_ma
         const int out = writes_snap ? 1 - w->d.cur : -1;
         HIP_TRY(launch_robot_sweep(w->d, 0, w->d.R_local, ext_mask, int_mask, n_int, out, hints, w->stream));
         if (writes_snap) w->d.cur ^= 1;
+        log_launch(w, -1, ext_mask, int_mask, n_int);
     } else {
         if ((size_t)robot >= w->robots.size() || w->robots[(size_t)robot].ghost) return fail(MGX_ERR_INVALID, "bad robot id %d", robot);
         if (ext_mask) return fail(MGX_ERR_INVALID, "external sweeps are world-wide (robot must be -1)");
         // single workgroup: nobody else reads the snapshot buffer concurrently => update in place
         HIP_TRY(launch_robot_sweep(w->d, w->dev_of[(size_t)robot], 1, 0, int_mask, n_int, writes_snap ? w->d.cur : -1, 0, w->stream));
+        log_launch(w, robot, 0, int_mask, n_int);
     }
     return MGX_OK;
 }
@@ -712,6 +834,11 @@ int mgx_robot_add(mgx_world *w, const mgx_robot_desc *d, int32_t *robot_id) {
     Robot rb;
     rb.K = K; rb.ghost = d->ghost != 0; rb.radius = d->radius; rb.order_key = d->order_key;
     rb.n_nodes = K + (K - 1) + 2 * (K - 2);
+    flush_counts(w);  // launches logged so far do not concern the new robot
+    {   // add_internal_edge (factorgraph.rs:304-330): the variable receives an (empty) message, the factor one if enabled
+        const uint32_t en = w->p.enable_mask;
+        rb.cnt[2] = (uint64_t)(2 * (K - 1) + 2 * (K - 2)) + ((en & 1u) ? 2 * (K - 1) : 0) + ((en & 4u) ? K - 2 : 0) + ((en & 8u) ? K - 2 : 0);
+    }
     rb.prior_eta.assign(4 * K, 0.0); rb.prior_lam.assign(16 * K, 0.0);
     rb.bel_eta.assign(4 * K, 0.0); rb.bel_lam.assign(16 * K, 0.0); rb.bel_mu.assign(4 * K, 0.0); rb.bel_cov.assign(16 * K, 0.0);
     rb.valid.assign(K, 1); rb.snap.assign(24 * K, 0.0); rb.epoch.assign(K, 0);
@@ -765,11 +892,22 @@ static int ir_connect(mgx_world *w, int32_t owner, int32_t other, uint64_t first
     if (first_robot_number == 0) return fail(MGX_ERR_INVALID, "robot_number is NonZeroUsize");
     // no "already connected" check: the reference creates whatever its connection sets ask for, and
     // a pair can legitimately hold two sets of factors (robot.rs:1391-1404, see mgx_update_topology)
+    flush_counts(w);
     IrConn c;
     c.owner = owner; c.other = other; c.first_number = first_robot_number;
     c.edges.resize((size_t)w->K - 1);
     c.node.resize((size_t)w->K - 1);
-    for (int &nd : c.node) nd = w->robots[(size_t)owner].alloc_node();  // add_factor, ascending i
+    // add_internal_edge + add_external_edge + the other variable's belief into the new factor
+    // (factorgraph.rs:304-353, robot.rs:1557-1585)
+    w->robots[(size_t)owner].cnt[2] += (uint64_t)(w->K - 1);
+    w->robots[(size_t)other].cnt[3] += (uint64_t)(w->K - 1);
+    if (w->p.enable_mask & 2u) { c.cnt[2] = (uint64_t)(w->K - 1); c.cnt[3] = (uint64_t)(w->K - 1); }
+    for (int &nd : c.node) {  // add_factor, ascending i
+        Robot &ow = w->robots[(size_t)owner];
+        nd = ow.alloc_node();
+        if (ow.slot_uses.size() <= (size_t)nd) ow.slot_uses.resize((size_t)nd + 1, 0);
+        c.updates_per_sweep += ++ow.slot_uses[(size_t)nd];
+    }
     w->conns.push_back(std::move(c));
     w->dirty = true;
     return MGX_OK;
@@ -780,6 +918,7 @@ static int ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
         return fail(MGX_ERR_INVALID, "bad robot ids");
     int rc = pull(w);  // keep the other connections' live state
     if (rc != MGX_OK) return rc;
+    flush_counts(w);  // the deleted factors take their counts with them (factorgraph.rs:876-890)
     w->dev_valid = false;
     // delete_interrobot_factors_connected_to on both graphs (factorgraph.rs:380-436): the node
     // slots are vacated in ascending index order
@@ -808,6 +947,7 @@ int mgx_robot_remove(mgx_world *w, int32_t robot) {
     Robot &rb = w->robots[(size_t)robot];
     if (rb.removed) return fail(MGX_ERR_STATE, "robot %d already removed", robot);
     if (rb.ghost) return fail(MGX_ERR_STATE, "ghost robots are removed by their owning rank");
+    flush_counts(w);
     rb.removed = true;
     rb.idle = 1;
     rb.antenna = 0;
@@ -819,6 +959,7 @@ int mgx_robot_remove(mgx_world *w, int32_t robot) {
 int mgx_set_antenna(mgx_world *w, int32_t robot, int32_t active) {
     if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
     if (w->robots[(size_t)robot].removed) return fail(MGX_ERR_STATE, "robot %d was removed", robot);
+    if (w->robots[(size_t)robot].antenna != (active ? 1 : 0)) flush_counts(w);
     w->robots[(size_t)robot].antenna = active ? 1 : 0;
     w->flags_dirty = true;
     return MGX_OK;
@@ -826,6 +967,7 @@ int mgx_set_antenna(mgx_world *w, int32_t robot, int32_t active) {
 int mgx_set_idle(mgx_world *w, int32_t robot, int32_t idle) {
     if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
     if (w->robots[(size_t)robot].removed) return fail(MGX_ERR_STATE, "robot %d was removed", robot);
+    if (w->robots[(size_t)robot].idle != (idle ? 1 : 0)) flush_counts(w);
     w->robots[(size_t)robot].idle = idle ? 1 : 0;
     w->flags_dirty = true;
     return MGX_OK;
@@ -837,6 +979,8 @@ int mgx_set_antennas(mgx_world *w, uint32_t n, const int32_t *robots, const uint
         if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
         if (w->robots[(size_t)robots[i]].removed) return fail(MGX_ERR_STATE, "robot %d was removed", robots[i]);
     }
+    for (uint32_t i = 0; i < n; i++)
+        if (w->robots[(size_t)robots[i]].antenna != (active[i] ? 1 : 0)) { flush_counts(w); break; }
     for (uint32_t i = 0; i < n; i++) w->robots[(size_t)robots[i]].antenna = active[i] ? 1 : 0;
     w->flags_dirty = true;
     return MGX_OK;
@@ -1068,7 +1212,7 @@ int mgx_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, const uin
     int32_t *hr = (int32_t *)(hm + 4 * (size_t)n);
     uint32_t *hv = (uint32_t *)(hm + 4 * (size_t)n + (n + 1) / 2);
     memcpy(hm, means, 4 * (size_t)n * sizeof(double));
-    for (uint32_t i = 0; i < n; i++) { hr[i] = w->dev_of[(size_t)robots[i]]; hv[i] = var_ix[i]; }
+    for (uint32_t i = 0; i < n; i++) { hr[i] = w->dev_of[(size_t)robots[i]]; hv[i] = var_ix[i]; log_change_prior(w, robots[i], (int)var_ix[i]); }
     void *dp = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
     const double *dm = (const double *)dp;
@@ -1097,7 +1241,11 @@ int mgx_update_priors(mgx_world *w, uint32_t n, const int32_t *robots, const dou
     uint8_t *hh = (uint8_t *)(hw + 3 * (size_t)n + w_r);
     memcpy(hw, waypoints_xy, 2 * (size_t)n * sizeof(double));
     memcpy(hw + 2 * (size_t)n, time_scale, (size_t)n * sizeof(double));
-    for (uint32_t i = 0; i < n; i++) hr[i] = w->dev_of[(size_t)robots[i]];
+    for (uint32_t i = 0; i < n; i++) {
+        hr[i] = w->dev_of[(size_t)robots[i]];
+        if (what[i] & 1u) log_change_prior(w, robots[i], w->K - 1);
+        if (what[i] & 2u) log_change_prior(w, robots[i], 0);
+    }
     memcpy(hh, what, n);
     void *dp = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
@@ -1118,6 +1266,21 @@ int mgx_num_robots(mgx_world *w, uint32_t *n_robots, uint32_t *n_variables) {
     for (const Robot &r : w->robots) nr += r.ghost ? 0 : 1;
     if (n_robots) *n_robots = nr;
     if (n_variables) *n_variables = nr * (uint32_t)w->K;
+    return MGX_OK;
+}
+
+// FactorGraph::messages_sent / messages_received (factorgraph.rs:876-890) of one robot's graph
+int mgx_message_counts(mgx_world *w, int32_t robot, uint64_t counts[4]) {
+    if (!w || !counts || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
+    for (const Robot &r : w->robots)
+        if (r.ghost) return fail(MGX_ERR_STATE, "message counts are kept for unsharded worlds only");
+    flush_counts(w);
+    const Robot &rb = w->robots[(size_t)robot];
+    for (int c = 0; c < 4; c++) counts[c] = rb.cnt[c];
+    for (const IrConn &cn : w->conns) {
+        if (cn.owner != robot) continue;
+        for (int c = 0; c < 4; c++) counts[c] += cn.cnt[c];
+    }
     return MGX_OK;
 }
 

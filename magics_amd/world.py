@@ -201,6 +201,12 @@ class World:
         self._chk(self._L.mgx_num_robots(self._w, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def message_counts(self, robot):
+        """(sent internal, sent external, received internal, received external) of one graph."""
+        out = (C.c_uint64 * 4)()
+        self._chk(self._L.mgx_message_counts(self._w, robot, out))
+        return tuple(int(x) for x in out)
+
     def read_means(self):
         _, nv = self.num_robots()
         means = np.zeros((nv, 4))

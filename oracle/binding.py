@@ -79,6 +79,7 @@ def _bind(path):
     L.orc_get_belief.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, c_double_p, c_double_p, c_double_p,
                                  c_double_p, C.POINTER(C.c_int32)]
     L.orc_read_beliefs.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p]
+    L.orc_message_counts.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]
     L.orc_num_robots.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.orc_variable_inbox.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_int32, C.POINTER(C.c_int32),
                                      C.POINTER(C.c_int32), c_double_p, c_double_p]
@@ -277,6 +278,12 @@ class OracleWorld:
 
     def read_means(self):
         return self.read_beliefs()[2]
+
+    def message_counts(self, robot):
+        """(sent internal, sent external, received internal, received external) of one graph."""
+        out = (C.c_uint64 * 4)()
+        self._chk(self._L.orc_message_counts(self._w, robot, out))
+        return tuple(int(x) for x in out)
 
     def read_beliefs(self):
         _, nv = self.num_robots()

@@ -108,6 +108,8 @@ typedef struct {
     double eta[DOFS], lam[16], mu[DOFS], cov[16];
     int valid;
     Inbox inbox;
+    int robot;       /* owning graph (world index) */
+    uint64_t cnt[4]; /* MessageCount (FG/mod.rs:29-137): sent internal / external, received internal / external */
 } Variable;
 
 /* FG/factor/mod.rs:133-148,597-623 + the per-kind structs */
@@ -119,6 +121,8 @@ typedef struct {
     double lam_meas[16]; /* measurement_precision, zdim x zdim */
     double x0[8];        /* linearisation_point */
     Inbox inbox;
+    int robot;           /* owning graph (world index) */
+    uint64_t cnt[4];     /* MessageCount, as in Variable */
     /* dynamic (factor/dynamic.rs:14-52) */
     double J_dyn[4 * 8];
     /* interrobot (factor/interrobot.rs:40-77) */
@@ -465,6 +469,7 @@ static void factor_jacobian(const World *w, Graph *g, Factor *f, const double *x
  * --------------------------------------------------------------------------------------- */
 static void factor_update(const World *w, Graph *g, Factor *f, Msg *out) {
     int nv = f->inbox.n, n = DOFS * f->nvars, m = f->zdim;
+    for (int j = 0; j < nv; j++) f->cnt[f->inbox.e[j].key.robot != f->robot] += 1; /* :353-367,410-452: one message per key, skipped or not */
     /* :336-349 linearisation point from inbox means (empty => zeros) */
     for (int j = 0; j < nv; j++)
         for (int i = 0; i < DOFS; i++)
@@ -508,9 +513,13 @@ static void factor_update(const World *w, Graph *g, Factor *f, Msg *out) {
 static void factor_receive(Factor *f, NodeId from, const Msg *m) {
     if (!f->enabled) return;
     *inbox_insert(&f->inbox, from) = *m;
+    f->cnt[2 + (from.robot != f->robot)] += 1; /* :312-316 */
 }
 /* VariableNode::receive_message_from — FG/variable.rs:179-191 */
-static void variable_receive(Variable *v, NodeId from, const Msg *m) { *inbox_insert(&v->inbox, from) = *m; }
+static void variable_receive(Variable *v, NodeId from, const Msg *m) {
+    *inbox_insert(&v->inbox, from) = *m;
+    v->cnt[2 + (from.robot != v->robot)] += 1; /* :185-189 */
+}
 
 /* VariableNode::prepare_message — FG/variable.rs:234-240 */
 static void variable_prepare_message(const Variable *v, Msg *m) {
@@ -543,6 +552,7 @@ static void variable_new(Variable *v, const double *mean, double prior_diag) {
 /* VariableNode::update_belief_and_create_factor_responses — FG/variable.rs:251-342.
  * out[k] = response for inbox entry k. */
 static void variable_update(Variable *v, Msg *out) {
+    for (int k = 0; k < v->inbox.n; k++) v->cnt[v->inbox.e[k].key.robot != v->robot] += 1; /* :299-332, one response per key */
     memcpy(v->eta, v->prior_eta, sizeof v->eta);
     memcpy(v->lam, v->prior_lam, sizeof v->lam);
     for (int k = 0; k < v->inbox.n; k++) { /* :263-271 */
@@ -703,6 +713,7 @@ int orc_robot_add(World *w, const orc_robot_desc *d, int32_t *robot_id) {
         int ix = graph_add_node(g);
         g->nodes[ix].is_factor = 0;
         variable_new(&g->nodes[ix].v, d->mean0 + 4 * i, d->prior_diag[i]);
+        g->nodes[ix].v.robot = r;
         g->var_indices[i] = ix;
     }
     for (int i = 0; i < K - 1; i++) { /* dynamic factors :1225-1255, dynamic.rs:22-52 */
@@ -710,6 +721,7 @@ int orc_robot_add(World *w, const orc_robot_desc *d, int32_t *robot_id) {
         g->nodes[ix].is_factor = 1;
         Factor *f = &g->nodes[ix].f;
         factor_state_new(f, K_DYNAMIC, 4, w->p.sigma_dynamics, 2, (w->p.enable_mask & EN_DYN) != 0);
+        f->robot = r;
         double dt = d->dt[i];
         double qc = 1.0 / (w->p.sigma_dynamics * w->p.sigma_dynamics); /* powi(strength,-2) */
         double q11 = 12.0 * (1.0 / (dt * dt * dt)) * qc;                /* powi(dt,-3) */
@@ -739,6 +751,7 @@ int orc_robot_add(World *w, const orc_robot_desc *d, int32_t *robot_id) {
         g->nodes[ix].is_factor = 1;
         Factor *f = &g->nodes[ix].f;
         factor_state_new(f, K_OBSTACLE, 1, w->p.sigma_obstacle, 1, (w->p.enable_mask & EN_OBS) != 0);
+        f->robot = r;
         push_int(&g->factor_indices, &g->n_factors, &g->cap_factors, ix);
         add_internal_edge(w, r, g->var_indices[i], ix);
     }
@@ -747,6 +760,7 @@ int orc_robot_add(World *w, const orc_robot_desc *d, int32_t *robot_id) {
         g->nodes[ix].is_factor = 1;
         Factor *f = &g->nodes[ix].f;
         factor_state_new(f, K_TRACKING, 1, w->p.sigma_tracking, 1, (w->p.enable_mask & EN_TRK) != 0);
+        f->robot = r;
         f->x0[0] = d->mean0[4 * i];
         f->x0[1] = d->mean0[4 * i + 1];
         f->last_pos[0] = (float)d->mean0[4 * i];
@@ -773,6 +787,7 @@ static int ir_connect(World *w, int32_t owner, int32_t other, uint64_t first_rob
         g->nodes[ix].is_factor = 1;
         Factor *f = &g->nodes[ix].f;
         factor_state_new(f, K_INTERROBOT, 4, w->p.sigma_interrobot, 2, (w->p.enable_mask & EN_IR) != 0);
+        f->robot = owner;
         f->safety_distance = w->p.safety_multiplier * g->radius; /* interrobot.rs:64 */
         f->tiny_offset = (double)1e-6f * (double)(first_robot_number + (uint64_t)(i - 1)); /* :75 */
         f->ext_robot = other;
@@ -1304,6 +1319,21 @@ int orc_num_robots(World *w, uint32_t *n_robots, uint32_t *n_variables) {
         }
     if (n_robots) *n_robots = nr;
     if (n_variables) *n_variables = nv;
+    return ORC_OK;
+}
+
+/* FactorGraph::messages_sent / messages_received (FG/factorgraph.rs:876-890): sums over the nodes
+ * the graph holds NOW (a deleted factor takes its counts with it).  out = sent internal, sent
+ * external, received internal, received external. */
+int orc_message_counts(World *w, int32_t r, uint64_t out[4]) {
+    if (!w || r < 0 || r >= w->n || !out) return ORC_ERR_INVALID;
+    const Graph *g = &w->g[r];
+    for (int c = 0; c < 4; c++) out[c] = 0;
+    for (int ix = 0; ix < g->n_nodes; ix++) {
+        const Node *nd = &g->nodes[ix];
+        if (!nd->alive) continue;
+        for (int c = 0; c < 4; c++) out[c] += nd->is_factor ? nd->f.cnt[c] : nd->v.cnt[c];
+    }
     return ORC_OK;
 }
 
