@@ -277,6 +277,55 @@ int mgx_ipc_export(const void *dev_ptr, uint8_t handle[64]);
 int mgx_ipc_open(const uint8_t handle[64], void **dev_ptr);
 int mgx_ipc_close(void *dev_ptr);
 
+/* ---- gbp_linalg + gbp_multivariate_normal value types (host only, no device) ---------------
+ * crates/gbp_linalg/src/lib.rs:47-128: euclidean_norm = sqrt(fold(0, acc + x*x)), l1_norm,
+ * normalize (untouched when the norm is 0 or infinite). */
+double mgx_euclidean_norm(const double *x, uint32_t n);
+double mgx_l1_norm(const double *x, uint32_t n);
+void mgx_normalize(double *x, uint32_t n);
+/* ndarray-inverse's contract as used by the reference (variable.rs:153,278; marginalise..:79;
+ * gbp_multivariate_normal): det(); inverse = "None" (returns 0) exactly when det() == 0, else 1.
+ * Row-major n x n. */
+double mgx_det(const double *a, uint32_t n);
+int mgx_inverse(const double *a, uint32_t n, double *out);
+
+/* MultivariateNormal in information form (crates/gbp_multivariate_normal/src/lib.rs:38-410).
+ * Errors mirror MultivariateNormalError (lib.rs:9-30); mgx_last_error() carries the variant text,
+ * e.g. "VectorLengthNotEqualMatrixShape(3, 2, 2)". */
+typedef struct mgx_mvn mgx_mvn;
+#define MGX_MVN_ERR_NON_SQUARE (-16)          /* NonSquarePrecisionMatrix(rows, cols)            */
+#define MGX_MVN_ERR_LENGTH (-17)              /* VectorLengthNotEqualMatrixShape(len, rows, cols) */
+#define MGX_MVN_ERR_SINGULAR_PRECISION (-18)  /* NonInvertiblePrecisionMatrix                     */
+#define MGX_MVN_ERR_SINGULAR_COVARIANCE (-19) /* NonInvertibleCovarianceMatrix                    */
+#define MGX_MVN_ADD 0
+#define MGX_MVN_SUB 1
+#define MGX_MVN_MUL 2 /* product of densities = sum in information form (lib.rs:380-410) */
+/* lib.rs:63-93: checks in this order: square, lengths, det == 0; mean = precision . information */
+int mgx_mvn_from_information_and_precision(const double *information, uint32_t len,
+                                           const double *precision, uint32_t rows, uint32_t cols,
+                                           mgx_mvn **out);
+/* lib.rs:114-143 */
+int mgx_mvn_from_mean_and_covariance(const double *mean, uint32_t len, const double *covariance,
+                                     uint32_t rows, uint32_t cols, mgx_mvn **out);
+void mgx_mvn_destroy(mgx_mvn *m);
+uint32_t mgx_mvn_len(const mgx_mvn *m);
+/* information_vector(), precision_matrix(), mean() (any pointer may be NULL); covariance() */
+int mgx_mvn_get(const mgx_mvn *m, double *information, double *precision, double *mean);
+int mgx_mvn_covariance(const mgx_mvn *m, double *covariance);
+/* update_information_vector / update_precision_matrix (lib.rs:158-178); set_* and add_assign_*
+ * (the `unsafe` ones, lib.rs:212-263: mean stale until update); update() returns 1 if the mean
+ * was recomputed, 0 if it was current (lib.rs:271-279) */
+int mgx_mvn_update_information_vector(mgx_mvn *m, const double *value);
+int mgx_mvn_update_precision_matrix(mgx_mvn *m, const double *value);
+int mgx_mvn_set_information_vector(mgx_mvn *m, const double *value);
+int mgx_mvn_set_precision_matrix(mgx_mvn *m, const double *value);
+int mgx_mvn_add_assign_information_vector(mgx_mvn *m, const double *value);
+int mgx_mvn_add_assign_precision_matrix(mgx_mvn *m, const double *value);
+int mgx_mvn_update(mgx_mvn *m);
+/* a op b -> new value (Add / Sub / Mul, lib.rs:300-410) and a op= b */
+int mgx_mvn_combine(const mgx_mvn *a, const mgx_mvn *b, int32_t op, mgx_mvn **out);
+int mgx_mvn_combine_assign(mgx_mvn *a, const mgx_mvn *b, int32_t op);
+
 /* ---- host helpers (no device needed) --------------------------------------------------- */
 /* gbp_schedule: fills steps[max(n_int,n_ext)] with MGX_STEP_* bits. Returns the count
  * or a negative status. (crates/gbp_schedule/src/schedules/ *.rs) */

@@ -777,6 +777,11 @@ static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_ma
 extern "C" {
 
 const char *mgx_last_error(void) { return g_err.c_str(); }
+// for the other translation units of the library (mgx_linalg.cpp): same thread-local text
+int mgx_set_error_(int code, const char *text) {
+    g_err = text ? text : "";
+    return code;
+}
 
 int mgx_world_create(const mgx_params *params, mgx_world **out) {
     if (!params || !out) return fail(MGX_ERR_INVALID, "null argument");

@@ -112,6 +112,26 @@ SYMBOLS = {
     "mgx_halo_plan": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_int32)]),
     "mgx_halo_pack": (C.c_int, [_V, _V]),
     "mgx_halo_unpack": (C.c_int, [_V, _V]),
+    "mgx_euclidean_norm": (C.c_double, [c_double_p, C.c_uint32]),
+    "mgx_l1_norm": (C.c_double, [c_double_p, C.c_uint32]),
+    "mgx_normalize": (None, [c_double_p, C.c_uint32]),
+    "mgx_det": (C.c_double, [c_double_p, C.c_uint32]),
+    "mgx_inverse": (C.c_int, [c_double_p, C.c_uint32, c_double_p]),
+    "mgx_mvn_from_information_and_precision": (C.c_int, [c_double_p, C.c_uint32, c_double_p, C.c_uint32, C.c_uint32, C.POINTER(_V)]),
+    "mgx_mvn_from_mean_and_covariance": (C.c_int, [c_double_p, C.c_uint32, c_double_p, C.c_uint32, C.c_uint32, C.POINTER(_V)]),
+    "mgx_mvn_destroy": (None, [_V]),
+    "mgx_mvn_len": (C.c_uint32, [_V]),
+    "mgx_mvn_get": (C.c_int, [_V, c_double_p, c_double_p, c_double_p]),
+    "mgx_mvn_covariance": (C.c_int, [_V, c_double_p]),
+    "mgx_mvn_update_information_vector": (C.c_int, [_V, c_double_p]),
+    "mgx_mvn_update_precision_matrix": (C.c_int, [_V, c_double_p]),
+    "mgx_mvn_set_information_vector": (C.c_int, [_V, c_double_p]),
+    "mgx_mvn_set_precision_matrix": (C.c_int, [_V, c_double_p]),
+    "mgx_mvn_add_assign_information_vector": (C.c_int, [_V, c_double_p]),
+    "mgx_mvn_add_assign_precision_matrix": (C.c_int, [_V, c_double_p]),
+    "mgx_mvn_update": (C.c_int, [_V]),
+    "mgx_mvn_combine": (C.c_int, [_V, _V, C.c_int32, C.POINTER(_V)]),
+    "mgx_mvn_combine_assign": (C.c_int, [_V, _V, C.c_int32]),
     "mgx_schedule": (C.c_int, [C.c_int32, C.c_uint8, C.c_uint8, C.c_char_p, C.c_uint32]),
     "mgx_variable_timesteps": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]),
 }
