@@ -70,7 +70,49 @@ extern __shared__ double lds[];
 // (a robot with too many edges for LDS) they are read from HBM / L2 in every variable sweep.
 // KT: horizon length K as a compile-time constant (0 = read it from the world): with K fixed every
 // LDS access is base + immediate offset, which keeps the address arithmetic out of the VGPR budget.
-constexpr int IR_STRIDE = 21;  // one staged inter-robot message: 20 f64 + 1 pad (bank spread)
+// Compact inter-robot messages.  The factor's Jacobian touches the two positions only
+// (interrobot.rs:149-159), so J^T L J and J^T L (..) vanish outside the position rows / columns,
+// and so does the Schur complement towards either variable: Lab has two non-zero rows and columns,
+// hence Lab W Lba and Lab W eb live in the top-left 2x2 block / first two entries — as exact zeros
+// as long as the arithmetic stays finite (0 * x is 0).  Such a message is six numbers:
+// eta0, eta1, lam00, lam01, lam10, lam11; the variable sums skip the structural zeros (x + 0 == x).
+// A message with anything else outside that block (NaN / inf made it there) is flagged dense, keeps
+// its 20 entries in HBM and is summed from there: slow, exact, and practically never taken.
+constexpr int IR_STRIDE = 7;  // one staged inter-robot message: 6 f64 + the dense flag
+// IRM, how a launch treats inter-robot messages: the world has no inter-robot edges at all (every
+// trace of them is compiled out: configs[1] runs this), they are read from HBM / L2 in every
+// variable sweep (a robot with too many edges for LDS), or they are staged in LDS.
+enum { IR_NONE = 0, IR_GLOBAL = 1, IR_STAGED = 2 };
+
+// Slow path of the variable sums for a robot that has at least one DENSE inter-robot message (see
+// "compact messages" above): per edge either the compact form (rows 0, 1 only) or all five entries
+// of row rr from HBM.  Kept out of line so that it costs the hot kernel no registers.
+struct Row5 { double a0, a1, a2, a3, a4; };  // eta[rr], lam[rr][0..3] (by value: stays in registers)
+template <bool STAGE_IR>
+__device__ __attribute__((noinline)) Row5 ir_rows_with_dense(const double *ir_fv_eta, const double *ir_fv_lam, const uint8_t *ir_dense,
+                                                             int NI, int rr, int e_from, int e_to, int ie0, const double *s_ir, Row5 in) {
+    double acc[5] = {in.a0, in.a1, in.a2, in.a3, in.a4};
+    struct { const double *ir_fv_eta, *ir_fv_lam; const uint8_t *ir_dense; int NI; } w = {ir_fv_eta, ir_fv_lam, ir_dense, NI};
+    for (int e = e_from; e < e_to; e++) {
+        const bool dense = STAGE_IR ? (s_ir[(e - ie0) * IR_STRIDE + 6] != 0.0) : (w.ir_dense[e] != 0);
+        if (dense) {
+            acc[0] += w.ir_fv_eta[(size_t)rr * w.NI + e];
+            for (int c = 0; c < 4; c++) acc[1 + c] += w.ir_fv_lam[(size_t)(rr * 4 + c) * w.NI + e];
+        } else if (rr < 2) {
+            if (STAGE_IR) {
+                const double *p = s_ir + (e - ie0) * IR_STRIDE;
+                acc[0] += p[rr];
+                acc[1] += p[2 + 2 * rr];
+                acc[2] += p[3 + 2 * rr];
+            } else {
+                acc[0] += w.ir_fv_eta[(size_t)rr * w.NI + e];
+                acc[1] += w.ir_fv_lam[(size_t)(rr * 4) * w.NI + e];
+                acc[2] += w.ir_fv_lam[(size_t)(rr * 4 + 1) * w.NI + e];
+            }
+        }
+    }
+    return Row5{acc[0], acc[1], acc[2], acc[3], acc[4]};
+}
 
 // straight copies between a robot's blob in HBM and its LDS image, 16 bytes per lane
 __device__ __forceinline__ void copy_words(double *dst, const double *src, int n, int tid) {
@@ -80,9 +122,10 @@ __device__ __forceinline__ void copy_words(double *dst, const double *src, int n
     if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
 }
 
-template <int KT, bool STAGE_IR>
+template <int KT, int IRM>
 __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int robot0, uint32_t ext_mask, uint32_t int_mask,
                                                              int n_int, int snap_out, uint32_t hints) {
+    constexpr bool HAS_IR = IRM != IR_NONE, STAGE_IR = IRM == IR_STAGED;
     STAMP(t_k0);
     const int r = robot0 + blockIdx.x;
     const int tid = threadIdx.x;
@@ -104,13 +147,14 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 
     double *blob = w.blob + (size_t)r * w.BS;
     const int v0 = r * K;
-    const int ie0 = w.ir_var_ptr[v0], ie1 = w.ir_var_ptr[v0 + K], ne = ie1 - ie0;
-    const bool ir_on = (w.enable & 2u) != 0;
+    const int ie0 = HAS_IR ? w.ir_var_ptr[v0] : 0, ne = HAS_IR ? w.ir_var_ptr[v0 + K] - ie0 : 0;
+    const bool ir_on = HAS_IR && (w.enable & 2u) != 0;
     const int n_dyn = 2 * (K - 1);
     const bool idle = w.idle[r] != 0;
     const bool radio = (w.antenna[r] != 0) && !idle;
 
     // ---- stage the robot in LDS (all 128 threads) -----------------------------------------------
+    bool stage_dense = false;  // this lane met a dense (exceptional) inter-robot message
     copy_words(s_prior, blob + L.prior(), 20 * K, tid);
     copy_words(s_io, blob + L.cov(), L.inout_words(), tid);
     {
@@ -118,23 +162,31 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = src[t];
         for (int t = tid; t < K; t += SWEEP_BLOCK) {
             s_epoch[t] = w.snap_epoch[w.cur][v0 + t];
-            s_irp[t] = w.ir_var_ptr[v0 + t];
-            s_irp[(K + 1) + t] = w.ir_var_mid[v0 + t];
-            s_irp[2 * (K + 1) + t] = w.ir_var_ptr[v0 + t + 1];
+            if (HAS_IR) {
+                s_irp[t] = w.ir_var_ptr[v0 + t];
+                s_irp[(K + 1) + t] = w.ir_var_mid[v0 + t];
+                s_irp[2 * (K + 1) + t] = w.ir_var_ptr[v0 + t + 1];
+            }
         }
         // messages that this launch's external factor sweep recomputes before anyone reads them are
         // not fetched
         const bool recompute = (ext_mask & PH_EXT_FACTOR) && radio && ir_on;
         if (STAGE_IR)
-            for (int j = tid; j < ne; j += SWEEP_BLOCK) {  // 20 independent loads in flight per lane
+            for (int j = tid; j < ne; j += SWEEP_BLOCK) {  // independent loads in flight per lane
                 if (recompute && w.ir_gate[ie0 + j]) continue;
-                double m[20];
+                const size_t e = (size_t)(ie0 + j);
+                double m[6];
+                m[0] = w.ir_fv_eta[0 * (size_t)w.NI + e];
+                m[1] = w.ir_fv_eta[1 * (size_t)w.NI + e];
+                m[2] = w.ir_fv_lam[0 * (size_t)w.NI + e];
+                m[3] = w.ir_fv_lam[1 * (size_t)w.NI + e];
+                m[4] = w.ir_fv_lam[4 * (size_t)w.NI + e];
+                m[5] = w.ir_fv_lam[5 * (size_t)w.NI + e];
+                const bool dense = w.ir_dense[e] != 0;
+                stage_dense |= dense;
 #pragma unroll
-                for (int c = 0; c < 4; c++) m[c] = w.ir_fv_eta[(size_t)c * w.NI + ie0 + j];
-#pragma unroll
-                for (int c = 0; c < 16; c++) m[4 + c] = w.ir_fv_lam[(size_t)c * w.NI + ie0 + j];
-#pragma unroll
-                for (int c = 0; c < 20; c++) s_ir[j * IR_STRIDE + c] = m[c];
+                for (int c = 0; c < 6; c++) s_ir[j * IR_STRIDE + c] = m[c];
+                s_ir[j * IR_STRIDE + 6] = dense ? 1.0 : 0.0;
             }
     }
     int itf = w.iter_factor[r];  // iteration_count.factor (every lane applies the same increments)
@@ -182,7 +234,14 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         trk_lp[1] = w.trk_last_pos[(size_t)w.NT + trk_item];
         trk_lv = w.trk_last_val[trk_item];
     }
-    __syncthreads();
+    if (HAS_IR && !STAGE_IR)
+        for (int j = tid; j < ne; j += SWEEP_BLOCK) stage_dense |= w.ir_dense[ie0 + j] != 0;
+    // any dense message among the robot's incoming edges? (normally not: the sums then never look at flags)
+    bool any_dense = false;
+    if (HAS_IR)
+        any_dense = __syncthreads_or(stage_dense ? 1 : 0) != 0;
+    else
+        __syncthreads();
     uint32_t my_epoch = (tid < 4 * K) ? s_epoch[tid % K] : 0u;  // deliveries of the variable this thread sums
     STAMP(t_staged);
 
@@ -190,6 +249,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // factorgraph.rs:745-754 keeps only the message to the other graph's variable, so F_AB is
     // evaluated here, at B, from A's snapshot record and B's last response mean.
     if (ext_mask & PH_EXT_FACTOR) {
+        bool ext_dense = false;
         if (radio && ir_on) {
             for (int j = tid; j < ne; j += SWEEP_BLOCK) {
                 const int e = ie0 + j;
@@ -225,23 +285,38 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #pragma unroll
                     for (int c = 0; c < 16; c++) ol[c] = 0.0;
                 }
-                // HINT_IR_DEAD: the caller's next sweep recomputes these messages before reading them
-                // (it starts with an external factor sweep under the same flags), and this launch
-                // reads them from LDS — then the HBM copy is dead and not stored
-                if (!(STAGE_IR && (hints & HINT_IR_DEAD))) {
+                bool dense = !(oe[2] == 0.0) || !(oe[3] == 0.0);  // (a NaN is "not zero")
+#pragma unroll
+                for (int c = 0; c < 16; c++)
+                    if ((c >> 2) >= 2 || (c & 3) >= 2) dense |= !(ol[c] == 0.0);
+                ext_dense |= dense;
+                w.ir_dense[e] = dense ? 1 : 0;
+                if (dense) {  // exceptional: all 20 entries live in HBM and are summed from there
                     st_soa4(w.ir_fv_eta, w.NI, e, oe);
                     st_soa16(w.ir_fv_lam, w.NI, e, ol);
+                } else if (!(STAGE_IR && (hints & HINT_IR_DEAD))) {
+                    // HINT_IR_DEAD: the caller's next sweep recomputes these messages before reading
+                    // them (it starts with an external factor sweep under the same flags), and this
+                    // launch reads them from LDS — then the HBM copy is dead and not stored
+                    w.ir_fv_eta[0 * (size_t)w.NI + e] = oe[0];
+                    w.ir_fv_eta[1 * (size_t)w.NI + e] = oe[1];
+                    w.ir_fv_lam[0 * (size_t)w.NI + e] = ol[0];
+                    w.ir_fv_lam[1 * (size_t)w.NI + e] = ol[1];
+                    w.ir_fv_lam[4 * (size_t)w.NI + e] = ol[4];
+                    w.ir_fv_lam[5 * (size_t)w.NI + e] = ol[5];
                 }
                 if (STAGE_IR) {
-#pragma unroll
-                    for (int c = 0; c < 4; c++) s_ir[j * IR_STRIDE + c] = oe[c];
-#pragma unroll
-                    for (int c = 0; c < 16; c++) s_ir[j * IR_STRIDE + 4 + c] = ol[c];
+                    double *p = s_ir + j * IR_STRIDE;
+                    p[0] = oe[0]; p[1] = oe[1]; p[2] = ol[0]; p[3] = ol[1]; p[4] = ol[4]; p[5] = ol[5];
+                    p[6] = dense ? 1.0 : 0.0;
                 }
             }
         }
         if (radio) itf += 1;  // iteration_count.factor of the robot's own external sweep (factorgraph.rs:757)
-        __syncthreads();
+        if (HAS_IR)
+            any_dense = (__syncthreads_or(ext_dense ? 1 : 0) != 0) || any_dense;
+        else
+            __syncthreads();
     }
 
     // Inbox sums of a variable sweep, one lane per (variable, row): lane (i, rr) accumulates eta[rr] and
@@ -275,32 +350,42 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             double acc[5];  // eta[rr], lam[rr][0..3]
 #pragma unroll
             for (int c = 0; c < 5; c++) acc[c] = pr[c];
-            const int x0 = s_irp[i], xm = s_irp[(K + 1) + i], x1 = s_irp[2 * (K + 1) + i];
+            const int x0 = HAS_IR ? s_irp[i] : 0, xm = HAS_IR ? s_irp[(K + 1) + i] : 0, x1 = HAS_IR ? s_irp[2 * (K + 1) + i] : 0;
             auto ir_rows = [&](int e_from, int e_to) {
-                // foreign messages are added in inbox order; four at a time are fetched before the adds
-                for (int e = e_from; e < e_to; e += 4) {
-                    double m[4][5];
+                if (!HAS_IR) return;
+                if (!any_dense) {
+                    // compact messages: rows 0, 1 add eta[rr], lam[rr][0], lam[rr][1]; rows 2, 3 only zeros
+                    if (rr >= 2) return;
+                    for (int e = e_from; e < e_to; e += 4) {  // four messages are fetched before the adds
+                        double m[4][3];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int ee = (e + u < e_to) ? e + u : e;  // clamp: the value is not added
-                        if (STAGE_IR) {
-                            const double *p = s_ir + (ee - ie0) * IR_STRIDE;
-                            m[u][0] = p[rr];
-#pragma unroll
-                            for (int c = 0; c < 4; c++) m[u][1 + c] = p[4 + rr * 4 + c];
-                        } else {
-                            m[u][0] = w.ir_fv_eta[(size_t)rr * w.NI + ee];
-#pragma unroll
-                            for (int c = 0; c < 4; c++) m[u][1 + c] = w.ir_fv_lam[(size_t)(rr * 4 + c) * w.NI + ee];
+                        for (int u = 0; u < 4; u++) {
+                            const int ee = (e + u < e_to) ? e + u : e;  // clamp: the value is not added
+                            if (STAGE_IR) {
+                                const double *p = s_ir + (ee - ie0) * IR_STRIDE;
+                                m[u][0] = p[rr];
+                                m[u][1] = p[2 + 2 * rr];
+                                m[u][2] = p[3 + 2 * rr];
+                            } else {
+                                m[u][0] = w.ir_fv_eta[(size_t)rr * w.NI + ee];
+                                m[u][1] = w.ir_fv_lam[(size_t)(rr * 4) * w.NI + ee];
+                                m[u][2] = w.ir_fv_lam[(size_t)(rr * 4 + 1) * w.NI + ee];
+                            }
                         }
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (e + u < e_to) {
+                                acc[0] += m[u][0];
+                                acc[1] += m[u][1];
+                                acc[2] += m[u][2];
+                            }
                     }
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        if (e + u < e_to) {
-#pragma unroll
-                            for (int c = 0; c < 5; c++) acc[c] += m[u][c];
-                        }
+                    return;
                 }
+                // some message of this robot is dense (non-finite arithmetic upstream): out-of-line, per edge
+                const Row5 o = ir_rows_with_dense<STAGE_IR>(w.ir_fv_eta, w.ir_fv_lam, w.ir_dense, w.NI, rr, e_from, e_to, ie0, s_ir,
+                                                            Row5{acc[0], acc[1], acc[2], acc[3], acc[4]});
+                acc[0] = o.a0; acc[1] = o.a1; acc[2] = o.a2; acc[3] = o.a3; acc[4] = o.a4;
             };
             ir_rows(x0, xm);
 #pragma unroll
@@ -555,10 +640,13 @@ __device__ void apply_change_prior(const DevWorld &w, int r, int i, const double
     // every inbox message of the variable becomes empty (:224-227)
     for (int e = w.ir_var_ptr[v]; e < w.ir_var_ptr[v + 1]; e++) {
         if (w.enable & 2u) st_soa4(w.ir_bmu, w.NI, e, m);
-#pragma unroll
-        for (int c = 0; c < 4; c++) w.ir_fv_eta[(size_t)c * w.NI + e] = 0.0;
-#pragma unroll
-        for (int c = 0; c < 16; c++) w.ir_fv_lam[(size_t)c * w.NI + e] = 0.0;
+        w.ir_fv_eta[0 * (size_t)w.NI + e] = 0.0;  // the compact form of the empty message
+        w.ir_fv_eta[1 * (size_t)w.NI + e] = 0.0;
+        w.ir_fv_lam[0 * (size_t)w.NI + e] = 0.0;
+        w.ir_fv_lam[1 * (size_t)w.NI + e] = 0.0;
+        w.ir_fv_lam[4 * (size_t)w.NI + e] = 0.0;
+        w.ir_fv_lam[5 * (size_t)w.NI + e] = 0.0;
+        w.ir_dense[e] = 0;
     }
     const int n_dyn = 2 * (K - 1);
     const int es[4] = {(i >= 1) ? (K - 1) + (i - 1) : -1, (i <= K - 2) ? i : -1,
@@ -727,11 +815,14 @@ static void launch_k(const DevWorld &w, int robot0, int n_robots, uint32_t ext_m
     // staging the inter-robot messages needs IR_STRIDE f64 per edge; beyond 64 KB of LDS fall back to
     // reading them from L2 in every variable sweep
     const size_t staged = sweep_lds_bytes(w.K, w.ir_max_edges);
-    if (staged <= 64 * 1024)
-        hipLaunchKernelGGL((k_robot_sweep<KT, true>), dim3(n_robots), dim3(SWEEP_BLOCK), staged, stream, w, robot0, ext_mask,
+    if (w.ir_max_edges == 0)
+        hipLaunchKernelGGL((k_robot_sweep<KT, IR_NONE>), dim3(n_robots), dim3(SWEEP_BLOCK), sweep_lds_bytes(w.K, 0), stream, w,
+                           robot0, ext_mask, int_mask, n_int, snap_out, hints);
+    else if (staged <= 64 * 1024)
+        hipLaunchKernelGGL((k_robot_sweep<KT, IR_STAGED>), dim3(n_robots), dim3(SWEEP_BLOCK), staged, stream, w, robot0, ext_mask,
                            int_mask, n_int, snap_out, hints);
     else
-        hipLaunchKernelGGL((k_robot_sweep<KT, false>), dim3(n_robots), dim3(SWEEP_BLOCK), sweep_lds_bytes(w.K, 0), stream, w,
+        hipLaunchKernelGGL((k_robot_sweep<KT, IR_GLOBAL>), dim3(n_robots), dim3(SWEEP_BLOCK), sweep_lds_bytes(w.K, 0), stream, w,
                            robot0, ext_mask, int_mask, n_int, snap_out, hints);
 }
 

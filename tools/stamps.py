@@ -15,7 +15,8 @@ from magics_amd.world import World  # noqa: E402
 
 out = os.path.join(ROOT, "gpurun_out", "libmgx_stamps.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-srcs = [os.path.join(ROOT, "magics_amd", "csrc", f) for f in ("mgx_kernels.hip", "mgx_world.hip", "mgx_host.cpp")]
+import __graft_entry__ as _ge  # noqa: E402
+srcs = [os.path.join(ROOT, "magics_amd", "csrc", f) for f in _ge.SOURCES]
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                 "-DMGX_STAMPS", "-o", out] + srcs, check=True)
 hostlib.LIB_PATH = out
