@@ -78,10 +78,8 @@ struct DevWorld {
     const uint8_t *ir_gate;       // [NI] 1 iff the OWNER robot is on air (antenna on, not idle): refreshed with
                                   //      the flags so that the edge lane needs no dependent flag loads
     double *ir_fv_eta, *ir_fv_lam;  // [4][NI],[16][NI] factor -> target variable
-    // An inter-robot factor constrains positions only (interrobot.rs:149-159): for finite inputs its
-    // message is zero outside eta[0..2) and lam[0..2)x[0..2) (mgx_kernels.hip, "compact messages").
-    // ir_dense[e] = 1 marks the exceptions (non-finite arithmetic), which keep all 20 entries.
-    uint8_t *ir_dense;              // [NI]
+    // only rows eta[0..2) and lam[0][0..2), lam[1][0..2) are live: an inter-robot factor constrains
+    // positions only, the rest of its message is structurally zero (mgx_kernels.hip, compact messages)
     double *ir_bmu;                 // [4][NI] mean of the target variable -> factor message (the
                                     // only part of that inbox entry the kept output depends on)
 

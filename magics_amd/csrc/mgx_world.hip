@@ -235,7 +235,7 @@ struct mgx_world {
     DevBuf<int32_t> trk_record, path_ptr, iter_factor, ir_var_ptr, ir_var_mid;
     DevBuf<uint32_t> epoch0, epoch1;
     DevBuf<float> trk_last_pos, path_xy;
-    DevBuf<uint8_t> ir_gate, ir_dense, antenna, idle, sdf;
+    DevBuf<uint8_t> ir_gate, antenna, idle, sdf;
     StageRing stage;  // packed per-tick arguments
     // message counters are advanced lazily: launches and prior changes are only logged here
     struct CountEntry { uint8_t ext, in; int n_int, robot; uint64_t times; };
@@ -390,8 +390,6 @@ static int pull(mgx_world *w) {
     HIP_TRY(w->ir_fv_eta.download(ife, s));
     HIP_TRY(w->ir_fv_lam.download(ifl, s));
     HIP_TRY(w->ir_bmu.download(ibm, s));
-    std::vector<uint8_t> idn;
-    HIP_TRY(w->ir_dense.download(idn, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (size_t dr = 0; dr < w->robot_of.size(); dr++) {
         Robot &rb = w->robots[(size_t)w->robot_of[dr]];
@@ -416,11 +414,10 @@ static int pull(mgx_world *w) {
         gather(ife, NI, e, ed.fv_eta, 4);
         gather(ifl, NI, e, ed.fv_lam, 16);
         gather(ibm, NI, e, ed.bmu, 4);
-        if (!idn[e]) {  // compact message: only eta[0..2) and lam[0..2)x[0..2) are kept on the device
-            ed.fv_eta[2] = ed.fv_eta[3] = 0.0;
-            for (int c = 0; c < 16; c++)
-                if ((c >> 2) >= 2 || (c & 3) >= 2) ed.fv_lam[c] = 0.0;
-        }
+        // compact messages: only eta[0..2) and lam[0..2)x[0..2) are kept on the device
+        ed.fv_eta[2] = ed.fv_eta[3] = 0.0;
+        for (int c = 0; c < 16; c++)
+            if ((c >> 2) >= 2 || (c & 3) >= 2) ed.fv_lam[c] = 0.0;
     }
     return MGX_OK;
 }
@@ -614,7 +611,6 @@ static int commit(mgx_world *w) {
     std::vector<int32_t> var_ptr((size_t)R_local * K + 1, 0), var_mid((size_t)R_local * K, 0);
     std::vector<IrEdgeRec> recs;
     std::vector<double> ife, ifl, ibm;
-    std::vector<uint8_t> idn;
     w->edge_src_robot.clear();
     w->edge_conn.clear();
     w->edge_i.clear();
@@ -624,7 +620,6 @@ static int commit(mgx_world *w) {
     ife.assign(4 * NIs, 0.0);
     ifl.assign(16 * NIs, 0.0);
     ibm.assign(4 * NIs, 0.0);
-    idn.assign(NIs, 0);
     size_t e = 0;
     for (size_t v = 0; v < per_var.size(); v++) {
         var_ptr[v] = (int32_t)e;
@@ -651,12 +646,6 @@ static int commit(mgx_world *w) {
             scatter(ife, NIs, e, ed.fv_eta, 4);
             scatter(ifl, NIs, e, ed.fv_lam, 16);
             scatter(ibm, NIs, e, ed.bmu, 4);
-            {   // dense iff something sits outside the position block (see mgx_kernels.hip, compact messages)
-                bool dense = !(ed.fv_eta[2] == 0.0) || !(ed.fv_eta[3] == 0.0);
-                for (int c = 0; c < 16; c++)
-                    if ((c >> 2) >= 2 || (c & 3) >= 2) dense |= !(ed.fv_lam[c] == 0.0);
-                idn[e] = dense ? 1 : 0;
-            }
             w->edge_conn.push_back(rf.conn);
             w->edge_i.push_back(rf.j);
             e++;
@@ -720,7 +709,6 @@ static int commit(mgx_world *w) {
     HIP_TRY(w->ir_fv_eta.upload(ife, s));
     HIP_TRY(w->ir_fv_lam.upload(ifl, s));
     HIP_TRY(w->ir_bmu.upload(ibm, s));
-    HIP_TRY(w->ir_dense.upload(idn, s));
     HIP_TRY(w->sdf.upload(w->sdf_red, s));
     HIP_TRY(hipStreamSynchronize(s));  // host staging vectors die at scope exit
 
@@ -737,7 +725,7 @@ static int commit(mgx_world *w) {
     d.trk_record = w->trk_record.p; d.trk_last_pos = w->trk_last_pos.p; d.trk_last_val = w->trk_last_val.p;
     d.path_ptr = w->path_ptr.p; d.path_xy = w->path_xy.p; d.iter_factor = w->iter_factor.p;
     d.ir_var_ptr = w->ir_var_ptr.p; d.ir_var_mid = w->ir_var_mid.p; d.ir_rec = w->ir_rec.p;
-    d.ir_fv_eta = w->ir_fv_eta.p; d.ir_fv_lam = w->ir_fv_lam.p; d.ir_bmu = w->ir_bmu.p; d.ir_dense = w->ir_dense.p;
+    d.ir_fv_eta = w->ir_fv_eta.p; d.ir_fv_lam = w->ir_fv_lam.p; d.ir_bmu = w->ir_bmu.p;
     d.sdf = w->sdf.p; d.sdf_w = w->sdf_w; d.sdf_h = w->sdf_h; d.world_w = w->world_w; d.world_h = w->world_h;
     // ObstacleFactor::new jacobian_delta (obstacle.rs:98-102)
     d.obs_delta = (w->sdf_w && w->sdf_h) ? (w->world_w / (double)w->sdf_w + w->world_h / (double)w->sdf_h) / 2.0 : 1.0;

@@ -175,3 +175,29 @@ def test_tracking_factor_waits_ten_factor_sweeps():
     assert not trk()[0][2]       # iteration_count.factor < 10 for the first ten sweeps
     w.iterate([1])
     assert trk()[0][2]
+
+
+def test_interrobot_messages_live_in_the_position_block():
+    """The engine stores an inter-robot message as six numbers (eta[0:2], lam[0:2, 0:2]): in the
+    faithful restatement, which computes all twenty with the generic J^T L J / Schur arithmetic,
+    every other entry must be an exact zero as long as the world is finite."""
+    from magics_amd import scenarios as S
+    sc = S.grid_scenario(16, 10, interrobot=True, pitch=2.0, comm_radius=5.0)
+    w = oracle.OracleWorld(sc["params"])
+    ids = S.populate(w, sc)
+    args = S.tick_inputs(sc)
+    seen = nonzero = 0
+    for tick in range(6):
+        w.update_priors(**args)
+        w.iterate(sc["steps"])
+        if tick % 3 != 2:
+            continue
+        for r in ids:
+            for i in range(1, sc["K"]):
+                for fr, _, present, eta, lam in w.variable_inbox(r, i):
+                    if fr == r or not present:
+                        continue
+                    seen += 1
+                    nonzero += int(np.abs(lam[:2, :2]).max() > 0)
+                    assert (eta[2:] == 0).all() and (lam[2:, :] == 0).all() and (lam[:, 2:] == 0).all(), (tick, r, i, fr)
+    assert seen > 100 and nonzero > 20, (seen, nonzero)   # robots 2 m apart with d_safe 2.5: plenty of active factors
