@@ -214,6 +214,10 @@ int mgx_get_belief(mgx_world *w, int32_t robot, uint32_t var_ix, double eta[4], 
 int mgx_read_beliefs(mgx_world *w, double *eta, double *lam, double *means);
 /* means only — what reached_waypoint (robot.rs:2125-2136) and the visualisers read per tick */
 int mgx_read_means(mgx_world *w, double *means);
+/* the mean of ONE variable of every robot, [n_robots][4]: nth_variable(0) / last_variable for
+ * reached_waypoint (robot.rs:2125-2136), variables 0 and 1 for the Transform increment of
+ * update_prior_of_current_state_v3 (robot.rs:2309-2330) — 32 bytes per robot instead of 32 K */
+int mgx_read_variable_means(mgx_world *w, uint32_t var_ix, double *means);
 int mgx_num_robots(mgx_world *w, uint32_t *n_robots, uint32_t *n_variables);
 /* FactorGraph::messages_sent() / messages_received() (factorgraph.rs:876-890; MessageCount,
  * factorgraph/mod.rs:29-137) of one robot's graph, as exported by export.rs:434-439:

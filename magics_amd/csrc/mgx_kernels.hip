@@ -731,6 +731,16 @@ __global__ void __launch_bounds__(256) k_halo_wait_unpack(DevWorld w, int n, con
         w.snap_epoch[w.cur][v0 + (q - SNAP_W * w.K)] = (uint32_t)val;
 }
 
+// belief mean of ONE variable of every local robot -> out[R][4] (the per-tick reads of the driver:
+// reached_waypoint, the Transform increment of update_prior_of_current_state_v3)
+__global__ void k_gather_variable_means(DevWorld w, int var, double *__restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= w.R_local * 4) return;
+    const int r = t >> 2, c = t & 3;
+    const BlobLayout L(w.K);
+    out[t] = w.blob[(size_t)r * w.BS + L.mu() + c * w.K + var];
+}
+
 // small byte copy (flag tables from the pinned argument ring into their device arrays)
 __global__ void k_copy_bytes(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, size_t n) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -803,6 +813,11 @@ hipError_t launch_halo_wait_unpack(const DevWorld &w, int n, const int32_t *ghos
     const int total = n * (SNAP_W + 1) * w.K;
     hipLaunchKernelGGL(k_halo_wait_unpack, dim3((total + 255) / 256), dim3(256), 0, stream, w, n, ghosts, recv, n_sources, flags, seq,
                        err, timeout_ticks);
+    return hipGetLastError();
+}
+hipError_t launch_gather_variable_means(const DevWorld &w, int var, double *out, hipStream_t stream) {
+    if (w.R_local <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_variable_means, dim3((unsigned)((w.R_local * 4 + 255) / 256)), dim3(256), 0, stream, w, var, out);
     return hipGetLastError();
 }
 hipError_t launch_copy_bytes(uint8_t *dst, const uint8_t *src, size_t n, hipStream_t stream) {

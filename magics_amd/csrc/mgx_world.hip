@@ -36,6 +36,7 @@ hipError_t launch_update_priors(const DevWorld &w, int n, const int32_t *robots,
 hipError_t launch_halo_pack(const DevWorld &w, int n, const int32_t *robots, double *buf, hipStream_t stream);
 hipError_t launch_halo_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *buf, hipStream_t stream);
 hipError_t launch_copy_bytes(uint8_t *dst, const uint8_t *src, size_t n, hipStream_t stream);
+hipError_t launch_gather_variable_means(const DevWorld &w, int var, double *out, hipStream_t stream);
 hipError_t launch_halo_push(const DevWorld &w, int n, const int32_t *robots, const unsigned long long *dst, int n_peers,
                             const unsigned long long *peer_flags, unsigned long long seq, unsigned int *done, hipStream_t stream);
 hipError_t launch_halo_wait_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *recv, int n_sources,
@@ -1275,6 +1276,26 @@ int mgx_num_robots(mgx_world *w, uint32_t *n_robots, uint32_t *n_variables) {
     for (const Robot &r : w->robots) nr += r.ghost ? 0 : 1;
     if (n_robots) *n_robots = nr;
     if (n_variables) *n_variables = nr * (uint32_t)w->K;
+    return MGX_OK;
+}
+
+// the mean of variable `var_ix` of every local robot, id order: what the driver reads every tick
+// (nth_variable(0) / last_variable for reached_waypoint, robot.rs:2125-2136; variables 0 and 1 for the
+// Transform increment, robot.rs:2309-2330) — gathered on the device straight into pinned memory
+int mgx_read_variable_means(mgx_world *w, uint32_t var_ix, double *means) {
+    if (!w || !means) return fail(MGX_ERR_INVALID, "null argument");
+    int rc = commit(w);
+    if (rc != MGX_OK) return rc;
+    if ((int)var_ix >= w->K) return fail(MGX_ERR_INVALID, "variable index out of range");
+    const size_t bytes = (size_t)w->d.R_local * 4 * sizeof(double);
+    void *hp = nullptr, *dp = nullptr;
+    int slot = 0;
+    HIP_TRY(w->stage.acquire(bytes, &hp, &slot));
+    HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+    HIP_TRY(launch_gather_variable_means(w->d, (int)var_ix, (double *)dp, w->stream));
+    HIP_TRY(w->stage.release(slot, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    memcpy(means, hp, bytes);
     return MGX_OK;
 }
 

@@ -99,6 +99,7 @@ SYMBOLS = {
     "mgx_read_beliefs": (C.c_int, [_V, c_double_p, c_double_p, c_double_p]),
     "mgx_message_counts": (C.c_int, [_V, C.c_int32, C.POINTER(C.c_uint64)]),
     "mgx_read_means": (C.c_int, [_V, c_double_p]),
+    "mgx_read_variable_means": (C.c_int, [_V, C.c_uint32, c_double_p]),
     "mgx_halo_direct_setup": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "mgx_halo_direct_connect": (C.c_int, [_V, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_halo_direct_exchange": (C.c_int, [_V, C.c_uint32]),

@@ -207,6 +207,13 @@ class World:
         self._chk(self._L.mgx_message_counts(self._w, robot, out))
         return tuple(int(x) for x in out)
 
+    def read_variable_means(self, var_ix):
+        """Belief mean of one variable of every robot, [n_robots, 4]."""
+        nr, _ = self.num_robots()
+        out = np.zeros((nr, 4))
+        self._chk(self._L.mgx_read_variable_means(self._w, var_ix, _dp(out)))
+        return out
+
     def read_means(self):
         _, nv = self.num_robots()
         means = np.zeros((nv, 4))

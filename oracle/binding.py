@@ -279,6 +279,11 @@ class OracleWorld:
     def read_means(self):
         return self.read_beliefs()[2]
 
+    def read_variable_means(self, var_ix):
+        mu = self.read_beliefs()[2]
+        nr = self.num_robots()[0]
+        return mu.reshape(nr, -1, 4)[:, var_ix, :].copy()
+
     def message_counts(self, robot):
         """(sent internal, sent external, received internal, received external) of one graph."""
         out = (C.c_uint64 * 4)()

@@ -62,6 +62,7 @@ extern "C" {
     pub fn mgx_get_belief(w: *mut mgx_world, robot: i32, var_ix: u32, eta: *mut f64, lam: *mut f64, mean: *mut f64, cov: *mut f64, valid: *mut i32) -> c_int;
     pub fn mgx_read_beliefs(w: *mut mgx_world, eta: *mut f64, lam: *mut f64, means: *mut f64) -> c_int;
     pub fn mgx_message_counts(w: *mut mgx_world, robot: i32, counts: *mut u64) -> c_int;
+    pub fn mgx_read_variable_means(w: *mut mgx_world, var_ix: u32, means: *mut f64) -> c_int;
     pub fn mgx_read_means(w: *mut mgx_world, means: *mut f64) -> c_int;
     pub fn mgx_num_robots(w: *mut mgx_world, n_robots: *mut u32, n_variables: *mut u32) -> c_int;
     pub fn mgx_halo_words(k: u32) -> u32;
