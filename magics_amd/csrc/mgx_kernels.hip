@@ -741,6 +741,43 @@ __global__ void k_gather_variable_means(DevWorld w, int var, double *__restrict_
     out[t] = w.blob[(size_t)r * w.BS + L.mu() + c * w.K + var];
 }
 
+// In-place topology change: build the new inter-robot edge arrays from the old ones.  old_of_new[e]
+// is the old index of new edge e (-1: created now), old_of_new[stride_new + e] its target variable.
+// A surviving edge keeps its message (the six live numbers), response mean and creation epoch; a
+// new one starts empty, created at the owner variable's current delivery count, with the target
+// variable's current belief mean as the response it has seen (robot.rs:1549-1585).
+__global__ void k_edge_rebuild(DevWorld w, int n_new, int stride_new, int stride_old, const int32_t *__restrict__ old_of_new,
+                               IrEdgeRec *__restrict__ recs, double *__restrict__ fv_eta, double *__restrict__ fv_lam,
+                               double *__restrict__ bmu) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_new) return;
+    const int o = old_of_new[e];
+    const size_t sn = (size_t)stride_new, so = (size_t)stride_old;
+    if (o >= 0) {
+        fv_eta[0 * sn + e] = w.ir_fv_eta[0 * so + o];
+        fv_eta[1 * sn + e] = w.ir_fv_eta[1 * so + o];
+        fv_lam[0 * sn + e] = w.ir_fv_lam[0 * so + o];
+        fv_lam[1 * sn + e] = w.ir_fv_lam[1 * so + o];
+        fv_lam[4 * sn + e] = w.ir_fv_lam[4 * so + o];
+        fv_lam[5 * sn + e] = w.ir_fv_lam[5 * so + o];
+#pragma unroll
+        for (int c = 0; c < 4; c++) bmu[c * sn + e] = w.ir_bmu[c * so + o];
+        recs[e].created = w.ir_rec[o].created;
+    } else {
+        fv_eta[0 * sn + e] = 0.0;
+        fv_eta[1 * sn + e] = 0.0;
+        fv_lam[0 * sn + e] = 0.0;
+        fv_lam[1 * sn + e] = 0.0;
+        fv_lam[4 * sn + e] = 0.0;
+        fv_lam[5 * sn + e] = 0.0;
+        const int v = old_of_new[stride_new + e], r = v / w.K, i = v - r * w.K;
+        const BlobLayout L(w.K);
+#pragma unroll
+        for (int c = 0; c < 4; c++) bmu[c * sn + e] = w.blob[(size_t)r * w.BS + L.mu() + c * w.K + i];
+        recs[e].created = w.snap_epoch[w.cur][recs[e].src_var];
+    }
+}
+
 // small byte copy (flag tables from the pinned argument ring into their device arrays)
 __global__ void k_copy_bytes(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, size_t n) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -818,6 +855,13 @@ hipError_t launch_halo_wait_unpack(const DevWorld &w, int n, const int32_t *ghos
 hipError_t launch_gather_variable_means(const DevWorld &w, int var, double *out, hipStream_t stream) {
     if (w.R_local <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_gather_variable_means, dim3((unsigned)((w.R_local * 4 + 255) / 256)), dim3(256), 0, stream, w, var, out);
+    return hipGetLastError();
+}
+hipError_t launch_edge_rebuild(const DevWorld &w, int n_new, int stride_new, int stride_old, const int32_t *old_of_new, IrEdgeRec *recs,
+                               double *fv_eta, double *fv_lam, double *bmu, hipStream_t stream) {
+    if (n_new <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_edge_rebuild, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, stream, w, n_new, stride_new, stride_old,
+                       old_of_new, recs, fv_eta, fv_lam, bmu);
     return hipGetLastError();
 }
 hipError_t launch_copy_bytes(uint8_t *dst, const uint8_t *src, size_t n, hipStream_t stream) {

@@ -37,6 +37,8 @@ hipError_t launch_halo_pack(const DevWorld &w, int n, const int32_t *robots, dou
 hipError_t launch_halo_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *buf, hipStream_t stream);
 hipError_t launch_copy_bytes(uint8_t *dst, const uint8_t *src, size_t n, hipStream_t stream);
 hipError_t launch_gather_variable_means(const DevWorld &w, int var, double *out, hipStream_t stream);
+hipError_t launch_edge_rebuild(const DevWorld &w, int n_new, int stride_new, int stride_old, const int32_t *old_of_new, IrEdgeRec *recs,
+                               double *fv_eta, double *fv_lam, double *bmu, hipStream_t stream);
 hipError_t launch_halo_push(const DevWorld &w, int n, const int32_t *robots, const unsigned long long *dst, int n_peers,
                             const unsigned long long *peer_flags, unsigned long long seq, unsigned int *done, hipStream_t stream);
 hipError_t launch_halo_wait_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *recv, int n_sources,
@@ -75,7 +77,15 @@ template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0, cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;  // owns its allocation
+    DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
+    void swap(DevBuf &o) {
+        std::swap(p, o.p);
+        std::swap(n, o.n);
+        std::swap(cap, o.cap);
+    }
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -208,6 +218,7 @@ struct IrConn {  // K-1 factors owner -> other
     // re-used slot is updated once per occurrence in every external sweep — same message, but every
     // update counts as sent / received.
     uint64_t updates_per_sweep = 0;
+    std::vector<int32_t> dev_edge;  // device edge index of each factor in the current tables (-1: not there)
 };
 
 }  // namespace
@@ -222,16 +233,19 @@ struct mgx_world {
     int K = 0;
 
     hipStream_t stream = nullptr;
-    bool dirty = true;       // topology / flags changed since the device arrays were built
+    bool dirty = true;       // robots / image changed since the device arrays were built: full rebuild
+    bool conns_dirty = false;  // only inter-robot connections changed: edge tables are rebuilt in place
     bool flags_dirty = true;
     bool dev_valid = false;  // device arrays hold live state
     DevWorld d{};
     std::vector<int> dev_of;     // robot id -> device robot index (locals first, then ghosts)
     std::vector<int> robot_of;   // device robot index -> robot id
-    std::vector<int> edge_conn, edge_i;  // device ir edge -> (conn index, i-1)
 
     DevBuf<double> blob, snap0, snap1, dyn_m, trk_last_val, ir_fv_eta, ir_fv_lam, ir_bmu;
     DevBuf<IrEdgeRec> ir_rec;
+    DevBuf<double> ir_fv_eta_b, ir_fv_lam_b, ir_bmu_b;  // second set: the edge tables are rebuilt out of place
+    DevBuf<IrEdgeRec> ir_rec_b;
+    DevBuf<int32_t> ir_map;  // scratch: old edge index of each new edge
     std::vector<int32_t> edge_src_robot;  // device robot index of each edge's owner (for the gates)
     DevBuf<int32_t> trk_record, path_ptr, iter_factor, ir_var_ptr, ir_var_mid;
     DevBuf<uint32_t> epoch0, epoch1;
@@ -391,6 +405,8 @@ static int pull(mgx_world *w) {
     HIP_TRY(w->ir_fv_eta.download(ife, s));
     HIP_TRY(w->ir_fv_lam.download(ifl, s));
     HIP_TRY(w->ir_bmu.download(ibm, s));
+    std::vector<IrEdgeRec> irc;
+    HIP_TRY(w->ir_rec.download(irc, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (size_t dr = 0; dr < w->robot_of.size(); dr++) {
         Robot &rb = w->robots[(size_t)w->robot_of[dr]];
@@ -410,16 +426,20 @@ static int pull(mgx_world *w) {
         }
         rb.iter_factor = itf[dr];
     }
-    for (size_t e = 0; e < w->edge_conn.size(); e++) {
-        IrEdge &ed = w->conns[(size_t)w->edge_conn[e]].edges[(size_t)w->edge_i[e]];
-        gather(ife, NI, e, ed.fv_eta, 4);
-        gather(ifl, NI, e, ed.fv_lam, 16);
-        gather(ibm, NI, e, ed.bmu, 4);
-        // compact messages: only eta[0..2) and lam[0..2)x[0..2) are kept on the device
-        ed.fv_eta[2] = ed.fv_eta[3] = 0.0;
-        for (int c = 0; c < 16; c++)
-            if ((c >> 2) >= 2 || (c & 3) >= 2) ed.fv_lam[c] = 0.0;
-    }
+    for (IrConn &c : w->conns)
+        for (size_t j = 0; j < c.dev_edge.size(); j++) {
+            if (c.dev_edge[j] < 0) continue;  // created since the tables were built: nothing on the device yet
+            const size_t e = (size_t)c.dev_edge[j];
+            IrEdge &ed = c.edges[j];
+            gather(ife, NI, e, ed.fv_eta, 4);
+            gather(ifl, NI, e, ed.fv_lam, 16);
+            gather(ibm, NI, e, ed.bmu, 4);
+            ed.created = irc[e].created;  // edges born in an in-place rebuild got theirs on the device
+            // compact messages: only eta[0..2) and lam[0..2)x[0..2) are kept on the device
+            ed.fv_eta[2] = ed.fv_eta[3] = 0.0;
+            for (int q = 0; q < 16; q++)
+                if ((q >> 2) >= 2 || (q & 3) >= 2) ed.fv_lam[q] = 0.0;
+        }
     return MGX_OK;
 }
 
@@ -562,9 +582,135 @@ static int upload_flags(mgx_world *w) {
     return MGX_OK;
 }
 
+// Inter-robot edges grouped by LOCAL target variable in inbox key order (graph key, node index —
+// message.rs / id.rs:19-117): CSR over variables, the split between lower-key and higher-key owners,
+// and the constant record of every edge (`created` is filled by the caller).  Flat counting sort:
+// this runs on every topology change.
+struct EdgeTables {
+    std::vector<int32_t> var_ptr, var_mid, conn, j;
+    std::vector<IrEdgeRec> recs;
+    int ir_max_edges = 0;
+};
+static void build_edge_tables(const mgx_world *w, int R_local, EdgeTables &t) {
+    const int K = w->K;
+    const size_t NV = (size_t)R_local * K;
+    t.var_ptr.assign(NV + 1, 0);
+    t.var_mid.assign(NV, 0);
+    for (const IrConn &c : w->conns) {
+        if (w->robots[(size_t)c.other].ghost) continue;  // target lives on another rank
+        const size_t v0 = (size_t)w->dev_of[(size_t)c.other] * K;
+        for (size_t j = 0; j < c.node.size(); j++) t.var_ptr[v0 + j + 2]++;  // variable j + 1, shifted by one for the scan
+    }
+    for (size_t v = 1; v <= NV; v++) t.var_ptr[v] += t.var_ptr[v - 1];
+    const size_t NI = (size_t)t.var_ptr[NV];
+    t.conn.assign(NI, 0);
+    t.j.assign(NI, 0);
+    std::vector<int32_t> fill(t.var_ptr.begin(), t.var_ptr.end() - 1);
+    for (size_t ci = 0; ci < w->conns.size(); ci++) {
+        const IrConn &c = w->conns[ci];
+        if (w->robots[(size_t)c.other].ghost) continue;
+        const size_t v0 = (size_t)w->dev_of[(size_t)c.other] * K;
+        for (size_t j = 0; j < c.node.size(); j++) {
+            const int32_t e = fill[v0 + j + 1]++;
+            t.conn[(size_t)e] = (int32_t)ci;
+            t.j[(size_t)e] = (int32_t)j;
+        }
+    }
+    t.recs.resize(std::max<size_t>(NI, 1));
+    t.recs[0] = IrEdgeRec{0, 0, 0, 0, 0.0, 0.0};
+    for (size_t v = 0; v < NV; v++) {
+        const int32_t lo = t.var_ptr[v], hi = t.var_ptr[v + 1];
+        auto key_of = [&](int32_t e) { return w->robots[(size_t)w->conns[(size_t)t.conn[(size_t)e]].owner].order_key; };
+        auto node_of = [&](int32_t e) { return w->conns[(size_t)t.conn[(size_t)e]].node[(size_t)t.j[(size_t)e]]; };
+        for (int32_t a = lo + 1; a < hi; a++) {  // insertion sort: a handful of edges per variable
+            const int32_t ca = t.conn[(size_t)a], ja = t.j[(size_t)a];
+            const uint64_t ka = key_of(a);
+            const int na = node_of(a);
+            int32_t b = a;
+            while (b > lo && (key_of(b - 1) > ka || (key_of(b - 1) == ka && node_of(b - 1) > na))) {
+                t.conn[(size_t)b] = t.conn[(size_t)b - 1];
+                t.j[(size_t)b] = t.j[(size_t)b - 1];
+                b--;
+            }
+            t.conn[(size_t)b] = ca;
+            t.j[(size_t)b] = ja;
+        }
+        const Robot &ot = w->robots[(size_t)w->robot_of[v / (size_t)K]];
+        t.var_mid[v] = hi;
+        for (int32_t e = lo; e < hi; e++) {
+            const IrConn &c = w->conns[(size_t)t.conn[(size_t)e]];
+            const Robot &ow = w->robots[(size_t)c.owner];
+            if (t.var_mid[v] == hi && ow.order_key > ot.order_key) t.var_mid[v] = e;
+            IrEdgeRec rec;
+            rec.src_var = w->dev_of[(size_t)c.owner] * K + t.j[(size_t)e] + 1;
+            rec.src_robot = w->dev_of[(size_t)c.owner];
+            rec.created = 0;
+            rec.dst = (int32_t)(v % (size_t)K) | ((ot.order_key > ow.order_key) ? (1 << 16) : 0);
+            rec.d_safe = w->p.safety_multiplier * ow.radius;                                        // interrobot.rs:64
+            rec.offset = (double)1e-6f * (double)(c.first_number + (uint64_t)t.j[(size_t)e]);      // interrobot.rs:52,75
+            t.recs[(size_t)e] = rec;
+        }
+    }
+    t.ir_max_edges = 0;
+    for (int dr = 0; dr < R_local; dr++)
+        t.ir_max_edges = std::max(t.ir_max_edges, (int)(t.var_ptr[(size_t)(dr + 1) * K] - t.var_ptr[(size_t)dr * K]));
+}
+
+static int upload_flags(mgx_world *w);
+
+// Only inter-robot connections changed (create_ / delete_interrobot_factors between two ticks):
+// the edge tables are rebuilt on the device from the old ones — surviving edges keep their state
+// (message, response mean, creation epoch), new edges are initialised from the owner's current
+// delivery count and the target's current belief mean (robot.rs:1549-1585) — without moving any
+// robot state between host and device.
+static int retopo(mgx_world *w) {
+    const int K = w->K, R_local = w->d.R_local;
+    EdgeTables t;
+    build_edge_tables(w, R_local, t);
+    const size_t NI = (size_t)t.var_ptr.back(), NIs = std::max<size_t>(NI, 1), NI_old = (size_t)w->d.NI;
+    std::vector<int32_t> map(2 * NIs, -1);  // old index of every new edge | its target variable
+    for (size_t v = 0; v + 1 < t.var_ptr.size(); v++)
+        for (int32_t e = t.var_ptr[v]; e < t.var_ptr[v + 1]; e++) map[NIs + (size_t)e] = (int32_t)v;
+    for (size_t e = 0; e < NI; e++) {
+        const IrConn &c = w->conns[(size_t)t.conn[e]];
+        map[e] = c.dev_edge.empty() ? -1 : c.dev_edge[(size_t)t.j[e]];
+    }
+    hipStream_t s = w->stream;
+    HIP_TRY(w->ir_map.upload(map, s));
+    HIP_TRY(w->ir_rec_b.upload(t.recs, s));
+    HIP_TRY(w->ir_var_ptr.upload(t.var_ptr, s));
+    HIP_TRY(w->ir_var_mid.upload(t.var_mid, s));
+    HIP_TRY(w->ir_fv_eta_b.reserve(4 * NIs));
+    HIP_TRY(w->ir_fv_lam_b.reserve(16 * NIs));
+    HIP_TRY(w->ir_bmu_b.reserve(4 * NIs));
+    HIP_TRY(launch_edge_rebuild(w->d, (int)NI, (int)NIs, (int)NI_old, w->ir_map.p, w->ir_rec_b.p, w->ir_fv_eta_b.p, w->ir_fv_lam_b.p,
+                                w->ir_bmu_b.p, s));
+    HIP_TRY(hipStreamSynchronize(s));  // `map`, `t` are pageable temporaries
+    w->ir_rec.swap(w->ir_rec_b);
+    w->ir_fv_eta.swap(w->ir_fv_eta_b);
+    w->ir_fv_lam.swap(w->ir_fv_lam_b);
+    w->ir_bmu.swap(w->ir_bmu_b);
+    DevWorld &d = w->d;
+    d.NI = (int)NIs;
+    d.ir_rec = w->ir_rec.p; d.ir_fv_eta = w->ir_fv_eta.p; d.ir_fv_lam = w->ir_fv_lam.p; d.ir_bmu = w->ir_bmu.p;
+    d.ir_var_ptr = w->ir_var_ptr.p; d.ir_var_mid = w->ir_var_mid.p;
+    d.ir_max_edges = t.ir_max_edges;
+    for (IrConn &c : w->conns) c.dev_edge.assign(c.node.size(), -1);
+    w->edge_src_robot.resize(NI);
+    for (size_t e = 0; e < NI; e++) {
+        IrConn &c = w->conns[(size_t)t.conn[e]];
+        c.dev_edge[(size_t)t.j[e]] = (int32_t)e;
+        c.edges[(size_t)t.j[e]].fresh = false;
+        w->edge_src_robot[e] = t.recs[e].src_robot;
+    }
+    w->conns_dirty = false;
+    return upload_flags(w);  // the gate bytes follow the edges
+}
+
 static int commit(mgx_world *w) {
     if (!device_ok()) return fail(MGX_ERR_NO_DEVICE, "no usable HIP device (this library has no CPU path)");
     if (!w->dirty) {
+        if (w->conns_dirty) return retopo(w);
         if (w->flags_dirty) return upload_flags(w);
         return MGX_OK;
     }
@@ -599,63 +745,25 @@ static int commit(mgx_world *w) {
             ed.fresh = false;
         }
 
-    // inter-robot edges grouped by LOCAL target variable, ordered by the owner's order key
-    struct Ref { int conn, j; uint64_t key; int node; };
-    std::vector<std::vector<Ref>> per_var((size_t)R_local * K);
-    for (size_t ci = 0; ci < w->conns.size(); ci++) {
-        const IrConn &c = w->conns[ci];
-        if (w->robots[(size_t)c.other].ghost) continue;  // target lives on another rank
-        const int dt = w->dev_of[(size_t)c.other];
-        for (size_t j = 0; j < c.edges.size(); j++)
-            per_var[(size_t)dt * K + j + 1].push_back({(int)ci, (int)j, w->robots[(size_t)c.owner].order_key, c.node[j]});
+    EdgeTables t;
+    build_edge_tables(w, R_local, t);
+    std::vector<int32_t> &var_ptr = t.var_ptr, &var_mid = t.var_mid;
+    std::vector<IrEdgeRec> &recs = t.recs;
+    const size_t NI = (size_t)var_ptr.back(), NIs = std::max<size_t>(NI, 1);
+    std::vector<double> ife(4 * NIs, 0.0), ifl(16 * NIs, 0.0), ibm(4 * NIs, 0.0);
+    w->edge_src_robot.resize(NI);
+    for (IrConn &c : w->conns) c.dev_edge.assign(c.node.size(), -1);
+    for (size_t e = 0; e < NI; e++) {
+        IrConn &c = w->conns[(size_t)t.conn[e]];
+        const IrEdge &ed = c.edges[(size_t)t.j[e]];
+        recs[e].created = ed.created;
+        w->edge_src_robot[e] = recs[e].src_robot;
+        c.dev_edge[(size_t)t.j[e]] = (int32_t)e;
+        scatter(ife, NIs, e, ed.fv_eta, 4);
+        scatter(ifl, NIs, e, ed.fv_lam, 16);
+        scatter(ibm, NIs, e, ed.bmu, 4);
     }
-    std::vector<int32_t> var_ptr((size_t)R_local * K + 1, 0), var_mid((size_t)R_local * K, 0);
-    std::vector<IrEdgeRec> recs;
-    std::vector<double> ife, ifl, ibm;
-    w->edge_src_robot.clear();
-    w->edge_conn.clear();
-    w->edge_i.clear();
-    size_t NI = 0;
-    for (auto &pv : per_var) NI += pv.size();
-    const size_t NIs = std::max<size_t>(NI, 1);
-    ife.assign(4 * NIs, 0.0);
-    ifl.assign(16 * NIs, 0.0);
-    ibm.assign(4 * NIs, 0.0);
-    size_t e = 0;
-    for (size_t v = 0; v < per_var.size(); v++) {
-        var_ptr[v] = (int32_t)e;
-        auto &pv = per_var[v];
-        // inbox key order: (graph, node index) — message.rs / id.rs:19-117
-        std::sort(pv.begin(), pv.end(), [](const Ref &a, const Ref &b) { return a.key != b.key ? a.key < b.key : a.node < b.node; });
-        const uint64_t own_key = w->robots[(size_t)w->robot_of[v / (size_t)K]].order_key;
-        var_mid[v] = (int32_t)(e + pv.size());
-        for (size_t q = 0; q < pv.size(); q++)
-            if (pv[q].key > own_key) { var_mid[v] = (int32_t)(e + q); break; }
-        for (const Ref &rf : pv) {
-            const IrConn &c = w->conns[(size_t)rf.conn];
-            const Robot &ow = w->robots[(size_t)c.owner], &ot = w->robots[(size_t)c.other];
-            const IrEdge &ed = c.edges[(size_t)rf.j];
-            IrEdgeRec rec;
-            rec.src_var = w->dev_of[(size_t)c.owner] * K + rf.j + 1;
-            rec.src_robot = w->dev_of[(size_t)c.owner];
-            rec.created = ed.created;
-            rec.dst = (int32_t)(v % (size_t)K) | ((ot.order_key > ow.order_key) ? (1 << 16) : 0);
-            rec.d_safe = w->p.safety_multiplier * ow.radius;                            // interrobot.rs:64
-            rec.offset = (double)1e-6f * (double)(c.first_number + (uint64_t)rf.j);    // interrobot.rs:52,75
-            recs.push_back(rec);
-            w->edge_src_robot.push_back(rec.src_robot);
-            scatter(ife, NIs, e, ed.fv_eta, 4);
-            scatter(ifl, NIs, e, ed.fv_lam, 16);
-            scatter(ibm, NIs, e, ed.bmu, 4);
-            w->edge_conn.push_back(rf.conn);
-            w->edge_i.push_back(rf.j);
-            e++;
-        }
-    }
-    var_ptr[per_var.size()] = (int32_t)e;
-    int ir_max_edges = 0;
-    for (int dr = 0; dr < R_local; dr++)
-        ir_max_edges = std::max(ir_max_edges, (int)(var_ptr[(size_t)(dr + 1) * K] - var_ptr[(size_t)dr * K]));
+    const int ir_max_edges = t.ir_max_edges;
 
     const size_t BS = (size_t)blob_words(K);
     std::vector<double> blb(BS * (size_t)R_total, 0.0), sn(24 * V), dm(16 * ND, 0.0), tlv(NT, 0.0);
@@ -746,6 +854,7 @@ static int commit(mgx_world *w) {
     d.dbg = nullptr;
 #endif
     w->dirty = false;
+    w->conns_dirty = false;
     w->dev_valid = true;
     w->halo_dirty = true;
     return upload_flags(w);
@@ -919,17 +1028,14 @@ static int ir_connect(mgx_world *w, int32_t owner, int32_t other, uint64_t first
         c.updates_per_sweep += ++ow.slot_uses[(size_t)nd];
     }
     w->conns.push_back(std::move(c));
-    w->dirty = true;
+    w->conns_dirty = true;
     return MGX_OK;
 }
 
 static int ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
     if (!w || a < 0 || b < 0 || (size_t)a >= w->robots.size() || (size_t)b >= w->robots.size() || a == b)
         return fail(MGX_ERR_INVALID, "bad robot ids");
-    int rc = pull(w);  // keep the other connections' live state
-    if (rc != MGX_OK) return rc;
     flush_counts(w);  // the deleted factors take their counts with them (factorgraph.rs:876-890)
-    w->dev_valid = false;
     // delete_interrobot_factors_connected_to on both graphs (factorgraph.rs:380-436): the node
     // slots are vacated in ascending index order
     for (int side = 0; side < 2; side++) {
@@ -944,7 +1050,7 @@ static int ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
     w->conns.erase(std::remove_if(w->conns.begin(), w->conns.end(),
                                   [&](const IrConn &c) { return (c.owner == a && c.other == b) || (c.owner == b && c.other == a); }),
                    w->conns.end());
-    w->dirty = true;
+    w->conns_dirty = true;  // the surviving connections' state stays on the device
     return MGX_OK;
 }
 
