@@ -594,66 +594,71 @@ struct EdgeTables {
 static void build_edge_tables(const mgx_world *w, int R_local, EdgeTables &t) {
     const int K = w->K;
     const size_t NV = (size_t)R_local * K;
+    // incoming connections of every local robot.  Each connection hangs one factor on every variable
+    // 1..K-1 of its target, and the inbox order is the same for all of them: by owner key, and for
+    // two connections of one owner by node slot — a connection's K-1 slots are one block of
+    // consecutive indices (fresh, or a whole vacated block: alloc_node), so comparing the first
+    // slots orders the whole blocks.
+    std::vector<int32_t> in_ptr((size_t)R_local + 1, 0);
+    for (const IrConn &c : w->conns)
+        if (!w->robots[(size_t)c.other].ghost) in_ptr[(size_t)w->dev_of[(size_t)c.other] + 1]++;
+    for (int r = 0; r < R_local; r++) in_ptr[(size_t)r + 1] += in_ptr[(size_t)r];
+    std::vector<int32_t> in_list((size_t)in_ptr[(size_t)R_local]), fill(in_ptr.begin(), in_ptr.end() - 1);
+    for (size_t ci = 0; ci < w->conns.size(); ci++)
+        if (!w->robots[(size_t)w->conns[ci].other].ghost) in_list[(size_t)fill[(size_t)w->dev_of[(size_t)w->conns[ci].other]]++] = (int32_t)ci;
+    const size_t NI = in_list.size() * (size_t)(K - 1);
     t.var_ptr.assign(NV + 1, 0);
     t.var_mid.assign(NV, 0);
-    for (const IrConn &c : w->conns) {
-        if (w->robots[(size_t)c.other].ghost) continue;  // target lives on another rank
-        const size_t v0 = (size_t)w->dev_of[(size_t)c.other] * K;
-        for (size_t j = 0; j < c.node.size(); j++) t.var_ptr[v0 + j + 2]++;  // variable j + 1, shifted by one for the scan
-    }
-    for (size_t v = 1; v <= NV; v++) t.var_ptr[v] += t.var_ptr[v - 1];
-    const size_t NI = (size_t)t.var_ptr[NV];
     t.conn.assign(NI, 0);
     t.j.assign(NI, 0);
-    std::vector<int32_t> fill(t.var_ptr.begin(), t.var_ptr.end() - 1);
-    for (size_t ci = 0; ci < w->conns.size(); ci++) {
-        const IrConn &c = w->conns[ci];
-        if (w->robots[(size_t)c.other].ghost) continue;
-        const size_t v0 = (size_t)w->dev_of[(size_t)c.other] * K;
-        for (size_t j = 0; j < c.node.size(); j++) {
-            const int32_t e = fill[v0 + j + 1]++;
-            t.conn[(size_t)e] = (int32_t)ci;
-            t.j[(size_t)e] = (int32_t)j;
-        }
-    }
     t.recs.resize(std::max<size_t>(NI, 1));
     t.recs[0] = IrEdgeRec{0, 0, 0, 0, 0.0, 0.0};
-    for (size_t v = 0; v < NV; v++) {
-        const int32_t lo = t.var_ptr[v], hi = t.var_ptr[v + 1];
-        auto key_of = [&](int32_t e) { return w->robots[(size_t)w->conns[(size_t)t.conn[(size_t)e]].owner].order_key; };
-        auto node_of = [&](int32_t e) { return w->conns[(size_t)t.conn[(size_t)e]].node[(size_t)t.j[(size_t)e]]; };
-        for (int32_t a = lo + 1; a < hi; a++) {  // insertion sort: a handful of edges per variable
-            const int32_t ca = t.conn[(size_t)a], ja = t.j[(size_t)a];
-            const uint64_t ka = key_of(a);
-            const int na = node_of(a);
-            int32_t b = a;
-            while (b > lo && (key_of(b - 1) > ka || (key_of(b - 1) == ka && node_of(b - 1) > na))) {
-                t.conn[(size_t)b] = t.conn[(size_t)b - 1];
-                t.j[(size_t)b] = t.j[(size_t)b - 1];
-                b--;
-            }
-            t.conn[(size_t)b] = ca;
-            t.j[(size_t)b] = ja;
-        }
-        const Robot &ot = w->robots[(size_t)w->robot_of[v / (size_t)K]];
-        t.var_mid[v] = hi;
-        for (int32_t e = lo; e < hi; e++) {
-            const IrConn &c = w->conns[(size_t)t.conn[(size_t)e]];
-            const Robot &ow = w->robots[(size_t)c.owner];
-            if (t.var_mid[v] == hi && ow.order_key > ot.order_key) t.var_mid[v] = e;
-            IrEdgeRec rec;
-            rec.src_var = w->dev_of[(size_t)c.owner] * K + t.j[(size_t)e] + 1;
-            rec.src_robot = w->dev_of[(size_t)c.owner];
-            rec.created = 0;
-            rec.dst = (int32_t)(v % (size_t)K) | ((ot.order_key > ow.order_key) ? (1 << 16) : 0);
-            rec.d_safe = w->p.safety_multiplier * ow.radius;                                        // interrobot.rs:64
-            rec.offset = (double)1e-6f * (double)(c.first_number + (uint64_t)t.j[(size_t)e]);      // interrobot.rs:52,75
-            t.recs[(size_t)e] = rec;
-        }
-    }
     t.ir_max_edges = 0;
-    for (int dr = 0; dr < R_local; dr++)
-        t.ir_max_edges = std::max(t.ir_max_edges, (int)(t.var_ptr[(size_t)(dr + 1) * K] - t.var_ptr[(size_t)dr * K]));
+    size_t base = 0;
+    for (int r = 0; r < R_local; r++) {
+        int32_t *seg = in_list.data() + in_ptr[(size_t)r];
+        const int n_in = in_ptr[(size_t)r + 1] - in_ptr[(size_t)r];
+        auto before = [&](int32_t a, int32_t b) {
+            const IrConn &ca = w->conns[(size_t)a], &cb = w->conns[(size_t)b];
+            const uint64_t ka = w->robots[(size_t)ca.owner].order_key, kb = w->robots[(size_t)cb.owner].order_key;
+            return ka != kb ? ka < kb : ca.node[0] < cb.node[0];
+        };
+        for (int a = 1; a < n_in; a++) {  // insertion sort: a handful of connections per robot
+            const int32_t v = seg[a];
+            int b = a;
+            while (b > 0 && before(v, seg[b - 1])) { seg[b] = seg[b - 1]; b--; }
+            seg[b] = v;
+        }
+        const Robot &ot = w->robots[(size_t)w->robot_of[(size_t)r]];
+        int mid = n_in;  // first connection whose owner has a HIGHER key than the target
+        for (int q = n_in - 1; q >= 0; q--)
+            if (w->robots[(size_t)w->conns[(size_t)seg[q]].owner].order_key > ot.order_key) mid = q;
+        t.var_ptr[(size_t)r * K] = (int32_t)base;  // variable 0 carries no inter-robot factor
+        t.var_mid[(size_t)r * K] = (int32_t)base;
+        for (int j = 0; j < K - 1; j++) {
+            const size_t v = (size_t)r * K + 1 + (size_t)j, e0 = base + (size_t)j * (size_t)n_in;
+            t.var_ptr[v] = (int32_t)e0;
+            t.var_mid[v] = (int32_t)(e0 + (size_t)mid);
+            for (int q = 0; q < n_in; q++) {
+                const size_t e = e0 + (size_t)q;
+                const IrConn &c = w->conns[(size_t)seg[q]];
+                const Robot &ow = w->robots[(size_t)c.owner];
+                t.conn[e] = seg[q];
+                t.j[e] = j;
+                IrEdgeRec rec;
+                rec.src_var = w->dev_of[(size_t)c.owner] * K + j + 1;
+                rec.src_robot = w->dev_of[(size_t)c.owner];
+                rec.created = 0;
+                rec.dst = (int32_t)(j + 1) | ((ot.order_key > ow.order_key) ? (1 << 16) : 0);
+                rec.d_safe = w->p.safety_multiplier * ow.radius;                      // interrobot.rs:64
+                rec.offset = (double)1e-6f * (double)(c.first_number + (uint64_t)j);  // interrobot.rs:52,75
+                t.recs[e] = rec;
+            }
+        }
+        base += (size_t)n_in * (size_t)(K - 1);
+        t.ir_max_edges = std::max(t.ir_max_edges, n_in * (K - 1));
+    }
+    t.var_ptr[NV] = (int32_t)base;
 }
 
 static int upload_flags(mgx_world *w);
