@@ -89,3 +89,54 @@ def test_all_schedule_kinds_full_tick_lengths():
             for w in (eng, ref):
                 w.iterate(steps)
             assert_identical(eng, ref, what=f"schedule {kind} ({ni},{ne})")
+
+
+@pytest.mark.parametrize("K,n,seed", [(10, 14, 11), (12, 9, 12), (16, 20, 13), (21, 7, 14), (8, 10, 15)])
+def test_random_script_with_dynamic_topology(K, n, seed):
+    """The same idea with the topology systems in the mix: robots wander (positions are the caller's
+    Transform inputs), whole update_robot_neighbours / delete / create passes run between sweeps
+    (in-place edge-table rebuilds on the device), robots despawn, antennas are rewritten in bulk;
+    connection sets, robot numbers, message counts and beliefs must all match."""
+    sc = _scenario(K, n, seed)
+    sc = dict(sc, ir=[])
+    eng, ref = make_pair(sc)
+    rng = np.random.default_rng(seed)
+    pos = np.array([[rb["pos"][0], 0.5, rb["pos"][1]] for rb in sc["robots"]], dtype=np.float32)
+    alive = np.ones(n, dtype=bool)
+    nxt = {id(eng): 1, id(ref): 1}
+    tick = S.tick_inputs(sc)
+    for step in range(24):
+        op = int(rng.integers(0, 7))
+        if op <= 2:
+            pos = pos + rng.normal(0, 1.2, size=pos.shape).astype(np.float32) * np.array([1, 0, 1], dtype=np.float32)
+            radius = float(rng.choice([3.0, 4.5, 6.0]))
+            res = []
+            for w in (eng, ref):
+                out = w.update_topology(pos, radius, nxt[id(w)])
+                nxt[id(w)] = out[0]
+                res.append(out)
+            assert res[0] == res[1], (step, res)
+        elif op == 3 and alive.sum() > 3:
+            r = int(rng.choice(np.nonzero(alive)[0]))
+            alive[r] = False
+            for w in (eng, ref):
+                w.remove_robot(r)
+        elif op == 4:
+            live = np.nonzero(alive)[0].astype(np.int32)
+            on = rng.random(len(live)) > 0.3
+            for w in (eng, ref):
+                w.set_antennas(live, on)
+        elif op == 5:
+            live = np.nonzero(alive)[0]
+            args = dict(tick, robots=tick["robots"][live], waypoints_xy=tick["waypoints_xy"][live], time_scale=tick["time_scale"][live],
+                        what=tick["what"][live])
+            for w in (eng, ref):
+                w.update_priors(**args)
+        steps = [int(x) for x in rng.integers(1, 4, size=int(rng.integers(1, 5)))]
+        for w in (eng, ref):
+            w.iterate(steps)
+        if step % 6 == 5:
+            assert [eng.connections(r) for r in range(n)] == [ref.connections(r) for r in range(n)]
+            assert [eng.message_counts(r) for r in range(n)] == [ref.message_counts(r) for r in range(n)], step
+            assert_identical(eng, ref, what=f"dynamic K={K} n={n} seed={seed} step {step}")
+    assert_identical(eng, ref, what=f"dynamic K={K} n={n} seed={seed} final")
