@@ -552,18 +552,21 @@ __device__ void apply_change_prior(const DevWorld &w, int r, int i, const double
     const BlobLayout L(K);
     double *b = w.blob + (size_t)r * w.BS;
     const int v = r * K + i;
+    // every load first (one round trip), then the stores: the thread is latency-bound
     double pl[16], be[4], bl[16];
 #pragma unroll
     for (int c = 0; c < 16; c++) pl[c] = b[L.prior() + (4 + c) * K + i];
+#pragma unroll
+    for (int c = 0; c < 4; c++) be[c] = b[L.bel() + c * K + i];
+#pragma unroll
+    for (int c = 0; c < 16; c++) bl[c] = b[L.bel() + (4 + c) * K + i];
+    const uint32_t epoch = w.snap_epoch[w.cur][v];
+    const int e0 = w.ir_var_ptr[v], e1 = w.ir_var_ptr[v + 1];
 #pragma unroll
     for (int a = 0; a < 4; a++)  // prior eta = prior lam . mean (:204)
         b[L.prior() + a * K + i] = ((pl[a * 4 + 0] * m[0] + pl[a * 4 + 1] * m[1]) + pl[a * 4 + 2] * m[2]) + pl[a * 4 + 3] * m[3];
 #pragma unroll
     for (int c = 0; c < 4; c++) b[L.mu() + c * K + i] = m[c];  // :206
-#pragma unroll
-    for (int c = 0; c < 4; c++) be[c] = b[L.bel() + c * K + i];
-#pragma unroll
-    for (int c = 0; c < 16; c++) bl[c] = b[L.bel() + (4 + c) * K + i];
     // the (stale eta, stale lam, new mean) belief goes to every connected factor (:210-221):
     //   own-graph factors read it from the snapshot record ...
     double *rec = w.snap[w.cur] + (size_t)v * SNAP_W;
@@ -573,10 +576,10 @@ __device__ void apply_change_prior(const DevWorld &w, int r, int i, const double
     for (int c = 0; c < 16; c++) rec[4 + c] = bl[c];
 #pragma unroll
     for (int c = 0; c < 4; c++) rec[20 + c] = m[c];
-    w.snap_epoch[w.cur][v] += 1;
+    w.snap_epoch[w.cur][v] = epoch + 1;
     //   ... and foreign inter-robot factors attached to this variable get it in their inbox;
     // every inbox message of the variable becomes empty (:224-227)
-    for (int e = w.ir_var_ptr[v]; e < w.ir_var_ptr[v + 1]; e++) {
+    for (int e = e0; e < e1; e++) {
         if (w.enable & 2u) st_soa4(w.ir_bmu, w.NI, e, m);
         w.ir_fv_eta[0 * (size_t)w.NI + e] = 0.0;  // the compact form of the empty message
         w.ir_fv_eta[1 * (size_t)w.NI + e] = 0.0;
