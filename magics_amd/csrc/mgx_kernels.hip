@@ -85,6 +85,19 @@ constexpr int IR_STRIDE = 7;  // one staged inter-robot message: 6 f64 + 1 pad (
 // variable sweep (a robot with too many edges for LDS), or they are staged in LDS.
 enum { IR_NONE = 0, IR_GLOBAL = 1, IR_STAGED = 2 };
 
+// Workgroups are handed to the eight XCDs round-robin by workgroup id, and each XCD has its own L2.
+// Robots are numbered along the grid, so inter-robot neighbours have nearby ids: giving XCD k the
+// k-th CONTIGUOUS eighth of the robots (instead of every eighth robot) lets the snapshot records that
+// several neighbours gather be fetched into that XCD's L2 once.  Bijection of [0, n) for any n.
+constexpr int N_XCD = 8;
+__device__ __forceinline__ int xcd_local_index(int block, int n) {
+    const int xcd = block % N_XCD, idx = block / N_XCD;
+    // workgroups with id = k (mod 8): ceil((n - k) / 8) of them; robots of XCD k start after those of 0..k-1
+    int start = 0;
+    for (int k = 0; k < xcd; k++) start += (n - k + N_XCD - 1) / N_XCD;
+    return start + idx;
+}
+
 // straight copies between a robot's blob in HBM and its LDS image, 16 bytes per lane
 __device__ __forceinline__ void copy_words(double *dst, const double *src, int n, int tid) {
     const double2 *s2 = reinterpret_cast<const double2 *>(src);
@@ -98,7 +111,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                                                              int n_int, int snap_out, uint32_t hints) {
     constexpr bool HAS_IR = IRM != IR_NONE, STAGE_IR = IRM == IR_STAGED;
     STAMP(t_k0);
-    const int r = robot0 + blockIdx.x;
+    const int r = robot0 + xcd_local_index(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x;
     const int role = tid >> 6, lane = tid & 63;
     const int K = KT > 0 ? KT : w.K, E = 4 * K - 6, E1 = E + 1;
