@@ -590,6 +590,7 @@ struct EdgeTables {
     std::vector<int32_t> var_ptr, var_mid, conn, j;
     std::vector<IrEdgeRec> recs;
     int ir_max_edges = 0;
+    bool blocks_ok = true;  // node slots of two connections of one owner never interleave (see below)
 };
 static void build_edge_tables(const mgx_world *w, int R_local, EdgeTables &t) {
     const int K = w->K;
@@ -621,7 +622,9 @@ static void build_edge_tables(const mgx_world *w, int R_local, EdgeTables &t) {
         auto before = [&](int32_t a, int32_t b) {
             const IrConn &ca = w->conns[(size_t)a], &cb = w->conns[(size_t)b];
             const uint64_t ka = w->robots[(size_t)ca.owner].order_key, kb = w->robots[(size_t)cb.owner].order_key;
-            return ka != kb ? ka < kb : ca.node[0] < cb.node[0];
+            if (ka != kb) return ka < kb;
+            if ((ca.node[0] < cb.node[0]) != (ca.node.back() < cb.node.back())) t.blocks_ok = false;
+            return ca.node[0] < cb.node[0];
         };
         for (int a = 1; a < n_in; a++) {  // insertion sort: a handful of connections per robot
             const int32_t v = seg[a];
@@ -672,6 +675,7 @@ static int retopo(mgx_world *w) {
     const int K = w->K, R_local = w->d.R_local;
     EdgeTables t;
     build_edge_tables(w, R_local, t);
+    if (!t.blocks_ok) return fail(MGX_ERR_STATE, "internal: node slots of two connections interleave");
     const size_t NI = (size_t)t.var_ptr.back(), NIs = std::max<size_t>(NI, 1), NI_old = (size_t)w->d.NI;
     std::vector<int32_t> map(2 * NIs, -1);  // old index of every new edge | its target variable
     for (size_t v = 0; v + 1 < t.var_ptr.size(); v++)
@@ -752,6 +756,7 @@ static int commit(mgx_world *w) {
 
     EdgeTables t;
     build_edge_tables(w, R_local, t);
+    if (!t.blocks_ok) return fail(MGX_ERR_STATE, "internal: node slots of two connections interleave");
     std::vector<int32_t> &var_ptr = t.var_ptr, &var_mid = t.var_mid;
     std::vector<IrEdgeRec> &recs = t.recs;
     const size_t NI = (size_t)var_ptr.back(), NIs = std::max<size_t>(NI, 1);
