@@ -223,3 +223,28 @@ def test_robot_removal_between_ticks():
     assert all(eng.connections(r) == [] for r in (0, 3, 7, 11))
     with pytest.raises(RuntimeError, match="removed"):
         eng.set_idle(3, False)
+
+
+def test_full_size_world_with_jittering_positions():
+    """1000 robots x 16 (BASELINE configs[2] size): topology passes that create and delete dozens of
+    connections per tick through the in-place edge-table rebuild, hash-grid search included."""
+    sc = S.grid_scenario(1000, 16, interrobot=True, comm_radius=8.0)
+    sc["ir"] = []
+    eng, ref = make_pair(sc)
+    ref._L.orc_set_threads(ref._w, 8)
+    rng = np.random.default_rng(21)
+    base = np.array([[rb["pos"][0], 0.5, rb["pos"][1]] for rb in sc["robots"]], dtype=np.float32)
+    nxt_e = nxt_r = 1
+    changed = 0
+    for tick in range(4):
+        pos = base + rng.normal(0, 0.15, size=base.shape).astype(np.float32)
+        oe = eng.update_topology(pos, 8.0, nxt_e)
+        orf = ref.update_topology(pos, 8.0, nxt_r)
+        assert oe == orf, (tick, oe, orf)
+        nxt_e, nxt_r = oe[0], orf[0]
+        changed += oe[1] + oe[2]
+        for w in (eng, ref):
+            w.iterate(sc["steps"])
+    assert changed > 7000 + 100          # the initial pass plus real churn afterwards
+    assert all(eng.connections(r) == ref.connections(r) for r in range(0, 1000, 37))
+    assert_identical(eng, ref, what="1000 robots, jittering positions, 4 ticks")
