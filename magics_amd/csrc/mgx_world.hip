@@ -17,6 +17,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/mgx.h"
@@ -1064,6 +1065,43 @@ static int ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
     return MGX_OK;
 }
 
+// Several (a, b) deletions in one sweep over the connections (a topology pass deletes dozens):
+// same effect as ir_disconnect(a, b) for each pair in order.
+static void ir_disconnect_batch(mgx_world *w, const std::vector<std::pair<int, int>> &pairs) {
+    if (pairs.empty()) return;
+    flush_counts(w);
+    const size_t n = w->robots.size();
+    std::vector<int32_t> out_ptr(n + 1, 0);  // connections by owner
+    for (const IrConn &c : w->conns) out_ptr[(size_t)c.owner + 1]++;
+    for (size_t r = 0; r < n; r++) out_ptr[r + 1] += out_ptr[r];
+    std::vector<int32_t> out(w->conns.size()), fill(out_ptr.begin(), out_ptr.end() - 1);
+    for (size_t ci = 0; ci < w->conns.size(); ci++) out[(size_t)fill[(size_t)w->conns[ci].owner]++] = (int32_t)ci;
+    std::vector<uint8_t> dead(w->conns.size(), 0);
+    for (const auto &pr : pairs)
+        for (int side = 0; side < 2; side++) {
+            const int self = side ? pr.second : pr.first, other = side ? pr.first : pr.second;
+            std::vector<int> gone;  // node slots are vacated in ascending index order (factorgraph.rs:380-436)
+            for (int32_t q = out_ptr[(size_t)self]; q < out_ptr[(size_t)self + 1]; q++) {
+                const int32_t ci = out[(size_t)q];
+                const IrConn &c = w->conns[(size_t)ci];
+                if (dead[(size_t)ci] || c.other != other) continue;
+                dead[(size_t)ci] = 1;
+                gone.insert(gone.end(), c.node.begin(), c.node.end());
+            }
+            std::sort(gone.begin(), gone.end());
+            std::vector<int> &fr = w->robots[(size_t)self].free_nodes;
+            fr.insert(fr.end(), gone.begin(), gone.end());
+        }
+    size_t k = 0;
+    for (size_t ci = 0; ci < w->conns.size(); ci++)
+        if (!dead[ci]) {
+            if (k != ci) w->conns[k] = std::move(w->conns[ci]);
+            k++;
+        }
+    w->conns.resize(k);
+    w->conns_dirty = true;
+}
+
 // Entity despawn (robot.rs:2172 + despawn_entity_after): the graph leaves every Bevy query, so it
 // is never iterated again and whatever is addressed to it is dropped (robot.rs:1815,1844: the
 // `query.get_mut` fails) — the same dataflow as idle with the antenna off, for good.  The other
@@ -1253,12 +1291,13 @@ int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, 
             else victim[(size_t)r] = o;
         cw.swap(keep);
     }
-    for (int r = 0; r < n; r++)
-        if (victim[(size_t)r] >= 0) {
-            rc = ir_disconnect(w, r, victim[(size_t)r]);
-            if (rc != MGX_OK) return rc;
-            deleted++;
-        }
+    {
+        std::vector<std::pair<int, int>> pairs;
+        for (int r = 0; r < n; r++)
+            if (victim[(size_t)r] >= 0) pairs.emplace_back(r, victim[(size_t)r]);
+        ir_disconnect_batch(w, pairs);
+        deleted = (uint32_t)pairs.size();
+    }
 
     // create_interrobot_factors (robot.rs:1441-1586): new = within range \ connected, ascending,
     // snapshotted for every robot first (:1449-1461); K-1 robot numbers per connection (:1527)
