@@ -48,6 +48,17 @@ struct IrEdgeRec {
     double offset;      // tiny offset 1e-6f * robot_number (interrobot.rs:52,75)
 };
 
+// One incoming connection of a local robot (K-1 factors, one per variable 1..K-1): what the device
+// needs to lay out that robot's edges when the topology changes (k_edge_rebuild).
+struct IrSlotRec {
+    int32_t tgt_robot;      // local device index of the target robot
+    int32_t src_robot;      // device index of the owner
+    int32_t old_slot;       // slot of this connection in the tables being replaced, -1 = created now
+    int32_t flags;          // bit 0: the target has the higher order key (slot order of the factor)
+    double d_safe;          // interrobot.rs:64
+    uint64_t first_number;  // robot_number of the factor on variable 1 (robot.rs:1527)
+};
+
 struct DevWorld {
     int R_local, R_total, K, E;
     int V, EI, ND, NT, NI;

@@ -757,19 +757,35 @@ __global__ void k_gather_variable_means(DevWorld w, int var, double *__restrict_
     out[t] = w.blob[(size_t)r * w.BS + L.mu() + c * w.K + var];
 }
 
-// In-place topology change: build the new inter-robot edge arrays from the old ones.  old_of_new[e]
-// is the old index of new edge e (-1: created now), old_of_new[stride_new + e] its target variable.
-// A surviving edge keeps its message (the six live numbers), response mean and creation epoch; a
-// new one starts empty, created at the owner variable's current delivery count, with the target
-// variable's current belief mean as the response it has seen (robot.rs:1549-1585).
-__global__ void k_edge_rebuild(DevWorld w, int n_new, int stride_new, int stride_old, const int32_t *__restrict__ old_of_new,
-                               IrEdgeRec *__restrict__ recs, double *__restrict__ fv_eta, double *__restrict__ fv_lam,
-                               double *__restrict__ bmu) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_new) return;
-    const int o = old_of_new[e];
-    const size_t sn = (size_t)stride_new, so = (size_t)stride_old;
-    if (o >= 0) {
+// In-place topology change.  A robot's incoming connections are kept as one sorted list of SLOTS;
+// every connection hangs one factor on each of the target's variables 1..K-1, so the edges of
+// variable i of robot r are  (K-1) * in_ptr[r] + (i-1) * n_in(r) + q,  q = position in the list.
+// k_edge_rebuild lays out the new edge arrays from the new slot list (one thread per factor):
+// a surviving connection (old_slot >= 0) carries its message (the six live numbers), response mean
+// and creation epoch over from the arrays being replaced; a new one starts empty, created at the
+// owner variable's current delivery count, with the target variable's current belief mean as the
+// response it has seen (robot.rs:1549-1585).  The constant record of every edge is derived here too.
+__global__ void k_edge_rebuild(DevWorld w, int n_slots, const IrSlotRec *__restrict__ slots, const int32_t *__restrict__ in_new,
+                               const int32_t *__restrict__ in_old, int stride_new, IrEdgeRec *__restrict__ recs,
+                               double *__restrict__ fv_eta, double *__restrict__ fv_lam, double *__restrict__ bmu) {
+    const int K1 = w.K - 1;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_slots * K1) return;
+    const int g = t / K1, j = t - g * K1;
+    const IrSlotRec sl = slots[g];
+    const int r = sl.tgt_robot;
+    const int n_in = in_new[r + 1] - in_new[r];
+    const int e = K1 * in_new[r] + j * n_in + (g - in_new[r]);
+    const size_t sn = (size_t)stride_new, so = (size_t)w.NI;
+    IrEdgeRec rec;
+    rec.src_var = sl.src_robot * w.K + j + 1;
+    rec.src_robot = sl.src_robot;
+    rec.dst = (int32_t)(j + 1) | ((sl.flags & 1) ? (1 << 16) : 0);
+    rec.d_safe = sl.d_safe;
+    rec.offset = (double)1e-6f * (double)(sl.first_number + (unsigned long long)j);  // interrobot.rs:52,75
+    if (sl.old_slot >= 0) {
+        const int n_old = in_old[r + 1] - in_old[r];
+        const int o = K1 * in_old[r] + j * n_old + (sl.old_slot - in_old[r]);
         fv_eta[0 * sn + e] = w.ir_fv_eta[0 * so + o];
         fv_eta[1 * sn + e] = w.ir_fv_eta[1 * so + o];
         fv_lam[0 * sn + e] = w.ir_fv_lam[0 * so + o];
@@ -778,7 +794,7 @@ __global__ void k_edge_rebuild(DevWorld w, int n_new, int stride_new, int stride
         fv_lam[5 * sn + e] = w.ir_fv_lam[5 * so + o];
 #pragma unroll
         for (int c = 0; c < 4; c++) bmu[c * sn + e] = w.ir_bmu[c * so + o];
-        recs[e].created = w.ir_rec[o].created;
+        rec.created = w.ir_rec[o].created;
     } else {
         fv_eta[0 * sn + e] = 0.0;
         fv_eta[1 * sn + e] = 0.0;
@@ -786,12 +802,32 @@ __global__ void k_edge_rebuild(DevWorld w, int n_new, int stride_new, int stride
         fv_lam[1 * sn + e] = 0.0;
         fv_lam[4 * sn + e] = 0.0;
         fv_lam[5 * sn + e] = 0.0;
-        const int v = old_of_new[stride_new + e], r = v / w.K, i = v - r * w.K;
         const BlobLayout L(w.K);
 #pragma unroll
-        for (int c = 0; c < 4; c++) bmu[c * sn + e] = w.blob[(size_t)r * w.BS + L.mu() + c * w.K + i];
-        recs[e].created = w.snap_epoch[w.cur][recs[e].src_var];
+        for (int c = 0; c < 4; c++) bmu[c * sn + e] = w.blob[(size_t)r * w.BS + L.mu() + c * w.K + (j + 1)];
+        rec.created = w.snap_epoch[w.cur][rec.src_var];
     }
+    recs[e] = rec;
+}
+// CSR over variables (and the lower-key / higher-key split) from the per-robot slot lists
+__global__ void k_var_tables(int R, int K, const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_mid,
+                             int32_t *__restrict__ var_ptr, int32_t *__restrict__ var_mid) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > R * K) return;
+    if (t == R * K) { var_ptr[t] = (K - 1) * in_ptr[R]; return; }
+    const int r = t / K, i = t - r * K;
+    const int n_in = in_ptr[r + 1] - in_ptr[r], base = (K - 1) * in_ptr[r];
+    const int p = (i == 0) ? base : base + (i - 1) * n_in;  // variable 0 carries no inter-robot factor
+    var_ptr[t] = p;
+    var_mid[t] = (i == 0) ? p : p + in_mid[r];
+}
+// gate byte of every edge: its OWNER is on air (antenna on, not idle)
+__global__ void k_edge_gates(int n, const IrEdgeRec *__restrict__ recs, const uint8_t *__restrict__ antenna,
+                             const uint8_t *__restrict__ idle, uint8_t *__restrict__ gate) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int a = recs[e].src_robot;
+    gate[e] = (antenna[a] && !idle[a]) ? 1 : 0;
 }
 
 // small byte copy (flag tables from the pinned argument ring into their device arrays)
@@ -873,11 +909,22 @@ hipError_t launch_gather_variable_means(const DevWorld &w, int var, double *out,
     hipLaunchKernelGGL(k_gather_variable_means, dim3((unsigned)((w.R_local * 4 + 255) / 256)), dim3(256), 0, stream, w, var, out);
     return hipGetLastError();
 }
-hipError_t launch_edge_rebuild(const DevWorld &w, int n_new, int stride_new, int stride_old, const int32_t *old_of_new, IrEdgeRec *recs,
-                               double *fv_eta, double *fv_lam, double *bmu, hipStream_t stream) {
-    if (n_new <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_edge_rebuild, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, stream, w, n_new, stride_new, stride_old,
-                       old_of_new, recs, fv_eta, fv_lam, bmu);
+hipError_t launch_edge_rebuild(const DevWorld &w, int n_slots, const IrSlotRec *slots, const int32_t *in_new, const int32_t *in_old,
+                               int stride_new, IrEdgeRec *recs, double *fv_eta, double *fv_lam, double *bmu, hipStream_t stream) {
+    const int total = n_slots * (w.K - 1);
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_edge_rebuild, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, n_slots, slots, in_new, in_old,
+                       stride_new, recs, fv_eta, fv_lam, bmu);
+    return hipGetLastError();
+}
+hipError_t launch_var_tables(int R, int K, const int32_t *in_ptr, const int32_t *in_mid, int32_t *var_ptr, int32_t *var_mid,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(k_var_tables, dim3((unsigned)((R * K + 1 + 255) / 256)), dim3(256), 0, stream, R, K, in_ptr, in_mid, var_ptr, var_mid);
+    return hipGetLastError();
+}
+hipError_t launch_edge_gates(int n, const IrEdgeRec *recs, const uint8_t *antenna, const uint8_t *idle, uint8_t *gate, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_edge_gates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, recs, antenna, idle, gate);
     return hipGetLastError();
 }
 hipError_t launch_copy_bytes(uint8_t *dst, const uint8_t *src, size_t n, hipStream_t stream) {

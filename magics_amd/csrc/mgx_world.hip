@@ -38,8 +38,11 @@ hipError_t launch_halo_pack(const DevWorld &w, int n, const int32_t *robots, dou
 hipError_t launch_halo_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *buf, hipStream_t stream);
 hipError_t launch_copy_bytes(uint8_t *dst, const uint8_t *src, size_t n, hipStream_t stream);
 hipError_t launch_gather_variable_means(const DevWorld &w, int var, double *out, hipStream_t stream);
-hipError_t launch_edge_rebuild(const DevWorld &w, int n_new, int stride_new, int stride_old, const int32_t *old_of_new, IrEdgeRec *recs,
-                               double *fv_eta, double *fv_lam, double *bmu, hipStream_t stream);
+hipError_t launch_edge_rebuild(const DevWorld &w, int n_slots, const IrSlotRec *slots, const int32_t *in_new, const int32_t *in_old,
+                               int stride_new, IrEdgeRec *recs, double *fv_eta, double *fv_lam, double *bmu, hipStream_t stream);
+hipError_t launch_var_tables(int R, int K, const int32_t *in_ptr, const int32_t *in_mid, int32_t *var_ptr, int32_t *var_mid,
+                             hipStream_t stream);
+hipError_t launch_edge_gates(int n, const IrEdgeRec *recs, const uint8_t *antenna, const uint8_t *idle, uint8_t *gate, hipStream_t stream);
 hipError_t launch_halo_push(const DevWorld &w, int n, const int32_t *robots, const unsigned long long *dst, int n_peers,
                             const unsigned long long *peer_flags, unsigned long long seq, unsigned int *done, hipStream_t stream);
 hipError_t launch_halo_wait_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *recv, int n_sources,
@@ -219,7 +222,7 @@ struct IrConn {  // K-1 factors owner -> other
     // re-used slot is updated once per occurrence in every external sweep — same message, but every
     // update counts as sent / received.
     uint64_t updates_per_sweep = 0;
-    std::vector<int32_t> dev_edge;  // device edge index of each factor in the current tables (-1: not there)
+    int32_t dev_slot = -1;  // slot of this connection in its target's incoming list on the device (-1: not there)
 };
 
 }  // namespace
@@ -246,8 +249,9 @@ struct mgx_world {
     DevBuf<IrEdgeRec> ir_rec;
     DevBuf<double> ir_fv_eta_b, ir_fv_lam_b, ir_bmu_b;  // second set: the edge tables are rebuilt out of place
     DevBuf<IrEdgeRec> ir_rec_b;
-    DevBuf<int32_t> ir_map;  // scratch: old edge index of each new edge
-    std::vector<int32_t> edge_src_robot;  // device robot index of each edge's owner (for the gates)
+    DevBuf<int32_t> in_ptr_dev, in_ptr_dev_b, in_mid_dev;  // per-robot slot ranges (current / being built), split index
+    DevBuf<IrSlotRec> slot_recs;
+    std::vector<int32_t> dev_in_ptr;  // [R_local + 1] incoming-slot ranges of the tables now on the device
     DevBuf<int32_t> trk_record, path_ptr, iter_factor, ir_var_ptr, ir_var_mid;
     DevBuf<uint32_t> epoch0, epoch1;
     DevBuf<float> trk_last_pos, path_xy;
@@ -281,6 +285,8 @@ struct mgx_world {
     DevBuf<float> nb_pos;
     DevBuf<int32_t> nb_cnt, nb_bucket_cnt, nb_bucket_ptr, nb_cursor, nb_members, nb_special, nb_nspecial, nb_ptr, nb_idx;
 };
+
+static size_t edge_index(const std::vector<int32_t> &in_ptr, int K, int r, int j, int slot);
 
 static bool device_ok() {
     static int state = 0;  // 0 unknown, 1 ok, -1 none
@@ -428,9 +434,9 @@ static int pull(mgx_world *w) {
         rb.iter_factor = itf[dr];
     }
     for (IrConn &c : w->conns)
-        for (size_t j = 0; j < c.dev_edge.size(); j++) {
-            if (c.dev_edge[j] < 0) continue;  // created since the tables were built: nothing on the device yet
-            const size_t e = (size_t)c.dev_edge[j];
+        for (size_t j = 0; j < c.edges.size(); j++) {
+            if (c.dev_slot < 0) continue;  // created since the tables were built: nothing on the device yet
+            const size_t e = edge_index(w->dev_in_ptr, w->K, w->dev_of[(size_t)c.other], (int)j, c.dev_slot);
             IrEdge &ed = c.edges[j];
             gather(ife, NI, e, ed.fv_eta, 4);
             gather(ifl, NI, e, ed.fv_lam, 16);
@@ -550,21 +556,17 @@ static void log_change_prior(mgx_world *w, int robot, int var) {
 
 // ---- commit: host mirror -> device arrays ---------------------------------------------------------
 static int upload_flags(mgx_world *w) {
-    // antenna[R] | idle[R] | gate[NI], staged in one pinned block and moved by a copy kernel: no
-    // blocking copy, no synchronisation (update_failed_comms rewrites every antenna each tick)
-    const size_t R = w->robot_of.size(), NE = std::max<size_t>(w->edge_src_robot.size(), 1);
+    // antenna[R] | idle[R] staged in one pinned block and moved by a copy kernel, the edge gates
+    // derived from them on the device: no blocking copy, no synchronisation (update_failed_comms
+    // rewrites every antenna each tick)
+    const size_t R = w->robot_of.size(), NE = (size_t)std::max(w->d.NI, 1);
     void *hp = nullptr;
     int slot = 0;
-    HIP_TRY(w->stage.acquire(2 * R + NE, &hp, &slot));
-    uint8_t *an = (uint8_t *)hp, *id = an + R, *gate = id + R;
+    HIP_TRY(w->stage.acquire(2 * R, &hp, &slot));
+    uint8_t *an = (uint8_t *)hp, *id = an + R;
     for (size_t dr = 0; dr < R; dr++) {
         an[dr] = w->robots[(size_t)w->robot_of[dr]].antenna;
         id[dr] = w->robots[(size_t)w->robot_of[dr]].idle;
-    }
-    gate[0] = 0;
-    for (size_t e = 0; e < w->edge_src_robot.size(); e++) {
-        const size_t a = (size_t)w->edge_src_robot[e];
-        gate[e] = (an[a] && !id[a]) ? 1 : 0;
     }
     HIP_TRY(w->antenna.reserve(R));
     HIP_TRY(w->idle.reserve(R));
@@ -574,8 +576,11 @@ static int upload_flags(mgx_world *w) {
     const uint8_t *src = (const uint8_t *)dp;
     HIP_TRY(launch_copy_bytes(w->antenna.p, src, R, w->stream));
     HIP_TRY(launch_copy_bytes(w->idle.p, src + R, R, w->stream));
-    HIP_TRY(launch_copy_bytes(w->ir_gate.p, src + 2 * R, NE, w->stream));
     HIP_TRY(w->stage.release(slot, w->stream));
+    // edge gates: the owner of the edge is on air
+    const int n_edges = w->dev_in_ptr.empty() ? 0 : w->dev_in_ptr.back() * (w->K - 1);
+    if (n_edges == 0) HIP_TRY(hipMemsetAsync(w->ir_gate.p, 0, NE, w->stream));
+    HIP_TRY(launch_edge_gates(n_edges, w->ir_rec.p, w->antenna.p, w->idle.p, w->ir_gate.p, w->stream));
     w->d.antenna = w->antenna.p;
     w->d.idle = w->idle.p;
     w->d.ir_gate = w->ir_gate.p;
@@ -583,43 +588,37 @@ static int upload_flags(mgx_world *w) {
     return MGX_OK;
 }
 
-// Inter-robot edges grouped by LOCAL target variable in inbox key order (graph key, node index —
-// message.rs / id.rs:19-117): CSR over variables, the split between lower-key and higher-key owners,
-// and the constant record of every edge (`created` is filled by the caller).  Flat counting sort:
-// this runs on every topology change.
-struct EdgeTables {
-    std::vector<int32_t> var_ptr, var_mid, conn, j;
-    std::vector<IrEdgeRec> recs;
+// Incoming inter-robot connections of every local robot in inbox key order (graph key, node index
+// — message.rs / id.rs:19-117), and the split between lower-key and higher-key owners.  Each
+// connection hangs one factor on every variable 1..K-1 of its target, and the order is the same for
+// all of them: by owner key, and for two connections of one owner by node slot — a connection's K-1
+// slots are one block of consecutive indices (fresh, or a whole vacated block: alloc_node), so
+// comparing the first slots orders the whole blocks.  Edge (variable i, list position q) of robot r
+// lives at  (K-1) * in_ptr[r] + (i-1) * n_in(r) + q.
+struct Incoming {
+    std::vector<int32_t> in_ptr, in_list, mid;
     int ir_max_edges = 0;
-    bool blocks_ok = true;  // node slots of two connections of one owner never interleave (see below)
+    bool blocks_ok = true;
 };
-static void build_edge_tables(const mgx_world *w, int R_local, EdgeTables &t) {
+static size_t edge_index(const std::vector<int32_t> &in_ptr, int K, int r, int j, int slot) {
+    const int n_in = in_ptr[(size_t)r + 1] - in_ptr[(size_t)r];
+    return (size_t)(K - 1) * (size_t)in_ptr[(size_t)r] + (size_t)j * (size_t)n_in + (size_t)(slot - in_ptr[(size_t)r]);
+}
+static void build_incoming(const mgx_world *w, int R_local, Incoming &t) {
     const int K = w->K;
-    const size_t NV = (size_t)R_local * K;
-    // incoming connections of every local robot.  Each connection hangs one factor on every variable
-    // 1..K-1 of its target, and the inbox order is the same for all of them: by owner key, and for
-    // two connections of one owner by node slot — a connection's K-1 slots are one block of
-    // consecutive indices (fresh, or a whole vacated block: alloc_node), so comparing the first
-    // slots orders the whole blocks.
-    std::vector<int32_t> in_ptr((size_t)R_local + 1, 0);
+    t.in_ptr.assign((size_t)R_local + 1, 0);
+    t.mid.assign((size_t)std::max(R_local, 1), 0);
     for (const IrConn &c : w->conns)
-        if (!w->robots[(size_t)c.other].ghost) in_ptr[(size_t)w->dev_of[(size_t)c.other] + 1]++;
-    for (int r = 0; r < R_local; r++) in_ptr[(size_t)r + 1] += in_ptr[(size_t)r];
-    std::vector<int32_t> in_list((size_t)in_ptr[(size_t)R_local]), fill(in_ptr.begin(), in_ptr.end() - 1);
+        if (!w->robots[(size_t)c.other].ghost) t.in_ptr[(size_t)w->dev_of[(size_t)c.other] + 1]++;  // ghost target: another rank's
+    for (int r = 0; r < R_local; r++) t.in_ptr[(size_t)r + 1] += t.in_ptr[(size_t)r];
+    t.in_list.assign((size_t)t.in_ptr[(size_t)R_local], 0);
+    std::vector<int32_t> fill(t.in_ptr.begin(), t.in_ptr.end() - 1);
     for (size_t ci = 0; ci < w->conns.size(); ci++)
-        if (!w->robots[(size_t)w->conns[ci].other].ghost) in_list[(size_t)fill[(size_t)w->dev_of[(size_t)w->conns[ci].other]]++] = (int32_t)ci;
-    const size_t NI = in_list.size() * (size_t)(K - 1);
-    t.var_ptr.assign(NV + 1, 0);
-    t.var_mid.assign(NV, 0);
-    t.conn.assign(NI, 0);
-    t.j.assign(NI, 0);
-    t.recs.resize(std::max<size_t>(NI, 1));
-    t.recs[0] = IrEdgeRec{0, 0, 0, 0, 0.0, 0.0};
+        if (!w->robots[(size_t)w->conns[ci].other].ghost) t.in_list[(size_t)fill[(size_t)w->dev_of[(size_t)w->conns[ci].other]]++] = (int32_t)ci;
     t.ir_max_edges = 0;
-    size_t base = 0;
     for (int r = 0; r < R_local; r++) {
-        int32_t *seg = in_list.data() + in_ptr[(size_t)r];
-        const int n_in = in_ptr[(size_t)r + 1] - in_ptr[(size_t)r];
+        int32_t *seg = t.in_list.data() + t.in_ptr[(size_t)r];
+        const int n_in = t.in_ptr[(size_t)r + 1] - t.in_ptr[(size_t)r];
         auto before = [&](int32_t a, int32_t b) {
             const IrConn &ca = w->conns[(size_t)a], &cb = w->conns[(size_t)b];
             const uint64_t ka = w->robots[(size_t)ca.owner].order_key, kb = w->robots[(size_t)cb.owner].order_key;
@@ -633,36 +632,25 @@ static void build_edge_tables(const mgx_world *w, int R_local, EdgeTables &t) {
             while (b > 0 && before(v, seg[b - 1])) { seg[b] = seg[b - 1]; b--; }
             seg[b] = v;
         }
-        const Robot &ot = w->robots[(size_t)w->robot_of[(size_t)r]];
+        const uint64_t own_key = w->robots[(size_t)w->robot_of[(size_t)r]].order_key;
         int mid = n_in;  // first connection whose owner has a HIGHER key than the target
         for (int q = n_in - 1; q >= 0; q--)
-            if (w->robots[(size_t)w->conns[(size_t)seg[q]].owner].order_key > ot.order_key) mid = q;
-        t.var_ptr[(size_t)r * K] = (int32_t)base;  // variable 0 carries no inter-robot factor
-        t.var_mid[(size_t)r * K] = (int32_t)base;
-        for (int j = 0; j < K - 1; j++) {
-            const size_t v = (size_t)r * K + 1 + (size_t)j, e0 = base + (size_t)j * (size_t)n_in;
-            t.var_ptr[v] = (int32_t)e0;
-            t.var_mid[v] = (int32_t)(e0 + (size_t)mid);
-            for (int q = 0; q < n_in; q++) {
-                const size_t e = e0 + (size_t)q;
-                const IrConn &c = w->conns[(size_t)seg[q]];
-                const Robot &ow = w->robots[(size_t)c.owner];
-                t.conn[e] = seg[q];
-                t.j[e] = j;
-                IrEdgeRec rec;
-                rec.src_var = w->dev_of[(size_t)c.owner] * K + j + 1;
-                rec.src_robot = w->dev_of[(size_t)c.owner];
-                rec.created = 0;
-                rec.dst = (int32_t)(j + 1) | ((ot.order_key > ow.order_key) ? (1 << 16) : 0);
-                rec.d_safe = w->p.safety_multiplier * ow.radius;                      // interrobot.rs:64
-                rec.offset = (double)1e-6f * (double)(c.first_number + (uint64_t)j);  // interrobot.rs:52,75
-                t.recs[e] = rec;
-            }
-        }
-        base += (size_t)n_in * (size_t)(K - 1);
+            if (w->robots[(size_t)w->conns[(size_t)seg[q]].owner].order_key > own_key) mid = q;
+        t.mid[(size_t)r] = mid;
         t.ir_max_edges = std::max(t.ir_max_edges, n_in * (K - 1));
     }
-    t.var_ptr[NV] = (int32_t)base;
+}
+// the constant record of edge (connection c, variable j + 1); `created` is the caller's
+static IrEdgeRec edge_record(const mgx_world *w, const IrConn &c, int j) {
+    const Robot &ow = w->robots[(size_t)c.owner], &ot = w->robots[(size_t)c.other];
+    IrEdgeRec rec;
+    rec.src_var = w->dev_of[(size_t)c.owner] * w->K + j + 1;
+    rec.src_robot = w->dev_of[(size_t)c.owner];
+    rec.created = 0;
+    rec.dst = (int32_t)(j + 1) | ((ot.order_key > ow.order_key) ? (1 << 16) : 0);
+    rec.d_safe = w->p.safety_multiplier * ow.radius;                      // interrobot.rs:64
+    rec.offset = (double)1e-6f * (double)(c.first_number + (uint64_t)j);  // interrobot.rs:52,75
+    return rec;
 }
 
 static int upload_flags(mgx_world *w);
@@ -671,48 +659,54 @@ static int upload_flags(mgx_world *w);
 // the edge tables are rebuilt on the device from the old ones — surviving edges keep their state
 // (message, response mean, creation epoch), new edges are initialised from the owner's current
 // delivery count and the target's current belief mean (robot.rs:1549-1585) — without moving any
-// robot state between host and device.
+// robot state between host and device.  The host sends one record per CONNECTION; the per-edge
+// arrays are laid out by k_edge_rebuild.
 static int retopo(mgx_world *w) {
     const int K = w->K, R_local = w->d.R_local;
-    EdgeTables t;
-    build_edge_tables(w, R_local, t);
+    Incoming t;
+    build_incoming(w, R_local, t);
     if (!t.blocks_ok) return fail(MGX_ERR_STATE, "internal: node slots of two connections interleave");
-    const size_t NI = (size_t)t.var_ptr.back(), NIs = std::max<size_t>(NI, 1), NI_old = (size_t)w->d.NI;
-    std::vector<int32_t> map(2 * NIs, -1);  // old index of every new edge | its target variable
-    for (size_t v = 0; v + 1 < t.var_ptr.size(); v++)
-        for (int32_t e = t.var_ptr[v]; e < t.var_ptr[v + 1]; e++) map[NIs + (size_t)e] = (int32_t)v;
-    for (size_t e = 0; e < NI; e++) {
-        const IrConn &c = w->conns[(size_t)t.conn[e]];
-        map[e] = c.dev_edge.empty() ? -1 : c.dev_edge[(size_t)t.j[e]];
+    const size_t n_slots = t.in_list.size(), NI = n_slots * (size_t)(K - 1), NIs = std::max<size_t>(NI, 1);
+    std::vector<IrSlotRec> slots(std::max<size_t>(n_slots, 1));
+    for (size_t g = 0; g < n_slots; g++) {
+        const IrConn &c = w->conns[(size_t)t.in_list[g]];
+        const Robot &ow = w->robots[(size_t)c.owner], &ot = w->robots[(size_t)c.other];
+        IrSlotRec &sl = slots[g];
+        sl.tgt_robot = w->dev_of[(size_t)c.other];
+        sl.src_robot = w->dev_of[(size_t)c.owner];
+        sl.old_slot = c.dev_slot;
+        sl.flags = (ot.order_key > ow.order_key) ? 1 : 0;
+        sl.d_safe = w->p.safety_multiplier * ow.radius;
+        sl.first_number = c.first_number;
     }
     hipStream_t s = w->stream;
-    HIP_TRY(w->ir_map.upload(map, s));
-    HIP_TRY(w->ir_rec_b.upload(t.recs, s));
-    HIP_TRY(w->ir_var_ptr.upload(t.var_ptr, s));
-    HIP_TRY(w->ir_var_mid.upload(t.var_mid, s));
+    HIP_TRY(w->slot_recs.upload(slots, s));
+    HIP_TRY(w->in_ptr_dev_b.upload(t.in_ptr, s));
+    HIP_TRY(w->in_mid_dev.upload(t.mid, s));
+    HIP_TRY(w->ir_rec_b.reserve(NIs));
     HIP_TRY(w->ir_fv_eta_b.reserve(4 * NIs));
     HIP_TRY(w->ir_fv_lam_b.reserve(16 * NIs));
     HIP_TRY(w->ir_bmu_b.reserve(4 * NIs));
-    HIP_TRY(launch_edge_rebuild(w->d, (int)NI, (int)NIs, (int)NI_old, w->ir_map.p, w->ir_rec_b.p, w->ir_fv_eta_b.p, w->ir_fv_lam_b.p,
-                                w->ir_bmu_b.p, s));
-    HIP_TRY(hipStreamSynchronize(s));  // `map`, `t` are pageable temporaries
+    HIP_TRY(launch_edge_rebuild(w->d, (int)n_slots, w->slot_recs.p, w->in_ptr_dev_b.p, w->in_ptr_dev.p, (int)NIs, w->ir_rec_b.p,
+                                w->ir_fv_eta_b.p, w->ir_fv_lam_b.p, w->ir_bmu_b.p, s));
+    HIP_TRY(launch_var_tables(R_local, K, w->in_ptr_dev_b.p, w->in_mid_dev.p, w->ir_var_ptr.p, w->ir_var_mid.p, s));
+    HIP_TRY(hipStreamSynchronize(s));  // `slots`, `t` are pageable temporaries
     w->ir_rec.swap(w->ir_rec_b);
     w->ir_fv_eta.swap(w->ir_fv_eta_b);
     w->ir_fv_lam.swap(w->ir_fv_lam_b);
     w->ir_bmu.swap(w->ir_bmu_b);
+    w->in_ptr_dev.swap(w->in_ptr_dev_b);
     DevWorld &d = w->d;
     d.NI = (int)NIs;
     d.ir_rec = w->ir_rec.p; d.ir_fv_eta = w->ir_fv_eta.p; d.ir_fv_lam = w->ir_fv_lam.p; d.ir_bmu = w->ir_bmu.p;
-    d.ir_var_ptr = w->ir_var_ptr.p; d.ir_var_mid = w->ir_var_mid.p;
     d.ir_max_edges = t.ir_max_edges;
-    for (IrConn &c : w->conns) c.dev_edge.assign(c.node.size(), -1);
-    w->edge_src_robot.resize(NI);
-    for (size_t e = 0; e < NI; e++) {
-        IrConn &c = w->conns[(size_t)t.conn[e]];
-        c.dev_edge[(size_t)t.j[e]] = (int32_t)e;
-        c.edges[(size_t)t.j[e]].fresh = false;
-        w->edge_src_robot[e] = t.recs[e].src_robot;
+    for (IrConn &c : w->conns) c.dev_slot = -1;
+    for (size_t g = 0; g < n_slots; g++) {
+        IrConn &c = w->conns[(size_t)t.in_list[g]];
+        c.dev_slot = (int32_t)g;
+        for (IrEdge &ed : c.edges) ed.fresh = false;
     }
+    w->dev_in_ptr = t.in_ptr;
     w->conns_dirty = false;
     return upload_flags(w);  // the gate bytes follow the edges
 }
@@ -755,25 +749,28 @@ static int commit(mgx_world *w) {
             ed.fresh = false;
         }
 
-    EdgeTables t;
-    build_edge_tables(w, R_local, t);
+    Incoming t;
+    build_incoming(w, R_local, t);
     if (!t.blocks_ok) return fail(MGX_ERR_STATE, "internal: node slots of two connections interleave");
-    std::vector<int32_t> &var_ptr = t.var_ptr, &var_mid = t.var_mid;
-    std::vector<IrEdgeRec> &recs = t.recs;
-    const size_t NI = (size_t)var_ptr.back(), NIs = std::max<size_t>(NI, 1);
+    const size_t n_slots = t.in_list.size(), NI = n_slots * (size_t)(K - 1), NIs = std::max<size_t>(NI, 1);
+    std::vector<IrEdgeRec> recs(NIs, IrEdgeRec{0, 0, 0, 0, 0.0, 0.0});
     std::vector<double> ife(4 * NIs, 0.0), ifl(16 * NIs, 0.0), ibm(4 * NIs, 0.0);
-    w->edge_src_robot.resize(NI);
-    for (IrConn &c : w->conns) c.dev_edge.assign(c.node.size(), -1);
-    for (size_t e = 0; e < NI; e++) {
-        IrConn &c = w->conns[(size_t)t.conn[e]];
-        const IrEdge &ed = c.edges[(size_t)t.j[e]];
-        recs[e].created = ed.created;
-        w->edge_src_robot[e] = recs[e].src_robot;
-        c.dev_edge[(size_t)t.j[e]] = (int32_t)e;
-        scatter(ife, NIs, e, ed.fv_eta, 4);
-        scatter(ifl, NIs, e, ed.fv_lam, 16);
-        scatter(ibm, NIs, e, ed.bmu, 4);
+    for (IrConn &c : w->conns) c.dev_slot = -1;
+    for (size_t g = 0; g < n_slots; g++) {
+        IrConn &c = w->conns[(size_t)t.in_list[g]];
+        c.dev_slot = (int32_t)g;
+        const int r = w->dev_of[(size_t)c.other];
+        for (int j = 0; j < K - 1; j++) {
+            const size_t e = edge_index(t.in_ptr, K, r, j, (int)g);
+            const IrEdge &ed = c.edges[(size_t)j];
+            recs[e] = edge_record(w, c, j);
+            recs[e].created = ed.created;
+            scatter(ife, NIs, e, ed.fv_eta, 4);
+            scatter(ifl, NIs, e, ed.fv_lam, 16);
+            scatter(ibm, NIs, e, ed.bmu, 4);
+        }
     }
+    w->dev_in_ptr = t.in_ptr;
     const int ir_max_edges = t.ir_max_edges;
 
     const size_t BS = (size_t)blob_words(K);
@@ -823,8 +820,11 @@ static int commit(mgx_world *w) {
     HIP_TRY(w->path_ptr.upload(pptr, s));
     HIP_TRY(w->path_xy.upload(pxy, s));
     HIP_TRY(w->iter_factor.upload(itf, s));
-    HIP_TRY(w->ir_var_ptr.upload(var_ptr, s));
-    HIP_TRY(w->ir_var_mid.upload(var_mid, s));
+    HIP_TRY(w->in_ptr_dev.upload(t.in_ptr, s));
+    HIP_TRY(w->in_mid_dev.upload(t.mid, s));
+    HIP_TRY(w->ir_var_ptr.reserve((size_t)R_local * K + 1));
+    HIP_TRY(w->ir_var_mid.reserve((size_t)std::max(R_local, 1) * K));
+    HIP_TRY(launch_var_tables(R_local, K, w->in_ptr_dev.p, w->in_mid_dev.p, w->ir_var_ptr.p, w->ir_var_mid.p, s));
     HIP_TRY(w->ir_rec.upload(recs, s));
     HIP_TRY(w->ir_fv_eta.upload(ife, s));
     HIP_TRY(w->ir_fv_lam.upload(ifl, s));
