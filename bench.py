@@ -412,6 +412,37 @@ def main():
             line["secondary"] = {"error": err or "another rank failed to build its shard"}
             sc2 = None
 
+    # ---- whole ticks with topology churn (N = 1 only): positions jitter every tick, so the comms-range
+    # search finds pairs that cross the radius and the engine creates / deletes their factors
+    if not multi and not a.no_secondary:
+        try:
+            import numpy as np
+            sc3 = S.grid_scenario(n_loc, K, interrobot=True, seed=805)
+            sc3["ir"] = []
+            wd = World(sc3["params"], stream=stream, fma=a.fma)
+            S.populate(wd, sc3)
+            rng = np.random.default_rng(805)
+            base = np.array([[rb["pos"][0], 0.5, rb["pos"][1]] for rb in sc3["robots"]], dtype=np.float32)
+            tk3 = S.tick_inputs(sc3)
+            nxt, _, _ = wd.update_topology(base, 8.0, 1)
+            wd.iterate(sc3["steps"])
+            wd.synchronize()
+            n_dyn, made, gone = 30, 0, 0
+            t0 = time.perf_counter()
+            for _ in range(n_dyn):
+                pos = base + rng.normal(0, 0.15, size=base.shape).astype(np.float32)
+                nxt, c, d = wd.update_topology(pos, 8.0, nxt)
+                wd.update_priors(**tk3)
+                wd.iterate(sc3["steps"])
+                made, gone = made + c, gone + d
+            wd.synchronize()
+            line["dynamic_tick"] = {"value": round(n_dyn / (time.perf_counter() - t0), 1), "unit": "driver ticks/s per GPU",
+                                    "what": f"{n_loc} robots x {K}: comms-range search + factor create/delete (on average "
+                                            f"{made / n_dyn:.0f} connections created, {gone / n_dyn:.0f} pairs deleted per tick) + prior "
+                                            "updates + 10 GBP iterations with inter-robot factors"}
+        except Exception as e:  # noqa: BLE001
+            line["dynamic_tick"] = {"error": f"{type(e).__name__}: {e}"}
+
     guard.cancel()
 
     # ---- the same sharded workload with the direct exchange, isolated in child processes ---------
