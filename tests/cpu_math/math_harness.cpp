@@ -2,6 +2,7 @@
 // the exact functions the gfx950 kernels call can be checked on a CPU-only machine
 // (tests/test_lane_math.py).  Not part of the product library.
 #include "../../magics_amd/csrc/gbp_math.h"
+#include "../../experiments/four_lane_forms.h"  // record of the cooperative-lane experiment, not product code
 
 extern "C" {
 int h_inv4(const double *m, double *o) {
