@@ -149,3 +149,72 @@ def test_all_to_all_exchange_gloo_world_size_2():
         p.join(timeout=60)
     assert [r[1] for r in res] == ["ok", "ok"], res
     assert all(r[3] > 0 for r in res)  # both ranks really had ghosts to fill
+
+
+class DirectFakeWorld(FakeWorld):
+    """FakeWorld + a host model of the direct halo exchange (include/mgx.h): every rank's receive
+    area is a numpy array in a shared registry keyed by a fake address; `connect` records where this
+    rank's segments go; `iterate` pushes through those addresses and unpacks from its own area."""
+    registry = {}
+    next_addr = [1 << 20]
+
+    def halo_direct_setup(self, n_sources):
+        words = self.halo_words(self.K)
+        self.area = np.full((2, max(1, len(self.recv)) * words), -1.0)
+        self.flags = np.zeros(max(1, n_sources), dtype=np.int64)
+        a_recv, a_flag = self.next_addr[0], self.next_addr[0] + (1 << 16)
+        self.next_addr[0] += 1 << 17
+        self.registry[a_recv] = ("area", self)
+        for j in range(max(1, n_sources)):
+            self.registry[a_flag + 8 * j] = ("flag", self, j)
+        self.n_sources, self.seq = n_sources, 0
+        return a_recv, a_flag
+
+    def halo_direct_connect(self, first, base, nrec, off, slot):
+        assert len(base) == self.n_sources, "producers and consumers of a rank must be the same peers"
+        assert first[0] == 0 and first[-1] == len(self.send)
+        self.peers = []
+        for p in range(len(base)):
+            kind, peer = self.registry[base[p]]
+            assert kind == "area" and nrec[p] == len(peer.recv)
+            fk = self.registry[slot[p]]
+            assert fk[0] == "flag" and fk[1] is peer
+            self.peers.append((peer, first[p], first[p + 1], off[p], fk[2]))
+
+    def direct_push(self):
+        self.seq += 1
+        w = self.halo_words(self.K)
+        for peer, lo, hi, off, fslot in self.peers:
+            for k, r in enumerate(self.send[lo:hi]):
+                rec = np.full(w, float(self.robots[r]["key"]))
+                rec[1] = self.robots[r]["version"]
+                peer.area[self.seq & 1, (off + k) * w:(off + k + 1) * w] = rec
+            peer.flags[fslot] = self.seq
+
+    def direct_wait_unpack(self):
+        assert (self.flags[:self.n_sources] >= self.seq).all(), "a producer has not pushed this exchange"
+        w = self.halo_words(self.K)
+        for j, r in enumerate(self.recv):
+            rec = self.area[self.seq & 1, j * w:(j + 1) * w]
+            assert rec[0] == self.robots[r]["key"], "record landed in the wrong ghost"
+            self.robots[r]["version"] = int(rec[1])
+
+
+@pytest.mark.parametrize("world_size", [2, 3, 4])
+def test_direct_exchange_wiring(world_size):
+    """ShardedWorld.direct_setup / direct_connect: segments, offsets and counter slots agree across
+    ranks, so that every ghost receives the snapshot of the right robot at the right version."""
+    DirectFakeWorld.registry.clear()
+    sc = _scenario()
+    ranks = [sharded.ShardedWorld(sc, r, world_size, DirectFakeWorld, tensor_factory=lambda n: None) for r in range(world_size)]
+    infos = {sw.plan.rank: sw.direct_setup(export_ipc=False) for sw in ranks}
+    for sw in ranks:
+        sw.direct_connect(infos)
+    for it in range(4):
+        for sw in ranks:
+            sw.world.direct_push()
+        for sw in ranks:
+            sw.world.direct_wait_unpack()
+            sw.world.sweep(3, 3, 1)
+    assert sum(sw.world.checked for sw in ranks) > 0
+    assert any(sw.plan.ghosts for sw in ranks)
