@@ -60,3 +60,18 @@ def test_argument_validation_needs_no_device():
     assert L.mgx_robot_add(None, None, None) == -1
     assert L.mgx_iterate(None, None, 0) == -1
     assert b"null" in L.mgx_last_error()
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C ABI: include/mgx.h must compile as C99 (-pedantic) and a C program must
+    link against libmgx.so and run (host-only entry points work without a GPU)."""
+    import subprocess
+    root = ROOT
+    src = os.path.join(ROOT, "tests", "c_abi", "c_client.c")
+    exe = str(tmp_path / "c_client")
+    libdir = os.path.join(root, "magics_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), src, "-o", exe,
+                    "-L", libdir, "-lmgx", f"-Wl,-rpath,{libdir}"], check=True)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout.decode())
+    assert b"c client ok" in r.stdout
