@@ -44,8 +44,9 @@ def parse():
                     help="N > 1 only: seconds the sharded (collective) phase may take before it is abandoned")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--fma", action="store_true", help="use the FMA-contracting build (not the product)")
-    ap.add_argument("--role", default="main", choices=["main", "direct-child"],
-                    help="direct-child: one rank of the isolated direct-exchange measurement (spawned by the main role)")
+    ap.add_argument("--role", default="main", choices=["main", "direct-child", "rccl-child"],
+                    help="*-child: one rank of an isolated measurement of the sharded workload with the exchange inside the "
+                         "engine (direct: peer-mapped stores; rccl: grouped ncclSend / ncclRecv), spawned by the main role")
     return ap.parse_args()
 
 
@@ -163,12 +164,12 @@ def direct_child(a):
         comm = sharded.TorchDistComm()
         sw = sharded.ShardedWorld(sc2, rank, world_size, lambda p: World(p, stream=stream, fma=a.fma), comm=comm)
         sw.world.sweep(0, 0, 0)
-        info = sw.direct_setup(export_ipc=True)
+        info = sw.direct_setup(export_ipc=True) if a.role == "direct-child" else None
     except Exception as e:  # noqa: BLE001
         err = f"{type(e).__name__}: {e}"
     if not agree(not err):
         out = {"error": err or "another rank failed to set up"}
-    else:
+    elif a.role == "direct-child":
         infos = comm.all_gather_object(info)
         try:
             sw.direct_connect({i["rank"]: i for i in infos})
@@ -176,12 +177,22 @@ def direct_child(a):
             err = f"{type(e).__name__}: {e}"
         if not agree(not err):
             out = {"error": err or "another rank failed to map its peers"}
+    else:
+        try:
+            sharded.connect_rccl(sw, comm)  # collective (ncclCommInitRank); a failure on one rank ends in the deadline
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        if not agree(not err):
+            out = {"error": err or "another rank failed to join the RCCL communicator"}
     if not out:
         steps2 = sc2["steps"]
         n2, w2 = max(SCHEDULE_LEN, a.steps // 4), max(SCHEDULE_LEN, a.warmup // 4)
         run_steps(sw.iterate, w2, steps2)
         try:
-            sw.world.halo_direct_status()  # synchronises; raises if a wait timed out
+            if a.role == "direct-child":
+                sw.world.halo_direct_status()  # synchronises; raises if a wait timed out
+            else:
+                sw.synchronize()
         except Exception as e:  # noqa: BLE001
             err = f"{type(e).__name__}: {e}"
         if not agree(not err):
@@ -200,8 +211,10 @@ def direct_child(a):
         t = torch.tensor([wall, ev0.elapsed_time(ev1) * 1e-3], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev = float(t[0]), float(t[1])
+        n_ex = None
         try:
-            n_ex = sw.world.halo_direct_status()
+            if a.role == "direct-child":
+                n_ex = sw.world.halo_direct_status()
         except Exception as e:  # noqa: BLE001
             err = f"{type(e).__name__}: {e}"
         if not agree(not err):
@@ -211,8 +224,10 @@ def direct_child(a):
             bytes2 = S.algorithmic_bytes_per_robot_iter(K, D) * n_loc
             out = {"value": round(n2 / wall, 2), "unit": f"GBP iterations/s (one iteration over all {n_tot} robots)",
                    "steps": n2, "ms_per_step": wall / n2 * 1e3, "exchanges": n_ex,
-                   "exchange": "direct: peer-mapped stores into the consumers' receive areas (hipIpc) + device-side arrival "
-                               "counters, one C call per tick, no collective",
+                   "exchange": ("direct: peer-mapped stores into the consumers' receive areas (hipIpc) + device-side arrival "
+                                "counters, one C call per tick, no collective") if a.role == "direct-child" else
+                               "RCCL inside the engine: grouped ncclSend / ncclRecv per external iteration on the launch stream, "
+                               "one C call per tick",
                    "ghost_robots_this_rank": len(sw.plan.ghosts),
                    "roofline": {"bound": "hbm", "achieved": round(bytes2 * n2 / dev / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(bytes2 * n2 / dev / 1e9 / HBM_PEAK_GBS, 4)}}
@@ -224,7 +239,7 @@ def direct_child(a):
     dist.destroy_process_group()
 
 
-def run_direct_children(a, rank, local_rank, world_size):
+def run_direct_children(a, rank, local_rank, world_size, role="direct-child", port_shift=23):
     """Spawn this rank's direct-exchange child and wait for it (bounded).  Returns the child's JSON
     (rank 0) or a description of what went wrong; never raises."""
     # the children rendezvous among themselves: nothing of the launcher's elastic agent may leak in
@@ -232,15 +247,15 @@ def run_direct_children(a, rank, local_rank, world_size):
     base = {k: v for k, v in os.environ.items() if not k.startswith(("TORCHELASTIC_", "GROUP_", "ROLE_"))}
     env = dict(base, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world_size),
                MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
-               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 23),
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + port_shift),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.setdefault("MGX_HALO_TIMEOUT_MS", "2000")
-    cmd = [sys.executable, os.path.abspath(__file__), "--role", "direct-child", "--gpus", str(world_size), "--steps", str(a.steps),
+    cmd = [sys.executable, os.path.abspath(__file__), "--role", role, "--gpus", str(world_size), "--steps", str(a.steps),
            "--warmup", str(a.warmup), "--robots-per-gpu", str(a.robots_per_gpu), "--horizon", str(a.horizon)] + (["--fma"] if a.fma else [])
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=a.secondary_deadline)
     except subprocess.TimeoutExpired:
-        return {"error": f"direct-exchange child did not finish within {a.secondary_deadline} s"}
+        return {"error": f"{role} did not finish within {a.secondary_deadline} s"}
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
     if rank != 0:
@@ -281,7 +296,7 @@ class _Deadline:
 
 def main():
     a = parse()
-    if a.role == "direct-child":
+    if a.role in ("direct-child", "rccl-child"):
         return direct_child(a)
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -450,6 +465,10 @@ def main():
         res = run_direct_children(a, rank, local_rank, world_size)
         if rank == 0 and isinstance(line.get("secondary"), dict):
             line["secondary"]["direct_exchange"] = res
+        if backend == "nccl":  # the in-library RCCL transport needs one GPU per rank
+            res = run_direct_children(a, rank, local_rank, world_size, role="rccl-child", port_shift=41)
+            if rank == 0 and isinstance(line.get("secondary"), dict):
+                line["secondary"]["rccl_in_engine"] = res
 
     # ---- CPU baseline: rank 0, N = 1 only ---------------------------------------------------------
     if rank == 0 and not multi and not a.no_cpu_baseline:

@@ -240,6 +240,20 @@ int mgx_halo_plan(mgx_world *w, uint32_t n_send, const int32_t *send_robots, uin
 int mgx_halo_pack(mgx_world *w, void *dev_buf);
 int mgx_halo_unpack(mgx_world *w, const void *dev_buf);
 
+/* ---- halo exchange through RCCL inside the library -------------------------------------------
+ * pack -> grouped ncclSend / ncclRecv with every peer (the all-to-all-v of boundary snapshots over
+ * xGMI) -> unpack, enqueued on the world's stream in front of every world-wide launch
+ * that starts with the external factor phase: no host work per exchange beyond the enqueue.  RCCL
+ * is resolved at run time (dlopen; the copy already in the process if there is one).  One rank
+ * creates the id (mgx_rccl_unique_id), all ranks get it over any control plane and call
+ * mgx_halo_rccl_connect (collective: ncclCommInitRank) with their peers and the segments of the
+ * send / receive lists (mgx_halo_plan) that belong to each. */
+int mgx_rccl_unique_id(uint8_t id[128]);
+int mgx_halo_rccl_connect(mgx_world *w, const uint8_t id[128], uint32_t n_ranks, uint32_t rank,
+                          uint32_t n_peers, const uint32_t *peer_rank, const uint32_t *send_first,
+                          const uint32_t *recv_first);
+int mgx_halo_rccl_disconnect(mgx_world *w);
+
 /* ---- direct halo exchange: peer-mapped stores instead of the collective -------
  * Same dataflow as pack -> all-to-all-v -> unpack, without a collective and without host work
  * per exchange: each producer's kernel stores its boundary records straight into the consumer

@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <dlfcn.h>
 #include <cstring>
 #include <map>
 #include <string>
@@ -225,6 +226,46 @@ struct IrConn {  // K-1 factors owner -> other
     int32_t dev_slot = -1;  // slot of this connection in its target's incoming list on the device (-1: not there)
 };
 
+// RCCL, resolved at run time (no link-time dependency): the copy already in the process (a host that
+// runs torch.distributed has one) or the system library.  Only what the halo exchange needs.
+struct RcclApi {
+    typedef int (*get_unique_id_t)(void *);
+    struct Id128 { char internal[128]; };
+    typedef int (*comm_destroy_t)(void *);
+    typedef int (*group_t)(void);
+    typedef int (*sendrecv_t)(void *, size_t, int, int, void *, hipStream_t);
+    typedef const char *(*error_string_t)(int);
+    get_unique_id_t get_unique_id = nullptr;
+    int (*comm_init_rank)(void **, int, Id128, int) = nullptr;
+    comm_destroy_t comm_destroy = nullptr;
+    group_t group_start = nullptr, group_end = nullptr;
+    sendrecv_t send = nullptr, recv = nullptr;
+    error_string_t error_string = nullptr;
+    bool tried = false, ok = false;
+    bool load() {
+        if (tried) return ok;
+        tried = true;
+        void *h = dlopen(nullptr, RTLD_NOW);  // symbols already in the process
+        if (!h || !dlsym(h, "ncclCommInitRank")) {
+            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!h) return false;
+        get_unique_id = (get_unique_id_t)dlsym(h, "ncclGetUniqueId");
+        comm_init_rank = (int (*)(void **, int, Id128, int))dlsym(h, "ncclCommInitRank");
+        comm_destroy = (comm_destroy_t)dlsym(h, "ncclCommDestroy");
+        group_start = (group_t)dlsym(h, "ncclGroupStart");
+        group_end = (group_t)dlsym(h, "ncclGroupEnd");
+        send = (sendrecv_t)dlsym(h, "ncclSend");
+        recv = (sendrecv_t)dlsym(h, "ncclRecv");
+        error_string = (error_string_t)dlsym(h, "ncclGetErrorString");
+        ok = get_unique_id && comm_init_rank && comm_destroy && group_start && group_end && send && recv;
+        return ok;
+    }
+};
+static RcclApi g_rccl;
+constexpr int NCCL_FLOAT64 = 8;  // ncclFloat64 (rccl.h)
+
 }  // namespace
 
 struct mgx_world {
@@ -281,6 +322,14 @@ struct mgx_world {
         DevBuf<unsigned long long> dst[2], peer_flags;
         DevBuf<unsigned int> done;
     } direct;
+    // halo exchange through RCCL inside the library (grouped ncclSend / ncclRecv on the world's stream)
+    struct RcclHalo {
+        void *comm = nullptr;
+        bool connected = false;
+        std::vector<int> peer_rank;
+        std::vector<uint32_t> send_first, recv_first;  // [n_peers + 1] into halo_send / halo_recv
+        DevBuf<double> send_buf, recv_buf;
+    } rccl;
     // neighbour search scratch (mgx_topology.hip)
     DevBuf<float> nb_pos;
     DevBuf<int32_t> nb_cnt, nb_bucket_cnt, nb_bucket_ptr, nb_cursor, nb_members, nb_special, nb_nspecial, nb_ptr, nb_idx;
@@ -873,6 +922,7 @@ static int commit(mgx_world *w) {
 
 // ---- launches -----------------------------------------------------------------------------------------
 static int direct_exchange(mgx_world *w);
+static int rccl_exchange(mgx_world *w);
 static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_mask, int n_int, uint32_t hints = 0) {
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
@@ -880,6 +930,9 @@ static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_ma
     if (robot < 0) {
         if (w->direct.connected && (ext_mask & PH_EXT_FACTOR)) {  // the inter-robot factors read the ghosts' snapshots
             rc = direct_exchange(w);
+            if (rc != MGX_OK) return rc;
+        } else if (w->rccl.connected && (ext_mask & PH_EXT_FACTOR)) {
+            rc = rccl_exchange(w);
             if (rc != MGX_OK) return rc;
         }
         const int out = writes_snap ? 1 - w->d.cur : -1;
@@ -924,6 +977,7 @@ int mgx_world_create(const mgx_params *params, mgx_world **out) {
 int mgx_world_destroy(mgx_world *w) {
     if (!w) return MGX_OK;
     if (w->dev_valid) (void)hipStreamSynchronize(w->stream);
+    if (w->rccl.comm && g_rccl.ok) (void)g_rccl.comm_destroy(w->rccl.comm);
     if (w->direct.recv) (void)hipFree(w->direct.recv);
     if (w->direct.flags) (void)hipFree(w->direct.flags);
     delete w;
@@ -1593,7 +1647,69 @@ static int direct_exchange(mgx_world *w) {
     return direct_wait(w);
 }
 
+// pack -> grouped ncclSend / ncclRecv (the all-to-all-v of boundary snapshots, RCCL over xGMI) -> unpack,
+// all enqueued on the world's stream
+static int rccl_exchange(mgx_world *w) {
+    int rc = halo_commit(w);
+    if (rc != MGX_OK) return rc;
+    mgx_world::RcclHalo &rh = w->rccl;
+    const size_t words = (size_t)mgx_halo_words((uint32_t)w->K);
+    HIP_TRY(launch_halo_pack(w->d, (int)w->halo_send.size(), w->halo_send_dev.p, rh.send_buf.p, w->stream));
+    int e = g_rccl.group_start();
+    for (size_t p = 0; p < rh.peer_rank.size() && e == 0; p++) {
+        const size_t ns = (size_t)(rh.send_first[p + 1] - rh.send_first[p]) * words, nr = (size_t)(rh.recv_first[p + 1] - rh.recv_first[p]) * words;
+        if (ns) e = g_rccl.send(rh.send_buf.p + (size_t)rh.send_first[p] * words, ns, NCCL_FLOAT64, rh.peer_rank[p], rh.comm, w->stream);
+        if (nr && e == 0) e = g_rccl.recv(rh.recv_buf.p + (size_t)rh.recv_first[p] * words, nr, NCCL_FLOAT64, rh.peer_rank[p], rh.comm, w->stream);
+    }
+    const int e2 = g_rccl.group_end();
+    if (e || e2) return fail(MGX_ERR_HIP, "RCCL: %s", g_rccl.error_string ? g_rccl.error_string(e ? e : e2) : "error");
+    HIP_TRY(launch_halo_unpack(w->d, (int)w->halo_recv.size(), w->halo_recv_dev.p, rh.recv_buf.p, w->stream));
+    return MGX_OK;
+}
+
 extern "C" {
+
+// ---- halo exchange through RCCL inside the library -----------------------------------------------------
+int mgx_rccl_unique_id(uint8_t id[128]) {
+    if (!id) return fail(MGX_ERR_INVALID, "null argument");
+    if (!g_rccl.load()) return fail(MGX_ERR_STATE, "RCCL is not available in this process");
+    const int e = g_rccl.get_unique_id(id);
+    if (e) return fail(MGX_ERR_HIP, "ncclGetUniqueId: %s", g_rccl.error_string ? g_rccl.error_string(e) : "error");
+    return MGX_OK;
+}
+int mgx_halo_rccl_connect(mgx_world *w, const uint8_t id[128], uint32_t n_ranks, uint32_t rank, uint32_t n_peers, const uint32_t *peer_rank,
+                          const uint32_t *send_first, const uint32_t *recv_first) {
+    if (!w || !id || (n_peers && (!peer_rank || !send_first || !recv_first))) return fail(MGX_ERR_INVALID, "null argument");
+    if (rank >= n_ranks) return fail(MGX_ERR_INVALID, "rank out of range");
+    if (!g_rccl.load()) return fail(MGX_ERR_STATE, "RCCL is not available in this process");
+    int rc = halo_commit(w);
+    if (rc != MGX_OK) return rc;
+    mgx_world::RcclHalo &rh = w->rccl;
+    if (n_peers && (send_first[0] != 0 || send_first[n_peers] != w->halo_send.size() || recv_first[0] != 0 || recv_first[n_peers] != w->halo_recv.size()))
+        return fail(MGX_ERR_INVALID, "segments do not cover the send / receive lists");
+    for (uint32_t p = 0; p < n_peers; p++)
+        if (peer_rank[p] >= n_ranks || peer_rank[p] == rank) return fail(MGX_ERR_INVALID, "bad peer rank");
+    if (!rh.comm) {
+        RcclApi::Id128 uid;
+        memcpy(uid.internal, id, 128);
+        const int e = g_rccl.comm_init_rank(&rh.comm, (int)n_ranks, uid, (int)rank);  // collective: every rank calls it
+        if (e) { rh.comm = nullptr; return fail(MGX_ERR_HIP, "ncclCommInitRank: %s", g_rccl.error_string ? g_rccl.error_string(e) : "error"); }
+    }
+    const size_t words = (size_t)mgx_halo_words((uint32_t)w->K);
+    HIP_TRY(rh.send_buf.reserve(std::max<size_t>(w->halo_send.size() * words, 1)));
+    HIP_TRY(rh.recv_buf.reserve(std::max<size_t>(w->halo_recv.size() * words, 1)));
+    rh.peer_rank.assign(peer_rank, peer_rank + n_peers);
+    rh.send_first.assign(send_first, send_first + n_peers + (n_peers ? 1 : 0));
+    rh.recv_first.assign(recv_first, recv_first + n_peers + (n_peers ? 1 : 0));
+    rh.connected = true;
+    return MGX_OK;
+}
+int mgx_halo_rccl_disconnect(mgx_world *w) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    w->rccl.connected = false;
+    return MGX_OK;
+}
 
 // ---- direct halo exchange (peer-mapped stores) ---------------------------------------------
 int mgx_halo_direct_setup(mgx_world *w, uint32_t n_sources, void **recv_base, void **flag_base) {

@@ -100,6 +100,9 @@ SYMBOLS = {
     "mgx_message_counts": (C.c_int, [_V, C.c_int32, C.POINTER(C.c_uint64)]),
     "mgx_read_means": (C.c_int, [_V, c_double_p]),
     "mgx_read_variable_means": (C.c_int, [_V, C.c_uint32, c_double_p]),
+    "mgx_rccl_unique_id": (C.c_int, [C.c_char_p]),
+    "mgx_halo_rccl_connect": (C.c_int, [_V, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgx_halo_rccl_disconnect": (C.c_int, [_V]),
     "mgx_halo_direct_setup": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "mgx_halo_direct_connect": (C.c_int, [_V, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_halo_direct_exchange": (C.c_int, [_V, C.c_uint32]),
@@ -189,6 +192,12 @@ def check(rc, L=None):
     if rc < 0:
         raise MgxError(f"mgx error {rc}: {(L or lib()).mgx_last_error().decode(errors='replace')}")
     return rc
+
+
+def rccl_unique_id():
+    buf = C.create_string_buffer(128)
+    check(lib().mgx_rccl_unique_id(buf))
+    return buf.raw
 
 
 def ipc_export(dev_ptr):

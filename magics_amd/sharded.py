@@ -156,6 +156,9 @@ class ShardedWorld:
 
     def direct_close(self):
         """Call on every rank, after a barrier: nobody may still be pushing into a closed area."""
+        if getattr(self, "rccl", False):
+            self.world.halo_rccl_disconnect()
+            self.direct = self.rccl = False
         if self.direct:
             self.world.halo_direct_disconnect()
             self.direct = False
@@ -219,6 +222,24 @@ def _torch_tensor_factory(n):
     if not torch.cuda.is_available():
         raise hostlib.MgxError("halo buffers need a GPU (pass tensor_factory explicitly for host-side tests)")
     return torch.zeros(n, dtype=torch.float64, device="cuda")
+
+
+def connect_rccl(sw, comm):
+    """The all-to-all-v inside the library: grouped ncclSend / ncclRecv enqueued by mgx_iterate itself
+    (include/mgx.h).  `comm` is only the control plane that spreads the RCCL unique id."""
+    plan = sw.plan
+    if plan.world_size == 1:
+        return
+    uid = hostlib.rccl_unique_id() if plan.rank == 0 else None
+    uid = comm.all_gather_object(uid)[0]
+    peers = [q for q in range(plan.world_size) if plan.send_lists[q] or plan.recv_lists[q]]
+    send_first, recv_first = [0], [0]
+    for q in peers:
+        send_first.append(send_first[-1] + len(plan.send_lists[q]))
+        recv_first.append(recv_first[-1] + len(plan.recv_lists[q]))
+    sw.world.halo_rccl_connect(uid, plan.world_size, plan.rank, peers, send_first, recv_first)
+    sw.direct = sw.rccl = True  # same driving mode: the engine exchanges inside its launch sequence
+    comm.barrier()
 
 
 def connect_direct(sw, comm):

@@ -231,6 +231,17 @@ class World:
     def halo_words(K):
         return hostlib.lib().mgx_halo_words(K)
 
+    # halo exchange through RCCL inside the library (see include/mgx.h)
+    def halo_rccl_connect(self, unique_id, n_ranks, rank, peer_rank, send_first, recv_first):
+        a = np.ascontiguousarray(peer_rank, dtype=np.uint32)
+        b = np.ascontiguousarray(send_first, dtype=np.uint32)
+        c = np.ascontiguousarray(recv_first, dtype=np.uint32)
+        assert b.size == c.size == (a.size + 1 if a.size else 0) or (a.size == 0)
+        self._chk(self._L.mgx_halo_rccl_connect(self._w, unique_id, n_ranks, rank, a.size, a.ctypes.data, b.ctypes.data, c.ctypes.data))
+
+    def halo_rccl_disconnect(self):
+        self._chk(self._L.mgx_halo_rccl_disconnect(self._w))
+
     # direct halo exchange (peer-mapped stores; see include/mgx.h)
     def halo_direct_setup(self, n_sources):
         recv, flags = C.c_void_p(), C.c_void_p()

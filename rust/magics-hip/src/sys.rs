@@ -65,6 +65,9 @@ extern "C" {
     pub fn mgx_read_variable_means(w: *mut mgx_world, var_ix: u32, means: *mut f64) -> c_int;
     pub fn mgx_read_means(w: *mut mgx_world, means: *mut f64) -> c_int;
     pub fn mgx_num_robots(w: *mut mgx_world, n_robots: *mut u32, n_variables: *mut u32) -> c_int;
+    pub fn mgx_rccl_unique_id(id: *mut u8) -> c_int;
+    pub fn mgx_halo_rccl_connect(w: *mut mgx_world, id: *const u8, n_ranks: u32, rank: u32, n_peers: u32, peer_rank: *const u32, send_first: *const u32, recv_first: *const u32) -> c_int;
+    pub fn mgx_halo_rccl_disconnect(w: *mut mgx_world) -> c_int;
     pub fn mgx_halo_words(k: u32) -> u32;
     pub fn mgx_halo_plan(w: *mut mgx_world, n_send: u32, send_robots: *const i32, n_recv: u32, recv_ghosts: *const i32) -> c_int;
     pub fn mgx_halo_pack(w: *mut mgx_world, dev_buf: *mut c_void) -> c_int;

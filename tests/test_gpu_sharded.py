@@ -109,3 +109,22 @@ def test_direct_exchange_reports_a_missing_peer(monkeypatch):
     lonely.iterate([3])            # rank 1 never runs its side of the exchange
     with pytest.raises(RuntimeError, match="timed out"):
         lonely.world.halo_direct_status()
+
+
+def test_rccl_transport_loads_and_runs_with_one_rank():
+    """The in-library RCCL exchange on the one GPU of the box: the library resolves RCCL, creates a
+    one-rank communicator and runs the (peerless) exchange in front of every external phase."""
+    from magics_amd import hostlib
+    sc = S.grid_scenario(16, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
+    w = World(sc["params"])
+    S.populate(w, sc)
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    uid = hostlib.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    w.halo_plan([], [])
+    w.halo_rccl_connect(uid, 1, 0, [], [0], [0])
+    for x in (w, ref):
+        x.iterate(sc["steps"])
+    assert_identical(w, ref, what="one-rank RCCL communicator")
+    w.halo_rccl_disconnect()
