@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-direct", action="store_true", help="N > 1: skip the direct-exchange child measurement")
-    ap.add_argument("--secondary-deadline", type=float, default=240.0,
+    ap.add_argument("--secondary-deadline", type=float, default=150.0,
                     help="N > 1 only: seconds the sharded (collective) phase may take before it is abandoned")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--fma", action="store_true", help="use the FMA-contracting build (not the product)")
