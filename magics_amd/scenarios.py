@@ -14,6 +14,7 @@ A scenario is a plain dict; ``populate(world, scenario)`` feeds it to any object
 ``World`` interface (``magics_amd.World``; the tests also pass the CPU oracle's world).
 """
 import math
+import os
 
 import numpy as np
 
@@ -100,22 +101,39 @@ def gaussian_blur_u8(img, sigma):
     k = np.exp(-0.5 * (xs / sigma) ** 2)
     k /= k.sum()
     out = img.astype(np.float64)
+    tmp = np.empty_like(out)
     for axis in (0, 1):
         pad = [(0, 0), (0, 0)]
         pad[axis] = (r, r)
         p = np.pad(out, pad, mode="edge")
         acc = np.zeros_like(out)
-        for j, kv in enumerate(k):
+        for j, kv in enumerate(k):  # acc += kv * window, without a temporary per tap
             sl = [slice(None), slice(None)]
             sl[axis] = slice(j, j + out.shape[axis])
-            acc += kv * p[tuple(sl)]
+            np.multiply(p[tuple(sl)], kv, out=tmp)
+            acc += tmp
         out = acc
     return out
 
 
 def synthetic_sdf(rng, world_w, world_h, px_per_m=10, disc_area_frac=0.02, blur_sigma_px=2.0):
-    """White RGB u8 image with seeded black discs (radius 1-3 m), Gaussian blurred."""
+    """White RGB u8 image with seeded black discs (radius 1-3 m), Gaussian blurred.  Large images are
+    cached on disk (the ranks and child processes of one bench run all build the same one)."""
     w, h = int(round(world_w * px_per_m)), int(round(world_h * px_per_m))
+    cache = None
+    if w * h >= 4_000_000:
+        import hashlib
+        import tempfile
+        key = hashlib.sha1(repr((rng.s, world_w, world_h, px_per_m, disc_area_frac, blur_sigma_px, "v1")).encode()).hexdigest()[:16]
+        cache = os.path.join(os.environ.get("MGX_SDF_CACHE", tempfile.gettempdir()), f"mgx_sdf_{key}.npz")
+        try:
+            with np.load(cache) as z:
+                red, state = z["red"], int(z["state"])
+            if red.shape == (h, w):
+                rng.s = state  # the generator ends where drawing the discs would have left it
+                return np.repeat(red[:, :, None], 3, axis=2)
+        except (OSError, ValueError, KeyError):
+            pass
     img = np.full((h, w), 255.0)
     n_discs = int(round(disc_area_frac * world_w * world_h / (math.pi * 4.0)))
     yy, xx = None, None
@@ -134,6 +152,13 @@ def synthetic_sdf(rng, world_w, world_h, px_per_m=10, disc_area_frac=0.02, blur_
         img[y0:y1, x0:x1][mask] = 0.0
     img = gaussian_blur_u8(img, blur_sigma_px)
     red = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    if cache is not None:
+        try:
+            tmp = f"{cache}.{os.getpid()}.tmp.npz"
+            np.savez(tmp, red=red, state=np.uint64(rng.s))
+            os.replace(tmp, cache)
+        except OSError:
+            pass
     return np.repeat(red[:, :, None], 3, axis=2)
 
 
