@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--horizon", type=int, default=16)
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dynamic", action="store_true", help="N = 1: skip the dynamic_tick measurement")
     ap.add_argument("--no-direct", action="store_true", help="N > 1: skip the direct-exchange child measurement")
     ap.add_argument("--secondary-deadline", type=float, default=150.0,
                     help="N > 1 only: seconds the sharded (collective) phase may take before it is abandoned")
@@ -429,7 +430,7 @@ def main():
 
     # ---- whole ticks with topology churn (N = 1 only): positions jitter every tick, so the comms-range
     # search finds pairs that cross the radius and the engine creates / deletes their factors
-    if not multi and not a.no_secondary:
+    if not multi and not a.no_secondary and not a.no_dynamic:
         try:
             import numpy as np
             sc3 = S.grid_scenario(n_loc, K, interrobot=True, seed=805)

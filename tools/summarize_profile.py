@@ -28,7 +28,7 @@ def main():
         sec = sec[len(sec) // 5:]                  # drop the secondary warm-up share
         return {"configs[1] dyn+obs, 10 iterations per dispatch": prim, "configs[2] +inter-robot, one iteration per dispatch": sec}
 
-    out = [f"# rocprofv3 summary — {tag}", "", "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline ...`", ""]
+    out = [f"# rocprofv3 summary — {tag}", "", "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-dynamic ...`", ""]
     tr = [r for r in rows(kdir, "*kernel_trace.csv") if "k_robot_sweep" in r["Kernel_Name"]]
     tr.sort(key=lambda r: int(r["Start_Timestamp"]))
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
