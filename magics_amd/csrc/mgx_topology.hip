@@ -115,46 +115,75 @@ __global__ void __launch_bounds__(1024) k_scan(const int32_t *__restrict__ a, in
     if (t == 1023) out[n] = part[1023];
 }
 
+// Sixteen lanes per robot: lanes 0..8 each walk the bucket of one of the 3x3 cells (a cell whose bucket an
+// earlier lane already has is skipped: two of the nine can hash alike), lane 9 walks the list of
+// robots with non-finite coordinates; a robot that is itself non-finite is compared with everybody
+// (a NaN distance counts as "in range"), all sixteen lanes striding.  The dependent loads of the nine
+// buckets run side by side instead of one after the other; counts are combined with a scan inside
+// the group.  FILL = second pass: lanes write their hits behind each other, lane 0 then orders the row.
+constexpr int QG = 16;  // lanes per robot
 template <bool FILL>
 __global__ void __launch_bounds__(256) k_grid_query(const float *__restrict__ pos, int n, float radius, double inv_cell, uint32_t mask,
                                                      const int32_t *__restrict__ bucket_ptr, const int32_t *__restrict__ members,
                                                      const int32_t *__restrict__ special, const int32_t *__restrict__ n_special,
                                                      int32_t *__restrict__ cnt, const int32_t *__restrict__ ptr,
                                                      int32_t *__restrict__ idx) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float ax = pos[3 * i], ay = pos[3 * i + 1], az = pos[3 * i + 2];
-    const int32_t base = FILL ? ptr[i] : 0;
-    int m = 0;
-    auto test = [&](int j) {
-        if (j == i) return;
-        if (in_comms_range(ax, ay, az, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], radius)) {
-            if (FILL) idx[base + m] = j;
-            m++;
-        }
-    };
-    if (!finite3(ax, ay, az)) {  // NaN distance counts as "in range": compare with everybody
-        for (int j = 0; j < n; j++) test(j);
-    } else {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t / QG, l = t % QG;
+    const bool live = i < n;
+    const int ii = live ? i : 0;  // every lane runs the shuffles
+    const float ax = pos[3 * ii], ay = pos[3 * ii + 1], az = pos[3 * ii + 2];
+    const bool wild = !finite3(ax, ay, az);
+    // this lane's candidate list: [q0, q1) of `list`, or every l-th robot
+    const int32_t *list = members;
+    int q0 = 0, q1 = 0, stride = 1;
+    uint32_t bucket = 0xffffffffu - (uint32_t)l;  // distinct dummies for the lanes without a bucket
+    if (live && wild) {
+        list = nullptr;
+        q0 = l; q1 = n; stride = QG;
+    } else if (live && l < 9) {
         const int cx = cell_of(ax, inv_cell), cz = cell_of(az, inv_cell);
-        uint32_t seen[9];
-        int ns = 0;
-        for (int dz = -1; dz <= 1; dz++)
-            for (int dx = -1; dx <= 1; dx++) {
-                const uint32_t b = bucket_of(cx + dx, cz + dz, mask);
-                bool dup = false;
-                for (int q = 0; q < ns; q++) dup |= seen[q] == b;
-                if (dup) continue;  // two of the nine cells hash to one bucket: visit it once
-                seen[ns++] = b;
-                for (int q = bucket_ptr[b]; q < bucket_ptr[b + 1]; q++) test(members[q]);
-            }
-        const int nsp = *n_special;
-        for (int q = 0; q < nsp; q++) test(special[q]);
+        bucket = bucket_of(cx + (l % 3) - 1, cz + (l / 3) - 1, mask);
+    } else if (live && l == 9) {
+        list = special;
+        q0 = 0; q1 = *n_special;
     }
+    bool dup = false;
+    for (int c = 0; c < 8; c++) {  // has an earlier lane of the group the same bucket?
+        const uint32_t other = __shfl(bucket, (threadIdx.x & 63 & ~(QG - 1)) + c, 64);
+        dup |= (c < l) && other == bucket;
+    }
+    if (live && !wild && l < 9 && !dup) {
+        q0 = bucket_ptr[bucket];
+        q1 = bucket_ptr[bucket + 1];
+    }
+    int m = 0;
+    auto hit = [&](int q) {
+        const int j = list ? list[q] : q;
+        return j != ii && in_comms_range(ax, ay, az, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], radius) ? j : -1;
+    };
+    for (int q = q0; q < q1; q += stride) m += hit(q) >= 0;
+    // exclusive scan of the counts over the group
+    int incl = m;
+    for (int d = 1; d < QG; d <<= 1) {
+        const int v = __shfl_up(incl, d, QG);
+        if (l >= d) incl += v;
+    }
+    const int total = __shfl(incl, (threadIdx.x & 63 & ~(QG - 1)) + QG - 1, 64);
+    if (!live) return;
     if (!FILL) {
-        cnt[i] = m;
-    } else {  // rows ascending in robot index (candidates arrive in bucket order)
-        for (int a = 1; a < m; a++) {
+        if (l == 0) cnt[i] = total;
+        return;
+    }
+    const int32_t base = ptr[i];
+    int w = base + incl - m;
+    for (int q = q0; q < q1; q += stride) {
+        const int j = hit(q);
+        if (j >= 0) idx[w++] = j;
+    }
+    __threadfence_block();  // the group's stores before lane 0 reads them back
+    if (l == 0)              // rows ascending in robot index (candidates arrive in bucket order)
+        for (int a = 1; a < total; a++) {
             const int32_t v = idx[base + a];
             int b = a;
             while (b > 0 && idx[base + b - 1] > v) {
@@ -163,7 +192,6 @@ __global__ void __launch_bounds__(256) k_grid_query(const float *__restrict__ po
             }
             idx[base + b] = v;
         }
-    }
 }
 
 // ---- host-side sequencing ---------------------------------------------------------------------------
@@ -184,7 +212,7 @@ hipError_t neighbours_count(const float *pos, int n, float radius, bool grid, ui
         hipLaunchKernelGGL(k_grid_hist, g256, dim3(256), 0, s, pos, n, inv_cell, M - 1, bucket_cnt, special, n_special);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, bucket_cnt, (int)M, bucket_ptr);
         hipLaunchKernelGGL(k_grid_scatter, g256, dim3(256), 0, s, pos, n, inv_cell, M - 1, bucket_ptr, cursor, members);
-        hipLaunchKernelGGL(k_grid_query<false>, g256, dim3(256), 0, s, pos, n, radius, inv_cell, M - 1, bucket_ptr, members, special,
+        hipLaunchKernelGGL(k_grid_query<false>, dim3((unsigned)(((size_t)n * QG + 255) / 256)), dim3(256), 0, s, pos, n, radius, inv_cell, M - 1, bucket_ptr, members, special,
                            n_special, cnt, (const int32_t *)nullptr, (int32_t *)nullptr);
     } else {
         hipLaunchKernelGGL(k_pairs<false>, g256, dim3(256), 0, s, pos, n, radius, cnt, (const int32_t *)nullptr, (int32_t *)nullptr);
@@ -199,7 +227,7 @@ hipError_t neighbours_fill(const float *pos, int n, float radius, bool grid, uin
     const dim3 g256((unsigned)((n + 255) / 256));
     if (grid) {
         const double inv_cell = 1.0 / ((double)radius * 1.001);
-        hipLaunchKernelGGL(k_grid_query<true>, g256, dim3(256), 0, s, pos, n, radius, inv_cell, M - 1, bucket_ptr, members, special,
+        hipLaunchKernelGGL(k_grid_query<true>, dim3((unsigned)(((size_t)n * QG + 255) / 256)), dim3(256), 0, s, pos, n, radius, inv_cell, M - 1, bucket_ptr, members, special,
                            n_special, (int32_t *)nullptr, ptr, idx);
     } else {
         hipLaunchKernelGGL(k_pairs<true>, g256, dim3(256), 0, s, pos, n, radius, (int32_t *)nullptr, ptr, idx);
