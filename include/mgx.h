@@ -344,6 +344,52 @@ int mgx_mvn_update(mgx_mvn *m);
 int mgx_mvn_combine(const mgx_mvn *a, const mgx_mvn *b, int32_t op, mgx_mvn **out);
 int mgx_mvn_combine_assign(mgx_mvn *a, const mgx_mvn *b, int32_t op);
 
+/* ---- environment rasteriser (scenario front-end) --------------------------- */
+/* gbp_environment::Environment (crates/gbp_environment/src/lib.rs:729-735) as plain data, and
+ * env_to_png::env_to_image / env_to_sdf_image (crates/env_to_png/src/lib.rs:149-206) computed on
+ * the device: what simulation_loader.rs:154-162 runs for each scenario to produce the image the
+ * obstacle factors sample.  Images are interleaved RGB u8 (R = G = B), row-major,
+ * (n_cols * resolution) x (n_rows * resolution).  Invalid input (a value the reference's
+ * Percentage / StrictlyPositiveFinite / Angle / RelativePoint constructors reject, an empty grid)
+ * returns MGX_ERR_INVALID where the reference panics or returns Err. */
+#define MGX_SHAPE_CIRCLE 0          /* radius                         (lib.rs:114-143) */
+#define MGX_SHAPE_TRIANGLE 1        /* angle_a, angle_b, radius       (lib.rs:158-223) */
+#define MGX_SHAPE_REGULAR_POLYGON 2 /* sides, radius                  (lib.rs:232-300) */
+#define MGX_SHAPE_POLYGON 3         /* n_points, points_xy            (lib.rs:345-415) */
+#define MGX_SHAPE_RECTANGLE 4       /* width, height                  (lib.rs:305-340) */
+typedef struct mgx_env_obstacle { /* gbp_environment::Obstacle (lib.rs:531-543) */
+    int32_t shape;                /* MGX_SHAPE_*                                              */
+    int32_t tile_row, tile_col;   /* tile_coordinates                                         */
+    uint32_t sides;               /* regular polygon                                          */
+    uint32_t n_points;            /* polygon                                                  */
+    const double *points_xy;      /* polygon: n_points (x, y) pairs, each in [0, 1]           */
+    double radius;                /* circle, triangle (inscribed circle), regular polygon     */
+    double angle_a, angle_b;      /* triangle: Angles { A, B } in radians                     */
+    double width, height;         /* rectangle                                                */
+    double rotation;              /* radians in [0, 2 pi] (angle::Angle)                      */
+    double translation_x, translation_y; /* RelativePoint: each in [0, 1]                     */
+} mgx_env_obstacle;
+typedef struct mgx_env_desc {
+    uint32_t n_rows, n_cols;      /* TileGrid::shape (lib.rs:45-63)                           */
+    const uint32_t *tiles;        /* n_rows * n_cols Unicode scalar values, row-major         */
+    float tile_size, path_width;  /* TileSettings (lib.rs:589-597)                            */
+    uint32_t sdf_resolution;      /* SdfSettings (lib.rs:599-617): pixels per tile,           */
+    float sdf_expansion, sdf_blur; /*   expansion and blur as fractions of a tile             */
+    uint32_t n_obstacles;
+    const mgx_env_obstacle *obstacles;
+} mgx_env_desc;
+int mgx_env_image_size(const mgx_env_desc *env, uint32_t resolution, uint32_t *width, uint32_t *height);
+/* env_to_image(env, resolution, expansion) (env_to_png lib.rs:165-206) */
+int mgx_env_to_image(const mgx_env_desc *env, uint32_t resolution, float expansion, uint8_t *rgb);
+/* env_to_sdf_image(env, resolution, expansion, blur_percent) (lib.rs:149-163): the image above,
+ * blurred with image::imageops::blur(sigma = blur_percent * resolution) unless sigma < 1 */
+int mgx_env_to_sdf_image(const mgx_env_desc *env, uint32_t resolution, float expansion,
+                         float blur_percent, uint8_t *rgb);
+/* The call chain of simulation_loader.rs:154-162 + robot.rs:1259-1264: rasterise with the
+ * environment's own sdf settings and install the result as the world's obstacle image, world
+ * size = tile_size * (n_cols, n_rows). */
+int mgx_world_set_environment(mgx_world *w, const mgx_env_desc *env);
+
 /* ---- host helpers (no device needed) --------------------------------------------------- */
 /* gbp_schedule: fills steps[max(n_int,n_ext)] with MGX_STEP_* bits. Returns the count
  * or a negative status. (crates/gbp_schedule/src/schedules/ *.rs) */

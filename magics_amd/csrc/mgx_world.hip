@@ -50,6 +50,8 @@ hipError_t launch_halo_wait_unpack(const DevWorld &w, int n, const int32_t *ghos
                                    const unsigned long long *flags, unsigned long long seq, unsigned long long *err,
                                    long long timeout_ticks, hipStream_t stream);
 // mgx_topology.hip
+int env_red_plane(const mgx_env_desc *d, uint32_t resolution, float expansion, float blur_percent, bool with_blur, hipStream_t s,
+                  std::vector<uint8_t> &red, uint32_t &W, uint32_t &H);  // mgx_env.hip
 hipError_t neighbours_count(const float *pos, int n, float radius, bool grid, uint32_t M, int32_t *cnt, int32_t *bucket_cnt,
                             int32_t *bucket_ptr, int32_t *cursor, int32_t *members, int32_t *special, int32_t *n_special,
                             int32_t *ptr, hipStream_t s);
@@ -1003,6 +1005,18 @@ int mgx_world_set_sdf(mgx_world *w, const uint8_t *rgb, uint32_t width, uint32_t
     w->sdf_red.resize((size_t)width * height);
     for (size_t i = 0; i < w->sdf_red.size(); i++) w->sdf_red[i] = rgb[3 * i];  // pixel[0], obstacle.rs:178
     w->sdf_w = width; w->sdf_h = height; w->world_w = world_w; w->world_h = world_h;
+    w->dirty = true;
+    return MGX_OK;
+}
+
+int mgx_world_set_environment(mgx_world *w, const mgx_env_desc *env) {
+    if (!w || !env) return fail(MGX_ERR_INVALID, "null argument");
+    uint32_t W = 0, H = 0;
+    const int rc = env_red_plane(env, env->sdf_resolution, env->sdf_expansion, env->sdf_blur, true, w->stream, w->sdf_red, W, H);
+    if (rc != MGX_OK) return rc;
+    w->sdf_w = W; w->sdf_h = H;
+    w->world_w = (double)env->tile_size * (double)env->n_cols;  // robot.rs:1259-1264
+    w->world_h = (double)env->tile_size * (double)env->n_rows;
     w->dirty = true;
     return MGX_OK;
 }

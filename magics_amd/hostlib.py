@@ -64,6 +64,43 @@ class RobotDesc(C.Structure):
     ]
 
 
+SHAPE_CIRCLE, SHAPE_TRIANGLE, SHAPE_REGULAR_POLYGON, SHAPE_POLYGON, SHAPE_RECTANGLE = range(5)
+
+
+class EnvObstacle(C.Structure):
+    _fields_ = [
+        ("shape", C.c_int32),
+        ("tile_row", C.c_int32),
+        ("tile_col", C.c_int32),
+        ("sides", C.c_uint32),
+        ("n_points", C.c_uint32),
+        ("points_xy", c_double_p),
+        ("radius", C.c_double),
+        ("angle_a", C.c_double),
+        ("angle_b", C.c_double),
+        ("width", C.c_double),
+        ("height", C.c_double),
+        ("rotation", C.c_double),
+        ("translation_x", C.c_double),
+        ("translation_y", C.c_double),
+    ]
+
+
+class EnvDesc(C.Structure):
+    _fields_ = [
+        ("n_rows", C.c_uint32),
+        ("n_cols", C.c_uint32),
+        ("tiles", C.POINTER(C.c_uint32)),
+        ("tile_size", C.c_float),
+        ("path_width", C.c_float),
+        ("sdf_resolution", C.c_uint32),
+        ("sdf_expansion", C.c_float),
+        ("sdf_blur", C.c_float),
+        ("n_obstacles", C.c_uint32),
+        ("obstacles", C.POINTER(EnvObstacle)),
+    ]
+
+
 # every symbol include/mgx.h declares: name -> (restype, argtypes)
 _V = C.c_void_p
 SYMBOLS = {
@@ -73,6 +110,10 @@ SYMBOLS = {
     "mgx_set_stream": (C.c_int, [_V, _V]),
     "mgx_synchronize": (C.c_int, [_V]),
     "mgx_world_set_sdf": (C.c_int, [_V, _V, C.c_uint32, C.c_uint32, C.c_double, C.c_double]),
+    "mgx_env_image_size": (C.c_int, [C.POINTER(EnvDesc), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "mgx_env_to_image": (C.c_int, [C.POINTER(EnvDesc), C.c_uint32, C.c_float, C.c_void_p]),
+    "mgx_env_to_sdf_image": (C.c_int, [C.POINTER(EnvDesc), C.c_uint32, C.c_float, C.c_float, C.c_void_p]),
+    "mgx_world_set_environment": (C.c_int, [_V, C.POINTER(EnvDesc)]),
     "mgx_robot_add": (C.c_int, [_V, C.POINTER(RobotDesc), C.POINTER(C.c_int32)]),
     "mgx_robot_remove": (C.c_int, [_V, C.c_int32]),
     "mgx_ir_connect": (C.c_int, [_V, C.c_int32, C.c_int32, C.c_uint64]),

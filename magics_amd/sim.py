@@ -1,0 +1,189 @@
+"""Headless run of a reference scenario directory (config.toml + environment.yaml + formation.yaml,
+unmodified) on a World-like backend — the HIP engine (`magics_amd.World`) in the product, the CPU
+oracle in the tests.  One `tick()` is one FixedUpdate of the reference at `simulation.hz`, preceded
+by the frame's Update systems that matter to the path (the formation spawners):
+
+    advance_time + spawn_formation          crates/magics/src/planner/spawner.rs:386-649   (Update)
+    reached_waypoint                        planner/robot.rs:2080-2176                     \\
+    update_robot_neighbours / delete_ / create_interrobot_factors   robot.rs:1362-1586      |
+    update_failed_comms                     robot.rs:1593-1601                               > FixedUpdate
+    update_prior_of_horizon_state / update_prior_of_current_state_v3   robot.rs:2182-2338   |
+    iterate_gbp_v2                          robot.rs:1769-1861                              /
+    export                                  crates/magics/src/export.rs:249-262,283-620
+
+The reference runs its Update systems at the display's frame rate against virtual time, so the
+interleaving of spawns with fixed ticks is not reproducible there; here a frame is exactly one
+fixed tick long.  Rendering, picking, RRT* planning (`planning-strategy: rrt-star` is rejected),
+collision bookkeeping with parry2d and goal areas are outside the path (SURVEY §8 out of scope).
+"""
+import json
+
+import numpy as np
+
+from . import config as _config
+from . import environment as _environment
+from . import hostlib, spawner
+from .prng import WyRand
+from .scenarios import robot_initial_state
+
+F = np.float32
+
+
+class Simulation:
+    def __init__(self, scenario, world, neighbours_method=hostlib.NEIGHBOURS_AUTO):
+        """scenario: `config.load_scenario(dir)` (or a dict of the same shape); world: a fresh
+        World-like object created with `config.world_params(scenario["config"])`."""
+        self.name = scenario.get("name", "")
+        self.cfg, self.env, self.formations = scenario["config"], scenario["environment"], scenario["formation"]["formations"]
+        self.w = world
+        sim, gbp = self.cfg["simulation"], self.cfg["gbp"]
+        self.hz = sim["hz"]
+        self.dt_ns = int(round(1e9 / self.hz))                   # Time::<Fixed>::from_hz
+        self.dt32 = F(self.dt_ns * 1e-9)                         # Time<Fixed>::delta_seconds
+        self.rng = WyRand(sim["prng-seed"])                      # simulation_loader.rs:651-652
+        self.world_dims = _environment.world_size(self.env)      # spawner.rs:437-442
+        sch = gbp["iteration-schedule"]
+        self.steps = hostlib.schedule(_config.SCHEDULE_KINDS[sch["schedule"]], sch["internal"], sch["external"])
+        self.comms_radius = self.cfg["robot"]["communication"]["radius"]
+        self.failure_rate = float(F(self.cfg["robot"]["communication"]["failure-rate"]))
+        self.max_speed = self.cfg["robot"]["target-speed"]
+        self.despawn = sim["despawn-robot-when-final-waypoint-reached"]
+        self.method = neighbours_method
+        world.set_environment(self.env)                          # simulation_loader.rs:154-162
+        self.spawners = [spawner.FormationSpawner(i, f) for i, f in enumerate(self.formations)]
+        self.robots = []           # per robot: dict (see _add_robot)
+        self.translation = np.zeros((0, 3), dtype=F)
+        self.tick_no, self.next_number, self.K = 0, 1, None
+        self.events = []           # (tick, connections created, pairs deleted)
+
+    # -- spawn_formation (spawner.rs:415-649) + RobotBundle::new (robot.rs:1134-1356) -------------------
+    def _add_robot(self, desc, formation_index):
+        if desc["planning-strategy"] != "only-local":
+            raise NotImplementedError("planning-strategy rrt-star: the global planner is outside the hot path")
+        rb = self.cfg["robot"]
+        states = desc["waypoints"]
+        mean0, prior, dt = robot_initial_state(states[0], states[1], desc["timesteps"], desc["radius"], rb["target-speed"], rb["planning-horizon"])
+        if self.K is None:
+            self.K = len(desc["timesteps"])
+        path = np.array([s[:2] for s in states], dtype=np.float32)  # the route's positions (robot.rs:1310-1315)
+        rid = self.w.add_robot(mean0, prior, dt, float(desc["radius"]), path=path)
+        assert rid == len(self.robots)
+        t0 = F(desc["radius"]) / F(2.0) / F(rb["target-speed"])
+        self.robots.append({"id": rid, "formation": formation_index, "radius": F(desc["radius"]), "waypoints": [s.copy() for s in states],
+                            "target": 1, "alive": True, "completed": False, "started_at": self.elapsed(), "finished_at": None,
+                            "time_scale": float(self.dt32 / t0), "colour": desc["colour"], "rng": desc["rng"],
+                            "strategy": desc["planning-strategy"], "reach": desc["waypoint-reached-when-intersects"],
+                            "finish": desc["finished-when-intersects"], "positions": [], "travelled": 0.0})
+        self.translation = np.vstack([self.translation, np.array([[states[0][0], -1.5, states[0][1]]], dtype=F)])  # spawner.rs:548
+
+    def _spawn(self):
+        for sp in self.spawners:
+            sp.tick(self.dt_ns)
+            if sp.ready_to_spawn():
+                sp.spawn()
+                descs = spawner.spawn_formation(self.formations[sp.index], self.cfg, self.world_dims, self.rng)
+                for d in descs or []:  # None: "failed to spawn formation", the reference logs and skips
+                    self._add_robot(d, sp.index)
+
+    def elapsed(self):
+        return self.tick_no * self.dt_ns * 1e-9
+
+    # -- reached_waypoint (robot.rs:2080-2176) --------------------------------------------------------------
+    def _reached_waypoint(self):
+        todo = [r for r in self.robots if r["alive"] and not r["completed"]]
+        if not todo:
+            return
+        means = {}
+
+        def mean_of(var):
+            if var not in means:
+                means[var] = self.w.read_variable_means(var)
+            return means[var]
+        for r in todo:
+            last = r["target"] == len(r["waypoints"]) - 1
+            when = r["finish"] if last else r["reach"]
+            kind, n = when["intersects-with"]
+            var = 0 if kind == "current" else (self.K - 1 if kind == "horizon" or n >= self.K else n)
+            est = mean_of(var)[r["id"], :2].astype(F)
+            dkind, meter = when["distance"]
+            limit = r["radius"] * r["radius"] if dkind == "robot-radius" else F(meter) * F(meter)
+            d = est - r["waypoints"][r["target"]][:2]
+            if F(d[0] * d[0] + d[1] * d[1]) < limit:
+                r["target"] += 1                                   # Route::advance
+                if r["target"] >= len(r["waypoints"]):             # Mission::next_route: the only route is done
+                    r["completed"], r["finished_at"] = True, self.elapsed()
+                    if self.despawn:
+                        self.w.remove_robot(r["id"])
+                        r["alive"] = False
+
+    def tick(self):
+        w = self.w
+        self._spawn()
+        if self.robots:
+            self._reached_waypoint()
+            self.next_number, created, deleted = w.update_topology(self.translation, self.comms_radius, self.next_number, method=self.method)
+            if created or deleted:
+                self.events.append((self.tick_no, created, deleted))
+            live = [r for r in self.robots if r["alive"]]
+            if live:
+                active = np.array([not self.rng.gen_bool(self.failure_rate) for _ in live], dtype=np.uint8)  # robot.rs:1599
+                if self.failure_rate > 0.0:
+                    w.set_antennas(np.array([r["id"] for r in live], dtype=np.int32), active)
+            moving = [r for r in live if not r["completed"]]
+            if moving:
+                ids = np.array([r["id"] for r in moving], dtype=np.int32)
+                m0, m1 = w.read_variable_means(0), w.read_variable_means(1)
+                ts = np.array([r["time_scale"] for r in moving])
+                change = ts[:, None] * (m1[ids] - m0[ids])                                   # robot.rs:2314
+                w.update_priors(robots=ids, waypoints_xy=np.array([r["waypoints"][r["target"]][:2] for r in moving], dtype=np.float64),
+                                time_scale=ts, what=np.full(len(moving), 3, dtype=np.uint8), max_speed=float(self.max_speed),
+                                delta_t=float(self.dt32))
+                self.translation[ids, 0] += change[:, 0].astype(F)                          # robot.rs:2328-2329
+                self.translation[ids, 2] += change[:, 1].astype(F)
+                for r, c in zip(moving, change):
+                    r["travelled"] += float(np.hypot(c[0], c[1]))
+            w.iterate(self.steps)
+            for r in live:  # PositionTracker (spawner.rs:620): sampled once per tick here
+                r["positions"].append([float(self.translation[r["id"], 0]), float(self.translation[r["id"], 2])])
+        self.tick_no += 1
+
+    def finished(self):
+        """AllFormationsFinished: every spawner is exhausted and every spawned robot completed its mission."""
+        return all(sp.exhausted() for sp in self.spawners) and all(r["completed"] for r in self.robots)
+
+    def run(self, max_ticks=None, max_time=None):
+        limit = self.cfg["simulation"]["max-time"] if max_time is None else max_time
+        while not self.finished() and self.elapsed() < limit and (max_ticks is None or self.tick_no < max_ticks):
+            self.tick()
+        return self
+
+    # -- export (export.rs:249-262, 283-620) ------------------------------------------------------------------
+    def export(self):
+        sch = self.cfg["gbp"]["iteration-schedule"]
+        robots = {}
+        for r in self.robots:
+            sent_i, sent_e, recv_i, recv_e = self.w.message_counts(r["id"])
+            wps = [[float(s[0]), float(s[1])] for s in r["waypoints"]]
+            fin = r["finished_at"] if r["finished_at"] is not None else self.elapsed()
+            robots[str(r["id"])] = {
+                "radius": float(r["radius"]), "positions": r["positions"], "velocities": [],
+                "collisions": {"robots": 0, "environment": 0},
+                "messages": {"sent": {"internal": sent_i, "external": sent_e}, "received": {"internal": recv_i, "external": recv_e}},
+                "mission": {"waypoints": [wps[0], wps[-1]], "started_at": r["started_at"], "finished_at": fin,
+                            "routes": [{"waypoints": wps, "started_at": r["started_at"], "finished_at": fin}]},
+                "planning_strategy": r["strategy"], "color": r["colour"]}
+        return {"scenario": self.name, "makespan": self.elapsed(), "delta_t": float(self.dt32),
+                "gbp": {"iterations": {"internal": sch["internal"], "external": sch["external"]}}, "robots": robots,
+                "prng_seed": self.cfg["simulation"]["prng-seed"], "config": self.cfg, "obstacles": {},
+                "collisions": {"robots": [], "environment": []}, "goal_areas": {}}
+
+    def export_json(self, path):
+        with open(path, "w", encoding="utf-8") as f:
+            json.dump(self.export(), f)
+
+
+def run_scenario(directory, world_factory, max_ticks=None, max_time=None):
+    """Load a scenario directory and run it to the end (or the given bound)."""
+    sc = _config.load_scenario(directory)
+    sim = Simulation(sc, world_factory(_config.world_params(sc["config"])))
+    return sim.run(max_ticks=max_ticks, max_time=max_time)

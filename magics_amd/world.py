@@ -74,6 +74,13 @@ class World:
         h, w, _ = rgb.shape
         self._chk(self._L.mgx_world_set_sdf(self._w, rgb.ctypes.data, w, h, float(world_w), float(world_h)))
 
+    def set_environment(self, env):
+        """simulation_loader.rs:154-162 + robot.rs:1259-1264: rasterise + blur the environment on the
+        device with its own sdf settings and use the result as the obstacle image."""
+        from .environment import _Desc
+        d = _Desc(env)
+        self._chk(self._L.mgx_world_set_environment(self._w, C.byref(d.desc)))
+
     def add_robot(self, mean0, prior_diag, dt, radius, path=None, order_key=None, ghost=False):
         mean0 = _f64(mean0)
         K = mean0.shape[0]

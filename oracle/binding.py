@@ -162,6 +162,14 @@ class OracleWorld:
         assert c == 3
         self._chk(self._L.orc_world_set_sdf(self._w, rgb.ctypes.data, w, h, float(world_w), float(world_h)))
 
+    def set_environment(self, env):
+        """simulation_loader.rs:154-162 + robot.rs:1259-1264 through the CPU rasteriser (oracle/env.py)."""
+        from . import env as _env
+        red = _env.env_to_sdf_image(env)
+        nrows, ncols = len(env["tiles"]["grid"]), len(env["tiles"]["grid"][0])
+        ts = float(np.float32(env["tiles"]["settings"]["tile-size"]))
+        self.set_sdf(np.repeat(red[:, :, None], 3, axis=2), ts * ncols, ts * nrows)
+
     def add_robot(self, mean0, prior_diag, dt, radius, path=None, order_key=None, ghost=False):
         mean0 = _f64(mean0)
         K = mean0.shape[0]
