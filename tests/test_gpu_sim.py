@@ -1,0 +1,76 @@
+"""GPU parity of whole scenario runs: the reference's scenario files (as parsed into
+tests/golden/scenarios.json) driven headless on the HIP engine and on the CPU oracle — same spawns,
+same topology events, same trajectories, beliefs bit for bit, same export."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from magics_amd import World, config, sim
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _scenario(name):
+    with open(os.path.join(ROOT, "tests", "golden", "scenarios.json"), encoding="utf-8") as f:
+        return json.load(f)[name]
+
+
+def _pair(sc):
+    p = config.world_params(sc["config"])
+    return sim.Simulation(sc, World(p)), sim.Simulation(sc, oracle.OracleWorld(p))
+
+
+def _run_both(name, ticks, check_every=10, tweak=None):
+    sc = _scenario(name)
+    if tweak:
+        tweak(sc)
+    a, b = _pair(sc)
+    for t in range(ticks):
+        a.tick()
+        b.tick()
+        if (t + 1) % check_every == 0 or t == ticks - 1:
+            assert len(a.robots) == len(b.robots)
+            assert np.array_equal(a.translation, b.translation), f"tick {t}"
+            if a.robots:
+                for x, y in zip(a.w.read_beliefs(), b.w.read_beliefs()):
+                    assert np.array_equal(x, y), f"tick {t}"
+    assert a.events == b.events
+    assert json.dumps(a.export(), sort_keys=True) == json.dumps(b.export(), sort_keys=True)
+    return a
+
+
+def test_junction_twoway():
+    s = _run_both("Junction Twoway", 90)
+    assert len(s.robots) >= 12 and s.K == 12 and s.events
+    moved = np.hypot(s.translation[:4, 0] - [r["waypoints"][0][0] for r in s.robots[:4]],
+                     s.translation[:4, 2] - [r["waypoints"][0][1] for r in s.robots[:4]])
+    assert (moved > 20).all()
+
+
+def test_circle_experiment():
+    def fewer(sc):  # 12 of the 30 robots: the oracle side stays within seconds
+        sc["formation"]["formations"][0]["robots"] = 12
+    s = _run_both("Circle Experiment", 45, tweak=fewer)
+    assert len(s.robots) == 12 and s.K == 21 and s.events
+
+
+def test_environment_obstacles_experiment_with_comms_failures():
+    def failing(sc):
+        sc["config"]["robot"]["communication"]["failure-rate"] = 0.3
+    s = _run_both("Environment Obstacles Experiment", 70, tweak=failing)
+    assert len(s.robots) == 5
+
+
+def test_robots_finish_and_despawn():
+    def short(sc):  # bring the far side of the circle within reach of a short run
+        f = sc["formation"]["formations"][0]
+        f["robots"] = 6
+        f["initial-position"]["shape"]["radius"] = 12.0
+        f["waypoints"][0]["shape"]["radius"] = 12.0
+    s = _run_both("Circle Experiment", 60, tweak=short)
+    assert any(r["completed"] for r in s.robots)
+    assert all((not r["alive"]) == r["completed"] for r in s.robots)
