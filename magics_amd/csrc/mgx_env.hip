@@ -142,55 +142,95 @@ __device__ bool shape_inside(const EnvObstacle &o, const double *pts, float x, f
     }
 }
 
-// env_to_image (lib.rs:165-206): one thread per pixel of the red plane
+// four horizontally adjacent bytes per thread go out as one 32-bit store when the rows allow it
+__device__ __forceinline__ void store4(uint8_t *__restrict__ out, uint32_t W, uint32_t x, uint32_t y, const uint8_t (&v)[4]) {
+    uint8_t *p = out + (size_t)y * W + x;
+    if ((W & 3u) == 0 && x + 3 < W) {
+        *reinterpret_cast<uint32_t *>(p) = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+    } else {
+        for (uint32_t i = 0; i < 4 && x + i < W; i++) p[i] = v[i];
+    }
+}
+
+// env_to_image (lib.rs:165-206): one thread per four pixels of a row of the red plane
 __global__ void __launch_bounds__(256) k_env_raster(EnvRaster e, uint8_t *__restrict__ out) {
-    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= e.W || y >= e.H) return;
-    const uint32_t tcx = (uint32_t)floorf((float)x / e.res_f), tcy = (uint32_t)floorf((float)y / e.res_f);  // lib.rs:248-257
-    const float px = pixel_percentage(x, e.res_f, e.tile_size), py = pixel_percentage(y, e.res_f, e.tile_size);
-    if (!(px >= 0.0f && px <= 1.0f && py >= 0.0f && py <= 1.0f) || tcx >= e.n_cols || tcy >= e.n_rows) {
-        *e.error = 1;  // Percentage::new assert / "Tile not found"
-        return;
+    const uint32_t x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+    if (x0 >= e.W || y >= e.H) return;
+    const uint32_t tcy = (uint32_t)floorf((float)y / e.res_f);  // lib.rs:248-257
+    const float py = pixel_percentage(y, e.res_f, e.tile_size);
+    uint8_t v[4] = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < 4 && x0 + i < e.W; i++) {
+        const uint32_t x = x0 + i;
+        const uint32_t tcx = (uint32_t)floorf((float)x / e.res_f);
+        const float px = pixel_percentage(x, e.res_f, e.tile_size);
+        if (!(px >= 0.0f && px <= 1.0f && py >= 0.0f && py <= 1.0f) || tcx >= e.n_cols || tcy >= e.n_rows) {
+            *e.error = 1;  // Percentage::new assert / "Tile not found"
+            continue;
+        }
+        bool obstacle = tile_obstacle(e.tiles[tcy * e.n_cols + tcx], px, py, e);
+        for (int q = 0; q < e.n_obstacles && !obstacle; q++) {  // is_placeable_obstacle (lib.rs:279-336)
+            const EnvObstacle &o = e.obstacles[q];
+            if ((uint32_t)o.col != tcx || (uint32_t)o.row != tcy) continue;
+            const float tx = px - o.tx, ty = py - o.ty;
+            // glam Quat::from_rotation_z(a).mul_vec3((tx, ty, 0)): v (w w - b.b) + b (2 v.b) + (w (b x v)) 2, b = (0, 0, s)
+            const float rx = (tx * o.k + 0.0f) + (o.c * (0.0f - ty * o.s)) * 2.0f;
+            const float ry = (ty * o.k + 0.0f) + (o.c * (o.s * tx)) * 2.0f;
+            obstacle = shape_inside(o, e.pts, rx, ry);
+        }
+        v[i] = obstacle ? 0 : 255;
     }
-    bool obstacle = tile_obstacle(e.tiles[tcy * e.n_cols + tcx], px, py, e);
-    for (int q = 0; q < e.n_obstacles && !obstacle; q++) {  // is_placeable_obstacle (lib.rs:279-336)
-        const EnvObstacle &o = e.obstacles[q];
-        if ((uint32_t)o.col != tcx || (uint32_t)o.row != tcy) continue;
-        const float tx = px - o.tx, ty = py - o.ty;
-        // glam Quat::from_rotation_z(a).mul_vec3((tx, ty, 0)): v (w w - b.b) + b (2 v.b) + (w (b x v)) 2, b = (0, 0, s)
-        const float rx = (tx * o.k + 0.0f) + (o.c * (0.0f - ty * o.s)) * 2.0f;
-        const float ry = (ty * o.k + 0.0f) + (o.c * (o.s * tx)) * 2.0f;
-        obstacle = shape_inside(o, e.pts, rx, ry);
-    }
-    out[(size_t)y * e.W + x] = obstacle ? 0 : 255;
+    store4(out, e.W, x0, y, v);
 }
 
 // imageops::blur, first pass (vertical_sample): u8 plane -> f32 plane.  Row `o` of the output is the
-// weighted sum of rows left[o] .. left[o] + cnt[o] - 1, accumulated in f32 in tap order.
+// weighted sum of rows left[o] .. left[o] + cnt[o] - 1, accumulated in f32 in tap order.  One thread
+// per four pixels of a row: a 32-bit load per tap, a 16-byte store.
 __global__ void __launch_bounds__(256) k_blur_vertical(const uint8_t *__restrict__ src, float *__restrict__ tmp, uint32_t W, uint32_t H,
                                                        const int32_t *__restrict__ left, const int32_t *__restrict__ cnt,
                                                        const float *__restrict__ wgt, int T) {
-    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, o = blockIdx.y;
-    if (x >= W || o >= H) return;
+    const uint32_t x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, o = blockIdx.y;
+    if (x0 >= W || o >= H) return;
     const int l = left[o], n = cnt[o];
     const float *w = wgt + (size_t)o * T;
-    float t = 0.0f;
-    for (int i = 0; i < n; i++) t += (float)src[(size_t)(l + i) * W + x] * w[i];
-    tmp[(size_t)o * W + x] = t;
+    float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if ((W & 3u) == 0) {
+        for (int i = 0; i < n; i++) {
+            const uint32_t q = *reinterpret_cast<const uint32_t *>(src + (size_t)(l + i) * W + x0);
+            const float wi = w[i];
+#pragma unroll
+            for (int c = 0; c < 4; c++) t[c] += (float)((q >> (8 * c)) & 0xffu) * wi;
+        }
+        *reinterpret_cast<float4 *>(tmp + (size_t)o * W + x0) = make_float4(t[0], t[1], t[2], t[3]);
+    } else {
+        for (uint32_t c = 0; c < 4 && x0 + c < W; c++) {
+            for (int i = 0; i < n; i++) t[c] += (float)src[(size_t)(l + i) * W + x0 + c] * w[i];
+            tmp[(size_t)o * W + x0 + c] = t[c];
+        }
+    }
 }
-// second pass (horizontal_sample): f32 plane -> u8, clamp to [0, 255] and round half away from zero
+// second pass (horizontal_sample): f32 plane -> u8, clamp to [0, 255] and round half away from zero.
+// One output per thread (neighbouring threads read neighbouring floats); four lanes then merge their
+// bytes so that every fourth lane issues one 32-bit store.
 __global__ void __launch_bounds__(256) k_blur_horizontal(const float *__restrict__ tmp, uint8_t *__restrict__ out, uint32_t W, uint32_t H,
                                                          const int32_t *__restrict__ left, const int32_t *__restrict__ cnt,
                                                          const float *__restrict__ wgt, int T) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (o >= W || y >= H) return;
-    const int l = left[o], n = cnt[o];
-    const float *w = wgt + (size_t)o * T;
-    const float *row = tmp + (size_t)y * W;
-    float t = 0.0f;
-    for (int i = 0; i < n; i++) t += row[l + i] * w[i];
-    t = (t < 0.0f) ? 0.0f : (t > 255.0f ? 255.0f : t);
-    out[(size_t)y * W + o] = (uint8_t)roundf(t);
+    uint32_t v = 0;
+    if (o < W) {
+        const int l = left[o], n = cnt[o];
+        const float *row = tmp + (size_t)y * W;
+        float t = 0.0f;
+        for (int i = 0; i < n; i++) t += row[l + i] * wgt[(size_t)i * W + o];  // tap-major table: lanes read neighbours
+        t = (t < 0.0f) ? 0.0f : (t > 255.0f ? 255.0f : t);
+        v = (uint32_t)roundf(t);
+    }
+    const uint32_t v1 = __shfl_down(v, 1, 64), v2 = __shfl_down(v, 2, 64), v3 = __shfl_down(v, 3, 64);
+    if (o >= W) return;
+    if ((W & 3u) == 0) {
+        if ((o & 3u) == 0) *reinterpret_cast<uint32_t *>(out + (size_t)y * W + o) = v | (v1 << 8) | (v2 << 16) | (v3 << 24);
+    } else {
+        out[(size_t)y * W + o] = (uint8_t)v;
+    }
 }
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -361,7 +401,7 @@ int env_red_plane(const mgx_env_desc *d, uint32_t resolution, float expansion, f
     ENV_HIP(plane.alloc((size_t)W * H));
     e.n_obstacles = (int)obs.size();
     e.tiles = tiles_d.p; e.obstacles = obs_d.p; e.pts = pts_d.p; e.error = err_d.p;
-    const dim3 grid((W + 255) / 256, H), block(256);
+    const dim3 grid((W + 1023) / 1024, H), block(256);  // four pixels of a row per thread
     hipLaunchKernelGGL(k_env_raster, grid, block, 0, s, e, plane.p);
     ENV_HIP(hipGetLastError());
     const uint8_t *result = plane.p;
@@ -377,12 +417,18 @@ int env_red_plane(const mgx_env_desc *d, uint32_t resolution, float expansion, f
         int TV = 0, TH = 0;
         blur_taps(H, sigma, vl, vc, vw, TV);
         blur_taps(W, sigma, hl, hc, hw, TH);
+        {  // the horizontal pass reads its weights tap-major ([tap][column]) so that a wave's loads coalesce
+            std::vector<float> t((size_t)W * TH);
+            for (uint32_t o = 0; o < W; o++)
+                for (int i = 0; i < TH; i++) t[(size_t)i * W + o] = hw[(size_t)o * TH + i];
+            hw.swap(t);
+        }
         ENV_HIP(vl_d.put(vl, s)); ENV_HIP(vc_d.put(vc, s)); ENV_HIP(vw_d.put(vw, s));
         ENV_HIP(hl_d.put(hl, s)); ENV_HIP(hc_d.put(hc, s)); ENV_HIP(hw_d.put(hw, s));
         ENV_HIP(tmp.alloc((size_t)W * H));
         ENV_HIP(blurred.alloc((size_t)W * H));
         hipLaunchKernelGGL(k_blur_vertical, grid, block, 0, s, plane.p, tmp.p, W, H, vl_d.p, vc_d.p, vw_d.p, TV);
-        hipLaunchKernelGGL(k_blur_horizontal, grid, block, 0, s, tmp.p, blurred.p, W, H, hl_d.p, hc_d.p, hw_d.p, TH);
+        hipLaunchKernelGGL(k_blur_horizontal, dim3((W + 255) / 256, H), block, 0, s, tmp.p, blurred.p, W, H, hl_d.p, hc_d.p, hw_d.p, TH);
         ENV_HIP(hipGetLastError());
         result = blurred.p;
     }

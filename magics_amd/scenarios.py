@@ -277,6 +277,68 @@ def circle_scenario(n_robots=10, K=10, circle_radius=50.0, seed=805, n_internal=
                 name=f"circle{n_robots}x{K}", target_speed=target_speed)
 
 
+def junction_environment(tiles):
+    """`tiles` x `tiles` crossroads with the settings of config/scenarios/Junction Twoway/environment.yaml
+    (tile-size 100, path-width 0.16, sdf: 200 px / tile, expansion 0.01, blur 0.01)."""
+    from . import environment
+    return environment.new(["┼" * tiles] * tiles, 0.16, 2.0, 100.0, sdf={"resolution": 200, "expansion": 0.01, "blur": 0.01})
+
+
+def junction_scenario(n_robots, K=32, tiles=None, comm_radius=20.0, seed=805, target_speed=5.0, radius=1.0,
+                      n_internal=10, n_external=10, tracking=True, interrobot=True):
+    """BASELINE.json configs[4] (SURVEY.md §8d "Config 5"): a `tiles` x `tiles` grid of two-way
+    crossroads rasterised by the env_to_png rule ON THE DEVICE (World.set_environment), robots on
+    the lanes of config/scenarios/Junction Twoway/formation.yaml (4 m off the centre line, entering
+    from the four sides, turning left / right or driving across), each with its 2-3 point lane
+    polyline as tracking path, Junction Twoway sigmas and communication radius."""
+    rng = SplitMix64(seed)
+    per_tile = 10
+    if tiles is None:
+        tiles = max(1, int(math.ceil(math.sqrt(n_robots / per_tile))))
+    per_tile = int(math.ceil(n_robots / (tiles * tiles)))
+    ts = timesteps_for_K(K)
+    planning_horizon = HORIZON_FOR_K[K] / target_speed
+    half = 50.0
+
+    def turn(p, k):  # k quarter turns clockwise about the tile centre: entries W -> N -> E -> S
+        x, y = p
+        for _ in range(k):
+            x, y = y, -x
+        return x, y
+    robots, pos = [], []
+    for r in range(n_robots):
+        tile, q = divmod(r, per_tile)
+        row, col = divmod(tile, tiles)
+        cx, cy = (col - (tiles - 1) / 2) * 100.0, ((tiles - 1) / 2 - row) * 100.0
+        entry, slot = q % 4, q // 4
+        lane = 4.0 + rng.uniform(-1.0, 1.0)
+        dist = 5.0 + 11.0 * slot + rng.uniform(-1.5, 1.5)
+        manoeuvre = int(rng.uniform(0.0, 3.0))
+        route = [(-half + dist, lane)]                      # entering from the west, heading east
+        if manoeuvre == 0:
+            route += [(-2.5 + rng.uniform(-1.0, 1.0), lane), (-2.5, half + 15.0)]     # left: north on x = -2.5
+        elif manoeuvre == 1:
+            route += [(lane, lane), (lane, -half - 15.0)]                             # right: south on x = +lane
+        else:
+            route += [(half + 15.0, lane)]                                            # across
+        route = [turn(p, entry) for p in route]
+        route = [(cx + x, cy + y) for x, y in route]
+        hx, hy = turn((1.0, 0.0), entry)
+        start = (route[0][0], route[0][1], target_speed * hx, target_speed * hy)
+        nxt = (route[1][0], route[1][1], target_speed * hx, target_speed * hy)
+        mean0, prior, dt = robot_initial_state(start, nxt, ts, radius, target_speed, planning_horizon)
+        robots.append(dict(mean0=mean0, prior_diag=prior, dt=dt, radius=radius, path=np.array(route, dtype=F32) if tracking else None,
+                           order_key=r, pos=np.array(route[0]), goal=np.array(route[1]), t0=F32(radius) / F32(2.0) / F32(target_speed)))
+        pos.append(route[0])
+    pos = np.array(pos)
+    enable = EN_DYN | EN_OBS | (EN_IR if interrobot else 0) | (EN_TRK if tracking else 0)
+    params = dict(JUNCTION_PARAMS, enable_mask=enable)
+    ir = number_ir_pairs(neighbour_pairs(pos, comm_radius) if interrobot else [], K)
+    steps = hostlib.schedule(hostlib.SCHEDULE_CENTERED, n_internal, n_external if interrobot else 0)
+    return dict(params=params, env=junction_environment(tiles), sdf=None, robots=robots, ir=ir, steps=steps, K=K, positions=pos,
+                target_speed=target_speed, name=f"junction{n_robots}x{K}+{tiles}x{tiles}tiles")
+
+
 def tick_inputs(sc, hz=10.0):
     """Arguments of `update_priors` for one driver tick at `hz` (FixedUpdate, config.simulation.hz):
     every robot heads for its goal; time_scale = fixed_dt / t0 as an f32 quotient (robot.rs:2309)."""
@@ -289,7 +351,10 @@ def tick_inputs(sc, hz=10.0):
 
 def populate(world, sc, robots=None):
     """Feed a scenario to a ``World``-like object. Returns the list of robot ids."""
-    world.set_sdf(sc["sdf"]["rgb"], sc["sdf"]["world_w"], sc["sdf"]["world_h"])
+    if sc.get("env") is not None:
+        world.set_environment(sc["env"])  # rasterised by the backend itself (device / CPU oracle)
+    else:
+        world.set_sdf(sc["sdf"]["rgb"], sc["sdf"]["world_w"], sc["sdf"]["world_h"])
     ids = []
     for rb in sc["robots"]:
         ids.append(world.add_robot(rb["mean0"], rb["prior_diag"], rb["dt"], rb["radius"], path=rb["path"],

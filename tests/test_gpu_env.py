@@ -137,3 +137,19 @@ def test_world_set_environment_feeds_the_obstacle_factors():
     for a, b in zip(eng.read_beliefs(), ref.read_beliefs()):
         assert np.array_equal(a, b)
     assert not np.array_equal(ref.read_beliefs()[2], bare.read_beliefs()[2])
+
+
+def test_junction_scenario_on_device_rasterised_tiles():
+    """BASELINE configs[4] in small: crossroads rasterised on the device, robots on the lanes with
+    tracking paths; beliefs after whole ticks equal the oracle's, whose image comes from the CPU rasteriser."""
+    sc = S.junction_scenario(40, 12, tiles=2)
+    eng, ref = World(sc["params"]), oracle.OracleWorld(sc["params"])
+    S.populate(eng, sc)
+    S.populate(ref, sc)
+    tick = S.tick_inputs(sc)
+    for _ in range(4):
+        for w in (eng, ref):
+            w.update_priors(**tick)
+            w.iterate(sc["steps"])
+    for a, b in zip(eng.read_beliefs(), ref.read_beliefs()):
+        assert np.isfinite(a).all() and np.array_equal(a, b)

@@ -28,5 +28,8 @@ for name, sc, ticks in (
     ("configs[3] per-GPU share: 1000 x 16 +inter-robot (8000 on 8 GPUs)", S.grid_scenario(1000, 16, interrobot=True), 30),
     ("configs[4] per-GPU share: 500 x 32 +inter-robot +tracking (4000 on 8 GPUs)", S.grid_scenario(500, 32, interrobot=True, tracking=True), 30),
     ("configs[4] whole on one GPU: 4000 x 32 +inter-robot +tracking", S.grid_scenario(4000, 32, interrobot=True, tracking=True), 10),
+    ("configs[4] as SURVEY §8d words it: 20 x 20 crossroads rasterised on the device, 4000 x 32 on the lanes +inter-robot +tracking",
+     S.junction_scenario(4000, 32), 10),
+    ("configs[4] per-GPU share of that: 500 x 32 on 7 x 7 crossroads", S.junction_scenario(500, 32, tiles=7), 30),
 ):
     print(f"{name}: {run(sc, ticks):.2f} us / iteration ({len(sc['steps'])}-step schedule)")
