@@ -124,6 +124,12 @@ int mgx_ir_disconnect(mgx_world *w, int32_t a, int32_t b);
 
 /* RadioAntenna.active (robot.rs:1593-1601) and Mission.state.idle() gates of
  * iterate_gbp_v2 (robot.rs:1794,1806,1822,1835,1851). */
+/* FactorGraph::change_factor_enabled(FactorsEnabledSection) applied to every graph
+ * (factorgraph.rs:1529-1539; ui/settings.rs:491-496) and to factors created from now on
+ * (robot.rs:1236,1276,1326,1506 read the same config entry): MGX_FACTOR_* bits.  A disabled factor
+ * keeps its last message in the variable's inbox.  Turning a kind back ON after sweeps or prior
+ * changes ran without it returns MGX_ERR_STATE (known deviation). */
+int mgx_set_enabled(mgx_world *w, uint32_t kind_mask);
 int mgx_set_antenna(mgx_world *w, int32_t robot, int32_t active);
 int mgx_set_idle(mgx_world *w, int32_t robot, int32_t idle);
 

@@ -149,6 +149,8 @@ public:
     }
     // update_robot_neighbours + delete_ + create_interrobot_factors (robot.rs:1362-1586);
     // translations: Transform::translation of every robot (x, y, z as f32), id order
+    /// FactorGraph::change_factor_enabled (factorgraph.rs:1529-1539) for every graph: MGX_FACTOR_* bits
+    void change_factor_enabled(uint32_t kind_mask) { check(mgx_set_enabled(w_, kind_mask)); }
     std::pair<uint32_t, uint32_t> update_topology(const std::vector<std::array<float, 3>> &translations, float comms_radius,
                                                   RobotNumberGenerator &numbers) {
         uint32_t stats[2] = {0, 0};

@@ -106,6 +106,14 @@ __device__ __forceinline__ void copy_words(double *dst, const double *src, int n
     if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
 }
 
+// the same, issued by one wave (64 lanes)
+__device__ __forceinline__ void copy_words_wave(double *dst, const double *src, int n, int lane) {
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    double2 *d2 = reinterpret_cast<double2 *>(dst);
+    for (int t = lane; t < (n >> 1); t += 64) d2[t] = s2[t];
+    if ((n & 1) && lane == 0) dst[n - 1] = src[n - 1];
+}
+
 template <int KT, int IRM>
 __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int robot0, uint32_t ext_mask, uint32_t int_mask,
                                                              int n_int, int snap_out, uint32_t hints) {
@@ -137,8 +145,32 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     const bool idle = w.idle[r] != 0;
     const bool radio = (w.antenna[r] != 0) && !idle;
 
+    // ---- operands of the external factor sweep, requested AROUND the staging copies ------------------
+    // An edge lane needs a chain of dependent loads (gate / constants -> the owner's delivery count and
+    // snapshot record); started here they travel while the blob is staged, instead of after the barrier.
+    // Each thread prefetches its first edge (robots have at most a few more edges than threads).
+    const bool do_extf = HAS_IR && (ext_mask & PH_EXT_FACTOR) && radio && ir_on;
+    bool pf_on = false, pf_present = false;
+    IrEdgeRec pf_er{};
+    double pf_bmu[4] = {0.0, 0.0, 0.0, 0.0}, pf_rec[SNAP_W];
+#pragma unroll
+    for (int c = 0; c < SNAP_W; c++) pf_rec[c] = 0.0;
+    uint8_t pf_gate = 0;
+    if (do_extf && tid < ne) {
+        pf_gate = w.ir_gate[ie0 + tid];
+        pf_er = w.ir_rec[ie0 + tid];
+        ld_soa4(w.ir_bmu, w.NI, ie0 + tid, pf_bmu);
+    }
+
     // ---- stage the robot in LDS (all 128 threads) -----------------------------------------------
     copy_words(s_prior, blob + L.prior(), 20 * K, tid);
+    if (do_extf && tid < ne && pf_gate) {  // second link of the chain: the owner's record (other robot, HBM / L2)
+        pf_on = true;
+        pf_present = w.snap_epoch[w.cur][pf_er.src_var] > pf_er.created;
+        const double *rec = w.snap[w.cur] + (size_t)pf_er.src_var * SNAP_W;
+#pragma unroll
+        for (int c = 0; c < SNAP_W; c++) pf_rec[c] = rec[c];  // absent (not yet delivered) records are zeroed below
+    }
     copy_words(s_io, blob + L.cov(), L.inout_words(), tid);
     {
         const double *src = w.snap[w.cur] + (size_t)v0 * SNAP_W;
@@ -225,12 +257,26 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         if (radio && ir_on) {
             for (int j = tid; j < ne; j += SWEEP_BLOCK) {
                 const int e = ie0 + j;
-                if (!w.ir_gate[e]) continue;  // the owner did not run its external factor sweep
-                const IrEdgeRec er = w.ir_rec[e];
+                IrEdgeRec er;
                 double ao_eta[4], ao_lam[16], a_mu[4], b_mu[4];
-                ld_soa4(w.ir_bmu, w.NI, e, b_mu);
-                const bool a_present = w.snap_epoch[w.cur][er.src_var] > er.created;
-                if (a_present) {
+                bool a_present;
+                if (j == tid) {  // operands prefetched during staging
+                    if (!pf_on) continue;  // the owner did not run its external factor sweep
+                    er = pf_er;
+                    a_present = pf_present;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) b_mu[c] = pf_bmu[c];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) ao_eta[c] = pf_rec[c];
+#pragma unroll
+                    for (int c = 0; c < 16; c++) ao_lam[c] = pf_rec[4 + c];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) a_mu[c] = pf_rec[20 + c];
+                } else {
+                    if (!w.ir_gate[e]) continue;
+                    er = w.ir_rec[e];
+                    ld_soa4(w.ir_bmu, w.NI, e, b_mu);
+                    a_present = w.snap_epoch[w.cur][er.src_var] > er.created;
                     const double *rec = w.snap[w.cur] + (size_t)er.src_var * SNAP_W;
 #pragma unroll
                     for (int c = 0; c < 4; c++) ao_eta[c] = rec[c];
@@ -238,7 +284,8 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     for (int c = 0; c < 16; c++) ao_lam[c] = rec[4 + c];
 #pragma unroll
                     for (int c = 0; c < 4; c++) a_mu[c] = rec[20 + c];
-                } else {
+                }
+                if (!a_present) {  // the owner's variable has not answered this factor yet: empty inbox entry
 #pragma unroll
                     for (int c = 0; c < 4; c++) { ao_eta[c] = 0.0; a_mu[c] = 0.0; }
 #pragma unroll
@@ -384,6 +431,37 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         }
     };
 
+    // Internal factor sweep, DYN wave: one lane per dynamic-factor message.  The two messages of one
+    // factor read each other's previous value; both lanes sit in the SAME wave, whose LDS reads all
+    // issue before its LDS writes, so no barrier is needed between reading the old and writing the new
+    // messages.  Reads s_snap, s_epoch and the dynamic columns of s_fv only.
+    auto dynamic_messages = [&]() {
+        double me[4], ml[16], oe[4], ol[16];
+        const int o = dyn_other_var, oe_ix = dyn_other_edge;
+        if (s_epoch[o] > 0) {  // other variable has answered: belief - our last message
+#pragma unroll
+            for (int c = 0; c < 4; c++) me[c] = s_snap[c * K + o] - s_fv[c * E1 + oe_ix];
+#pragma unroll
+            for (int c = 0; c < 16; c++) ml[c] = s_snap[(4 + c) * K + o] - s_fv[(4 + c) * E1 + oe_ix];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) me[c] = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; c++) ml[c] = 0.0;
+        }
+        if (!dynamic_message(maa, mab, mba, mbb, me, ml, oe, ol)) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) oe[c] = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; c++) ol[c] = 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) s_fv[c * E1 + lane] = oe[c];
+#pragma unroll
+        for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + lane] = ol[c];
+    };
+
+    bool dyn_prefired = false;  // the DYN wave already ran the dynamic messages of internal iteration 0
     STAMP(t_extf);
     // ======================= external variable sweep ==========================================
     if (ext_mask & PH_EXT_VARIABLE) {
@@ -392,6 +470,14 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         double *s_sum = has_int_var ? s_tmp : s_prior;
         if (radio) variable_sums(s_sum, false, false);
         __syncthreads();
+        // The first internal factor sweep of this launch does not depend on anything the external
+        // sweeps produce (a dynamic factor reads the snapshot of the last INTERNAL variable sweep and
+        // its own previous messages): the DYN wave computes its messages now, next to the UV wave's
+        // mean / covariance of the external variable sweep (one 4x4 inverse per variable either way).
+        if (radio && role == ROLE_DYN && is_dyn && (w.enable & 1u) && n_int > 0 && !idle && (int_mask & PH_INT_FACTOR)) {
+            dynamic_messages();
+            dyn_prefired = true;
+        }
         if (radio && is_var) variable_finish(s_sum, false);
         __syncthreads();
         if (radio && ir_on) {
@@ -422,34 +508,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         for (int it = 0; it < n_int && !idle; it++) {
             STAMP(t0);
             if (int_mask & PH_INT_FACTOR) {
-                // The two messages of one dynamic factor read each other's previous value; both lanes
-                // sit in the SAME wave, whose LDS reads all issue before its LDS writes, so no barrier
-                // is needed between reading the old and writing the new messages.
-                if (is_dyn && (w.enable & 1u)) {
-                    double me[4], ml[16], oe[4], ol[16];
-                    const int o = dyn_other_var, oe_ix = dyn_other_edge;
-                    if (s_epoch[o] > 0) {  // other variable has answered: belief - our last message
-#pragma unroll
-                        for (int c = 0; c < 4; c++) me[c] = s_snap[c * K + o] - s_fv[c * E1 + oe_ix];
-#pragma unroll
-                        for (int c = 0; c < 16; c++) ml[c] = s_snap[(4 + c) * K + o] - s_fv[(4 + c) * E1 + oe_ix];
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 4; c++) me[c] = 0.0;
-#pragma unroll
-                        for (int c = 0; c < 16; c++) ml[c] = 0.0;
-                    }
-                    if (!dynamic_message(maa, mab, mba, mbb, me, ml, oe, ol)) {
-#pragma unroll
-                        for (int c = 0; c < 4; c++) oe[c] = 0.0;
-#pragma unroll
-                        for (int c = 0; c < 16; c++) ol[c] = 0.0;
-                    }
-#pragma unroll
-                    for (int c = 0; c < 4; c++) s_fv[c * E1 + lane] = oe[c];
-#pragma unroll
-                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + lane] = ol[c];
-                }
+                if (is_dyn && (w.enable & 1u) && !(it == 0 && dyn_prefired)) dynamic_messages();
                 // UV wave: first the belief of the previous sweep (mean, covariance) that the unary
                 // factors linearise at — same wave, so its LDS writes precede their LDS reads
                 if (pending && is_var) variable_finish(s_snap, true);
@@ -524,7 +583,15 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 STAMP_ADD(c_vb, t4, t5);
             }
         }
-        if (pending && is_var) variable_finish(s_snap, true);
+        // Tail: the UV wave completes the last variable sweep (mean, covariance) while the DYN wave
+        // already writes back what that does not touch — the factor -> variable messages and the belief
+        // (eta, lam) image, three quarters of the robot's output.
+        if (role == ROLE_UV) {
+            if (pending && is_var) variable_finish(s_snap, true);
+        } else {
+            copy_words_wave(blob + L.fv(), s_fv, 20 * E1, lane);
+            if (any_sweep) copy_words_wave(blob + L.bel(), s_prior, 20 * K, lane);
+        }
         __syncthreads();
 #ifdef MGX_STAMPS
         if (w.dbg && lane == 0) {  // per wave: cycles in factor phase, its barrier, variable phase, its barrier
@@ -539,8 +606,8 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     }
 
     // ---- write back: straight copies of the LDS images ----------------------------------------------
-    copy_words(blob + L.cov(), s_io, L.inout_words(), tid);
-    if (any_sweep) copy_words(blob + L.bel(), s_prior, 20 * K, tid);
+    copy_words(blob + L.cov(), s_cov, 20 * K, tid);  // covariance + mean
+    copy_words(blob + L.valid(), (const double *)s_valid, K, tid);
     if (snap_out >= 0) {
         double *dst = w.snap[snap_out] + (size_t)v0 * SNAP_W;
         for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) dst[t] = s_snap[(t % SNAP_W) * K + (t / SNAP_W)];

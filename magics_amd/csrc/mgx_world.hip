@@ -284,6 +284,7 @@ struct mgx_world {
     bool conns_dirty = false;  // only inter-robot connections changed: edge tables are rebuilt in place
     bool flags_dirty = true;
     bool dev_valid = false;  // device arrays hold live state
+    uint32_t stale_kinds = 0;  // disabled factor kinds whose inboxes have missed a delivery (mgx_set_enabled)
     DevWorld d{};
     std::vector<int> dev_of;     // robot id -> device robot index (locals first, then ghosts)
     std::vector<int> robot_of;   // device robot index -> robot id
@@ -928,6 +929,7 @@ static int rccl_exchange(mgx_world *w);
 static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_mask, int n_int, uint32_t hints = 0) {
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
+    if (!w->robots.empty()) w->stale_kinds |= ~w->p.enable_mask & 15u;  // disabled factors miss what this sweep delivers
     const bool writes_snap = (int_mask & PH_INT_VARIABLE) && n_int > 0;
     if (robot < 0) {
         if (w->direct.connected && (ext_mask & PH_EXT_FACTOR)) {  // the inter-robot factors read the ghosts' snapshots
@@ -1185,6 +1187,26 @@ int mgx_robot_remove(mgx_world *w, int32_t robot) {
     rb.antenna = 0;
     rb.connected.clear();
     w->flags_dirty = true;
+    return MGX_OK;
+}
+
+// FactorGraph::change_factor_enabled for every graph (factorgraph.rs:1529-1539, ui/settings.rs:491-496).
+// Disabling is exact as it stands: a disabled factor is never updated (its last message stays in the
+// variable's inbox and keeps being summed, factorgraph.rs:695,734), change_prior still empties and
+// re-delivers (variable.rs:203-230), the counters stop counting it.  Re-enabling a kind that has
+// missed deliveries would need the inbox its factors froze with (the engine derives factor inboxes
+// from the variables' snapshots) and is refused with MGX_ERR_STATE.
+int mgx_set_enabled(mgx_world *w, uint32_t kind_mask) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    if (kind_mask & ~15u) return fail(MGX_ERR_INVALID, "unknown factor kind bits 0x%x", kind_mask);
+    const uint32_t turning_on = kind_mask & ~w->p.enable_mask;
+    if (turning_on & w->stale_kinds)
+        return fail(MGX_ERR_STATE, "re-enabling factor kinds 0x%x after sweeps ran without them is not supported", turning_on & w->stale_kinds);
+    if (kind_mask == w->p.enable_mask) return MGX_OK;
+    flush_counts(w);  // what was logged so far was sent under the old flags
+    w->p.enable_mask = kind_mask;
+    w->d.enable = kind_mask;
+    w->stale_kinds &= ~kind_mask;
     return MGX_OK;
 }
 
@@ -1449,6 +1471,7 @@ int mgx_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, const uin
     void *dp = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
     const double *dm = (const double *)dp;
+    w->stale_kinds |= ~w->p.enable_mask & 15u;
     HIP_TRY(launch_change_prior(w->d, (int)n, (const int32_t *)(dm + 4 * (size_t)n), (const uint32_t *)(dm + 4 * (size_t)n + (n + 1) / 2), dm,
                                 w->stream));
     HIP_TRY(w->stage.release(slot, w->stream));
@@ -1483,6 +1506,7 @@ int mgx_update_priors(mgx_world *w, uint32_t n, const int32_t *robots, const dou
     void *dp = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
     const double *dw = (const double *)dp;
+    w->stale_kinds |= ~w->p.enable_mask & 15u;
     HIP_TRY(launch_update_priors(w->d, (int)n, (const int32_t *)(dw + 3 * (size_t)n), dw, dw + 2 * (size_t)n,
                                  (const uint8_t *)(dw + 3 * (size_t)n + w_r), max_speed, delta_t, w->stream));
     HIP_TRY(w->stage.release(slot, w->stream));

@@ -118,6 +118,7 @@ SYMBOLS = {
     "mgx_robot_remove": (C.c_int, [_V, C.c_int32]),
     "mgx_ir_connect": (C.c_int, [_V, C.c_int32, C.c_int32, C.c_uint64]),
     "mgx_ir_disconnect": (C.c_int, [_V, C.c_int32, C.c_int32]),
+    "mgx_set_enabled": (C.c_int, [_V, C.c_uint32]),
     "mgx_set_antenna": (C.c_int, [_V, C.c_int32, C.c_int32]),
     "mgx_set_idle": (C.c_int, [_V, C.c_int32, C.c_int32]),
     "mgx_set_antennas": (C.c_int, [_V, C.c_uint32, C.c_void_p, C.c_void_p]),

@@ -113,6 +113,10 @@ class World:
     def ir_disconnect(self, a, b):
         self._chk(self._L.mgx_ir_disconnect(self._w, a, b))
 
+    def set_enabled(self, mask):
+        """change_factor_enabled for every graph (factorgraph.rs:1529-1539): MGX_FACTOR_* bits."""
+        self._chk(self._L.mgx_set_enabled(self._w, int(mask)))
+
     def set_antenna(self, robot, active):
         self._chk(self._L.mgx_set_antenna(self._w, robot, int(bool(active))))
 

@@ -204,6 +204,10 @@ class OracleWorld:
     def ir_disconnect(self, a, b):
         self._chk(self._L.orc_ir_disconnect(self._w, a, b))
 
+    def set_enabled(self, mask):
+        self._L.orc_set_enabled.argtypes = [C.c_void_p, C.c_uint32]
+        self._chk(self._L.orc_set_enabled(self._w, int(mask)))
+
     def set_antenna(self, robot, active):
         self._chk(self._L.orc_set_antenna(self._w, robot, int(bool(active))))
 

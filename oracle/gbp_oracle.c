@@ -1020,6 +1020,25 @@ int orc_set_idle(World *w, int32_t r, int32_t idle) {
     return ORC_OK;
 }
 
+/* FactorGraph::change_factor_enabled (FG/factorgraph.rs:1529-1539) for every graph, as the settings
+ * panel applies it (ui/settings.rs:491-496) together with the config entry new factors read. */
+int orc_set_enabled(World *w, uint32_t mask) {
+    if (!w || (mask & ~15u)) return ORC_ERR_INVALID;
+    w->p.enable_mask = mask;
+    for (int r = 0; r < w->n; r++) {
+        Graph *g = &w->g[r];
+        if (g->removed) continue;
+        for (int i = 0; i < g->n_factors; i++) {
+            Node *nd = &g->nodes[g->factor_indices[i]];
+            if (!nd->alive || !nd->is_factor) continue;
+            Factor *f = &nd->f;
+            f->enabled = f->kind == K_DYNAMIC ? (mask & EN_DYN) != 0 : f->kind == K_INTERROBOT ? (mask & EN_IR) != 0
+                       : f->kind == K_OBSTACLE ? (mask & EN_OBS) != 0 : (mask & EN_TRK) != 0;
+        }
+    }
+    return ORC_OK;
+}
+
 static void prepare_factor(const World *w, Factor *f) {
     if (f->kind == K_OBSTACLE) /* obstacle.rs:98-102 */
         f->jac_delta = (w->world_w / (double)w->sdf_w + w->world_h / (double)w->sdf_h) / 2.0;

@@ -47,6 +47,11 @@ impl World {
         Ok((stats[0], stats[1]))
     }
     /// `update_failed_comms` (robot.rs:1593-1601): the Bernoulli draws stay with the caller's PRNG
+    /// `FactorGraph::change_factor_enabled` for every graph (factorgraph.rs:1529-1539)
+    pub fn change_factor_enabled(&self, kind_mask: u32) -> Result<(), MgxError> {
+        check(unsafe { sys::mgx_set_enabled(self.raw, kind_mask) })
+    }
+
     pub fn set_antennas(&self, robots: &[i32], active: &[u8]) -> Result<(), MgxError> {
         assert_eq!(robots.len(), active.len());
         check(unsafe { sys::mgx_set_antennas(self.raw, robots.len() as u32, robots.as_ptr(), active.as_ptr()) })

@@ -277,3 +277,42 @@ def test_fma_build_shows_the_chaotic_transient():
     assert e_mu > 1e-3
     both(eng, ref, lambda w: w.iterate([1] * 8))
     assert_parity(eng, ref, tol=TOL, what="fma build after the transient")
+
+
+def test_runtime_disable_of_factor_kinds():
+    """change_factor_enabled (factorgraph.rs:1529-1539) at run time: a disabled kind keeps its last
+    messages in the variables' inboxes (they go on being summed), prior changes still empty and
+    re-deliver, counters stop counting it.  Kinds are switched off one after the other between ticks;
+    beliefs and message counts follow the oracle bit for bit.  Switching a kind back on after sweeps ran
+    without it is refused."""
+    from magics_amd import MgxError
+    sc = S.grid_scenario(24, 10, interrobot=True, tracking=True)
+    eng, ref = make_pair(sc)
+    tick = S.tick_inputs(sc)
+    mask = sc["params"]["enable_mask"]
+    assert mask == 15
+    for step, off in enumerate((0, 4, 8, 2, 0, 1)):
+        mask &= ~off
+        for w in (eng, ref):
+            w.set_enabled(mask)
+            w.update_priors(**tick)
+            w.iterate(sc["steps"])
+            if step == 2:
+                w.change_prior(3, 5, np.array([1.0, -2.0, 0.5, 0.25]))   # an interior variable, factors of two kinds off
+        for a, b in zip(eng.read_beliefs(), ref.read_beliefs()):
+            assert np.array_equal(a, b), (step, mask)
+        for r in (0, 5, 23):
+            assert eng.message_counts(r) == ref.message_counts(r), (step, mask, r)
+    assert mask == 0
+    with pytest.raises(MgxError):
+        eng.set_enabled(4)          # obstacle factors have missed deliveries since they were switched off
+    eng.set_enabled(0)              # no change: fine
+    # before anything ran, kinds can be switched freely (the config entry new factors read)
+    sc2 = S.grid_scenario(9, 10, interrobot=False)
+    eng2, ref2 = make_pair(sc2)
+    for w in (eng2, ref2):
+        w.set_enabled(1)
+        w.set_enabled(1 | 4)
+        w.iterate([1] * 6)
+    for a, b in zip(eng2.read_beliefs(), ref2.read_beliefs()):
+        assert np.array_equal(a, b)
