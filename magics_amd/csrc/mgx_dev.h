@@ -101,6 +101,7 @@ struct DevWorld {
     uint32_t sdf_w, sdf_h;
     double world_w, world_h, obs_delta;
     int ir_max_edges;  // largest number of inter-robot edges attached to one robot (LDS staging size)
+    int trk_cols;      // 0: tracking factors have never been enabled in this world (their message columns are all zero)
 
     double inv_s2_obs, inv_s2_ir, inv_s2_trk, trk_pad, trk_attr;
     // diagnostic builds only (-DMGX_STAMPS, tools/stamps.py): per-workgroup phase cycle sums
@@ -115,5 +116,9 @@ constexpr uint32_t PH_INT_VARIABLE = 8u;  // internal_variable_iteration
 
 // launch hints
 constexpr uint32_t HINT_IR_DEAD = 1u;  // the next sweep recomputes every inter-robot message this one computes
+// A later launch of the same mgx_iterate call runs an external / internal variable sweep: a robot that takes part
+// in it (flags do not change inside a call) rewrites its belief (eta, lam) image there, so this launch need not store it
+constexpr uint32_t HINT_LATER_EXT_VARIABLE = 2u;
+constexpr uint32_t HINT_LATER_INT_VARIABLE = 4u;
 
 }  // namespace mgx

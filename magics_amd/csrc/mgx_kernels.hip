@@ -106,6 +106,35 @@ __device__ __forceinline__ void copy_words(double *dst, const double *src, int n
     if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
 }
 
+// HBM -> LDS with every load of the thread in flight before its first LDS store: a copy loop that
+// waits for each 16 bytes before asking for the next costs one memory round trip per iteration, and
+// staging is a handful of such loops.  N (f64 words) is a compile-time constant: the loops unroll into
+// independent loads held in registers.
+template <int N>
+struct StageRegs {
+    static constexpr int N2 = N / 2, ITERS = (N2 + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+    double2 v[ITERS];
+    double last;
+    __device__ __forceinline__ void load(const double *src, int tid) {
+        const double2 *s2 = reinterpret_cast<const double2 *>(src);
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const int t = tid + it * SWEEP_BLOCK;
+            v[it] = (t < N2) ? s2[t] : make_double2(0.0, 0.0);
+        }
+        last = ((N & 1) && tid == 0) ? src[N - 1] : 0.0;
+    }
+    __device__ __forceinline__ void store(double *dst, int tid) const {
+        double2 *d2 = reinterpret_cast<double2 *>(dst);
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const int t = tid + it * SWEEP_BLOCK;
+            if (t < N2) d2[t] = v[it];
+        }
+        if ((N & 1) && tid == 0) dst[N - 1] = last;
+    }
+};
+
 // the same, issued by one wave (64 lanes)
 __device__ __forceinline__ void copy_words_wave(double *dst, const double *src, int n, int lane) {
     const double2 *s2 = reinterpret_cast<const double2 *>(src);
@@ -135,7 +164,8 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     int32_t *s_valid = (int32_t *)(s_io + 20 * K + 20 * E1);  // [K]
     uint32_t *s_epoch = (uint32_t *)(s_io + L.inout_words() + (L.inout_words() & 1));  // [K] deliveries
     int32_t *s_irp = (int32_t *)(s_epoch + ((K + 1) & ~1));  // [3][K+1] inbox ranges of foreign factors
-    double *s_ir = (double *)(s_irp + ((3 * (K + 1) + 1) & ~1));  // [ne][IR_STRIDE] inter-robot messages (STAGE_IR)
+    int32_t *s_covset = s_irp + ((3 * (K + 1) + 1) & ~1);     // [K] this launch recomputed the variable's covariance
+    double *s_ir = (double *)(s_covset + ((K + 1) & ~1));     // [ne][IR_STRIDE] inter-robot messages (STAGE_IR)
 
     double *blob = w.blob + (size_t)r * w.BS;
     const int v0 = r * K;
@@ -163,18 +193,52 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     }
 
     // ---- stage the robot in LDS (all 128 threads) -----------------------------------------------
-    copy_words(s_prior, blob + L.prior(), 20 * K, tid);
-    if (do_extf && tid < ne && pf_gate) {  // second link of the chain: the owner's record (other robot, HBM / L2)
-        pf_on = true;
-        pf_present = w.snap_epoch[w.cur][pf_er.src_var] > pf_er.created;
-        const double *rec = w.snap[w.cur] + (size_t)pf_er.src_var * SNAP_W;
+    // Constant-K instantiations: TWO memory round trips for the whole stage.  First every load that
+    // needs no other load's result (prior, mean | messages | valid, own snapshot records, and above the
+    // first link of the edge chain), then the chain's second link, then the LDS stores.  The covariance
+    // is output only (a variable whose covariance this launch does not recompute keeps the HBM copy).
+    auto chain_second_link = [&]() {
+        if (do_extf && tid < ne && pf_gate) {  // the owner's record (other robot, HBM / L2)
+            pf_on = true;
+            pf_present = w.snap_epoch[w.cur][pf_er.src_var] > pf_er.created;
+            const double2 *rec = reinterpret_cast<const double2 *>(w.snap[w.cur] + (size_t)pf_er.src_var * SNAP_W);
 #pragma unroll
-        for (int c = 0; c < SNAP_W; c++) pf_rec[c] = rec[c];  // absent (not yet delivered) records are zeroed below
-    }
-    copy_words(s_io, blob + L.cov(), L.inout_words(), tid);
+            for (int c = 0; c < SNAP_W / 2; c++) {  // absent (not yet delivered) records are zeroed when used
+                const double2 q = rec[c];
+                pf_rec[2 * c] = q.x;
+                pf_rec[2 * c + 1] = q.y;
+            }
+        }
+    };
     {
         const double *src = w.snap[w.cur] + (size_t)v0 * SNAP_W;
-        for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = src[t];
+        if constexpr (KT > 0) {
+            StageRegs<20 * KT> r_prior;
+            StageRegs<BlobLayout(KT).inout_words() - 16 * KT> r_io;
+            constexpr int IT = (SNAP_W * KT + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+            double r_snap[IT];
+            r_prior.load(blob + L.prior(), tid);
+            r_io.load(blob + L.mu(), tid);
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int t = tid + it * SWEEP_BLOCK;
+                r_snap[it] = (t < SNAP_W * K) ? src[t] : 0.0;
+            }
+            chain_second_link();
+            r_prior.store(s_prior, tid);
+            r_io.store(s_mu, tid);
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int t = tid + it * SWEEP_BLOCK;
+                if (t < SNAP_W * K) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = r_snap[it];
+            }
+        } else {
+            copy_words(s_prior, blob + L.prior(), 20 * K, tid);
+            chain_second_link();
+            copy_words(s_mu, blob + L.mu(), L.inout_words() - 16 * K, tid);
+            for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = src[t];
+        }
+        for (int t = tid; t < K; t += SWEEP_BLOCK) s_covset[t] = 0;
         for (int t = tid; t < K; t += SWEEP_BLOCK) {
             s_epoch[t] = w.snap_epoch[w.cur][v0 + t];
             if (HAS_IR) {
@@ -211,6 +275,8 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // which variable sweep of this launch is the robot's last one (its belief goes out)
     const bool has_int_var = (int_mask & PH_INT_VARIABLE) && n_int > 0 && !idle;
     const bool any_sweep = has_int_var || ((ext_mask & PH_EXT_VARIABLE) && radio);
+    // a later launch of the same call rewrites this robot's belief image: this one's copy is never read
+    const bool bel_dead = ((hints & HINT_LATER_EXT_VARIABLE) && radio) || ((hints & HINT_LATER_INT_VARIABLE) && !idle);
 
     // DYN wave: constant potential blocks of this lane's message
     double maa[4], mab[4], mba[4], mbb[4];
@@ -277,7 +343,14 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     er = w.ir_rec[e];
                     ld_soa4(w.ir_bmu, w.NI, e, b_mu);
                     a_present = w.snap_epoch[w.cur][er.src_var] > er.created;
-                    const double *rec = w.snap[w.cur] + (size_t)er.src_var * SNAP_W;
+                    const double2 *rec2 = reinterpret_cast<const double2 *>(w.snap[w.cur] + (size_t)er.src_var * SNAP_W);
+                    double rec[SNAP_W];
+#pragma unroll
+                    for (int c = 0; c < SNAP_W / 2; c++) {
+                        const double2 q = rec2[c];
+                        rec[2 * c] = q.x;
+                        rec[2 * c + 1] = q.y;
+                    }
 #pragma unroll
                     for (int c = 0; c < 4; c++) ao_eta[c] = rec[c];
 #pragma unroll
@@ -424,6 +497,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #pragma unroll
             for (int c = 0; c < 4; c++) s_mu[c * K + lane] = mu[c];
             s_valid[lane] = valid;
+            s_covset[lane] = 1;
         }
         if (internal) {
 #pragma unroll
@@ -590,7 +664,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             if (pending && is_var) variable_finish(s_snap, true);
         } else {
             copy_words_wave(blob + L.fv(), s_fv, 20 * E1, lane);
-            if (any_sweep) copy_words_wave(blob + L.bel(), s_prior, 20 * K, lane);
+            if (any_sweep && !bel_dead) copy_words_wave(blob + L.bel(), s_prior, 20 * K, lane);
         }
         __syncthreads();
 #ifdef MGX_STAMPS
@@ -606,7 +680,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     }
 
     // ---- write back: straight copies of the LDS images ----------------------------------------------
-    copy_words(blob + L.cov(), s_cov, 20 * K, tid);  // covariance + mean
+    for (int t = tid; t < 16 * K; t += SWEEP_BLOCK)  // covariance of the variables that recomputed it
+        if (s_covset[t % K]) blob[L.cov() + t] = s_cov[t];
+    copy_words(blob + L.mu(), s_mu, 4 * K, tid);
     copy_words(blob + L.valid(), (const double *)s_valid, K, tid);
     if (snap_out >= 0) {
         double *dst = w.snap[snap_out] + (size_t)v0 * SNAP_W;
@@ -907,7 +983,8 @@ __global__ void k_copy_bytes(uint8_t *__restrict__ dst, const uint8_t *__restric
 size_t sweep_lds_bytes(int K, int ir_edges) {
     const BlobLayout L(K);
     const int io = L.inout_words() + (L.inout_words() & 1);
-    return sizeof(double) * (size_t)((SNAP_W + 20 + 20) * K + io + IR_STRIDE * ir_edges) + 4 * (size_t)(((K + 1) & ~1) + ((3 * (K + 1) + 1) & ~1));
+    return sizeof(double) * (size_t)((SNAP_W + 20 + 20) * K + io + IR_STRIDE * ir_edges) +
+           4 * (size_t)(2 * ((K + 1) & ~1) + ((3 * (K + 1) + 1) & ~1));
 }
 bool sweep_supports(int K) { return K >= 3 && 2 * (K - 1) <= 64; }
 int blob_words(int K) { const BlobLayout L(K); return (L.words() + 1) & ~1; }

@@ -284,6 +284,7 @@ struct mgx_world {
     bool conns_dirty = false;  // only inter-robot connections changed: edge tables are rebuilt in place
     bool flags_dirty = true;
     bool dev_valid = false;  // device arrays hold live state
+    bool trk_ever_on = false;  // tracking factors were enabled at some point: their message columns may be non-zero
     uint32_t stale_kinds = 0;  // disabled factor kinds whose inboxes have missed a delivery (mgx_set_enabled)
     DevWorld d{};
     std::vector<int> dev_of;     // robot id -> device robot index (locals first, then ghosts)
@@ -889,6 +890,7 @@ static int commit(mgx_world *w) {
     d.V = (int)V; d.EI = (int)EI; d.ND = (int)ND; d.NT = (int)NT; d.NI = (int)NIs;
     d.cur = 0;
     d.ir_max_edges = ir_max_edges;
+    d.trk_cols = w->trk_ever_on ? 1 : 0;
     d.enable = w->p.enable_mask;
     d.blob = w->blob.p; d.BS = (int)BS;
     d.snap[0] = w->snap0.p; d.snap[1] = w->snap1.p;
@@ -974,6 +976,7 @@ int mgx_world_create(const mgx_params *params, mgx_world **out) {
     mgx_world *w = new (std::nothrow) mgx_world();
     if (!w) return fail(MGX_ERR_NOMEM, "out of memory");
     w->p = *params;
+    w->trk_ever_on = (params->enable_mask & 8u) != 0;
     *out = w;
     return MGX_OK;
 }
@@ -1206,6 +1209,7 @@ int mgx_set_enabled(mgx_world *w, uint32_t kind_mask) {
     flush_counts(w);  // what was logged so far was sent under the old flags
     w->p.enable_mask = kind_mask;
     w->d.enable = kind_mask;
+    if (kind_mask & 8u) { w->trk_ever_on = true; w->d.trk_cols = 1; }
     w->stale_kinds &= ~kind_mask;
     return MGX_OK;
 }
@@ -1437,7 +1441,9 @@ int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n) {
         while (i < ph.size() && ph[i] == 'I') { n_int++; i++; }
         // the next launch of this call (if any) starts with an external phase: the inter-robot messages
         // this launch computes are recomputed before anything reads their HBM copy
-        const uint32_t hints = (ext && i < ph.size()) ? HINT_IR_DEAD : 0u;
+        uint32_t hints = (ext && i < ph.size()) ? HINT_IR_DEAD : 0u;
+        // later launches of this call that run a variable sweep rewrite the belief images (nothing reads them in between)
+        for (size_t j = i; j < ph.size(); j++) hints |= (ph[j] == 'E') ? HINT_LATER_EXT_VARIABLE : HINT_LATER_INT_VARIABLE;
         int rc = sweep(w, -1, ext, n_int ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, n_int, hints);
         if (rc != MGX_OK) return rc;
     }
