@@ -175,96 +175,6 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     const bool idle = w.idle[r] != 0;
     const bool radio = (w.antenna[r] != 0) && !idle;
 
-    // ---- operands of the external factor sweep, requested AROUND the staging copies ------------------
-    // An edge lane needs a chain of dependent loads (gate / constants -> the owner's delivery count and
-    // snapshot record); started here they travel while the blob is staged, instead of after the barrier.
-    // Each thread prefetches its first edge (robots have at most a few more edges than threads).
-    const bool do_extf = HAS_IR && (ext_mask & PH_EXT_FACTOR) && radio && ir_on;
-    bool pf_on = false, pf_present = false;
-    IrEdgeRec pf_er{};
-    double pf_bmu[4] = {0.0, 0.0, 0.0, 0.0}, pf_rec[SNAP_W];
-#pragma unroll
-    for (int c = 0; c < SNAP_W; c++) pf_rec[c] = 0.0;
-    uint8_t pf_gate = 0;
-    if (do_extf && tid < ne) {
-        pf_gate = w.ir_gate[ie0 + tid];
-        pf_er = w.ir_rec[ie0 + tid];
-        ld_soa4(w.ir_bmu, w.NI, ie0 + tid, pf_bmu);
-    }
-
-    // ---- stage the robot in LDS (all 128 threads) -----------------------------------------------
-    // Constant-K instantiations: TWO memory round trips for the whole stage.  First every load that
-    // needs no other load's result (prior, mean | messages | valid, own snapshot records, and above the
-    // first link of the edge chain), then the chain's second link, then the LDS stores.  The covariance
-    // is output only (a variable whose covariance this launch does not recompute keeps the HBM copy).
-    auto chain_second_link = [&]() {
-        if (do_extf && tid < ne && pf_gate) {  // the owner's record (other robot, HBM / L2)
-            pf_on = true;
-            pf_present = w.snap_epoch[w.cur][pf_er.src_var] > pf_er.created;
-            const double2 *rec = reinterpret_cast<const double2 *>(w.snap[w.cur] + (size_t)pf_er.src_var * SNAP_W);
-#pragma unroll
-            for (int c = 0; c < SNAP_W / 2; c++) {  // absent (not yet delivered) records are zeroed when used
-                const double2 q = rec[c];
-                pf_rec[2 * c] = q.x;
-                pf_rec[2 * c + 1] = q.y;
-            }
-        }
-    };
-    {
-        const double *src = w.snap[w.cur] + (size_t)v0 * SNAP_W;
-        if constexpr (KT > 0) {
-            StageRegs<20 * KT> r_prior;
-            StageRegs<BlobLayout(KT).inout_words() - 16 * KT> r_io;
-            constexpr int IT = (SNAP_W * KT + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
-            double r_snap[IT];
-            r_prior.load(blob + L.prior(), tid);
-            r_io.load(blob + L.mu(), tid);
-#pragma unroll
-            for (int it = 0; it < IT; it++) {
-                const int t = tid + it * SWEEP_BLOCK;
-                r_snap[it] = (t < SNAP_W * K) ? src[t] : 0.0;
-            }
-            chain_second_link();
-            r_prior.store(s_prior, tid);
-            r_io.store(s_mu, tid);
-#pragma unroll
-            for (int it = 0; it < IT; it++) {
-                const int t = tid + it * SWEEP_BLOCK;
-                if (t < SNAP_W * K) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = r_snap[it];
-            }
-        } else {
-            copy_words(s_prior, blob + L.prior(), 20 * K, tid);
-            chain_second_link();
-            copy_words(s_mu, blob + L.mu(), L.inout_words() - 16 * K, tid);
-            for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = src[t];
-        }
-        for (int t = tid; t < K; t += SWEEP_BLOCK) s_covset[t] = 0;
-        for (int t = tid; t < K; t += SWEEP_BLOCK) {
-            s_epoch[t] = w.snap_epoch[w.cur][v0 + t];
-            if (HAS_IR) {
-                s_irp[t] = w.ir_var_ptr[v0 + t];
-                s_irp[(K + 1) + t] = w.ir_var_mid[v0 + t];
-                s_irp[2 * (K + 1) + t] = w.ir_var_ptr[v0 + t + 1];
-            }
-        }
-        // messages that this launch's external factor sweep recomputes before anyone reads them are
-        // not fetched
-        const bool recompute = (ext_mask & PH_EXT_FACTOR) && radio && ir_on;
-        if (STAGE_IR)
-            for (int j = tid; j < ne; j += SWEEP_BLOCK) {  // independent loads in flight per lane
-                if (recompute && w.ir_gate[ie0 + j]) continue;
-                const size_t e = (size_t)(ie0 + j);
-                double m[6];
-                m[0] = w.ir_fv_eta[0 * (size_t)w.NI + e];
-                m[1] = w.ir_fv_eta[1 * (size_t)w.NI + e];
-                m[2] = w.ir_fv_lam[0 * (size_t)w.NI + e];
-                m[3] = w.ir_fv_lam[1 * (size_t)w.NI + e];
-                m[4] = w.ir_fv_lam[4 * (size_t)w.NI + e];
-                m[5] = w.ir_fv_lam[5 * (size_t)w.NI + e];
-#pragma unroll
-                for (int c = 0; c < 6; c++) s_ir[j * IR_STRIDE + c] = m[c];
-            }
-    }
     int itf = w.iter_factor[r];  // iteration_count.factor (every lane applies the same increments)
 
     // ---- roles ------------------------------------------------------------------------------------
@@ -311,6 +221,124 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         trk_lp[0] = w.trk_last_pos[trk_item];
         trk_lp[1] = w.trk_last_pos[(size_t)w.NT + trk_item];
         trk_lv = w.trk_last_val[trk_item];
+    }
+
+    // ---- operands of the external factor sweep, requested AROUND the staging copies ------------------
+    // An edge lane needs a chain of dependent loads (gate / constants -> the owner's delivery count and
+    // snapshot record); started here they travel while the blob is staged, instead of after the barrier.
+    // Each thread prefetches its first edge (robots have at most a few more edges than threads).
+    const bool do_extf = HAS_IR && (ext_mask & PH_EXT_FACTOR) && radio && ir_on;
+    bool pf_on = false, pf_present = false;
+    IrEdgeRec pf_er{};
+    double pf_bmu[4] = {0.0, 0.0, 0.0, 0.0}, pf_rec[SNAP_W];
+#pragma unroll
+    for (int c = 0; c < SNAP_W; c++) pf_rec[c] = 0.0;
+    uint8_t pf_gate = 0;
+    if (HAS_IR && tid < ne) pf_gate = w.ir_gate[ie0 + tid];
+    if (do_extf && tid < ne) {
+        pf_er = w.ir_rec[ie0 + tid];
+        ld_soa4(w.ir_bmu, w.NI, ie0 + tid, pf_bmu);
+    }
+    // per-variable words (K <= 64 < threads: one pass)
+    uint32_t r_epoch = 0;
+    int r_irp[3] = {0, 0, 0};
+    if (tid < K) {
+        r_epoch = w.snap_epoch[w.cur][v0 + tid];
+        if (HAS_IR) {
+            r_irp[0] = w.ir_var_ptr[v0 + tid];
+            r_irp[1] = w.ir_var_mid[v0 + tid];
+            r_irp[2] = w.ir_var_ptr[v0 + tid + 1];
+        }
+    }
+    // messages that this launch's external factor sweep recomputes before anyone reads them are not fetched
+    const bool recompute = (ext_mask & PH_EXT_FACTOR) && radio && ir_on;
+    double r_ir[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    bool r_ir_on = false;
+
+    // ---- stage the robot in LDS (all 128 threads) -----------------------------------------------
+    // Constant-K instantiations: TWO memory round trips for the whole stage.  First every load that
+    // needs no other load's result (prior, mean | messages | valid, own snapshot records, and above the
+    // first link of the edge chain), then the chain's second link, then the LDS stores.  The covariance
+    // is output only (a variable whose covariance this launch does not recompute keeps the HBM copy).
+    auto chain_second_link = [&]() {
+        if (STAGE_IR && tid < ne && !(recompute && pf_gate)) {  // the thread's first staged inter-robot message
+            const size_t e = (size_t)(ie0 + tid);
+            r_ir_on = true;
+            r_ir[0] = w.ir_fv_eta[0 * (size_t)w.NI + e];
+            r_ir[1] = w.ir_fv_eta[1 * (size_t)w.NI + e];
+            r_ir[2] = w.ir_fv_lam[0 * (size_t)w.NI + e];
+            r_ir[3] = w.ir_fv_lam[1 * (size_t)w.NI + e];
+            r_ir[4] = w.ir_fv_lam[4 * (size_t)w.NI + e];
+            r_ir[5] = w.ir_fv_lam[5 * (size_t)w.NI + e];
+        }
+        if (do_extf && tid < ne && pf_gate) {  // the owner's record (other robot, HBM / L2)
+            pf_on = true;
+            pf_present = w.snap_epoch[w.cur][pf_er.src_var] > pf_er.created;
+            const double2 *rec = reinterpret_cast<const double2 *>(w.snap[w.cur] + (size_t)pf_er.src_var * SNAP_W);
+#pragma unroll
+            for (int c = 0; c < SNAP_W / 2; c++) {  // absent (not yet delivered) records are zeroed when used
+                const double2 q = rec[c];
+                pf_rec[2 * c] = q.x;
+                pf_rec[2 * c + 1] = q.y;
+            }
+        }
+    };
+    {
+        const double *src = w.snap[w.cur] + (size_t)v0 * SNAP_W;
+        if constexpr (KT > 0) {
+            StageRegs<20 * KT> r_prior;
+            StageRegs<BlobLayout(KT).inout_words() - 16 * KT> r_io;
+            constexpr int IT = (SNAP_W * KT + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+            double r_snap[IT];
+            r_prior.load(blob + L.prior(), tid);
+            r_io.load(blob + L.mu(), tid);
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int t = tid + it * SWEEP_BLOCK;
+                r_snap[it] = (t < SNAP_W * K) ? src[t] : 0.0;
+            }
+            chain_second_link();
+            r_prior.store(s_prior, tid);
+            r_io.store(s_mu, tid);
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int t = tid + it * SWEEP_BLOCK;
+                if (t < SNAP_W * K) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = r_snap[it];
+            }
+        } else {
+            copy_words(s_prior, blob + L.prior(), 20 * K, tid);
+            chain_second_link();
+            copy_words(s_mu, blob + L.mu(), L.inout_words() - 16 * K, tid);
+            for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = src[t];
+        }
+        for (int t = tid; t < K; t += SWEEP_BLOCK) s_covset[t] = 0;
+        if (tid < K) {
+            s_epoch[tid] = r_epoch;
+            if (HAS_IR) {
+                s_irp[tid] = r_irp[0];
+                s_irp[(K + 1) + tid] = r_irp[1];
+                s_irp[2 * (K + 1) + tid] = r_irp[2];
+            }
+        }
+        if (STAGE_IR) {
+            if (r_ir_on) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) s_ir[tid * IR_STRIDE + c] = r_ir[c];
+            }
+            for (int j = tid + SWEEP_BLOCK; j < ne; j += SWEEP_BLOCK) {  // robots with more edges than threads
+                if (recompute && w.ir_gate[ie0 + j]) continue;
+                const size_t e = (size_t)(ie0 + j);
+                double m[6];
+                m[0] = w.ir_fv_eta[0 * (size_t)w.NI + e];
+                m[1] = w.ir_fv_eta[1 * (size_t)w.NI + e];
+                m[2] = w.ir_fv_lam[0 * (size_t)w.NI + e];
+                m[3] = w.ir_fv_lam[1 * (size_t)w.NI + e];
+                m[4] = w.ir_fv_lam[4 * (size_t)w.NI + e];
+                m[5] = w.ir_fv_lam[5 * (size_t)w.NI + e];
+#pragma unroll
+                for (int c = 0; c < 6; c++) s_ir[j * IR_STRIDE + c] = m[c];
+            }
+        }
     }
     __syncthreads();
     uint32_t my_epoch = (tid < 4 * K) ? s_epoch[tid % K] : 0u;  // deliveries of the variable this thread sums
