@@ -209,27 +209,53 @@ __global__ void __launch_bounds__(256) k_blur_vertical(const uint8_t *__restrict
     }
 }
 // second pass (horizontal_sample): f32 plane -> u8, clamp to [0, 255] and round half away from zero.
-// One output per thread (neighbouring threads read neighbouring floats); four lanes then merge their
-// bytes so that every fourth lane issues one 32-bit store.
+// One output per thread; the 256 outputs of a workgroup read overlapping windows of one row, so the
+// row segment they cover (256 + taps floats) is staged in LDS once instead of being fetched once per
+// tap through L1 / L2; four lanes then merge their bytes so that every fourth lane issues one
+// 32-bit store.  The weight table is tap-major ([tap][column]) so that a wave's weight loads coalesce.
+constexpr int BLUR_TAPS_REG = 16;
 __global__ void __launch_bounds__(256) k_blur_horizontal(const float *__restrict__ tmp, uint8_t *__restrict__ out, uint32_t W, uint32_t H,
                                                          const int32_t *__restrict__ left, const int32_t *__restrict__ cnt,
-                                                         const float *__restrict__ wgt, int T) {
-    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    uint32_t v = 0;
-    if (o < W) {
-        const int l = left[o], n = cnt[o];
-        const float *row = tmp + (size_t)y * W;
-        float t = 0.0f;
-        for (int i = 0; i < n; i++) t += row[l + i] * wgt[(size_t)i * W + o];  // tap-major table: lanes read neighbours
-        t = (t < 0.0f) ? 0.0f : (t > 255.0f ? 255.0f : t);
-        v = (uint32_t)roundf(t);
+                                                         const float *__restrict__ wgt, int T, uint32_t rows) {
+    // `rows` rows per workgroup: the column's weights are fetched once and reused (large images); small
+    // images keep one row per workgroup so that the grid still fills the chip
+    extern __shared__ float s_row[];
+    const uint32_t o_first = blockIdx.x * blockDim.x, o = o_first + threadIdx.x, y0 = blockIdx.y * rows;
+    const uint32_t o_last = (o_first + blockDim.x - 1 < W) ? o_first + blockDim.x - 1 : W - 1;
+    const int lo = left[o_first], hi = left[o_last] + cnt[o_last];  // windows move right with the output
+    const int l = (o < W) ? left[o] - lo : 0, n = (o < W) ? cnt[o] : 0;
+    float wreg[BLUR_TAPS_REG];  // this column's weights, when they fit (sigma up to ~3 pixels)
+    const bool in_regs = T <= BLUR_TAPS_REG;
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < BLUR_TAPS_REG; i++) wreg[i] = (i < n) ? wgt[(size_t)i * W + o] : 0.0f;
     }
-    const uint32_t v1 = __shfl_down(v, 1, 64), v2 = __shfl_down(v, 2, 64), v3 = __shfl_down(v, 3, 64);
-    if (o >= W) return;
-    if ((W & 3u) == 0) {
-        if ((o & 3u) == 0) *reinterpret_cast<uint32_t *>(out + (size_t)y * W + o) = v | (v1 << 8) | (v2 << 16) | (v3 << 24);
-    } else {
-        out[(size_t)y * W + o] = (uint8_t)v;
+    for (uint32_t y = y0; y < y0 + rows && y < H; y++) {
+        const float *row = tmp + (size_t)y * W;
+        __syncthreads();  // the previous row's readers are done
+        for (int j = threadIdx.x; j < hi - lo; j += blockDim.x) s_row[j] = row[lo + j];
+        __syncthreads();
+        uint32_t v = 0;
+        if (o < W) {
+            float t = 0.0f;
+            if (in_regs) {
+#pragma unroll
+                for (int i = 0; i < BLUR_TAPS_REG; i++)
+                    if (i < n) t += s_row[l + i] * wreg[i];
+            } else {
+                for (int i = 0; i < n; i++) t += s_row[l + i] * wgt[(size_t)i * W + o];
+            }
+            t = (t < 0.0f) ? 0.0f : (t > 255.0f ? 255.0f : t);
+            v = (uint32_t)roundf(t);
+        }
+        const uint32_t v1 = __shfl_down(v, 1, 64), v2 = __shfl_down(v, 2, 64), v3 = __shfl_down(v, 3, 64);
+        if (o < W) {
+            if ((W & 3u) == 0) {
+                if ((o & 3u) == 0) *reinterpret_cast<uint32_t *>(out + (size_t)y * W + o) = v | (v1 << 8) | (v2 << 16) | (v3 << 24);
+            } else {
+                out[(size_t)y * W + o] = (uint8_t)v;
+            }
+        }
     }
 }
 
@@ -425,10 +451,12 @@ int env_red_plane(const mgx_env_desc *d, uint32_t resolution, float expansion, f
         }
         ENV_HIP(vl_d.put(vl, s)); ENV_HIP(vc_d.put(vc, s)); ENV_HIP(vw_d.put(vw, s));
         ENV_HIP(hl_d.put(hl, s)); ENV_HIP(hc_d.put(hc, s)); ENV_HIP(hw_d.put(hw, s));
+        const uint32_t hrows = ((uint64_t)W * H >= (1u << 22)) ? 16u : ((uint64_t)W * H >= (1u << 19) ? 4u : 1u);
         ENV_HIP(tmp.alloc((size_t)W * H));
         ENV_HIP(blurred.alloc((size_t)W * H));
         hipLaunchKernelGGL(k_blur_vertical, grid, block, 0, s, plane.p, tmp.p, W, H, vl_d.p, vc_d.p, vw_d.p, TV);
-        hipLaunchKernelGGL(k_blur_horizontal, dim3((W + 255) / 256, H), block, 0, s, tmp.p, blurred.p, W, H, hl_d.p, hc_d.p, hw_d.p, TH);
+        hipLaunchKernelGGL(k_blur_horizontal, dim3((W + 255) / 256, (H + hrows - 1) / hrows), block, sizeof(float) * (size_t)(256 + TH + 2), s, tmp.p, blurred.p, W, H,
+                           hl_d.p, hc_d.p, hw_d.p, TH, hrows);
         ENV_HIP(hipGetLastError());
         result = blurred.p;
     }

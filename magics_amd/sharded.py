@@ -92,7 +92,10 @@ class ShardedWorld:
         plan = self.plan
         self.world = world_factory(sc["params"])
         w = self.world
-        w.set_sdf(sc["sdf"]["rgb"], sc["sdf"]["world_w"], sc["sdf"]["world_h"])
+        if sc.get("env") is not None:
+            w.set_environment(sc["env"])  # every rank rasterises the same environment itself
+        else:
+            w.set_sdf(sc["sdf"]["rgb"], sc["sdf"]["world_w"], sc["sdf"]["world_h"])
         self.lid = {}
         for g in plan.local:
             rb = sc["robots"][g]

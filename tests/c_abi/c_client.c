@@ -30,7 +30,22 @@ int main(void) {
     p.safety_multiplier = 2.5; p.enable_mask = 7;
     rc = mgx_world_create(&p, &w);
     if (rc == MGX_OK) {
+        /* the environment of config/scenarios/Junction Twoway as plain data: one crossroads tile */
+        static const uint32_t tiles[1] = {0x253C};
+        static uint8_t rgb[3 * 200 * 200];
+        mgx_env_desc env;
+        uint32_t iw = 0, ih = 0;
+        memset(&env, 0, sizeof env);
+        env.n_rows = 1; env.n_cols = 1; env.tiles = tiles; env.tile_size = 100.0f; env.path_width = 0.16f;
+        env.sdf_resolution = 200; env.sdf_expansion = 0.01f; env.sdf_blur = 0.01f;
         printf("gpu: world created\n");
+        if (mgx_env_image_size(&env, 200, &iw, &ih) != MGX_OK || iw != 200 || ih != 200) return 10;
+        if (mgx_env_to_sdf_image(&env, 200, 0.01f, 0.01f, rgb) != MGX_OK) return 11;
+        if (rgb[3 * (100 * 200 + 100)] != 255 || rgb[3 * (5 * 200 + 5)] != 0) return 12; /* road centre / corner block */
+        if (mgx_world_set_environment(w, &env) != MGX_OK) return 13;
+        env.path_width = 0.001f; /* path_width - expansion < 0: Percentage::new panics in the reference */
+        if (mgx_env_to_sdf_image(&env, 200, 0.01f, 0.01f, rgb) != MGX_ERR_INVALID) return 14;
+        if (mgx_set_enabled(w, MGX_FACTOR_DYNAMIC | MGX_FACTOR_OBSTACLE) != MGX_OK) return 15;
         if (mgx_world_destroy(w) != MGX_OK) return 8;
     } else if (rc == MGX_ERR_NO_DEVICE) {
         printf("no gpu: %s\n", mgx_last_error());

@@ -75,3 +75,18 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout.decode())
     assert b"c client ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_client_on_the_gpu(tmp_path):
+    """The same C program on a machine with a GPU: it creates a world, rasterises an environment
+    through mgx_env_* / mgx_world_set_environment and checks the error path of the rasteriser."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "c_abi", "c_client.c")
+    exe = str(tmp_path / "c_client")
+    libdir = os.path.join(ROOT, "magics_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                    "-L", libdir, "-lmgx", f"-Wl,-rpath,{libdir}"], check=True)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout.decode())
+    assert b"gpu: world created" in r.stdout and b"c client ok" in r.stdout

@@ -153,3 +153,24 @@ def test_junction_scenario_on_device_rasterised_tiles():
             w.iterate(sc["steps"])
     for a, b in zip(eng.read_beliefs(), ref.read_beliefs()):
         assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
+def test_full_size_environment_through_properties():
+    """BASELINE configs[4] size (20 x 20 tiles, 4000 x 4000 pixels) is beyond what the numpy oracle
+    finishes in seconds; the image is checked through what the domain guarantees instead: every tile
+    is the same crossroads, so away from the image border the picture is periodic with the tile, and
+    its interior equals the oracle's rasterisation of a 3 x 3 neighbourhood's centre tile."""
+    env = S.junction_environment(20)
+    img = ENV.env_to_sdf_image(env)[:, :, 0]
+    assert img.shape == (4000, 4000)
+    res = 200
+    centre = E.env_to_sdf_image(S.junction_environment(3))[res:2 * res, res:2 * res]
+    tiles = img.reshape(20, res, 20, res).transpose(0, 2, 1, 3)
+    assert (tiles[1:-1, 1:-1] == centre).all()            # 18 x 18 interior tiles, byte for byte
+    edge = E.env_to_sdf_image(S.junction_environment(3))
+    assert (tiles[0, 0] == edge[:res, :res]).all() and (tiles[-1, -1] == edge[-res:, -res:]).all()
+    assert (tiles[0, 5] == edge[:res, res:2 * res]).all() and (tiles[7, -1] == edge[res:2 * res, -res:]).all()
+    # the raw (unblurred) image: strictly black / white, and symmetric under the crossroads' symmetries
+    raw = ENV.env_to_image(env, res, 0.01)[:, :, 0]
+    assert set(np.unique(raw)) == {0, 255}
+    assert (raw == raw[::-1, ::-1]).all() and (raw == raw.T).all()

@@ -128,3 +128,17 @@ def test_rccl_transport_loads_and_runs_with_one_rank():
         x.iterate(sc["steps"])
     assert_identical(w, ref, what="one-rank RCCL communicator")
     w.halo_rccl_disconnect()
+
+
+def test_sharded_junction_scenario_rasterises_on_every_rank():
+    """BASELINE configs[4] in small, sharded: every rank rasterises the crossroads itself
+    (mgx_world_set_environment) and the cluster's beliefs equal the single-world oracle's."""
+    sc = S.junction_scenario(60, 12, tiles=2)
+    cluster = sharded.LocalCluster(sc, 3, World)
+    assert any(sw.plan.ghosts for sw in cluster.ranks)
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    for tick in range(2):
+        cluster.iterate(sc["steps"])
+        ref.iterate(sc["steps"])
+        assert_identical(cluster, ref, what=f"junction tiles on 3 ranks, tick {tick}")
