@@ -240,6 +240,19 @@ uint32_t mgx_halo_words(uint32_t K);
  * to the send buffer (in this order) and the ghost robots filled from the receive buffer. */
 int mgx_halo_plan(mgx_world *w, uint32_t n_send, const int32_t *send_robots, uint32_t n_recv,
                   const int32_t *recv_ghosts);
+/* The same lists derived from the connections this world holds, for a sharded world that FOLLOWS its
+ * topology: every rank holds every robot (its own ones and ghost copies of all the others, ids equal
+ * on all ranks), runs mgx_update_topology on all positions — the bookkeeping of robot.rs:1386-1586 is
+ * then replicated, identical everywhere — and exchanges the snapshot records of exactly those robots
+ * that own a connection into a robot of another rank.  rank_of[robot] = owning rank; the lists are
+ * grouped by peer rank, ascending robot id inside a group, and both ends of every exchange derive
+ * matching groups.  send_counts / recv_counts [n_ranks]: records per peer.  Call after every topology
+ * pass that changed something, then exchange once (pack / all-to-all-v / unpack) BEFORE the next
+ * sweep: the factors the pass created take the owner's delivery count of that exchange as their
+ * creation epoch.  Host-driven transports only (the direct / RCCL wirings are per plan). */
+int mgx_halo_plan_from_connections(mgx_world *w, const int32_t *rank_of, uint32_t n_robots,
+                                   int32_t my_rank, uint32_t n_ranks, uint32_t *send_counts,
+                                   uint32_t *recv_counts);
 /* Pack the planned robots' variable->own-factor snapshots (what their inter-robot factors on
  * other ranks read) into `dev_buf` (device pointer, n_send records of mgx_halo_words(K) f64),
  * resp. unpack n_recv records into the ghost robots.  Asynchronous on the world's stream. */

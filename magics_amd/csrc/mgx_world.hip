@@ -1183,7 +1183,6 @@ int mgx_robot_remove(mgx_world *w, int32_t robot) {
     if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
     Robot &rb = w->robots[(size_t)robot];
     if (rb.removed) return fail(MGX_ERR_STATE, "robot %d already removed", robot);
-    if (rb.ghost) return fail(MGX_ERR_STATE, "ghost robots are removed by their owning rank");
     flush_counts(w);
     rb.removed = true;
     rb.idle = 1;
@@ -1278,7 +1277,9 @@ static int neighbours(mgx_world *w, const float *pos, float radius, uint32_t met
     std::vector<int> alive;  // removed robots are in no query: search the others, map back
     std::vector<float> packed;
     for (int r = 0; r < n_all; r++) {
-        if (w->robots[(size_t)r].ghost) return fail(MGX_ERR_STATE, "neighbour search needs every robot on this rank (world has ghost robots)");
+        // ghosts take part: a sharded world that follows a changing topology holds EVERY robot of the
+        // scenario (its own ones and ghost copies of all others) and is handed all positions, so that
+        // the connection bookkeeping below runs identically on every rank
         if (!w->robots[(size_t)r].removed) alive.push_back(r);
     }
     const bool compact = (int)alive.size() != n_all;
@@ -1643,9 +1644,50 @@ int mgx_halo_plan(mgx_world *w, uint32_t n_send, const int32_t *send_robots, uin
     return MGX_OK;
 }
 
+// The exchange lists a rank needs for the connections it holds: every connection A -> B is evaluated on
+// the rank of B, which needs A's snapshot records.  With the replicated bookkeeping of a sharded world
+// that follows its topology (all robots present everywhere) both ends derive the same lists.
+int mgx_halo_plan_from_connections(mgx_world *w, const int32_t *rank_of, uint32_t n_robots, int32_t my_rank, uint32_t n_ranks,
+                                   uint32_t *send_counts, uint32_t *recv_counts) {
+    if (!w || !rank_of || !send_counts || !recv_counts) return fail(MGX_ERR_INVALID, "null argument");
+    if (n_robots != w->robots.size() || my_rank < 0 || (uint32_t)my_rank >= n_ranks) return fail(MGX_ERR_INVALID, "bad rank table");
+    for (uint32_t r = 0; r < n_robots; r++) {
+        if (rank_of[r] < 0 || (uint32_t)rank_of[r] >= n_ranks) return fail(MGX_ERR_INVALID, "robot %u: bad rank %d", r, rank_of[r]);
+        if ((rank_of[r] != my_rank) != w->robots[r].ghost) return fail(MGX_ERR_INVALID, "robot %u: rank table and ghost flag disagree", r);
+    }
+    std::vector<std::vector<int32_t>> send(n_ranks), recv(n_ranks);
+    for (const IrConn &c : w->conns) {
+        const int ro = rank_of[(size_t)c.owner], rt = rank_of[(size_t)c.other];
+        if (ro == rt) continue;
+        if (rt == my_rank) recv[(size_t)ro].push_back(c.owner);
+        else if (ro == my_rank) send[(size_t)rt].push_back(c.owner);
+    }
+    w->halo_send.clear();
+    w->halo_recv.clear();
+    for (uint32_t p = 0; p < n_ranks; p++) {
+        for (std::vector<int32_t> *l : {&send[p], &recv[p]}) {
+            std::sort(l->begin(), l->end());
+            l->erase(std::unique(l->begin(), l->end()), l->end());
+        }
+        send_counts[p] = (uint32_t)send[p].size();
+        recv_counts[p] = (uint32_t)recv[p].size();
+        w->halo_send.insert(w->halo_send.end(), send[p].begin(), send[p].end());
+        w->halo_recv.insert(w->halo_recv.end(), recv[p].begin(), recv[p].end());
+    }
+    w->halo_dirty = true;
+    return MGX_OK;
+}
+
 static int halo_commit(mgx_world *w) {
-    int rc = commit(w);
-    if (rc != MGX_OK) return rc;
+    // Changed connections alone (conns_dirty) are left to the next sweep: an exchange does not read the
+    // edge tables, and the edges created by a topology pass must find the ghosts' records of the exchange
+    // that follows the pass (their creation epoch is the owner's delivery count at that moment).
+    if (w->dirty || !w->dev_valid) {
+        int rc = commit(w);
+        if (rc != MGX_OK) return rc;
+    } else if (!device_ok()) {
+        return fail(MGX_ERR_NO_DEVICE, "no usable HIP device");
+    }
     if (!w->halo_dirty) return MGX_OK;
     std::vector<int32_t> a(w->halo_send.size()), b(w->halo_recv.size());
     for (size_t i = 0; i < a.size(); i++) a[i] = w->dev_of[(size_t)w->halo_send[i]];

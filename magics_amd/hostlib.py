@@ -156,6 +156,8 @@ SYMBOLS = {
     "mgx_num_robots": (C.c_int, [_V, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mgx_halo_words": (C.c_uint32, [C.c_uint32]),
     "mgx_halo_plan": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_int32)]),
+    "mgx_halo_plan_from_connections": (C.c_int, [_V, C.POINTER(C.c_int32), C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32),
+                                                 C.POINTER(C.c_uint32)]),
     "mgx_halo_pack": (C.c_int, [_V, _V]),
     "mgx_halo_unpack": (C.c_int, [_V, _V]),
     "mgx_euclidean_norm": (C.c_double, [c_double_p, C.c_uint32]),

@@ -87,11 +87,22 @@ class ShardPlan:
 
 
 class ShardedWorld:
-    def __init__(self, sc, rank, world_size, world_factory, comm=None, owner=None, tensor_factory=None):
+    def __init__(self, sc, rank, world_size, world_factory, comm=None, owner=None, tensor_factory=None, dynamic=False):
+        """dynamic=True: the world FOLLOWS its topology (robots move, connections come and go).  Every
+        rank then holds every robot of the scenario — its own ones and ghost copies of all the others,
+        under the same ids everywhere — so that `update_topology` on all positions replays the
+        reference's connection bookkeeping (robot.rs:1386-1586: connection sets, robot numbers, node
+        slots) identically on every rank; only the factors whose target is local exist on the device,
+        and the exchange lists are re-derived from the connections after every pass that changed
+        something (`mgx_halo_plan_from_connections`).  Host-driven exchange only."""
         self.sc, self.plan, self.comm = sc, ShardPlan(sc, rank, world_size, owner), comm
         plan = self.plan
+        self.dynamic = dynamic
         self.world = world_factory(sc["params"])
         w = self.world
+        if dynamic:
+            self._init_dynamic(sc, tensor_factory)
+            return
         if sc.get("env") is not None:
             w.set_environment(sc["env"])  # every rank rasterises the same environment itself
         else:
@@ -118,6 +129,79 @@ class ShardedWorld:
         self.recv_buf = make(max(1, sum(self.recv_counts)))
 
         self.direct = False
+
+    # -- a world that follows its topology ---------------------------------------------------------------
+    def _init_dynamic(self, sc, tensor_factory):
+        w, plan = self.world, self.plan
+        if sc.get("env") is not None:
+            w.set_environment(sc["env"])
+        else:
+            w.set_sdf(sc["sdf"]["rgb"], sc["sdf"]["world_w"], sc["sdf"]["world_h"])
+        self.lid = {}
+        for g, rb in enumerate(sc["robots"]):
+            local = plan.owner[g] == plan.rank
+            self.lid[g] = w.add_robot(rb["mean0"], rb["prior_diag"], rb["dt"], rb["radius"], path=rb["path"] if local else None,
+                                      order_key=rb["order_key"], ghost=not local)
+            assert self.lid[g] == g
+        for a, b, n0 in sc["ir"]:
+            w.ir_connect(a, b, n0)  # bookkeeping on every rank; device edges only where b is local
+        self._make = tensor_factory or _torch_tensor_factory
+        self.send_buf = self.recv_buf = None
+        self.direct = False
+        self.replan()
+
+    def replan(self):
+        """Exchange lists for the connections now held (same result on both ends of every exchange)."""
+        plan, words = self.plan, self.world.halo_words(self.plan.K)
+        sc_, rc_ = self.world.halo_plan_from_connections(plan.owner, plan.rank, plan.world_size)
+        self.send_counts, self.recv_counts = [c * words for c in sc_], [c * words for c in rc_]
+        for name, need in (("send_buf", sum(self.send_counts)), ("recv_buf", sum(self.recv_counts))):
+            buf = getattr(self, name)
+            if buf is None or buf.numel() < max(1, need):
+                setattr(self, name, self._make(max(1, need) * 2))
+
+    def update_topology(self, positions_all, radius, next_number, method=hostlib.NEIGHBOURS_AUTO):
+        """One topology pass on ALL robots' positions (the caller gathers them); then the new exchange
+        lists and one exchange, so that the factors the pass created find their owners' current records
+        when the next sweep lays them out.  Collective: every rank calls it with the same arguments."""
+        assert self.dynamic
+        out = self.world.update_topology(positions_all, radius, next_number, method=method)
+        if out[1] or out[2]:
+            self.replan()
+            if self.comm is not None:
+                self.exchange()
+        return out
+
+    # per-tick calls of a driver over global robot ids: every rank runs the same driver (replicated
+    # control plane, magics_amd/driver.py) and applies to its world what concerns it
+    def read_variable_means(self, var_ix):
+        assert self.dynamic
+        n = len(self.plan.owner)
+        out = np.zeros((n, 4))
+        mine = (list(self.plan.local), self.world.read_variable_means(var_ix))
+        for ids, rows in ([mine] if self.comm is None else self.comm.all_gather_object(mine)):
+            out[ids] = rows
+        return out
+
+    def update_priors(self, robots, waypoints_xy, time_scale, what, max_speed, delta_t):
+        robots = np.asarray(robots)
+        mine = np.nonzero(self.plan.owner[robots] == self.plan.rank)[0]
+        if len(mine):
+            self.world.update_priors(robots=robots[mine].astype(np.int32), waypoints_xy=np.asarray(waypoints_xy)[mine],
+                                     time_scale=np.asarray(time_scale)[mine], what=np.asarray(what)[mine], max_speed=max_speed,
+                                     delta_t=delta_t)
+
+    def set_antennas(self, robots, active):
+        self.world.set_antennas(robots, active)  # flags of every robot live on every rank
+
+    def remove_robot(self, robot):
+        self.world.remove_robot(robot)
+
+    def connections(self, robot):
+        return self.world.connections(robot)
+
+    def message_counts(self, robot):
+        return (0, 0, 0, 0)  # MessageCount is kept for unsharded worlds only (include/mgx.h)
 
     # -- direct exchange wiring ----------------------------------------------------------------------
     def direct_setup(self, export_ipc):
@@ -206,6 +290,7 @@ class ShardedWorld:
         if robot in self.lid:
             self.world.set_idle(self.lid[robot], idle)
 
+
     def change_prior(self, robot, var_ix, mean):
         if self.plan.owner[robot] == self.plan.rank:
             self.world.change_prior(self.lid[robot], var_ix, mean)
@@ -288,12 +373,15 @@ class LocalCluster:
     """All ranks of a sharded world inside ONE process (one GPU): used by the tests to check the
     ghost / halo numerics against the unsharded world without a multi-GPU node."""
 
-    def __init__(self, sc, world_size, world_factory, owner=None, tensor_factory=None, direct=False):
+    def __init__(self, sc, world_size, world_factory, owner=None, tensor_factory=None, direct=False, dynamic=False):
         """direct=True: the ranks exchange through peer-mapped stores (same address space, no IPC);
         `world_factory` must then give every rank its OWN stream — a rank's wait kernel would block
-        a shared stream before the other rank's stores are even enqueued."""
+        a shared stream before the other rank's stores are even enqueued.
+        dynamic=True: worlds that follow their topology (see ShardedWorld); the cluster then also
+        offers the per-tick calls of magics_amd.driver.Driver over global robot ids."""
+        assert not (direct and dynamic)
         self.ranks = [ShardedWorld(sc, r, world_size, world_factory, comm=None, owner=owner,
-                                   tensor_factory=tensor_factory) for r in range(world_size)]
+                                   tensor_factory=tensor_factory, dynamic=dynamic) for r in range(world_size)]
         self.n_robots, self.K = len(sc["robots"]), sc["K"]
         if direct and world_size > 1:
             infos = {sw.plan.rank: sw.direct_setup(export_ipc=False) for sw in self.ranks}
@@ -332,13 +420,58 @@ class LocalCluster:
             for sw in self.ranks:
                 sw.sweep_segment(ext, n_int, next_ext=k + 1 < len(segs) and segs[k + 1][0])
 
+    # -- per-tick calls of a driver, over global robot ids (dynamic clusters) ------------------------------
+    def update_topology(self, positions_all, radius, next_number, method=hostlib.NEIGHBOURS_AUTO):
+        outs = [sw.update_topology(positions_all, radius, next_number, method=method) for sw in self.ranks]
+        assert all(o == outs[0] for o in outs), "the replicated bookkeeping diverged"
+        if (outs[0][1] or outs[0][2]) and len(self.ranks) > 1:
+            self._exchange()
+        return outs[0]
+
+    def read_variable_means(self, var_ix):
+        out = np.zeros((self.n_robots, 4))
+        for sw in self.ranks:
+            out[sw.plan.local] = sw.world.read_variable_means(var_ix)
+        return out
+
+    def update_priors(self, robots, waypoints_xy, time_scale, what, max_speed, delta_t):
+        robots = np.asarray(robots)
+        for sw in self.ranks:
+            mine = np.nonzero(sw.plan.owner[robots] == sw.plan.rank)[0]
+            if len(mine):
+                sw.world.update_priors(robots=robots[mine].astype(np.int32), waypoints_xy=np.asarray(waypoints_xy)[mine],
+                                       time_scale=np.asarray(time_scale)[mine], what=np.asarray(what)[mine], max_speed=max_speed,
+                                       delta_t=delta_t)
+
+    def set_antennas(self, robots, active):
+        for sw in self.ranks:  # flags of every robot are kept on every rank (they gate both ends of a connection)
+            sw.world.set_antennas(robots, active)
+
+    def remove_robot(self, robot):
+        for sw in self.ranks:
+            sw.world.remove_robot(robot)
+
+    def connections(self, robot):
+        outs = [sw.world.connections(robot) for sw in self.ranks]
+        assert all(list(o) == list(outs[0]) for o in outs)
+        return outs[0]
+
+    def message_counts(self, robot):
+        return (0, 0, 0, 0)  # MessageCount is kept for unsharded worlds only (include/mgx.h)
+
     def set_antenna(self, robot, active):
         for sw in self.ranks:
-            sw.set_antenna(robot, active)
+            if sw.dynamic:
+                sw.world.set_antenna(robot, active)
+            else:
+                sw.set_antenna(robot, active)
 
     def set_idle(self, robot, idle):
         for sw in self.ranks:
-            sw.set_idle(robot, idle)
+            if sw.dynamic:
+                sw.world.set_idle(robot, idle)
+            else:
+                sw.set_idle(robot, idle)
 
     def change_prior(self, robot, var_ix, mean):
         for sw in self.ranks:

@@ -287,6 +287,15 @@ class World:
         ip = C.POINTER(C.c_int32)
         self._chk(self._L.mgx_halo_plan(self._w, len(a), a.ctypes.data_as(ip), len(b), b.ctypes.data_as(ip)))
 
+    def halo_plan_from_connections(self, rank_of, my_rank, n_ranks):
+        """Exchange lists derived from the connections held (mgx_halo_plan_from_connections):
+        returns (send_counts, recv_counts) in records per peer rank."""
+        rank_of = np.ascontiguousarray(rank_of, dtype=np.int32)
+        sc, rc = (C.c_uint32 * n_ranks)(), (C.c_uint32 * n_ranks)()
+        self._chk(self._L.mgx_halo_plan_from_connections(self._w, rank_of.ctypes.data_as(C.POINTER(C.c_int32)), rank_of.size,
+                                                         int(my_rank), int(n_ranks), sc, rc))
+        return list(sc), list(rc)
+
     def halo_pack(self, dev_ptr):
         self._chk(self._L.mgx_halo_pack(self._w, C.c_void_p(dev_ptr)))
 

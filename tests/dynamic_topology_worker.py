@@ -1,0 +1,38 @@
+"""One rank of the multi-process dynamic-topology test (tests/test_gpu_sharded_topology_mp.py): every
+rank is its own process on cuda:0 with a sharded world that follows its topology; the control plane
+and the halo all-to-all-v go through gloo (device buffers staged through the host — a dry run of the
+RCCL path).  Every rank runs the same driver.  usage: dynamic_topology_worker.py RANK WORLD_SIZE PORT OUT.npz"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, ws, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(ws))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    torch.cuda.set_device(0)
+    from magics_amd import World, scenarios as S, sharded
+    from magics_amd.driver import Driver
+    n, K, ticks = 8, 10, 60
+    sc = S.circle_scenario(n, K, circle_radius=12.0, n_internal=10, n_external=10)
+    sc["ir"] = []
+    comm = sharded.TorchDistComm(stage_through_host=True)
+    sw = sharded.ShardedWorld(sc, rank, ws, World, comm=comm, owner=np.arange(n) % ws, dynamic=True)
+    drv = Driver(sw, n, K, waypoints=[[tuple(rb["goal"])] for rb in sc["robots"]], radii=[rb["radius"] for rb in sc["robots"]],
+                 t0=[rb["t0"] for rb in sc["robots"]], steps=sc["steps"], comms_radius=12.0, target_speed=sc["target_speed"])
+    events = [drv.tick() for _ in range(ticks)]
+    ids, eta, lam, mu = sw.read_beliefs()
+    np.savez(out, ids=np.array(ids), eta=eta, lam=lam, mu=mu, events=np.array(events), translation=drv.translation,
+             finished_at=drv.finished_at, next_number=drv.next_number)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -142,3 +142,63 @@ def test_sharded_junction_scenario_rasterises_on_every_rank():
         cluster.iterate(sc["steps"])
         ref.iterate(sc["steps"])
         assert_identical(cluster, ref, what=f"junction tiles on 3 ranks, tick {tick}")
+
+
+def _circle_driver(w, sc, n, K, **kw):
+    from magics_amd.driver import Driver
+    return Driver(w, n, K, waypoints=[[tuple(rb["goal"])] for rb in sc["robots"]], radii=[rb["radius"] for rb in sc["robots"]],
+                  t0=[rb["t0"] for rb in sc["robots"]], steps=sc["steps"], comms_radius=12.0, target_speed=sc["target_speed"], **kw)
+
+
+@pytest.mark.parametrize("world_size", [2, 3])
+def test_sharded_world_follows_its_topology(world_size):
+    """A whole mission on a sharded world that follows its topology: robots cross a circle, connect and
+    disconnect across rank boundaries, arrive and despawn.  Every rank replays the connection
+    bookkeeping on all positions; exchange lists follow the connections.  Topology events, robot
+    numbers, trajectories and beliefs equal the single-world oracle's, tick by tick."""
+    n, K = 9, 10
+    sc = S.circle_scenario(n, K, circle_radius=12.0, n_internal=10, n_external=10)
+    sc["ir"] = []
+    owner = np.arange(n) % world_size  # interleaved ownership: every neighbour pair crosses a rank boundary sooner or later
+    cluster = sharded.LocalCluster(sc, world_size, World, owner=owner, dynamic=True)
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    dc, dr = _circle_driver(cluster, sc, n, K), _circle_driver(ref, sc, n, K)
+    events, plans = [], set()
+    for tick in range(400):
+        if not (dc.finished_at < 0).any():
+            break
+        ec, er = dc.tick(), dr.tick()
+        assert ec == er, (tick, ec, er)
+        events.append(ec)
+        assert dc.next_number == dr.next_number
+        assert np.array_equal(dc.translation, dr.translation) and np.array_equal(dc.finished_at, dr.finished_at), tick
+        plans.add(tuple(tuple(sw.send_counts) for sw in cluster.ranks))
+        if tick % 10 == 9:
+            assert_identical(cluster, ref, what=f"{world_size} ranks following their topology, tick {tick + 1}")
+            for r in range(n):
+                if dc.alive[r]:
+                    assert list(cluster.connections(r)) == list(ref.connections(r))
+    assert (dc.finished_at >= 0).all() and np.array_equal(dc.finished_at, dr.finished_at)
+    assert sum(c for c, _ in events) > n and sum(d for _, d in events) > 0   # connections came and went
+    assert len(plans) > 3                                                      # and the exchange lists with them
+
+
+def test_sharded_topology_with_comms_failures_and_initial_connections():
+    n, K, world_size = 10, 10, 2
+    sc = S.circle_scenario(n, K, circle_radius=10.0, n_internal=10, n_external=10)   # comes with its initial connections
+    assert sc["ir"]
+    cluster = sharded.LocalCluster(sc, world_size, World, dynamic=True)
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    rng = np.random.default_rng(11)
+    draws = rng.random((80, n)) > 0.25
+
+    def failures(tick, k):
+        return draws[tick, :k]
+    first = 1 + (K - 1) * len(sc["ir"])
+    dc, dr = (_circle_driver(w, sc, n, K, failure_draws=failures, despawn_when_finished=False) for w in (cluster, ref))
+    dc.next_number = dr.next_number = first
+    for tick in range(80):
+        assert dc.tick() == dr.tick(), tick
+    assert_identical(cluster, ref, what="2 ranks, comms failures, initial connections")

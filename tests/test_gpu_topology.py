@@ -176,14 +176,24 @@ def test_bulk_antennas_match_single_calls():
     assert_identical(eng, ref, what="bulk antenna writes")
 
 
-def test_topology_calls_reject_sharded_worlds():
+def test_ghost_robots_take_part_in_the_search():
+    """A sharded world that follows its topology holds ghost copies of the other ranks' robots and
+    is handed all positions: the search covers them (magics_amd/sharded.py, dynamic mode)."""
     sc = S.grid_scenario(4, 10, interrobot=False)
     w = World(sc["params"])
     S.populate(w, sc)
     rb = sc["robots"][0]
-    w.add_robot(rb["mean0"], rb["prior_diag"], rb["dt"], rb["radius"], order_key=99, ghost=True)
-    with pytest.raises(RuntimeError, match="ghost"):
-        w.neighbours(np.zeros((5, 3), dtype=np.float32), 1.0)
+    g = w.add_robot(rb["mean0"], rb["prior_diag"], rb["dt"], rb["radius"], order_key=99, ghost=True)
+    pos = np.zeros((5, 3), dtype=np.float32)
+    pos[:, 0] = [0.0, 10.0, 20.0, 30.0, 10.5]
+    ptr, idx = w.neighbours(pos, 1.0)
+    rows = [list(idx[ptr[r]:ptr[r + 1]]) for r in range(5)]
+    assert rows == [[], [g], [], [], [1]]
+    nxt, created, deleted = w.update_topology(pos, 1.0, 1)
+    assert (created, deleted) == (2, 0) and nxt == 1 + 2 * 9
+    assert list(w.connections(1)) == [g] and list(w.connections(g)) == [1]
+    w.iterate(sc["steps"])  # only the connection whose target is local has device edges
+    assert np.isfinite(w.read_beliefs()[2]).all()
 
 
 def test_robot_removal_between_ticks():
