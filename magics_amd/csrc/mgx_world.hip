@@ -1194,10 +1194,11 @@ int mgx_robot_remove(mgx_world *w, int32_t robot) {
 
 // FactorGraph::change_factor_enabled for every graph (factorgraph.rs:1529-1539, ui/settings.rs:491-496).
 // Disabling is exact as it stands: a disabled factor is never updated (its last message stays in the
-// variable's inbox and keeps being summed, factorgraph.rs:695,734), change_prior still empties and
-// re-delivers (variable.rs:203-230), the counters stop counting it.  Re-enabling a kind that has
-// missed deliveries would need the inbox its factors froze with (the engine derives factor inboxes
-// from the variables' snapshots) and is refused with MGX_ERR_STATE.
+// variable's inbox and keeps being summed, factorgraph.rs:695,734) and drops whatever is sent to it
+// (FactorNode::receive_message_from returns early, factor/mod.rs:307-310) while change_prior still
+// empties the variables' inboxes (variable.rs:224-227); the counters stop counting it.  Re-enabling a
+// kind that has missed deliveries would need the inbox its factors froze with (the engine derives factor
+// inboxes from the variables' current snapshots) and is refused with MGX_ERR_STATE.
 int mgx_set_enabled(mgx_world *w, uint32_t kind_mask) {
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (kind_mask & ~15u) return fail(MGX_ERR_INVALID, "unknown factor kind bits 0x%x", kind_mask);

@@ -37,6 +37,12 @@ impl World {
         assert_eq!(rgb.len(), (width * height * 3) as usize);
         check(unsafe { sys::mgx_world_set_sdf(self.raw, rgb.as_ptr(), width, height, world_w, world_h) })
     }
+    /// `env_to_png::env_to_sdf_image` with the environment's own sdf settings + the `Sdf` resource handed
+    /// to every `ObstacleFactor` (simulation_loader.rs:154-162, robot.rs:1259-1285): rasterised and
+    /// blurred on the device.  `desc` must point at live tile / obstacle arrays for the call.
+    pub fn set_environment(&self, desc: &sys::mgx_env_desc) -> Result<(), MgxError> {
+        check(unsafe { sys::mgx_world_set_environment(self.raw, desc) })
+    }
     /// `update_robot_neighbours` + `delete_interrobot_factors` + `create_interrobot_factors`
     /// (robot.rs:1362-1586) in one call: `translations` are the robots' `Transform::translation`
     /// in robot-id order, `robot_number` is the `RobotNumberGenerator` state.  Returns

@@ -33,7 +33,54 @@ pub struct mgx_robot_desc {
     pub reserved: u32,
 }
 
+pub const MGX_SHAPE_CIRCLE: i32 = 0;
+pub const MGX_SHAPE_TRIANGLE: i32 = 1;
+pub const MGX_SHAPE_REGULAR_POLYGON: i32 = 2;
+pub const MGX_SHAPE_POLYGON: i32 = 3;
+pub const MGX_SHAPE_RECTANGLE: i32 = 4;
+
+/// gbp_environment::Obstacle as plain data (include/mgx.h)
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct mgx_env_obstacle {
+    pub shape: i32,
+    pub tile_row: i32,
+    pub tile_col: i32,
+    pub sides: u32,
+    pub n_points: u32,
+    pub points_xy: *const f64,
+    pub radius: f64,
+    pub angle_a: f64,
+    pub angle_b: f64,
+    pub width: f64,
+    pub height: f64,
+    pub rotation: f64,
+    pub translation_x: f64,
+    pub translation_y: f64,
+}
+
+/// gbp_environment::Environment as plain data (include/mgx.h)
+#[repr(C)]
+pub struct mgx_env_desc {
+    pub n_rows: u32,
+    pub n_cols: u32,
+    pub tiles: *const u32,
+    pub tile_size: f32,
+    pub path_width: f32,
+    pub sdf_resolution: u32,
+    pub sdf_expansion: f32,
+    pub sdf_blur: f32,
+    pub n_obstacles: u32,
+    pub obstacles: *const mgx_env_obstacle,
+}
+
 extern "C" {
+    pub fn mgx_env_image_size(env: *const mgx_env_desc, resolution: u32, width: *mut u32, height: *mut u32) -> c_int;
+    pub fn mgx_env_to_image(env: *const mgx_env_desc, resolution: u32, expansion: f32, rgb: *mut u8) -> c_int;
+    pub fn mgx_env_to_sdf_image(env: *const mgx_env_desc, resolution: u32, expansion: f32, blur_percent: f32, rgb: *mut u8) -> c_int;
+    pub fn mgx_world_set_environment(w: *mut mgx_world, env: *const mgx_env_desc) -> c_int;
+    pub fn mgx_halo_plan_from_connections(w: *mut mgx_world, rank_of: *const i32, n_robots: u32, my_rank: i32, n_ranks: u32,
+                                          send_counts: *mut u32, recv_counts: *mut u32) -> c_int;
     pub fn mgx_world_create(params: *const mgx_params, out: *mut *mut mgx_world) -> c_int;
     pub fn mgx_world_destroy(w: *mut mgx_world) -> c_int;
     pub fn mgx_last_error() -> *const c_char;
