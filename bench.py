@@ -295,6 +295,25 @@ class _Deadline:
             self._t.cancel()
 
 
+def scenario_run(World, name="Junction Twoway", sim_seconds=30.0):
+    """The reference's scenario files (parsed form: tests/golden/scenarios.json) run headless on the
+    engine: environment rasterised on the device, formations spawned over time, whole ticks of the
+    driver chain (topology pass, prior updates, GBP schedule, waypoints / despawn) — simulated seconds
+    per wall-clock second, host logic included."""
+    from magics_amd import config, sim
+    with open(os.path.join(ROOT, "tests", "golden", "scenarios.json"), encoding="utf-8") as f:
+        sc = json.load(f)[name]
+    s = sim.Simulation(sc, World(config.world_params(sc["config"])))
+    t0 = time.perf_counter()
+    s.run(max_time=sim_seconds)
+    s.w.synchronize()
+    wall = time.perf_counter() - t0
+    return {"name": name, "simulated_s": round(s.elapsed(), 2), "wall_s": round(wall, 3), "ticks": s.tick_no,
+            "ticks_per_s": round(s.tick_no / wall, 1), "robots_spawned": len(s.robots), "horizon": s.K,
+            "what": "config.toml + environment.yaml + formation.yaml of the reference, unmodified: device rasteriser, "
+                    "spawner, topology pass, prior updates, GBP schedule, waypoint logic (Python host loop included)"}
+
+
 def main():
     a = parse()
     if a.role in ("direct-child", "rccl-child"):
@@ -458,6 +477,13 @@ def main():
                                             "updates + 10 GBP iterations with inter-robot factors"}
         except Exception as e:  # noqa: BLE001
             line["dynamic_tick"] = {"error": f"{type(e).__name__}: {e}"}
+
+    # ---- a reference scenario end to end (N = 1): the front-end of SURVEY §8 f3 ----------------------------
+    if not multi and not a.no_secondary and not a.no_dynamic:
+        try:
+            line["scenario"] = scenario_run(World)
+        except Exception as e:  # noqa: BLE001
+            line["scenario"] = {"error": f"{type(e).__name__}: {e}"}
 
     guard.cancel()
 
