@@ -94,6 +94,17 @@ struct DevWorld {
     double *ir_bmu;                 // [4][NI] mean of the target variable -> factor message (the
                                     // only part of that inbox entry the kept output depends on)
 
+    // Factor kinds switched back ON at run time (mgx_set_enabled).  A disabled factor receives nothing
+    // (factor/mod.rs:307-310), so when its kind is enabled again it resumes from the inbox it had when it
+    // was switched off.  That inbox is kept per internal edge, in edge-slot order: 2(K-1) dynamic lanes
+    // x 20 (eta, lam of the OTHER variable's message), then K-2 obstacle and K-2 tracking factors x 4 (the
+    // mean they linearise at); frozen_flag says whether the entry is present (a message, not empty).
+    double *frozen;        // [R_local][frozen_words(K)] or null: no kind has ever been switched at run time
+    uint8_t *frozen_flag;  // [R_local][E]
+    uint8_t *thaw;         // [R_local] kinds (MGX_FACTOR_* bits) whose factors take their next update from `frozen`
+    uint8_t *skip0;        // [R_local] kinds whose first factor sweep of the coming launch k_thaw has computed; null
+                           //           whenever no robot is thawing (the sweep kernel then reads nothing)
+
     const uint8_t *antenna, *idle;  // [R_total]
 
     // obstacle image
@@ -107,6 +118,8 @@ struct DevWorld {
     // diagnostic builds only (-DMGX_STAMPS, tools/stamps.py): per-workgroup phase cycle sums
     unsigned long long *dbg;
 };
+
+__host__ __device__ constexpr int frozen_words(int K) { return 40 * (K - 1) + 8 * (K - 2); }
 
 // phases of one launch
 constexpr uint32_t PH_EXT_FACTOR = 1u;    // external_factor_iteration (+ routing)

@@ -172,6 +172,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     const int ie0 = HAS_IR ? w.ir_var_ptr[v0] : 0, ne = HAS_IR ? w.ir_var_ptr[v0 + K] - ie0 : 0;
     const bool ir_on = HAS_IR && (w.enable & 2u) != 0;
     const int n_dyn = 2 * (K - 1);
+    // kinds whose first internal factor sweep of this launch has already been computed from the inbox they
+    // froze with (k_thaw, mgx_set_enabled); the pointer is null unless some robot is thawing
+    const uint32_t skip0 = w.skip0 ? (uint32_t)w.skip0[r] : 0u;
     const bool idle = w.idle[r] != 0;
     const bool radio = (w.antenna[r] != 0) && !idle;
 
@@ -576,7 +579,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         // sweeps produce (a dynamic factor reads the snapshot of the last INTERNAL variable sweep and
         // its own previous messages): the DYN wave computes its messages now, next to the UV wave's
         // mean / covariance of the external variable sweep (one 4x4 inverse per variable either way).
-        if (radio && role == ROLE_DYN && is_dyn && (w.enable & 1u) && n_int > 0 && !idle && (int_mask & PH_INT_FACTOR)) {
+        if (radio && role == ROLE_DYN && is_dyn && (w.enable & 1u) && !(skip0 & 1u) && n_int > 0 && !idle && (int_mask & PH_INT_FACTOR)) {
             dynamic_messages();
             dyn_prefired = true;
         }
@@ -610,14 +613,14 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         for (int it = 0; it < n_int && !idle; it++) {
             STAMP(t0);
             if (int_mask & PH_INT_FACTOR) {
-                if (is_dyn && (w.enable & 1u) && !(it == 0 && dyn_prefired)) dynamic_messages();
+                if (is_dyn && (w.enable & 1u) && !(it == 0 && (dyn_prefired || (skip0 & 1u)))) dynamic_messages();
                 // UV wave: first the belief of the previous sweep (mean, covariance) that the unary
                 // factors linearise at — same wave, so its LDS writes precede their LDS reads
                 if (pending && is_var) variable_finish(s_snap, true);
                 pending = false;
                 if (obs_rows) {
                     // four lanes per obstacle factor: lane q samples tap q and writes row q of the message
-                    if (role == ROLE_UV && lane < 4 * (K - 2) && (w.enable & 4u)) {
+                    if (role == ROLE_UV && lane < 4 * (K - 2) && (w.enable & 4u) && !(it == 0 && (skip0 & 4u))) {
                         const int j = lane >> 2, q = lane & 3, var = j + 1, col = n_dyn + j;
                         double x0[4];
                         const bool pres = s_epoch[var] > 0;
@@ -634,7 +637,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #pragma unroll
                         for (int c = 0; c < 4; c++) s_fv[(4 + q * 4 + c) * E1 + col] = lam_q[c];
                     }
-                } else if (is_obs && (w.enable & 4u)) {
+                } else if (is_obs && (w.enable & 4u) && !(it == 0 && (skip0 & 4u))) {
                     double x0[4], oe[4], ol[16];
                     const bool pres = s_epoch[uvar] > 0;
 #pragma unroll
@@ -650,7 +653,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #pragma unroll
                     for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + uedge] = ol[c];
                 }
-                if (is_trk && (w.enable & 8u) && itf >= 10) {  // factorgraph.rs:701
+                if (is_trk && (w.enable & 8u) && itf >= 10 && !(it == 0 && (skip0 & 8u))) {  // factorgraph.rs:701
                     double x0[4], oe[4], ol[16];
 #pragma unroll
                     for (int c = 0; c < 4; c++) x0[c] = s_snap[(20 + c) * K + uvar];
@@ -772,6 +775,38 @@ __device__ void apply_change_prior(const DevWorld &w, int r, int i, const double
         w.ir_fv_lam[4 * (size_t)w.NI + e] = 0.0;
         w.ir_fv_lam[5 * (size_t)w.NI + e] = 0.0;
     }
+    // factors that are thawing (enabled again, first update still to come) receive this delivery like any
+    // enabled factor: it replaces the entry they froze with
+    if (w.thaw) {
+        const uint32_t tb = w.thaw[r];
+        if (tb) {
+            double *fz = w.frozen + (size_t)r * frozen_words(K);
+            uint8_t *fl = w.frozen_flag + (size_t)r * E;
+            if (tb & 1u) {
+                const int lanes[2] = {(i >= 1) ? i - 1 : -1, (i <= K - 2) ? (K - 1) + i : -1};  // lanes whose OTHER variable is i
+                for (int q = 0; q < 2; q++) {
+                    if (lanes[q] < 0) continue;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) fz[lanes[q] * 20 + c] = be[c];
+#pragma unroll
+                    for (int c = 0; c < 16; c++) fz[lanes[q] * 20 + 4 + c] = bl[c];
+                    fl[lanes[q]] = 1;
+                }
+            }
+            if (i >= 1 && i <= K - 2) {
+                if (tb & 4u) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) fz[40 * (K - 1) + 4 * (i - 1) + c] = m[c];
+                    fl[2 * (K - 1) + (i - 1)] = 1;
+                }
+                if (tb & 8u) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) fz[40 * (K - 1) + 4 * (K - 2) + 4 * (i - 1) + c] = m[c];
+                    fl[2 * (K - 1) + (K - 2) + (i - 1)] = 1;
+                }
+            }
+        }
+    }
     const int n_dyn = 2 * (K - 1);
     const int es[4] = {(i >= 1) ? (K - 1) + (i - 1) : -1, (i <= K - 2) ? i : -1,
                        (i >= 1 && i <= K - 2) ? n_dyn + (i - 1) : -1,
@@ -830,6 +865,132 @@ __global__ void k_update_priors(DevWorld w, int n, const int32_t *robots, const 
         }
         apply_change_prior(w, r, 0, m);
     }
+}
+
+// ---- factor kinds switched off and on at run time (mgx_set_enabled) ------------------------------------
+// k_freeze: the inbox of every internal factor of the given kinds as it is NOW (a kind is being switched
+// off: from here on these factors receive nothing, factor/mod.rs:307-310), one thread per (robot, edge slot).
+__global__ void k_freeze(DevWorld w, uint32_t kinds) {
+    const int K = w.K, E = w.E, E1 = E + 1, n_dyn = 2 * (K - 1);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= w.R_local * E) return;
+    const int r = t / E, e = t - r * E;
+    const uint32_t bit = e < n_dyn ? 1u : (e < n_dyn + (K - 2) ? 4u : 8u);
+    if (!(kinds & bit)) return;
+    if (w.thaw[r] & bit) return;  // still thawing from an earlier switch: the inbox it froze with then is still its inbox
+    const BlobLayout L(K);
+    const double *blob = w.blob + (size_t)r * w.BS;
+    double *fz = w.frozen + (size_t)r * frozen_words(K);
+    const int v0 = r * K;
+    if (bit == 1u) {  // what the lane of k_robot_sweep would read: the other variable's snapshot minus our last message to it
+        const int f = e % (K - 1), slot = e / (K - 1), o = f + 1 - slot, oe_ix = (1 - slot) * (K - 1) + f;
+        const bool present = w.snap_epoch[w.cur][v0 + o] > 0;
+        const double *rec = w.snap[w.cur] + (size_t)(v0 + o) * SNAP_W;
+        for (int c = 0; c < 20; c++) fz[e * 20 + c] = present ? rec[c] - blob[L.fv() + c * E1 + oe_ix] : 0.0;
+        w.frozen_flag[(size_t)r * E + e] = present ? 1 : 0;
+    } else {
+        const int j = (bit == 4u) ? e - n_dyn : e - n_dyn - (K - 2), var = j + 1;
+        const bool present = w.snap_epoch[w.cur][v0 + var] > 0;
+        const double *rec = w.snap[w.cur] + (size_t)(v0 + var) * SNAP_W;
+        double *dst = fz + 40 * (K - 1) + (bit == 8u ? 4 * (K - 2) : 0) + 4 * j;
+        for (int c = 0; c < 4; c++) dst[c] = present ? rec[20 + c] : 0.0;
+        w.frozen_flag[(size_t)r * E + e] = present ? 1 : 0;
+    }
+}
+// thaw[r] = (thaw[r] & keep) | set: a kind is being switched on again (set) / off while still thawing (keep)
+__global__ void k_or_bytes(uint8_t *p, int n, uint8_t keep, uint8_t set) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) p[t] = (uint8_t)((p[t] & keep) | set);
+}
+// k_thaw: runs right before a launch of k_robot_sweep that contains an internal factor sweep.  For every
+// robot that takes part (not idle) and has thawing kinds, the first update of those factors is computed
+// here from the inbox they froze with — same functions, same operand order as the sweep kernel — and
+// written to the robot's blob; skip0[r] then tells the sweep kernel to leave those kinds alone in its first
+// internal factor sweep.  One thread per (robot, edge slot).
+__global__ void k_thaw(DevWorld w, int robot0, int n_robots, uint32_t ext_mask) {
+    const int K = w.K, E = w.E, E1 = E + 1, n_dyn = 2 * (K - 1);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_robots * E) return;
+    const int r = robot0 + t / E, e = t % E;
+    const uint32_t tb = (uint32_t)w.thaw[r] & w.enable & 13u;
+    const bool idle = w.idle[r] != 0;
+    if (!tb || idle) return;
+    if (e == 0) w.skip0[r] = (uint8_t)tb;
+    const uint32_t bit = e < n_dyn ? 1u : (e < n_dyn + (K - 2) ? 4u : 8u);
+    if (!(tb & bit)) return;
+    const BlobLayout L(K);
+    double *blob = w.blob + (size_t)r * w.BS;
+    const double *fz = w.frozen + (size_t)r * frozen_words(K);
+    const bool present = w.frozen_flag[(size_t)r * E + e] != 0;
+    double oe[4], ol[16];
+    bool ok = true;
+    if (bit == 1u) {
+        const int f = e % (K - 1), slot = e / (K - 1);
+        const int a2 = 2 * slot, b2 = 2 * (1 - slot), it = r * (K - 1) + f;
+        double maa[4], mab[4], mba[4], mbb[4], me[4], ml[16];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                maa[i * 2 + j] = w.dyn_m[(size_t)((a2 + i) * 4 + (a2 + j)) * w.ND + it];
+                mab[i * 2 + j] = w.dyn_m[(size_t)((a2 + i) * 4 + (b2 + j)) * w.ND + it];
+                mba[i * 2 + j] = w.dyn_m[(size_t)((b2 + i) * 4 + (a2 + j)) * w.ND + it];
+                mbb[i * 2 + j] = w.dyn_m[(size_t)((b2 + i) * 4 + (b2 + j)) * w.ND + it];
+            }
+#pragma unroll
+        for (int c = 0; c < 4; c++) me[c] = present ? fz[e * 20 + c] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; c++) ml[c] = present ? fz[e * 20 + 4 + c] : 0.0;
+        ok = dynamic_message(maa, mab, mba, mbb, me, ml, oe, ol);
+    } else {
+        const int j = (bit == 4u) ? e - n_dyn : e - n_dyn - (K - 2);
+        const double *src = fz + 40 * (K - 1) + (bit == 8u ? 4 * (K - 2) : 0) + 4 * j;
+        double x0[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) x0[c] = present ? src[c] : 0.0;
+        if (bit == 4u) {
+            const SdfView sdf = make_sdf_view(w.sdf, w.sdf_w, w.sdf_h, w.world_w, w.world_h);
+            long long idx[4];
+            obstacle_taps(sdf, x0[0], x0[1], w.obs_delta, idx);
+            double h[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) h[q] = (idx[q] >= 0) ? sdf_value(w.sdf[idx[q]]) : 0.0;
+            obstacle_message(h, w.obs_delta, w.inv_s2_obs, x0, oe, ol);
+        } else {
+            const bool radio = (w.antenna[r] != 0) && !idle;
+            const int itf = w.iter_factor[r] + (((ext_mask & PH_EXT_FACTOR) && radio) ? 1 : 0);
+            if (itf < 10) return;  // factorgraph.rs:701: the sweep kernel skips it too, the entry stays frozen
+            const int item = r * (K - 2) + j;
+            int rec = w.trk_record[item];
+            float lp[2] = {w.trk_last_pos[item], w.trk_last_pos[(size_t)w.NT + item]};
+            double lv = w.trk_last_val[item];
+            const int p0 = w.path_ptr[r], np = w.path_ptr[r + 1] - p0;
+            ok = tracking_message(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, rec, lp, lv, oe, ol);
+            w.trk_record[item] = rec;
+            w.trk_last_pos[item] = lp[0];
+            w.trk_last_pos[(size_t)w.NT + item] = lp[1];
+            w.trk_last_val[item] = lv;
+        }
+    }
+    if (!ok) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) oe[c] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; c++) ol[c] = 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) blob[L.fv() + c * E1 + e] = oe[c];
+#pragma unroll
+    for (int c = 0; c < 16; c++) blob[L.fv() + (4 + c) * E1 + e] = ol[c];
+}
+// after that launch: a robot that ran an internal variable sweep has delivered fresh messages to every enabled
+// factor of its graph, nothing is thawing there any more; skip0 is cleared either way
+__global__ void k_thaw_done(DevWorld w, int robot0, int n_robots, int ran_variable_sweep) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_robots) return;
+    const int r = robot0 + t;
+    if (ran_variable_sweep && !w.idle[r]) w.thaw[r] = 0;
+    w.skip0[r] = 0;
 }
 
 // halo: the snapshot records (variables 0..K-1: eta, lam, mu; then the K epochs) of whole robots
@@ -1097,6 +1258,28 @@ hipError_t launch_var_tables(int R, int K, const int32_t *in_ptr, const int32_t 
 hipError_t launch_edge_gates(int n, const IrEdgeRec *recs, const uint8_t *antenna, const uint8_t *idle, uint8_t *gate, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_edge_gates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, recs, antenna, idle, gate);
+    return hipGetLastError();
+}
+hipError_t launch_freeze(const DevWorld &w, uint32_t kinds, hipStream_t stream) {
+    const int n = w.R_local * w.E;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_freeze, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, kinds);
+    return hipGetLastError();
+}
+hipError_t launch_or_bytes(uint8_t *p, int n, uint8_t keep, uint8_t set, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_or_bytes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, n, keep, set);
+    return hipGetLastError();
+}
+hipError_t launch_thaw(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, hipStream_t stream) {
+    const int n = n_robots * w.E;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_thaw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, robot0, n_robots, ext_mask);
+    return hipGetLastError();
+}
+hipError_t launch_thaw_done(const DevWorld &w, int robot0, int n_robots, int clear, hipStream_t stream) {
+    if (n_robots <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_thaw_done, dim3((unsigned)((n_robots + 255) / 256)), dim3(256), 0, stream, w, robot0, n_robots, clear);
     return hipGetLastError();
 }
 hipError_t launch_copy_bytes(uint8_t *dst, const uint8_t *src, size_t n, hipStream_t stream) {

@@ -38,6 +38,10 @@ hipError_t launch_update_priors(const DevWorld &w, int n, const int32_t *robots,
 hipError_t launch_halo_pack(const DevWorld &w, int n, const int32_t *robots, double *buf, hipStream_t stream);
 hipError_t launch_halo_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *buf, hipStream_t stream);
 hipError_t launch_copy_bytes(uint8_t *dst, const uint8_t *src, size_t n, hipStream_t stream);
+hipError_t launch_freeze(const DevWorld &w, uint32_t kinds, hipStream_t stream);
+hipError_t launch_or_bytes(uint8_t *p, int n, uint8_t keep, uint8_t set, hipStream_t stream);
+hipError_t launch_thaw(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, hipStream_t stream);
+hipError_t launch_thaw_done(const DevWorld &w, int robot0, int n_robots, int clear, hipStream_t stream);
 hipError_t launch_gather_variable_means(const DevWorld &w, int var, double *out, hipStream_t stream);
 hipError_t launch_edge_rebuild(const DevWorld &w, int n_slots, const IrSlotRec *slots, const int32_t *in_new, const int32_t *in_old,
                                int stride_new, IrEdgeRec *recs, double *fv_eta, double *fv_lam, double *bmu, hipStream_t stream);
@@ -207,6 +211,11 @@ struct Robot {
     uint64_t cnt[4] = {0, 0, 0, 0};
     int64_t cnt_itf = 0;  // iteration_count.factor as far as the counters have been advanced
     std::vector<uint32_t> slot_uses;  // per node slot: entries of interrobot_factor_indices naming it
+    // run-time switching of factor kinds (mgx_set_enabled): the inbox the internal factors froze with, whether each
+    // entry is present, and the kinds still to take their first update from it (empty until the world needs them)
+    std::vector<double> frozen;
+    std::vector<uint8_t> frozen_flag;
+    uint8_t thaw = 0;
 };
 
 struct IrEdge {  // one InterRobotFactor, kept at its target variable
@@ -284,6 +293,10 @@ struct mgx_world {
     bool conns_dirty = false;  // only inter-robot connections changed: edge tables are rebuilt in place
     bool flags_dirty = true;
     bool dev_valid = false;  // device arrays hold live state
+    bool frozen_live = false;     // the frozen-inbox arrays exist (a kind has been switched at run time)
+    uint32_t thaw_kinds = 0;      // kinds some robot may still be thawing: k_thaw runs before sweeps with a factor phase
+    DevBuf<double> frozen_buf;
+    DevBuf<uint8_t> frozen_flag_buf, thaw_buf, skip0_buf;
     bool trk_ever_on = false;  // tracking factors were enabled at some point: their message columns may be non-zero
     uint32_t stale_kinds = 0;  // disabled factor kinds whose inboxes have missed a delivery (mgx_set_enabled)
     DevWorld d{};
@@ -467,6 +480,13 @@ static int pull(mgx_world *w) {
     HIP_TRY(w->ir_bmu.download(ibm, s));
     std::vector<IrEdgeRec> irc;
     HIP_TRY(w->ir_rec.download(irc, s));
+    std::vector<double> fzd;
+    std::vector<uint8_t> fzf, thw;
+    if (w->frozen_live) {
+        HIP_TRY(w->frozen_buf.download(fzd, s));
+        HIP_TRY(w->frozen_flag_buf.download(fzf, s));
+        HIP_TRY(w->thaw_buf.download(thw, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));
     for (size_t dr = 0; dr < w->robot_of.size(); dr++) {
         Robot &rb = w->robots[(size_t)w->robot_of[dr]];
@@ -485,6 +505,12 @@ static int pull(mgx_world *w) {
             rb.trk_last_val[j] = tlv[t];
         }
         rb.iter_factor = itf[dr];
+        if (w->frozen_live) {
+            const size_t FZ = (size_t)frozen_words(K), E = (size_t)(4 * K - 6);
+            rb.frozen.assign(fzd.begin() + (long)(dr * FZ), fzd.begin() + (long)((dr + 1) * FZ));
+            rb.frozen_flag.assign(fzf.begin() + (long)(dr * E), fzf.begin() + (long)((dr + 1) * E));
+            rb.thaw = thw[dr];
+        }
     }
     for (IrConn &c : w->conns)
         for (size_t j = 0; j < c.edges.size(); j++) {
@@ -883,6 +909,25 @@ static int commit(mgx_world *w) {
     HIP_TRY(w->ir_fv_lam.upload(ifl, s));
     HIP_TRY(w->ir_bmu.upload(ibm, s));
     HIP_TRY(w->sdf.upload(w->sdf_red, s));
+    std::vector<double> fzd;
+    std::vector<uint8_t> fzf, thw, zero_bytes;
+    if (w->frozen_live) {  // robots that joined since start with empty frozen inboxes and nothing to thaw
+        const size_t FZ = (size_t)frozen_words(K), RL = (size_t)std::max(R_local, 1);
+        fzd.assign(RL * FZ, 0.0);
+        fzf.assign(RL * (size_t)E, 0);
+        thw.assign(RL, 0);
+        zero_bytes.assign(RL, 0);
+        for (int dr = 0; dr < R_local; dr++) {
+            const Robot &rb = w->robots[(size_t)w->robot_of[(size_t)dr]];
+            if (rb.frozen.size() == FZ) std::copy(rb.frozen.begin(), rb.frozen.end(), fzd.begin() + (long)((size_t)dr * FZ));
+            if (rb.frozen_flag.size() == (size_t)E) std::copy(rb.frozen_flag.begin(), rb.frozen_flag.end(), fzf.begin() + (long)((size_t)dr * (size_t)E));
+            thw[(size_t)dr] = rb.thaw;
+        }
+        HIP_TRY(w->frozen_buf.upload(fzd, s));
+        HIP_TRY(w->frozen_flag_buf.upload(fzf, s));
+        HIP_TRY(w->thaw_buf.upload(thw, s));
+        HIP_TRY(w->skip0_buf.upload(zero_bytes, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));  // host staging vectors die at scope exit
 
     DevWorld &d = w->d;
@@ -891,6 +936,10 @@ static int commit(mgx_world *w) {
     d.cur = 0;
     d.ir_max_edges = ir_max_edges;
     d.trk_cols = w->trk_ever_on ? 1 : 0;
+    d.frozen = w->frozen_live ? w->frozen_buf.p : nullptr;
+    d.frozen_flag = w->frozen_live ? w->frozen_flag_buf.p : nullptr;
+    d.thaw = w->frozen_live ? w->thaw_buf.p : nullptr;
+    d.skip0 = (w->frozen_live && w->thaw_kinds) ? w->skip0_buf.p : nullptr;
     d.enable = w->p.enable_mask;
     d.blob = w->blob.p; d.BS = (int)BS;
     d.snap[0] = w->snap0.p; d.snap[1] = w->snap1.p;
@@ -942,14 +991,25 @@ static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_ma
             if (rc != MGX_OK) return rc;
         }
         const int out = writes_snap ? 1 - w->d.cur : -1;
+        const bool thawing = w->thaw_kinds && (int_mask & PH_INT_FACTOR) && n_int > 0;
+        if (thawing) HIP_TRY(launch_thaw(w->d, 0, w->d.R_local, ext_mask, w->stream));
         HIP_TRY(launch_robot_sweep(w->d, 0, w->d.R_local, ext_mask, int_mask, n_int, out, hints, w->stream));
+        if (w->thaw_kinds && (thawing || writes_snap)) {
+            HIP_TRY(launch_thaw_done(w->d, 0, w->d.R_local, writes_snap ? 1 : 0, w->stream));
+            bool all_take_part = true;  // idle robots keep thawing until they iterate again
+            for (const Robot &rb : w->robots) all_take_part = all_take_part && (rb.ghost || rb.removed || !rb.idle);
+            if (writes_snap && all_take_part) { w->thaw_kinds = 0; w->d.skip0 = nullptr; }
+        }
         if (writes_snap) w->d.cur ^= 1;
         log_launch(w, -1, ext_mask, int_mask, n_int);
     } else {
         if ((size_t)robot >= w->robots.size() || w->robots[(size_t)robot].ghost) return fail(MGX_ERR_INVALID, "bad robot id %d", robot);
         if (ext_mask) return fail(MGX_ERR_INVALID, "external sweeps are world-wide (robot must be -1)");
         // single workgroup: nobody else reads the snapshot buffer concurrently => update in place
+        const bool thawing = w->thaw_kinds && (int_mask & PH_INT_FACTOR) && n_int > 0;
+        if (thawing) HIP_TRY(launch_thaw(w->d, w->dev_of[(size_t)robot], 1, 0, w->stream));
         HIP_TRY(launch_robot_sweep(w->d, w->dev_of[(size_t)robot], 1, 0, int_mask, n_int, writes_snap ? w->d.cur : -1, 0, w->stream));
+        if (w->thaw_kinds && (thawing || writes_snap)) HIP_TRY(launch_thaw_done(w->d, w->dev_of[(size_t)robot], 1, writes_snap ? 1 : 0, w->stream));
         log_launch(w, robot, 0, int_mask, n_int);
     }
     return MGX_OK;
@@ -1199,14 +1259,49 @@ int mgx_robot_remove(mgx_world *w, int32_t robot) {
 // empties the variables' inboxes (variable.rs:224-227); the counters stop counting it.  Re-enabling a
 // kind that has missed deliveries would need the inbox its factors froze with (the engine derives factor
 // inboxes from the variables' current snapshots) and is refused with MGX_ERR_STATE.
+static int ensure_frozen(mgx_world *w) {
+    if (w->frozen_live) return MGX_OK;
+    const size_t RL = (size_t)std::max(w->d.R_local, 1);
+    std::vector<double> z((size_t)frozen_words(w->K) * RL, 0.0);
+    std::vector<uint8_t> zf((size_t)(4 * w->K - 6) * RL, 0), zb(RL, 0);
+    HIP_TRY(w->frozen_buf.upload(z, w->stream));
+    HIP_TRY(w->frozen_flag_buf.upload(zf, w->stream));
+    HIP_TRY(w->thaw_buf.upload(zb, w->stream));
+    HIP_TRY(w->skip0_buf.upload(zb, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    w->frozen_live = true;
+    w->d.frozen = w->frozen_buf.p; w->d.frozen_flag = w->frozen_flag_buf.p; w->d.thaw = w->thaw_buf.p;
+    return MGX_OK;
+}
+
 int mgx_set_enabled(mgx_world *w, uint32_t kind_mask) {
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (kind_mask & ~15u) return fail(MGX_ERR_INVALID, "unknown factor kind bits 0x%x", kind_mask);
-    const uint32_t turning_on = kind_mask & ~w->p.enable_mask;
-    if (turning_on & w->stale_kinds)
-        return fail(MGX_ERR_STATE, "re-enabling factor kinds 0x%x after sweeps ran without them is not supported", turning_on & w->stale_kinds);
+    const uint32_t on = kind_mask & ~w->p.enable_mask, off = w->p.enable_mask & ~kind_mask;
+    if ((on & 2u) & w->stale_kinds)
+        return fail(MGX_ERR_STATE, "re-enabling inter-robot factors after sweeps ran without them is not supported");
     if (kind_mask == w->p.enable_mask) return MGX_OK;
     flush_counts(w);  // what was logged so far was sent under the old flags
+    // Internal kinds (dynamic, obstacle, tracking): a factor switched off keeps the inbox it has now and
+    // resumes from it when it is switched on again (FactorNode::receive_message_from drops everything in
+    // between, factor/mod.rs:307-310).  The engine derives factor inboxes from the variables' snapshots, so
+    // the inboxes are materialised here (k_freeze) and consumed by k_thaw in front of the first factor sweep.
+    const uint32_t off_int = off & 13u, thaw_int = on & 13u & w->stale_kinds;
+    if ((off_int || thaw_int) && !w->robots.empty()) {
+        int rc = commit(w);  // the device holds the state the inboxes are derived from
+        if (rc != MGX_OK) return rc;
+        rc = ensure_frozen(w);
+        if (rc != MGX_OK) return rc;
+        if (off_int) {
+            HIP_TRY(launch_freeze(w->d, off_int, w->stream));
+            HIP_TRY(launch_or_bytes(w->thaw_buf.p, w->d.R_local, (uint8_t)~off_int, 0, w->stream));  // off again: nothing to thaw
+        }
+        if (thaw_int) {
+            HIP_TRY(launch_or_bytes(w->thaw_buf.p, w->d.R_local, 0xff, (uint8_t)thaw_int, w->stream));
+            w->thaw_kinds |= thaw_int;
+            w->d.skip0 = w->skip0_buf.p;
+        }
+    }
     w->p.enable_mask = kind_mask;
     w->d.enable = kind_mask;
     if (kind_mask & 8u) { w->trk_ever_on = true; w->d.trk_cols = 1; }

@@ -279,40 +279,67 @@ def test_fma_build_shows_the_chaotic_transient():
     assert_parity(eng, ref, tol=TOL, what="fma build after the transient")
 
 
-def test_runtime_disable_of_factor_kinds():
-    """change_factor_enabled (factorgraph.rs:1529-1539) at run time: a disabled kind keeps its last
-    messages in the variables' inboxes (they go on being summed), prior changes still empty and
-    re-deliver, counters stop counting it.  Kinds are switched off one after the other between ticks;
-    beliefs and message counts follow the oracle bit for bit.  Switching a kind back on after sweeps ran
-    without it is refused."""
+def test_runtime_switching_of_factor_kinds():
+    """change_factor_enabled (factorgraph.rs:1529-1539) at run time.  A disabled kind keeps its last
+    messages in the variables' inboxes (they go on being summed) and drops what is sent to it; switched
+    on again, its factors resume from the inbox they froze with (engine: k_freeze / k_thaw), except for
+    what prior changes deliver once they are enabled.  Kinds go off and on between ticks; beliefs and
+    message counts follow the oracle bit for bit.  Only inter-robot factors cannot come back
+    (DESIGN.md §10)."""
     from magics_amd import MgxError
     sc = S.grid_scenario(24, 10, interrobot=True, tracking=True)
     eng, ref = make_pair(sc)
     tick = S.tick_inputs(sc)
-    mask = sc["params"]["enable_mask"]
-    assert mask == 15
-    for step, off in enumerate((0, 4, 8, 2, 0, 1)):
-        mask &= ~off
+    assert sc["params"]["enable_mask"] == 15
+
+    def same(what):
+        for a, b in zip(eng.read_beliefs(), ref.read_beliefs()):
+            assert np.array_equal(a, b), what
+        for r in (0, 5, 23):
+            assert eng.message_counts(r) == ref.message_counts(r), (what, r)
+    script = [15, 15 & ~4, 15 & ~4 & ~8, 15 & ~8, 15, 15 & ~1, 15 & ~1, 15, 15 & ~1 & ~4 & ~8, 15, 15 & ~2, 15 & ~2 & ~4, 15 & ~2]
+    for step, mask in enumerate(script):
         for w in (eng, ref):
             w.set_enabled(mask)
+            if step in (4, 7, 9):      # a prior change on an interior variable between the switch and the first sweep
+                w.change_prior(3, 5, np.array([1.0 + step, -2.0, 0.5, 0.25]))
             w.update_priors(**tick)
             w.iterate(sc["steps"])
             if step == 2:
-                w.change_prior(3, 5, np.array([1.0, -2.0, 0.5, 0.25]))   # an interior variable, factors of two kinds off
-        for a, b in zip(eng.read_beliefs(), ref.read_beliefs()):
-            assert np.array_equal(a, b), (step, mask)
-        for r in (0, 5, 23):
-            assert eng.message_counts(r) == ref.message_counts(r), (step, mask, r)
-    assert mask == 0
+                w.change_prior(3, 5, np.array([1.0, -2.0, 0.5, 0.25]))   # delivered to factors of which two kinds are off
+        same((step, mask))
     with pytest.raises(MgxError):
-        eng.set_enabled(4)          # obstacle factors have missed deliveries since they were switched off
-    eng.set_enabled(0)              # no change: fine
-    # before anything ran, kinds can be switched freely (the config entry new factors read)
+        eng.set_enabled(15)          # inter-robot factors have missed deliveries since they were switched off
+    # a robot that sits out (idle) while a kind comes back resumes from the frozen inbox when it iterates again,
+    # and single sweeps through the fine-grained calls thaw the same way
     sc2 = S.grid_scenario(9, 10, interrobot=False)
     eng2, ref2 = make_pair(sc2)
     for w in (eng2, ref2):
-        w.set_enabled(1)
+        w.set_enabled(1)             # before anything ran: just the flags new factors read
         w.set_enabled(1 | 4)
         w.iterate([1] * 6)
+        w.set_enabled(1)
+        w.iterate([1] * 3)
+        w.set_idle(2, True)
+        w.set_enabled(1 | 4)
+        w.iterate([1] * 2)
+        w.set_idle(2, False)
+        w.internal_factor_iteration()
+        w.internal_variable_iteration()
+        w.iterate([1] * 4)
     for a, b in zip(eng2.read_beliefs(), ref2.read_beliefs()):
+        assert np.array_equal(a, b)
+    # robots that join while a kind is off start with empty frozen inboxes
+    sc3 = S.grid_scenario(6, 10, interrobot=False)
+    eng3, ref3 = make_pair(sc3)
+    extra = S.grid_scenario(7, 10, interrobot=False)["robots"][6]
+    for w in (eng3, ref3):
+        w.iterate([1] * 5)
+        w.set_enabled(1)
+        w.iterate([1] * 2)
+        w.add_robot(extra["mean0"], extra["prior_diag"], extra["dt"], extra["radius"], order_key=77)
+        w.iterate([1] * 3)
+        w.set_enabled(1 | 4)
+        w.iterate([1] * 5)
+    for a, b in zip(eng3.read_beliefs(), ref3.read_beliefs()):
         assert np.array_equal(a, b)
