@@ -211,6 +211,14 @@ int mgx_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, const uin
  * not skip (not idle / not finished / with a next waypoint) and keeps the mission logic. */
 int mgx_update_priors(mgx_world *w, uint32_t n, const int32_t *robots, const double *waypoints_xy,
                       const double *time_scale, const uint8_t *what, double max_speed, double delta_t);
+/* One FixedUpdate tick of the planner chain in one call: the two prior updates above for the listed
+ * robots, then iterate_gbp_v2 over `steps` (robot.rs:86-103).  Same results as mgx_update_priors
+ * followed by mgx_iterate; when the schedule opens with an internal iteration (every schedule of the
+ * reference does) the prior updates are applied inside the launch that runs it, on the image each
+ * robot's workgroup has just staged, instead of by a kernel of their own. */
+int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *waypoints_xy,
+             const double *time_scale, const uint8_t *what, double max_speed, double delta_t,
+             const uint8_t *steps, uint32_t n_steps);
 
 /* ---- read-back ----------------------------------------------------------------------- */
 /* VariableNode.belief (variable.rs:40-54).  Any output pointer may be NULL. */

@@ -149,6 +149,13 @@ public:
     }
     // update_robot_neighbours + delete_ + create_interrobot_factors (robot.rs:1362-1586);
     // translations: Transform::translation of every robot (x, y, z as f32), id order
+    /// One FixedUpdate tick of the planner chain (robot.rs:86-103): both prior updates for the listed robots, then
+    /// iterate_gbp_v2 over `steps` — one call, the prior updates ride in the launch that opens the tick
+    void tick(const std::vector<int32_t> &robots, const std::vector<double> &waypoints_xy, const std::vector<double> &time_scale,
+              const std::vector<uint8_t> &what, double max_speed, double delta_t, const std::vector<uint8_t> &steps) {
+        check(mgx_tick(w_, (uint32_t)robots.size(), robots.data(), waypoints_xy.data(), time_scale.data(), what.data(), max_speed,
+                       delta_t, steps.data(), (uint32_t)steps.size()));
+    }
     /// FactorGraph::change_factor_enabled (factorgraph.rs:1529-1539) for every graph: MGX_FACTOR_* bits
     void change_factor_enabled(uint32_t kind_mask) { check(mgx_set_enabled(w_, kind_mask)); }
     std::pair<uint32_t, uint32_t> update_topology(const std::vector<std::array<float, 3>> &translations, float comms_radius,

@@ -105,6 +105,11 @@ struct DevWorld {
     uint8_t *skip0;        // [R_local] kinds whose first factor sweep of the coming launch k_thaw has computed; null
                            //           whenever no robot is thawing (the sweep kernel then reads nothing)
 
+    // mgx_tick: the driver's two per-tick prior updates folded into the launch that opens the tick.  One
+    // record per local robot in device order: waypoint x, y, time scale, what (0..3 as a double); null otherwise
+    const double *upd;
+    double upd_max_speed, upd_delta_t;
+
     const uint8_t *antenna, *idle;  // [R_total]
 
     // obstacle image

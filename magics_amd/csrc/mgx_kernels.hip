@@ -253,6 +253,14 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             r_irp[2] = w.ir_var_ptr[v0 + tid + 1];
         }
     }
+    // mgx_tick: this robot's prior updates (waypoint, time scale, what) and, lane c < 20 of each wave, entry c of
+    // the belief (eta, lam) the variable it updates holds in HBM — wave 0: the horizon variable, wave 1: variable 0
+    double u_rec[4] = {0.0, 0.0, 0.0, 0.0}, u_bel = 0.0;
+    if (w.upd) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) u_rec[c] = w.upd[(size_t)r * 4 + c];
+        if (lane < 20) u_bel = blob[L.bel() + lane * K + (role == 0 ? K - 1 : 0)];
+    }
     // messages that this launch's external factor sweep recomputes before anyone reads them are not fetched
     const bool recompute = (ext_mask & PH_EXT_FACTOR) && radio && ir_on;
     double r_ir[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -344,6 +352,77 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         }
     }
     __syncthreads();
+    // ---- mgx_tick: update_prior_of_horizon_state (wave 0, variable K-1) and update_prior_of_current_state_v3
+    // (wave 1, variable 0) on the staged image, each ending in change_prior of that variable
+    // (robot.rs:2182-2338, variable.rs:203-230; same arithmetic as k_update_priors / apply_change_prior).  For
+    // K >= 3 the two touch disjoint state, and nobody else reads this robot's snapshot in a launch without an
+    // external factor sweep, so the change needs no other synchronisation than the barrier below.
+    if (w.upd) {
+        const uint32_t what = (uint32_t)u_rec[3];
+        const int i = role == 0 ? K - 1 : 0;
+        if (role == 0 ? (what & 1u) : (what & 2u)) {
+            double m[4];
+            if (role == 0) {
+                const double ex = s_mu[0 * K + i], ey = s_mu[1 * K + i];         // estimated position (:2242)
+                double hx = u_rec[0] - ex, hy = u_rec[1] - ey;                    // horizon2waypoint
+                const double dist = std::sqrt(hx * hx + hy * hy);                 // euclidean_norm
+                double nx = hx, ny = hy;                                           // .normalized(): unchanged if |.| is 0 / inf
+                if (!(dist == 0.0 || std::isinf(dist))) { nx = hx / dist; ny = hy / dist; }
+                const double sp = (w.upd_max_speed < dist || dist != dist) ? w.upd_max_speed : dist;  // Float::min(max_speed, dist)
+                const double vx = sp * nx, vy = sp * ny;                           // new_velocity
+                m[0] = ex + vx * w.upd_delta_t; m[1] = ey + vy * w.upd_delta_t; m[2] = vx; m[3] = vy;  // (:2253-2256)
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const double m0 = s_mu[c * K + 0], m1 = s_mu[c * K + 1];
+                    m[c] = m0 + u_rec[2] * (m1 - m0);                              // (:2309-2316)
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // every lane has read the means before lanes 4..7 overwrite them
+            if (lane < 4) {  // prior eta = prior lam . mean (:204), in LDS and in the blob (the sweep never writes priors back)
+                double pl[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) pl[c] = s_prior[(4 + lane * 4 + c) * K + i];
+                const double pe = ((pl[0] * m[0] + pl[1] * m[1]) + pl[2] * m[2]) + pl[3] * m[3];
+                s_prior[lane * K + i] = pe;
+                blob[L.prior() + lane * K + i] = pe;
+            } else if (lane < 8) {  // belief mean (:206) and the mean of the message the variable sends (:210-221)
+                const double mc = lane == 4 ? m[0] : (lane == 5 ? m[1] : (lane == 6 ? m[2] : m[3]));
+                s_mu[(lane - 4) * K + i] = mc;
+                s_snap[(20 + lane - 4) * K + i] = mc;
+            } else if (lane == 8) {
+                s_epoch[i] += 1;
+            }
+            if (lane < 20) s_snap[lane * K + i] = u_bel;  // (stale eta, stale lam) of that message
+            // every inbox message of the variable becomes empty (:224-227)
+            const int es[4] = {(i >= 1) ? (K - 1) + (i - 1) : -1, (i <= K - 2) ? i : -1,
+                               (i >= 1 && i <= K - 2) ? n_dyn + (i - 1) : -1, (i >= 1 && i <= K - 2) ? n_dyn + (K - 2) + (i - 1) : -1};
+            for (int t = lane; t < 80; t += 64) {
+                const int col = es[t & 3];
+                if (col >= 0) s_fv[(t >> 2) * E1 + col] = 0.0;
+            }
+            if (HAS_IR) {  // foreign inter-robot factors attached to the variable: their message goes, they get the new mean
+                const int x0 = w.ir_var_ptr[v0 + i], x1 = w.ir_var_ptr[v0 + i + 1];
+                for (int e = x0 + lane; e < x1; e += 64) {
+                    if (w.enable & 2u) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = m[c];
+                    }
+                    w.ir_fv_eta[0 * (size_t)w.NI + e] = 0.0;
+                    w.ir_fv_eta[1 * (size_t)w.NI + e] = 0.0;
+                    w.ir_fv_lam[0 * (size_t)w.NI + e] = 0.0;
+                    w.ir_fv_lam[1 * (size_t)w.NI + e] = 0.0;
+                    w.ir_fv_lam[4 * (size_t)w.NI + e] = 0.0;
+                    w.ir_fv_lam[5 * (size_t)w.NI + e] = 0.0;
+                    if (STAGE_IR) {
+#pragma unroll
+                        for (int c = 0; c < 6; c++) s_ir[(e - ie0) * IR_STRIDE + c] = 0.0;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
     uint32_t my_epoch = (tid < 4 * K) ? s_epoch[tid % K] : 0u;  // deliveries of the variable this thread sums
     STAMP(t_staged);
 

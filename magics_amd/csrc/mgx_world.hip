@@ -936,6 +936,7 @@ static int commit(mgx_world *w) {
     d.cur = 0;
     d.ir_max_edges = ir_max_edges;
     d.trk_cols = w->trk_ever_on ? 1 : 0;
+    d.upd = nullptr; d.upd_max_speed = 0.0; d.upd_delta_t = 0.0;
     d.frozen = w->frozen_live ? w->frozen_buf.p : nullptr;
     d.frozen_flag = w->frozen_live ? w->frozen_flag_buf.p : nullptr;
     d.thaw = w->frozen_live ? w->thaw_buf.p : nullptr;
@@ -1521,27 +1522,35 @@ int mgx_sweep(mgx_world *w, int32_t robot, uint32_t external_phases, uint32_t in
     return sweep(w, robot, external_phases, internal_phases << 2, internal_phases ? (int)n_internal : 0, h);
 }
 
-int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n) {
-    if (!w || (!steps && n)) return fail(MGX_ERR_INVALID, "null argument");
-    // flatten to phases I / E (robot.rs:1787-1860: internal first, then external, per step) and
-    // group them into launches of the form [E] I* (one workgroup-resident pass each)
+// the launches of a schedule: phases I / E flattened (robot.rs:1787-1860: internal first, then external, per
+// step) and grouped into launches of the form [E] I* (one workgroup-resident pass each)
+struct Launch { uint32_t ext; int n_int; uint32_t hints; };
+static std::vector<Launch> plan_launches(const uint8_t *steps, uint32_t n) {
     std::vector<uint8_t> ph;
     for (uint32_t i = 0; i < n; i++) {
         if (steps[i] & MGX_STEP_INTERNAL) ph.push_back('I');
         if (steps[i] & MGX_STEP_EXTERNAL) ph.push_back('E');
     }
+    std::vector<Launch> out;
     size_t i = 0;
     while (i < ph.size()) {
-        uint32_t ext = 0;
-        if (ph[i] == 'E') { ext = PH_EXT_FACTOR | PH_EXT_VARIABLE; i++; }
-        int n_int = 0;
-        while (i < ph.size() && ph[i] == 'I') { n_int++; i++; }
+        Launch l{0u, 0, 0u};
+        if (ph[i] == 'E') { l.ext = PH_EXT_FACTOR | PH_EXT_VARIABLE; i++; }
+        while (i < ph.size() && ph[i] == 'I') { l.n_int++; i++; }
         // the next launch of this call (if any) starts with an external phase: the inter-robot messages
         // this launch computes are recomputed before anything reads their HBM copy
-        uint32_t hints = (ext && i < ph.size()) ? HINT_IR_DEAD : 0u;
+        l.hints = (l.ext && i < ph.size()) ? HINT_IR_DEAD : 0u;
         // later launches of this call that run a variable sweep rewrite the belief images (nothing reads them in between)
-        for (size_t j = i; j < ph.size(); j++) hints |= (ph[j] == 'E') ? HINT_LATER_EXT_VARIABLE : HINT_LATER_INT_VARIABLE;
-        int rc = sweep(w, -1, ext, n_int ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, n_int, hints);
+        for (size_t j = i; j < ph.size(); j++) l.hints |= (ph[j] == 'E') ? HINT_LATER_EXT_VARIABLE : HINT_LATER_INT_VARIABLE;
+        out.push_back(l);
+    }
+    return out;
+}
+
+int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n) {
+    if (!w || (!steps && n)) return fail(MGX_ERR_INVALID, "null argument");
+    for (const Launch &l : plan_launches(steps, n)) {
+        int rc = sweep(w, -1, l.ext, l.n_int ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, l.n_int, l.hints);
         if (rc != MGX_OK) return rc;
     }
     return MGX_OK;
@@ -1613,6 +1622,54 @@ int mgx_update_priors(mgx_world *w, uint32_t n, const int32_t *robots, const dou
     HIP_TRY(launch_update_priors(w->d, (int)n, (const int32_t *)(dw + 3 * (size_t)n), dw, dw + 2 * (size_t)n,
                                  (const uint8_t *)(dw + 3 * (size_t)n + w_r), max_speed, delta_t, w->stream));
     HIP_TRY(w->stage.release(slot, w->stream));
+    return MGX_OK;
+}
+
+// One driver tick in one call: update_prior_of_horizon_state + update_prior_of_current_state_v3 for the listed
+// robots, then iterate_gbp_v2 (robot.rs:86-103).  When the schedule opens with an internal iteration — every
+// schedule of the reference does — the two prior updates ride in the launch that runs it: each robot's
+// workgroup applies them to the image it has just staged, which saves the separate kernel and its trip
+// through HBM.  Otherwise (or while factors are thawing) this is mgx_update_priors followed by mgx_iterate.
+int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *waypoints_xy, const double *time_scale,
+             const uint8_t *what, double max_speed, double delta_t, const uint8_t *steps, uint32_t n_steps) {
+    if (!w || (!steps && n_steps) || (n && (!robots || !waypoints_xy || !time_scale || !what))) return fail(MGX_ERR_INVALID, "null argument");
+    const std::vector<Launch> plan = plan_launches(steps, n_steps);
+    const bool fuse = n > 0 && !plan.empty() && plan[0].ext == 0 && plan[0].n_int > 0 && w->thaw_kinds == 0 && w->K >= 3;
+    if (!fuse) {
+        int rc = mgx_update_priors(w, n, robots, waypoints_xy, time_scale, what, max_speed, delta_t);
+        return rc != MGX_OK ? rc : mgx_iterate(w, steps, n_steps);
+    }
+    for (uint32_t i = 0; i < n; i++)
+        if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size() || w->robots[(size_t)robots[i]].ghost || w->robots[(size_t)robots[i]].removed || (what[i] & ~3u))
+            return fail(MGX_ERR_INVALID, "bad entry %u", i);
+    int rc = commit(w);
+    if (rc != MGX_OK) return rc;
+    const size_t RL = (size_t)w->d.R_local;
+    void *hp = nullptr, *dp = nullptr;
+    int slot = 0;
+    HIP_TRY(w->stage.acquire(4 * RL * sizeof(double), &hp, &slot));
+    double *rec = (double *)hp;
+    std::fill(rec, rec + 4 * RL, 0.0);
+    for (uint32_t i = 0; i < n; i++) {
+        double *q = rec + 4 * (size_t)w->dev_of[(size_t)robots[i]];
+        q[0] = waypoints_xy[2 * i]; q[1] = waypoints_xy[2 * i + 1]; q[2] = time_scale[i]; q[3] = (double)what[i];
+        if (what[i] & 1u) log_change_prior(w, robots[i], w->K - 1);
+        if (what[i] & 2u) log_change_prior(w, robots[i], 0);
+    }
+    HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+    w->stale_kinds |= ~w->p.enable_mask & 15u;
+    bool first = true;
+    for (const Launch &l : plan) {
+        if (first) { w->d.upd = (const double *)dp; w->d.upd_max_speed = max_speed; w->d.upd_delta_t = delta_t; }
+        rc = sweep(w, -1, l.ext, l.n_int ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, l.n_int, l.hints);
+        if (first) {
+            w->d.upd = nullptr;
+            first = false;
+            hipError_t e = w->stage.release(slot, w->stream);
+            if (rc == MGX_OK && e != hipSuccess) rc = fail(MGX_ERR_HIP, "event record: %s", hipGetErrorString(e));
+        }
+        if (rc != MGX_OK) return rc;
+    }
     return MGX_OK;
 }
 

@@ -73,13 +73,19 @@ class Driver:
         if len(moving):
             m0, m1 = w.read_variable_means(0), w.read_variable_means(1)
             change = self.time_scale[moving, None] * (m1[moving] - m0[moving])   # change_in_state (robot.rs:2314)
-            w.update_priors(robots=moving, waypoints_xy=np.array([self.way[r][0] for r in moving], dtype=np.float64),
-                            time_scale=self.time_scale[moving], what=np.full(len(moving), 3, dtype=np.uint8),
-                            max_speed=self.max_speed, delta_t=self.delta_t)
+            args = dict(robots=moving, waypoints_xy=np.array([self.way[r][0] for r in moving], dtype=np.float64),
+                        time_scale=self.time_scale[moving], what=np.full(len(moving), 3, dtype=np.uint8),
+                        max_speed=self.max_speed, delta_t=self.delta_t)
             self.translation[moving, 0] += change[:, 0].astype(F32)             # robot.rs:2328-2329
             self.translation[moving, 2] += change[:, 1].astype(F32)
             self.travelled[moving] += np.hypot(change[:, 0], change[:, 1])
-        w.iterate(self.steps)
+            if hasattr(w, "tick"):
+                w.tick(steps=self.steps, **args)                                 # prior updates + schedule, one call
+            else:
+                w.update_priors(**args)
+                w.iterate(self.steps)
+        else:
+            w.iterate(self.steps)
         self.tick_no += 1
         return created, deleted
 

@@ -136,6 +136,8 @@ SYMBOLS = {
     "mgx_change_priors": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), c_double_p]),
     "mgx_update_priors": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), c_double_p, c_double_p, C.POINTER(C.c_uint8), C.c_double,
                           C.c_double]),
+    "mgx_tick": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), c_double_p, c_double_p, C.POINTER(C.c_uint8), C.c_double, C.c_double,
+                 C.c_char_p, C.c_uint32]),
     "mgx_get_belief": (C.c_int, [_V, C.c_int32, C.c_uint32, c_double_p, c_double_p, c_double_p, c_double_p,
                                  C.POINTER(C.c_int32)]),
     "mgx_read_beliefs": (C.c_int, [_V, c_double_p, c_double_p, c_double_p]),

@@ -135,14 +135,15 @@ class Simulation:
                 m0, m1 = w.read_variable_means(0), w.read_variable_means(1)
                 ts = np.array([r["time_scale"] for r in moving])
                 change = ts[:, None] * (m1[ids] - m0[ids])                                   # robot.rs:2314
-                w.update_priors(robots=ids, waypoints_xy=np.array([r["waypoints"][r["target"]][:2] for r in moving], dtype=np.float64),
-                                time_scale=ts, what=np.full(len(moving), 3, dtype=np.uint8), max_speed=float(self.max_speed),
-                                delta_t=float(self.dt32))
                 self.translation[ids, 0] += change[:, 0].astype(F)                          # robot.rs:2328-2329
                 self.translation[ids, 2] += change[:, 1].astype(F)
                 for r, c in zip(moving, change):
                     r["travelled"] += float(np.hypot(c[0], c[1]))
-            w.iterate(self.steps)
+                w.tick(robots=ids, waypoints_xy=np.array([r["waypoints"][r["target"]][:2] for r in moving], dtype=np.float64),
+                       time_scale=ts, what=np.full(len(moving), 3, dtype=np.uint8), max_speed=float(self.max_speed),
+                       delta_t=float(self.dt32), steps=self.steps)                          # prior updates + iterate_gbp_v2
+            else:
+                w.iterate(self.steps)
             for r in live:  # PositionTracker (spawner.rs:620): sampled once per tick here
                 r["positions"].append([float(self.translation[r["id"], 0]), float(self.translation[r["id"], 2])])
         self.tick_no += 1

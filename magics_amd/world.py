@@ -200,6 +200,18 @@ class World:
         self._chk(self._L.mgx_update_priors(self._w, n, robots.ctypes.data_as(C.POINTER(C.c_int32)), _dp(wp), _dp(ts),
                                             what.ctypes.data_as(C.POINTER(C.c_uint8)), float(max_speed), float(delta_t)))
 
+    def tick(self, robots, waypoints_xy, time_scale, what, max_speed, delta_t, steps):
+        """One FixedUpdate tick of the planner chain (robot.rs:86-103): the prior updates of `update_priors`
+        for the listed robots, then `iterate(steps)` — one C call (mgx_tick)."""
+        robots = np.ascontiguousarray(robots, dtype=np.int32)
+        n = len(robots)
+        wp = _f64(waypoints_xy, (n, 2))
+        ts = _f64(time_scale, (n,))
+        what = np.ascontiguousarray(what, dtype=np.uint8)
+        steps = bytes(bytearray(int(s) for s in steps))
+        self._chk(self._L.mgx_tick(self._w, n, robots.ctypes.data_as(C.POINTER(C.c_int32)), _dp(wp), _dp(ts),
+                                   what.ctypes.data_as(C.POINTER(C.c_uint8)), float(max_speed), float(delta_t), steps, len(steps)))
+
     # -- read-back -----------------------------------------------------------------------------
     def get_belief(self, robot, var_ix):
         eta, lam, mean, cov = np.zeros(4), np.zeros((4, 4)), np.zeros(4), np.zeros((4, 4))

@@ -276,6 +276,11 @@ class OracleWorld:
         self._chk(self._L.orc_update_priors(self._w, n, robots.ctypes.data_as(C.POINTER(C.c_int32)), _dp(wp), _dp(ts),
                                             what.ctypes.data_as(C.POINTER(C.c_uint8)), float(max_speed), float(delta_t)))
 
+    def tick(self, robots, waypoints_xy, time_scale, what, max_speed, delta_t, steps):
+        """The reference's chain: both prior updates for the listed robots, then the schedule (robot.rs:86-103)."""
+        self.update_priors(robots, waypoints_xy, time_scale, what, max_speed, delta_t)
+        self.iterate(steps)
+
     def get_belief(self, robot, var_ix):
         eta, lam, mean, cov = np.zeros(4), np.zeros((4, 4)), np.zeros(4), np.zeros((4, 4))
         valid = C.c_int32()

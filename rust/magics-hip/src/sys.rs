@@ -94,6 +94,8 @@ extern "C" {
     pub fn mgx_set_antenna(w: *mut mgx_world, robot: i32, active: i32) -> c_int;
     pub fn mgx_set_idle(w: *mut mgx_world, robot: i32, idle: i32) -> c_int;
     pub fn mgx_set_enabled(w: *mut mgx_world, kind_mask: u32) -> c_int;
+    pub fn mgx_tick(w: *mut mgx_world, n: u32, robots: *const i32, waypoints_xy: *const f64, time_scale: *const f64, what: *const u8,
+                    max_speed: f64, delta_t: f64, steps: *const u8, n_steps: u32) -> c_int;
     pub fn mgx_set_antennas(w: *mut mgx_world, n: u32, robots: *const i32, active: *const u8) -> c_int;
     pub fn mgx_neighbours(w: *mut mgx_world, positions_xyz: *const f32, radius: f32, method: u32, row_ptr: *mut i32, neighbours_out: *mut i32, capacity: u64, needed: *mut u64) -> c_int;
     pub fn mgx_update_topology(w: *mut mgx_world, positions_xyz: *const f32, radius: f32, method: u32, robot_number_next: *mut u64, stats: *mut u32) -> c_int;
