@@ -86,8 +86,9 @@ struct DevWorld {
     const int32_t *ir_var_ptr;    // [R_local * K + 1]
     const int32_t *ir_var_mid;    // [R_local * K] first edge whose owner has a HIGHER graph key
     const IrEdgeRec *ir_rec;      // [NI] constants of each edge (one 32-byte load)
-    const uint8_t *ir_gate;       // [NI] 1 iff the OWNER robot is on air (antenna on, not idle): refreshed with
-                                  //      the flags so that the edge lane needs no dependent flag loads
+    const uint8_t *ir_gate;       // [NI] non-zero iff the OWNER robot is on air (antenna on, not idle): refreshed with
+                                  //      the flags so that the edge lane needs no dependent flag loads; 1: the edge
+                                  //      lane evaluates the factor, 2: k_thaw_ir already has (see ir_thaw_epoch)
     double *ir_fv_eta, *ir_fv_lam;  // [4][NI],[16][NI] factor -> target variable
     // only rows eta[0..2) and lam[0][0..2), lam[1][0..2) are live: an inter-robot factor constrains
     // positions only, the rest of its message is structurally zero (mgx_kernels.hip, compact messages)
@@ -104,6 +105,14 @@ struct DevWorld {
     uint8_t *thaw;         // [R_local] kinds (MGX_FACTOR_* bits) whose factors take their next update from `frozen`
     uint8_t *skip0;        // [R_local] kinds whose first factor sweep of the coming launch k_thaw has computed; null
                            //           whenever no robot is thawing (the sweep kernel then reads nothing)
+
+    // Inter-robot factors switched back on: a factor F_AB resumes from what A's variable had sent it when the
+    // kind was switched off (ir_frozen_*), until A's variable delivers again (its epoch leaves ir_thaw_epoch).
+    // k_thaw_ir evaluates such edges in front of the sweep launch and marks them ir_gate == 2 ("on air, already
+    // evaluated"); all three are null unless the world is thawing inter-robot factors.
+    const double *ir_frozen_snap;     // [V][24]
+    const uint32_t *ir_frozen_epoch;  // [V]
+    const uint32_t *ir_thaw_epoch;    // [V] delivery counts when the kind came back
 
     // mgx_tick: the driver's two per-tick prior updates folded into the launch that opens the tick.  One
     // record per local robot in device order: waypoint x, y, time scale, what (0..3 as a double); null otherwise

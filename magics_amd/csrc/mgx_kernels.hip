@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // first link of the edge chain), then the chain's second link, then the LDS stores.  The covariance
     // is output only (a variable whose covariance this launch does not recompute keeps the HBM copy).
     auto chain_second_link = [&]() {
-        if (STAGE_IR && tid < ne && !(recompute && pf_gate)) {  // the thread's first staged inter-robot message
+        if (STAGE_IR && tid < ne && !(recompute && pf_gate == 1)) {  // the thread's first staged inter-robot message
             const size_t e = (size_t)(ie0 + tid);
             r_ir_on = true;
             r_ir[0] = w.ir_fv_eta[0 * (size_t)w.NI + e];
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             r_ir[4] = w.ir_fv_lam[4 * (size_t)w.NI + e];
             r_ir[5] = w.ir_fv_lam[5 * (size_t)w.NI + e];
         }
-        if (do_extf && tid < ne && pf_gate) {  // the owner's record (other robot, HBM / L2)
+        if (do_extf && tid < ne && pf_gate == 1) {  // the owner's record (other robot, HBM / L2)
             pf_on = true;
             pf_present = w.snap_epoch[w.cur][pf_er.src_var] > pf_er.created;
             const double2 *rec = reinterpret_cast<const double2 *>(w.snap[w.cur] + (size_t)pf_er.src_var * SNAP_W);
@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 for (int c = 0; c < 6; c++) s_ir[tid * IR_STRIDE + c] = r_ir[c];
             }
             for (int j = tid + SWEEP_BLOCK; j < ne; j += SWEEP_BLOCK) {  // robots with more edges than threads
-                if (recompute && w.ir_gate[ie0 + j]) continue;
+                if (recompute && w.ir_gate[ie0 + j] == 1) continue;
                 const size_t e = (size_t)(ie0 + j);
                 double m[6];
                 m[0] = w.ir_fv_eta[0 * (size_t)w.NI + e];
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #pragma unroll
                     for (int c = 0; c < 4; c++) a_mu[c] = pf_rec[20 + c];
                 } else {
-                    if (!w.ir_gate[e]) continue;
+                    if (w.ir_gate[e] != 1) continue;
                     er = w.ir_rec[e];
                     ld_soa4(w.ir_bmu, w.NI, e, b_mu);
                     a_present = w.snap_epoch[w.cur][er.src_var] > er.created;
@@ -1072,6 +1072,56 @@ __global__ void k_thaw_done(DevWorld w, int robot0, int n_robots, int ran_variab
     w.skip0[r] = 0;
 }
 
+// Inter-robot factors going off: what every variable has last sent to its own factors is what the inter-robot
+// factors it owns keep in their inbox.  A variable that has not delivered since an earlier switch-on keeps
+// the record frozen then.
+__global__ void k_ir_freeze(DevWorld w, double *frozen_snap, uint32_t *frozen_epoch) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= w.V) return;
+    if (w.ir_thaw_epoch && w.snap_epoch[w.cur][v] == w.ir_thaw_epoch[v]) return;
+    for (int c = 0; c < SNAP_W; c++) frozen_snap[(size_t)v * SNAP_W + c] = w.snap[w.cur][(size_t)v * SNAP_W + c];
+    frozen_epoch[v] = w.snap_epoch[w.cur][v];
+}
+// ... and coming back: in front of a launch with an external factor sweep, the factors whose owner's variable has
+// not delivered since are evaluated here from the frozen record (same function as the sweep kernel's edge lane)
+// and marked so that the edge lane leaves them alone.  One thread per (robot, incoming edge).
+__global__ void k_thaw_ir(DevWorld w, uint8_t *gate) {
+    const int r = blockIdx.x;
+    const int v0 = r * w.K, ie0 = w.ir_var_ptr[v0], ne = w.ir_var_ptr[v0 + w.K] - ie0;
+    const bool radio = (w.antenna[r] != 0) && (w.idle[r] == 0);
+    if (!radio || !(w.enable & 2u)) return;
+    for (int j = threadIdx.x; j < ne; j += blockDim.x) {
+        const int e = ie0 + j;
+        const uint8_t g = gate[e];
+        if (!g) continue;
+        const IrEdgeRec er = w.ir_rec[e];
+        if (w.snap_epoch[w.cur][er.src_var] != w.ir_thaw_epoch[er.src_var]) {  // the owner has delivered since: live record
+            if (g == 2) gate[e] = 1;
+            continue;
+        }
+        double ao_eta[4], ao_lam[16], a_mu[4], b_mu[4], oe[4], ol[16];
+        ld_soa4(w.ir_bmu, w.NI, e, b_mu);
+        const bool a_present = w.ir_frozen_epoch[er.src_var] > er.created;
+        const double *rec = w.ir_frozen_snap + (size_t)er.src_var * SNAP_W;
+#pragma unroll
+        for (int c = 0; c < 4; c++) ao_eta[c] = a_present ? rec[c] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; c++) ao_lam[c] = a_present ? rec[4 + c] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) a_mu[c] = a_present ? rec[20 + c] : 0.0;
+        const int dslot = er.dst >> 16;
+        const bool ok = dslot ? interrobot_message(a_mu, b_mu, er.d_safe, er.offset, w.inv_s2_ir, 1, ao_eta, ao_lam, oe, ol)
+                              : interrobot_message(b_mu, a_mu, er.d_safe, er.offset, w.inv_s2_ir, 0, ao_eta, ao_lam, oe, ol);
+        w.ir_fv_eta[0 * (size_t)w.NI + e] = ok ? oe[0] : 0.0;
+        w.ir_fv_eta[1 * (size_t)w.NI + e] = ok ? oe[1] : 0.0;
+        w.ir_fv_lam[0 * (size_t)w.NI + e] = ok ? ol[0] : 0.0;
+        w.ir_fv_lam[1 * (size_t)w.NI + e] = ok ? ol[1] : 0.0;
+        w.ir_fv_lam[4 * (size_t)w.NI + e] = ok ? ol[4] : 0.0;
+        w.ir_fv_lam[5 * (size_t)w.NI + e] = ok ? ol[5] : 0.0;
+        gate[e] = 2;
+    }
+}
+
 // halo: the snapshot records (variables 0..K-1: eta, lam, mu; then the K epochs) of whole robots
 __global__ void k_halo_pack(DevWorld w, int n, const int32_t *robots, double *buf) {
     const int words = (SNAP_W + 1) * w.K;
@@ -1215,7 +1265,8 @@ __global__ void k_edge_rebuild(DevWorld w, int n_slots, const IrSlotRec *__restr
         fv_lam[5 * sn + e] = 0.0;
         const BlobLayout L(w.K);
 #pragma unroll
-        for (int c = 0; c < 4; c++) bmu[c * sn + e] = w.blob[(size_t)r * w.BS + L.mu() + c * w.K + (j + 1)];
+        for (int c = 0; c < 4; c++)  // the target's belief goes into the new factor — which drops it while its kind is off
+            bmu[c * sn + e] = (w.enable & 2u) ? w.blob[(size_t)r * w.BS + L.mu() + c * w.K + (j + 1)] : 0.0;
         rec.created = w.snap_epoch[w.cur][rec.src_var];
     }
     recs[e] = rec;
@@ -1359,6 +1410,16 @@ hipError_t launch_thaw(const DevWorld &w, int robot0, int n_robots, uint32_t ext
 hipError_t launch_thaw_done(const DevWorld &w, int robot0, int n_robots, int clear, hipStream_t stream) {
     if (n_robots <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_thaw_done, dim3((unsigned)((n_robots + 255) / 256)), dim3(256), 0, stream, w, robot0, n_robots, clear);
+    return hipGetLastError();
+}
+hipError_t launch_ir_freeze(const DevWorld &w, double *frozen_snap, uint32_t *frozen_epoch, hipStream_t stream) {
+    if (w.V <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ir_freeze, dim3((unsigned)((w.V + 255) / 256)), dim3(256), 0, stream, w, frozen_snap, frozen_epoch);
+    return hipGetLastError();
+}
+hipError_t launch_thaw_ir(const DevWorld &w, uint8_t *gate, hipStream_t stream) {
+    if (w.R_local <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_thaw_ir, dim3((unsigned)w.R_local), dim3(128), 0, stream, w, gate);
     return hipGetLastError();
 }
 hipError_t launch_copy_bytes(uint8_t *dst, const uint8_t *src, size_t n, hipStream_t stream) {

@@ -39,6 +39,8 @@ hipError_t launch_halo_pack(const DevWorld &w, int n, const int32_t *robots, dou
 hipError_t launch_halo_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *buf, hipStream_t stream);
 hipError_t launch_copy_bytes(uint8_t *dst, const uint8_t *src, size_t n, hipStream_t stream);
 hipError_t launch_freeze(const DevWorld &w, uint32_t kinds, hipStream_t stream);
+hipError_t launch_ir_freeze(const DevWorld &w, double *frozen_snap, uint32_t *frozen_epoch, hipStream_t stream);
+hipError_t launch_thaw_ir(const DevWorld &w, uint8_t *gate, hipStream_t stream);
 hipError_t launch_or_bytes(uint8_t *p, int n, uint8_t keep, uint8_t set, hipStream_t stream);
 hipError_t launch_thaw(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, hipStream_t stream);
 hipError_t launch_thaw_done(const DevWorld &w, int robot0, int n_robots, int clear, hipStream_t stream);
@@ -216,6 +218,8 @@ struct Robot {
     std::vector<double> frozen;
     std::vector<uint8_t> frozen_flag;
     uint8_t thaw = 0;
+    std::vector<double> ir_frozen_snap;                    // [K][24] what the variables had sent when inter-robot factors went off
+    std::vector<uint32_t> ir_frozen_epoch, ir_thaw_epoch;  // [K]
 };
 
 struct IrEdge {  // one InterRobotFactor, kept at its target variable
@@ -297,6 +301,10 @@ struct mgx_world {
     uint32_t thaw_kinds = 0;      // kinds some robot may still be thawing: k_thaw runs before sweeps with a factor phase
     DevBuf<double> frozen_buf;
     DevBuf<uint8_t> frozen_flag_buf, thaw_buf, skip0_buf;
+    bool ir_frozen_live = false;  // ir_frozen_* hold what the variables had sent when inter-robot factors were switched off
+    bool ir_thaw_active = false;  // inter-robot factors are back and some owner may not have delivered since
+    DevBuf<double> ir_frozen_snap_buf;
+    DevBuf<uint32_t> ir_frozen_epoch_buf, ir_thaw_epoch_buf;
     bool trk_ever_on = false;  // tracking factors were enabled at some point: their message columns may be non-zero
     uint32_t stale_kinds = 0;  // disabled factor kinds whose inboxes have missed a delivery (mgx_set_enabled)
     DevWorld d{};
@@ -487,10 +495,22 @@ static int pull(mgx_world *w) {
         HIP_TRY(w->frozen_flag_buf.download(fzf, s));
         HIP_TRY(w->thaw_buf.download(thw, s));
     }
+    std::vector<double> ifs;
+    std::vector<uint32_t> ife_, ite;
+    if (w->ir_frozen_live) {
+        HIP_TRY(w->ir_frozen_snap_buf.download(ifs, s));
+        HIP_TRY(w->ir_frozen_epoch_buf.download(ife_, s));
+        if (w->ir_thaw_active) HIP_TRY(w->ir_thaw_epoch_buf.download(ite, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));
     for (size_t dr = 0; dr < w->robot_of.size(); dr++) {
         Robot &rb = w->robots[(size_t)w->robot_of[dr]];
         blob_unpack(rb, &bl[dr * BS]);
+        if (w->ir_frozen_live) {
+            rb.ir_frozen_snap.assign(ifs.begin() + (long)(dr * K * 24), ifs.begin() + (long)((dr + 1) * K * 24));
+            rb.ir_frozen_epoch.assign(ife_.begin() + (long)(dr * K), ife_.begin() + (long)((dr + 1) * K));
+            if (w->ir_thaw_active) rb.ir_thaw_epoch.assign(ite.begin() + (long)(dr * K), ite.begin() + (long)((dr + 1) * K));
+        }
         for (int i = 0; i < K; i++) {
             const size_t v = dr * K + i;
             memcpy(&rb.snap[24 * i], &sn[v * 24], 24 * sizeof(double));
@@ -824,7 +844,7 @@ static int commit(mgx_world *w) {
             if (!ed.fresh) continue;
             const Robot &ow = w->robots[(size_t)c.owner], &ot = w->robots[(size_t)c.other];
             ed.created = ow.epoch[j + 1];
-            for (int q = 0; q < 4; q++) ed.bmu[q] = ot.bel_mu[4 * (j + 1) + q];
+            for (int q = 0; q < 4; q++) ed.bmu[q] = (w->p.enable_mask & 2u) ? ot.bel_mu[4 * (j + 1) + q] : 0.0;  // dropped while the kind is off
             ed.fresh = false;
         }
 
@@ -928,6 +948,22 @@ static int commit(mgx_world *w) {
         HIP_TRY(w->thaw_buf.upload(thw, s));
         HIP_TRY(w->skip0_buf.upload(zero_bytes, s));
     }
+    std::vector<double> ifs;
+    std::vector<uint32_t> ife_, ite;
+    if (w->ir_frozen_live) {  // robots that joined since have sent nothing their (disabled) factors could have kept
+        ifs.assign(24 * V, 0.0);
+        ife_.assign(V, 0);
+        ite.assign(V, 0xffffffffu);  // "has delivered since": a joiner's live record is its inbox
+        for (int dr = 0; dr < R_total; dr++) {
+            const Robot &rb = w->robots[(size_t)w->robot_of[(size_t)dr]];
+            if (rb.ir_frozen_snap.size() == (size_t)24 * K) std::copy(rb.ir_frozen_snap.begin(), rb.ir_frozen_snap.end(), ifs.begin() + (long)((size_t)dr * K * 24));
+            if (rb.ir_frozen_epoch.size() == (size_t)K) std::copy(rb.ir_frozen_epoch.begin(), rb.ir_frozen_epoch.end(), ife_.begin() + (long)((size_t)dr * K));
+            if (rb.ir_thaw_epoch.size() == (size_t)K) std::copy(rb.ir_thaw_epoch.begin(), rb.ir_thaw_epoch.end(), ite.begin() + (long)((size_t)dr * K));
+        }
+        HIP_TRY(w->ir_frozen_snap_buf.upload(ifs, s));
+        HIP_TRY(w->ir_frozen_epoch_buf.upload(ife_, s));
+        HIP_TRY(w->ir_thaw_epoch_buf.upload(ite, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));  // host staging vectors die at scope exit
 
     DevWorld &d = w->d;
@@ -937,6 +973,9 @@ static int commit(mgx_world *w) {
     d.ir_max_edges = ir_max_edges;
     d.trk_cols = w->trk_ever_on ? 1 : 0;
     d.upd = nullptr; d.upd_max_speed = 0.0; d.upd_delta_t = 0.0;
+    d.ir_frozen_snap = w->ir_thaw_active ? w->ir_frozen_snap_buf.p : nullptr;
+    d.ir_frozen_epoch = w->ir_thaw_active ? w->ir_frozen_epoch_buf.p : nullptr;
+    d.ir_thaw_epoch = w->ir_thaw_active ? w->ir_thaw_epoch_buf.p : nullptr;
     d.frozen = w->frozen_live ? w->frozen_buf.p : nullptr;
     d.frozen_flag = w->frozen_live ? w->frozen_flag_buf.p : nullptr;
     d.thaw = w->frozen_live ? w->thaw_buf.p : nullptr;
@@ -994,7 +1033,19 @@ static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_ma
         const int out = writes_snap ? 1 - w->d.cur : -1;
         const bool thawing = w->thaw_kinds && (int_mask & PH_INT_FACTOR) && n_int > 0;
         if (thawing) HIP_TRY(launch_thaw(w->d, 0, w->d.R_local, ext_mask, w->stream));
+        if (w->ir_thaw_active && (ext_mask & PH_EXT_FACTOR) && w->d.NI > 0 && !w->conns.empty())
+            HIP_TRY(launch_thaw_ir(w->d, w->ir_gate.p, w->stream));
         HIP_TRY(launch_robot_sweep(w->d, 0, w->d.R_local, ext_mask, int_mask, n_int, out, hints, w->stream));
+        if (w->ir_thaw_active && writes_snap) {  // once every robot has run an internal variable sweep, every owner has delivered
+            bool all_take_part = true;
+            for (const Robot &rb : w->robots) all_take_part = all_take_part && (rb.ghost || rb.removed || !rb.idle);
+            if (all_take_part) {
+                w->ir_thaw_active = false;
+                w->d.ir_frozen_snap = nullptr; w->d.ir_frozen_epoch = nullptr; w->d.ir_thaw_epoch = nullptr;
+                for (Robot &rb : w->robots) rb.ir_thaw_epoch.clear();
+                w->flags_dirty = true;  // gate bytes back to 0 / 1
+            }
+        }
         if (w->thaw_kinds && (thawing || writes_snap)) {
             HIP_TRY(launch_thaw_done(w->d, 0, w->d.R_local, writes_snap ? 1 : 0, w->stream));
             bool all_take_part = true;  // idle robots keep thawing until they iterate again
@@ -1279,8 +1330,10 @@ int mgx_set_enabled(mgx_world *w, uint32_t kind_mask) {
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (kind_mask & ~15u) return fail(MGX_ERR_INVALID, "unknown factor kind bits 0x%x", kind_mask);
     const uint32_t on = kind_mask & ~w->p.enable_mask, off = w->p.enable_mask & ~kind_mask;
-    if ((on & 2u) & w->stale_kinds)
-        return fail(MGX_ERR_STATE, "re-enabling inter-robot factors after sweeps ran without them is not supported");
+    bool has_ghosts = false;
+    for (const Robot &rb : w->robots) has_ghosts = has_ghosts || rb.ghost;
+    if (((on & 2u) & w->stale_kinds) && has_ghosts)
+        return fail(MGX_ERR_STATE, "re-enabling inter-robot factors after sweeps ran without them is not supported on sharded worlds");
     if (kind_mask == w->p.enable_mask) return MGX_OK;
     flush_counts(w);  // what was logged so far was sent under the old flags
     // Internal kinds (dynamic, obstacle, tracking): a factor switched off keeps the inbox it has now and
@@ -1301,6 +1354,34 @@ int mgx_set_enabled(mgx_world *w, uint32_t kind_mask) {
             HIP_TRY(launch_or_bytes(w->thaw_buf.p, w->d.R_local, 0xff, (uint8_t)thaw_int, w->stream));
             w->thaw_kinds |= thaw_int;
             w->d.skip0 = w->skip0_buf.p;
+        }
+    }
+    // Inter-robot factors: F_AB's inbox entry from A's variable is what that variable last sent to its own
+    // factors; it is kept per variable when the kind goes off (k_ir_freeze) and used by k_thaw_ir, in front of
+    // launches with an external factor sweep, for as long as the variable has not delivered again.
+    if (((off & 2u) || ((on & 2u) & w->stale_kinds)) && !w->robots.empty()) {
+        int rc = commit(w);
+        if (rc != MGX_OK) return rc;
+        const size_t V = (size_t)w->d.V;
+        if (!w->ir_frozen_live) {  // never frozen before: nothing was ever received (kind off since the world began)
+            std::vector<double> z(24 * V, 0.0);
+            std::vector<uint32_t> ze(V, 0);
+            HIP_TRY(w->ir_frozen_snap_buf.upload(z, w->stream));
+            HIP_TRY(w->ir_frozen_epoch_buf.upload(ze, w->stream));
+            HIP_TRY(w->ir_thaw_epoch_buf.upload(ze, w->stream));
+            HIP_TRY(hipStreamSynchronize(w->stream));
+            w->ir_frozen_live = true;
+        }
+        if (off & 2u) {
+            HIP_TRY(launch_ir_freeze(w->d, w->ir_frozen_snap_buf.p, w->ir_frozen_epoch_buf.p, w->stream));
+            w->ir_thaw_active = false;
+            w->d.ir_frozen_snap = nullptr; w->d.ir_frozen_epoch = nullptr; w->d.ir_thaw_epoch = nullptr;
+            w->flags_dirty = true;
+        } else {
+            HIP_TRY(hipMemcpyAsync(w->ir_thaw_epoch_buf.p, w->d.snap_epoch[w->d.cur], sizeof(uint32_t) * V, hipMemcpyDeviceToDevice, w->stream));
+            w->ir_thaw_active = true;
+            w->d.ir_frozen_snap = w->ir_frozen_snap_buf.p; w->d.ir_frozen_epoch = w->ir_frozen_epoch_buf.p;
+            w->d.ir_thaw_epoch = w->ir_thaw_epoch_buf.p;
         }
     }
     w->p.enable_mask = kind_mask;

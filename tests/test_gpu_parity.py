@@ -308,8 +308,11 @@ def test_runtime_switching_of_factor_kinds():
             if step == 2:
                 w.change_prior(3, 5, np.array([1.0, -2.0, 0.5, 0.25]))   # delivered to factors of which two kinds are off
         same((step, mask))
-    with pytest.raises(MgxError):
-        eng.set_enabled(15)          # inter-robot factors have missed deliveries since they were switched off
+    for w in (eng, ref):             # inter-robot factors come back too (k_ir_freeze / k_thaw_ir)
+        w.set_enabled(15)
+        w.update_priors(**tick)
+        w.iterate(sc["steps"])
+    same("inter-robot factors back")
     # a robot that sits out (idle) while a kind comes back resumes from the frozen inbox when it iterates again,
     # and single sweeps through the fine-grained calls thaw the same way
     sc2 = S.grid_scenario(9, 10, interrobot=False)
@@ -329,6 +332,38 @@ def test_runtime_switching_of_factor_kinds():
         w.iterate([1] * 4)
     for a, b in zip(eng2.read_beliefs(), ref2.read_beliefs()):
         assert np.array_equal(a, b)
+    # inter-robot factors off and on while the topology changes, robots fall silent and priors move; a schedule
+    # that runs external iterations before the owners' next internal sweep makes the frozen records count
+    sc4 = S.grid_scenario(30, 10, interrobot=True, pitch=2.2, comm_radius=5.0)
+    sc4["ir"] = []
+    eng4, ref4 = make_pair(sc4)
+    import oracle
+    never = oracle.OracleWorld(sc4["params"])   # control: the same script, but inter-robot factors stay off after t = 2
+    S.populate(never, sc4)
+    base = np.array([[rb["pos"][0], 0.5, rb["pos"][1]] for rb in sc4["robots"]], dtype=np.float32)
+    rng = np.random.default_rng(3)
+    tk4 = S.tick_inputs(sc4)
+    nxt = {id(eng4): 1, id(ref4): 1, id(never): 1}
+    masks = [7, 7, 5, 5, 7, 7, 5, 7, 7]
+    steps4 = [[3] * 6, [3] * 6, [3] * 6, [1, 3, 3], [2, 2, 3, 3], [3] * 4, [3] * 3, [2, 3, 2, 3], [3] * 5]
+    for t, (mask, st) in enumerate(zip(masks, steps4)):
+        pos = base + rng.normal(0, 0.5, size=base.shape).astype(np.float32)
+        for w in (eng4, ref4, never):
+            w.set_enabled(mask if (w is not never or t < 2) else 5)
+            nxt[id(w)], _, _ = w.update_topology(pos, 5.0, nxt[id(w)])
+            if t == 3:
+                w.set_antenna(4, False)
+            if t == 4:
+                w.change_prior(7, 9, np.array([0.3, -0.2, 1.0, 0.5]))   # after the switch-on, before the first external sweep
+            if t == 6:
+                w.set_antenna(4, True)
+            w.update_priors(**tk4)
+            w.iterate(st)
+        for a, b in zip(eng4.read_beliefs(), ref4.read_beliefs()):
+            assert np.array_equal(a, b), (t, mask)
+        if t == 4:  # the first sweeps after the switch-on are external: the messages come from the frozen records
+            assert not np.array_equal(ref4.read_beliefs()[2], never.read_beliefs()[2])
+    assert nxt[id(eng4)] == nxt[id(ref4)]
     # robots that join while a kind is off start with empty frozen inboxes
     sc3 = S.grid_scenario(6, 10, interrobot=False)
     eng3, ref3 = make_pair(sc3)
