@@ -1,9 +1,9 @@
 """Summarise rocprofv3 output (kernel trace + PMC passes) of bench.py into profiles/<tag>_summary.md.
 
 usage: python tools/summarize_profile.py <tag> <steps> <warmup> <kernel_trace_dir> [<pmc_steps> <pmc_warmup> <pmc_fetch_dir> <pmc_write_dir>]
-The sweep kernel serves both bench workloads; bench.py runs the primary workload (configs[1]: one
-dispatch per 10-step tick) first, then one commit dispatch, then the inter-robot workload, so the
-dispatches are split by their position in the trace."""
+The sweep kernel serves both bench workloads in two instantiations: k_robot_sweep<K, 0> (no inter-robot
+edges: configs[1], one dispatch per 10-step tick; the warm-up and timed dispatches come first in the trace,
+the whole-tick measurements after them) and k_robot_sweep<K, 2> (inter-robot messages staged: configs[2])."""
 import collections
 import csv
 import glob
@@ -21,19 +21,18 @@ def main():
     pmc_steps, pmc_warm = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (0, 0)
     pmc = sys.argv[7:9]
 
-    def split(seq, steps, warm):
+    def split(rows_, value, steps, warm):
         n_w, n_t = -(-warm // 10), -(-steps // 10)
-        prim = seq[n_w:n_w + n_t]                  # timed primary dispatches
-        sec = seq[n_w + n_t + 1:]                  # after the commit dispatch
-        sec = sec[len(sec) // 5:]                  # drop the secondary warm-up share
+        prim = [value(r) for r in rows_ if ", 0>" in r["Kernel_Name"]][n_w:n_w + n_t]   # timed primary dispatches
+        sec = [value(r) for r in rows_ if ", 2>" in r["Kernel_Name"]]
+        sec = sec[len(sec) // 5:]                                                        # drop the secondary warm-up share
         return {"configs[1] dyn+obs, 10 iterations per dispatch": prim, "configs[2] +inter-robot, one iteration per dispatch": sec}
 
     out = [f"# rocprofv3 summary — {tag}", "", "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-dynamic ...`", ""]
     tr = [r for r in rows(kdir, "*kernel_trace.csv") if "k_robot_sweep" in r["Kernel_Name"]]
     tr.sort(key=lambda r: int(r["Start_Timestamp"]))
-    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
     out += [f"bench.py --steps {steps} --warmup {warm}", "", "| workload | dispatches | avg us | min us | max us | grid x block |", "|---|---|---|---|---|---|"]
-    for name, d in split(durs, steps, warm).items():
+    for name, d in split(tr, lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, steps, warm).items():
         if d:
             out.append(f"| {name} | {len(d)} | {sum(d) / len(d):.2f} | {min(d):.2f} | {max(d):.2f} | {tr[0]['Grid_Size_X']} x {tr[0]['Workgroup_Size_X']} |")
     st = rows(kdir, "*kernel_stats.csv")
@@ -44,9 +43,8 @@ def main():
     for d, name in zip(pmc, ("FETCH_SIZE", "WRITE_SIZE")):
         cr = [r for r in rows(d, "*counter_collection.csv") if "k_robot_sweep" in r["Kernel_Name"] and r["Counter_Name"] == name]
         cr.sort(key=lambda r: int(r["Start_Timestamp"]))
-        vals = [float(r["Counter_Value"]) for r in cr]
         out += ["", f"{name} per dispatch (KiB as reported by rocprofv3; own --pmc pass, bench.py --steps {pmc_steps} --warmup {pmc_warm}):", ""]
-        for wl, v in split(vals, pmc_steps, pmc_warm).items():
+        for wl, v in split(cr, lambda r: float(r["Counter_Value"]), pmc_steps, pmc_warm).items():
             if v:
                 out.append(f"* {wl}: mean {sum(v) / len(v):.1f} KiB over {len(v)} dispatches")
     os.makedirs("profiles", exist_ok=True)
