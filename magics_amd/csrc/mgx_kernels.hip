@@ -147,6 +147,9 @@ template <int KT, int IRM>
 __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int robot0, uint32_t ext_mask, uint32_t int_mask,
                                                              int n_int, int snap_out, uint32_t hints) {
     constexpr bool HAS_IR = IRM != IR_NONE, STAGE_IR = IRM == IR_STAGED;
+    // KT > 0: horizon length fixed at compile time; 0: read from the world (K <= 33); -1: read from the world, any K.
+    // BIG: more than 64 dynamic-factor messages / tracking factors per robot (K > 33): some lanes carry two.
+    constexpr bool BIG = KT < 0 || KT > 33;
     STAMP(t_k0);
     const int r = robot0 + xcd_local_index(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x;
@@ -633,6 +636,20 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #pragma unroll
             for (int c = 0; c < 16; c++) ml[c] = 0.0;
         }
+        // Horizons beyond 33 variables (BIG instantiations only) have more messages than the wave has lanes:
+        // lane l also computes message l + 64.  Its operands are read here, before ANY message of this sweep
+        // is written — the partner of a second-pass message may be a first-pass message.
+        double me2[4], ml2[16];
+        const int lane2 = lane + 64;
+        const bool has2 = BIG && lane2 < n_dyn;
+        if (has2) {
+            const int f2 = lane2 % (K - 1), slot2 = lane2 / (K - 1), o2 = f2 + 1 - slot2, oe2 = (1 - slot2) * (K - 1) + f2;
+            const bool pres = s_epoch[o2] > 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) me2[c] = pres ? s_snap[c * K + o2] - s_fv[c * E1 + oe2] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; c++) ml2[c] = pres ? s_snap[(4 + c) * K + o2] - s_fv[(4 + c) * E1 + oe2] : 0.0;
+        }
         if (!dynamic_message(maa, mab, mba, mbb, me, ml, oe, ol)) {
 #pragma unroll
             for (int c = 0; c < 4; c++) oe[c] = 0.0;
@@ -643,6 +660,29 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         for (int c = 0; c < 4; c++) s_fv[c * E1 + lane] = oe[c];
 #pragma unroll
         for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + lane] = ol[c];
+        if (has2) {  // potential blocks of the second message straight from HBM / L2: a rare shape, not worth registers
+            const int f2 = lane2 % (K - 1), slot2 = lane2 / (K - 1), a2 = 2 * slot2, b2 = 2 * (1 - slot2), it2 = r * (K - 1) + f2;
+            double naa[4], nab[4], nba[4], nbb[4];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    naa[i * 2 + j] = w.dyn_m[(size_t)((a2 + i) * 4 + (a2 + j)) * w.ND + it2];
+                    nab[i * 2 + j] = w.dyn_m[(size_t)((a2 + i) * 4 + (b2 + j)) * w.ND + it2];
+                    nba[i * 2 + j] = w.dyn_m[(size_t)((b2 + i) * 4 + (a2 + j)) * w.ND + it2];
+                    nbb[i * 2 + j] = w.dyn_m[(size_t)((b2 + i) * 4 + (b2 + j)) * w.ND + it2];
+                }
+            if (!dynamic_message(naa, nab, nba, nbb, me2, ml2, oe, ol)) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) oe[c] = 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; c++) ol[c] = 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_fv[c * E1 + lane2] = oe[c];
+#pragma unroll
+            for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + lane2] = ol[c];
+        }
     };
 
     bool dyn_prefired = false;  // the DYN wave already ran the dynamic messages of internal iteration 0
@@ -748,6 +788,33 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     for (int c = 0; c < 4; c++) s_fv[c * E1 + uedge] = oe[c];
 #pragma unroll
                     for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + uedge] = ol[c];
+                }
+                // horizons beyond 33 variables: tracking factors K-2+64 .. 2(K-2)-1 have no lane of their own; lanes
+                // 0 .. of the UV wave take them on, with their state in HBM (BIG instantiations only)
+                if (BIG && role == ROLE_UV && lane + 64 >= K - 2 && lane + 64 < 2 * (K - 2) && (w.enable & 8u) && itf >= 10 &&
+                    !(it == 0 && (skip0 & 8u))) {
+                    const int j2 = lane + 64 - (K - 2), var2 = j2 + 1, col2 = n_dyn + (K - 2) + j2, item2 = r * (K - 2) + j2;
+                    double x0[4], oe[4], ol[16];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) x0[c] = s_snap[(20 + c) * K + var2];
+                    int rec2 = w.trk_record[item2];
+                    float lp2[2] = {w.trk_last_pos[item2], w.trk_last_pos[(size_t)w.NT + item2]};
+                    double lv2 = w.trk_last_val[item2];
+                    const int p0 = w.path_ptr[r], np = w.path_ptr[r + 1] - p0;
+                    if (!tracking_message(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, rec2, lp2, lv2, oe, ol)) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) oe[c] = 0.0;
+#pragma unroll
+                        for (int c = 0; c < 16; c++) ol[c] = 0.0;
+                    }
+                    w.trk_record[item2] = rec2;
+                    w.trk_last_pos[item2] = lp2[0];
+                    w.trk_last_pos[(size_t)w.NT + item2] = lp2[1];
+                    w.trk_last_val[item2] = lv2;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) s_fv[c * E1 + col2] = oe[c];
+#pragma unroll
+                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + col2] = ol[c];
                 }
                 itf += 1;
                 STAMP(t1);
@@ -1305,7 +1372,7 @@ size_t sweep_lds_bytes(int K, int ir_edges) {
     return sizeof(double) * (size_t)((SNAP_W + 20 + 20) * K + io + IR_STRIDE * ir_edges) +
            4 * (size_t)(2 * ((K + 1) & ~1) + ((3 * (K + 1) + 1) & ~1));
 }
-bool sweep_supports(int K) { return K >= 3 && 2 * (K - 1) <= 64; }
+bool sweep_supports(int K) { return K >= 3 && 2 * (K - 1) <= 128; }  // beyond 33 variables: two dynamic messages per lane
 int blob_words(int K) { const BlobLayout L(K); return (L.words() + 1) & ~1; }
 
 template <int KT>
@@ -1330,11 +1397,17 @@ hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint3
     if (n_robots <= 0) return hipSuccess;
     switch (w.K) {  // horizon lengths of BASELINE.json / the reference scenarios get constant-K code
     case 10: launch_k<10>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;
-    case 12: launch_k<12>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;
+    case 12: launch_k<12>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;  // Junction Twoway
+    case 13: launch_k<13>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;  // Junction Experiment
     case 16: launch_k<16>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;
-    case 21: launch_k<21>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;
+    case 17: launch_k<17>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;  // Merge, Iteration Amount
+    case 21: launch_k<21>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;  // Circle Experiment
     case 32: launch_k<32>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;
-    default: launch_k<0>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;
+    case 35: launch_k<35>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;  // Communications Failure
+    default:
+        if (2 * (w.K - 1) > 64) launch_k<-1>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream);
+        else launch_k<0>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream);
+        break;
     }
     return hipGetLastError();
 }

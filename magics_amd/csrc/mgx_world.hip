@@ -821,7 +821,7 @@ static int commit(mgx_world *w) {
     int rc = pull(w);
     if (rc != MGX_OK) return rc;
     const int K = w->K, E = 4 * K - 6;
-    if (!sweep_supports(K) || sweep_lds_bytes(K, 0) > 60 * 1024) return fail(MGX_ERR_INVALID, "K = %d not supported (3 <= K <= 33)", K);
+    if (!sweep_supports(K) || sweep_lds_bytes(K, 0) > 60 * 1024) return fail(MGX_ERR_INVALID, "K = %d not supported (3 <= K <= 45: the robot's graph has to fit 60 KB of LDS)", K);
 
     // device robot order: locals (id order), then ghosts
     w->robot_of.clear();

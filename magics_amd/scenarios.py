@@ -61,7 +61,7 @@ CIRCLE_PARAMS = dict(
 EN_DYN, EN_IR, EN_OBS, EN_TRK = 1, 2, 4, 8
 
 # lookahead horizons reaching the BASELINE.json horizon lengths with lookahead_multiple 3
-HORIZON_FOR_K = {10: 18, 12: 25, 16: 45, 21: 75, 32: 176}
+HORIZON_FOR_K = {10: 18, 12: 25, 16: 45, 21: 75, 32: 176, 33: 180, 34: 188, 35: 199, 40: 261, 45: 331}
 
 
 def timesteps_for_K(K, multiple=3):

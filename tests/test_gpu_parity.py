@@ -378,3 +378,22 @@ def test_runtime_switching_of_factor_kinds():
         w.iterate([1] * 5)
     for a, b in zip(eng3.read_beliefs(), ref3.read_beliefs()):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("K", [33, 34, 35, 45])
+def test_horizons_beyond_one_message_per_lane(K):
+    """K = 35 is what two of the reference's scenarios ask for (target speed x planning horizon = 199:
+    Communications Failure Experiment, Varying Network Connectivity Experiment).  Beyond 33 variables a
+    robot has more dynamic-factor messages (2(K-1)) and tracking factors than a wave has lanes: the
+    runtime-K kernel gives the first lanes a second message / factor.  Inter-robot factors, tracking,
+    whole ticks: bit-identical to the oracle."""
+    sc = S.grid_scenario(12, K, interrobot=True, tracking=True, pitch=3.0, comm_radius=7.0)
+    eng, ref = make_pair(sc)
+    tick = S.tick_inputs(sc)
+    for block in range(3):
+        for w in (eng, ref):
+            for _ in range(2):
+                w.tick(steps=sc["steps"], **tick)
+        assert_identical(eng, ref, what=f"K = {K}, block {block}")
+    for r in (0, 7):
+        assert eng.message_counts(r) == ref.message_counts(r)

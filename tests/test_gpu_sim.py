@@ -74,3 +74,30 @@ def test_robots_finish_and_despawn():
     s = _run_both("Circle Experiment", 60, tweak=short)
     assert any(r["completed"] for r in s.robots)
     assert all((not r["alive"]) == r["completed"] for r in s.robots)
+
+
+def _only_local_scenarios():
+    with open(os.path.join(ROOT, "tests", "golden", "scenarios.json"), encoding="utf-8") as f:
+        scenarios = json.load(f)
+    return sorted(n for n, sc in scenarios.items()
+                  if all(f["planning-strategy"] == "only-local" for f in sc["formation"]["formations"]) and
+                  sum(f["robots"] for f in sc["formation"]["formations"]) > 0)
+
+
+@pytest.mark.parametrize("name", _only_local_scenarios())
+def test_every_local_planning_scenario_of_the_reference(name):
+    """Every scenario directory of the reference that plans locally (the RRT* ones need the global
+    planner, out of scope), unmodified, for its first simulated seconds: environment, spawns, topology,
+    prior updates, schedule — engine and oracle stay bit-identical."""
+    sc = _scenario(name)
+    n_first = max(f["robots"] for f in sc["formation"]["formations"])
+    first_spawn = min(f["delay"] for f in sc["formation"]["formations"]) / 1e9
+    ticks = int((first_spawn + (1.5 if n_first > 12 else 3.0)) * sc["config"]["simulation"]["hz"]) + 1
+    a, b = _pair(sc)
+    for t in range(ticks):
+        a.tick()
+        b.tick()
+    assert len(a.robots) == len(b.robots) and len(a.robots) > 0
+    assert np.array_equal(a.translation, b.translation) and a.events == b.events
+    for x, y in zip(a.w.read_beliefs(), b.w.read_beliefs()):
+        assert np.array_equal(x, y)
