@@ -73,7 +73,8 @@ class Simulation:
                             "target": 1, "alive": True, "completed": False, "started_at": self.elapsed(), "finished_at": None,
                             "time_scale": float(self.dt32 / t0), "colour": desc["colour"], "rng": desc["rng"],
                             "strategy": desc["planning-strategy"], "reach": desc["waypoint-reached-when-intersects"],
-                            "finish": desc["finished-when-intersects"], "positions": [], "travelled": 0.0})
+                            "finish": desc["finished-when-intersects"], "positions": [], "velocities": [], "travelled": 0.0,
+                            "trk_elapsed": 0, "trk_prev": None})
         self.translation = np.vstack([self.translation, np.array([[states[0][0], -1.5, states[0][1]]], dtype=F)])  # spawner.rs:548
 
     def _spawn(self):
@@ -144,8 +145,22 @@ class Simulation:
                        delta_t=float(self.dt32), steps=self.steps)                          # prior updates + iterate_gbp_v2
             else:
                 w.iterate(self.steps)
-            for r in live:  # PositionTracker (spawner.rs:620): sampled once per tick here
-                r["positions"].append([float(self.translation[r["id"], 0]), float(self.translation[r["id"], 2])])
+            # PositionTracker / VelocityTracker (planner/tracking.rs:104-122,189-218; 100 ms timers, spawner.rs:620-621):
+            # FixedUpdate systems over Changed<Transform>, i.e. the robots that moved this tick; sampled after the move
+            now = (self.tick_no + 1) * self.dt_ns * 1e-9
+            for r in moving:
+                r["trk_elapsed"] += self.dt_ns
+                if r["trk_elapsed"] < 100_000_000:
+                    continue
+                r["trk_elapsed"] %= 100_000_000
+                pos = self.translation[r["id"]].copy()
+                r["positions"].append([float(pos[0]), float(pos[2])])
+                if r["trk_prev"] is not None:
+                    dt = now - r["trk_prev"][1]
+                    v = (pos - r["trk_prev"][0]) / F(dt)
+                    r["velocities"].append({"velocity": [float(v[0]), float(v[1]), float(v[2])], "timestamp": now,
+                                            "measured_over": {"secs": int(dt), "nanos": int(round((dt - int(dt)) * 1e9))}})
+                r["trk_prev"] = (pos, now)
         self.tick_no += 1
 
     def finished(self):
@@ -167,7 +182,7 @@ class Simulation:
             wps = [[float(s[0]), float(s[1])] for s in r["waypoints"]]
             fin = r["finished_at"] if r["finished_at"] is not None else self.elapsed()
             robots[str(r["id"])] = {
-                "radius": float(r["radius"]), "positions": r["positions"], "velocities": [],
+                "radius": float(r["radius"]), "positions": r["positions"], "velocities": r["velocities"],
                 "collisions": {"robots": 0, "environment": 0},
                 "messages": {"sent": {"internal": sent_i, "external": sent_e}, "received": {"internal": recv_i, "external": recv_e}},
                 "mission": {"waypoints": [wps[0], wps[-1]], "started_at": r["started_at"], "finished_at": fin,

@@ -235,6 +235,9 @@ def test_junction_twoway_runs_headless(scenarios):
     r0 = ex["robots"]["0"]
     assert set(r0) == {"radius", "positions", "velocities", "collisions", "messages", "mission", "planning_strategy", "color"}
     assert r0["messages"]["sent"]["internal"] > 0 and len(r0["positions"]) == 70 and ex["makespan"] == pytest.approx(7.0)
+    assert len(r0["velocities"]) == 69 and set(r0["velocities"][0]) == {"velocity", "timestamp", "measured_over"}
+    speed = [math.hypot(v["velocity"][0], v["velocity"][2]) for v in r0["velocities"][5:]]
+    assert 1.0 < min(speed) and max(speed) < 15.0 and r0["velocities"][0]["measured_over"] == {"secs": 0, "nanos": 100000000}
     json.dumps(ex)
 
 
