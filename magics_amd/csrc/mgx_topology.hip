@@ -44,9 +44,10 @@ __device__ __forceinline__ uint32_t bucket_of(int cx, int cz, uint32_t mask) {
 // one thread per robot i, positions of j staged through LDS in tiles; FILL = second pass
 template <bool FILL>
 __global__ void __launch_bounds__(256) k_pairs(const float *__restrict__ pos, int n, float radius, int32_t *__restrict__ cnt,
-                                                const int32_t *__restrict__ ptr, int32_t *__restrict__ idx) {
+                                                const int32_t *__restrict__ ptr, int32_t *__restrict__ idx, int32_t cap) {
     __shared__ float tile[256 * 3];
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (FILL && ptr[n] > cap) return;  // speculative second pass: the rows do not fit the buffer the host guessed
     const bool live = i < n;
     const float ax = live ? pos[3 * i] : 0.f, ay = live ? pos[3 * i + 1] : 0.f, az = live ? pos[3 * i + 2] : 0.f;
     int m = 0;
@@ -127,7 +128,7 @@ __global__ void __launch_bounds__(256) k_grid_query(const float *__restrict__ po
                                                      const int32_t *__restrict__ bucket_ptr, const int32_t *__restrict__ members,
                                                      const int32_t *__restrict__ special, const int32_t *__restrict__ n_special,
                                                      int32_t *__restrict__ cnt, const int32_t *__restrict__ ptr,
-                                                     int32_t *__restrict__ idx) {
+                                                     int32_t *__restrict__ idx, int32_t cap) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int i = t / QG, l = t % QG;
     const bool live = i < n;
@@ -175,6 +176,7 @@ __global__ void __launch_bounds__(256) k_grid_query(const float *__restrict__ po
         if (l == 0) cnt[i] = total;
         return;
     }
+    if (ptr[n] > cap) return;  // speculative second pass: the rows do not fit the buffer the host guessed
     const int32_t base = ptr[i];
     int w = base + incl - m;
     for (int q = q0; q < q1; q += stride) {
@@ -213,24 +215,24 @@ hipError_t neighbours_count(const float *pos, int n, float radius, bool grid, ui
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, bucket_cnt, (int)M, bucket_ptr);
         hipLaunchKernelGGL(k_grid_scatter, g256, dim3(256), 0, s, pos, n, inv_cell, M - 1, bucket_ptr, cursor, members);
         hipLaunchKernelGGL(k_grid_query<false>, dim3((unsigned)(((size_t)n * QG + 255) / 256)), dim3(256), 0, s, pos, n, radius, inv_cell, M - 1, bucket_ptr, members, special,
-                           n_special, cnt, (const int32_t *)nullptr, (int32_t *)nullptr);
+                           n_special, cnt, (const int32_t *)nullptr, (int32_t *)nullptr, 0);
     } else {
-        hipLaunchKernelGGL(k_pairs<false>, g256, dim3(256), 0, s, pos, n, radius, cnt, (const int32_t *)nullptr, (int32_t *)nullptr);
+        hipLaunchKernelGGL(k_pairs<false>, g256, dim3(256), 0, s, pos, n, radius, cnt, (const int32_t *)nullptr, (int32_t *)nullptr, 0);
     }
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, cnt, n, ptr);
     return hipGetLastError();
 }
 hipError_t neighbours_fill(const float *pos, int n, float radius, bool grid, uint32_t M, const int32_t *bucket_ptr,
                            const int32_t *members, const int32_t *special, const int32_t *n_special, const int32_t *ptr,
-                           int32_t *idx, hipStream_t s) {
+                           int32_t *idx, int32_t cap, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const dim3 g256((unsigned)((n + 255) / 256));
     if (grid) {
         const double inv_cell = 1.0 / ((double)radius * 1.001);
         hipLaunchKernelGGL(k_grid_query<true>, dim3((unsigned)(((size_t)n * QG + 255) / 256)), dim3(256), 0, s, pos, n, radius, inv_cell, M - 1, bucket_ptr, members, special,
-                           n_special, (int32_t *)nullptr, ptr, idx);
+                           n_special, (int32_t *)nullptr, ptr, idx, cap);
     } else {
-        hipLaunchKernelGGL(k_pairs<true>, g256, dim3(256), 0, s, pos, n, radius, (int32_t *)nullptr, ptr, idx);
+        hipLaunchKernelGGL(k_pairs<true>, g256, dim3(256), 0, s, pos, n, radius, (int32_t *)nullptr, ptr, idx, cap);
     }
     return hipGetLastError();
 }

@@ -63,12 +63,21 @@ hipError_t neighbours_count(const float *pos, int n, float radius, bool grid, ui
                             int32_t *ptr, hipStream_t s);
 hipError_t neighbours_fill(const float *pos, int n, float radius, bool grid, uint32_t M, const int32_t *bucket_ptr,
                            const int32_t *members, const int32_t *special, const int32_t *n_special, const int32_t *ptr,
-                           int32_t *idx, hipStream_t s);
+                           int32_t *idx, int32_t cap, hipStream_t s);
 }  // namespace mgx
 
 using namespace mgx;
 
 static thread_local std::string g_err;
+// MGX_TIMING=1: host-side stage times of the topology pass and the table rebuild on stderr (diagnostic)
+struct StageTimer {
+    bool on;
+    double t0;
+    const char *what;
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+    explicit StageTimer(const char *w) : what(w) { static const bool e = getenv("MGX_TIMING") != nullptr; on = e; t0 = on ? now() : 0.0; }
+    void lap(const char *stage) { if (on) { const double t = now(); fprintf(stderr, "[mgx timing] %s: %s %.1f us\n", what, stage, t - t0); t0 = t; } }
+};
 static int fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -120,11 +129,12 @@ struct DevBuf {
     }
     hipError_t reserve(size_t want) {  // contents undefined afterwards
         if (want < 1) want = 1;
-        if (want > cap) {
-            release();
-            hipError_t e = hipMalloc((void **)&p, sizeof(T) * want);
+        if (want > cap) {  // grow with headroom: tables that follow a churning topology would otherwise be
+            release();     // re-allocated (a device-wide synchronisation) at every new maximum
+            const size_t room = want + want / 4 + 64;
+            hipError_t e = hipMalloc((void **)&p, sizeof(T) * room);
             if (e != hipSuccess) return e;
-            cap = want;
+            cap = room;
         }
         n = want;
         return hipSuccess;
@@ -239,6 +249,7 @@ struct IrConn {  // K-1 factors owner -> other
     // update counts as sent / received.
     uint64_t updates_per_sweep = 0;
     int32_t dev_slot = -1;  // slot of this connection in its target's incoming list on the device (-1: not there)
+    bool has_fresh = true;  // some edge still carries `fresh` (created since the device tables were last laid out)
 };
 
 // RCCL, resolved at run time (no link-time dependency): the copy already in the process (a host that
@@ -358,6 +369,7 @@ struct mgx_world {
     // neighbour search scratch (mgx_topology.hip)
     DevBuf<float> nb_pos;
     DevBuf<int32_t> nb_cnt, nb_bucket_cnt, nb_bucket_ptr, nb_cursor, nb_members, nb_special, nb_nspecial, nb_ptr, nb_idx;
+    size_t nb_last_total = 0;  // rows of the last search: sizes the speculative second pass of the next one
 };
 
 static size_t edge_index(const std::vector<int32_t> &in_ptr, int K, int r, int j, int slot);
@@ -613,12 +625,7 @@ static void flush_counts(mgx_world *w) {
         }
     // change_prior (variable.rs:203-230): its sends stay in a local counter; the connected factors receive
     if (!w->cp_dirty.empty()) {
-        std::vector<std::vector<int>> own_of(n), foreign_of(n);
-        if (en & 2u)
-            for (size_t ci = 0; ci < w->conns.size(); ci++) {
-                own_of[(size_t)w->conns[ci].owner].push_back((int)ci);
-                foreign_of[(size_t)w->conns[ci].other].push_back((int)ci);
-            }
+        std::vector<uint64_t> on_ir(n, 0);  // per robot: prior changes of variables that carry inter-robot factors (i >= 1)
         for (uint32_t key : w->cp_dirty) {
             const size_t r = key / (uint32_t)K;
             const int i = (int)(key % (uint32_t)K);
@@ -627,11 +634,13 @@ static void flush_counts(mgx_world *w) {
             Robot &rb = w->robots[r];
             const uint64_t dyn_here = (uint64_t)((i >= 1) + (i <= K - 2));
             rb.cnt[2] += c * (((en & 1u) ? dyn_here : 0) + ((i >= 1 && i <= K - 2) ? (uint64_t)(((en & 4u) != 0) + ((en & 8u) != 0)) : 0));
-            if (i >= 1) {  // one inter-robot factor per connection hangs on this variable
-                for (int ci : own_of[r]) w->conns[(size_t)ci].cnt[2] += c;
-                for (int ci : foreign_of[r]) w->conns[(size_t)ci].cnt[3] += c;
-            }
+            if (i >= 1) on_ir[r] += c;  // one inter-robot factor per connection hangs on this variable
         }
+        if (en & 2u)
+            for (IrConn &c : w->conns) {
+                c.cnt[2] += on_ir[(size_t)c.owner];  // the owner's own variable delivers to its factor
+                c.cnt[3] += on_ir[(size_t)c.other];  // the foreign variable delivers to it
+            }
         w->cp_dirty.clear();
     }
     w->clog.clear();
@@ -762,8 +771,10 @@ static int upload_flags(mgx_world *w);
 // arrays are laid out by k_edge_rebuild.
 static int retopo(mgx_world *w) {
     const int K = w->K, R_local = w->d.R_local;
+    StageTimer tm("retopo");
     Incoming t;
     build_incoming(w, R_local, t);
+    tm.lap("build_incoming");
     if (!t.blocks_ok) return fail(MGX_ERR_STATE, "internal: node slots of two connections interleave");
     const size_t n_slots = t.in_list.size(), NI = n_slots * (size_t)(K - 1), NIs = std::max<size_t>(NI, 1);
     std::vector<IrSlotRec> slots(std::max<size_t>(n_slots, 1));
@@ -778,10 +789,23 @@ static int retopo(mgx_world *w) {
         sl.d_safe = w->p.safety_multiplier * ow.radius;
         sl.first_number = c.first_number;
     }
+    tm.lap("slot records");
     hipStream_t s = w->stream;
-    HIP_TRY(w->slot_recs.upload(slots, s));
-    HIP_TRY(w->in_ptr_dev_b.upload(t.in_ptr, s));
-    HIP_TRY(w->in_mid_dev.upload(t.mid, s));
+    // the three host tables travel through one pinned block of the argument ring: true asynchronous copies, and
+    // no synchronisation at the end of the rebuild (the block is released by an event after the kernels)
+    const size_t b_slots = sizeof(IrSlotRec) * slots.size(), b_ptr = sizeof(int32_t) * t.in_ptr.size(), b_mid = sizeof(int32_t) * t.mid.size();
+    void *hp = nullptr;
+    int ring_slot = 0;
+    HIP_TRY(w->stage.acquire(b_slots + b_ptr + b_mid, &hp, &ring_slot));
+    memcpy(hp, slots.data(), b_slots);
+    memcpy((char *)hp + b_slots, t.in_ptr.data(), b_ptr);
+    memcpy((char *)hp + b_slots + b_ptr, t.mid.data(), b_mid);
+    HIP_TRY(w->slot_recs.reserve(slots.size()));
+    HIP_TRY(w->in_ptr_dev_b.reserve(t.in_ptr.size()));
+    HIP_TRY(w->in_mid_dev.reserve(t.mid.size()));
+    HIP_TRY(hipMemcpyAsync(w->slot_recs.p, hp, b_slots, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(w->in_ptr_dev_b.p, (char *)hp + b_slots, b_ptr, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(w->in_mid_dev.p, (char *)hp + b_slots + b_ptr, b_mid, hipMemcpyHostToDevice, s));
     HIP_TRY(w->ir_rec_b.reserve(NIs));
     HIP_TRY(w->ir_fv_eta_b.reserve(4 * NIs));
     HIP_TRY(w->ir_fv_lam_b.reserve(16 * NIs));
@@ -789,7 +813,8 @@ static int retopo(mgx_world *w) {
     HIP_TRY(launch_edge_rebuild(w->d, (int)n_slots, w->slot_recs.p, w->in_ptr_dev_b.p, w->in_ptr_dev.p, (int)NIs, w->ir_rec_b.p,
                                 w->ir_fv_eta_b.p, w->ir_fv_lam_b.p, w->ir_bmu_b.p, s));
     HIP_TRY(launch_var_tables(R_local, K, w->in_ptr_dev_b.p, w->in_mid_dev.p, w->ir_var_ptr.p, w->ir_var_mid.p, s));
-    HIP_TRY(hipStreamSynchronize(s));  // `slots`, `t` are pageable temporaries
+    HIP_TRY(w->stage.release(ring_slot, s));
+    tm.lap("uploads + launches");
     w->ir_rec.swap(w->ir_rec_b);
     w->ir_fv_eta.swap(w->ir_fv_eta_b);
     w->ir_fv_lam.swap(w->ir_fv_lam_b);
@@ -803,11 +828,17 @@ static int retopo(mgx_world *w) {
     for (size_t g = 0; g < n_slots; g++) {
         IrConn &c = w->conns[(size_t)t.in_list[g]];
         c.dev_slot = (int32_t)g;
-        for (IrEdge &ed : c.edges) ed.fresh = false;
+        if (c.has_fresh) {
+            for (IrEdge &ed : c.edges) ed.fresh = false;
+            c.has_fresh = false;
+        }
     }
     w->dev_in_ptr = t.in_ptr;
     w->conns_dirty = false;
-    return upload_flags(w);  // the gate bytes follow the edges
+    tm.lap("slot bookkeeping");
+    const int rc_flags = upload_flags(w);  // the gate bytes follow the edges
+    tm.lap("flags + gates");
+    return rc_flags;
 }
 
 static int commit(mgx_world *w) {
@@ -1485,15 +1516,27 @@ static int neighbours(mgx_world *w, const float *pos, float radius, uint32_t met
     if (n) HIP_TRY(hipMemcpyAsync(w->nb_pos.p, pos, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
     HIP_TRY(neighbours_count(w->nb_pos.p, n, radius, grid, M, w->nb_cnt.p, w->nb_bucket_cnt.p, w->nb_bucket_ptr.p, w->nb_cursor.p,
                              w->nb_members.p, w->nb_special.p, w->nb_nspecial.p, w->nb_ptr.p, s));
+    // The second pass needs the total to size its output — one more host round trip.  Instead it runs right
+    // away into the buffer left from the last search (the kernels leave it alone if the rows do not fit), and
+    // rows and counts come back together; only a total beyond the guess costs the second trip.
     ptr.assign((size_t)n + 1, 0);
+    const size_t guess = std::min(w->nb_idx.cap, w->nb_last_total + w->nb_last_total / 4 + 64);
+    if (guess > 0 && w->nb_idx.p)
+        HIP_TRY(neighbours_fill(w->nb_pos.p, n, radius, grid, M, w->nb_bucket_ptr.p, w->nb_members.p, w->nb_special.p,
+                                w->nb_nspecial.p, w->nb_ptr.p, w->nb_idx.p, (int32_t)guess, s));
     HIP_TRY(hipMemcpyAsync(ptr.data(), w->nb_ptr.p, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, s));
+    idx.assign(guess, 0);
+    if (guess > 0 && w->nb_idx.p) HIP_TRY(hipMemcpyAsync(idx.data(), w->nb_idx.p, sizeof(int32_t) * guess, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const size_t total = (size_t)ptr[(size_t)n];
-    idx.assign(total, 0);
-    if (total) {
+    w->nb_last_total = total;
+    if (total <= guess && (w->nb_idx.p || total == 0)) {
+        idx.resize(total);
+    } else {
+        idx.assign(total, 0);
         HIP_TRY(w->nb_idx.reserve(total));
         HIP_TRY(neighbours_fill(w->nb_pos.p, n, radius, grid, M, w->nb_bucket_ptr.p, w->nb_members.p, w->nb_special.p,
-                                w->nb_nspecial.p, w->nb_ptr.p, w->nb_idx.p, s));
+                                w->nb_nspecial.p, w->nb_ptr.p, w->nb_idx.p, (int32_t)total, s));
         HIP_TRY(hipMemcpyAsync(idx.data(), w->nb_idx.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
@@ -1544,8 +1587,10 @@ int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, 
     if (*robot_number_next == 0) return fail(MGX_ERR_INVALID, "robot_number is NonZeroUsize");
     if (method > MGX_NEIGHBOURS_GRID) return fail(MGX_ERR_INVALID, "bad method");
     std::vector<int32_t> ptr, idx;
+    StageTimer tm("update_topology");
     int rc = neighbours(w, positions_xyz, radius, method, ptr, idx);  // update_robot_neighbours, robot.rs:1362-1384
     if (rc != MGX_OK) return rc;
+    tm.lap("neighbour search");
     const int n = (int)w->robots.size();
     uint32_t created = 0, deleted = 0;
     auto in_range = [&](int r, int o) { return std::find(idx.begin() + ptr[(size_t)r], idx.begin() + ptr[(size_t)r + 1], o) != idx.begin() + ptr[(size_t)r + 1]; };
@@ -1558,18 +1603,23 @@ int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, 
     std::vector<int> victim((size_t)n, -1);
     for (int r = 0; r < n; r++) {
         if (w->robots[(size_t)r].removed) continue;  // not in the query any more
-        std::vector<int> &cw = w->robots[(size_t)r].connected, keep;
-        for (int o : cw)
-            if (in_range(r, o)) keep.push_back(o);
+        std::vector<int> &cw = w->robots[(size_t)r].connected;
+        size_t kept = 0;
+        for (size_t q = 0; q < cw.size(); q++) {
+            const int o = cw[q];
+            if (in_range(r, o)) cw[kept++] = o;
             else victim[(size_t)r] = o;
-        cw.swap(keep);
+        }
+        cw.resize(kept);
     }
     {
         std::vector<std::pair<int, int>> pairs;
         for (int r = 0; r < n; r++)
             if (victim[(size_t)r] >= 0) pairs.emplace_back(r, victim[(size_t)r]);
+        tm.lap("out-of-range scan");
         ir_disconnect_batch(w, pairs);
         deleted = (uint32_t)pairs.size();
+        tm.lap("delete");
     }
 
     // create_interrobot_factors (robot.rs:1441-1586): new = within range \ connected, ascending,
@@ -1580,6 +1630,7 @@ int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, 
         for (int32_t q = ptr[(size_t)r]; q < ptr[(size_t)r + 1]; q++)
             if (std::find(cw.begin(), cw.end(), idx[(size_t)q]) == cw.end()) fresh[(size_t)r].push_back(idx[(size_t)q]);
     }
+    tm.lap("fresh scan");
     for (int r = 0; r < n; r++)
         for (int o : fresh[(size_t)r]) {
             rc = ir_connect(w, r, o, *robot_number_next);
@@ -1589,6 +1640,7 @@ int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, 
             sort_by_key(w, w->robots[(size_t)r].connected);
             created++;
         }
+    tm.lap("create");
     if (stats) { stats[0] = created; stats[1] = deleted; }
     return MGX_OK;
 }
