@@ -397,3 +397,33 @@ def test_horizons_beyond_one_message_per_lane(K):
         assert_identical(eng, ref, what=f"K = {K}, block {block}")
     for r in (0, 7):
         assert eng.message_counts(r) == ref.message_counts(r)
+
+
+def test_newer_entry_points_validate_their_arguments():
+    """mgx_tick, mgx_set_enabled, mgx_halo_plan_from_connections, mgx_world_set_environment: bad input is an
+    error code with a message, never a crash or a silent no-op."""
+    import ctypes as C
+    from magics_amd import MgxError, World, environment
+    sc = S.grid_scenario(4, 10, interrobot=False)
+    w = World(sc["params"])
+    S.populate(w, sc)
+    tick = S.tick_inputs(sc)
+    with pytest.raises(MgxError):
+        w.tick(steps=sc["steps"], **dict(tick, robots=np.array([0, 1, 2, 9], dtype=np.int32)))     # robot 9 does not exist
+    with pytest.raises(MgxError):
+        w.tick(steps=sc["steps"], **dict(tick, what=np.array([3, 3, 3, 7], dtype=np.uint8)))        # unknown update bit
+    w.tick(steps=[], **tick)                                                                         # no steps: prior updates only
+    w.tick(steps=sc["steps"], robots=np.zeros(0, np.int32), waypoints_xy=np.zeros((0, 2)), time_scale=np.zeros(0),
+           what=np.zeros(0, np.uint8), max_speed=1.0, delta_t=0.1)                                  # nobody moves: just the schedule
+    with pytest.raises(MgxError):
+        w.set_enabled(16)
+    with pytest.raises(MgxError):
+        w.halo_plan_from_connections(np.zeros(3, np.int32), 0, 1)                                    # table of the wrong length
+    with pytest.raises(MgxError):
+        w.halo_plan_from_connections(np.array([0, 0, 1, 0], np.int32), 0, 2)                         # robot 2 is local, not a ghost
+    assert w.halo_plan_from_connections(np.zeros(4, np.int32), 0, 1) == ([0], [0])
+    with pytest.raises(MgxError):
+        w.set_environment(environment.new(["┼"], 0.05, 1.0, 100.0, sdf={"resolution": 50, "expansion": 0.1, "blur": 0.0}))
+    with pytest.raises(MgxError):
+        w._chk(w._L.mgx_world_set_environment(w._w, None))
+    assert np.isfinite(w.read_beliefs()[2]).all()
