@@ -128,8 +128,9 @@ int mgx_ir_disconnect(mgx_world *w, int32_t a, int32_t b);
  * (factorgraph.rs:1529-1539; ui/settings.rs:491-496) and to factors created from now on
  * (robot.rs:1236,1276,1326,1506 read the same config entry): MGX_FACTOR_* bits.  A disabled factor
  * keeps its last message in the variable's inbox and drops what is sent to it; switched on again it
- * resumes from the inbox it froze with (all four kinds).  On a sharded world (ghost robots) turning
- * INTER-ROBOT factors back on after sweeps ran without them returns MGX_ERR_STATE. */
+ * resumes from the inbox it froze with (all four kinds).  On a sharded world every rank calls this with
+ * the same mask right after a halo exchange (the records inter-robot factors freeze with / thaw against
+ * include the ghosts' — they have to be the owners' current ones). */
 int mgx_set_enabled(mgx_world *w, uint32_t kind_mask);
 int mgx_set_antenna(mgx_world *w, int32_t robot, int32_t active);
 int mgx_set_idle(mgx_world *w, int32_t robot, int32_t idle);

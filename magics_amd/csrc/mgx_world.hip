@@ -1068,8 +1068,8 @@ static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_ma
             HIP_TRY(launch_thaw_ir(w->d, w->ir_gate.p, w->stream));
         HIP_TRY(launch_robot_sweep(w->d, 0, w->d.R_local, ext_mask, int_mask, n_int, out, hints, w->stream));
         if (w->ir_thaw_active && writes_snap) {  // once every robot has run an internal variable sweep, every owner has delivered
-            bool all_take_part = true;
-            for (const Robot &rb : w->robots) all_take_part = all_take_part && (rb.ghost || rb.removed || !rb.idle);
+            bool all_take_part = true;  // ghosts count: their owners' flags are kept here too, and their records arrive by exchange
+            for (const Robot &rb : w->robots) all_take_part = all_take_part && (rb.removed || !rb.idle);
             if (all_take_part) {
                 w->ir_thaw_active = false;
                 w->d.ir_frozen_snap = nullptr; w->d.ir_frozen_epoch = nullptr; w->d.ir_thaw_epoch = nullptr;
@@ -1361,10 +1361,6 @@ int mgx_set_enabled(mgx_world *w, uint32_t kind_mask) {
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (kind_mask & ~15u) return fail(MGX_ERR_INVALID, "unknown factor kind bits 0x%x", kind_mask);
     const uint32_t on = kind_mask & ~w->p.enable_mask, off = w->p.enable_mask & ~kind_mask;
-    bool has_ghosts = false;
-    for (const Robot &rb : w->robots) has_ghosts = has_ghosts || rb.ghost;
-    if (((on & 2u) & w->stale_kinds) && has_ghosts)
-        return fail(MGX_ERR_STATE, "re-enabling inter-robot factors after sweeps ran without them is not supported on sharded worlds");
     if (kind_mask == w->p.enable_mask) return MGX_OK;
     flush_counts(w);  // what was logged so far was sent under the old flags
     // Internal kinds (dynamic, obstacle, tracking): a factor switched off keeps the inbox it has now and

@@ -295,6 +295,13 @@ class ShardedWorld:
         if self.plan.owner[robot] == self.plan.rank:
             self.world.change_prior(self.lid[robot], var_ix, mean)
 
+    def set_enabled(self, mask):
+        """change_factor_enabled on every rank (collective): an exchange first, so that the ghosts' records the
+        inter-robot factors freeze with / thaw against are their owners' current ones."""
+        if not self.direct:
+            self.exchange()
+        self.world.set_enabled(mask)
+
     def read_beliefs(self):
         """(global robot ids of the local robots, eta, lam, means) of this rank."""
         eta, lam, mu = self.world.read_beliefs()
@@ -450,6 +457,12 @@ class LocalCluster:
     def remove_robot(self, robot):
         for sw in self.ranks:
             sw.world.remove_robot(robot)
+
+    def set_enabled(self, mask):
+        if len(self.ranks) > 1:
+            self._exchange()
+        for sw in self.ranks:
+            sw.world.set_enabled(mask)
 
     def connections(self, robot):
         outs = [sw.world.connections(robot) for sw in self.ranks]

@@ -202,3 +202,22 @@ def test_sharded_topology_with_comms_failures_and_initial_connections():
     for tick in range(80):
         assert dc.tick() == dr.tick(), tick
     assert_identical(cluster, ref, what="2 ranks, comms failures, initial connections")
+
+
+def test_sharded_world_switches_factor_kinds():
+    """change_factor_enabled on a sharded world (all ranks together, after an exchange): inter-robot factors
+    go off and come back across rank boundaries, with schedules that run external iterations before the
+    owners' next internal sweep, next to obstacle factors switched the same way."""
+    sc = S.grid_scenario(36, 10, interrobot=True, pitch=2.2, comm_radius=5.0)
+    cluster = sharded.LocalCluster(sc, 3, World)
+    assert any(sw.plan.ghosts for sw in cluster.ranks)
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    script = [(7, [3] * 4), (5, [3] * 3), (5, [1, 3, 3]), (7, [2, 2, 3, 3]), (3, [3] * 3), (7, [2, 3, 3]), (7, [3] * 3)]
+    for t, (mask, steps) in enumerate(script):
+        for w in (cluster, ref):
+            w.set_enabled(mask)
+            if t == 3:
+                w.change_prior(7, 9, np.array([0.3, -0.2, 1.0, 0.5]))
+            w.iterate(steps)
+        assert_identical(cluster, ref, what=f"sharded kind switching, step {t} (mask {mask})")
