@@ -506,6 +506,21 @@ def main():
             res = run_direct_children(a, rank, local_rank, world_size, role="rccl-child", port_shift=41)
             if rank == 0 and isinstance(line.get("secondary"), dict):
                 line["secondary"]["rccl_in_engine"] = res
+        # the three transports carry the same exchange; the headline of the secondary block is the fastest one that
+        # ran (the host-driven collective pays ~70 us of Python per external iteration, the in-engine ones do not)
+        if rank == 0 and isinstance(line.get("secondary"), dict) and "value" in line["secondary"]:
+            sec = line["secondary"]
+            sec["transport"] = "collective (torch.distributed all_to_all_single, host-driven)"
+            sec["by_transport"] = {"collective": sec["value"]}
+            for key, label in (("direct_exchange", "direct (peer-mapped stores, in-engine)"), ("rccl_in_engine", "RCCL grouped send/recv, in-engine")):
+                r = sec.get(key)
+                if isinstance(r, dict) and isinstance(r.get("value"), (int, float)):
+                    sec["by_transport"][key] = r["value"]
+                    if r["value"] > sec["value"]:
+                        sec["value"], sec["ms_per_step"], sec["transport"] = r["value"], r.get("ms_per_step"), label
+                        if isinstance(r.get("roofline"), dict):
+                            sec["roofline"] = dict(sec.get("roofline", {}), **r["roofline"])
+                            sec["roofline"]["avg_launch_us"] = None  # measured for the collective run only
 
     # ---- CPU baseline: rank 0, N = 1 only ---------------------------------------------------------
     if rank == 0 and not multi and not a.no_cpu_baseline:
