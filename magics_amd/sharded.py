@@ -67,7 +67,12 @@ class ShardPlan:
     def __init__(self, sc, rank, world_size, owner=None):
         self.rank, self.world_size = rank, world_size
         n = len(sc["robots"])
-        self.owner = np.asarray(owner) if owner is not None else partition_strips(sc["positions"], world_size)
+        if owner is not None:
+            self.owner = np.asarray(owner)
+        elif n:
+            self.owner = partition_strips(sc["positions"], world_size)
+        else:
+            self.owner = np.zeros(0, dtype=np.int64)  # an empty world: robots join later (ShardedWorld.add_robot)
         assert len(self.owner) == n
         self.local = [r for r in range(n) if self.owner[r] == rank]
         ghosts, send = set(), [set() for _ in range(world_size)]
@@ -83,7 +88,7 @@ class ShardPlan:
         self.ghosts = sorted(ghosts)
         self.send_lists = [sorted(s) for s in send]
         self.recv_lists = [[g for g in self.ghosts if self.owner[g] == p] for p in range(world_size)]
-        self.K = sc["K"]
+        self.K = sc.get("K")
 
 
 class ShardedWorld:
@@ -135,7 +140,7 @@ class ShardedWorld:
         w, plan = self.world, self.plan
         if sc.get("env") is not None:
             w.set_environment(sc["env"])
-        else:
+        elif sc.get("sdf") is not None:
             w.set_sdf(sc["sdf"]["rgb"], sc["sdf"]["world_w"], sc["sdf"]["world_h"])
         self.lid = {}
         for g, rb in enumerate(sc["robots"]):
@@ -147,11 +152,35 @@ class ShardedWorld:
             w.ir_connect(a, b, n0)  # bookkeeping on every rank; device edges only where b is local
         self._make = tensor_factory or _torch_tensor_factory
         self.send_buf = self.recv_buf = None
+        self.send_counts = self.recv_counts = [0] * plan.world_size
         self.direct = False
         self.replan()
 
+    def add_robot(self, mean0, prior_diag, dt, radius, path=None, owner=None):
+        """A robot joins a world that follows its topology (a formation spawns): every rank calls this with the
+        same arguments; the robot is real on its owner's rank (default: round robin) and a ghost everywhere else."""
+        assert self.dynamic
+        plan = self.plan
+        g = len(plan.owner)
+        owner = g % plan.world_size if owner is None else int(owner)
+        local = owner == plan.rank
+        rid = self.world.add_robot(mean0, prior_diag, dt, radius, path=path if local else None, order_key=g, ghost=not local)
+        assert rid == g
+        plan.owner = np.append(plan.owner, owner)
+        if local:
+            plan.local.append(g)
+        plan.K = np.asarray(mean0).shape[0]
+        self.lid[g] = g
+        self.replan()
+        return g
+
+    def set_environment(self, env):
+        self.world.set_environment(env)
+
     def replan(self):
         """Exchange lists for the connections now held (same result on both ends of every exchange)."""
+        if self.plan.K is None:
+            return
         plan, words = self.plan, self.world.halo_words(self.plan.K)
         sc_, rc_ = self.world.halo_plan_from_connections(plan.owner, plan.rank, plan.world_size)
         self.send_counts, self.recv_counts = [c * words for c in sc_], [c * words for c in rc_]
@@ -389,7 +418,7 @@ class LocalCluster:
         assert not (direct and dynamic)
         self.ranks = [ShardedWorld(sc, r, world_size, world_factory, comm=None, owner=owner,
                                    tensor_factory=tensor_factory, dynamic=dynamic) for r in range(world_size)]
-        self.n_robots, self.K = len(sc["robots"]), sc["K"]
+        self.n_robots, self.K = len(sc["robots"]), sc.get("K")
         if direct and world_size > 1:
             infos = {sw.plan.rank: sw.direct_setup(export_ipc=False) for sw in self.ranks}
             for sw in self.ranks:
@@ -426,6 +455,21 @@ class LocalCluster:
                     self._exchange()
             for sw in self.ranks:
                 sw.sweep_segment(ext, n_int, next_ext=k + 1 < len(segs) and segs[k + 1][0])
+
+    # -- what a scenario runner needs on top (magics_amd/sim.py on a dynamic cluster) --------------------------
+    def set_environment(self, env):
+        for sw in self.ranks:
+            sw.set_environment(env)
+
+    def add_robot(self, mean0, prior_diag, dt, radius, path=None, owner=None):
+        ids = [sw.add_robot(mean0, prior_diag, dt, radius, path=path, owner=owner) for sw in self.ranks]
+        assert all(i == ids[0] for i in ids)
+        self.n_robots, self.K = ids[0] + 1, np.asarray(mean0).shape[0]
+        return ids[0]
+
+    def tick(self, robots, waypoints_xy, time_scale, what, max_speed, delta_t, steps):
+        self.update_priors(robots, waypoints_xy, time_scale, what, max_speed, delta_t)
+        self.iterate(steps)
 
     # -- per-tick calls of a driver, over global robot ids (dynamic clusters) ------------------------------
     def update_topology(self, positions_all, radius, next_number, method=hostlib.NEIGHBOURS_AUTO):

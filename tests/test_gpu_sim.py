@@ -101,3 +101,24 @@ def test_every_local_planning_scenario_of_the_reference(name):
     assert np.array_equal(a.translation, b.translation) and a.events == b.events
     for x, y in zip(a.w.read_beliefs(), b.w.read_beliefs()):
         assert np.array_equal(x, y)
+
+
+def test_scenario_on_a_sharded_world():
+    """The scenario runner on a world sharded over three ranks that follows its topology: formations spawn robots
+    over time (each joins as a real robot on its owner's rank and as a ghost on the others), connections come and
+    go across rank boundaries, robots finish and despawn — same trajectories and beliefs as the single-world oracle."""
+    from magics_amd import sharded
+    sc = _scenario("Junction Twoway")
+    params = config.world_params(sc["config"])
+    cluster = sharded.LocalCluster(dict(params=params, robots=[], ir=[], K=None), 3, World, dynamic=True)
+    a, b = sim.Simulation(sc, cluster), sim.Simulation(sc, oracle.OracleWorld(params))
+    for t in range(130):
+        a.tick()
+        b.tick()
+        if t % 10 == 9:
+            assert len(a.robots) == len(b.robots)
+            assert np.array_equal(a.translation, b.translation), t
+            for x, y in zip(a.w.read_beliefs(), b.w.read_beliefs()):
+                assert np.array_equal(x, y), t
+    assert a.events == b.events and len(a.robots) >= 20
+    assert len({sw.plan.owner[r["id"]] for sw in cluster.ranks for r in a.robots}) == 3   # robots live on all three ranks
