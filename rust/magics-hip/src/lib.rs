@@ -52,12 +52,11 @@ impl World {
         check(unsafe { sys::mgx_update_topology(self.raw, translations.as_ptr().cast(), radius, 0, robot_number, stats.as_mut_ptr()) })?;
         Ok((stats[0], stats[1]))
     }
-    /// `update_failed_comms` (robot.rs:1593-1601): the Bernoulli draws stay with the caller's PRNG
     /// `FactorGraph::change_factor_enabled` for every graph (factorgraph.rs:1529-1539)
     pub fn change_factor_enabled(&self, kind_mask: u32) -> Result<(), MgxError> {
         check(unsafe { sys::mgx_set_enabled(self.raw, kind_mask) })
     }
-
+    /// `update_failed_comms` (robot.rs:1593-1601): the Bernoulli draws stay with the caller's PRNG
     pub fn set_antennas(&self, robots: &[i32], active: &[u8]) -> Result<(), MgxError> {
         assert_eq!(robots.len(), active.len());
         check(unsafe { sys::mgx_set_antennas(self.raw, robots.len() as u32, robots.as_ptr(), active.as_ptr()) })
@@ -96,7 +95,19 @@ impl World {
     pub fn iterate(&self, steps: &[u8]) -> Result<(), MgxError> {
         check(unsafe { sys::mgx_iterate(self.raw, steps.as_ptr(), steps.len() as u32) })
     }
-    /// `update_prior_of_horizon_state` + `update_prior_of_current_state_v3` batched (robot.rs:2182-2338)
+    /// One FixedUpdate of the planner chain (robot.rs:86-103): `update_prior_of_horizon_state` +
+    /// `update_prior_of_current_state_v3` for the listed robots, then `iterate_gbp_v2` over `steps`.
+    /// `what[i]`: bit 0 = horizon prior, bit 1 = current prior.
+    #[allow(clippy::too_many_arguments)]
+    pub fn tick(&self, robots: &[i32], waypoints_xy: &[[f64; 2]], time_scale: &[f64], what: &[u8],
+                max_speed: f64, delta_t: f64, steps: &[u8]) -> Result<(), MgxError> {
+        assert!(robots.len() == waypoints_xy.len() && robots.len() == time_scale.len() && robots.len() == what.len());
+        check(unsafe {
+            sys::mgx_tick(self.raw, robots.len() as u32, robots.as_ptr(), waypoints_xy.as_ptr().cast(), time_scale.as_ptr(),
+                          what.as_ptr(), max_speed, delta_t, steps.as_ptr(), steps.len() as u32)
+        })
+    }
+    /// single prior changes batched (`FactorGraph::change_prior_of_variable`, factorgraph.rs:494-528)
     pub fn change_priors(&self, robots: &[i32], vars: &[u32], means: &[[f64; 4]]) -> Result<(), MgxError> {
         assert!(robots.len() == vars.len() && vars.len() == means.len());
         check(unsafe { sys::mgx_change_priors(self.raw, robots.len() as u32, robots.as_ptr(), vars.as_ptr(), means.as_ptr().cast()) })
