@@ -477,8 +477,7 @@ def main():
             for _ in range(n_dyn):
                 pos = base + rng.normal(0, 0.15, size=base.shape).astype(np.float32)
                 nxt, c, d = wd.update_topology(pos, 8.0, nxt)
-                wd.update_priors(**tk3)
-                wd.iterate(sc3["steps"])
+                wd.tick(steps=sc3["steps"], **tk3)
                 made, gone = made + c, gone + d
             wd.synchronize()
             line["dynamic_tick"] = {"value": round(n_dyn / (time.perf_counter() - t0), 1), "unit": "driver ticks/s per GPU",
