@@ -240,9 +240,11 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #pragma unroll
     for (int c = 0; c < SNAP_W; c++) pf_rec[c] = 0.0;
     uint8_t pf_gate = 0;
+    int pf_dst = 0;
     if (HAS_IR && tid < ne) pf_gate = w.ir_gate[ie0 + tid];
     if (do_extf && tid < ne) {
         pf_er = w.ir_rec[ie0 + tid];
+        pf_dst = pf_er.dst;
         ld_soa4(w.ir_bmu, w.NI, ie0 + tid, pf_bmu);
     }
     // per-variable words (K <= 64 < threads: one pass)
@@ -685,7 +687,93 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         }
     };
 
-    bool dyn_prefired = false;  // the DYN wave already ran the dynamic messages of internal iteration 0
+    // Unary factors of an internal factor sweep, UV wave: obstacle factors (four lanes each when they fit) and
+    // tracking factors.  Reads the snapshot means and delivery counts, writes its own message columns.
+    // skip: kinds whose sweep k_thaw has already computed (first sweep after mgx_set_enabled only).
+    const SdfView sdf = make_sdf_view(w.sdf, w.sdf_w, w.sdf_h, w.world_w, w.world_h);
+    auto unary_messages = [&](uint32_t skip) __attribute__((always_inline)) {
+        if (obs_rows) {
+            // four lanes per obstacle factor: lane q samples tap q and writes row q of the message
+            if (role == ROLE_UV && lane < 4 * (K - 2) && (w.enable & 4u) && !(skip & 4u)) {
+                const int j = lane >> 2, q = lane & 3, var = j + 1, col = n_dyn + j;
+                double x0[4];
+                const bool pres = s_epoch[var] > 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) x0[c] = pres ? s_snap[(20 + c) * K + var] : 0.0;
+                const long long idx = obstacle_tap(sdf, x0[0], x0[1], w.obs_delta, q);
+                const double hq = (idx >= 0) ? sdf_value(w.sdf[idx]) : 0.0;
+                double h[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) h[t] = __shfl(hq, (lane & ~3) + t, 64);
+                double eta_q, lam_q[4];
+                obstacle_message_row(h, w.obs_delta, w.inv_s2_obs, x0, q, eta_q, lam_q);
+                s_fv[q * E1 + col] = eta_q;
+#pragma unroll
+                for (int c = 0; c < 4; c++) s_fv[(4 + q * 4 + c) * E1 + col] = lam_q[c];
+            }
+        } else if (is_obs && (w.enable & 4u) && !(skip & 4u)) {
+            double x0[4], oe[4], ol[16];
+            const bool pres = s_epoch[uvar] > 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) x0[c] = pres ? s_snap[(20 + c) * K + uvar] : 0.0;
+            long long idx[4];
+            obstacle_taps(sdf, x0[0], x0[1], w.obs_delta, idx);
+            double h[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) h[q] = (idx[q] >= 0) ? sdf_value(w.sdf[idx[q]]) : 0.0;
+            obstacle_message(h, w.obs_delta, w.inv_s2_obs, x0, oe, ol);
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_fv[c * E1 + uedge] = oe[c];
+#pragma unroll
+            for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + uedge] = ol[c];
+        }
+        if (is_trk && (w.enable & 8u) && itf >= 10 && !(skip & 8u)) {  // factorgraph.rs:701
+            double x0[4], oe[4], ol[16];
+#pragma unroll
+            for (int c = 0; c < 4; c++) x0[c] = s_snap[(20 + c) * K + uvar];
+            const int p0 = w.path_ptr[r], np = w.path_ptr[r + 1] - p0;
+            if (!tracking_message(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, trk_rec,
+                                  trk_lp, trk_lv, oe, ol)) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) oe[c] = 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; c++) ol[c] = 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_fv[c * E1 + uedge] = oe[c];
+#pragma unroll
+            for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + uedge] = ol[c];
+        }
+        // horizons beyond 33 variables: tracking factors K-2+64 .. 2(K-2)-1 have no lane of their own; lanes
+        // 0 .. of the UV wave take them on, with their state in HBM (BIG instantiations only)
+        if (BIG && role == ROLE_UV && lane + 64 >= K - 2 && lane + 64 < 2 * (K - 2) && (w.enable & 8u) && itf >= 10 &&
+            !(skip & 8u)) {
+            const int j2 = lane + 64 - (K - 2), var2 = j2 + 1, col2 = n_dyn + (K - 2) + j2, item2 = r * (K - 2) + j2;
+            double x0[4], oe[4], ol[16];
+#pragma unroll
+            for (int c = 0; c < 4; c++) x0[c] = s_snap[(20 + c) * K + var2];
+            int rec2 = w.trk_record[item2];
+            float lp2[2] = {w.trk_last_pos[item2], w.trk_last_pos[(size_t)w.NT + item2]};
+            double lv2 = w.trk_last_val[item2];
+            const int p0 = w.path_ptr[r], np = w.path_ptr[r + 1] - p0;
+            if (!tracking_message(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, rec2, lp2, lv2, oe, ol)) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) oe[c] = 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; c++) ol[c] = 0.0;
+            }
+            w.trk_record[item2] = rec2;
+            w.trk_last_pos[item2] = lp2[0];
+            w.trk_last_pos[(size_t)w.NT + item2] = lp2[1];
+            w.trk_last_val[item2] = lv2;
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_fv[c * E1 + col2] = oe[c];
+#pragma unroll
+            for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + col2] = ol[c];
+        }
+    };
+
+    bool prefired = false;  // both waves already ran the factor sweep of internal iteration 0
     STAMP(t_extf);
     // ======================= external variable sweep ==========================================
     if (ext_mask & PH_EXT_VARIABLE) {
@@ -698,31 +786,39 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         // sweeps produce (a dynamic factor reads the snapshot of the last INTERNAL variable sweep and
         // its own previous messages): the DYN wave computes its messages now, next to the UV wave's
         // mean / covariance of the external variable sweep (one 4x4 inverse per variable either way).
-        if (radio && role == ROLE_DYN && is_dyn && (w.enable & 1u) && !(skip0 & 1u) && n_int > 0 && !idle && (int_mask & PH_INT_FACTOR)) {
-            dynamic_messages();
-            dyn_prefired = true;
-        }
+        // The unary factors do not either (they linearise at the means of the last INTERNAL sweep): the UV wave
+        // runs them right after its finish instead of idling until the DYN wave is done.
+        prefired = radio && n_int > 0 && !idle && (int_mask & PH_INT_FACTOR) && skip0 == 0u;  // same for the whole workgroup
+        if (prefired && is_dyn && (w.enable & 1u)) dynamic_messages();
         if (radio && is_var) variable_finish(s_sum, false);
+        if (prefired) unary_messages(0u);
         __syncthreads();
         if (radio && ir_on) {
             // responses to the foreign factors attached to our variables, routed to their inbox
             // (robot.rs:1842-1858): only the mean of that inbox entry is ever used (it sets the
-            // linearisation point; eta / lam of the target side never reach the kept message)
+            // linearisation point; eta / lam of the target side never reach the kept message).
+            // Plain stores of LDS values: nothing in this launch waits for them (the means are next
+            // written after the barrier that ends the coming factor sweep / by nobody).
             for (int j = tid; j < ne; j += SWEEP_BLOCK) {
                 const int e = ie0 + j;
-                if (!w.ir_gate[e]) continue;  // the owner cannot receive
-                const int i = w.ir_rec[e].dst & 0xffff;
+                int dst;
+                if (j == tid && do_extf) {  // gate and constants of the thread's first edge are in registers
+                    if (!pf_gate) continue;
+                    dst = pf_dst;
+                } else {
+                    if (!w.ir_gate[e]) continue;  // the owner cannot receive
+                    dst = w.ir_rec[e].dst;
+                }
+                const int i = dst & 0xffff;
 #pragma unroll
                 for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = s_mu[c * K + i] - 0.0;
             }
         }
-        __syncthreads();
     }
 
     STAMP(t_extv);
     // ======================= internal iterations ==============================================
     {
-        const SdfView sdf = make_sdf_view(w.sdf, w.sdf_w, w.sdf_h, w.world_w, w.world_h);
 #ifdef MGX_STAMPS
         unsigned long long c_f = 0, c_fb = 0, c_v = 0, c_vb = 0;
         const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
@@ -731,91 +827,15 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         bool pending = false;  // the last internal sums still await their finish (mean, covariance)
         for (int it = 0; it < n_int && !idle; it++) {
             STAMP(t0);
-            if (int_mask & PH_INT_FACTOR) {
-                if (is_dyn && (w.enable & 1u) && !(it == 0 && (dyn_prefired || (skip0 & 1u)))) dynamic_messages();
+            if ((int_mask & PH_INT_FACTOR) && it == 0 && prefired) {
+                itf += 1;  // this sweep ran next to the external variable sweep, in front of that block's last barrier
+            } else if (int_mask & PH_INT_FACTOR) {
+                if (is_dyn && (w.enable & 1u) && !(it == 0 && (skip0 & 1u))) dynamic_messages();
                 // UV wave: first the belief of the previous sweep (mean, covariance) that the unary
                 // factors linearise at — same wave, so its LDS writes precede their LDS reads
                 if (pending && is_var) variable_finish(s_snap, true);
                 pending = false;
-                if (obs_rows) {
-                    // four lanes per obstacle factor: lane q samples tap q and writes row q of the message
-                    if (role == ROLE_UV && lane < 4 * (K - 2) && (w.enable & 4u) && !(it == 0 && (skip0 & 4u))) {
-                        const int j = lane >> 2, q = lane & 3, var = j + 1, col = n_dyn + j;
-                        double x0[4];
-                        const bool pres = s_epoch[var] > 0;
-#pragma unroll
-                        for (int c = 0; c < 4; c++) x0[c] = pres ? s_snap[(20 + c) * K + var] : 0.0;
-                        const long long idx = obstacle_tap(sdf, x0[0], x0[1], w.obs_delta, q);
-                        const double hq = (idx >= 0) ? sdf_value(w.sdf[idx]) : 0.0;
-                        double h[4];
-#pragma unroll
-                        for (int t = 0; t < 4; t++) h[t] = __shfl(hq, (lane & ~3) + t, 64);
-                        double eta_q, lam_q[4];
-                        obstacle_message_row(h, w.obs_delta, w.inv_s2_obs, x0, q, eta_q, lam_q);
-                        s_fv[q * E1 + col] = eta_q;
-#pragma unroll
-                        for (int c = 0; c < 4; c++) s_fv[(4 + q * 4 + c) * E1 + col] = lam_q[c];
-                    }
-                } else if (is_obs && (w.enable & 4u) && !(it == 0 && (skip0 & 4u))) {
-                    double x0[4], oe[4], ol[16];
-                    const bool pres = s_epoch[uvar] > 0;
-#pragma unroll
-                    for (int c = 0; c < 4; c++) x0[c] = pres ? s_snap[(20 + c) * K + uvar] : 0.0;
-                    long long idx[4];
-                    obstacle_taps(sdf, x0[0], x0[1], w.obs_delta, idx);
-                    double h[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) h[q] = (idx[q] >= 0) ? sdf_value(w.sdf[idx[q]]) : 0.0;
-                    obstacle_message(h, w.obs_delta, w.inv_s2_obs, x0, oe, ol);
-#pragma unroll
-                    for (int c = 0; c < 4; c++) s_fv[c * E1 + uedge] = oe[c];
-#pragma unroll
-                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + uedge] = ol[c];
-                }
-                if (is_trk && (w.enable & 8u) && itf >= 10 && !(it == 0 && (skip0 & 8u))) {  // factorgraph.rs:701
-                    double x0[4], oe[4], ol[16];
-#pragma unroll
-                    for (int c = 0; c < 4; c++) x0[c] = s_snap[(20 + c) * K + uvar];
-                    const int p0 = w.path_ptr[r], np = w.path_ptr[r + 1] - p0;
-                    if (!tracking_message(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, trk_rec,
-                                          trk_lp, trk_lv, oe, ol)) {
-#pragma unroll
-                        for (int c = 0; c < 4; c++) oe[c] = 0.0;
-#pragma unroll
-                        for (int c = 0; c < 16; c++) ol[c] = 0.0;
-                    }
-#pragma unroll
-                    for (int c = 0; c < 4; c++) s_fv[c * E1 + uedge] = oe[c];
-#pragma unroll
-                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + uedge] = ol[c];
-                }
-                // horizons beyond 33 variables: tracking factors K-2+64 .. 2(K-2)-1 have no lane of their own; lanes
-                // 0 .. of the UV wave take them on, with their state in HBM (BIG instantiations only)
-                if (BIG && role == ROLE_UV && lane + 64 >= K - 2 && lane + 64 < 2 * (K - 2) && (w.enable & 8u) && itf >= 10 &&
-                    !(it == 0 && (skip0 & 8u))) {
-                    const int j2 = lane + 64 - (K - 2), var2 = j2 + 1, col2 = n_dyn + (K - 2) + j2, item2 = r * (K - 2) + j2;
-                    double x0[4], oe[4], ol[16];
-#pragma unroll
-                    for (int c = 0; c < 4; c++) x0[c] = s_snap[(20 + c) * K + var2];
-                    int rec2 = w.trk_record[item2];
-                    float lp2[2] = {w.trk_last_pos[item2], w.trk_last_pos[(size_t)w.NT + item2]};
-                    double lv2 = w.trk_last_val[item2];
-                    const int p0 = w.path_ptr[r], np = w.path_ptr[r + 1] - p0;
-                    if (!tracking_message(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, rec2, lp2, lv2, oe, ol)) {
-#pragma unroll
-                        for (int c = 0; c < 4; c++) oe[c] = 0.0;
-#pragma unroll
-                        for (int c = 0; c < 16; c++) ol[c] = 0.0;
-                    }
-                    w.trk_record[item2] = rec2;
-                    w.trk_last_pos[item2] = lp2[0];
-                    w.trk_last_pos[(size_t)w.NT + item2] = lp2[1];
-                    w.trk_last_val[item2] = lv2;
-#pragma unroll
-                    for (int c = 0; c < 4; c++) s_fv[c * E1 + col2] = oe[c];
-#pragma unroll
-                    for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + col2] = ol[c];
-                }
+                unary_messages(it == 0 ? skip0 : 0u);
                 itf += 1;
                 STAMP(t1);
                 __syncthreads();
