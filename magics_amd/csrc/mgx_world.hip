@@ -171,7 +171,7 @@ struct StageRing {
             if ((e = hipEventSynchronize(ev[i])) != hipSuccess) return e;
             pending[i] = false;
         }
-        if (bytes > cap[i]) {
+        if (bytes > cap[i] || !host[i]) {  // also for a request of zero bytes (a rank that holds ghosts only): callers map the slot
             if (host[i]) (void)hipHostFree(host[i]);
             host[i] = nullptr;
             cap[i] = 0;

@@ -221,3 +221,22 @@ def test_sharded_world_switches_factor_kinds():
                 w.change_prior(7, 9, np.array([0.3, -0.2, 1.0, 0.5]))
             w.iterate(steps)
         assert_identical(cluster, ref, what=f"sharded kind switching, step {t} (mask {mask})")
+
+
+def test_rank_that_owns_no_robot_yet():
+    """A rank of a world that follows its topology may hold ghosts only (formations spawn where they spawn): every
+    per-tick call still works there — zero-sized reads and uploads included — and the run equals the oracle's."""
+    n, K, world_size = 6, 10, 3
+    sc = S.circle_scenario(n, K, circle_radius=9.0, n_internal=10, n_external=10)
+    sc["ir"] = []
+    owner = np.arange(n) % 2   # rank 2 owns nothing
+    cluster = sharded.LocalCluster(sc, world_size, World, owner=owner, dynamic=True)
+    assert len(cluster.ranks[2].plan.local) == 0 and all(len(cluster.ranks[q].plan.local) == 3 for q in (0, 1))
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    dc, dr = _circle_driver(cluster, sc, n, K), _circle_driver(ref, sc, n, K)
+    for tick in range(60):
+        assert dc.tick() == dr.tick(), tick
+        assert np.array_equal(dc.translation, dr.translation), tick
+    assert np.array_equal(cluster.read_variable_means(0), ref.read_variable_means(0))
+    assert_identical(cluster, ref, what="a rank with ghosts only")
