@@ -248,6 +248,13 @@ struct IrConn {  // K-1 factors owner -> other
     // re-used slot is updated once per occurrence in every external sweep — same message, but every
     // update counts as sent / received.
     uint64_t updates_per_sweep = 0;
+    // Factors created while their kind is switched off drop the two messages that would have filled their inbox
+    // (factor/mod.rs:307-310), and FactorNode::update answers inbox KEYS: once enabled, such a factor sends nothing to
+    // a variable that has not delivered to it yet.  The messages themselves are handled on the device (delivery
+    // counts); this is the same knowledge for the counters: per factor, bit 0 = the own variable's key is there,
+    // bit 1 = the foreign variable's; `uses` = the factor's share of updates_per_sweep.  Empty: every key is there.
+    std::vector<uint8_t> keys;
+    std::vector<uint32_t> uses;
     int32_t dev_slot = -1;  // slot of this connection in its target's incoming list on the device (-1: not there)
     bool has_fresh = true;  // some edge still carries `fresh` (created since the device tables were last laid out)
 };
@@ -337,6 +344,7 @@ struct mgx_world {
     // message counters are advanced lazily: launches and prior changes are only logged here
     struct CountEntry { uint8_t ext, in; int n_int, robot; uint64_t times; };
     std::vector<CountEntry> clog;
+    int n_keyless = 0;  // connections whose factors still lack inbox keys (IrConn::keys)
     std::vector<uint32_t> cp_pending;  // [robot * K + variable] change_prior calls not yet counted
     std::vector<uint32_t> cp_dirty;
     DevBuf<unsigned long long> dbg;  // diagnostic builds only
@@ -618,10 +626,29 @@ static void flush_counts(mgx_world *w) {
             const Robot &a = w->robots[(size_t)c.owner], &b = w->robots[(size_t)c.other];
             const bool radio_a = a.antenna && !a.idle, radio_b = b.antenna && !b.idle;
             c.cnt[2] += nIv[(size_t)c.owner] * (uint64_t)(K - 1);            // own variables' responses (internal sweeps)
-            c.cnt[0] += nEf[(size_t)c.owner] * c.updates_per_sweep;          // external factor sweep: one message per key,
-            c.cnt[1] += nEf[(size_t)c.owner] * c.updates_per_sweep;          //   the own and the foreign variable
-            if (radio_b) w->robots[(size_t)c.other].cnt[3] += nEf[(size_t)c.owner] * c.updates_per_sweep;  // delivered (robot.rs:1813-1831)
             if (radio_a) c.cnt[3] += nEv[(size_t)c.other] * (uint64_t)(K - 1);  // the foreign variables' responses (robot.rs:1842-1858)
+            uint64_t to_own = nEf[(size_t)c.owner] * c.updates_per_sweep, to_foreign = to_own;  // external factor sweeps: one message per key
+            if (!c.keys.empty()) {  // some keys are still missing: replay the log in order until they are all there
+                to_own = to_foreign = 0;
+                for (const mgx_world::CountEntry &e : w->clog) {
+                    if (e.robot >= 0 && e.robot != c.owner) continue;  // per-robot launches run internal sweeps only
+                    for (uint64_t rep = 0; rep < e.times; rep++) {
+                        if (e.robot < 0 && (e.ext & 1u) && radio_a)
+                            for (size_t f = 0; f < c.keys.size(); f++) { to_own += c.uses[f] * (c.keys[f] & 1u); to_foreign += c.uses[f] * ((c.keys[f] >> 1) & 1u); }
+                        if (e.robot < 0 && (e.ext & 2u) && radio_a && radio_b)
+                            for (uint8_t &k : c.keys) k |= 2u;
+                        if ((e.in & 2u) && e.n_int > 0 && !a.idle)
+                            for (uint8_t &k : c.keys) k |= 1u;
+                        if ((e.in & 1u) && e.n_int > 1 && !a.idle) (void)0;  // internal factor sweeps do not touch these factors
+                    }
+                }
+                bool all = true;
+                for (uint8_t k : c.keys) all = all && k == 3u;
+                if (all) { c.keys.clear(); c.uses.clear(); w->n_keyless--; }
+            }
+            c.cnt[0] += to_own;
+            c.cnt[1] += to_foreign;
+            if (radio_b) w->robots[(size_t)c.other].cnt[3] += to_foreign;  // delivered (robot.rs:1813-1831)
         }
     // change_prior (variable.rs:203-230): its sends stay in a local counter; the connected factors receive
     if (!w->cp_dirty.empty()) {
@@ -656,7 +683,16 @@ static void log_launch(mgx_world *w, int robot, uint32_t ext_mask, uint32_t int_
     w->clog.push_back({ext, in, in ? n_int : 0, robot, 1});
     if (w->clog.size() > 4096) flush_counts(w);
 }
+static void flush_counts(mgx_world *w);
 static void log_change_prior(mgx_world *w, int robot, int var) {
+    if (w->n_keyless > 0 && var >= 1 && (w->p.enable_mask & 2u)) {  // the delivery fills inbox keys of factors that lack them
+        flush_counts(w);                                           // (what was logged so far saw them missing)
+        for (IrConn &c : w->conns) {
+            if (c.keys.empty()) continue;
+            if (c.owner == robot) c.keys[(size_t)var - 1] |= 1u;
+            if (c.other == robot) c.keys[(size_t)var - 1] |= 2u;
+        }
+    }
     const size_t key = (size_t)robot * (size_t)w->K + (size_t)var;
     if (w->cp_pending.size() <= key) w->cp_pending.resize(w->robots.size() * (size_t)w->K, 0);
     if (w->cp_pending[key]++ == 0) w->cp_dirty.push_back((uint32_t)key);
@@ -1053,6 +1089,15 @@ static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_ma
     if (rc != MGX_OK) return rc;
     if (!w->robots.empty()) w->stale_kinds |= ~w->p.enable_mask & 15u;  // disabled factors miss what this sweep delivers
     const bool writes_snap = (int_mask & PH_INT_VARIABLE) && n_int > 0;
+    if (robot < 0 && ext_mask && w->thaw_kinds && (int_mask & PH_INT_FACTOR) && n_int > 0) {
+        // Factors that come back from being switched off take their first update in front of the sweep launch (k_thaw
+        // writes their messages into the robots' images).  An external variable sweep at the head of the same launch
+        // would sum those new messages where the reference still sums the stale ones — its beliefs are overwritten by
+        // the internal sweep that follows, but the means it hands to the neighbours' factors are not.  So the external
+        // iteration runs as a launch of its own first.
+        rc = sweep(w, -1, ext_mask, 0, 0, 0);
+        return rc != MGX_OK ? rc : sweep(w, -1, 0, int_mask, n_int, hints & ~HINT_IR_DEAD);
+    }
     if (robot < 0) {
         if (w->direct.connected && (ext_mask & PH_EXT_FACTOR)) {  // the inter-robot factors read the ghosts' snapshots
             rc = direct_exchange(w);
@@ -1248,12 +1293,16 @@ static int ir_connect(mgx_world *w, int32_t owner, int32_t other, uint64_t first
     w->robots[(size_t)owner].cnt[2] += (uint64_t)(w->K - 1);
     w->robots[(size_t)other].cnt[3] += (uint64_t)(w->K - 1);
     if (w->p.enable_mask & 2u) { c.cnt[2] = (uint64_t)(w->K - 1); c.cnt[3] = (uint64_t)(w->K - 1); }
+    const bool keyless = !(w->p.enable_mask & 2u);  // created switched off: the two inbox-filling messages are dropped
     for (int &nd : c.node) {  // add_factor, ascending i
         Robot &ow = w->robots[(size_t)owner];
         nd = ow.alloc_node();
         if (ow.slot_uses.size() <= (size_t)nd) ow.slot_uses.resize((size_t)nd + 1, 0);
-        c.updates_per_sweep += ++ow.slot_uses[(size_t)nd];
+        const uint32_t u = ++ow.slot_uses[(size_t)nd];
+        c.updates_per_sweep += u;
+        if (keyless) { c.keys.push_back(0); c.uses.push_back(u); }
     }
+    if (keyless) w->n_keyless++;
     w->conns.push_back(std::move(c));
     w->conns_dirty = true;
     return MGX_OK;
@@ -1277,6 +1326,8 @@ static int ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
     w->conns.erase(std::remove_if(w->conns.begin(), w->conns.end(),
                                   [&](const IrConn &c) { return (c.owner == a && c.other == b) || (c.owner == b && c.other == a); }),
                    w->conns.end());
+    w->n_keyless = 0;
+    for (const IrConn &c : w->conns) w->n_keyless += c.keys.empty() ? 0 : 1;
     w->conns_dirty = true;  // the surviving connections' state stays on the device
     return MGX_OK;
 }
@@ -1315,6 +1366,8 @@ static void ir_disconnect_batch(mgx_world *w, const std::vector<std::pair<int, i
             k++;
         }
     w->conns.resize(k);
+    w->n_keyless = 0;
+    for (const IrConn &c : w->conns) w->n_keyless += c.keys.empty() ? 0 : 1;
     w->conns_dirty = true;
 }
 

@@ -380,6 +380,22 @@ def test_runtime_switching_of_factor_kinds():
         assert np.array_equal(a, b)
 
 
+def test_kinds_switched_back_on_in_front_of_an_external_iteration():
+    # found by tools/soak_switching.py: the first update of factors that come back (k_thaw, in front of the launch) must
+    # not be seen by an external variable sweep at the head of that launch — it would hand the neighbours' factors a
+    # mean computed from the new messages (visible one external iteration later)
+    sc = S.grid_scenario(7, 10, interrobot=True, tracking=True, seed=5001, pitch=2.5, comm_radius=4.5)
+    for off in (15 & ~8, 15 & ~4, 15 & ~1, 5):
+        eng, ref = make_pair(sc)
+        for w in (eng, ref):
+            w.iterate([1, 3, 1, 2, 1, 3, 1, 2])
+            w.set_enabled(off)
+            w.iterate([3, 3])
+            w.set_enabled(15)
+            w.iterate([2, 1, 2, 2])
+        assert_identical(eng, ref, what=f"kinds {15 & ~off} back on, schedule E I E E")
+
+
 @pytest.mark.parametrize("K", [33, 34, 35, 45])
 def test_horizons_beyond_one_message_per_lane(K):
     """K = 35 is what two of the reference's scenarios ask for (target speed x planning horizon = 199:
