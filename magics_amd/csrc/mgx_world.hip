@@ -1326,8 +1326,10 @@ static int ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
     w->conns.erase(std::remove_if(w->conns.begin(), w->conns.end(),
                                   [&](const IrConn &c) { return (c.owner == a && c.other == b) || (c.owner == b && c.other == a); }),
                    w->conns.end());
-    w->n_keyless = 0;
-    for (const IrConn &c : w->conns) w->n_keyless += c.keys.empty() ? 0 : 1;
+    if (w->n_keyless > 0) {  // some of them may just have gone
+        w->n_keyless = 0;
+        for (const IrConn &c : w->conns) w->n_keyless += c.keys.empty() ? 0 : 1;
+    }
     w->conns_dirty = true;  // the surviving connections' state stays on the device
     return MGX_OK;
 }
@@ -1366,8 +1368,10 @@ static void ir_disconnect_batch(mgx_world *w, const std::vector<std::pair<int, i
             k++;
         }
     w->conns.resize(k);
-    w->n_keyless = 0;
-    for (const IrConn &c : w->conns) w->n_keyless += c.keys.empty() ? 0 : 1;
+    if (w->n_keyless > 0) {  // some of them may just have gone
+        w->n_keyless = 0;
+        for (const IrConn &c : w->conns) w->n_keyless += c.keys.empty() ? 0 : 1;
+    }
     w->conns_dirty = true;
 }
 
