@@ -1056,7 +1056,10 @@ __global__ void k_freeze(DevWorld w, uint32_t kinds) {
         w.frozen_flag[(size_t)r * E + e] = present ? 1 : 0;
     } else {
         const int j = (bit == 4u) ? e - n_dyn : e - n_dyn - (K - 2), var = j + 1;
-        const bool present = w.snap_epoch[w.cur][v0 + var] > 0;
+        // a tracking factor is created WITH the variable's first message in its inbox (FG/factorgraph.rs add_internal_edge
+        // hands it variable.prepare_message(), the other kinds get an empty one): before the first delivery its entry is
+        // the record the snapshot starts out with (initial belief, mean = initial mean), not an empty message
+        const bool present = bit == 8u || w.snap_epoch[w.cur][v0 + var] > 0;
         const double *rec = w.snap[w.cur] + (size_t)(v0 + var) * SNAP_W;
         double *dst = fz + 40 * (K - 1) + (bit == 8u ? 4 * (K - 2) : 0) + 4 * j;
         for (int c = 0; c < 4; c++) dst[c] = present ? rec[20 + c] : 0.0;

@@ -396,6 +396,23 @@ def test_kinds_switched_back_on_in_front_of_an_external_iteration():
         assert_identical(eng, ref, what=f"kinds {15 & ~off} back on, schedule E I E E")
 
 
+def test_tracking_switched_off_before_its_first_delivery():
+    # found by tools/soak_switching.py: a tracking factor is created with the variable's first message already in its
+    # inbox (the other kinds start with an empty one), so switched off before the world's first iteration and back on
+    # after its ten-iteration gate has opened, it resumes from the initial mean, not from zero
+    sc = S.grid_scenario(7, 10, interrobot=True, tracking=True, seed=5151, pitch=2.5, comm_radius=4.5)
+    for off in (15 & ~8, 0):
+        eng, ref = make_pair(sc)
+        for w in (eng, ref):
+            w.set_enabled(off)
+            w.iterate([3] * 12)
+            w.set_enabled(15)
+            w.iterate([1])
+        assert_identical(eng, ref, what=f"kinds {15 & ~off} off from the start, back on after the gate")
+        both(eng, ref, lambda w: w.iterate([3, 3]))
+        assert_identical(eng, ref, what="... and two more steps")
+
+
 @pytest.mark.parametrize("K", [33, 34, 35, 45])
 def test_horizons_beyond_one_message_per_lane(K):
     """K = 35 is what two of the reference's scenarios ask for (target speed x planning horizon = 199:

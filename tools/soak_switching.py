@@ -19,10 +19,9 @@ from parity import make_pair  # noqa: E402
 # a factor starts with an empty inbox and the reference sends nothing to the other robot's variable until that
 # variable has answered once; the engine does not keep that key yet) — MGX_SOAK_CONNECT_WHILE_OFF=1 includes them.
 CONNECT_WHILE_OFF = os.environ.get("MGX_SOAK_CONNECT_WHILE_OFF", "0") == "1"
-# Likewise kinds switched off before the world's first iteration (second open item of DESIGN.md §10: tracking factors
-# that were switched off before they ever received anything and come back after their ten-iteration gate has opened take a
-# first update the reference does not) — MGX_SOAK_SWITCH_BEFORE_FIRST_ITERATION=1 includes such scripts.
-SWITCH_FIRST = os.environ.get("MGX_SOAK_SWITCH_BEFORE_FIRST_ITERATION", "0") == "1"
+# Kinds may be switched off before the world's first iteration (MGX_SOAK_SWITCH_BEFORE_FIRST_ITERATION=0 starts every script
+# with one iteration instead: that was the domain while tracking factors frozen before their first delivery were still wrong).
+SWITCH_FIRST = os.environ.get("MGX_SOAK_SWITCH_BEFORE_FIRST_ITERATION", "1") == "1"
 
 
 def identical(eng, ref, what):
