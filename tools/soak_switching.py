@@ -73,6 +73,9 @@ def one(seed, trace=False, skip=(), masks=None, last_steps=None, upto=None):
         else:
             f, desc = (lambda w: w.update_priors(**tick)), "update_priors(all)"
         steps = [int(x) for x in rng.integers(1, 4, size=int(rng.integers(1, 6)))]
+        one_call = desc == "update_priors(all)" and rng.random() < 0.5  # the same as ONE mgx_tick call (prior updates inside the first launch)
+        if one_call:
+            f, desc = (lambda w, steps=steps: w.tick(steps=steps, **tick)), "tick(all)"
         if masks and step in masks:  # experiments: another mask at this step
             mask = masks[step]
             f, desc = (lambda w, m=mask: w.set_enabled(m)), f"set_enabled({mask})*"
@@ -81,7 +84,8 @@ def one(seed, trace=False, skip=(), masks=None, last_steps=None, upto=None):
         for w in (eng, ref):
             if step not in skip:
                 f(w)
-            w.iterate(steps)
+            if not one_call:
+                w.iterate(steps)
         if upto is not None and step == upto:
             try:
                 return "ok" if identical(eng, ref, "experiment") else "diverged"
