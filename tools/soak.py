@@ -1,6 +1,6 @@
 """Soak run of the seeded random scripts of tests/test_gpu_fuzz.py over many more seeds than the test suite holds
 (GPU box, a few minutes): engine vs oracle, beliefs bit-identical after every script.
-usage: python tools/soak.py [seconds]   -> prints progress lines and a one-line summary"""
+usage: python tools/soak.py [seconds] [K,K,...]   -> prints progress lines and a one-line summary"""
 import contextlib
 import io
 import os
@@ -35,7 +35,7 @@ def _finite_domain_only(eng, ref, what=""):
 T.assert_identical = _finite_domain_only
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-KS = [5, 8, 10, 12, 13, 16, 19, 21, 32]
+KS = [int(k) for k in sys.argv[2].split(",")] if len(sys.argv) > 2 else [5, 8, 10, 12, 13, 16, 19, 21, 32]
 t0, runs, seed = time.time(), {"static": 0, "dynamic": 0, "diverged": 0}, 1000
 last = t0
 while time.time() - t0 < budget:
