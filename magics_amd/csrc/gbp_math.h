@@ -319,7 +319,10 @@ MGX_HD bool interrobot_message(const double (&x_lo)[4], const double (&x_hi)[4],
         jl0 = cl * d0; jl1 = cl * d1; jh0 = ch * d0; jh1 = ch * d1;
     }
     // row 0 of J = [jl0 jl1 0 0 | jh0 jh1 0 0]; lam_p = (J0^T / s^2) J0 ; eta_p = (J0^T / s^2) rhs
-    const double jx = ((jl0 * x_lo[0] + jl1 * x_lo[1]) + jh0 * x_hi[0]) + jh1 * x_hi[1];
+    // J x0 (factor/mod.rs:399) is an ndarray mat-vec: each row . x0 goes through numeric_util::unrolled_dot
+    // (ndarray 0.15.6, no BLAS), which for the 8-long rows of a two-variable factor keeps eight partial sums and
+    // adds them pairwise, (p0 + p4) + (p1 + p5) + (p2 + p6) + (p3 + p7): lane 0 of slot 0 with lane 0 of slot 1
+    const double jx = (jl0 * x_lo[0] + jh0 * x_hi[0]) + (jl1 * x_lo[1] + jh1 * x_hi[1]);
     const double rhs = jx + (0.0 - h0);
     const double ja0 = dst_slot ? jh0 : jl0, ja1 = dst_slot ? jh1 : jl1;  // target block
     const double jb0 = dst_slot ? jl0 : jh0, jb1 = dst_slot ? jl1 : jh1;  // marginalised block

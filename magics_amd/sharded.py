@@ -216,7 +216,8 @@ class ShardedWorld:
         robots = np.asarray(robots)
         mine = np.nonzero(self.plan.owner[robots] == self.plan.rank)[0]
         if len(mine):
-            self.world.update_priors(robots=robots[mine].astype(np.int32), waypoints_xy=np.asarray(waypoints_xy)[mine],
+            local_ids = np.array([self.lid[int(g)] for g in robots[mine]], dtype=np.int32)
+            self.world.update_priors(robots=local_ids, waypoints_xy=np.asarray(waypoints_xy)[mine],
                                      time_scale=np.asarray(time_scale)[mine], what=np.asarray(what)[mine], max_speed=max_speed,
                                      delta_t=delta_t)
 
@@ -490,7 +491,8 @@ class LocalCluster:
         for sw in self.ranks:
             mine = np.nonzero(sw.plan.owner[robots] == sw.plan.rank)[0]
             if len(mine):
-                sw.world.update_priors(robots=robots[mine].astype(np.int32), waypoints_xy=np.asarray(waypoints_xy)[mine],
+                local_ids = np.array([sw.lid[int(g)] for g in robots[mine]], dtype=np.int32)  # rank-local ids (equal to the global ones on a dynamic world)
+                sw.world.update_priors(robots=local_ids, waypoints_xy=np.asarray(waypoints_xy)[mine],
                                        time_scale=np.asarray(time_scale)[mine], what=np.asarray(what)[mine], max_speed=max_speed,
                                        delta_t=delta_t)
 

@@ -6,4 +6,4 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
 status); this module is a thin ctypes binding exposing the same ``World`` interface as
 ``magics_amd.World`` so one scenario script can drive either.
 """
-from .binding import OracleWorld, build, lib, schedule, variable_timesteps  # noqa: F401
+from .binding import FLAVOURS, OracleWorld, build, build_flavour, lib, schedule, variable_timesteps  # noqa: F401

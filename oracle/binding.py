@@ -40,6 +40,20 @@ class RobotDesc(C.Structure):
     ]
 
 
+FLAVOURS = ("fma", "lu", "seq", "fma_lu")  # arithmetic variants of the same restatement (gbp_oracle.c header)
+
+
+def build_flavour(flavour):
+    """The oracle with one of the reference's unknowable arithmetic choices swapped (gbp_oracle.c,
+    FLAVOURS): 'fma' fused GEMM steps, 'lu' pivoting 4x4 inverse, 'seq' no unrolled_dot pairing."""
+    assert flavour in FLAVOURS, flavour
+    out = os.path.join(_HERE, f"libgbp_oracle_{flavour}.so")
+    src = os.path.join(_HERE, "gbp_oracle.c")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, os.path.basename(out)], check=True, capture_output=True)
+    return out
+
+
 def build(native=False, out_dir=None):
     """Compile gbp_oracle.c with gcc. ``native=True`` builds a -march=native variant
     (used by bench.py's cpu_baseline on the box it runs on)."""
@@ -50,7 +64,7 @@ def build(native=False, out_dir=None):
                "-fPIC", "-shared", "-o", out, os.path.join(_HERE, "gbp_oracle.c"), "-lm"]
         subprocess.run(cmd, check=True, capture_output=True)
         return out
-    subprocess.run(["make", "-C", _HERE, "libgbp_oracle.so"], check=True, capture_output=True)
+    subprocess.run(["make", "-C", _HERE, "libgbp_oracle.so", "variants"], check=True, capture_output=True)
     return os.path.join(_HERE, "libgbp_oracle.so")
 
 

@@ -178,23 +178,63 @@ typedef struct {
 #define ORC_ERR_INVALID (-1)
 
 /* ---------------------------------------------------------------------------------------
- * small dense helpers: generic loops, k ascending, no contraction (built -ffp-contract=off)
- * as ndarray `dot` on tiny operands.
+ * small dense helpers, as ndarray 0.15.6 (Cargo.lock:4857, `blas` feature off, Cargo.toml:46-47)
+ * evaluates them — third-party code absent from /root/reference, restated from its published
+ * source; built -ffp-contract=off so that nothing contracts unless a flavour asks for it.
+ *
+ *  matvec  Array2.dot(&Array1) = general_mat_vec_mul: one `row.dot(x)` per row, and a dot of two
+ *          contiguous slices is numeric_util::unrolled_dot: eight partial sums p0..p7 over chunks
+ *          of 8, sum = 0 + (p0+p4) + (p1+p5) + (p2+p6) + (p3+p7), then the < 8 leftover products
+ *          added one by one.  Rows of 4 (J^T L rhs, lam_ab lam_bb^-1 eta_b, cov eta, prior lam mu) are
+ *          therefore plain left-to-right sums; the 8-long rows of J x0 (FG/factor/mod.rs:399, dynamic
+ *          and inter-robot factors) are paired (x0 y0 + x4 y4) + (x1 y1 + x5 y5) + ...
+ *  matmul  Array2.dot(&Array2) = matrixmultiply 0.3.8 dgemm (Cargo.lock:4686): every C[i][j] is a
+ *          k-ascending accumulation from 0.  Its x86-64 kernels are chosen at run time; the FMA one
+ *          fuses each step (flavour ORC_GEMM_FMA), the fallback does not (default).
+ *
+ * FLAVOURS (compile-time; tests/test_oracle_variants.py): the reference binary's rounding is
+ * not reproducible here (no Rust toolchain, third-party sources absent), so the tolerance claim of
+ * BASELINE.json is checked against every plausible arithmetic instead of one guess:
+ *   ORC_GEMM_FMA   matmul steps fused (matrixmultiply's FMA kernel on a machine with FMA)
+ *   ORC_INV_LU     4x4 inverse by LU with partial pivoting instead of cofactors (None iff a pivot is 0)
+ *   ORC_DOT_SEQ    every dot product a plain left-to-right sum (no unrolled_dot pairing)
  * --------------------------------------------------------------------------------------- */
 static void matmul(const double *A, const double *B, double *C, int m, int k, int n) {
     for (int i = 0; i < m; i++)
         for (int j = 0; j < n; j++) {
             double s = 0.0;
+#ifdef ORC_GEMM_FMA
+            for (int l = 0; l < k; l++) s = fma(A[i * k + l], B[l * n + j], s);
+#else
             for (int l = 0; l < k; l++) s += A[i * k + l] * B[l * n + j];
+#endif
             C[i * n + j] = s;
         }
 }
-static void matvec(const double *A, const double *x, double *y, int m, int n) {
-    for (int i = 0; i < m; i++) {
-        double s = 0.0;
-        for (int l = 0; l < n; l++) s += A[i * n + l] * x[l];
-        y[i] = s;
+/* ndarray::numeric_util::unrolled_dot */
+static double unrolled_dot(const double *x, const double *y, int n) {
+#ifdef ORC_DOT_SEQ
+    double s = 0.0;
+    for (int l = 0; l < n; l++) s += x[l] * y[l];
+    return s;
+#else
+    double p[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, sum = 0.0;
+    while (n >= 8) {
+        for (int l = 0; l < 8; l++) p[l] = p[l] + x[l] * y[l];
+        x += 8;
+        y += 8;
+        n -= 8;
     }
+    sum = sum + (p[0] + p[4]);
+    sum = sum + (p[1] + p[5]);
+    sum = sum + (p[2] + p[6]);
+    sum = sum + (p[3] + p[7]);
+    for (int l = 0; l < n; l++) sum = sum + x[l] * y[l];
+    return sum;
+#endif
+}
+static void matvec(const double *A, const double *x, double *y, int m, int n) {
+    for (int i = 0; i < m; i++) y[i] = unrolled_dot(A + i * n, x, n);
 }
 
 /* ndarray-inverse 0.1.9 `Inverse::inv` for a 4x4 (Cargo.lock:4870).  Third-party, source absent
@@ -210,6 +250,40 @@ static double det3(const double *r0, const double *r1, const double *r2, int j) 
     double g = r2[c0], h = r2[c1], k = r2[c2];
     return (a * (e * k - f * h) - b * (d * k - f * g)) + c * (d * h - e * g);
 }
+#ifdef ORC_INV_LU
+/* flavour: Gauss-Jordan on [m | I] with partial pivoting; "None" iff a pivot column is all zeros */
+static int inv4(const double *m, double *out) {
+    double a[4][8];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            a[i][j] = m[i * 4 + j];
+            a[i][4 + j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 4; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 4; r++)
+            if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0.0) return 0;
+        if (piv != c)
+            for (int j = 0; j < 8; j++) {
+                double t = a[c][j];
+                a[c][j] = a[piv][j];
+                a[piv][j] = t;
+            }
+        double ip = 1.0 / a[c][c];
+        for (int j = 0; j < 8; j++) a[c][j] *= ip;
+        for (int r = 0; r < 4; r++) {
+            if (r == c) continue;
+            double f = a[r][c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < 8; j++) a[r][j] -= f * a[c][j];
+        }
+    }
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) out[i * 4 + j] = a[i][4 + j];
+    return 1;
+}
+#else
 static int inv4(const double *m, double *out) {
     double cf[4][4];
     for (int i = 0; i < 4; i++) {
@@ -229,6 +303,7 @@ static int inv4(const double *m, double *out) {
         for (int j = 0; j < 4; j++) out[j * 4 + i] = cf[i][j] * id;
     return 1;
 }
+#endif
 int orc_inv4(const double *m, double *out) { return inv4(m, out); }
 
 /* crates/gbp_linalg/src/lib.rs:47-93 */

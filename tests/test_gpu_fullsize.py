@@ -1,0 +1,115 @@
+"""BASELINE.json configs[3] and configs[4] AT THEIR FULL SIZE against the CPU oracle, bit for bit.
+
+configs[3]: 8000 robots x 16 horizon + inter-robot factors, robots sharded 8 ways — the eight
+ranks run inside one process on the one GPU of the box (sharded.LocalCluster: same ghosts, same
+halo plan, same kernels as eight processes; only the transport of the all-to-all-v differs), over
+the collective transport and over the direct (peer-mapped stores) one, one driver tick each, and
+the single-world oracle is the checker (robot.rs:1769-1861, 2182-2338).
+
+configs[4]: 4000 robots x 32 horizon with tracking + inter-robot + obstacle + dynamic factors — on
+the 20 x 20 crossroads of the Junction Twoway environment rasterised on the device (SURVEY §8d
+"Config 5") and on the synthetic grid (7.6 neighbours per robot), two ticks each so that the
+tracking factors are past their ten-sweep gate (factorgraph.rs:701, tracking.rs:197-346).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from magics_amd import World, scenarios as S, sharded
+from parity import assert_identical
+
+pytestmark = pytest.mark.gpu
+
+ORACLE_THREADS = 16
+
+
+# ---- configs[3] -------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def config3():
+    """The scenario and the oracle's beliefs after one tick (computed once for both transports)."""
+    sc = S.grid_scenario(8000, 16, interrobot=True)
+    assert len(sc["robots"]) == 8000 and sc["K"] == 16
+    ref = oracle.OracleWorld(sc["params"], threads=ORACLE_THREADS)
+    S.populate(ref, sc)
+    tick = S.tick_inputs(sc)
+    ref.tick(steps=sc["steps"], **tick)
+    beliefs = ref.read_beliefs()
+    ref.close()
+    return sc, tick, beliefs
+
+
+class _Frozen:
+    """read_beliefs() of an oracle that has already been run and released"""
+
+    def __init__(self, beliefs):
+        self._b = beliefs
+
+    def read_beliefs(self):
+        return self._b
+
+
+def _check_cluster(cluster, sc):
+    owners = cluster.ranks[0].plan.owner
+    assert len(cluster.ranks) == 8 and sorted(np.bincount(owners)) == [1000] * 8
+    assert all(sw.plan.ghosts for sw in cluster.ranks), "every strip has neighbours across its border"
+    n_ext = sum(1 for s in sc["steps"] if s & 2)
+    assert n_ext == 10
+
+
+def test_config3_full_size_sharded_8_ways_collective(config3):
+    sc, tick, beliefs = config3
+    cluster = sharded.LocalCluster(sc, 8, World)
+    _check_cluster(cluster, sc)
+    cluster.tick(steps=sc["steps"], **tick)
+    assert_identical(cluster, _Frozen(beliefs), what="configs[3] 8000 x 16 + ir, 8 ranks, collective transport, 1 tick")
+
+
+def test_config3_full_size_sharded_8_ways_direct(config3):
+    import torch
+    sc, tick, beliefs = config3
+    streams = []
+
+    def make(params):
+        streams.append(torch.cuda.Stream())
+        return World(params, stream=streams[-1].cuda_stream)
+    cluster = sharded.LocalCluster(sc, 8, make, direct=True)
+    _check_cluster(cluster, sc)
+    assert all(sw.direct for sw in cluster.ranks)
+    cluster.tick(steps=sc["steps"], **tick)
+    assert_identical(cluster, _Frozen(beliefs), what="configs[3] 8000 x 16 + ir, 8 ranks, direct transport, 1 tick")
+    for sw in cluster.ranks:
+        assert sw.world.halo_direct_status() == 10  # one exchange per external iteration, none timed out
+
+
+# ---- configs[4] -------------------------------------------------------------------------------------
+def _two_ticks(sc):
+    eng, ref = World(sc["params"]), oracle.OracleWorld(sc["params"], threads=ORACLE_THREADS)
+    assert S.populate(eng, sc) == S.populate(ref, sc)
+    tick = S.tick_inputs(sc)
+    for t in range(2):
+        for w in (eng, ref):
+            w.tick(steps=sc["steps"], **tick)
+        assert_identical(eng, ref, what=f"{sc['name']} tick {t}")
+    return eng, ref
+
+
+def test_config4_full_size_junction_tiles():
+    sc = S.junction_scenario(4000, 32, tiles=20)
+    assert len(sc["robots"]) == 4000 and sc["K"] == 32 and sc["params"]["enable_mask"] == 15
+    assert all(rb["path"] is not None and len(rb["path"]) >= 2 for rb in sc["robots"])
+    assert len(sc["ir"]) > 4000
+    eng, ref = _two_ticks(sc)
+    # the tracking factors did fire: switching them off changes the result
+    sc2 = dict(sc, params=dict(sc["params"], enable_mask=7))
+    off = World(sc2["params"])
+    S.populate(off, sc2)
+    tick = S.tick_inputs(sc2)
+    for _ in range(2):
+        off.tick(steps=sc2["steps"], **tick)
+    assert not np.array_equal(off.read_beliefs()[2], eng.read_beliefs()[2])
+
+
+def test_config4_full_size_grid():
+    sc = S.grid_scenario(4000, 32, interrobot=True, tracking=True)
+    assert len(sc["ir"]) / 4000 > 7.0
+    _two_ticks(sc)
