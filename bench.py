@@ -3,21 +3,27 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is ONE GBP iteration (one schedule step: internal factor + variable sweep and, when the
-workload has inter-robot factors, external factor sweep -> routing -> external variable sweep ->
-routing) over every robot.  Steps are issued the way the reference's driver issues
-them: one `mgx_iterate` call per tick's schedule (10 steps, Junction-Twoway 10/10), inputs already
-resident in HBM, priors frozen.
+A "step" is ONE GBP iteration (one schedule step: internal factor + variable sweep, external factor sweep ->
+routing -> external variable sweep -> routing) over 1000 robots x 16 horizon per GPU.  Steps are
+issued the way the reference's driver issues them: one `mgx_iterate` call per tick's schedule (10 steps,
+Junction-Twoway 10/10), inputs already resident in HBM, priors frozen.
 
-Primary line (`value`): BASELINE.json configs[1] — synthetic 1000 robots x 16 horizon per GPU,
-dynamics + obstacle factors; robots are independent, so at N > 1 ranks are independent shards
-(no data-path collective) and scaling is weak.  `secondary`: configs[2]/[3] — the same robots with
-inter-robot factors (comm radius 8), 1000*N robots sharded N ways with one RCCL all-to-all-v of
-boundary snapshots per external iteration.
+Headline (`value`) — the workload BASELINE.json's north star scales: dynamics + obstacle + INTER-ROBOT factors
+(comm radius 8).  N = 1: configs[2], 1000 robots x 16 on one GPU.  N > 1: configs[3]'s layout, 1000 * N robots
+sharded N ways in (y, x) strips with ONE exchange of boundary snapshot records per external iteration (RCCL
+all-to-all-v over xGMI, or the in-engine transports), weak scaling: `value` = N * steps / time, i.e. iterations
+of 1000 robots' worth of graph per second, the same unit at every N.
+`configs1`: BASELINE configs[1] (the same robots without inter-robot factors; at N > 1 independent shards, no
+exchange), with its own roofline and CPU baseline.
+
+Timing protocol (declared in the line): W warm-up steps, a clock pre-heat of `preheat_ms`, then `repeats`
+repetitions of EXACTLY K steps, each bracketed by barrier + synchronize, MAX over ranks per repetition; `value`
+comes from the MEDIAN repetition (`ms_per_step`), the spread is reported beside it.
 """
 import argparse
 import json
 import os
+import statistics
 import subprocess
 import sys
 import time
@@ -27,22 +33,28 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s peak, ~6.3 achievable)
+# FP64 vector peak: 256 CUs x 4 SIMDs x 32 lanes x 2 (FMA) x 2.4 GHz / 2 (f64 issues at half the f32 rate) = 78.6 TFLOP/s
+# = half the guide's 157.3 TFLOP/s FP32 vector figure; as an issue rate: one f64 VALU wave-instruction per SIMD per 4 clocks
+F64_VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4.0
 SCHEDULE_LEN = 10
+PROFILE_TAG = "r02"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--repeats", type=int, default=15, help="repetitions of the timed K-step block (median reported)")
+    ap.add_argument("--preheat-ms", type=float, default=60.0, help="untimed work in front of the repetitions (clock ramp)")
     ap.add_argument("--robots-per-gpu", type=int, default=1000)
     ap.add_argument("--horizon", type=int, default=16)
-    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-configs1", action="store_true", help="skip the BASELINE configs[1] block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-dynamic", action="store_true", help="N = 1: skip the dynamic_tick measurement")
-    ap.add_argument("--no-direct", action="store_true", help="N > 1: skip the direct-exchange child measurement")
-    ap.add_argument("--secondary-deadline", type=float, default=150.0,
-                    help="N > 1 only: seconds the sharded (collective) phase may take before it is abandoned")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the tick / dynamic_tick / scenario measurements")
+    ap.add_argument("--no-children", action="store_true", help="N > 1: skip the in-engine transports (measured in child processes)")
+    ap.add_argument("--deadline", type=float, default=150.0,
+                    help="N > 1 only: seconds a phase with collectives may take before the run is abandoned (non-zero exit)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--fma", action="store_true", help="use the FMA-contracting build (not the product)")
     ap.add_argument("--role", default="main", choices=["main", "direct-child", "rccl-child"],
@@ -60,28 +72,45 @@ def run_steps(iterate, n, steps_one_tick):
         iterate(steps_one_tick[:rem])
 
 
-def timed(torch, dist, iterate, steps_one_tick, n_steps, n_warm, multi, red_dev="cuda"):
-    """W warm-up steps, then exactly K steps between barrier + synchronize; returns
-    (wall seconds MAX over ranks, device seconds between HIP events on the launch stream)."""
-    run_steps(iterate, n_warm, steps_one_tick)
+def timed(torch, dist, iterate, steps_one_tick, a, multi, red_dev="cuda", sync=None):
+    """The contract's measurement, repeated: W warm-up steps, a pre-heat, then `repeats` x [barrier + synchronize,
+    EXACTLY K steps, barrier + synchronize].  Returns per-repetition (wall seconds MAX over ranks, device seconds
+    between HIP events on the launch stream MAX over ranks)."""
+    sync = sync or torch.cuda.synchronize
+    run_steps(iterate, a.warmup, steps_one_tick)
+    sync()
+    t_end = time.perf_counter() + a.preheat_ms * 1e-3
+    while time.perf_counter() < t_end:  # the same work, untimed: clocks ramp up in the first tens of milliseconds
+        run_steps(iterate, max(a.steps, SCHEDULE_LEN), steps_one_tick)
+        sync()
+    walls, devs = [], []
+    for _ in range(a.repeats):
+        if multi:
+            dist.barrier()
+        sync()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        run_steps(iterate, a.steps, steps_one_tick)
+        ev1.record()
+        if multi:
+            dist.barrier()
+        sync()
+        walls.append(time.perf_counter() - t0)
+        devs.append(ev0.elapsed_time(ev1) * 1e-3)
     if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    run_steps(iterate, n_steps, steps_one_tick)
-    ev1.record()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    dev = ev0.elapsed_time(ev1) * 1e-3
-    if multi:
-        t = torch.tensor([wall, dev], dtype=torch.float64, device=red_dev)
+        t = torch.tensor([walls, devs], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev = float(t[0]), float(t[1])
-    return wall, dev
+        walls, devs = [float(x) for x in t[0]], [float(x) for x in t[1]]
+    return walls, devs
+
+
+def summary(walls, devs, steps, units_per_step=1.0):
+    """median repetition -> throughput; spread of the repetitions beside it"""
+    w, d = statistics.median(walls), statistics.median(devs)
+    return {"value": units_per_step * steps / w, "ms_per_step": w / steps * 1e3, "device_ms_per_step": d / steps * 1e3,
+            "wall_s_median": w, "device_s_median": d,
+            "spread": {"repeats": len(walls), "ms_per_step_min": min(walls) / steps * 1e3, "ms_per_step_max": max(walls) / steps * 1e3}}
 
 
 def cpu_baseline(sc, seconds):
@@ -102,7 +131,7 @@ def cpu_baseline(sc, seconds):
         lib_path = None  # fall back to the prebuilt x86-64-v3 library
     # thread counts tried (the reference runs robots on Bevy's compute pool, a subset of the cores):
     # the fastest one is reported, with the count actually used
-    cands = sorted({1, min(avail, 8), min(avail, 16), min(avail, 32), min(avail, 64), avail})
+    cands = sorted({1, min(avail, 8), min(avail, 16), min(avail, 32), min(avail, 64)})
     per = max(1.0, seconds / len(cands))
     res = {}
     for threads in cands:
@@ -129,21 +158,54 @@ def cpu_baseline(sc, seconds):
     }
 
 
-def measured_traffic(key):
-    """HBM bytes per dispatch from the committed PMC passes (profiles/traffic_r01.json): FETCH_SIZE
-    doubled (gfx950 correction for wide streaming reads) + WRITE_SIZE; None when absent."""
+def profiled(key):
+    """What rocprofv3 measured for this round's build (profiles/traffic_r02.json, written by tools/profile_round.py from
+    separate --pmc passes of THIS command): HBM bytes per dispatch (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
+    correction + WRITE_SIZE) and the SQ instruction counters.  None when the file or the key is absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic_r01.json")) as f:
-            t = json.load(f)[key]
-        return int((2 * t["fetch_kib"] + t["write_kib"]) * 1024)
+        with open(os.path.join(ROOT, "profiles", f"traffic_{PROFILE_TAG}.json")) as f:
+            return json.load(f)[key]
     except Exception:  # noqa: BLE001
         return None
 
 
-def direct_child(a):
-    """One rank of the sharded inter-robot workload with the DIRECT halo exchange (peer-mapped
-    stores over xGMI, include/mgx.h) — run as a child process of each bench rank so that nothing
-    it does can take the main measurement down.  Control plane: gloo; no RCCL in this process."""
+def roofline(kernel, alg_bytes_per_launch, launches, dev_seconds, prof_key, iterations_per_launch):
+    """The contract's roofline object (algorithmic bytes per launch / live launch duration) plus what makes it
+    physical: HBM bytes actually moved per launch (rocprofv3 PMC, from profiles/) and the f64 VALU issue rate."""
+    avg = dev_seconds / launches
+    ach = alg_bytes_per_launch / avg / 1e9
+    out = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+           "algorithmic_bytes_per_launch": alg_bytes_per_launch, "iterations_per_launch": iterations_per_launch,
+           "avg_launch_us": round(avg * 1e6, 3),
+           "note": "contract figure: SURVEY §8d algorithmic bytes (every live message / belief read and written once per "
+                   "sweep) / live launch duration from HIP events on the launch stream.  The robots' graphs stay in LDS across "
+                   "the iterations of a launch, so most of those bytes never cross HBM and frac can exceed 1: it is a "
+                   "work-rate expressed in the survey's byte model, not a bandwidth.  hbm_measured_* and compute below are "
+                   "the physical picture."}
+    p = profiled(prof_key)
+    if p:
+        traffic = int((2 * p["fetch_kib"] + p["write_kib"]) * 1024)
+        out["traffic"] = traffic
+        out["traffic_source"] = p.get("source", f"profiles/{PROFILE_TAG}_*: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes")
+        out["hbm_measured_gbs"] = round(traffic / avg / 1e9, 1)
+        out["hbm_measured_frac"] = round(traffic / avg / 1e9 / HBM_PEAK_GBS, 4)
+        if p.get("valu_wave_instr"):
+            rate = p["valu_wave_instr"] / avg
+            out["compute"] = {"bound": "f64 VALU issue", "valu_wave_instr_per_launch": p["valu_wave_instr"],
+                              "achieved_wave_instr_per_s": round(rate, 1), "peak_wave_instr_per_s": F64_VALU_WAVE_INSTR_PER_S,
+                              "frac": round(rate / F64_VALU_WAVE_INSTR_PER_S, 4), "valu_busy_pct": p.get("valu_busy_pct"),
+                              "note": "SQ_INSTS_VALU per launch (rocprofv3 --pmc, profiles/) / live launch duration against one f64 "
+                                      "VALU wave-instruction per SIMD per 4 clocks (1024 SIMDs x 2.4 GHz): the kernel's real bound"}
+    return out
+
+
+# ---- N > 1: the sharded workload with the exchange INSIDE the engine, one rank per child process ------------------
+def transport_child(a):
+    """One rank of the sharded inter-robot workload with the exchange inside the engine: DIRECT (peer-mapped
+    stores over xGMI + device-side arrival counters, include/mgx.h) or RCCL grouped send / recv enqueued by
+    mgx_iterate.  Runs as a child process of each bench rank so that nothing it does can take the collective
+    measurement down.  Control plane: gloo."""
     import torch
     import torch.distributed as dist
     rank, world_size = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -186,52 +248,24 @@ def direct_child(a):
         if not agree(not err):
             out = {"error": err or "another rank failed to join the RCCL communicator"}
     if not out:
-        steps2 = sc2["steps"]
-        n2, w2 = max(SCHEDULE_LEN, a.steps // 4), max(SCHEDULE_LEN, a.warmup // 4)
-        run_steps(sw.iterate, w2, steps2)
+        def sync():
+            sw.synchronize()  # mgx_synchronize: raises if a wait on the device gave up
         try:
-            if a.role == "direct-child":
-                sw.world.halo_direct_status()  # synchronises; raises if a wait timed out
-            else:
-                sw.synchronize()
+            walls, devs = timed(torch, dist, sw.iterate, sc2["steps"], a, True, red_dev="cpu", sync=sync)
         except Exception as e:  # noqa: BLE001
             err = f"{type(e).__name__}: {e}"
-        if not agree(not err):
-            out = {"error": err or "another rank timed out in the warm-up"}
-    if not out:
-        dist.barrier()
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
-        run_steps(sw.iterate, n2, steps2)
-        ev1.record()
-        torch.cuda.synchronize()
-        dist.barrier()
-        wall = time.perf_counter() - t0
-        t = torch.tensor([wall, ev0.elapsed_time(ev1) * 1e-3], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev = float(t[0]), float(t[1])
-        n_ex = None
-        try:
-            if a.role == "direct-child":
-                n_ex = sw.world.halo_direct_status()
-        except Exception as e:  # noqa: BLE001
-            err = f"{type(e).__name__}: {e}"
+            walls = devs = None
         if not agree(not err):
             out = {"error": err or "another rank timed out"}
         else:
-            D = len(sc2["ir"]) / n_tot
-            bytes2 = S.algorithmic_bytes_per_robot_iter(K, D) * n_loc
-            out = {"value": round(n2 / wall, 2), "unit": f"GBP iterations/s (one iteration over all {n_tot} robots)",
-                   "steps": n2, "ms_per_step": wall / n2 * 1e3, "exchanges": n_ex,
+            res = summary(walls, devs, a.steps, units_per_step=world_size)
+            out = {"value": round(res["value"], 2), "ms_per_step": res["ms_per_step"], "device_ms_per_step": res["device_ms_per_step"],
+                   "spread": res["spread"],
                    "exchange": ("direct: peer-mapped stores into the consumers' receive areas (hipIpc) + device-side arrival "
                                 "counters, one C call per tick, no collective") if a.role == "direct-child" else
                                "RCCL inside the engine: grouped ncclSend / ncclRecv per external iteration on the launch stream, "
                                "one C call per tick",
-                   "ghost_robots_this_rank": len(sw.plan.ghosts),
-                   "roofline": {"bound": "hbm", "achieved": round(bytes2 * n2 / dev / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(bytes2 * n2 / dev / 1e9 / HBM_PEAK_GBS, 4)}}
+                   "ghost_robots_this_rank": len(sw.plan.ghosts)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     dist.barrier()
@@ -240,8 +274,8 @@ def direct_child(a):
     dist.destroy_process_group()
 
 
-def run_direct_children(a, rank, local_rank, world_size, role="direct-child", port_shift=23):
-    """Spawn this rank's direct-exchange child and wait for it (bounded).  Returns the child's JSON
+def run_children(a, rank, local_rank, world_size, role, port_shift):
+    """Spawn this rank's child for an in-engine transport and wait for it (bounded).  Returns the child's JSON
     (rank 0) or a description of what went wrong; never raises."""
     # the children rendezvous among themselves: nothing of the launcher's elastic agent may leak in
     # (with TORCHELASTIC_USE_AGENT_STORE set, rank 0 would not host the store on the new port)
@@ -252,11 +286,12 @@ def run_direct_children(a, rank, local_rank, world_size, role="direct-child", po
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.setdefault("MGX_HALO_TIMEOUT_MS", "2000")
     cmd = [sys.executable, os.path.abspath(__file__), "--role", role, "--gpus", str(world_size), "--steps", str(a.steps),
-           "--warmup", str(a.warmup), "--robots-per-gpu", str(a.robots_per_gpu), "--horizon", str(a.horizon)] + (["--fma"] if a.fma else [])
+           "--warmup", str(a.warmup), "--repeats", str(a.repeats), "--preheat-ms", str(a.preheat_ms),
+           "--robots-per-gpu", str(a.robots_per_gpu), "--horizon", str(a.horizon)] + (["--fma"] if a.fma else [])
     try:
-        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=a.secondary_deadline)
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=a.deadline)
     except subprocess.TimeoutExpired:
-        return {"error": f"{role} did not finish within {a.secondary_deadline} s"}
+        return {"error": f"{role} did not finish within {a.deadline} s"}
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
     if rank != 0:
@@ -272,7 +307,9 @@ def run_direct_children(a, rank, local_rank, world_size, role="direct-child", po
 
 
 class _Deadline:
-    """Ends the process from a timer thread if a phase with collectives overruns (see main)."""
+    """A phase with collectives that overruns ends the process from a timer thread: rank 0 prints what it has (the
+    line without a headline value, marked as failed) and EVERY rank exits non-zero — a stalled collective on a
+    process that has used the GPU must never be reported as success."""
 
     def __init__(self, seconds, rank, line):
         import threading
@@ -286,9 +323,9 @@ class _Deadline:
     def _expire(seconds, rank, line):
         if rank == 0:
             out = dict(line)
-            out["secondary"] = {"error": f"sharded phase did not finish within {seconds} s; skipped"}
+            out["error"] = f"the sharded phase did not finish within {seconds} s: no headline value"
             print(json.dumps(out), flush=True)
-        os._exit(0)
+        os._exit(3)
 
     def cancel(self):
         if self._t is not None:
@@ -317,7 +354,7 @@ def scenario_run(World, name="Junction Twoway", sim_seconds=30.0):
 def main():
     a = parse()
     if a.role in ("direct-child", "rccl-child"):
-        return direct_child(a)
+        return transport_child(a)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -349,117 +386,132 @@ def main():
     from magics_amd import World, scenarios as S, sharded
     stream = torch.cuda.current_stream().cuda_stream
     n_loc, K = a.robots_per_gpu, a.horizon
+    n_tot = n_loc * world_size
+    full_size = (n_loc, K) == (1000, 16)
 
-    # ---- primary: configs[1], dynamics + obstacle factors, ranks are independent shards --------
-    sc = S.grid_scenario(n_loc, K, interrobot=False, seed=805 + rank)
-    w = World(sc["params"], stream=stream, fma=a.fma)
-    S.populate(w, sc)
-    steps = sc["steps"]
-    assert len(steps) == SCHEDULE_LEN
-    wall, dev = timed(torch, dist, w.iterate, steps, a.steps, a.warmup, multi, red_dev)
-    bytes_iter = S.algorithmic_bytes_per_robot_iter(K, 0.0) * n_loc  # per GPU per iteration
-    n_launch = -(-a.steps // SCHEDULE_LEN)
     line = {
         "metric": "GBP iterations/sec (whole node), N robots x K horizon",
-        "value": round(world_size * a.steps / wall, 2),
-        "unit": "GBP iterations/s (one iteration over 1000 robots x 16 horizon per GPU)",
-        "n_gpus": world_size, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": wall / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": None,
+        "unit": f"GBP iterations/s (one iteration = every factor and variable of {n_loc} robots x {K} horizon updated once; "
+                f"{n_tot} robots on {world_size} GPU(s) advance {world_size} such units per step)",
+        "n_gpus": world_size, "steps": a.steps, "warmup": a.warmup, "repeats": a.repeats, "preheat_ms": a.preheat_ms,
+        "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: synthetic {n_loc} robots x {K} horizon per GPU, dynamics + "
-                               "obstacle factors, seed 805, 10-step schedule per launch",
-                   "robots_per_gpu": n_loc, "horizon": K, "robots_total": n_loc * world_size,
-                   "parallelism": f"{world_size} independent shard(s), no collective"},
-        "roofline": {
-            "bound": "hbm", "kernel": "k_robot_sweep",
-            "achieved": round(bytes_iter * a.steps / dev / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(bytes_iter * a.steps / dev / 1e9 / HBM_PEAK_GBS, 4),
-            "traffic": measured_traffic("config2") if (n_loc, K) == (1000, 16) else None,
-            "algorithmic_bytes_per_launch": bytes_iter * SCHEDULE_LEN,
-            "avg_launch_us": round(dev / n_launch * 1e6, 3),
-            "note": "algorithmic bytes = SURVEY §8d model (38 656 B per robot-iteration); the launch keeps each "
-                    "robot's graph in LDS for its 10 iterations, so real HBM traffic is far below it",
-        },
+        "timing": "median of `repeats` repetitions of exactly `steps` steps, each between barrier + synchronize, MAX over ranks "
+                  "per repetition, after `warmup` steps and `preheat_ms` of untimed work",
     }
-    # whole driver ticks: prior updates of the current and horizon state of every robot
-    # (one launch, robot.rs:2182-2338) + the 10-step schedule; includes the host-side argument upload
-    tk = S.tick_inputs(sc)
-    n_ticks = max(10, a.steps // 20)
-    for _ in range(5):
-        w.update_priors(**tk)
-        w.iterate(steps)
-    w.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n_ticks):
-        w.update_priors(**tk)
-        w.iterate(steps)
-    w.synchronize()
-    two_calls = n_ticks / (time.perf_counter() - t0)
-    for _ in range(5):
-        w.tick(steps=steps, **tk)
-    w.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n_ticks):
-        w.tick(steps=steps, **tk)   # mgx_tick: the prior updates ride in the launch that opens the tick
-    w.synchronize()
-    line["tick"] = {"value": round(n_ticks / (time.perf_counter() - t0), 1), "unit": "driver ticks/s per GPU",
-                    "what": "update_prior_of_horizon_state + update_prior_of_current_state_v3 for all robots, then 10 GBP "
-                            "iterations, one mgx_tick call per tick",
-                    "as_two_calls": round(two_calls, 1)}
-    w.synchronize()
 
-    # ---- secondary: configs[2]/[3], + inter-robot factors, robots sharded with halo exchange ------
-    sc2 = None
-    # The sharded workload is the only phase with a collective in it.  Should that collective ever
-    # stall on some node, the primary measurement must still be reported: every rank carries a
-    # deadline for this phase, and on expiry rank 0 prints the line without the secondary figures
-    # and all ranks leave.
-    guard = _Deadline(a.secondary_deadline if multi else 0, rank, line)
-    if not a.no_secondary:
-        # Every rank first builds its shard; the ranks then agree that all of them succeeded BEFORE the
-        # first collective, so a failure on one rank can never leave the others waiting in RCCL.
-        n_tot = n_loc * world_size
-        sw, err = None, ""
-        try:
-            sc2 = S.grid_scenario(n_tot, K, interrobot=True, seed=805)
-            comm = sharded.TorchDistComm(stage_through_host=backend != "nccl") if multi else None
-            sw = sharded.ShardedWorld(sc2, rank, world_size, lambda p: World(p, stream=stream, fma=a.fma), comm=comm)
-            sw.world.sweep(0, 0, 0)  # commit: device arrays built, no phase run
-        except Exception as e:  # noqa: BLE001
-            err = f"{type(e).__name__}: {e}"
-        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=red_dev)
-        if multi:
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok[0]) == 1:
-            steps2 = sc2["steps"]
-            n2, w2 = max(SCHEDULE_LEN, a.steps // 4), max(SCHEDULE_LEN, a.warmup // 4)
-            wall2, dev2 = timed(torch, dist, sw.iterate, steps2, n2, w2, multi, red_dev)
-            D = len(sc2["ir"]) / n_tot
-            bytes2 = S.algorithmic_bytes_per_robot_iter(K, D) * n_loc
-            line["secondary"] = {
-                "value": round(n2 / wall2, 2), "unit": f"GBP iterations/s (one iteration over all {n_tot} robots)",
-                "steps": n2, "ms_per_step": wall2 / n2 * 1e3,
-                "config": {"workload": f"BASELINE configs[2]/[3]: synthetic {n_tot} robots x {K} horizon + inter-robot "
-                                       f"factors (comm radius 8, {D:.2f} neighbours/robot), sharded {world_size} way(s)",
-                           "parallelism": (f"robots sharded over {world_size} GPUs, one RCCL all-to-all-v of boundary "
-                                           "snapshots per external iteration") if multi else "1 GPU, no collective",
-                           "ghost_robots_this_rank": len(sw.plan.ghosts)},
-                "roofline": {"bound": "hbm", "kernel": "k_robot_sweep",
-                             "achieved": round(bytes2 * n2 / dev2 / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(bytes2 * n2 / dev2 / 1e9 / HBM_PEAK_GBS, 4),
-                             "traffic": measured_traffic("config3") if (n_loc, K, world_size) == (1000, 16, 1) else None,
-                             "algorithmic_bytes_per_launch": bytes2,
-                             "avg_launch_us": round(dev2 / (n2 + -(-n2 // SCHEDULE_LEN)) * 1e6, 3)},
-            }
-            sw.synchronize()
-        else:
-            line["secondary"] = {"error": err or "another rank failed to build its shard"}
-            sc2 = None
+    # Every phase below contains collectives at N > 1 (barriers, reductions, the halo exchange): the run carries a
+    # deadline (see _Deadline) that ends it with a non-zero exit code instead of hanging.
+    guard = _Deadline(a.deadline if multi else 0, rank, line)
 
-    # ---- whole ticks with topology churn (N = 1 only): positions jitter every tick, so the comms-range
-    # search finds pairs that cross the radius and the engine creates / deletes their factors
-    if not multi and not a.no_secondary and not a.no_dynamic:
+    # ---- configs[1]: dynamics + obstacle factors, no inter-robot factors; ranks are independent shards ------------
+    sc1 = None
+    if not a.no_configs1:
+        sc1 = S.grid_scenario(n_loc, K, interrobot=False, seed=805 + rank)
+        w1 = World(sc1["params"], stream=stream, fma=a.fma)
+        S.populate(w1, sc1)
+        assert len(sc1["steps"]) == SCHEDULE_LEN
+        walls, devs = timed(torch, dist, w1.iterate, sc1["steps"], a, multi, red_dev)
+        r1 = summary(walls, devs, a.steps, units_per_step=world_size)
+        bytes1 = S.algorithmic_bytes_per_robot_iter(K, 0.0) * n_loc
+        n_launch = -(-a.steps // SCHEDULE_LEN)
+        line["configs1"] = {
+            "value": round(r1["value"], 2), "unit": "GBP iterations/s (same unit as the headline)",
+            "ms_per_step": r1["ms_per_step"], "device_ms_per_step": r1["device_ms_per_step"], "spread": r1["spread"],
+            "config": {"workload": f"BASELINE configs[1]: synthetic {n_loc} robots x {K} horizon per GPU, dynamics + obstacle factors, "
+                                   "seed 805, 10-step schedule = one launch",
+                       "parallelism": f"{world_size} independent shard(s), no exchange (robots do not interact)"},
+            "roofline": roofline("k_robot_sweep<16,0,false>", bytes1 * SCHEDULE_LEN, n_launch, r1["device_s_median"], "config1" if full_size else "",
+                                 SCHEDULE_LEN),
+        }
+        w1.synchronize()
+
+    # ---- headline: + inter-robot factors, robots sharded over the ranks ------------------------------------------------
+    # Every rank first builds its shard; the ranks then agree that all of them succeeded BEFORE the first collective, so
+    # a failure on one rank can never leave the others waiting in RCCL.
+    sw, err, sc2 = None, "", None
+    try:
+        sc2 = S.grid_scenario(n_tot, K, interrobot=True, seed=805)
+        comm = sharded.TorchDistComm(stage_through_host=backend != "nccl") if multi else None
+        sw = sharded.ShardedWorld(sc2, rank, world_size, lambda p: World(p, stream=stream, fma=a.fma), comm=comm)
+        sw.world.sweep(0, 0, 0)  # commit: device arrays built, no phase run
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=red_dev)
+    if multi:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok[0]) != 1:
+        if rank == 0:
+            line["error"] = err or "another rank failed to build its shard"
+            print(json.dumps(line), flush=True)
+        os._exit(3)
+    D = len(sc2["ir"]) / n_tot
+    bytes2 = S.algorithmic_bytes_per_robot_iter(K, D) * n_loc  # per GPU per iteration
+    walls, devs = timed(torch, dist, sw.iterate, sc2["steps"], a, multi, red_dev)
+    sw.iterate(sc2["steps"])
+    resident = sw.world.last_launch_count() == 1  # the engine ran the 10-step schedule as ONE resident launch
+    r2 = summary(walls, devs, a.steps, units_per_step=world_size)
+    by_transport = {("one GPU, no exchange" if not multi else "collective"): round(r2["value"], 2)}
+    transport = "none (one GPU)" if not multi else "collective (torch.distributed all_to_all_single over RCCL, host-driven)"
+    sw.synchronize()
+    guard.cancel()
+    # launches per 10-step tick: ONE when the whole schedule runs as a resident launch (N = 1), else 11 ([I], 9 x [E I], [E])
+    ticks = -(-a.steps // SCHEDULE_LEN)
+    launches = ticks if resident else a.steps + ticks
+    it_per_launch = SCHEDULE_LEN if resident else 1
+    kernel = "k_robot_sweep<16,2,true> (whole schedule resident)" if resident else "k_robot_sweep<16,2,false> (one iteration per launch)"
+    line.update({
+        "value": round(r2["value"], 2), "ms_per_step": r2["ms_per_step"], "device_ms_per_step": r2["device_ms_per_step"],
+        "spread": r2["spread"],
+        "config": {"workload": f"BASELINE configs[{'2' if not multi else '3 layout'}]: synthetic {n_tot} robots x {K} horizon, dynamics + "
+                               f"obstacle + inter-robot factors (comm radius 8, {D:.2f} neighbours/robot), seed 805, 10/10 schedule",
+                   "robots_per_gpu": n_loc, "horizon": K, "robots_total": n_tot,
+                   "parallelism": (f"robots sharded over {world_size} GPUs in (y, x) strips, one exchange of boundary snapshot records "
+                                   "per external iteration") if multi else "1 GPU: the 10-step schedule is ONE resident launch, "
+                                   "neighbouring workgroups hand their snapshot records over inside it" if resident else "1 GPU",
+                   "ghost_robots_this_rank": len(sw.plan.ghosts)},
+        "roofline": roofline(kernel, bytes2 * it_per_launch, launches, r2["device_s_median"],
+                             ("config2_resident" if resident else "config2") if (full_size and not multi) else "", it_per_launch),
+    })
+
+    # ---- the same sharded workload with the exchange inside the engine, isolated in child processes -----------------
+    if multi and not a.no_children:
+        children = {}
+        children["direct"] = run_children(a, rank, local_rank, world_size, "direct-child", 23)
+        if backend == "nccl":  # the in-library RCCL transport needs one GPU per rank
+            children["rccl_in_engine"] = run_children(a, rank, local_rank, world_size, "rccl-child", 41)
+        if rank == 0:
+            line["in_engine_transports"] = children
+            labels = {"direct": "direct (peer-mapped stores over xGMI, in-engine, one C call per tick)",
+                      "rccl_in_engine": "RCCL grouped send / recv enqueued by the engine (one C call per tick)"}
+            for key, r in children.items():
+                if isinstance(r, dict) and isinstance(r.get("value"), (int, float)):
+                    by_transport[key] = r["value"]
+                    if r["value"] > line["value"]:  # the transports carry the same exchange: the headline is the fastest that ran
+                        line["value"], line["ms_per_step"], line["device_ms_per_step"] = r["value"], r["ms_per_step"], r.get("device_ms_per_step")
+                        line["spread"] = r.get("spread")
+                        transport = labels[key]
+                        if r.get("device_ms_per_step"):
+                            dev_s = r["device_ms_per_step"] * 1e-3 * a.steps
+                            line["roofline"] = roofline(kernel, bytes2 * it_per_launch, launches, dev_s, "", it_per_launch)
+    line["transport"], line["by_transport"] = transport, by_transport
+
+    # ---- N = 1 extras: whole driver ticks, topology churn, a reference scenario end to end ----------------------------
+    if not multi and not a.no_extras:
+        w = sw.world
+        tk = S.tick_inputs(sc2)
+        n_ticks = max(20, a.steps // 10)
+        for _ in range(5):
+            w.tick(steps=sc2["steps"], **tk)
+        w.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_ticks):
+            w.tick(steps=sc2["steps"], **tk)   # mgx_tick: the prior updates ride in the launch that opens the tick
+        w.synchronize()
+        line["tick"] = {"value": round(n_ticks / (time.perf_counter() - t0), 1), "unit": "driver ticks/s per GPU",
+                        "what": "update_prior_of_horizon_state + update_prior_of_current_state_v3 for all robots, then the 10/10 "
+                                "schedule (inter-robot workload), one mgx_tick call per tick"}
         try:
             import numpy as np
             sc3 = S.grid_scenario(n_loc, K, interrobot=True, seed=805)
@@ -486,50 +538,20 @@ def main():
                                             "updates + 10 GBP iterations with inter-robot factors"}
         except Exception as e:  # noqa: BLE001
             line["dynamic_tick"] = {"error": f"{type(e).__name__}: {e}"}
-
-    # ---- a reference scenario end to end (N = 1): the front-end of SURVEY §8 f3 ----------------------------
-    if not multi and not a.no_secondary and not a.no_dynamic:
         try:
             line["scenario"] = scenario_run(World)
         except Exception as e:  # noqa: BLE001
             line["scenario"] = {"error": f"{type(e).__name__}: {e}"}
 
-    guard.cancel()
-
-    # ---- the same sharded workload with the direct exchange, isolated in child processes ---------
-    if multi and not a.no_secondary and not a.no_direct:
-        res = run_direct_children(a, rank, local_rank, world_size)
-        if rank == 0 and isinstance(line.get("secondary"), dict):
-            line["secondary"]["direct_exchange"] = res
-        if backend == "nccl":  # the in-library RCCL transport needs one GPU per rank
-            res = run_direct_children(a, rank, local_rank, world_size, role="rccl-child", port_shift=41)
-            if rank == 0 and isinstance(line.get("secondary"), dict):
-                line["secondary"]["rccl_in_engine"] = res
-        # the three transports carry the same exchange; the headline of the secondary block is the fastest one that
-        # ran (the host-driven collective pays ~70 us of Python per external iteration, the in-engine ones do not)
-        if rank == 0 and isinstance(line.get("secondary"), dict) and "value" in line["secondary"]:
-            sec = line["secondary"]
-            sec["transport"] = "collective (torch.distributed all_to_all_single, host-driven)"
-            sec["by_transport"] = {"collective": sec["value"]}
-            for key, label in (("direct_exchange", "direct (peer-mapped stores, in-engine)"), ("rccl_in_engine", "RCCL grouped send/recv, in-engine")):
-                r = sec.get(key)
-                if isinstance(r, dict) and isinstance(r.get("value"), (int, float)):
-                    sec["by_transport"][key] = r["value"]
-                    if r["value"] > sec["value"]:
-                        sec["value"], sec["ms_per_step"], sec["transport"] = r["value"], r.get("ms_per_step"), label
-                        if isinstance(r.get("roofline"), dict):
-                            sec["roofline"] = dict(sec.get("roofline", {}), **r["roofline"])
-                            sec["roofline"]["avg_launch_us"] = None  # measured for the collective run only
-
-    # ---- CPU baseline: rank 0, N = 1 only ---------------------------------------------------------
+    # ---- CPU baseline: rank 0, N = 1 only ---------------------------------------------------------------------------
     if rank == 0 and not multi and not a.no_cpu_baseline:
-        cb = cpu_baseline(sc, a.cpu_seconds)
+        cb = cpu_baseline(sc2, a.cpu_seconds)
         line["cpu_baseline"] = cb
         line["speedup_vs_cpu_baseline"] = round(line["value"] / cb["value"], 1)
-        if sc2 is not None and "value" in line.get("secondary", {}):
-            cb2 = cpu_baseline(sc2, a.cpu_seconds)
-            line["secondary"]["cpu_baseline"] = cb2
-            line["secondary"]["speedup_vs_cpu_baseline"] = round(line["secondary"]["value"] / cb2["value"], 1)
+        if sc1 is not None:
+            cb1 = cpu_baseline(sc1, a.cpu_seconds)
+            line["configs1"]["cpu_baseline"] = cb1
+            line["configs1"]["speedup_vs_cpu_baseline"] = round(line["configs1"]["value"] / cb1["value"], 1)
 
     if rank == 0:
         print(json.dumps(line))

@@ -173,6 +173,13 @@ int mgx_connections(mgx_world *w, int32_t robot, int32_t *others, uint32_t capac
  * steps[i] & MGX_STEP_EXTERNAL.  Asynchronous on the world's stream. */
 int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n);
 
+/* How the last mgx_iterate / mgx_tick call ran: the number of sweep-kernel launches it enqueued.  A world whose
+ * robots all live on this device, with inter-robot factors enabled and few enough robots for every workgroup
+ * to be resident at once, runs a whole schedule as ONE launch (robots hand their snapshot records to their
+ * neighbours inside it); otherwise one launch per [external iteration] internal* segment.  MGX_PERSISTENT=0 in
+ * the environment forces the latter.  Diagnostic (bench.py prices its roofline per launch with it). */
+int mgx_last_launch_count(mgx_world *w, uint32_t *n_launches);
+
 /* The launch primitive the calls above and below are built on: one device pass per robot
  * that runs the external phases in `external_phases` (bit0 = external factor sweep + routing,
  * bit1 = external variable sweep + routing) and then `n_internal` internal iterations of the

@@ -129,6 +129,16 @@ struct DevWorld {
     int trk_cols;      // 0: tracking factors have never been enabled in this world (their message columns are all zero)
 
     double inv_s2_obs, inv_s2_ir, inv_s2_trk, trk_pad, trk_attr;
+
+    // Resident schedule launches (k_robot_sweep<.., PERSIST>, SegPlan below): one progress word per local robot
+    // ("segments of resident launches completed", monotonic over the life of the device arrays), the robots each
+    // one exchanges snapshot records with (owners of its incoming edges and targets of its outgoing ones, CSR),
+    // and two words for a wait that gave up: [0] device-side "stop waiting", [1] a host-mapped copy the host reads
+    unsigned long long *sweep_flag;   // [R_local]
+    const int32_t *peer_ptr;          // [R_local + 1]
+    const int32_t *peer_idx;          // device robot indices
+    unsigned long long *sweep_abort;  // device memory
+    unsigned long long *sweep_err;    // host-mapped
     // diagnostic builds only (-DMGX_STAMPS, tools/stamps.py): per-workgroup phase cycle sums
     unsigned long long *dbg;
 };
@@ -140,6 +150,20 @@ constexpr uint32_t PH_EXT_FACTOR = 1u;    // external_factor_iteration (+ routin
 constexpr uint32_t PH_EXT_VARIABLE = 2u;  // external_variable_iteration (+ routing)
 constexpr uint32_t PH_INT_FACTOR = 4u;    // internal_factor_iteration
 constexpr uint32_t PH_INT_VARIABLE = 8u;  // internal_variable_iteration
+
+// A whole schedule (mgx_iterate / mgx_tick) in ONE launch: the sequence of [external iteration] internal*
+// segments that the launch-per-segment path runs as separate launches.  Every robot's workgroup stays resident,
+// keeps its graph in LDS across the segments, publishes its snapshot records at the end of each one (write-through
+// stores + one progress word) and, in front of an external iteration, waits only for the robots it shares
+// inter-robot factors with.  Needs every workgroup of the launch co-resident (checked on the host).
+constexpr int MAX_SEGS = 32;
+struct SegPlan {
+    int32_t n;                     // segments in this launch
+    uint8_t ext[MAX_SEGS];         // 1: the segment opens with an external iteration (factor + variable sweep)
+    uint8_t n_int[MAX_SEGS];       // internal iterations that follow
+    unsigned long long flag_base;  // every progress word holds at least this much when the launch starts
+    long long timeout_ticks;       // 100 MHz wall-clock ticks a wait may take before it gives up (reported, never a hang)
+};
 
 // launch hints
 constexpr uint32_t HINT_IR_DEAD = 1u;  // the next sweep recomputes every inter-robot message this one computes

@@ -143,10 +143,23 @@ __device__ __forceinline__ void copy_words_wave(double *dst, const double *src, 
     if ((n & 1) && lane == 0) dst[n - 1] = src[n - 1];
 }
 
-template <int KT, int IRM>
+// Accesses to what ANOTHER workgroup of the same launch writes or reads (resident schedule launches): relaxed
+// agent-scope atomics = global_load / global_store ... sc1 — they bypass this CU's L1 and write through the XCD's L2,
+// which is what makes a record published by one workgroup readable by another without cache maintenance
+// (MI355X_MICROARCH.md, inter-workgroup visibility: all-sc1 stores and loads, every storing wave drains vmcnt,
+// one lane signals behind a workgroup barrier, the consumer polls that word and loads behind a barrier).
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// PERSIST: the launch runs a whole schedule (SegPlan, mgx_dev.h) instead of one segment.
+template <int KT, int IRM, bool PERSIST>
 __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int robot0, uint32_t ext_mask, uint32_t int_mask,
-                                                             int n_int, int snap_out, uint32_t hints) {
+                                                             int n_int, int snap_out, uint32_t hints, const SegPlan plan) {
     constexpr bool HAS_IR = IRM != IR_NONE, STAGE_IR = IRM == IR_STAGED;
+    static_assert(!PERSIST || IRM == IR_STAGED, "resident schedule launches exist for worlds with staged inter-robot messages");
+    const int nseg = PERSIST ? plan.n : 1;
     // KT > 0: horizon length fixed at compile time; 0: read from the world (K <= 33); -1: read from the world, any K.
     // BIG: more than 64 dynamic-factor messages / tracking factors per robot (K > 33): some lanes carry two.
     constexpr bool BIG = KT < 0 || KT > 33;
@@ -189,8 +202,11 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     const bool is_trk = role == ROLE_UV && lane >= K - 2 && lane < 2 * (K - 2);
     const bool is_var = role == ROLE_UV && lane < K;
     // which variable sweep of this launch is the robot's last one (its belief goes out)
-    const bool has_int_var = (int_mask & PH_INT_VARIABLE) && n_int > 0 && !idle;
-    const bool any_sweep = has_int_var || ((ext_mask & PH_EXT_VARIABLE) && radio);
+    bool plan_int = false, plan_ext = false;  // PERSIST: some segment has internal iterations / an external iteration
+    if (PERSIST)
+        for (int k = 0; k < nseg; k++) { plan_int = plan_int || plan.n_int[k] > 0; plan_ext = plan_ext || plan.ext[k] != 0; }
+    const bool has_int_var = PERSIST ? (plan_int && !idle) : ((int_mask & PH_INT_VARIABLE) && n_int > 0 && !idle);
+    const bool any_sweep = has_int_var || ((PERSIST ? plan_ext : (ext_mask & PH_EXT_VARIABLE) != 0) && radio);
     // a later launch of the same call rewrites this robot's belief image: this one's copy is never read
     const bool bel_dead = ((hints & HINT_LATER_EXT_VARIABLE) && radio) || ((hints & HINT_LATER_INT_VARIABLE) && !idle);
 
@@ -233,7 +249,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // An edge lane needs a chain of dependent loads (gate / constants -> the owner's delivery count and
     // snapshot record); started here they travel while the blob is staged, instead of after the barrier.
     // Each thread prefetches its first edge (robots have at most a few more edges than threads).
-    const bool do_extf = HAS_IR && (ext_mask & PH_EXT_FACTOR) && radio && ir_on;
+    const bool do_extf = !PERSIST && HAS_IR && (ext_mask & PH_EXT_FACTOR) && radio && ir_on;
     bool pf_on = false, pf_present = false;
     IrEdgeRec pf_er{};
     double pf_bmu[4] = {0.0, 0.0, 0.0, 0.0}, pf_rec[SNAP_W];
@@ -267,7 +283,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         if (lane < 20) u_bel = blob[L.bel() + lane * K + (role == 0 ? K - 1 : 0)];
     }
     // messages that this launch's external factor sweep recomputes before anyone reads them are not fetched
-    const bool recompute = (ext_mask & PH_EXT_FACTOR) && radio && ir_on;
+    const bool recompute = (PERSIST ? plan.ext[0] != 0 : (ext_mask & PH_EXT_FACTOR) != 0) && radio && ir_on;
     double r_ir[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     bool r_ir_on = false;
 
@@ -434,14 +450,29 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // ======================= external factor sweep (pull form) ================================
     // factorgraph.rs:745-754 keeps only the message to the other graph's variable, so F_AB is
     // evaluated here, at B, from A's snapshot record and B's last response mean.
-    if (ext_mask & PH_EXT_FACTOR) {
+    // k: segment of a resident schedule launch (0 otherwise); store_fv: the HBM copy of the messages is needed
+    auto external_factor_sweep = [&](int k, bool store_fv) __attribute__((always_inline)) {
+        const int buf = PERSIST ? ((w.cur + k) & 1) : w.cur;  // snapshot buffer the owners' records are read from
         if (radio && ir_on) {
             for (int j = tid; j < ne; j += SWEEP_BLOCK) {
                 const int e = ie0 + j;
                 IrEdgeRec er;
                 double ao_eta[4], ao_lam[16], a_mu[4], b_mu[4];
                 bool a_present;
-                if (j == tid) {  // operands prefetched during staging
+                if (PERSIST) {  // records published by other workgroups of THIS launch: agent-scope loads
+                    if (w.ir_gate[e] != 1) continue;
+                    er = w.ir_rec[e];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) b_mu[c] = ld_agent(&w.ir_bmu[(size_t)c * w.NI + e]);
+                    a_present = ld_agent(&w.snap_epoch[buf][er.src_var]) > er.created;
+                    const double *rec = w.snap[buf] + (size_t)er.src_var * SNAP_W;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) ao_eta[c] = ld_agent(rec + c);
+#pragma unroll
+                    for (int c = 0; c < 16; c++) ao_lam[c] = ld_agent(rec + 4 + c);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) a_mu[c] = ld_agent(rec + 20 + c);
+                } else if (j == tid) {  // operands prefetched during staging
                     if (!pf_on) continue;  // the owner did not run its external factor sweep
                     er = pf_er;
                     a_present = pf_present;
@@ -494,8 +525,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 }
                 // HINT_IR_DEAD: the caller's next sweep recomputes these messages before reading them (it
                 // starts with an external factor sweep under the same flags), and this launch reads
-                // them from LDS — then the HBM copy is dead and not stored
-                if (!(STAGE_IR && (hints & HINT_IR_DEAD))) {
+                // them from LDS — then the HBM copy is dead and not stored; likewise every external
+                // iteration of a resident schedule launch but its last one
+                if (store_fv && !(STAGE_IR && (hints & HINT_IR_DEAD))) {
                     w.ir_fv_eta[0 * (size_t)w.NI + e] = oe[0];
                     w.ir_fv_eta[1 * (size_t)w.NI + e] = oe[1];
                     w.ir_fv_lam[0 * (size_t)w.NI + e] = ol[0];
@@ -511,7 +543,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         }
         if (radio) itf += 1;  // iteration_count.factor of the robot's own external sweep (factorgraph.rs:757)
         __syncthreads();
-    }
+    };
 
     // Inbox sums of a variable sweep, one lane per (variable, row): lane (i, rr) accumulates eta[rr] and
     // lam[rr][0..3] in the reference's inbox order (BTreeMap<FactorId, _>, id.rs:19-54): factors of
@@ -773,63 +805,112 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         }
     };
 
-    bool prefired = false;  // both waves already ran the factor sweep of internal iteration 0
-    STAMP(t_extf);
-    // ======================= external variable sweep ==========================================
-    if (ext_mask & PH_EXT_VARIABLE) {
-        // beliefs are recomputed, nothing is delivered to own factors (factorgraph.rs:794-826): the
-        // sums go to the belief image if this is the robot's last sweep of the launch, else to scratch
-        double *s_sum = has_int_var ? s_tmp : s_prior;
-        if (radio) variable_sums(s_sum, false, false);
-        __syncthreads();
-        // The first internal factor sweep of this launch does not depend on anything the external
-        // sweeps produce (a dynamic factor reads the snapshot of the last INTERNAL variable sweep and
-        // its own previous messages): the DYN wave computes its messages now, next to the UV wave's
-        // mean / covariance of the external variable sweep (one 4x4 inverse per variable either way).
-        // The unary factors do not either (they linearise at the means of the last INTERNAL sweep): the UV wave
-        // runs them right after its finish instead of idling until the DYN wave is done.
-        prefired = radio && n_int > 0 && !idle && (int_mask & PH_INT_FACTOR) && skip0 == 0u;  // same for the whole workgroup
-        if (prefired && is_dyn && (w.enable & 1u)) dynamic_messages();
-        if (radio && is_var) variable_finish(s_sum, false);
-        if (prefired) unary_messages(0u);
-        __syncthreads();
-        if (radio && ir_on) {
-            // responses to the foreign factors attached to our variables, routed to their inbox
-            // (robot.rs:1842-1858): only the mean of that inbox entry is ever used (it sets the
-            // linearisation point; eta / lam of the target side never reach the kept message).
-            // Plain stores of LDS values: nothing in this launch waits for them (the means are next
-            // written after the barrier that ends the coming factor sweep / by nobody).
-            for (int j = tid; j < ne; j += SWEEP_BLOCK) {
-                const int e = ie0 + j;
-                int dst;
-                if (j == tid && do_extf) {  // gate and constants of the thread's first edge are in registers
-                    if (!pf_gate) continue;
-                    dst = pf_dst;
-                } else {
-                    if (!w.ir_gate[e]) continue;  // the owner cannot receive
-                    dst = w.ir_rec[e].dst;
+    // Resident schedule launch: in front of the external iteration of segment k, wait until every robot this one
+    // exchanges snapshot records with (and that is on air) has completed segment k - 1 — its records for this
+    // iteration are then published, and it has finished reading ours of the iteration before, whose buffer the
+    // end of this segment overwrites.  One lane per peer polls that robot's progress word (relaxed agent-scope
+    // loads, s_sleep in between); a wait that outlasts the wall-clock bound raises the world's abort word, which
+    // releases every waiter: the launch then ends with wrong beliefs and the host reports it (never a hung GPU).
+    auto wait_for_peers = [&](int k) __attribute__((always_inline)) {
+        if (PERSIST && radio && ir_on && role == ROLE_DYN) {
+            const unsigned long long want = plan.flag_base + (unsigned long long)k;
+            const int q1 = w.peer_ptr[r + 1];
+            for (int q = w.peer_ptr[r] + lane; q < q1; q += 64) {
+                const int pr = w.peer_idx[q];
+                if (!w.antenna[pr] || w.idle[pr]) continue;  // not on air: neither reads our records nor has its own read
+                const long long t0 = wall_clock64();
+                unsigned spins = 0;
+                while (__hip_atomic_load(&w.sweep_flag[pr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if ((++spins & 31u) == 0u) {
+                        if (__hip_atomic_load(w.sweep_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+                        if (wall_clock64() - t0 > plan.timeout_ticks) {
+                            __hip_atomic_store(w.sweep_abort, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(w.sweep_err, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            break;
+                        }
+                    }
                 }
-                const int i = dst & 0xffff;
-#pragma unroll
-                for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = s_mu[c * K + i] - 0.0;
             }
         }
-    }
+        __syncthreads();
+    };
 
-    STAMP(t_extv);
-    // ======================= internal iterations ==============================================
-    {
+    bool prefired = false;  // both waves already ran the factor sweep of internal iteration 0
+    bool pending = false;   // the last internal sums still await their finish (mean, covariance)
+    int last_int_seg = -1, last_ext_seg = -1;  // PERSIST: last segment with internal iterations / an external iteration
+    if (PERSIST)
+        for (int k = 0; k < nseg; k++) {
+            if (plan.n_int[k] > 0) last_int_seg = k;
+            if (plan.ext[k]) last_ext_seg = k;
+        }
 #ifdef MGX_STAMPS
-        unsigned long long c_f = 0, c_fb = 0, c_v = 0, c_vb = 0;
-        const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long c_f = 0, c_fb = 0, c_v = 0, c_vb = 0, t_extf = t_staged, t_extv = t_staged, t_loop0 = t_staged;
+    unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        STAMP(t_loop0);
-        bool pending = false;  // the last internal sums still await their finish (mean, covariance)
-        for (int it = 0; it < n_int && !idle; it++) {
+    for (int k = 0; k < nseg; k++) {
+        const uint32_t ext_k = PERSIST ? (plan.ext[k] ? (PH_EXT_FACTOR | PH_EXT_VARIABLE) : 0u) : ext_mask;
+        const uint32_t int_k = PERSIST ? (PH_INT_FACTOR | PH_INT_VARIABLE) : int_mask;
+        const int n_int_k = PERSIST ? (int)plan.n_int[k] : n_int;
+        const bool last_seg = k == nseg - 1;
+        // ======================= external factor sweep ============================================
+        if (PERSIST && ext_k && k > 0) wait_for_peers(k);  // k == 0: the launch boundary has published everything
+        if (ext_k & PH_EXT_FACTOR) external_factor_sweep(k, !PERSIST || k == last_ext_seg);
+#ifdef MGX_STAMPS
+        if (k == 0) t_extf = __builtin_readcyclecounter();
+#endif
+        // ======================= external variable sweep ==========================================
+        prefired = false;
+        if (ext_k & PH_EXT_VARIABLE) {
+            // beliefs are recomputed, nothing is delivered to own factors (factorgraph.rs:794-826): the
+            // sums go to the belief image if this is the robot's last sweep of the launch, else to scratch
+            // (the image doubles as the prior, which every later sweep of the launch still needs)
+            const bool ext_is_last = PERSIST ? (last_seg && n_int_k == 0) : !has_int_var;
+            double *s_sum = ext_is_last ? s_prior : s_tmp;
+            if (radio) variable_sums(s_sum, false, false);
+            __syncthreads();
+            // The first internal factor sweep of this segment does not depend on anything the external
+            // sweeps produce (a dynamic factor reads the snapshot of the last INTERNAL variable sweep and
+            // its own previous messages): the DYN wave computes its messages now, next to the UV wave's
+            // mean / covariance of the external variable sweep (one 4x4 inverse per variable either way).
+            // The unary factors do not either (they linearise at the means of the last INTERNAL sweep): the UV wave
+            // runs them right after its finish instead of idling until the DYN wave is done.
+            prefired = radio && n_int_k > 0 && !idle && (int_k & PH_INT_FACTOR) && skip0 == 0u;  // same for the whole workgroup
+            if (prefired && is_dyn && (w.enable & 1u)) dynamic_messages();
+            if (radio && is_var) variable_finish(s_sum, false);
+            if (prefired) unary_messages(0u);
+            __syncthreads();
+            if (radio && ir_on) {
+                // responses to the foreign factors attached to our variables, routed to their inbox
+                // (robot.rs:1842-1858): only the mean of that inbox entry is ever used (it sets the
+                // linearisation point; eta / lam of the target side never reach the kept message).
+                // Plain stores of LDS values: nothing in this launch but the storing thread itself reads them
+                // (the means are next written after the barrier that ends the coming factor sweep / by nobody).
+                for (int j = tid; j < ne; j += SWEEP_BLOCK) {
+                    const int e = ie0 + j;
+                    int dst;
+                    if (j == tid && do_extf) {  // gate and constants of the thread's first edge are in registers
+                        if (!pf_gate) continue;
+                        dst = pf_dst;
+                    } else {
+                        if (!w.ir_gate[e]) continue;  // the owner cannot receive
+                        dst = w.ir_rec[e].dst;
+                    }
+                    const int i = dst & 0xffff;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = s_mu[c * K + i] - 0.0;
+                }
+            }
+        }
+#ifdef MGX_STAMPS
+        if (k == 0) { t_extv = __builtin_readcyclecounter(); t_loop0 = t_extv; rt0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+        // ======================= internal iterations ==============================================
+        for (int it = 0; it < n_int_k && !idle; it++) {
             STAMP(t0);
-            if ((int_mask & PH_INT_FACTOR) && it == 0 && prefired) {
+            if ((int_k & PH_INT_FACTOR) && it == 0 && prefired) {
                 itf += 1;  // this sweep ran next to the external variable sweep, in front of that block's last barrier
-            } else if (int_mask & PH_INT_FACTOR) {
+            } else if (int_k & PH_INT_FACTOR) {
                 if (is_dyn && (w.enable & 1u) && !(it == 0 && (skip0 & 1u))) dynamic_messages();
                 // UV wave: first the belief of the previous sweep (mean, covariance) that the unary
                 // factors linearise at — same wave, so its LDS writes precede their LDS reads
@@ -844,8 +925,11 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 STAMP_ADD(c_fb, t1, t2);
             }
             STAMP(t3);
-            if (int_mask & PH_INT_VARIABLE) {
-                variable_sums(s_snap, true, it == n_int - 1);
+            if (int_k & PH_INT_VARIABLE) {
+                // the robot's last sweep of the launch leaves its sums in the belief image as well (a robot that is
+                // off the air runs no external sweep: its last one is the last internal iteration of the schedule)
+                const bool is_last = it == n_int_k - 1 && (!PERSIST || (k == last_int_seg && (last_seg || !radio)));
+                variable_sums(s_snap, true, is_last);
                 pending = true;
                 STAMP(t4);
                 __syncthreads();
@@ -854,6 +938,25 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 STAMP_ADD(c_vb, t4, t5);
             }
         }
+        // ======================= end of a segment of a resident schedule launch ====================
+        // The snapshot records of this robot (what its variables last sent to their own factors: all that another
+        // robot's inter-robot factors read) go out for the external iteration that opens the next segment: into the
+        // buffer nobody reads during this segment, write-through, every wave drained, then the progress word.
+        if (PERSIST && !last_seg) {
+            if (role == ROLE_UV && pending && is_var) variable_finish(s_snap, true);
+            pending = false;
+            __syncthreads();
+            const int ob = (w.cur + k + 1) & 1;
+            double *dst = w.snap[ob] + (size_t)v0 * SNAP_W;
+            for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) st_agent(dst + t, s_snap[(t % SNAP_W) * K + (t / SNAP_W)]);
+            for (int t = tid; t < K; t += SWEEP_BLOCK) st_agent(&w.snap_epoch[ob][v0 + t], s_epoch[t]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_store(&w.sweep_flag[r], plan.flag_base + (unsigned long long)k + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    {
         // Tail: the UV wave completes the last variable sweep (mean, covariance) while the DYN wave
         // already writes back what that does not touch — the factor -> variable messages and the belief
         // (eta, lam) image, three quarters of the robot's output.
@@ -875,6 +978,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         }
 #endif
     }
+    if (PERSIST) snap_out = (w.cur + nseg) & 1;  // where the records of the schedule's last sweep go (the host follows)
 
     // ---- write back: straight copies of the LDS images ----------------------------------------------
     for (int t = tid; t < 16 * K; t += SWEEP_BLOCK)  // covariance of the variables that recomputed it
@@ -1264,28 +1368,35 @@ __global__ void __launch_bounds__(256) k_halo_push(DevWorld w, int n, const int3
         }
     }
 }
-// wait + unpack: every workgroup waits until all producers have published exchange `seq` (bounded:
-// after `timeout_ticks` of the 100 MHz wall clock it records the failure and leaves), then moves
-// the received records into the ghost robots' snapshot buffers.
+// wait + unpack: workgroup 0 waits until all producers have published exchange `seq` (bounded: after
+// `timeout_ticks` of the 100 MHz wall clock it records the failure — in the rank's error word and in the host-mapped
+// one the host checks after every synchronisation) and then announces the exchange in `ready`; every other workgroup
+// waits for that announcement only, so the whole launch follows ONE decision: either every ghost record of the
+// exchange is unpacked or none is, and once an exchange has failed no later one unpacks anything (the error words
+// are never cleared: the world's beliefs are no longer trusted, mgx_synchronize / mgx_read_* / the next sweep say so).
 __global__ void __launch_bounds__(256) k_halo_wait_unpack(DevWorld w, int n, const int32_t *ghosts, const double *recv, int n_sources,
                                                           const unsigned long long *flags, unsigned long long seq,
-                                                          unsigned long long *err, long long timeout_ticks) {
-    __shared__ int ok;
-    if (threadIdx.x == 0) ok = 1;
-    __syncthreads();
-    for (int j = threadIdx.x; j < n_sources; j += blockDim.x) {
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(&flags[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-            if (wall_clock64() - t0 > timeout_ticks) {
-                ok = 0;
-                __hip_atomic_store(err, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
+                                                          unsigned long long *err, long long timeout_ticks, unsigned long long *ready,
+                                                          unsigned long long *host_err) {
+    if (blockIdx.x == 0) {
+        for (int j = threadIdx.x; j < n_sources; j += blockDim.x) {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(&flags[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+                if (wall_clock64() - t0 > timeout_ticks) {
+                    __hip_atomic_store(err, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (host_err) __hip_atomic_store(host_err, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
             }
-            __builtin_amdgcn_s_sleep(16);
         }
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (threadIdx.x == 0) {
+        while (__hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) __builtin_amdgcn_s_sleep(8);
     }
     __syncthreads();
-    if (!ok) return;
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull) return;  // this exchange or an earlier one failed
     const int words = (SNAP_W + 1) * w.K;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * words) return;
@@ -1404,34 +1515,72 @@ static void launch_k(const DevWorld &w, int robot0, int n_robots, uint32_t ext_m
     // staging the inter-robot messages needs IR_STRIDE f64 per edge; beyond 64 KB of LDS fall back to
     // reading them from L2 in every variable sweep
     const size_t staged = sweep_lds_bytes(w.K, w.ir_max_edges);
+    const SegPlan none{};
     if (w.ir_max_edges == 0)
-        hipLaunchKernelGGL((k_robot_sweep<KT, IR_NONE>), dim3(n_robots), dim3(SWEEP_BLOCK), sweep_lds_bytes(w.K, 0), stream, w,
-                           robot0, ext_mask, int_mask, n_int, snap_out, hints);
+        hipLaunchKernelGGL((k_robot_sweep<KT, IR_NONE, false>), dim3(n_robots), dim3(SWEEP_BLOCK), sweep_lds_bytes(w.K, 0), stream, w,
+                           robot0, ext_mask, int_mask, n_int, snap_out, hints, none);
     else if (staged <= 64 * 1024)
-        hipLaunchKernelGGL((k_robot_sweep<KT, IR_STAGED>), dim3(n_robots), dim3(SWEEP_BLOCK), staged, stream, w, robot0, ext_mask,
-                           int_mask, n_int, snap_out, hints);
+        hipLaunchKernelGGL((k_robot_sweep<KT, IR_STAGED, false>), dim3(n_robots), dim3(SWEEP_BLOCK), staged, stream, w, robot0, ext_mask,
+                           int_mask, n_int, snap_out, hints, none);
     else
-        hipLaunchKernelGGL((k_robot_sweep<KT, IR_GLOBAL>), dim3(n_robots), dim3(SWEEP_BLOCK), sweep_lds_bytes(w.K, 0), stream, w,
-                           robot0, ext_mask, int_mask, n_int, snap_out, hints);
+        hipLaunchKernelGGL((k_robot_sweep<KT, IR_GLOBAL, false>), dim3(n_robots), dim3(SWEEP_BLOCK), sweep_lds_bytes(w.K, 0), stream, w,
+                           robot0, ext_mask, int_mask, n_int, snap_out, hints, none);
 }
+
+// horizon lengths of BASELINE.json / the reference scenarios get constant-K code
+#define MGX_FOR_K(K_, DO)                                                     \
+    switch (K_) {                                                             \
+    case 10: DO(10); break;                                                   \
+    case 12: DO(12); break; /* Junction Twoway */                             \
+    case 13: DO(13); break; /* Junction Experiment */                         \
+    case 16: DO(16); break;                                                   \
+    case 17: DO(17); break; /* Merge, Iteration Amount */                     \
+    case 21: DO(21); break; /* Circle Experiment */                           \
+    case 32: DO(32); break;                                                   \
+    case 35: DO(35); break; /* Communications Failure */                      \
+    default:                                                                  \
+        if (2 * ((K_) - 1) > 64) { DO(-1); } else { DO(0); }                  \
+        break;                                                                \
+    }
 
 hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, uint32_t int_mask, int n_int,
                               int snap_out, uint32_t hints, hipStream_t stream) {
     if (n_robots <= 0) return hipSuccess;
-    switch (w.K) {  // horizon lengths of BASELINE.json / the reference scenarios get constant-K code
-    case 10: launch_k<10>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;
-    case 12: launch_k<12>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;  // Junction Twoway
-    case 13: launch_k<13>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;  // Junction Experiment
-    case 16: launch_k<16>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;
-    case 17: launch_k<17>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;  // Merge, Iteration Amount
-    case 21: launch_k<21>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;  // Circle Experiment
-    case 32: launch_k<32>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;
-    case 35: launch_k<35>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream); break;  // Communications Failure
-    default:
-        if (2 * (w.K - 1) > 64) launch_k<-1>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream);
-        else launch_k<0>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream);
-        break;
-    }
+#define MGX_DO(KT) launch_k<KT>(w, robot0, n_robots, ext_mask, int_mask, n_int, snap_out, hints, stream)
+    MGX_FOR_K(w.K, MGX_DO)
+#undef MGX_DO
+    return hipGetLastError();
+}
+
+// ---- resident schedule launches ------------------------------------------------------------------------
+// How many workgroups of the resident kernel the device holds at once (0: this world's shape has no resident
+// form: no inter-robot edges, or too many per robot to stage in LDS).  Every workgroup of such a launch waits for
+// its neighbours INSIDE the launch, so all of them have to be resident together.
+template <int KT>
+static int resident_capacity_k(const DevWorld &w) {
+    const size_t staged = sweep_lds_bytes(w.K, w.ir_max_edges);
+    if (w.ir_max_edges == 0 || staged > 64 * 1024) return 0;
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_robot_sweep<KT, IR_STAGED, true>, SWEEP_BLOCK, staged) != hipSuccess) return 0;
+    return per_cu * cus;
+}
+int sweep_resident_capacity(const DevWorld &w) {
+    int cap = 0;
+#define MGX_DO(KT) cap = resident_capacity_k<KT>(w)
+    MGX_FOR_K(w.K, MGX_DO)
+#undef MGX_DO
+    return cap;
+}
+hipError_t launch_robot_schedule(const DevWorld &w, int n_robots, const SegPlan &plan, hipStream_t stream) {
+    if (n_robots <= 0 || plan.n <= 0) return hipSuccess;
+    const size_t staged = sweep_lds_bytes(w.K, w.ir_max_edges);
+#define MGX_DO(KT)                                                                                                                 \
+    hipLaunchKernelGGL((k_robot_sweep<KT, IR_STAGED, true>), dim3(n_robots), dim3(SWEEP_BLOCK), staged, stream, w, 0, 0u, 0u, 0, -1, \
+                       0u, plan)
+    MGX_FOR_K(w.K, MGX_DO)
+#undef MGX_DO
     return hipGetLastError();
 }
 hipError_t launch_change_prior(const DevWorld &w, int n, const int32_t *robots, const uint32_t *vars, const double *means,
@@ -1456,11 +1605,11 @@ hipError_t launch_halo_push(const DevWorld &w, int n, const int32_t *robots, con
 }
 hipError_t launch_halo_wait_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *recv, int n_sources,
                                    const unsigned long long *flags, unsigned long long seq, unsigned long long *err,
-                                   long long timeout_ticks, hipStream_t stream) {
+                                   long long timeout_ticks, unsigned long long *ready, unsigned long long *host_err, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     const int total = n * (SNAP_W + 1) * w.K;
     hipLaunchKernelGGL(k_halo_wait_unpack, dim3((total + 255) / 256), dim3(256), 0, stream, w, n, ghosts, recv, n_sources, flags, seq,
-                       err, timeout_ticks);
+                       err, timeout_ticks, ready, host_err);
     return hipGetLastError();
 }
 hipError_t launch_gather_variable_means(const DevWorld &w, int var, double *out, hipStream_t stream) {

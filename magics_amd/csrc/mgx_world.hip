@@ -31,6 +31,8 @@ int blob_words(int K);
 bool sweep_supports(int K);
 hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, uint32_t int_mask, int n_int,
                               int snap_out, uint32_t hints, hipStream_t stream);
+int sweep_resident_capacity(const DevWorld &w);
+hipError_t launch_robot_schedule(const DevWorld &w, int n_robots, const SegPlan &plan, hipStream_t stream);
 hipError_t launch_change_prior(const DevWorld &w, int n, const int32_t *robots, const uint32_t *vars, const double *means,
                                hipStream_t stream);
 hipError_t launch_update_priors(const DevWorld &w, int n, const int32_t *robots, const double *waypoints, const double *time_scale,
@@ -54,7 +56,7 @@ hipError_t launch_halo_push(const DevWorld &w, int n, const int32_t *robots, con
                             const unsigned long long *peer_flags, unsigned long long seq, unsigned int *done, hipStream_t stream);
 hipError_t launch_halo_wait_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *recv, int n_sources,
                                    const unsigned long long *flags, unsigned long long seq, unsigned long long *err,
-                                   long long timeout_ticks, hipStream_t stream);
+                                   long long timeout_ticks, unsigned long long *ready, unsigned long long *host_err, hipStream_t stream);
 // mgx_topology.hip
 int env_red_plane(const mgx_env_desc *d, uint32_t resolution, float expansion, float blur_percent, bool with_blur, hipStream_t s,
                   std::vector<uint8_t> &red, uint32_t &W, uint32_t &H);  // mgx_env.hip
@@ -341,6 +343,14 @@ struct mgx_world {
     DevBuf<float> trk_last_pos, path_xy;
     DevBuf<uint8_t> ir_gate, antenna, idle, sdf;
     StageRing stage;  // packed per-tick arguments
+    // resident schedule launches (SegPlan, mgx_dev.h): progress words, peer lists, the abort / error words
+    DevBuf<unsigned long long> sweep_flag_buf, sweep_abort_buf;
+    DevBuf<int32_t> peer_ptr_dev, peer_idx_dev;
+    unsigned long long *sweep_err_host = nullptr;  // host-mapped; non-zero once a wait inside a resident launch gave up
+    unsigned long long flag_base = 0;              // every progress word is below or at this value between launches
+    int resident_cap = -1;                         // workgroups of the resident kernel the device holds at once (-1: not asked yet)
+    bool peers_valid = false;
+    uint32_t last_sweep_launches = 0;  // sweep-kernel launches of the last mgx_iterate / mgx_tick call (mgx_last_launch_count)
     // message counters are advanced lazily: launches and prior changes are only logged here
     struct CountEntry { uint8_t ext, in; int n_int, robot; uint64_t times; };
     std::vector<CountEntry> clog;
@@ -363,7 +373,7 @@ struct mgx_world {
         bool connected = false;
         unsigned long long seq = 0, push_seq = 0;  // exchanges waited for / pushed
         long long timeout_ticks = 500000000ll;  // 5 s of the 100 MHz wall clock
-        DevBuf<unsigned long long> dst[2], peer_flags;
+        DevBuf<unsigned long long> dst[2], peer_flags, ready;  // ready: the exchange workgroup 0 of the wait kernel has announced
         DevBuf<unsigned int> done;
     } direct;
     // halo exchange through RCCL inside the library (grouped ncclSend / ncclRecv on the world's stream)
@@ -871,6 +881,7 @@ static int retopo(mgx_world *w) {
     }
     w->dev_in_ptr = t.in_ptr;
     w->conns_dirty = false;
+    w->peers_valid = false;
     tm.lap("slot bookkeeping");
     const int rc_flags = upload_flags(w);  // the gate bytes follow the edges
     tm.lap("flags + gates");
@@ -1078,7 +1089,30 @@ static int commit(mgx_world *w) {
     w->conns_dirty = false;
     w->dev_valid = true;
     w->halo_dirty = true;
+    w->peers_valid = false;
+    w->sweep_flag_buf.n = 0;  // progress words of resident launches: re-created (zero) for the new device arrays
+    w->flag_base = 0;
+    w->resident_cap = -1;
+    if (!w->sweep_err_host) {  // the word device code reports a wait that gave up in (resident launches, direct halo waits)
+        HIP_TRY(hipHostMalloc((void **)&w->sweep_err_host, sizeof(unsigned long long), hipHostMallocMapped));
+        *w->sweep_err_host = 0ull;
+    }
+    {
+        void *dp = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dp, w->sweep_err_host, 0));
+        w->d.sweep_err = (unsigned long long *)dp;
+    }
     return upload_flags(w);
+}
+
+// A wait on the device gave up — a direct halo exchange whose producer never published, or a resident schedule
+// launch whose neighbour never did: the waiting kernels end (never a hung GPU) but what they computed from stale
+// records is wrong.  Sticky: every later sweep, synchronisation and read-back reports it.
+static int check_device_error(mgx_world *w) {
+    if (w->sweep_err_host && *w->sweep_err_host != 0ull)
+        return fail(MGX_ERR_STATE, "a wait on the device timed out (exchange / progress word %llu): a peer rank or a neighbouring "
+                    "workgroup never published its records, the world's beliefs are invalid", *w->sweep_err_host);
+    return MGX_OK;
 }
 
 // ---- launches -----------------------------------------------------------------------------------------
@@ -1087,6 +1121,7 @@ static int rccl_exchange(mgx_world *w);
 static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_mask, int n_int, uint32_t hints = 0) {
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
+    if ((rc = check_device_error(w)) != MGX_OK) return rc;
     if (!w->robots.empty()) w->stale_kinds |= ~w->p.enable_mask & 15u;  // disabled factors miss what this sweep delivers
     const bool writes_snap = (int_mask & PH_INT_VARIABLE) && n_int > 0;
     if (robot < 0 && ext_mask && w->thaw_kinds && (int_mask & PH_INT_FACTOR) && n_int > 0) {
@@ -1112,6 +1147,7 @@ static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_ma
         if (w->ir_thaw_active && (ext_mask & PH_EXT_FACTOR) && w->d.NI > 0 && !w->conns.empty())
             HIP_TRY(launch_thaw_ir(w->d, w->ir_gate.p, w->stream));
         HIP_TRY(launch_robot_sweep(w->d, 0, w->d.R_local, ext_mask, int_mask, n_int, out, hints, w->stream));
+        w->last_sweep_launches++;
         if (w->ir_thaw_active && writes_snap) {  // once every robot has run an internal variable sweep, every owner has delivered
             bool all_take_part = true;  // ghosts count: their owners' flags are kept here too, and their records arrive by exchange
             for (const Robot &rb : w->robots) all_take_part = all_take_part && (rb.removed || !rb.idle);
@@ -1141,6 +1177,114 @@ static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_ma
         log_launch(w, robot, 0, int_mask, n_int);
     }
     return MGX_OK;
+}
+
+// ---- resident schedule launches: a whole mgx_iterate / mgx_tick schedule in ONE launch -----------------------
+struct Launch { uint32_t ext; int n_int; uint32_t hints; };
+
+static bool resident_enabled() {  // MGX_PERSISTENT=0 keeps every schedule on the launch-per-segment path
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MGX_PERSISTENT"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+// a wait inside a resident launch gave up (a neighbour's workgroup never published): the beliefs are not to be trusted
+// the robots each local robot exchanges snapshot records with: owners of its incoming connections and targets of
+// its outgoing ones (the latter matter when the reference's bookkeeping has left a connection one-sided)
+static int ensure_resident_tables(mgx_world *w) {
+    hipStream_t s = w->stream;
+    const size_t R = (size_t)w->d.R_local;
+    if (!w->sweep_abort_buf.p) {
+        std::vector<unsigned long long> z(1, 0ull);
+        HIP_TRY(w->sweep_abort_buf.upload(z, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (w->sweep_flag_buf.n != R) {
+        HIP_TRY(w->sweep_flag_buf.reserve(R));
+        HIP_TRY(hipMemsetAsync(w->sweep_flag_buf.p, 0, sizeof(unsigned long long) * R, s));
+        w->flag_base = 0;
+    }
+    if (!w->peers_valid) {
+        std::vector<int32_t> ptr(R + 1, 0);
+        for (const IrConn &c : w->conns) { ptr[(size_t)w->dev_of[(size_t)c.owner] + 1]++; ptr[(size_t)w->dev_of[(size_t)c.other] + 1]++; }
+        for (size_t r = 0; r < R; r++) ptr[r + 1] += ptr[r];
+        std::vector<int32_t> idx((size_t)ptr[R]), fill(ptr.begin(), ptr.end() - 1);
+        for (const IrConn &c : w->conns) {
+            const int o = w->dev_of[(size_t)c.owner], t = w->dev_of[(size_t)c.other];
+            idx[(size_t)fill[(size_t)o]++] = t;
+            idx[(size_t)fill[(size_t)t]++] = o;
+        }
+        std::vector<int32_t> uptr(R + 1, 0), uidx;
+        uidx.reserve(idx.size());
+        for (size_t r = 0; r < R; r++) {
+            std::sort(idx.begin() + ptr[r], idx.begin() + ptr[r + 1]);
+            for (int q = ptr[r]; q < ptr[r + 1]; q++)
+                if (q == ptr[r] || idx[(size_t)q] != idx[(size_t)q - 1]) uidx.push_back(idx[(size_t)q]);
+            uptr[r + 1] = (int32_t)uidx.size();
+        }
+        if (uidx.empty()) uidx.push_back(0);
+        const size_t b_ptr = sizeof(int32_t) * uptr.size(), b_idx = sizeof(int32_t) * uidx.size();
+        void *hp = nullptr;
+        int slot = 0;
+        HIP_TRY(w->stage.acquire(b_ptr + b_idx, &hp, &slot));
+        memcpy(hp, uptr.data(), b_ptr);
+        memcpy((char *)hp + b_ptr, uidx.data(), b_idx);
+        HIP_TRY(w->peer_ptr_dev.reserve(uptr.size()));
+        HIP_TRY(w->peer_idx_dev.reserve(uidx.size()));
+        HIP_TRY(hipMemcpyAsync(w->peer_ptr_dev.p, hp, b_ptr, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(w->peer_idx_dev.p, (char *)hp + b_ptr, b_idx, hipMemcpyHostToDevice, s));
+        HIP_TRY(w->stage.release(slot, s));
+        w->peers_valid = true;
+    }
+    w->d.sweep_flag = w->sweep_flag_buf.p;
+    w->d.sweep_abort = w->sweep_abort_buf.p;
+    w->d.peer_ptr = w->peer_ptr_dev.p;
+    w->d.peer_idx = w->peer_idx_dev.p;
+    return MGX_OK;
+}
+// Runs the schedule as resident launches if this world qualifies: 1 = done, 0 = not eligible (the caller takes the
+// launch-per-segment path), negative = error.  Eligible: inter-robot factors enabled and staged in LDS, every robot
+// local (no ghosts: their records arrive between launches), nothing thawing, and every workgroup co-resident.
+static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
+    if (!resident_enabled() || plan.size() < 2) return 0;
+    int rc = commit(w);
+    if (rc != MGX_OK) return rc;
+    const DevWorld &d = w->d;
+    if (d.R_total != d.R_local || d.ir_max_edges == 0 || w->conns.empty() || !(w->p.enable_mask & 2u)) return 0;
+    if (w->thaw_kinds || w->ir_thaw_active || w->direct.connected || w->rccl.connected) return 0;
+    if (sweep_lds_bytes(w->K, d.ir_max_edges) > 64 * 1024) return 0;
+    for (const Launch &l : plan)
+        if (l.n_int > 255) return 0;
+    if (w->resident_cap < 0) w->resident_cap = sweep_resident_capacity(d);
+    if (d.R_local > w->resident_cap) return 0;
+    rc = ensure_resident_tables(w);
+    if (rc != MGX_OK) return rc;
+    static const long long timeout_ticks = [] {
+        const char *e = getenv("MGX_RESIDENT_TIMEOUT_MS");
+        const long long ms = e ? atoll(e) : 2000;
+        return (ms > 0 ? ms : 2000) * 100000ll;  // 100 MHz wall clock
+    }();
+    w->stale_kinds |= ~w->p.enable_mask & 15u;  // disabled factors miss what these sweeps deliver
+    for (size_t i0 = 0; i0 < plan.size(); i0 += MAX_SEGS) {
+        SegPlan sp{};
+        sp.n = (int32_t)std::min<size_t>(MAX_SEGS, plan.size() - i0);
+        for (int k = 0; k < sp.n; k++) {
+            const Launch &l = plan[i0 + (size_t)k];
+            sp.ext[k] = l.ext ? 1 : 0;
+            sp.n_int[k] = (uint8_t)l.n_int;
+        }
+        sp.flag_base = w->flag_base;
+        sp.timeout_ticks = timeout_ticks;
+        HIP_TRY(launch_robot_schedule(w->d, w->d.R_local, sp, w->stream));
+        w->last_sweep_launches++;
+        w->d.upd = nullptr;  // mgx_tick's prior updates ride in the first launch only
+        w->d.cur = (w->d.cur + sp.n) & 1;
+        w->flag_base += (unsigned long long)sp.n;
+        for (int k = 0; k < sp.n; k++) {
+            const Launch &l = plan[i0 + (size_t)k];
+            log_launch(w, -1, l.ext, l.n_int ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, l.n_int);
+        }
+    }
+    return 1;
 }
 
 // =========================================================================================================
@@ -1175,6 +1319,7 @@ int mgx_world_destroy(mgx_world *w) {
     if (w->rccl.comm && g_rccl.ok) (void)g_rccl.comm_destroy(w->rccl.comm);
     if (w->direct.recv) (void)hipFree(w->direct.recv);
     if (w->direct.flags) (void)hipFree(w->direct.flags);
+    if (w->sweep_err_host) (void)hipHostFree(w->sweep_err_host);
     delete w;
     return MGX_OK;
 }
@@ -1190,7 +1335,7 @@ int mgx_synchronize(mgx_world *w) {
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (!device_ok()) return fail(MGX_ERR_NO_DEVICE, "no usable HIP device");
     HIP_TRY(hipStreamSynchronize(w->stream));
-    return MGX_OK;
+    return check_device_error(w);
 }
 
 int mgx_world_set_sdf(mgx_world *w, const uint8_t *rgb, uint32_t width, uint32_t height, double world_w, double world_h) {
@@ -1710,7 +1855,6 @@ int mgx_sweep(mgx_world *w, int32_t robot, uint32_t external_phases, uint32_t in
 
 // the launches of a schedule: phases I / E flattened (robot.rs:1787-1860: internal first, then external, per
 // step) and grouped into launches of the form [E] I* (one workgroup-resident pass each)
-struct Launch { uint32_t ext; int n_int; uint32_t hints; };
 static std::vector<Launch> plan_launches(const uint8_t *steps, uint32_t n) {
     std::vector<uint8_t> ph;
     for (uint32_t i = 0; i < n; i++) {
@@ -1735,7 +1879,11 @@ static std::vector<Launch> plan_launches(const uint8_t *steps, uint32_t n) {
 
 int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n) {
     if (!w || (!steps && n)) return fail(MGX_ERR_INVALID, "null argument");
-    for (const Launch &l : plan_launches(steps, n)) {
+    const std::vector<Launch> plan = plan_launches(steps, n);
+    w->last_sweep_launches = 0;
+    const int resident = run_resident(w, plan);
+    if (resident != 0) return resident < 0 ? resident : MGX_OK;
+    for (const Launch &l : plan) {
         int rc = sweep(w, -1, l.ext, l.n_int ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, l.n_int, l.hints);
         if (rc != MGX_OK) return rc;
     }
@@ -1820,6 +1968,7 @@ int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *wayp
              const uint8_t *what, double max_speed, double delta_t, const uint8_t *steps, uint32_t n_steps) {
     if (!w || (!steps && n_steps) || (n && (!robots || !waypoints_xy || !time_scale || !what))) return fail(MGX_ERR_INVALID, "null argument");
     const std::vector<Launch> plan = plan_launches(steps, n_steps);
+    w->last_sweep_launches = 0;
     const bool fuse = n > 0 && !plan.empty() && plan[0].ext == 0 && plan[0].n_int > 0 && w->thaw_kinds == 0 && w->K >= 3;
     if (!fuse) {
         int rc = mgx_update_priors(w, n, robots, waypoints_xy, time_scale, what, max_speed, delta_t);
@@ -1844,6 +1993,17 @@ int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *wayp
     }
     HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
     w->stale_kinds |= ~w->p.enable_mask & 15u;
+    {   // the whole tick as one resident launch when the world qualifies: the prior updates ride in it all the same
+        w->d.upd = (const double *)dp; w->d.upd_max_speed = max_speed; w->d.upd_delta_t = delta_t;
+        const int resident = run_resident(w, plan);
+        if (resident != 0) {
+            w->d.upd = nullptr;
+            hipError_t e = w->stage.release(slot, w->stream);
+            if (resident < 0) return resident;
+            return e == hipSuccess ? MGX_OK : fail(MGX_ERR_HIP, "event record: %s", hipGetErrorString(e));
+        }
+        w->d.upd = nullptr;
+    }
     bool first = true;
     for (const Launch &l : plan) {
         if (first) { w->d.upd = (const double *)dp; w->d.upd_max_speed = max_speed; w->d.upd_delta_t = delta_t; }
@@ -1861,6 +2021,12 @@ int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *wayp
 
 int mgx_change_prior(mgx_world *w, int32_t robot, uint32_t var_ix, const double mean[4]) {
     return mgx_change_priors(w, 1, &robot, &var_ix, mean);
+}
+
+int mgx_last_launch_count(mgx_world *w, uint32_t *n_launches) {
+    if (!w || !n_launches) return fail(MGX_ERR_INVALID, "null argument");
+    *n_launches = w->last_sweep_launches;
+    return MGX_OK;
 }
 
 int mgx_num_robots(mgx_world *w, uint32_t *n_robots, uint32_t *n_variables) {
@@ -1889,7 +2055,7 @@ int mgx_read_variable_means(mgx_world *w, uint32_t var_ix, double *means) {
     HIP_TRY(w->stage.release(slot, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
     memcpy(means, hp, bytes);
-    return MGX_OK;
+    return check_device_error(w);
 }
 
 // FactorGraph::messages_sent / messages_received (factorgraph.rs:876-890) of one robot's graph
@@ -1930,6 +2096,7 @@ int mgx_read_beliefs(mgx_world *w, double *eta, double *lam, double *means) {
         HIP_TRY(hipMemcpy2DAsync(mu.data(), 4 * K * sizeof(double), w->blob.p + L.mu(), BS * sizeof(double),
                                  4 * K * sizeof(double), R, hipMemcpyDeviceToHost, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
+    if ((rc = check_device_error(w)) != MGX_OK) return rc;
     // device local order == id order of non-ghost robots
     for (size_t r = 0; r < R; r++)
         for (int i = 0; i < K; i++) {
@@ -1955,6 +2122,7 @@ int mgx_get_belief(mgx_world *w, int32_t robot, uint32_t var_ix, double eta[4], 
     HIP_TRY(hipMemcpyAsync(b.data(), w->blob.p + (size_t)w->dev_of[(size_t)robot] * w->d.BS, sizeof(double) * b.size(),
                            hipMemcpyDeviceToHost, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
+    if ((rc = check_device_error(w)) != MGX_OK) return rc;
     if (eta)
         for (int c = 0; c < 4; c++) eta[c] = b[L.bel() + c * K + i];
     if (lam)
@@ -2061,7 +2229,8 @@ static int direct_wait(mgx_world *w) {
     dh.seq += 1;
     const int par = (int)(dh.seq & 1ull);
     HIP_TRY(launch_halo_wait_unpack(w->d, (int)w->halo_recv.size(), w->halo_recv_dev.p, dh.recv + (size_t)par * dh.recv_words,
-                                    dh.n_sources, dh.flags, dh.seq, dh.flags + dh.n_sources, dh.timeout_ticks, w->stream));
+                                    dh.n_sources, dh.flags, dh.seq, dh.flags + dh.n_sources, dh.timeout_ticks, dh.ready.p, w->d.sweep_err,
+                                    w->stream));
     return MGX_OK;
 }
 static int direct_exchange(mgx_world *w) {
@@ -2154,7 +2323,12 @@ int mgx_halo_direct_setup(mgx_world *w, uint32_t n_sources, void **recv_base, vo
     HIP_TRY(hipExtMallocWithFlags((void **)&dh.flags, fb, hipDeviceMallocFinegrained));
     HIP_TRY(hipMemsetAsync(dh.recv, 0, rb, w->stream));
     HIP_TRY(hipMemsetAsync(dh.flags, 0, fb, w->stream));
+    {
+        std::vector<unsigned long long> z(1, 0ull);
+        HIP_TRY(dh.ready.upload(z, w->stream));
+    }
     HIP_TRY(hipStreamSynchronize(w->stream));
+    if (w->sweep_err_host) *w->sweep_err_host = 0ull;  // a freshly wired exchange starts clean
     dh.seq = dh.push_seq = 0;
     if (const char *ms = getenv("MGX_HALO_TIMEOUT_MS")) {
         const long long v = atoll(ms);

@@ -156,6 +156,7 @@ SYMBOLS = {
     "mgx_ipc_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "mgx_ipc_close": (C.c_int, [C.c_void_p]),
     "mgx_num_robots": (C.c_int, [_V, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "mgx_last_launch_count": (C.c_int, [_V, C.POINTER(C.c_uint32)]),
     "mgx_halo_words": (C.c_uint32, [C.c_uint32]),
     "mgx_halo_plan": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_int32)]),
     "mgx_halo_plan_from_connections": (C.c_int, [_V, C.POINTER(C.c_int32), C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32),

@@ -224,6 +224,12 @@ class World:
         self._chk(self._L.mgx_num_robots(self._w, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def last_launch_count(self):
+        """sweep-kernel launches of the last iterate / tick call (1: the whole schedule ran as one resident launch)"""
+        n = C.c_uint32()
+        self._chk(self._L.mgx_last_launch_count(self._w, C.byref(n)))
+        return n.value
+
     def message_counts(self, robot):
         """(sent internal, sent external, received internal, received external) of one graph."""
         out = (C.c_uint64 * 4)()

@@ -64,3 +64,32 @@ def assert_parity(eng, ref, tol=TOL, what=""):
 def both(eng, ref, fn):
     fn(eng)
     fn(ref)
+
+
+def assert_identical_where_finite(eng, ref, what="", max_nan_only_mismatch=1e-3):
+    """Bit-identity for worlds the reference's own arithmetic drives out of the finite range.  BASELINE configs[4]
+    (inter-robot AND tracking factors, Junction sigmas) does that on every synthetic input tried — the first
+    inter-robot messages are Schur complements of rank-1 blocks (rounding residue instead of zero), a variable
+    whose only other information is the residue of the dynamics factors inverts that noise into a mean thousands
+    of metres off, and the tracking factor's un-normalised Jacobian (tracking.rs:171-194: (x - m) / h with h
+    clamped to 1) squares the distance into its precision: 1e+100 and inf / NaN within one tick, in the oracle
+    and in the engine alike.  There the two must agree bit for bit wherever the oracle is finite,
+    be non-finite in the same places, and may differ only where the oracle holds a NaN and the engine — which
+    never multiplies by the structural zeros of a Jacobian, DESIGN.md §10 — a number; that set must be tiny."""
+    total = bad_finite = nan_only = nonfinite = 0
+    for name, a, b in zip(("eta", "lam", "mean"), eng.read_beliefs(), ref.read_beliefs()):
+        same = (a == b) | (np.isnan(a) & np.isnan(b))
+        bad = ~same
+        total += a.size
+        nonfinite += int((~np.isfinite(b)).sum())
+        nan_only += int((bad & np.isnan(b)).sum())
+        bad_finite += int((bad & ~np.isnan(b)).sum())
+        if (bad & ~np.isnan(b)).any():
+            i = np.argwhere(bad & ~np.isnan(b))[0]
+            raise AssertionError(f"{what}: {name} differs where the oracle holds a number, first at {tuple(i)}: "
+                                 f"engine {a[tuple(i)]!r} oracle {b[tuple(i)]!r} ({bad_finite} such elements)")
+    frac = nan_only / max(total, 1)
+    print(f"[parity {what}] bit-identical wherever the oracle holds a number; oracle non-finite in {nonfinite} of {total} "
+          f"entries ({100.0 * nonfinite / total:.2f} %), engine finite where the oracle is NaN in {nan_only} ({100.0 * frac:.4f} %)")
+    assert frac <= max_nan_only_mismatch, (what, nan_only, total)
+    return nonfinite / total
