@@ -259,7 +259,8 @@ def transport_child(a):
             out = {"error": err or "another rank timed out"}
         else:
             res = summary(walls, devs, a.steps, units_per_step=world_size)
-            out = {"value": round(res["value"], 2), "ms_per_step": res["ms_per_step"], "device_ms_per_step": res["device_ms_per_step"],
+            n_ex = sw.world.halo_direct_status() if a.role == "direct-child" else None  # exchanges run; raises if one timed out
+            out = {"value": round(res["value"], 2), "exchanges": n_ex, "ms_per_step": res["ms_per_step"], "device_ms_per_step": res["device_ms_per_step"],
                    "spread": res["spread"],
                    "exchange": ("direct: peer-mapped stores into the consumers' receive areas (hipIpc) + device-side arrival "
                                 "counters, one C call per tick, no collective") if a.role == "direct-child" else

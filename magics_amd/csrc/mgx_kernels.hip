@@ -153,6 +153,23 @@ __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_a
 __device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// The same for 16 bytes: raw buffer accesses with aux = 16 (sc1); the descriptor is built from wave-uniform values.
+typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sc1_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void ld16_agent(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, double &a, double &b) {
+    const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16);
+    a = __hiloint2double((int)v.y, (int)v.x);
+    b = __hiloint2double((int)v.w, (int)v.z);
+}
+__device__ __forceinline__ void st16_agent(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, double a, double b) {
+    v4u32 v;
+    v.x = (unsigned)__double2loint(a); v.y = (unsigned)__double2hiint(a);
+    v.z = (unsigned)__double2loint(b); v.w = (unsigned)__double2hiint(b);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, 16);
+}
+
 // PERSIST: the launch runs a whole schedule (SegPlan, mgx_dev.h) instead of one segment.
 template <int KT, int IRM, bool PERSIST>
 __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int robot0, uint32_t ext_mask, uint32_t int_mask,
@@ -181,7 +198,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     uint32_t *s_epoch = (uint32_t *)(s_io + L.inout_words() + (L.inout_words() & 1));  // [K] deliveries
     int32_t *s_irp = (int32_t *)(s_epoch + ((K + 1) & ~1));  // [3][K+1] inbox ranges of foreign factors
     int32_t *s_covset = s_irp + ((3 * (K + 1) + 1) & ~1);     // [K] this launch recomputed the variable's covariance
-    double *s_ir = (double *)(s_covset + ((K + 1) & ~1));     // [ne][IR_STRIDE] inter-robot messages (STAGE_IR)
+    // resident launches: shadow of s_fv that takes the factor sweep computed AHEAD of the external iteration it follows
+    double *s_sh = (double *)(s_covset + ((K + 1) & ~1));     // [20][E1] (PERSIST only)
+    double *s_ir = s_sh + (PERSIST ? 20 * E1 : 0);            // [ne][IR_STRIDE] inter-robot messages (STAGE_IR)
 
     double *blob = w.blob + (size_t)r * w.BS;
     const int v0 = r * K;
@@ -262,6 +281,10 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         pf_er = w.ir_rec[ie0 + tid];
         pf_dst = pf_er.dst;
         ld_soa4(w.ir_bmu, w.NI, ie0 + tid, pf_bmu);
+    }
+    if (PERSIST && tid < ne) {  // resident launches: the edge's constants stay in registers for every external iteration
+        pf_er = w.ir_rec[ie0 + tid];
+        pf_dst = pf_er.dst;
     }
     // per-variable words (K <= 64 < threads: one pass)
     uint32_t r_epoch = 0;
@@ -444,6 +467,10 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         }
         __syncthreads();
     }
+    if (PERSIST) {  // columns no sweep recomputes (disabled kinds, tracking in front of its gate) must be equal in both
+        for (int t = tid; t < 20 * E1; t += SWEEP_BLOCK) s_sh[t] = s_fv[t];
+        __syncthreads();
+    }
     uint32_t my_epoch = (tid < 4 * K) ? s_epoch[tid % K] : 0u;  // deliveries of the variable this thread sums
     STAMP(t_staged);
 
@@ -451,6 +478,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // factorgraph.rs:745-754 keeps only the message to the other graph's variable, so F_AB is
     // evaluated here, at B, from A's snapshot record and B's last response mean.
     // k: segment of a resident schedule launch (0 otherwise); store_fv: the HBM copy of the messages is needed
+    // descriptors of the two snapshot buffers for the 16-byte agent-scope accesses of resident launches
+    const unsigned snap_bytes = (unsigned)w.V * (unsigned)(SNAP_W * sizeof(double));
+    const __amdgpu_buffer_rsrc_t rs_snap[2] = {sc1_rsrc(w.snap[0], PERSIST ? snap_bytes : 0u), sc1_rsrc(w.snap[1], PERSIST ? snap_bytes : 0u)};
     auto external_factor_sweep = [&](int k, bool store_fv) __attribute__((always_inline)) {
         const int buf = PERSIST ? ((w.cur + k) & 1) : w.cur;  // snapshot buffer the owners' records are read from
         if (radio && ir_on) {
@@ -459,19 +489,27 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 IrEdgeRec er;
                 double ao_eta[4], ao_lam[16], a_mu[4], b_mu[4];
                 bool a_present;
-                if (PERSIST) {  // records published by other workgroups of THIS launch: agent-scope loads
-                    if (w.ir_gate[e] != 1) continue;
-                    er = w.ir_rec[e];
+                if (PERSIST) {  // records published by other workgroups of THIS launch: agent-scope (sc1) loads, 16 bytes each
+                    if (j == tid) {
+                        if (pf_gate != 1) continue;
+                        er = pf_er;
+                    } else {
+                        if (w.ir_gate[e] != 1) continue;
+                        er = w.ir_rec[e];
+                    }
+                    double rec[SNAP_W];
 #pragma unroll
                     for (int c = 0; c < 4; c++) b_mu[c] = ld_agent(&w.ir_bmu[(size_t)c * w.NI + e]);
                     a_present = ld_agent(&w.snap_epoch[buf][er.src_var]) > er.created;
-                    const double *rec = w.snap[buf] + (size_t)er.src_var * SNAP_W;
+                    const unsigned ro = (unsigned)er.src_var * (unsigned)(SNAP_W * sizeof(double));
 #pragma unroll
-                    for (int c = 0; c < 4; c++) ao_eta[c] = ld_agent(rec + c);
+                    for (int c = 0; c < SNAP_W / 2; c++) ld16_agent(rs_snap[buf], ro + 16u * c, rec[2 * c], rec[2 * c + 1]);
 #pragma unroll
-                    for (int c = 0; c < 16; c++) ao_lam[c] = ld_agent(rec + 4 + c);
+                    for (int c = 0; c < 4; c++) ao_eta[c] = rec[c];
 #pragma unroll
-                    for (int c = 0; c < 4; c++) a_mu[c] = ld_agent(rec + 20 + c);
+                    for (int c = 0; c < 16; c++) ao_lam[c] = rec[4 + c];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) a_mu[c] = rec[20 + c];
                 } else if (j == tid) {  // operands prefetched during staging
                     if (!pf_on) continue;  // the owner did not run its external factor sweep
                     er = pf_er;
@@ -542,7 +580,6 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             }
         }
         if (radio) itf += 1;  // iteration_count.factor of the robot's own external sweep (factorgraph.rs:757)
-        __syncthreads();
     };
 
     // Inbox sums of a variable sweep, one lane per (variable, row): lane (i, rr) accumulates eta[rr] and
@@ -656,7 +693,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // factor read each other's previous value; both lanes sit in the SAME wave, whose LDS reads all
     // issue before its LDS writes, so no barrier is needed between reading the old and writing the new
     // messages.  Reads s_snap, s_epoch and the dynamic columns of s_fv only.
-    auto dynamic_messages = [&]() {
+    auto dynamic_messages = [&](double *s_out) {
         double me[4], ml[16], oe[4], ol[16];
         const int o = dyn_other_var, oe_ix = dyn_other_edge;
         if (s_epoch[o] > 0) {  // other variable has answered: belief - our last message
@@ -691,9 +728,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             for (int c = 0; c < 16; c++) ol[c] = 0.0;
         }
 #pragma unroll
-        for (int c = 0; c < 4; c++) s_fv[c * E1 + lane] = oe[c];
+        for (int c = 0; c < 4; c++) s_out[c * E1 + lane] = oe[c];
 #pragma unroll
-        for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + lane] = ol[c];
+        for (int c = 0; c < 16; c++) s_out[(4 + c) * E1 + lane] = ol[c];
         if (has2) {  // potential blocks of the second message straight from HBM / L2: a rare shape, not worth registers
             const int f2 = lane2 % (K - 1), slot2 = lane2 / (K - 1), a2 = 2 * slot2, b2 = 2 * (1 - slot2), it2 = r * (K - 1) + f2;
             double naa[4], nab[4], nba[4], nbb[4];
@@ -713,9 +750,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 for (int c = 0; c < 16; c++) ol[c] = 0.0;
             }
 #pragma unroll
-            for (int c = 0; c < 4; c++) s_fv[c * E1 + lane2] = oe[c];
+            for (int c = 0; c < 4; c++) s_out[c * E1 + lane2] = oe[c];
 #pragma unroll
-            for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + lane2] = ol[c];
+            for (int c = 0; c < 16; c++) s_out[(4 + c) * E1 + lane2] = ol[c];
         }
     };
 
@@ -723,7 +760,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // tracking factors.  Reads the snapshot means and delivery counts, writes its own message columns.
     // skip: kinds whose sweep k_thaw has already computed (first sweep after mgx_set_enabled only).
     const SdfView sdf = make_sdf_view(w.sdf, w.sdf_w, w.sdf_h, w.world_w, w.world_h);
-    auto unary_messages = [&](uint32_t skip) __attribute__((always_inline)) {
+    auto unary_messages = [&](uint32_t skip, double *s_out, int itf_gate) __attribute__((always_inline)) {
         if (obs_rows) {
             // four lanes per obstacle factor: lane q samples tap q and writes row q of the message
             if (role == ROLE_UV && lane < 4 * (K - 2) && (w.enable & 4u) && !(skip & 4u)) {
@@ -739,9 +776,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 for (int t = 0; t < 4; t++) h[t] = __shfl(hq, (lane & ~3) + t, 64);
                 double eta_q, lam_q[4];
                 obstacle_message_row(h, w.obs_delta, w.inv_s2_obs, x0, q, eta_q, lam_q);
-                s_fv[q * E1 + col] = eta_q;
+                s_out[q * E1 + col] = eta_q;
 #pragma unroll
-                for (int c = 0; c < 4; c++) s_fv[(4 + q * 4 + c) * E1 + col] = lam_q[c];
+                for (int c = 0; c < 4; c++) s_out[(4 + q * 4 + c) * E1 + col] = lam_q[c];
             }
         } else if (is_obs && (w.enable & 4u) && !(skip & 4u)) {
             double x0[4], oe[4], ol[16];
@@ -755,11 +792,11 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             for (int q = 0; q < 4; q++) h[q] = (idx[q] >= 0) ? sdf_value(w.sdf[idx[q]]) : 0.0;
             obstacle_message(h, w.obs_delta, w.inv_s2_obs, x0, oe, ol);
 #pragma unroll
-            for (int c = 0; c < 4; c++) s_fv[c * E1 + uedge] = oe[c];
+            for (int c = 0; c < 4; c++) s_out[c * E1 + uedge] = oe[c];
 #pragma unroll
-            for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + uedge] = ol[c];
+            for (int c = 0; c < 16; c++) s_out[(4 + c) * E1 + uedge] = ol[c];
         }
-        if (is_trk && (w.enable & 8u) && itf >= 10 && !(skip & 8u)) {  // factorgraph.rs:701
+        if (is_trk && (w.enable & 8u) && itf_gate >= 10 && !(skip & 8u)) {  // factorgraph.rs:701
             double x0[4], oe[4], ol[16];
 #pragma unroll
             for (int c = 0; c < 4; c++) x0[c] = s_snap[(20 + c) * K + uvar];
@@ -772,13 +809,13 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 for (int c = 0; c < 16; c++) ol[c] = 0.0;
             }
 #pragma unroll
-            for (int c = 0; c < 4; c++) s_fv[c * E1 + uedge] = oe[c];
+            for (int c = 0; c < 4; c++) s_out[c * E1 + uedge] = oe[c];
 #pragma unroll
-            for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + uedge] = ol[c];
+            for (int c = 0; c < 16; c++) s_out[(4 + c) * E1 + uedge] = ol[c];
         }
         // horizons beyond 33 variables: tracking factors K-2+64 .. 2(K-2)-1 have no lane of their own; lanes
         // 0 .. of the UV wave take them on, with their state in HBM (BIG instantiations only)
-        if (BIG && role == ROLE_UV && lane + 64 >= K - 2 && lane + 64 < 2 * (K - 2) && (w.enable & 8u) && itf >= 10 &&
+        if (BIG && role == ROLE_UV && lane + 64 >= K - 2 && lane + 64 < 2 * (K - 2) && (w.enable & 8u) && itf_gate >= 10 &&
             !(skip & 8u)) {
             const int j2 = lane + 64 - (K - 2), var2 = j2 + 1, col2 = n_dyn + (K - 2) + j2, item2 = r * (K - 2) + j2;
             double x0[4], oe[4], ol[16];
@@ -799,9 +836,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             w.trk_last_pos[(size_t)w.NT + item2] = lp2[1];
             w.trk_last_val[item2] = lv2;
 #pragma unroll
-            for (int c = 0; c < 4; c++) s_fv[c * E1 + col2] = oe[c];
+            for (int c = 0; c < 4; c++) s_out[c * E1 + col2] = oe[c];
 #pragma unroll
-            for (int c = 0; c < 16; c++) s_fv[(4 + c) * E1 + col2] = ol[c];
+            for (int c = 0; c < 16; c++) s_out[(4 + c) * E1 + col2] = ol[c];
         }
     };
 
@@ -812,7 +849,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // loads, s_sleep in between); a wait that outlasts the wall-clock bound raises the world's abort word, which
     // releases every waiter: the launch then ends with wrong beliefs and the host reports it (never a hung GPU).
     auto wait_for_peers = [&](int k) __attribute__((always_inline)) {
-        if (PERSIST && radio && ir_on && role == ROLE_DYN) {
+        if (PERSIST && radio && ir_on && role == ROLE_UV) {
             const unsigned long long want = plan.flag_base + (unsigned long long)k;
             const int q1 = w.peer_ptr[r + 1];
             for (int q = w.peer_ptr[r] + lane; q < q1; q += 64) {
@@ -833,11 +870,20 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 }
             }
         }
-        __syncthreads();
     };
 
     bool prefired = false;  // both waves already ran the factor sweep of internal iteration 0
     bool pending = false;   // the last internal sums still await their finish (mean, covariance)
+    // resident launches: the factor sweep of the coming segment's first internal iteration has been computed into
+    // s_sh at the end of the previous segment, under the publish / wait latency of the hand-off (it reads nothing an
+    // external iteration produces: snapshots of the last INTERNAL variable sweep and the factors' own last messages)
+    bool early = false;
+    auto adopt_early = [&](int t0, int step) __attribute__((always_inline)) {  // s_sh -> s_fv, columns 0 .. E-1
+        for (int t = t0; t < 20 * E; t += step) {
+            const int c = t / E, e = t - c * E;
+            s_fv[c * E1 + e] = s_sh[c * E1 + e];
+        }
+    };
     int last_int_seg = -1, last_ext_seg = -1;  // PERSIST: last segment with internal iterations / an external iteration
     if (PERSIST)
         for (int k = 0; k < nseg; k++) {
@@ -847,6 +893,15 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #ifdef MGX_STAMPS
     unsigned long long c_f = 0, c_fb = 0, c_v = 0, c_vb = 0, t_extf = t_staged, t_extv = t_staged, t_loop0 = t_staged;
     unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long p_wait = 0, p_extf = 0, p_extv = 0, p_int = 0, p_pub = 0;  // resident launches: cycles per stage, all segments
+    unsigned long long q[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // ... and inside the stages
+#define PSTAMP(v) const unsigned long long v = __builtin_readcyclecounter()
+#define QSTAMP(i, since) do { const unsigned long long _n = __builtin_readcyclecounter(); q[i] += _n - (since); (since) = _n; } while (0)
+#define QBEGIN(v) unsigned long long v = __builtin_readcyclecounter()
+#else
+#define PSTAMP(v)
+#define QSTAMP(i, since)
+#define QBEGIN(v)
 #endif
     for (int k = 0; k < nseg; k++) {
         const uint32_t ext_k = PERSIST ? (plan.ext[k] ? (PH_EXT_FACTOR | PH_EXT_VARIABLE) : 0u) : ext_mask;
@@ -854,8 +909,22 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         const int n_int_k = PERSIST ? (int)plan.n_int[k] : n_int;
         const bool last_seg = k == nseg - 1;
         // ======================= external factor sweep ============================================
-        if (PERSIST && ext_k && k > 0) wait_for_peers(k);  // k == 0: the launch boundary has published everything
-        if (ext_k & PH_EXT_FACTOR) external_factor_sweep(k, !PERSIST || k == last_ext_seg);
+        PSTAMP(ps0);
+        QBEGIN(qt);
+        if (PERSIST && ext_k && k > 0) {  // k == 0: the launch boundary has published everything
+            wait_for_peers(k);
+            QSTAMP(0, qt);
+            __syncthreads();
+            QSTAMP(1, qt);
+        }
+        PSTAMP(ps1);
+        if (ext_k & PH_EXT_FACTOR) {
+            external_factor_sweep(k, !PERSIST || k == last_ext_seg);
+            QSTAMP(2, qt);
+            __syncthreads();
+            QSTAMP(3, qt);
+        }
+        PSTAMP(ps2);
 #ifdef MGX_STAMPS
         if (k == 0) t_extf = __builtin_readcyclecounter();
 #endif
@@ -868,18 +937,23 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             const bool ext_is_last = PERSIST ? (last_seg && n_int_k == 0) : !has_int_var;
             double *s_sum = ext_is_last ? s_prior : s_tmp;
             if (radio) variable_sums(s_sum, false, false);
+            QSTAMP(4, qt);
             __syncthreads();
+            QSTAMP(5, qt);
             // The first internal factor sweep of this segment does not depend on anything the external
             // sweeps produce (a dynamic factor reads the snapshot of the last INTERNAL variable sweep and
             // its own previous messages): the DYN wave computes its messages now, next to the UV wave's
             // mean / covariance of the external variable sweep (one 4x4 inverse per variable either way).
             // The unary factors do not either (they linearise at the means of the last INTERNAL sweep): the UV wave
             // runs them right after its finish instead of idling until the DYN wave is done.
-            prefired = radio && n_int_k > 0 && !idle && (int_k & PH_INT_FACTOR) && skip0 == 0u;  // same for the whole workgroup
-            if (prefired && is_dyn && (w.enable & 1u)) dynamic_messages();
+            prefired = !early && radio && n_int_k > 0 && !idle && (int_k & PH_INT_FACTOR) && skip0 == 0u;  // same for the whole workgroup
+            if (prefired && is_dyn && (w.enable & 1u)) dynamic_messages(s_fv);
+            if (PERSIST && early && radio && role == ROLE_DYN) adopt_early(lane, 64);  // the sums above were the last readers of the old messages
             if (radio && is_var) variable_finish(s_sum, false);
-            if (prefired) unary_messages(0u);
+            if (prefired) unary_messages(0u, s_fv, itf);
+            QSTAMP(6, qt);
             __syncthreads();
+            QSTAMP(7, qt);
             if (radio && ir_on) {
                 // responses to the foreign factors attached to our variables, routed to their inbox
                 // (robot.rs:1842-1858): only the mean of that inbox entry is ever used (it sets the
@@ -889,7 +963,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 for (int j = tid; j < ne; j += SWEEP_BLOCK) {
                     const int e = ie0 + j;
                     int dst;
-                    if (j == tid && do_extf) {  // gate and constants of the thread's first edge are in registers
+                    if (j == tid && (do_extf || PERSIST)) {  // gate and constants of the thread's first edge are in registers
                         if (!pf_gate) continue;
                         dst = pf_dst;
                     } else {
@@ -902,21 +976,29 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 }
             }
         }
+        QSTAMP(8, qt);
+        PSTAMP(ps3);
 #ifdef MGX_STAMPS
         if (k == 0) { t_extv = __builtin_readcyclecounter(); t_loop0 = t_extv; rt0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
         // ======================= internal iterations ==============================================
+        if (PERSIST && early && !((ext_k & PH_EXT_VARIABLE) && radio)) {  // no external variable sweep ran: adopt here
+            adopt_early(tid, SWEEP_BLOCK);
+            __syncthreads();
+        }
+        if (PERSIST && early) prefired = true;
+        early = false;
         for (int it = 0; it < n_int_k && !idle; it++) {
             STAMP(t0);
             if ((int_k & PH_INT_FACTOR) && it == 0 && prefired) {
                 itf += 1;  // this sweep ran next to the external variable sweep, in front of that block's last barrier
             } else if (int_k & PH_INT_FACTOR) {
-                if (is_dyn && (w.enable & 1u) && !(it == 0 && (skip0 & 1u))) dynamic_messages();
+                if (is_dyn && (w.enable & 1u) && !(it == 0 && (skip0 & 1u))) dynamic_messages(s_fv);
                 // UV wave: first the belief of the previous sweep (mean, covariance) that the unary
                 // factors linearise at — same wave, so its LDS writes precede their LDS reads
                 if (pending && is_var) variable_finish(s_snap, true);
                 pending = false;
-                unary_messages(it == 0 ? skip0 : 0u);
+                unary_messages(it == 0 ? skip0 : 0u, s_fv, itf);
                 itf += 1;
                 STAMP(t1);
                 __syncthreads();
@@ -942,19 +1024,44 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         // The snapshot records of this robot (what its variables last sent to their own factors: all that another
         // robot's inter-robot factors read) go out for the external iteration that opens the next segment: into the
         // buffer nobody reads during this segment, write-through, every wave drained, then the progress word.
+        PSTAMP(ps4);
+        // ONE wave does all of it (the one that completes the means), so it may signal for itself after its own drain.
         if (PERSIST && !last_seg) {
-            if (role == ROLE_UV && pending && is_var) variable_finish(s_snap, true);
+            QSTAMP(9, qt);
+            if (role == ROLE_UV) {
+                if (pending && is_var) variable_finish(s_snap, true);
+                QSTAMP(10, qt);
+                __builtin_amdgcn_wave_barrier();  // the wave's LDS writes (means) precede its LDS reads below
+                const int ob = (w.cur + k + 1) & 1;
+                const unsigned base = (unsigned)v0 * (unsigned)(SNAP_W * sizeof(double));
+                for (int t = lane; t < (SNAP_W / 2) * K; t += 64) {  // 16 bytes = components 2c, 2c + 1 of variable i
+                    const int i = t / (SNAP_W / 2), c = t - i * (SNAP_W / 2);
+                    st16_agent(rs_snap[ob], base + (unsigned)(i * SNAP_W + 2 * c) * 8u, s_snap[(2 * c) * K + i], s_snap[(2 * c + 1) * K + i]);
+                }
+                for (int t = lane; t < K; t += 64) st_agent(&w.snap_epoch[ob][v0 + t], s_epoch[t]);
+                QSTAMP(11, qt);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                QSTAMP(12, qt);
+                if (lane == 0)
+                    __hip_atomic_store(&w.sweep_flag[r], plan.flag_base + (unsigned long long)k + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             pending = false;
-            __syncthreads();
-            const int ob = (w.cur + k + 1) & 1;
-            double *dst = w.snap[ob] + (size_t)v0 * SNAP_W;
-            for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) st_agent(dst + t, s_snap[(t % SNAP_W) * K + (t / SNAP_W)]);
-            for (int t = tid; t < K; t += SWEEP_BLOCK) st_agent(&w.snap_epoch[ob][v0 + t], s_epoch[t]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0)
-                __hip_atomic_store(&w.sweep_flag[r], plan.flag_base + (unsigned long long)k + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the factor sweep that opens the next segment's internal iterations, while the records travel: the DYN wave
+            // starts at once (a dynamic factor reads no mean), the UV wave after its publish.  The tracking factors' gate
+            // (factorgraph.rs:701) counts the external factor sweep that the reference runs in between.
+            early = plan.n_int[k + 1] > 0 && !idle && skip0 == 0u;
+            if (early) {
+                if (is_dyn && (w.enable & 1u)) dynamic_messages(s_sh);
+                unary_messages(0u, s_sh, itf + ((plan.ext[k + 1] && radio) ? 1 : 0));
+            }
+            QSTAMP(13, qt);
         }
+#ifdef MGX_STAMPS
+        {
+            PSTAMP(ps5);
+            p_wait += ps1 - ps0; p_extf += ps2 - ps1; p_extv += ps3 - ps2; p_int += ps4 - ps3; p_pub += ps5 - ps4;
+        }
+#endif
     }
     {
         // Tail: the UV wave completes the last variable sweep (mean, covariance) while the DYN wave
@@ -975,6 +1082,11 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             d[6] = t_staged - t_k0;
             d[0] = (d[0] & 0xffffffffull) | ((t_extf - t_staged) << 32);  // external factor sweep (high word)
             d[1] = (d[1] & 0xffffffffull) | ((t_extv - t_extf) << 32);    // external variable sweep (high word)
+            if (PERSIST) {
+                d[0] = p_wait; d[1] = p_extf; d[2] = p_extv; d[3] = p_int; d[4] = p_pub;
+                unsigned long long *d2 = w.dbg + (size_t)(gridDim.x + 4) * 16 + ((size_t)blockIdx.x * 2 + role) * 16;
+                for (int i = 0; i < 16; i++) d2[i] = q[i];
+            }
         }
 #endif
     }
@@ -1500,12 +1612,13 @@ __global__ void k_copy_bytes(uint8_t *__restrict__ dst, const uint8_t *__restric
 }
 
 // ---- launch wrappers (called from mgx_world.hip) -------------------------------------------------
-size_t sweep_lds_bytes(int K, int ir_edges) {
+size_t sweep_lds_bytes(int K, int ir_edges, bool resident) {  // resident: + the shadow of the factor -> variable messages
     const BlobLayout L(K);
     const int io = L.inout_words() + (L.inout_words() & 1);
-    return sizeof(double) * (size_t)((SNAP_W + 20 + 20) * K + io + IR_STRIDE * ir_edges) +
+    return sizeof(double) * (size_t)((SNAP_W + 20 + 20) * K + io + IR_STRIDE * ir_edges + (resident ? 20 * L.E1 : 0)) +
            4 * (size_t)(2 * ((K + 1) & ~1) + ((3 * (K + 1) + 1) & ~1));
 }
+size_t sweep_lds_bytes(int K, int ir_edges) { return sweep_lds_bytes(K, ir_edges, false); }
 bool sweep_supports(int K) { return K >= 3 && 2 * (K - 1) <= 128; }  // beyond 33 variables: two dynamic messages per lane
 int blob_words(int K) { const BlobLayout L(K); return (L.words() + 1) & ~1; }
 
@@ -1558,7 +1671,7 @@ hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint3
 // its neighbours INSIDE the launch, so all of them have to be resident together.
 template <int KT>
 static int resident_capacity_k(const DevWorld &w) {
-    const size_t staged = sweep_lds_bytes(w.K, w.ir_max_edges);
+    const size_t staged = sweep_lds_bytes(w.K, w.ir_max_edges, true);
     if (w.ir_max_edges == 0 || staged > 64 * 1024) return 0;
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
@@ -1575,7 +1688,7 @@ int sweep_resident_capacity(const DevWorld &w) {
 }
 hipError_t launch_robot_schedule(const DevWorld &w, int n_robots, const SegPlan &plan, hipStream_t stream) {
     if (n_robots <= 0 || plan.n <= 0) return hipSuccess;
-    const size_t staged = sweep_lds_bytes(w.K, w.ir_max_edges);
+    const size_t staged = sweep_lds_bytes(w.K, w.ir_max_edges, true);
 #define MGX_DO(KT)                                                                                                                 \
     hipLaunchKernelGGL((k_robot_sweep<KT, IR_STAGED, true>), dim3(n_robots), dim3(SWEEP_BLOCK), staged, stream, w, 0, 0u, 0u, 0, -1, \
                        0u, plan)

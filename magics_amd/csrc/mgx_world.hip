@@ -27,6 +27,7 @@
 
 namespace mgx {
 size_t sweep_lds_bytes(int K, int ir_edges);
+size_t sweep_lds_bytes(int K, int ir_edges, bool resident);
 int blob_words(int K);
 bool sweep_supports(int K);
 hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, uint32_t int_mask, int n_int,
@@ -1077,7 +1078,7 @@ static int commit(mgx_world *w) {
     d.trk_attr = w->p.tracking_attraction_distance;
 #ifdef MGX_STAMPS
     {
-        std::vector<unsigned long long> z((size_t)(R_local + 4) * 16, 0ull);
+        std::vector<unsigned long long> z((size_t)(R_local + 4) * 48, 0ull);  // [.. * 16): stages per wave, then 16 sub-stage sums per wave
         HIP_TRY(w->dbg.upload(z, s));
         HIP_TRY(hipStreamSynchronize(s));
         d.dbg = w->dbg.p;
@@ -1251,7 +1252,7 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
     const DevWorld &d = w->d;
     if (d.R_total != d.R_local || d.ir_max_edges == 0 || w->conns.empty() || !(w->p.enable_mask & 2u)) return 0;
     if (w->thaw_kinds || w->ir_thaw_active || w->direct.connected || w->rccl.connected) return 0;
-    if (sweep_lds_bytes(w->K, d.ir_max_edges) > 64 * 1024) return 0;
+    if (sweep_lds_bytes(w->K, d.ir_max_edges, true) > 64 * 1024) return 0;
     for (const Launch &l : plan)
         if (l.n_int > 255) return 0;
     if (w->resident_cap < 0) w->resident_cap = sweep_resident_capacity(d);

@@ -32,9 +32,23 @@ for name, kw in (("config2", dict(interrobot=False)), ("config3", dict(interrobo
     w.synchronize()
     L = hostlib.lib()
     L.mgx_debug_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32]
-    buf = (C.c_ulonglong * (1004 * 16))()
+    buf = (C.c_ulonglong * (1004 * 48))()
     n = L.mgx_debug_read_stamps(w._w, buf, len(buf))
-    raw = np.array(buf[:n], dtype=np.uint64).reshape(-1, 2, 8)
+    allw = np.array(buf[:n], dtype=np.uint64)
+    raw = allw[:1004 * 16].reshape(-1, 2, 8)
+    sub = allw[1004 * 16:1004 * 48].reshape(-1, 2, 16).astype(np.float64)
+    if name == "config3" and os.environ.get("MGX_PERSISTENT", "1") != "0":  # resident launch: cycles per stage over the 10 iterations
+        a = raw.astype(np.float64)
+        a = a[a[:, 0, 7] > 0]
+        for role, rn in ((0, "DYN"), (1, "UV ")):
+            wt, ef, ev, it_, pb, rt, stg, whole = (a[:, role, k].mean() for k in range(8))
+            print(f"config3 resident {rn}: per launch (10 iterations) cycles: wait {wt:.0f}  ext factor {ef:.0f}  ext variable {ev:.0f}  internal {it_:.0f}  "
+                  f"finish+publish {pb:.0f}  staging {stg:.0f}  whole kernel {whole:.0f}  (wait max {a[:, role, 0].max():.0f} min {a[:, role, 0].min():.0f})")
+            names = ["poll", "poll barrier", "ext factor edges", "its barrier", "ext var sums", "barrier", "ext finish | adopt", "barrier", "response means",
+                     "(internal)", "int finish", "publish stores", "drain", "early factor sweep", "-", "-"]
+            m = sub[:1000, role, :].mean(axis=0) / 10.0
+            print("   per iteration: " + "  ".join(f"{nm} {v:.0f}" for nm, v in zip(names, m) if nm != "-"))
+        continue
     ext_f, ext_v = (raw[:, :, 0] >> np.uint64(32)).astype(np.float64), (raw[:, :, 1] >> np.uint64(32)).astype(np.float64)
     raw[:, :, 0] &= np.uint64(0xffffffff)
     raw[:, :, 1] &= np.uint64(0xffffffff)
