@@ -210,6 +210,18 @@ int mgx_change_prior(mgx_world *w, int32_t robot, uint32_t var_ix, const double 
 int mgx_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, const uint32_t *var_ix,
                       const double *means);
 
+/* FactorGraph::reset_variables(&means, first_last_sigma, inbetween_sigma) (factorgraph.rs:1541-1564; VariableNode::reset,
+ * variable.rs:350-360; FactorNode::empty_inbox, factor/mod.rs:480-483) for one robot's graph: every variable's belief mean
+ * becomes means[i] and its belief precision diag(sigma) — first_last_sigma for variables 0 and K-1, inbetween_sigma for the
+ * others, used as the reference uses them (AS the diagonal, +inf allowed) — and every message in the variables' inboxes and
+ * in the inboxes of the graph's own factors becomes empty.  means: [K][4].  mgx_reset_tracking_factors:
+ * FactorGraph::reset_tracking_factors (factorgraph.rs:1566-1590) — the graph's tracking factors skip their next ten
+ * updates (tracking.rs:153-155,362-371).  The reference calls the pair (means, 1e30, +inf) when a global path arrives
+ * (robot.rs:766-769); rare, so the engine re-lays the device state out on the next launch. */
+int mgx_reset_variables(mgx_world *w, int32_t robot, const double *means, double first_last_sigma,
+                        double inbetween_sigma);
+int mgx_reset_tracking_factors(mgx_world *w, int32_t robot);
+
 /* The driver's per-tick prior updates, batched over robots in one launch:
  *   what[i] & 1: update_prior_of_horizon_state (robot.rs:2182-2283) — the last variable of robots[i]
  *                moves towards waypoints_xy[i] at min(max_speed, distance) for delta_t seconds;
@@ -270,6 +282,27 @@ int mgx_halo_plan(mgx_world *w, uint32_t n_send, const int32_t *send_robots, uin
 int mgx_halo_plan_from_connections(mgx_world *w, const int32_t *rank_of, uint32_t n_robots,
                                    int32_t my_rank, uint32_t n_ranks, uint32_t *send_counts,
                                    uint32_t *recv_counts);
+/* The sharding plan itself (host only, no device; identical on every rank, no communication):
+ * mgx_shard_partition — owner rank of every robot: contiguous strips in (y, x) order of the robots' positions with equal
+ *   robot counts (spatial blocks keep cross-rank pairs few); ties broken by robot index.
+ * mgx_shard_plan_create — one rank's view, from the owner map and the directed connections (owner robot a, other robot
+ *   b) of create_interrobot_factors (robot.rs:1490-1541): the local robots, the ghosts (owners of connections whose
+ *   target is local), the indices of the connections evaluated here, and per peer rank q the robots whose snapshot
+ *   records go to q / arrive from q — segments [first[q], first[q+1]) of the send / receive lists, ascending robot id
+ *   inside a segment, i.e. exactly the order mgx_halo_plan and the transports expect.
+ * mgx_shard_plan_counts sizes the arrays of mgx_shard_plan_get (first arrays: n_ranks + 1 entries); any output may be NULL. */
+typedef struct mgx_shard_plan mgx_shard_plan;
+int mgx_shard_partition(const double *positions_xy, uint32_t n_robots, uint32_t n_ranks, int32_t *owner);
+int mgx_shard_plan_create(const int32_t *owner, uint32_t n_robots, const int32_t *conn_owner,
+                          const int32_t *conn_other, uint32_t n_conns, int32_t rank, uint32_t n_ranks,
+                          mgx_shard_plan **out);
+void mgx_shard_plan_destroy(mgx_shard_plan *plan);
+int mgx_shard_plan_counts(const mgx_shard_plan *plan, uint32_t *n_local, uint32_t *n_ghosts,
+                          uint32_t *n_connections, uint32_t *n_send, uint32_t *n_recv);
+int mgx_shard_plan_get(const mgx_shard_plan *plan, int32_t *local, int32_t *ghosts, uint32_t *connections,
+                       uint32_t *send_first, int32_t *send_robots, uint32_t *recv_first,
+                       int32_t *recv_robots);
+
 /* Pack the planned robots' variable->own-factor snapshots (what their inter-robot factors on
  * other ranks read) into `dev_buf` (device pointer, n_send records of mgx_halo_words(K) f64),
  * resp. unpack n_recv records into the ghost robots.  Asynchronous on the world's stream. */

@@ -412,4 +412,26 @@ MGX_HD bool tracking_message(const float *path, int n_path, double pad, double a
     return true;
 }
 
+// TrackingFactor::skip's timeout (tracking.rs:153-155,362-371: Option<usize>, set by FactorGraph::reset_tracking_factors)
+// rides in the upper half of the factor's `record` word: 0 = None, n + 1 = Some(n).  Returns true when the factor
+// skips this update because of it (Some(n > 0) -> Some(n - 1)); Some(0) becomes None and the update goes ahead.
+MGX_HD bool tracking_timeout_skips(int &record_packed) {
+    const int code = record_packed >> 16;
+    if (code == 0) return false;
+    const int rec = record_packed & 0xffff;
+    if (code == 1) { record_packed = rec; return false; }
+    record_packed = rec | ((code - 1) << 16);
+    return true;
+}
+// tracking_message on the packed record word (the timeout survives the update)
+MGX_HD bool tracking_update(const float *path, int n_path, double pad, double attraction, double inv_sigma2, const double (&x0)[4],
+                            int &record_packed, float (&last_pos)[2], double &last_val, double (&eta)[4], double (&lam)[16]) {
+    if (tracking_timeout_skips(record_packed)) return false;
+    int rec = record_packed & 0xffff;
+    const int code = record_packed >> 16;
+    const bool ok = tracking_message(path, n_path, pad, attraction, inv_sigma2, x0, rec, last_pos, last_val, eta, lam);
+    record_packed = rec | (code << 16);
+    return ok;
+}
+
 }  // namespace mgx

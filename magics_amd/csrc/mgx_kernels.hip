@@ -801,7 +801,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #pragma unroll
             for (int c = 0; c < 4; c++) x0[c] = s_snap[(20 + c) * K + uvar];
             const int p0 = w.path_ptr[r], np = w.path_ptr[r + 1] - p0;
-            if (!tracking_message(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, trk_rec,
+            if (!tracking_update(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, trk_rec,
                                   trk_lp, trk_lv, oe, ol)) {
 #pragma unroll
                 for (int c = 0; c < 4; c++) oe[c] = 0.0;
@@ -825,7 +825,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             float lp2[2] = {w.trk_last_pos[item2], w.trk_last_pos[(size_t)w.NT + item2]};
             double lv2 = w.trk_last_val[item2];
             const int p0 = w.path_ptr[r], np = w.path_ptr[r + 1] - p0;
-            if (!tracking_message(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, rec2, lp2, lv2, oe, ol)) {
+            if (!tracking_update(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, rec2, lp2, lv2, oe, ol)) {
 #pragma unroll
                 for (int c = 0; c < 4; c++) oe[c] = 0.0;
 #pragma unroll
@@ -1350,7 +1350,7 @@ __global__ void k_thaw(DevWorld w, int robot0, int n_robots, uint32_t ext_mask) 
             float lp[2] = {w.trk_last_pos[item], w.trk_last_pos[(size_t)w.NT + item]};
             double lv = w.trk_last_val[item];
             const int p0 = w.path_ptr[r], np = w.path_ptr[r + 1] - p0;
-            ok = tracking_message(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, rec, lp, lv, oe, ol);
+            ok = tracking_update(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, rec, lp, lv, oe, ol);
             w.trk_record[item] = rec;
             w.trk_last_pos[item] = lp[0];
             w.trk_last_pos[(size_t)w.NT + item] = lp[1];

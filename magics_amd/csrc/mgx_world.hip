@@ -2020,6 +2020,60 @@ int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *wayp
     return MGX_OK;
 }
 
+// FactorGraph::reset_variables (factorgraph.rs:1541-1564: VariableNode::reset, variable.rs:350-360, for every variable, then
+// FactorNode::empty_inbox, factor/mod.rs:480-483, for every factor of the graph).  In the engine's terms:
+//   belief mean / precision  <- the given mean / diag(sigma) (the reference uses the sigma AS the precision's diagonal, +inf
+//                               included); information vector, covariance, validity and the prior stay;
+//   variable inboxes emptied <- own factor -> variable messages and the messages of foreign inter-robot factors attached to
+//                               these variables become the empty (= zero) message;
+//   own factors' inboxes emptied <- the variables' delivery counts restart at zero (an own factor's inbox entry is "present"
+//                               once its variable has delivered; a tracking factor reads the record's mean even before, so
+//                               that becomes zero as well), and for the inter-robot factors this graph owns the entry from
+//                               the other robot's variable (its last response mean) is emptied and their creation epoch
+//                               restarts with the count.
+// A rare call (the reference makes it when a global path has been found, robot.rs:700-790): the device state is pulled,
+// edited on the host mirror and laid out again by the next launch.
+int mgx_reset_variables(mgx_world *w, int32_t robot, const double *means, double first_last_sigma, double inbetween_sigma) {
+    if (!w || !means || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
+    if (w->robots[(size_t)robot].ghost || w->robots[(size_t)robot].removed) return fail(MGX_ERR_INVALID, "robot %d is not a live local robot", robot);
+    int rc = pull(w);
+    if (rc != MGX_OK) return rc;
+    flush_counts(w);
+    Robot &rb = w->robots[(size_t)robot];
+    const int K = rb.K, E = 4 * K - 6;
+    for (int i = 0; i < K; i++) {
+        const double sigma = (i == 0 || i == K - 1) ? first_last_sigma : inbetween_sigma;
+        for (int c = 0; c < 4; c++) rb.bel_mu[4 * i + c] = means[4 * i + c];
+        for (int c = 0; c < 16; c++) rb.bel_lam[16 * i + c] = (c % 5 == 0) ? sigma : 0.0;
+        rb.epoch[(size_t)i] = 0;
+        for (int c = 0; c < 4; c++) rb.snap[24 * i + 20 + c] = 0.0;
+    }
+    std::fill(rb.fv_eta.begin(), rb.fv_eta.begin() + 4 * E, 0.0);
+    std::fill(rb.fv_lam.begin(), rb.fv_lam.begin() + 16 * E, 0.0);
+    for (IrConn &c : w->conns) {
+        if (c.other == robot)  // foreign factors attached to these variables: their message to us is emptied
+            for (IrEdge &ed : c.edges) { std::fill(ed.fv_eta, ed.fv_eta + 4, 0.0); std::fill(ed.fv_lam, ed.fv_lam + 16, 0.0); }
+        if (c.owner == robot)  // own inter-robot factors: both inbox entries emptied
+            for (IrEdge &ed : c.edges) { std::fill(ed.bmu, ed.bmu + 4, 0.0); ed.created = 0; ed.fresh = false; }
+    }
+    w->dirty = true;
+    w->dev_valid = false;  // the host mirror is the truth now: the next launch lays it out again (and must not pull over it)
+    return MGX_OK;
+}
+// FactorGraph::reset_tracking_factors (factorgraph.rs:1566-1590): set_timeout(10) on every tracking factor of the graph —
+// its next ten updates are skipped (tracking.rs:362-371) and send the empty message.
+int mgx_reset_tracking_factors(mgx_world *w, int32_t robot) {
+    if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
+    if (w->robots[(size_t)robot].ghost || w->robots[(size_t)robot].removed) return fail(MGX_ERR_INVALID, "robot %d is not a live local robot", robot);
+    int rc = pull(w);
+    if (rc != MGX_OK) return rc;
+    Robot &rb = w->robots[(size_t)robot];
+    for (int32_t &rec : rb.trk_record) rec = (rec & 0xffff) | (11 << 16);  // Some(10), gbp_math.h tracking_timeout_skips
+    w->dirty = true;
+    w->dev_valid = false;
+    return MGX_OK;
+}
+
 int mgx_change_prior(mgx_world *w, int32_t robot, uint32_t var_ix, const double mean[4]) {
     return mgx_change_priors(w, 1, &robot, &var_ix, mean);
 }

@@ -155,12 +155,21 @@ SYMBOLS = {
     "mgx_ipc_export": (C.c_int, [C.c_void_p, C.c_char_p]),
     "mgx_ipc_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "mgx_ipc_close": (C.c_int, [C.c_void_p]),
+    "mgx_reset_variables": (C.c_int, [_V, C.c_int32, c_double_p, C.c_double, C.c_double]),
+    "mgx_reset_tracking_factors": (C.c_int, [_V, C.c_int32]),
     "mgx_num_robots": (C.c_int, [_V, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mgx_last_launch_count": (C.c_int, [_V, C.POINTER(C.c_uint32)]),
     "mgx_halo_words": (C.c_uint32, [C.c_uint32]),
     "mgx_halo_plan": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_int32)]),
     "mgx_halo_plan_from_connections": (C.c_int, [_V, C.POINTER(C.c_int32), C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32),
                                                  C.POINTER(C.c_uint32)]),
+    "mgx_shard_partition": (C.c_int, [c_double_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32)]),
+    "mgx_shard_plan_create": (C.c_int, [C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_uint32, C.c_int32,
+                                        C.c_uint32, C.POINTER(_V)]),
+    "mgx_shard_plan_destroy": (None, [_V]),
+    "mgx_shard_plan_counts": (C.c_int, [_V] + [C.POINTER(C.c_uint32)] * 5),
+    "mgx_shard_plan_get": (C.c_int, [_V, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
     "mgx_halo_pack": (C.c_int, [_V, _V]),
     "mgx_halo_unpack": (C.c_int, [_V, _V]),
     "mgx_euclidean_norm": (C.c_double, [c_double_p, C.c_uint32]),
@@ -280,3 +289,37 @@ def variable_timesteps(lookahead_horizon, lookahead_multiple):
     if n < 0:
         raise ValueError("bad arguments")
     return list(buf[:n])
+
+
+def shard_partition(positions_xy, n_ranks):
+    """mgx_shard_partition: owner rank of every robot (equal-count strips in (y, x) order)."""
+    import numpy as np
+    pos = np.ascontiguousarray(np.asarray(positions_xy, dtype=np.float64).reshape(-1, 2))
+    owner = np.zeros(len(pos), dtype=np.int32)
+    check(lib().mgx_shard_partition(pos.ctypes.data_as(c_double_p), len(pos), int(n_ranks), owner.ctypes.data_as(C.POINTER(C.c_int32))))
+    return owner
+
+
+def shard_plan(owner, conn_owner, conn_other, rank, n_ranks):
+    """mgx_shard_plan_create / _get: dict(local, ghosts, connections, send_first, send_robots, recv_first, recv_robots)."""
+    import numpy as np
+    L = lib()
+    i32p, u32p = C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+    owner = np.ascontiguousarray(owner, dtype=np.int32)
+    ca, cb = np.ascontiguousarray(conn_owner, dtype=np.int32), np.ascontiguousarray(conn_other, dtype=np.int32)
+    h = C.c_void_p()
+    check(L.mgx_shard_plan_create(owner.ctypes.data_as(i32p), len(owner), ca.ctypes.data_as(i32p), cb.ctypes.data_as(i32p), len(ca), int(rank),
+                                  int(n_ranks), C.byref(h)))
+    try:
+        n = [C.c_uint32() for _ in range(5)]
+        check(L.mgx_shard_plan_counts(h, *[C.byref(x) for x in n]))
+        nl, ng, nc, ns, nr = (x.value for x in n)
+        out = dict(local=np.zeros(nl, np.int32), ghosts=np.zeros(ng, np.int32), connections=np.zeros(nc, np.uint32),
+                   send_first=np.zeros(n_ranks + 1, np.uint32), send_robots=np.zeros(ns, np.int32),
+                   recv_first=np.zeros(n_ranks + 1, np.uint32), recv_robots=np.zeros(nr, np.int32))
+        check(L.mgx_shard_plan_get(h, out["local"].ctypes.data_as(i32p), out["ghosts"].ctypes.data_as(i32p), out["connections"].ctypes.data_as(u32p),
+                                   out["send_first"].ctypes.data_as(u32p), out["send_robots"].ctypes.data_as(i32p),
+                                   out["recv_first"].ctypes.data_as(u32p), out["recv_robots"].ctypes.data_as(i32p)))
+    finally:
+        L.mgx_shard_plan_destroy(h)
+    return out

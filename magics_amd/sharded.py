@@ -27,14 +27,8 @@ PH_FACTOR, PH_VARIABLE = 1, 2
 
 def partition_strips(positions, world_size):
     """Owner rank of every robot: contiguous strips in (y, x) order with equal robot counts —
-    spatial blocks keep cross-rank neighbour pairs few."""
-    positions = np.asarray(positions)
-    order = np.lexsort((positions[:, 0], positions[:, 1]))
-    owner = np.empty(len(positions), dtype=np.int64)
-    n = len(positions)
-    for k in range(world_size):
-        owner[order[k * n // world_size:(k + 1) * n // world_size]] = k
-    return owner
+    spatial blocks keep cross-rank neighbour pairs few.  mgx_shard_partition."""
+    return hostlib.shard_partition(np.asarray(positions)[:, :2], world_size).astype(np.int64)
 
 
 def segments(steps):
@@ -61,8 +55,9 @@ def segments(steps):
 
 
 class ShardPlan:
-    """Pure host logic (numpy only): who owns what, which robots are ghosts here, what is sent
-    where, in which order.  Identical code on every rank; no communication needed to build it."""
+    """Who owns what, which robots are ghosts here, what is sent where, in which order: the C ABI's
+    mgx_shard_partition / mgx_shard_plan_* (host logic of the library, identical on every rank, no
+    communication); this class only holds the result for the launcher."""
 
     def __init__(self, sc, rank, world_size, owner=None):
         self.rank, self.world_size = rank, world_size
@@ -74,20 +69,14 @@ class ShardPlan:
         else:
             self.owner = np.zeros(0, dtype=np.int64)  # an empty world: robots join later (ShardedWorld.add_robot)
         assert len(self.owner) == n
-        self.local = [r for r in range(n) if self.owner[r] == rank]
-        ghosts, send = set(), [set() for _ in range(world_size)]
-        self.connections = []
-        for a, b, n0 in sc["ir"]:
-            oa, ob = self.owner[a], self.owner[b]
-            if ob == rank:
-                self.connections.append((a, b, n0))  # evaluated here (target is local)
-                if oa != rank:
-                    ghosts.add(a)
-            elif oa == rank:
-                send[ob].add(a)  # b's rank evaluates F_ab and needs a's snapshots
-        self.ghosts = sorted(ghosts)
-        self.send_lists = [sorted(s) for s in send]
-        self.recv_lists = [[g for g in self.ghosts if self.owner[g] == p] for p in range(world_size)]
+        ir = sc["ir"]
+        p = hostlib.shard_plan(self.owner, [c[0] for c in ir], [c[1] for c in ir], rank, world_size)
+        self.local = [int(r) for r in p["local"]]
+        self.ghosts = [int(g) for g in p["ghosts"]]
+        self.connections = [ir[int(c)] for c in p["connections"]]  # evaluated here (target is local)
+        sf, rf = p["send_first"], p["recv_first"]
+        self.send_lists = [[int(g) for g in p["send_robots"][sf[q]:sf[q + 1]]] for q in range(world_size)]
+        self.recv_lists = [[int(g) for g in p["recv_robots"][rf[q]:rf[q + 1]]] for q in range(world_size)]
         self.K = sc.get("K")
 
 
@@ -134,6 +123,7 @@ class ShardedWorld:
         self.recv_buf = make(max(1, sum(self.recv_counts)))
 
         self.direct = False
+        self.transport = "collective" if plan.world_size > 1 else "none"  # sharded.connect() moves it to an in-engine one
 
     # -- a world that follows its topology ---------------------------------------------------------------
     def _init_dynamic(self, sc, tensor_factory):
@@ -375,6 +365,78 @@ def connect_direct(sw, comm):
     infos = comm.all_gather_object(sw.direct_setup(export_ipc=True))
     sw.direct_connect({inf["rank"]: inf for inf in infos})
     comm.barrier()
+
+
+def connect(sw, comm, transport="auto"):
+    """Wire the exchange of a multi-process sharded world, in-engine transports first (one C call per tick, no host
+    work per exchange): "direct" (peer-mapped stores through hipIpc) -> "rccl" (grouped ncclSend / ncclRecv enqueued by
+    the engine) -> "collective" (pack / all_to_all_single / unpack driven from the host: the fallback that only needs
+    `comm`).  Collective: every rank calls it with the same arguments; after every step the ranks agree on whether ALL
+    of them succeeded, so a failure on one rank moves every rank to the next transport instead of leaving the others
+    waiting.  Returns the transport in use (also `sw.transport`)."""
+    if sw.plan.world_size == 1 or comm is None:
+        sw.transport = "none"
+        return sw.transport
+    order = {"auto": ["direct", "rccl", "collective"], "direct": ["direct", "collective"], "rccl": ["rccl", "collective"],
+             "collective": ["collective"]}[transport]
+
+    def all_ok(ok):
+        return all(comm.all_gather_object(bool(ok)))
+    for t in order:
+        if t == "collective":
+            break
+        try:
+            if t == "direct":
+                info, err = None, None
+                try:
+                    info = sw.direct_setup(export_ipc=True)
+                except Exception as e:  # noqa: BLE001
+                    err = e
+                infos = comm.all_gather_object(info)
+                if any(i is None for i in infos):
+                    continue
+                try:
+                    sw.direct_connect({i["rank"]: i for i in infos})
+                    ok = True
+                except Exception:  # noqa: BLE001
+                    ok = False
+                if all_ok(ok):
+                    comm.barrier()
+                    sw.transport = "direct"
+                    return sw.transport
+                comm.barrier()
+                sw.direct_close()
+            else:
+                uid = None
+                try:
+                    uid = hostlib.rccl_unique_id() if sw.plan.rank == 0 else b""
+                except Exception:  # noqa: BLE001
+                    uid = None
+                uids = comm.all_gather_object(uid)
+                if uids[0] is None:
+                    continue
+                plan = sw.plan
+                peers = [q for q in range(plan.world_size) if plan.send_lists[q] or plan.recv_lists[q]]
+                send_first, recv_first = [0], [0]
+                for q in peers:
+                    send_first.append(send_first[-1] + len(plan.send_lists[q]))
+                    recv_first.append(recv_first[-1] + len(plan.recv_lists[q]))
+                try:
+                    sw.world.halo_rccl_connect(uids[0], plan.world_size, plan.rank, peers, send_first, recv_first)
+                    ok = True
+                except Exception:  # noqa: BLE001
+                    ok = False
+                if all_ok(ok):
+                    sw.direct = sw.rccl = True
+                    comm.barrier()
+                    sw.transport = "rccl"
+                    return sw.transport
+                if ok:
+                    sw.world.halo_rccl_disconnect()
+        except Exception:  # noqa: BLE001
+            raise
+    sw.transport = "collective"
+    return sw.transport
 
 
 class TorchDistComm:

@@ -182,6 +182,15 @@ class World:
         mean = _f64(mean, (4,))
         self._chk(self._L.mgx_change_prior(self._w, robot, var_ix, _dp(mean)))
 
+    def reset_variables(self, robot, means, first_last_sigma=1e30, inbetween_sigma=float("inf")):
+        """FactorGraph::reset_variables (factorgraph.rs:1541-1564); the defaults are the reference's call (robot.rs:768)."""
+        m = _f64(means)
+        self._chk(self._L.mgx_reset_variables(self._w, robot, _dp(m), float(first_last_sigma), float(inbetween_sigma)))
+
+    def reset_tracking_factors(self, robot):
+        """FactorGraph::reset_tracking_factors (factorgraph.rs:1566-1590)."""
+        self._chk(self._L.mgx_reset_tracking_factors(self._w, robot))
+
     def change_priors(self, robots, var_ix, means):
         robots = np.ascontiguousarray(robots, dtype=np.int32)
         var_ix = np.ascontiguousarray(var_ix, dtype=np.uint32)

@@ -88,6 +88,8 @@ def _bind(path):
     for n in ("internal_factor", "internal_variable", "external_factor", "external_variable"):
         getattr(L, f"orc_{n}_iteration").argtypes = [C.c_void_p, C.c_int32]
     L.orc_change_prior.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, c_double_p]
+    L.orc_reset_variables.argtypes = [C.c_void_p, C.c_int32, c_double_p, C.c_double, C.c_double]
+    L.orc_reset_tracking_factors.argtypes = [C.c_void_p, C.c_int32]
     L.orc_update_priors.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), c_double_p, c_double_p, C.POINTER(C.c_uint8),
                                     C.c_double, C.c_double]
     L.orc_get_belief.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, c_double_p, c_double_p, c_double_p,
@@ -276,6 +278,13 @@ class OracleWorld:
     def change_prior(self, robot, var_ix, mean):
         mean = _f64(mean, (4,))
         self._chk(self._L.orc_change_prior(self._w, robot, var_ix, _dp(mean)))
+
+    def reset_variables(self, robot, means, first_last_sigma=1e30, inbetween_sigma=float("inf")):
+        m = _f64(means)
+        self._chk(self._L.orc_reset_variables(self._w, robot, _dp(m), float(first_last_sigma), float(inbetween_sigma)))
+
+    def reset_tracking_factors(self, robot):
+        self._chk(self._L.orc_reset_tracking_factors(self._w, robot))
 
     def change_priors(self, robots, var_ix, means):
         means = _f64(means)

@@ -134,6 +134,7 @@ typedef struct {
     int record;
     float last_pos[2];
     double last_value;
+    int timeout; /* Option<usize> (tracking.rs:80,153-155): -1 = None */
 } Factor;
 
 typedef struct {
@@ -465,13 +466,17 @@ static double tracking_measure(const World *w, Factor *f, const Graph *g, const 
 }
 
 /* `Factor::skip` per kind */
-static int factor_skip(const Graph *g, const Factor *f) {
+static int factor_skip(const Graph *g, Factor *f) {
     if (f->kind == K_INTERROBOT) { /* interrobot.rs:213-226 (no tiny offset) */
         double dx = f->x0[0] - f->x0[DOFS], dy = f->x0[1] - f->x0[DOFS + 1];
         double sq = dx * dx + dy * dy; /* mapv(powi(2)).sum() */
         return sq >= f->safety_distance * f->safety_distance;
     }
-    if (f->kind == K_TRACKING) { /* tracking.rs:362-381; timeout never set on this path */
+    if (f->kind == K_TRACKING) { /* tracking.rs:362-381 */
+        if (f->timeout >= 0) { /* :363-371: Some(0) -> None and go on; Some(n) -> Some(n - 1) and skip */
+            if (f->timeout == 0) f->timeout = -1;
+            else { f->timeout -= 1; return 1; }
+        }
         int len = g->n_path;
         if (len < 2) return 1;
         return f->record >= len - 1;
@@ -699,6 +704,7 @@ static void factor_state_new(Factor *f, int kind, int zdim, double strength, int
     f->enabled = enabled;
     f->zdim = zdim;
     f->nvars = nvars;
+    f->timeout = -1;
     double s2 = strength * strength; /* powi(strength, 2) */
     for (int i = 0; i < zdim; i++) f->lam_meas[i * zdim + i] = 1.0 / s2;
 }
@@ -1336,6 +1342,40 @@ int orc_change_prior(World *w, int32_t r, uint32_t var_ix, const double *mean) {
         if (factor_node_exists(w, to)) /* FG/factorgraph.rs:511-513, ROBOT:2277-2281 */
             factor_receive(&w->g[to.robot].nodes[to.index].f, mkid(w, r, vix), &m);
         memset(&v->inbox.e[j].msg, 0, sizeof(Msg)); /* :224-227 */
+    }
+    return ORC_OK;
+}
+
+/* FactorGraph::reset_variables — FG/factorgraph.rs:1541-1564 with VariableNode::reset (FG/variable.rs:350-360) and
+ * FactorNode::empty_inbox (FG/factor/mod.rs:480-483): belief mean and precision replaced (the `sigma` arguments are used
+ * AS the diagonal of the precision, infinite included; information vector, covariance, prior untouched), every message
+ * in the variables' inboxes and in the inboxes of the graph's own factors (inter-robot ones included) becomes empty.
+ * Called by the path-finding completion handler with (means, 1e30, +inf) (ROBOT:768). */
+int orc_reset_variables(World *w, int32_t r, const double *means, double first_last_sigma, double inbetween_sigma) {
+    if (!w || r < 0 || r >= w->n || !means || w->g[r].removed || w->g[r].ghost) return ORC_ERR_INVALID;
+    Graph *g = &w->g[r];
+    for (int i = 0; i < g->K; i++) {
+        Variable *v = &g->nodes[g->var_indices[i]].v;
+        double sigma = (i == 0 || i == g->K - 1) ? first_last_sigma : inbetween_sigma;
+        memcpy(v->mu, means + 4 * i, sizeof v->mu);
+        for (int q = 0; q < 16; q++) v->lam[q] = (q % 5 == 0) ? sigma : 0.0; /* Matrix::from_diag_elem */
+        for (int j = 0; j < v->inbox.n; j++) memset(&v->inbox.e[j].msg, 0, sizeof(Msg));
+    }
+    for (int q = 0; q < g->n_factors; q++) {
+        Node *nd = &g->nodes[g->factor_indices[q]];
+        if (!nd->alive || !nd->is_factor) continue;
+        for (int j = 0; j < nd->f.inbox.n; j++) memset(&nd->f.inbox.e[j].msg, 0, sizeof(Msg));
+    }
+    return ORC_OK;
+}
+/* FactorGraph::reset_tracking_factors — FG/factorgraph.rs:1566-1590: every tracking factor attached to a variable
+ * 1 .. K-2 (all of them, ROBOT:1290-1334) gets set_timeout(10): its next ten updates are skipped (tracking.rs:362-371) */
+int orc_reset_tracking_factors(World *w, int32_t r) {
+    if (!w || r < 0 || r >= w->n || w->g[r].removed || w->g[r].ghost) return ORC_ERR_INVALID;
+    Graph *g = &w->g[r];
+    for (int q = 0; q < g->n_factors; q++) {
+        Node *nd = &g->nodes[g->factor_indices[q]];
+        if (nd->alive && nd->is_factor && nd->f.kind == K_TRACKING) nd->f.timeout = 10;
     }
     return ORC_OK;
 }

@@ -114,6 +114,51 @@ impl World {
     }
 }
 
+/// Owner rank of every robot for a node of `n_ranks` GPUs (`mgx_shard_partition`: equal-count strips in (y, x) order).
+pub fn shard_partition(positions_xy: &[[f64; 2]], n_ranks: u32) -> Result<Vec<i32>, MgxError> {
+    let mut owner = vec![0i32; positions_xy.len()];
+    check(unsafe { sys::mgx_shard_partition(positions_xy.as_ptr().cast(), positions_xy.len() as u32, n_ranks, owner.as_mut_ptr()) })?;
+    Ok(owner)
+}
+
+/// One rank's view of a sharded world (`mgx_shard_plan_*`): local robots, ghosts, the connections evaluated here and the
+/// per-peer send / receive lists in the order `mgx_halo_plan` and the transports expect.
+pub struct ShardPlan {
+    pub local: Vec<i32>,
+    pub ghosts: Vec<i32>,
+    pub connections: Vec<u32>,
+    pub send_first: Vec<u32>,
+    pub send_robots: Vec<i32>,
+    pub recv_first: Vec<u32>,
+    pub recv_robots: Vec<i32>,
+}
+impl ShardPlan {
+    pub fn new(owner: &[i32], conn_owner: &[i32], conn_other: &[i32], rank: i32, n_ranks: u32) -> Result<Self, MgxError> {
+        assert_eq!(conn_owner.len(), conn_other.len());
+        let mut raw = std::ptr::null_mut();
+        check(unsafe {
+            sys::mgx_shard_plan_create(owner.as_ptr(), owner.len() as u32, conn_owner.as_ptr(), conn_other.as_ptr(), conn_owner.len() as u32,
+                                       rank, n_ranks, &mut raw)
+        })?;
+        let (mut nl, mut ng, mut nc, mut ns, mut nr) = (0u32, 0u32, 0u32, 0u32, 0u32);
+        let rc = unsafe { sys::mgx_shard_plan_counts(raw, &mut nl, &mut ng, &mut nc, &mut ns, &mut nr) };
+        let mut p = ShardPlan {
+            local: vec![0; nl as usize], ghosts: vec![0; ng as usize], connections: vec![0; nc as usize],
+            send_first: vec![0; n_ranks as usize + 1], send_robots: vec![0; ns as usize],
+            recv_first: vec![0; n_ranks as usize + 1], recv_robots: vec![0; nr as usize],
+        };
+        let rc2 = if rc >= 0 {
+            unsafe {
+                sys::mgx_shard_plan_get(raw, p.local.as_mut_ptr(), p.ghosts.as_mut_ptr(), p.connections.as_mut_ptr(), p.send_first.as_mut_ptr(),
+                                        p.send_robots.as_mut_ptr(), p.recv_first.as_mut_ptr(), p.recv_robots.as_mut_ptr())
+            }
+        } else { rc };
+        unsafe { sys::mgx_shard_plan_destroy(raw) };
+        check(rc2)?;
+        Ok(p)
+    }
+}
+
 impl Drop for World {
     fn drop(&mut self) {
         unsafe { sys::mgx_world_destroy(self.raw) };
@@ -146,6 +191,22 @@ impl FactorGraph {
     pub fn change_prior_of_variable(&mut self, variable_index: u32, new_mean: [f64; 4]) -> Result<Vec<()>, MgxError> {
         check(unsafe { sys::mgx_change_prior(self.world.raw, self.robot, variable_index, new_mean.as_ptr()) })?;
         Ok(Vec::new())
+    }
+    /// `FactorGraph::reset_variables(&means, first_last_sigma, inbetween_sigma)` (factorgraph.rs:1541-1564); the
+    /// reference's call is `(means, 1e30, Float::INFINITY)` (robot.rs:768)
+    pub fn reset_variables(&mut self, means: &[[f64; 4]], first_last_sigma: f64, inbetween_sigma: f64) -> Result<(), MgxError> {
+        check(unsafe { sys::mgx_reset_variables(self.world.raw, self.robot, means.as_ptr().cast(), first_last_sigma, inbetween_sigma) })
+    }
+    /// `FactorGraph::reset_tracking_factors` (factorgraph.rs:1566-1590)
+    pub fn reset_tracking_factors(&mut self) -> Result<(), MgxError> {
+        check(unsafe { sys::mgx_reset_tracking_factors(self.world.raw, self.robot) })
+    }
+    /// `messages_sent()` / `messages_received()` (factorgraph.rs:876-890): [sent internal, sent external, received
+    /// internal, received external]
+    pub fn message_counts(&self) -> Result<[u64; 4], MgxError> {
+        let mut c = [0u64; 4];
+        check(unsafe { sys::mgx_message_counts(self.world.raw, self.robot, c.as_mut_ptr()) })?;
+        Ok(c)
     }
     pub fn set_antenna(&mut self, active: bool) -> Result<(), MgxError> {
         check(unsafe { sys::mgx_set_antenna(self.world.raw, self.robot, active as i32) })

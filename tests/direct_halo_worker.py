@@ -20,7 +20,7 @@ def main():
     sc = S.grid_scenario(64, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
     comm = sharded.TorchDistComm()
     sw = sharded.ShardedWorld(sc, rank, ws, World, comm=comm)
-    sharded.connect_direct(sw, comm)
+    assert sharded.connect(sw, comm) == "direct"  # the default wiring: in-engine transports first
     steps = sc["steps"] + [1, 1, 2, 3, 2]
     boundary = sorted({g for r in range(ws) for g in sharded.ShardPlan(sc, r, ws).ghosts})
     for tick in range(3):

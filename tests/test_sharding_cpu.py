@@ -121,6 +121,9 @@ def _worker(rank, world_size, port, q):
         sc = _scenario()
         sw = sharded.ShardedWorld(sc, rank, world_size, FakeWorld, comm=sharded.TorchDistComm(),
                                   tensor_factory=lambda n: torch.zeros(n, dtype=torch.float64))
+        # the in-engine transports need the real engine: on this (fake, CPU) world every rank fails to wire them, the
+        # ranks agree on that, and all of them fall back to the host-driven collective
+        assert sharded.connect(sw, sw.comm) == "collective" and sw.transport == "collective"
         steps = [3, 3, 1, 1, 3, 2, 3]
         sw.iterate(steps)
         sw.iterate(steps)
@@ -218,3 +221,46 @@ def test_direct_exchange_wiring(world_size):
             sw.world.sweep(3, 3, 1)
     assert sum(sw.world.checked for sw in ranks) > 0
     assert any(sw.plan.ghosts for sw in ranks)
+
+
+def _plan_reference(sc, owner, rank, world_size):
+    """the plan as the round-1 Python launcher derived it (kept here as the checker of mgx_shard_plan_*)"""
+    local = [r for r in range(len(sc["robots"])) if owner[r] == rank]
+    ghosts, send, conns = set(), [set() for _ in range(world_size)], []
+    for a, b, n0 in sc["ir"]:
+        if owner[b] == rank:
+            conns.append((a, b, n0))
+            if owner[a] != rank:
+                ghosts.add(a)
+        elif owner[a] == rank:
+            send[owner[b]].add(a)
+    ghosts = sorted(ghosts)
+    return local, ghosts, conns, [sorted(s) for s in send], [[g for g in ghosts if owner[g] == p] for p in range(world_size)]
+
+
+@pytest.mark.parametrize("world_size", [1, 2, 3, 8])
+def test_shard_plan_of_the_c_abi_equals_the_reference_derivation(world_size):
+    sc = S.grid_scenario(400, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
+    pos = np.asarray(sc["positions"])
+    owner = sharded.partition_strips(pos, world_size)
+    # equal-count strips in (y, x) order
+    order = np.lexsort((pos[:, 0], pos[:, 1]))
+    want = np.empty(len(pos), dtype=np.int64)
+    for k in range(world_size):
+        want[order[k * len(pos) // world_size:(k + 1) * len(pos) // world_size]] = k
+    assert np.array_equal(owner, want)
+    for rank in range(world_size):
+        plan = sharded.ShardPlan(sc, rank, world_size)
+        local, ghosts, conns, send, recv = _plan_reference(sc, owner, rank, world_size)
+        assert plan.local == local and plan.ghosts == ghosts and plan.connections == conns
+        assert plan.send_lists == send and plan.recv_lists == recv
+
+
+def test_shard_plan_rejects_bad_input():
+    from magics_amd import hostlib
+    with pytest.raises(hostlib.MgxError):
+        hostlib.shard_plan([0, 1, 5], [0], [1], 0, 2)       # owner rank out of range
+    with pytest.raises(hostlib.MgxError):
+        hostlib.shard_plan([0, 1], [0], [7], 0, 2)          # connection names a robot that does not exist
+    with pytest.raises(hostlib.MgxError):
+        hostlib.shard_plan([0, 1], [0], [1], 2, 2)          # rank out of range
