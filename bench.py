@@ -84,19 +84,23 @@ def timed(torch, dist, iterate, steps_one_tick, a, multi, red_dev="cuda", sync=N
         run_steps(iterate, max(a.steps, SCHEDULE_LEN), steps_one_tick)
         sync()
     walls, devs = [], []
-    for _ in range(a.repeats):
+    for _ in range(a.repeats):  # wall clock: nothing but the K steps between the two barrier + synchronize pairs
         if multi:
             dist.barrier()
         sync()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record()
         run_steps(iterate, a.steps, steps_one_tick)
-        ev1.record()
         if multi:
             dist.barrier()
         sync()
         walls.append(time.perf_counter() - t0)
+    for _ in range(a.repeats):  # device time of the same block: HIP events on the launch stream (own repetitions: recording them costs host time)
+        sync()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        run_steps(iterate, a.steps, steps_one_tick)
+        ev1.record()
+        sync()
         devs.append(ev0.elapsed_time(ev1) * 1e-3)
     if multi:
         t = torch.tensor([walls, devs], dtype=torch.float64, device=red_dev)

@@ -240,6 +240,40 @@ int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *wayp
              const double *time_scale, const uint8_t *what, double max_speed, double delta_t,
              const uint8_t *steps, uint32_t n_steps);
 
+/* ---- whole driver ticks on the device -----------------------------------------------------
+ * The rest of the reference's FixedUpdate chain around iterate_gbp_v2 (robot.rs:86-103) with its state on the device, so
+ * that a tick costs the host ONE synchronisation (the neighbour rows the connection bookkeeping needs) instead of four
+ * belief read-backs: a robot's mission — its route, the next waypoint, the reached-when rules of formation.yaml and the
+ * Bevy Transform it moves — is handed over once (mgx_mission_set); every mgx_mission_tick then runs
+ *   reached_waypoint                         robot.rs:2080-2176  estimated position (belief mean of the rule's variable, as f32)
+ *                                                                against the next waypoint, f32 squared distance; the last
+ *                                                                waypoint completes the mission (and despawns the robot,
+ *                                                                robot.rs:2172, when despawn_finished is set)
+ *   update_robot_neighbours + delete_ / create_interrobot_factors   robot.rs:1362-1586  on the device's Transforms, exactly
+ *                                                                mgx_update_topology otherwise
+ *   update_failed_comms                      robot.rs:1593-1601  `antennas` (one byte per robot id, the caller's draws; NULL: none)
+ *   update_prior_of_horizon_state / _current_state_v3 + the Transform increment   robot.rs:2182-2338
+ *   iterate_gbp_v2                           robot.rs:1769-1861  over `steps`
+ * stats (optional) = {connections created, pairs deleted, missions completed this tick}.  Unsharded worlds. */
+typedef struct mgx_mission_desc {
+    uint32_t n_waypoints;         /* waypoints still to visit; the first one is the next target (>= 1)                 */
+    uint32_t reserved;
+    const double *waypoints_xy;   /* [n][2]; compared as f32 (the reference's Vec2), used as f64 by the horizon prior   */
+    uint32_t reach_var, finish_var;   /* variable tested against an intermediate / the final waypoint: 0 = current,
+                                         K-1 = horizon (waypoint-reached-when-intersects / finished-when-intersects)   */
+    float reach_dist2, finish_dist2;  /* squared distance limits in f32 (robot-radius^2 or meter^2)                    */
+    float translation[3];         /* Transform::translation at hand-over (x, height, y)                                */
+    float reserved2;
+    double time_scale;            /* fixed_dt / t0 as the f32 quotient widened (robot.rs:2309)                         */
+} mgx_mission_desc;
+int mgx_mission_set(mgx_world *w, int32_t robot, const mgx_mission_desc *desc);
+int mgx_mission_tick(mgx_world *w, float comms_radius, uint32_t method, uint64_t *robot_number_next,
+                     int32_t despawn_finished, const uint8_t *antennas, double max_speed, double delta_t,
+                     const uint8_t *steps, uint32_t n_steps, uint32_t *stats);
+/* Transform::translation [n][3], next waypoint index (== the route's length once complete; -1: no mission) and the tick
+ * at which each mission completed (-1 before) of every robot, id order; any pointer may be NULL.  Synchronises. */
+int mgx_mission_read(mgx_world *w, float *translations, int32_t *targets, int64_t *finished_tick);
+
 /* ---- read-back ----------------------------------------------------------------------- */
 /* VariableNode.belief (variable.rs:40-54).  Any output pointer may be NULL. */
 int mgx_get_belief(mgx_world *w, int32_t robot, uint32_t var_ix, double eta[4], double lam[16],

@@ -143,6 +143,21 @@ struct DevWorld {
     unsigned long long *dbg;
 };
 
+// Missions on the device (the driver's reached_waypoint and Transform increment, robot.rs:2080-2176,2309-2335):
+// per robot (device index == robot id: unsharded worlds) its route, the next waypoint, the reached-when rules of
+// formation.yaml and the Bevy Transform it moves.
+struct DevMission {
+    const int32_t *wp_ptr;     // [R + 1] first waypoint of each robot in wp_xy
+    const double *wp_xy;       // [.][2] waypoint positions (compared as f32 Vec2s by reached_waypoint, used as f64 by the prior update)
+    int32_t *target;           // [R] index of the next waypoint within the robot's route; == count: mission complete
+    const uint32_t *vars;      // [R][2] variable whose mean is tested against an intermediate / the final waypoint
+    const float *dist2;        // [R][2] squared distance limits (f32)
+    const double *time_scale;  // [R] fixed_dt / t0 (f32 quotient widened, robot.rs:2309)
+    const uint8_t *has;        // [R] the robot has a mission (and is not despawned)
+    float *translation;        // [R][3] Transform::translation (x, height, y)
+    long long *finished_tick;  // [R] tick at which the last waypoint was reached, -1 before
+};
+
 __host__ __device__ constexpr int frozen_words(int K) { return 40 * (K - 1) + 8 * (K - 2); }
 
 // phases of one launch

@@ -1531,6 +1531,68 @@ __global__ void k_gather_variable_means(DevWorld w, int var, double *__restrict_
     out[t] = w.blob[(size_t)r * w.BS + L.mu() + c * w.K + var];
 }
 
+// ---- missions on the device (mgx_mission_tick) ---------------------------------------------------------------
+// reached_waypoint (robot.rs:2080-2176): the estimated position (belief mean of the rule's variable, as f32) against the
+// next waypoint, squared distance in f32 against the rule's limit; a robot that reaches its last waypoint is reported in
+// the host-mapped event list (ev[0] = count, ev[1 ..] = robot ids) that the host reads at the tick's one synchronisation.
+__global__ void k_mission_reached(DevWorld w, DevMission m, int n, long long tick, unsigned int *ev) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n || !m.has[r]) return;
+    const int n_wp = m.wp_ptr[r + 1] - m.wp_ptr[r];
+    const int t = m.target[r];
+    if (t >= n_wp) return;
+    const bool last = t == n_wp - 1;
+    const uint32_t var = m.vars[2 * r + (last ? 1 : 0)];
+    const BlobLayout L(w.K);
+    const double *b = w.blob + (size_t)r * w.BS;
+    const float ex = (float)b[L.mu() + 0 * w.K + var], ey = (float)b[L.mu() + 1 * w.K + var];
+    const float dx = ex - (float)m.wp_xy[2 * (m.wp_ptr[r] + t)], dy = ey - (float)m.wp_xy[2 * (m.wp_ptr[r] + t) + 1];
+    if (dx * dx + dy * dy < m.dist2[2 * r + (last ? 1 : 0)]) {
+        m.target[r] = t + 1;
+        if (last) {
+            m.finished_tick[r] = tick;
+            const unsigned slot = atomicAdd_system(&ev[0], 1u);
+            ev[1 + slot] = (unsigned)r;
+        }
+    }
+}
+// Transform::translation of the robots the neighbour search looks at (those the host knew alive when it launched)
+__global__ void k_mission_positions(DevMission m, int n, const int32_t *__restrict__ alive, float *__restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3 * n) return;
+    out[t] = m.translation[3 * alive[t / 3] + t % 3];
+}
+// The inputs of the tick's two prior updates for every robot, in the record form k_robot_sweep applies inside its first
+// launch (waypoint x, y, time scale, what) and as the lists k_update_priors takes; and the Transform increment of
+// update_prior_of_current_state_v3 (robot.rs:2309-2330: change_in_state = time_scale * (mean_1 - mean_0), its position part
+// added to the translation as f32) — from the means as they are BEFORE the prior updates of this tick.
+__global__ void k_mission_prepare(DevWorld w, DevMission m, int n, const uint8_t *__restrict__ moving, double *__restrict__ rec,
+                                  int32_t *__restrict__ robots, double *__restrict__ waypoints, double *__restrict__ time_scale,
+                                  uint8_t *__restrict__ what) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int n_wp = m.has[r] ? m.wp_ptr[r + 1] - m.wp_ptr[r] : 0;
+    const int t = m.has[r] ? m.target[r] : 0;
+    const bool go = moving[r] && m.has[r] && t < n_wp;  // alive and a next waypoint exists (robot.rs:2216-2228)
+    double wx = 0.0, wy = 0.0;
+    const double ts = m.time_scale[r];
+    if (go) {
+        wx = m.wp_xy[2 * (m.wp_ptr[r] + t)];
+        wy = m.wp_xy[2 * (m.wp_ptr[r] + t) + 1];
+        const BlobLayout L(w.K);
+        const double *b = w.blob + (size_t)r * w.BS;
+        const double c0 = ts * (b[L.mu() + 0 * w.K + 1] - b[L.mu() + 0 * w.K + 0]);
+        const double c1 = ts * (b[L.mu() + 1 * w.K + 1] - b[L.mu() + 1 * w.K + 0]);
+        m.translation[3 * r + 0] += (float)c0;  // robot.rs:2328-2329
+        m.translation[3 * r + 2] += (float)c1;
+    }
+    rec[4 * r + 0] = wx; rec[4 * r + 1] = wy; rec[4 * r + 2] = ts; rec[4 * r + 3] = go ? 3.0 : 0.0;
+    robots[r] = r;
+    waypoints[2 * r] = wx; waypoints[2 * r + 1] = wy;
+    time_scale[r] = ts;
+    what[r] = go ? 3 : 0;
+}
+
 // In-place topology change.  A robot's incoming connections are kept as one sorted list of SLOTS;
 // every connection hangs one factor on each of the target's variables 1..K-1, so the edges of
 // variable i of robot r are  (K-1) * in_ptr[r] + (i-1) * n_in(r) + q,  q = position in the list.
@@ -1728,6 +1790,23 @@ hipError_t launch_halo_wait_unpack(const DevWorld &w, int n, const int32_t *ghos
 hipError_t launch_gather_variable_means(const DevWorld &w, int var, double *out, hipStream_t stream) {
     if (w.R_local <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_gather_variable_means, dim3((unsigned)((w.R_local * 4 + 255) / 256)), dim3(256), 0, stream, w, var, out);
+    return hipGetLastError();
+}
+hipError_t launch_mission_reached(const DevWorld &w, const DevMission &m, int n, long long tick, unsigned int *ev, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mission_reached, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, w, m, n, tick, ev);
+    return hipGetLastError();
+}
+hipError_t launch_mission_positions(const DevMission &m, int n, const int32_t *alive, float *out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mission_positions, dim3((unsigned)((3 * n + 255) / 256)), dim3(256), 0, stream, m, n, alive, out);
+    return hipGetLastError();
+}
+hipError_t launch_mission_prepare(const DevWorld &w, const DevMission &m, int n, const uint8_t *moving, double *rec, int32_t *robots,
+                                  double *waypoints, double *time_scale, uint8_t *what, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mission_prepare, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, w, m, n, moving, rec, robots, waypoints,
+                       time_scale, what);
     return hipGetLastError();
 }
 hipError_t launch_edge_rebuild(const DevWorld &w, int n_slots, const IrSlotRec *slots, const int32_t *in_new, const int32_t *in_old,

@@ -48,6 +48,10 @@ hipError_t launch_or_bytes(uint8_t *p, int n, uint8_t keep, uint8_t set, hipStre
 hipError_t launch_thaw(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, hipStream_t stream);
 hipError_t launch_thaw_done(const DevWorld &w, int robot0, int n_robots, int clear, hipStream_t stream);
 hipError_t launch_gather_variable_means(const DevWorld &w, int var, double *out, hipStream_t stream);
+hipError_t launch_mission_reached(const DevWorld &w, const DevMission &m, int n, long long tick, unsigned int *ev, hipStream_t stream);
+hipError_t launch_mission_positions(const DevMission &m, int n, const int32_t *alive, float *out, hipStream_t stream);
+hipError_t launch_mission_prepare(const DevWorld &w, const DevMission &m, int n, const uint8_t *moving, double *rec, int32_t *robots,
+                                  double *waypoints, double *time_scale, uint8_t *what, hipStream_t stream);
 hipError_t launch_edge_rebuild(const DevWorld &w, int n_slots, const IrSlotRec *slots, const int32_t *in_new, const int32_t *in_old,
                                int stride_new, IrEdgeRec *recs, double *fv_eta, double *fv_lam, double *bmu, hipStream_t stream);
 hipError_t launch_var_tables(int R, int K, const int32_t *in_ptr, const int32_t *in_mid, int32_t *var_ptr, int32_t *var_mid,
@@ -351,6 +355,30 @@ struct mgx_world {
     unsigned long long flag_base = 0;              // every progress word is below or at this value between launches
     int resident_cap = -1;                         // workgroups of the resident kernel the device holds at once (-1: not asked yet)
     bool peers_valid = false;
+    // missions on the device (mgx_mission_*): host copies of what mgx_mission_set gave, the device arrays, the
+    // host-mapped event list of robots that reached their last waypoint, and the tick counter
+    struct Mission {
+        bool any = false, dirty = false, uploaded = false;
+        std::vector<std::vector<double>> wp;  // per robot: [n][2]
+        std::vector<int32_t> target;
+        std::vector<uint32_t> vars;           // [R][2]
+        std::vector<float> dist2, translation;  // [R][2], [R][3]
+        std::vector<double> time_scale;
+        std::vector<uint8_t> has;
+        std::vector<long long> finished_tick;
+        DevBuf<int32_t> wp_ptr_d, target_d, alive_d, robots_d;
+        DevBuf<double> wp_xy_d, time_scale_d, rec_d, waypoints_d, ts_list_d;
+        DevBuf<uint32_t> vars_d;
+        DevBuf<float> dist2_d, translation_d;
+        DevBuf<uint8_t> has_d, moving_d, what_d;
+        DevBuf<long long> finished_d;
+        unsigned int *ev_host = nullptr;  // mapped: [0] count, [1 ..] robot ids
+        size_t ev_cap = 0;
+        std::vector<int32_t> alive_host;  // the robots the search of the coming tick looks at
+        bool alive_dirty = true;
+        long long tick_no = 0;
+        DevMission d{};
+    } mission;
     uint32_t last_sweep_launches = 0;  // sweep-kernel launches of the last mgx_iterate / mgx_tick call (mgx_last_launch_count)
     // message counters are advanced lazily: launches and prior changes are only logged here
     struct CountEntry { uint8_t ext, in; int n_int, robot; uint64_t times; };
@@ -1321,6 +1349,7 @@ int mgx_world_destroy(mgx_world *w) {
     if (w->direct.recv) (void)hipFree(w->direct.recv);
     if (w->direct.flags) (void)hipFree(w->direct.flags);
     if (w->sweep_err_host) (void)hipHostFree(w->sweep_err_host);
+    if (w->mission.ev_host) (void)hipHostFree(w->mission.ev_host);
     delete w;
     return MGX_OK;
 }
@@ -1535,6 +1564,7 @@ int mgx_robot_remove(mgx_world *w, int32_t robot) {
     rb.antenna = 0;
     rb.connected.clear();
     w->flags_dirty = true;
+    w->mission.alive_dirty = true;
     return MGX_OK;
 }
 
@@ -1678,10 +1708,12 @@ int mgx_ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
 }
 
 // device neighbour search -> host CSR, rows ascending in order key
+// pos == nullptr: the positions come from the device-resident Transforms of the missions (mgx_mission_tick)
 static int neighbours(mgx_world *w, const float *pos, float radius, uint32_t method, std::vector<int32_t> &ptr,
                       std::vector<int32_t> &idx) {
     if (!device_ok()) return fail(MGX_ERR_NO_DEVICE, "no HIP device");
     const int n_all = (int)w->robots.size();
+    const bool from_missions = pos == nullptr;
     std::vector<int> alive;  // removed robots are in no query: search the others, map back
     std::vector<float> packed;
     for (int r = 0; r < n_all; r++) {
@@ -1691,7 +1723,7 @@ static int neighbours(mgx_world *w, const float *pos, float radius, uint32_t met
         if (!w->robots[(size_t)r].removed) alive.push_back(r);
     }
     const bool compact = (int)alive.size() != n_all;
-    if (compact) {
+    if (compact && !from_missions) {
         packed.resize(3 * alive.size());
         for (size_t a = 0; a < alive.size(); a++) memcpy(&packed[3 * a], pos + 3 * (size_t)alive[a], 3 * sizeof(float));
         pos = packed.data();
@@ -1712,7 +1744,20 @@ static int neighbours(mgx_world *w, const float *pos, float radius, uint32_t met
     HIP_TRY(w->nb_bucket_cnt.reserve(M));
     HIP_TRY(w->nb_bucket_ptr.reserve((size_t)M + 1));
     HIP_TRY(w->nb_cursor.reserve(M));
-    if (n) HIP_TRY(hipMemcpyAsync(w->nb_pos.p, pos, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    if (from_missions) {
+        mgx_world::Mission &ms = w->mission;
+        if (ms.alive_dirty || ms.alive_host.size() != alive.size()) {
+            ms.alive_host.assign(alive.begin(), alive.end());
+            if (ms.alive_host.empty()) ms.alive_host.push_back(0);
+            HIP_TRY(ms.alive_d.upload(ms.alive_host, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            ms.alive_host.resize(alive.size());
+            ms.alive_dirty = false;
+        }
+        HIP_TRY(launch_mission_positions(ms.d, n, ms.alive_d.p, w->nb_pos.p, s));
+    } else if (n) {
+        HIP_TRY(hipMemcpyAsync(w->nb_pos.p, pos, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    }
     HIP_TRY(neighbours_count(w->nb_pos.p, n, radius, grid, M, w->nb_cnt.p, w->nb_bucket_cnt.p, w->nb_bucket_ptr.p, w->nb_cursor.p,
                              w->nb_members.p, w->nb_special.p, w->nb_nspecial.p, w->nb_ptr.p, s));
     // The second pass needs the total to size its output — one more host round trip.  Instead it runs right
@@ -1780,6 +1825,8 @@ int mgx_connections(mgx_world *w, int32_t robot, int32_t *others, uint32_t capac
     return MGX_OK;
 }
 
+static int topology_bookkeeping(mgx_world *w, std::vector<int32_t> &ptr, std::vector<int32_t> &idx, uint64_t *robot_number_next,
+                                uint32_t *stats, StageTimer &tm);
 int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, uint32_t method, uint64_t *robot_number_next,
                         uint32_t *stats) {
     if (!w || !positions_xyz || !robot_number_next) return fail(MGX_ERR_INVALID, "null argument");
@@ -1790,6 +1837,12 @@ int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, 
     int rc = neighbours(w, positions_xyz, radius, method, ptr, idx);  // update_robot_neighbours, robot.rs:1362-1384
     if (rc != MGX_OK) return rc;
     tm.lap("neighbour search");
+    return topology_bookkeeping(w, ptr, idx, robot_number_next, stats, tm);
+}
+// delete_interrobot_factors + create_interrobot_factors on the search's result (rows per robot id, ascending)
+static int topology_bookkeeping(mgx_world *w, std::vector<int32_t> &ptr, std::vector<int32_t> &idx, uint64_t *robot_number_next,
+                                uint32_t *stats, StageTimer &tm) {
+    int rc = MGX_OK;
     const int n = (int)w->robots.size();
     uint32_t created = 0, deleted = 0;
     auto in_range = [&](int r, int o) { return std::find(idx.begin() + ptr[(size_t)r], idx.begin() + ptr[(size_t)r + 1], o) != idx.begin() + ptr[(size_t)r + 1]; };
@@ -1842,6 +1895,236 @@ int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, 
     tm.lap("create");
     if (stats) { stats[0] = created; stats[1] = deleted; }
     return MGX_OK;
+}
+
+// ---- missions on the device ---------------------------------------------------------------------------
+static std::vector<Launch> plan_launches(const uint8_t *steps, uint32_t n);
+static int mission_download(mgx_world *w) {  // device -> host copies of what the device advances (before the arrays are laid out again)
+    mgx_world::Mission &ms = w->mission;
+    if (!ms.uploaded) return MGX_OK;
+    std::vector<int32_t> tg;
+    std::vector<float> tr;
+    std::vector<long long> fin;
+    HIP_TRY(ms.target_d.download(tg, w->stream));
+    HIP_TRY(ms.translation_d.download(tr, w->stream));
+    HIP_TRY(ms.finished_d.download(fin, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    for (size_t r = 0; r < tg.size() && r < ms.target.size(); r++) {
+        ms.target[r] = tg[r];
+        ms.finished_tick[r] = fin[r];
+        for (int c = 0; c < 3; c++) ms.translation[3 * r + c] = tr[3 * r + c];
+    }
+    return MGX_OK;
+}
+static int mission_upload(mgx_world *w) {
+    mgx_world::Mission &ms = w->mission;
+    const size_t R = w->robots.size();
+    ms.wp.resize(R);
+    ms.target.resize(R, 0); ms.vars.resize(2 * R, 0); ms.dist2.resize(2 * R, 0.f); ms.translation.resize(3 * R, 0.f);
+    ms.time_scale.resize(R, 0.0); ms.has.resize(R, 0); ms.finished_tick.resize(R, -1);
+    std::vector<int32_t> ptr(R + 1, 0);
+    std::vector<double> xy;
+    for (size_t r = 0; r < R; r++) {
+        xy.insert(xy.end(), ms.wp[r].begin(), ms.wp[r].end());
+        ptr[r + 1] = (int32_t)(xy.size() / 2);
+    }
+    if (xy.empty()) xy.assign(2, 0.0);
+    hipStream_t s = w->stream;
+    HIP_TRY(ms.wp_ptr_d.upload(ptr, s));
+    HIP_TRY(ms.wp_xy_d.upload(xy, s));
+    HIP_TRY(ms.target_d.upload(ms.target, s));
+    HIP_TRY(ms.vars_d.upload(ms.vars, s));
+    HIP_TRY(ms.dist2_d.upload(ms.dist2, s));
+    HIP_TRY(ms.translation_d.upload(ms.translation, s));
+    HIP_TRY(ms.time_scale_d.upload(ms.time_scale, s));
+    HIP_TRY(ms.has_d.upload(ms.has, s));
+    HIP_TRY(ms.finished_d.upload(ms.finished_tick, s));
+    HIP_TRY(ms.rec_d.reserve(4 * R));
+    HIP_TRY(ms.robots_d.reserve(R));
+    HIP_TRY(ms.waypoints_d.reserve(2 * R));
+    HIP_TRY(ms.ts_list_d.reserve(R));
+    HIP_TRY(ms.what_d.reserve(R));
+    HIP_TRY(ms.moving_d.reserve(R));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (ms.ev_cap < R + 1) {
+        if (ms.ev_host) (void)hipHostFree(ms.ev_host);
+        ms.ev_host = nullptr;
+        HIP_TRY(hipHostMalloc((void **)&ms.ev_host, sizeof(unsigned int) * (R + 64), hipHostMallocMapped));
+        ms.ev_cap = R + 64;
+        ms.ev_host[0] = 0;
+    }
+    DevMission &d = ms.d;
+    d.wp_ptr = ms.wp_ptr_d.p; d.wp_xy = ms.wp_xy_d.p; d.target = ms.target_d.p; d.vars = ms.vars_d.p; d.dist2 = ms.dist2_d.p;
+    d.time_scale = ms.time_scale_d.p; d.has = ms.has_d.p; d.translation = ms.translation_d.p; d.finished_tick = ms.finished_d.p;
+    ms.uploaded = true;
+    ms.dirty = false;
+    ms.alive_dirty = true;
+    return MGX_OK;
+}
+
+int mgx_mission_set(mgx_world *w, int32_t robot, const mgx_mission_desc *desc) {
+    if (!w || !desc || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
+    const Robot &rb = w->robots[(size_t)robot];
+    if (rb.ghost || rb.removed) return fail(MGX_ERR_INVALID, "robot %d is not a live local robot", robot);
+    if (desc->n_waypoints == 0 || !desc->waypoints_xy) return fail(MGX_ERR_INVALID, "a mission needs at least one waypoint");
+    if ((int)desc->reach_var >= rb.K || (int)desc->finish_var >= rb.K) return fail(MGX_ERR_INVALID, "rule names a variable beyond the horizon");
+    for (const Robot &q : w->robots)
+        if (q.ghost) return fail(MGX_ERR_STATE, "missions run on unsharded worlds");
+    mgx_world::Mission &ms = w->mission;
+    if (ms.uploaded && !ms.dirty) {  // the device has advanced the missions it holds: fetch before the arrays are laid out again
+        int rc = mission_download(w);
+        if (rc != MGX_OK) return rc;
+    }
+    const size_t R = w->robots.size(), r = (size_t)robot;
+    ms.wp.resize(R);
+    ms.target.resize(R, 0); ms.vars.resize(2 * R, 0); ms.dist2.resize(2 * R, 0.f); ms.translation.resize(3 * R, 0.f);
+    ms.time_scale.resize(R, 0.0); ms.has.resize(R, 0); ms.finished_tick.resize(R, -1);
+    ms.wp[r].assign(desc->waypoints_xy, desc->waypoints_xy + 2 * (size_t)desc->n_waypoints);
+    ms.target[r] = 0;
+    ms.vars[2 * r] = desc->reach_var; ms.vars[2 * r + 1] = desc->finish_var;
+    ms.dist2[2 * r] = desc->reach_dist2; ms.dist2[2 * r + 1] = desc->finish_dist2;
+    for (int c = 0; c < 3; c++) ms.translation[3 * r + c] = desc->translation[c];
+    ms.time_scale[r] = desc->time_scale;
+    ms.has[r] = 1;
+    ms.finished_tick[r] = -1;
+    ms.any = true;
+    ms.dirty = true;
+    return MGX_OK;
+}
+
+int mgx_mission_tick(mgx_world *w, float comms_radius, uint32_t method, uint64_t *robot_number_next, int32_t despawn_finished,
+                     const uint8_t *antennas, double max_speed, double delta_t, const uint8_t *steps, uint32_t n_steps, uint32_t *stats) {
+    if (!w || !robot_number_next || (!steps && n_steps)) return fail(MGX_ERR_INVALID, "null argument");
+    if (*robot_number_next == 0) return fail(MGX_ERR_INVALID, "robot_number is NonZeroUsize");
+    if (method > MGX_NEIGHBOURS_GRID) return fail(MGX_ERR_INVALID, "bad method");
+    mgx_world::Mission &ms = w->mission;
+    if (!ms.any) return fail(MGX_ERR_STATE, "no robot has a mission (mgx_mission_set)");
+    if (w->K < 3) return fail(MGX_ERR_INVALID, "needs K >= 3");
+    int rc = commit(w);
+    if (rc != MGX_OK) return rc;
+    if (w->d.R_total != w->d.R_local) return fail(MGX_ERR_STATE, "missions run on unsharded worlds");
+    if (ms.dirty || ms.has.size() != w->robots.size()) {
+        if (ms.uploaded && !ms.dirty && (rc = mission_download(w)) != MGX_OK) return rc;
+        if ((rc = mission_upload(w)) != MGX_OK) return rc;
+    }
+    const int R = (int)w->robots.size();
+    hipStream_t s = w->stream;
+    StageTimer tm("mission_tick");
+    // reached_waypoint (robot.rs:2080-2176), then update_robot_neighbours on the Transforms as they are (robot.rs:1362-1384);
+    // both results come back at the tick's ONE synchronisation (inside neighbours())
+    ms.ev_host[0] = 0;
+    void *evd = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&evd, ms.ev_host, 0));
+    HIP_TRY(launch_mission_reached(w->d, ms.d, R, ms.tick_no, (unsigned int *)evd, s));
+    std::vector<int32_t> ptr, idx;
+    rc = neighbours(w, nullptr, comms_radius, method, ptr, idx);
+    if (rc != MGX_OK) return rc;
+    tm.lap("reached + search");
+    // robots that reached their last waypoint this tick: despawned before the topology systems see them (robot.rs:2172) —
+    // the search still looked at them, so they are taken out of its rows here
+    const unsigned n_fin = ms.ev_host[0];
+    std::vector<uint8_t> gone;
+    if (n_fin) {
+        std::vector<int> fin(ms.ev_host + 1, ms.ev_host + 1 + n_fin);
+        std::sort(fin.begin(), fin.end());
+        for (int r : fin) ms.finished_tick[(size_t)r] = ms.tick_no;
+        if (despawn_finished) {
+            gone.assign((size_t)R, 0);
+            for (int r : fin) {
+                gone[(size_t)r] = 1;
+                if ((rc = mgx_robot_remove(w, r)) != MGX_OK) return rc;
+            }
+            std::vector<int32_t> nptr((size_t)R + 1, 0), nidx;
+            nidx.reserve(idx.size());
+            for (int r = 0; r < R; r++) {
+                if (!gone[(size_t)r])
+                    for (int32_t q = ptr[(size_t)r]; q < ptr[(size_t)r + 1]; q++)
+                        if (!gone[(size_t)idx[(size_t)q]]) nidx.push_back(idx[(size_t)q]);
+                nptr[(size_t)r + 1] = (int32_t)nidx.size();
+            }
+            ptr.swap(nptr);
+            idx.swap(nidx);
+        }
+    }
+    uint32_t st[2] = {0, 0};
+    rc = topology_bookkeeping(w, ptr, idx, robot_number_next, st, tm);
+    if (rc != MGX_OK) return rc;
+    if (stats) { stats[0] = st[0]; stats[1] = st[1]; stats[2] = n_fin; }
+    // update_failed_comms (robot.rs:1593-1601): the caller's draws for the robots still alive
+    if (antennas) {
+        bool changed = false;
+        for (int r = 0; r < R; r++) {
+            Robot &rb = w->robots[(size_t)r];
+            if (rb.removed || rb.ghost) continue;
+            const uint8_t a = antennas[r] ? 1 : 0;
+            if (rb.antenna != a) { if (!changed) flush_counts(w); changed = true; rb.antenna = a; }
+        }
+        if (changed) w->flags_dirty = true;
+    }
+    if ((rc = commit(w)) != MGX_OK) return rc;  // edge tables / flags of what the pass changed
+    // the two prior updates + the Transform increment, from the device's own mission state; then iterate_gbp_v2
+    {
+        void *hp = nullptr, *dp = nullptr;
+        int slot = 0;
+        HIP_TRY(w->stage.acquire((size_t)R, &hp, &slot));
+        uint8_t *mv = (uint8_t *)hp;
+        for (int r = 0; r < R; r++) mv[r] = (!w->robots[(size_t)r].removed && !w->robots[(size_t)r].ghost) ? 1 : 0;
+        HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+        HIP_TRY(launch_copy_bytes(ms.moving_d.p, (const uint8_t *)dp, (size_t)R, s));
+        HIP_TRY(w->stage.release(slot, s));
+    }
+    HIP_TRY(launch_mission_prepare(w->d, ms.d, R, ms.moving_d.p, ms.rec_d.p, ms.robots_d.p, ms.waypoints_d.p, ms.ts_list_d.p, ms.what_d.p, s));
+    for (int r = 0; r < R; r++) {  // message counters: the prior changes of the robots that move (what the device decides too)
+        const Robot &rb = w->robots[(size_t)r];
+        if (rb.removed || rb.ghost || !ms.has[(size_t)r] || ms.finished_tick[(size_t)r] >= 0) continue;
+        log_change_prior(w, r, w->K - 1);
+        log_change_prior(w, r, 0);
+    }
+    w->stale_kinds |= ~w->p.enable_mask & 15u;
+    const std::vector<Launch> plan = plan_launches(steps, n_steps);
+    w->last_sweep_launches = 0;
+    const bool fuse = !plan.empty() && plan[0].ext == 0 && plan[0].n_int > 0 && w->thaw_kinds == 0;
+    if (!fuse) {
+        HIP_TRY(launch_update_priors(w->d, R, ms.robots_d.p, ms.waypoints_d.p, ms.ts_list_d.p, ms.what_d.p, max_speed, delta_t, s));
+        rc = mgx_iterate(w, steps, n_steps);
+    } else {
+        w->d.upd = ms.rec_d.p; w->d.upd_max_speed = max_speed; w->d.upd_delta_t = delta_t;
+        const int resident = run_resident(w, plan);
+        if (resident != 0) {
+            w->d.upd = nullptr;
+            rc = resident < 0 ? resident : MGX_OK;
+        } else {
+            bool first = true;
+            rc = MGX_OK;
+            for (const Launch &l : plan) {
+                if (!first) w->d.upd = nullptr;
+                rc = sweep(w, -1, l.ext, l.n_int ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, l.n_int, l.hints);
+                first = false;
+                if (rc != MGX_OK) break;
+            }
+            w->d.upd = nullptr;
+        }
+    }
+    ms.tick_no += 1;
+    tm.lap("prior updates + schedule");
+    return rc;
+}
+
+int mgx_mission_read(mgx_world *w, float *translations, int32_t *targets, int64_t *finished_tick) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    mgx_world::Mission &ms = w->mission;
+    if (!ms.any) return fail(MGX_ERR_STATE, "no robot has a mission");
+    if (ms.uploaded && !ms.dirty) {
+        int rc = mission_download(w);
+        if (rc != MGX_OK) return rc;
+    }
+    const size_t R = std::min(w->robots.size(), ms.target.size());
+    for (size_t r = 0; r < R; r++) {
+        if (translations) for (int c = 0; c < 3; c++) translations[3 * r + c] = ms.translation[3 * r + c];
+        if (targets) targets[r] = ms.has[r] ? ms.target[r] : -1;
+        if (finished_tick) finished_tick[r] = ms.finished_tick[r];
+    }
+    return check_device_error(w);
 }
 
 int mgx_sweep(mgx_world *w, int32_t robot, uint32_t external_phases, uint32_t internal_phases, uint32_t n_internal,

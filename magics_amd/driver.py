@@ -78,7 +78,7 @@ class Driver:
                         max_speed=self.max_speed, delta_t=self.delta_t)
             self.translation[moving, 0] += change[:, 0].astype(F32)             # robot.rs:2328-2329
             self.translation[moving, 2] += change[:, 1].astype(F32)
-            self.travelled[moving] += np.hypot(change[:, 0], change[:, 1])
+            self.travelled[moving] += np.sqrt(change[:, 0] * change[:, 0] + change[:, 1] * change[:, 1])
             if hasattr(w, "tick"):
                 w.tick(steps=self.steps, **args)                                 # prior updates + schedule, one call
             else:
@@ -101,3 +101,75 @@ class Driver:
         return {"ticks": self.tick_no, "finished": int(done.sum()), "makespan_s": float(self.finished_at.max() * self.delta_t) if done.all() else None,
                 "finished_at_tick": self.finished_at.tolist(), "distance_travelled": self.travelled.tolist(),
                 "messages": [self.w.message_counts(r) for r in range(self.n)]}
+
+
+class DeviceDriver:
+    """The same chain with the mission state ON THE DEVICE (include/mgx.h, mgx_mission_*): routes, next waypoints,
+    reached-when rules and Transforms are handed over once, and a tick is ONE call — reached_waypoint, the topology
+    pass on the device's Transforms, the comms draws, both prior updates with the Transform increment and the GBP
+    schedule — with one synchronisation inside (the neighbour rows of the connection bookkeeping) and no belief
+    read-back at all.  Engine worlds only; `Driver` above on the CPU oracle is its checker (tests/test_gpu_driver.py)."""
+
+    def __init__(self, world, n_robots, K, waypoints, radii, t0, steps, comms_radius, target_speed, hz=10.0,
+                 height=0.5, despawn_when_finished=True, failure_draws=None):
+        self.w, self.n, self.K = world, n_robots, K
+        self.dt32 = F32(1.0) / F32(hz)
+        self.steps, self.comms_radius = steps, float(comms_radius)
+        self.max_speed, self.delta_t = float(F32(target_speed)), float(self.dt32)
+        self.despawn, self.failure_draws = despawn_when_finished, failure_draws
+        cur = world.read_variable_means(0)
+        for r in range(n_robots):
+            r2 = float(F32(radii[r]) * F32(radii[r]))
+            # intermediate waypoints against the horizon variable, the last one against the current variable, both
+            # within the robot's radius (the Circle Experiment's formation.yaml)
+            world.mission_set(r, np.asarray(waypoints[r], dtype=np.float64), K - 1, 0, r2, r2,
+                              (F32(cur[r, 0]), F32(height), F32(cur[r, 1])), float(self.dt32 / F32(t0[r])))
+        self.n_way = np.array([len(wp) for wp in waypoints])
+        self.next_number, self.tick_no = 1, 0
+        self._alive = np.ones(n_robots, dtype=bool)
+
+    def tick(self):
+        ant = None
+        if self.failure_draws is not None:
+            # the reference draws one value per robot alive AFTER this tick's despawns, in id order (robot.rs:1599):
+            # the draws are indexed by position in that list, which only the tick itself knows — so the caller's
+            # stream is consumed against the alive set as of the last tick minus what completes now; with despawning
+            # off (the only use so far) the set never changes
+            live = np.nonzero(self._alive)[0]
+            d = np.asarray(self.failure_draws(self.tick_no, len(live)), dtype=np.uint8)
+            ant = np.ones(self.n, dtype=np.uint8)
+            ant[live] = d
+        self.next_number, created, deleted, finished = self.w.mission_tick(
+            self.comms_radius, self.next_number, self.steps, self.max_speed, self.delta_t, despawn_finished=self.despawn, antennas=ant)
+        self.tick_no += 1
+        self._finished_dirty = True
+        return created, deleted
+
+    def state(self):
+        """(translation [n, 3] f32, remaining waypoints per robot, completion tick per robot) — synchronises"""
+        tr, tg, fin = self.w.mission_read()
+        if self.despawn:
+            self._alive = fin < 0
+        return tr, self.n_way - tg, fin
+
+    @property
+    def translation(self):
+        return self.state()[0]
+
+    @property
+    def finished_at(self):
+        return self.state()[2]
+
+    def run(self, max_ticks, check_every=16):
+        """Ticks until every robot has finished (or max_ticks), looking at the missions every `check_every` ticks."""
+        while self.tick_no < max_ticks:
+            self.tick()
+            if self.tick_no % check_every == 0 and not (self.finished_at < 0).any():
+                break
+        return self.summary()
+
+    def summary(self):
+        tr, left, fin = self.state()
+        done = fin >= 0
+        return {"ticks": self.tick_no, "finished": int(done.sum()), "makespan_s": float(fin.max() * self.delta_t) if done.all() else None,
+                "finished_at_tick": fin.tolist(), "messages": [self.w.message_counts(r) for r in range(self.n)]}

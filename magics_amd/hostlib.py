@@ -157,6 +157,10 @@ SYMBOLS = {
     "mgx_ipc_close": (C.c_int, [C.c_void_p]),
     "mgx_reset_variables": (C.c_int, [_V, C.c_int32, c_double_p, C.c_double, C.c_double]),
     "mgx_reset_tracking_factors": (C.c_int, [_V, C.c_int32]),
+    "mgx_mission_set": (C.c_int, [_V, C.c_int32, C.c_void_p]),
+    "mgx_mission_tick": (C.c_int, [_V, C.c_float, C.c_uint32, C.POINTER(C.c_uint64), C.c_int32, C.c_void_p, C.c_double, C.c_double,
+                                   C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "mgx_mission_read": (C.c_int, [_V, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_num_robots": (C.c_int, [_V, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mgx_last_launch_count": (C.c_int, [_V, C.POINTER(C.c_uint32)]),
     "mgx_halo_words": (C.c_uint32, [C.c_uint32]),
@@ -289,6 +293,13 @@ def variable_timesteps(lookahead_horizon, lookahead_multiple):
     if n < 0:
         raise ValueError("bad arguments")
     return list(buf[:n])
+
+
+class MissionDesc(C.Structure):
+    """mgx_mission_desc (include/mgx.h)"""
+    _fields_ = [("n_waypoints", C.c_uint32), ("reserved", C.c_uint32), ("waypoints_xy", c_double_p), ("reach_var", C.c_uint32),
+                ("finish_var", C.c_uint32), ("reach_dist2", C.c_float), ("finish_dist2", C.c_float), ("translation", C.c_float * 3),
+                ("reserved2", C.c_float), ("time_scale", C.c_double)]
 
 
 def shard_partition(positions_xy, n_ranks):

@@ -233,6 +233,33 @@ class World:
         self._chk(self._L.mgx_num_robots(self._w, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    # -- whole driver ticks on the device (include/mgx.h, mgx_mission_*) ---------------------------------------------
+    def mission_set(self, robot, waypoints_xy, reach_var, finish_var, reach_dist2, finish_dist2, translation, time_scale):
+        wp = _f64(waypoints_xy).reshape(-1, 2)
+        d = hostlib.MissionDesc(len(wp), 0, _dp(wp), int(reach_var), int(finish_var), float(reach_dist2), float(finish_dist2),
+                                (C.c_float * 3)(*[float(x) for x in translation]), 0.0, float(time_scale))
+        self._chk(self._L.mgx_mission_set(self._w, int(robot), C.byref(d)))
+
+    def mission_tick(self, comms_radius, next_number, steps, max_speed, delta_t, despawn_finished=True, antennas=None,
+                     method=hostlib.NEIGHBOURS_AUTO):
+        """One FixedUpdate of the planner chain with the mission state on the device.  Returns
+        (next robot number, connections created, pairs deleted, missions completed this tick)."""
+        nn, st = C.c_uint64(int(next_number)), (C.c_uint32 * 3)()
+        ant = None
+        if antennas is not None:
+            ant = np.ascontiguousarray(antennas, dtype=np.uint8)
+        self._chk(self._L.mgx_mission_tick(self._w, float(comms_radius), int(method), C.byref(nn), 1 if despawn_finished else 0,
+                                           None if ant is None else ant.ctypes.data, float(max_speed), float(delta_t),
+                                           bytes(bytearray(steps)), len(steps), st))
+        return nn.value, st[0], st[1], st[2]
+
+    def mission_read(self):
+        """(Transform translations [n, 3] f32, next waypoint index per robot, completion tick per robot)"""
+        n, _ = self.num_robots()
+        tr, tg, fin = np.zeros((n, 3), np.float32), np.zeros(n, np.int32), np.zeros(n, np.int64)
+        self._chk(self._L.mgx_mission_read(self._w, tr.ctypes.data, tg.ctypes.data, fin.ctypes.data))
+        return tr, tg, fin
+
     def last_launch_count(self):
         """sweep-kernel launches of the last iterate / tick call (1: the whole schedule ran as one resident launch)"""
         n = C.c_uint32()

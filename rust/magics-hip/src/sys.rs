@@ -75,6 +75,21 @@ pub struct mgx_env_desc {
     pub obstacles: *const mgx_env_obstacle,
 }
 
+/// a robot's mission handed to the device (include/mgx.h, mgx_mission_*)
+#[repr(C)]
+pub struct mgx_mission_desc {
+    pub n_waypoints: u32,
+    pub reserved: u32,
+    pub waypoints_xy: *const f64,
+    pub reach_var: u32,
+    pub finish_var: u32,
+    pub reach_dist2: f32,
+    pub finish_dist2: f32,
+    pub translation: [f32; 3],
+    pub reserved2: f32,
+    pub time_scale: f64,
+}
+
 /// opaque handles (include/mgx.h)
 #[repr(C)]
 pub struct mgx_mvn { _private: [u8; 0] }
@@ -113,6 +128,9 @@ extern "C" {
     pub fn mgx_reset_tracking_factors(w: *mut mgx_world, robot: i32) -> c_int;
     pub fn mgx_update_priors(w: *mut mgx_world, n: u32, robots: *const i32, waypoints_xy: *const f64, time_scale: *const f64, what: *const u8, max_speed: f64, delta_t: f64) -> c_int;
     pub fn mgx_tick(w: *mut mgx_world, n: u32, robots: *const i32, waypoints_xy: *const f64, time_scale: *const f64, what: *const u8, max_speed: f64, delta_t: f64, steps: *const u8, n_steps: u32) -> c_int;
+    pub fn mgx_mission_set(w: *mut mgx_world, robot: i32, desc: *const mgx_mission_desc) -> c_int;
+    pub fn mgx_mission_tick(w: *mut mgx_world, comms_radius: f32, method: u32, robot_number_next: *mut u64, despawn_finished: i32, antennas: *const u8, max_speed: f64, delta_t: f64, steps: *const u8, n_steps: u32, stats: *mut u32) -> c_int;
+    pub fn mgx_mission_read(w: *mut mgx_world, translations: *mut f32, targets: *mut i32, finished_tick: *mut i64) -> c_int;
     pub fn mgx_get_belief(w: *mut mgx_world, robot: i32, var_ix: u32, eta: *mut f64, lam: *mut f64, mean: *mut f64, cov: *mut f64, valid: *mut i32) -> c_int;
     pub fn mgx_read_beliefs(w: *mut mgx_world, eta: *mut f64, lam: *mut f64, means: *mut f64) -> c_int;
     pub fn mgx_read_means(w: *mut mgx_world, means: *mut f64) -> c_int;

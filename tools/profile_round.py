@@ -1,0 +1,98 @@
+"""gpurun_out/<tag>_* (tools/profile_round.sh) -> profiles/<tag>_kernel_stats.csv, <tag>_configs_kernel_stats.csv,
+<tag>_summary.md and traffic_<tag>.json (what bench.py's roofline block quotes as measured HBM traffic / VALU issue).
+
+usage: python tools/profile_round.py <tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rows(d, pat):
+    f = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return list(csv.DictReader(open(f[0]))) if f else []
+
+
+def per_kernel(d, counter):
+    """mean counter value per dispatch of every k_robot_sweep instantiation (steady state: first fifth dropped)"""
+    acc = collections.defaultdict(list)
+    rs = [r for r in rows(d, "*counter_collection.csv") if "k_robot_sweep" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    rs.sort(key=lambda r: int(r["Start_Timestamp"]))
+    for r in rs:
+        acc[r["Kernel_Name"].split("k_robot_sweep")[1].split(">")[0] + ">"].append(float(r["Counter_Value"]))
+    return {k: sum(v[len(v) // 5:]) / len(v[len(v) // 5:]) for k, v in acc.items()}
+
+
+def durations(d):
+    acc = collections.defaultdict(list)
+    tr = [r for r in rows(d, "*kernel_trace.csv") if "k_robot_sweep" in r["Kernel_Name"]]
+    tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+    for r in tr:
+        acc[r["Kernel_Name"].split("k_robot_sweep")[1].split(">")[0] + ">"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    return {k: (sum(v[len(v) // 5:]) / len(v[len(v) // 5:]), len(v)) for k, v in acc.items()}
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    g = os.path.join(ROOT, "gpurun_out", tag)
+    prof = os.path.join(ROOT, "profiles")
+    os.makedirs(prof, exist_ok=True)
+    out = [f"# rocprofv3 summary — {tag}", "",
+           "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-extras` "
+           "(tools/profile_round.sh; MI355X).  `<16, 0, false>`: configs[1], 10 iterations per dispatch; `<16, 2, true>`: configs[2], the 10-step "
+           "schedule as ONE resident dispatch; `<16, 2, false>` (second run, `MGX_PERSISTENT=0`): configs[2], one iteration per dispatch.", ""]
+    for sub, name in (("_kt", "kernel_stats"), ("_kt_np", "kernel_stats_launch_per_iteration"), ("_cfg", "configs_kernel_stats")):
+        f = glob.glob(os.path.join(g + sub, "**", "*kernel_stats.csv"), recursive=True)
+        if f:
+            shutil.copy(f[0], os.path.join(prof, f"{tag}_{name}.csv"))
+            st = list(csv.DictReader(open(f[0])))
+            out += [f"## {name} (`profiles/{tag}_{name}.csv`)", "", "| kernel | calls | total ns | avg ns | % |", "|---|---|---|---|---|"]
+            for r in st[:8]:
+                out.append(f"| {r['Name'][:70]} | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {float(r['Percentage']):.2f} |")
+            out.append("")
+    dur = durations(g + "_kt")
+    dur.update({k + " (MGX_PERSISTENT=0)": v for k, v in durations(g + "_kt_np").items()})
+    out += ["## steady-state dispatch durations (kernel trace)", "", "| instantiation | dispatches | avg us |", "|---|---|---|"]
+    for k, (avg, n) in sorted(dur.items()):
+        out.append(f"| k_robot_sweep{k} | {n} | {avg:.2f} |")
+    traffic = {"_source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, tools/profile_round.sh) on `python3 bench.py "
+                          f"--steps 200 --warmup 50 --no-cpu-baseline --no-extras`, MI355X, round {tag}.  KiB per dispatch as reported; per "
+                          "MI355X_MICROARCH.md (HBM section) gfx950 FETCH_SIZE counts half the bytes of wide 16-B-per-lane streaming reads, so "
+                          "bench.py doubles the reads (an upper bound here: part of the staging uses 8-B loads)."}
+    keys = {"<16, 0, false>": ("config1", ""), "<16, 2, true>": ("config2_resident", ""), "<16, 2, false>": ("config2", "_np")}
+    out += ["", "## PMC per dispatch (separate passes)", "", "| instantiation | FETCH_SIZE KiB | WRITE_SIZE KiB | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU x4 / SQ_BUSY_CYCLES x4 | SQ_WAIT_ANY / SQ_WAVE_CYCLES |", "|---|---|---|---|---|---|"]
+    for inst, (key, suf) in keys.items():
+        f = per_kernel(g + "_pmc_FETCH_SIZE" + suf, "FETCH_SIZE").get(inst)
+        w = per_kernel(g + "_pmc_WRITE_SIZE" + suf, "WRITE_SIZE").get(inst)
+        sq = {c: per_kernel(g + "_pmc_SQ_INSTS_VALU" + suf, c).get(inst) for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY")}
+        if f is None or w is None:
+            continue
+        ent = {"fetch_kib": round(f, 1), "write_kib": round(w, 1), "source": f"profiles/{tag}_summary.md (rocprofv3 --pmc, separate passes)"}
+        busy = None
+        if sq["SQ_INSTS_VALU"]:
+            ent["valu_wave_instr"] = round(sq["SQ_INSTS_VALU"])
+            if sq["SQ_BUSY_CYCLES"]:
+                # SQ_ACTIVE_INST_VALU: quad-cycles summed over the SIMDs; SQ_BUSY_CYCLES: quad-cycles summed over the shader engines' SQs
+                busy = sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"] * 100.0
+                ent["valu_busy_pct"] = round(busy, 1)
+        traffic[key] = ent
+        out.append(f"| k_robot_sweep{inst} | {f:.1f} | {w:.1f} | {sq['SQ_INSTS_VALU'] or 0:.4g} | VALU active {busy or 0:.1f} % of wave-cycles | "
+                   f"{(sq['SQ_WAIT_ANY'] or 0) / (sq['SQ_WAVE_CYCLES'] or 1) * 100:.0f} % waiting |")
+    json.dump(traffic, open(os.path.join(prof, f"traffic_{tag}.json"), "w"), indent=1)
+    for f in glob.glob(g + "_kt.json"):
+        shutil.copy(f, os.path.join(prof, f"{tag}_bench_under_rocprof.json"))
+    cfg = g + "_cfg.log"
+    if os.path.exists(cfg):
+        out += ["", "## every BASELINE config on one MI355X (`tools/bench_configs.py` under rocprofv3 --kernel-trace --stats)", ""]
+        out += ["* " + ln.strip() for ln in open(cfg) if "us / iteration" in ln]
+    open(os.path.join(prof, f"{tag}_summary.md"), "w").write("\n".join(out) + "\n")
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()
