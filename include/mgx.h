@@ -270,6 +270,20 @@ int mgx_mission_set(mgx_world *w, int32_t robot, const mgx_mission_desc *desc);
 int mgx_mission_tick(mgx_world *w, float comms_radius, uint32_t method, uint64_t *robot_number_next,
                      int32_t despawn_finished, const uint8_t *antennas, double max_speed, double delta_t,
                      const uint8_t *steps, uint32_t n_steps, uint32_t *stats);
+/* The tick in two halves, for a caller whose comms-failure draws depend on which robots are still alive after this tick's
+ * despawns (the reference draws once per live robot, robot.rs:1599): _begin runs reached_waypoint and the topology pass (the
+ * tick's one synchronisation) and leaves the robots whose mission completed in mgx_mission_finished (ascending ids);
+ * _end applies the antennas, the prior updates with the Transform increment and the schedule.  Robots may be added (and
+ * given missions) between the halves.  mgx_mission_tick == _begin + _end. */
+int mgx_mission_tick_begin(mgx_world *w, float comms_radius, uint32_t method, uint64_t *robot_number_next,
+                           int32_t despawn_finished, uint32_t *stats);
+int mgx_mission_tick_end(mgx_world *w, const uint8_t *antennas, double max_speed, double delta_t,
+                         const uint8_t *steps, uint32_t n_steps);
+int mgx_mission_finished(mgx_world *w, int32_t *robots, uint32_t capacity, uint32_t *n);
+/* Transform::translation [n][3] of every robot as of the end of the last tick, WITHOUT synchronising: _end sends them to
+ * the host behind its launches, so they are complete once the stream has been synchronised since — which the next
+ * mgx_mission_tick_begin does by itself.  (PositionTracker / VelocityTracker samples, planner/tracking.rs:104-218.) */
+int mgx_mission_translations(mgx_world *w, float *translations, uint32_t capacity_robots, uint32_t *n_robots);
 /* Transform::translation [n][3], next waypoint index (== the route's length once complete; -1: no mission) and the tick
  * at which each mission completed (-1 before) of every robot, id order; any pointer may be NULL.  Synchronises. */
 int mgx_mission_read(mgx_world *w, float *translations, int32_t *targets, int64_t *finished_tick);

@@ -377,6 +377,10 @@ struct mgx_world {
         std::vector<int32_t> alive_host;  // the robots the search of the coming tick looks at
         bool alive_dirty = true;
         long long tick_no = 0;
+        bool in_tick = false;                // between mgx_mission_tick_begin and _end
+        std::vector<int32_t> last_finished;  // robots whose mission completed in the last begin, ascending
+        float *tr_host = nullptr;            // pinned: Transforms after the last tick's move (valid after the next synchronisation)
+        size_t tr_cap = 0, tr_n = 0;
         DevMission d{};
     } mission;
     uint32_t last_sweep_launches = 0;  // sweep-kernel launches of the last mgx_iterate / mgx_tick call (mgx_last_launch_count)
@@ -1350,6 +1354,7 @@ int mgx_world_destroy(mgx_world *w) {
     if (w->direct.flags) (void)hipFree(w->direct.flags);
     if (w->sweep_err_host) (void)hipHostFree(w->sweep_err_host);
     if (w->mission.ev_host) (void)hipHostFree(w->mission.ev_host);
+    if (w->mission.tr_host) (void)hipHostFree(w->mission.tr_host);
     delete w;
     return MGX_OK;
 }
@@ -1994,7 +1999,13 @@ int mgx_mission_set(mgx_world *w, int32_t robot, const mgx_mission_desc *desc) {
 
 int mgx_mission_tick(mgx_world *w, float comms_radius, uint32_t method, uint64_t *robot_number_next, int32_t despawn_finished,
                      const uint8_t *antennas, double max_speed, double delta_t, const uint8_t *steps, uint32_t n_steps, uint32_t *stats) {
-    if (!w || !robot_number_next || (!steps && n_steps)) return fail(MGX_ERR_INVALID, "null argument");
+    int rc = mgx_mission_tick_begin(w, comms_radius, method, robot_number_next, despawn_finished, stats);
+    return rc != MGX_OK ? rc : mgx_mission_tick_end(w, antennas, max_speed, delta_t, steps, n_steps);
+}
+
+int mgx_mission_tick_begin(mgx_world *w, float comms_radius, uint32_t method, uint64_t *robot_number_next, int32_t despawn_finished,
+                           uint32_t *stats) {
+    if (!w || !robot_number_next) return fail(MGX_ERR_INVALID, "null argument");
     if (*robot_number_next == 0) return fail(MGX_ERR_INVALID, "robot_number is NonZeroUsize");
     if (method > MGX_NEIGHBOURS_GRID) return fail(MGX_ERR_INVALID, "bad method");
     mgx_world::Mission &ms = w->mission;
@@ -2024,9 +2035,11 @@ int mgx_mission_tick(mgx_world *w, float comms_radius, uint32_t method, uint64_t
     // the search still looked at them, so they are taken out of its rows here
     const unsigned n_fin = ms.ev_host[0];
     std::vector<uint8_t> gone;
+    ms.last_finished.clear();
     if (n_fin) {
         std::vector<int> fin(ms.ev_host + 1, ms.ev_host + 1 + n_fin);
         std::sort(fin.begin(), fin.end());
+        ms.last_finished.assign(fin.begin(), fin.end());
         for (int r : fin) ms.finished_tick[(size_t)r] = ms.tick_no;
         if (despawn_finished) {
             gone.assign((size_t)R, 0);
@@ -2050,6 +2063,24 @@ int mgx_mission_tick(mgx_world *w, float comms_radius, uint32_t method, uint64_t
     rc = topology_bookkeeping(w, ptr, idx, robot_number_next, st, tm);
     if (rc != MGX_OK) return rc;
     if (stats) { stats[0] = st[0]; stats[1] = st[1]; stats[2] = n_fin; }
+    ms.in_tick = true;
+    return MGX_OK;
+}
+
+int mgx_mission_tick_end(mgx_world *w, const uint8_t *antennas, double max_speed, double delta_t, const uint8_t *steps, uint32_t n_steps) {
+    if (!w || (!steps && n_steps)) return fail(MGX_ERR_INVALID, "null argument");
+    mgx_world::Mission &ms = w->mission;
+    if (!ms.in_tick) return fail(MGX_ERR_STATE, "mgx_mission_tick_end without mgx_mission_tick_begin");
+    ms.in_tick = false;
+    int rc = MGX_OK;
+    const int R = (int)w->robots.size();
+    hipStream_t s = w->stream;
+    StageTimer tm("mission_tick_end");
+    if (ms.dirty || ms.has.size() != w->robots.size()) {  // robots joined between the two halves: lay the missions out again
+        if (ms.uploaded && !ms.dirty && (rc = mission_download(w)) != MGX_OK) return rc;
+        if ((rc = commit(w)) != MGX_OK) return rc;
+        if ((rc = mission_upload(w)) != MGX_OK) return rc;
+    }
     // update_failed_comms (robot.rs:1593-1601): the caller's draws for the robots still alive
     if (antennas) {
         bool changed = false;
@@ -2074,6 +2105,16 @@ int mgx_mission_tick(mgx_world *w, float comms_radius, uint32_t method, uint64_t
         HIP_TRY(w->stage.release(slot, s));
     }
     HIP_TRY(launch_mission_prepare(w->d, ms.d, R, ms.moving_d.p, ms.rec_d.p, ms.robots_d.p, ms.waypoints_d.p, ms.ts_list_d.p, ms.what_d.p, s));
+    // the Transforms after this tick's move travel to the host behind the launch: complete at the next synchronisation
+    // (the next tick's own one), read without one by mgx_mission_translations
+    if (ms.tr_cap < (size_t)R) {
+        if (ms.tr_host) (void)hipHostFree(ms.tr_host);
+        ms.tr_host = nullptr;
+        HIP_TRY(hipHostMalloc((void **)&ms.tr_host, sizeof(float) * 3 * ((size_t)R + 64), hipHostMallocDefault));
+        ms.tr_cap = (size_t)R + 64;
+    }
+    HIP_TRY(hipMemcpyAsync(ms.tr_host, ms.translation_d.p, sizeof(float) * 3 * (size_t)R, hipMemcpyDeviceToHost, s));
+    ms.tr_n = (size_t)R;
     for (int r = 0; r < R; r++) {  // message counters: the prior changes of the robots that move (what the device decides too)
         const Robot &rb = w->robots[(size_t)r];
         if (rb.removed || rb.ghost || !ms.has[(size_t)r] || ms.finished_tick[(size_t)r] >= 0) continue;
@@ -2108,6 +2149,23 @@ int mgx_mission_tick(mgx_world *w, float comms_radius, uint32_t method, uint64_t
     ms.tick_no += 1;
     tm.lap("prior updates + schedule");
     return rc;
+}
+
+int mgx_mission_finished(mgx_world *w, int32_t *robots, uint32_t capacity, uint32_t *n) {
+    if (!w || !n) return fail(MGX_ERR_INVALID, "null argument");
+    const std::vector<int32_t> &f = w->mission.last_finished;
+    *n = (uint32_t)f.size();
+    if (robots)
+        for (size_t i = 0; i < f.size() && i < capacity; i++) robots[i] = f[i];
+    return MGX_OK;
+}
+int mgx_mission_translations(mgx_world *w, float *translations, uint32_t capacity_robots, uint32_t *n_robots) {
+    if (!w || !translations) return fail(MGX_ERR_INVALID, "null argument");
+    const mgx_world::Mission &ms = w->mission;
+    const size_t n = std::min<size_t>(ms.tr_n, capacity_robots);
+    if (ms.tr_host && n) memcpy(translations, ms.tr_host, sizeof(float) * 3 * n);
+    if (n_robots) *n_robots = (uint32_t)ms.tr_n;
+    return MGX_OK;
 }
 
 int mgx_mission_read(mgx_world *w, float *translations, int32_t *targets, int64_t *finished_tick) {

@@ -160,6 +160,10 @@ SYMBOLS = {
     "mgx_mission_set": (C.c_int, [_V, C.c_int32, C.c_void_p]),
     "mgx_mission_tick": (C.c_int, [_V, C.c_float, C.c_uint32, C.POINTER(C.c_uint64), C.c_int32, C.c_void_p, C.c_double, C.c_double,
                                    C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "mgx_mission_tick_begin": (C.c_int, [_V, C.c_float, C.c_uint32, C.POINTER(C.c_uint64), C.c_int32, C.POINTER(C.c_uint32)]),
+    "mgx_mission_tick_end": (C.c_int, [_V, C.c_void_p, C.c_double, C.c_double, C.c_char_p, C.c_uint32]),
+    "mgx_mission_finished": (C.c_int, [_V, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "mgx_mission_translations": (C.c_int, [_V, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "mgx_mission_read": (C.c_int, [_V, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_num_robots": (C.c_int, [_V, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mgx_last_launch_count": (C.c_int, [_V, C.POINTER(C.c_uint32)]),

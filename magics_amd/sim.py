@@ -30,9 +30,15 @@ F = np.float32
 
 
 class Simulation:
-    def __init__(self, scenario, world, neighbours_method=hostlib.NEIGHBOURS_AUTO):
+    def __init__(self, scenario, world, neighbours_method=hostlib.NEIGHBOURS_AUTO, device_missions=None):
         """scenario: `config.load_scenario(dir)` (or a dict of the same shape); world: a fresh
-        World-like object created with `config.world_params(scenario["config"])`."""
+        World-like object created with `config.world_params(scenario["config"])`.
+        device_missions (default: whenever the world offers them, i.e. the engine): routes, reached-when rules and
+        Transforms live on the device (include/mgx.h, mgx_mission_*) and a tick is two calls around the comms draws with
+        ONE synchronisation and no belief read-back; otherwise this loop does all of it on the host (the CPU oracle's
+        path, and the checker of the other one: tests/test_gpu_sim.py)."""
+        self.dev = hasattr(world, "mission_tick_begin") if device_missions is None else bool(device_missions)
+        self._pending_track = None
         self.name = scenario.get("name", "")
         self.cfg, self.env, self.formations = scenario["config"], scenario["environment"], scenario["formation"]["formations"]
         self.w = world
@@ -52,7 +58,7 @@ class Simulation:
         world.set_environment(self.env)                          # simulation_loader.rs:154-162
         self.spawners = [spawner.FormationSpawner(i, f) for i, f in enumerate(self.formations)]
         self.robots = []           # per robot: dict (see _add_robot)
-        self.translation = np.zeros((0, 3), dtype=F)
+        self._translation = np.zeros((0, 3), dtype=F)
         self.tick_no, self.next_number, self.K = 0, 1, None
         self.events = []           # (tick, connections created, pairs deleted)
 
@@ -75,7 +81,27 @@ class Simulation:
                             "strategy": desc["planning-strategy"], "reach": desc["waypoint-reached-when-intersects"],
                             "finish": desc["finished-when-intersects"], "positions": [], "velocities": [], "travelled": 0.0,
                             "trk_elapsed": 0, "trk_prev": None})
-        self.translation = np.vstack([self.translation, np.array([[states[0][0], -1.5, states[0][1]]], dtype=F)])  # spawner.rs:548
+        self._translation = np.vstack([self._translation, np.array([[states[0][0], -1.5, states[0][1]]], dtype=F)])  # spawner.rs:548
+        if self.dev:
+            me = self.robots[-1]
+
+            def rule(when):
+                kind, n = when["intersects-with"]
+                var = 0 if kind == "current" else (self.K - 1 if kind == "horizon" or n >= self.K else n)
+                dkind, meter = when["distance"]
+                lim = me["radius"] * me["radius"] if dkind == "robot-radius" else F(meter) * F(meter)
+                return var, float(lim)
+            (rv, rd), (fv, fd) = rule(me["reach"]), rule(me["finish"])
+            self.w.mission_set(rid, np.array([s_[:2] for s_ in states[1:]], dtype=np.float64), rv, fv, rd, fd,
+                               self._translation[-1], me["time_scale"])
+
+    @property
+    def translation(self):
+        """Transform::translation of every robot [n, 3] f32 (fetched from the device when the missions live there)"""
+        if self.dev and self.robots:
+            tr = self.w.mission_read()[0]
+            self._translation[:len(tr)] = tr[:len(self._translation)]
+        return self._translation
 
     def _spawn(self):
         for sp in self.spawners:
@@ -117,12 +143,66 @@ class Simulation:
                         self.w.remove_robot(r["id"])
                         r["alive"] = False
 
+    # PositionTracker / VelocityTracker (planner/tracking.rs:104-122,189-218; 100 ms timers, spawner.rs:620-621):
+    # FixedUpdate systems over Changed<Transform>, i.e. the robots that moved this tick; sampled after the move
+    def _track(self, moving, translation, now):
+        for r in moving:
+            r["trk_elapsed"] += self.dt_ns
+            if r["trk_elapsed"] < 100_000_000:
+                continue
+            r["trk_elapsed"] %= 100_000_000
+            pos = translation[r["id"]].copy()
+            r["positions"].append([float(pos[0]), float(pos[2])])
+            if r["trk_prev"] is not None:
+                dt = now - r["trk_prev"][1]
+                v = (pos - r["trk_prev"][0]) / F(dt)
+                r["velocities"].append({"velocity": [float(v[0]), float(v[1]), float(v[2])], "timestamp": now,
+                                        "measured_over": {"secs": int(dt), "nanos": int(round((dt - int(dt)) * 1e9))}})
+            r["trk_prev"] = (pos, now)
+
+    def _flush_trackers(self, synchronise=False):
+        """device missions: the samples of the last tick, taken from the Transforms that tick sent to the host behind its
+        launches (complete after the next synchronisation — the next tick's own, or an explicit one here)"""
+        if self._pending_track is None:
+            return
+        if synchronise:
+            self.w.synchronize()
+        moving, now = self._pending_track
+        self._pending_track = None
+        self._track(moving, self.w.mission_translations(), now)
+
+    def _tick_device(self):
+        w = self.w
+        self.next_number, created, deleted, fin = w.mission_tick_begin(self.comms_radius, self.next_number, despawn_finished=self.despawn,
+                                                                       method=self.method)
+        self._flush_trackers()
+        if created or deleted:
+            self.events.append((self.tick_no, created, deleted))
+        for rid in fin:                                            # reached_waypoint completed the mission (robot.rs:2150-2176)
+            r = self.robots[int(rid)]
+            r["target"] = len(r["waypoints"])
+            r["completed"], r["finished_at"] = True, self.elapsed()
+            if self.despawn:
+                r["alive"] = False
+        live = [r for r in self.robots if r["alive"]]
+        ant = None
+        if live:
+            active = np.array([not self.rng.gen_bool(self.failure_rate) for _ in live], dtype=np.uint8)  # robot.rs:1599
+            if self.failure_rate > 0.0:
+                ant = np.ones(len(self.robots), dtype=np.uint8)
+                ant[[r["id"] for r in live]] = active
+        moving = [r for r in live if not r["completed"]]
+        w.mission_tick_end(self.steps, float(self.max_speed), float(self.dt32), antennas=ant)
+        self._pending_track = (moving, (self.tick_no + 1) * self.dt_ns * 1e-9)
+
     def tick(self):
         w = self.w
         self._spawn()
-        if self.robots:
+        if self.robots and self.dev:
+            self._tick_device()
+        elif self.robots:
             self._reached_waypoint()
-            self.next_number, created, deleted = w.update_topology(self.translation, self.comms_radius, self.next_number, method=self.method)
+            self.next_number, created, deleted = w.update_topology(self._translation, self.comms_radius, self.next_number, method=self.method)
             if created or deleted:
                 self.events.append((self.tick_no, created, deleted))
             live = [r for r in self.robots if r["alive"]]
@@ -136,8 +216,8 @@ class Simulation:
                 m0, m1 = w.read_variable_means(0), w.read_variable_means(1)
                 ts = np.array([r["time_scale"] for r in moving])
                 change = ts[:, None] * (m1[ids] - m0[ids])                                   # robot.rs:2314
-                self.translation[ids, 0] += change[:, 0].astype(F)                          # robot.rs:2328-2329
-                self.translation[ids, 2] += change[:, 1].astype(F)
+                self._translation[ids, 0] += change[:, 0].astype(F)                          # robot.rs:2328-2329
+                self._translation[ids, 2] += change[:, 1].astype(F)
                 for r, c in zip(moving, change):
                     r["travelled"] += float(np.hypot(c[0], c[1]))
                 w.tick(robots=ids, waypoints_xy=np.array([r["waypoints"][r["target"]][:2] for r in moving], dtype=np.float64),
@@ -145,22 +225,7 @@ class Simulation:
                        delta_t=float(self.dt32), steps=self.steps)                          # prior updates + iterate_gbp_v2
             else:
                 w.iterate(self.steps)
-            # PositionTracker / VelocityTracker (planner/tracking.rs:104-122,189-218; 100 ms timers, spawner.rs:620-621):
-            # FixedUpdate systems over Changed<Transform>, i.e. the robots that moved this tick; sampled after the move
-            now = (self.tick_no + 1) * self.dt_ns * 1e-9
-            for r in moving:
-                r["trk_elapsed"] += self.dt_ns
-                if r["trk_elapsed"] < 100_000_000:
-                    continue
-                r["trk_elapsed"] %= 100_000_000
-                pos = self.translation[r["id"]].copy()
-                r["positions"].append([float(pos[0]), float(pos[2])])
-                if r["trk_prev"] is not None:
-                    dt = now - r["trk_prev"][1]
-                    v = (pos - r["trk_prev"][0]) / F(dt)
-                    r["velocities"].append({"velocity": [float(v[0]), float(v[1]), float(v[2])], "timestamp": now,
-                                            "measured_over": {"secs": int(dt), "nanos": int(round((dt - int(dt)) * 1e9))}})
-                r["trk_prev"] = (pos, now)
+            self._track(moving, self._translation, (self.tick_no + 1) * self.dt_ns * 1e-9)
         self.tick_no += 1
 
     def finished(self):
@@ -171,10 +236,14 @@ class Simulation:
         limit = self.cfg["simulation"]["max-time"] if max_time is None else max_time
         while not self.finished() and self.elapsed() < limit and (max_ticks is None or self.tick_no < max_ticks):
             self.tick()
+        if self.dev:
+            self._flush_trackers(synchronise=True)
         return self
 
     # -- export (export.rs:249-262, 283-620) ------------------------------------------------------------------
     def export(self):
+        if self.dev:
+            self._flush_trackers(synchronise=True)
         sch = self.cfg["gbp"]["iteration-schedule"]
         robots = {}
         for r in self.robots:

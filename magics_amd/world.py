@@ -253,6 +253,29 @@ class World:
                                            bytes(bytearray(steps)), len(steps), st))
         return nn.value, st[0], st[1], st[2]
 
+    def mission_tick_begin(self, comms_radius, next_number, despawn_finished=True, method=hostlib.NEIGHBOURS_AUTO):
+        """reached_waypoint + the topology pass (the tick's one synchronisation).  Returns (next robot number, connections
+        created, pairs deleted, ids of the robots whose mission completed in this tick)."""
+        nn, st = C.c_uint64(int(next_number)), (C.c_uint32 * 3)()
+        self._chk(self._L.mgx_mission_tick_begin(self._w, float(comms_radius), int(method), C.byref(nn), 1 if despawn_finished else 0, st))
+        fin = np.zeros(st[2], dtype=np.int32)
+        if st[2]:
+            k = C.c_uint32()
+            self._chk(self._L.mgx_mission_finished(self._w, fin.ctypes.data, st[2], C.byref(k)))
+        return nn.value, st[0], st[1], fin
+
+    def mission_tick_end(self, steps, max_speed, delta_t, antennas=None):
+        ant = None if antennas is None else np.ascontiguousarray(antennas, dtype=np.uint8)
+        self._chk(self._L.mgx_mission_tick_end(self._w, None if ant is None else ant.ctypes.data, float(max_speed), float(delta_t),
+                                               bytes(bytearray(steps)), len(steps)))
+
+    def mission_translations(self):
+        """Transforms [n, 3] as of the end of the last tick; valid once the stream has been synchronised since (no sync here)."""
+        n, _ = self.num_robots()
+        out, k = np.zeros((n, 3), np.float32), C.c_uint32()
+        self._chk(self._L.mgx_mission_translations(self._w, out.ctypes.data, n, C.byref(k)))
+        return out[:min(n, k.value)]
+
     def mission_read(self):
         """(Transform translations [n, 3] f32, next waypoint index per robot, completion tick per robot)"""
         n, _ = self.num_robots()

@@ -130,6 +130,10 @@ extern "C" {
     pub fn mgx_tick(w: *mut mgx_world, n: u32, robots: *const i32, waypoints_xy: *const f64, time_scale: *const f64, what: *const u8, max_speed: f64, delta_t: f64, steps: *const u8, n_steps: u32) -> c_int;
     pub fn mgx_mission_set(w: *mut mgx_world, robot: i32, desc: *const mgx_mission_desc) -> c_int;
     pub fn mgx_mission_tick(w: *mut mgx_world, comms_radius: f32, method: u32, robot_number_next: *mut u64, despawn_finished: i32, antennas: *const u8, max_speed: f64, delta_t: f64, steps: *const u8, n_steps: u32, stats: *mut u32) -> c_int;
+    pub fn mgx_mission_tick_begin(w: *mut mgx_world, comms_radius: f32, method: u32, robot_number_next: *mut u64, despawn_finished: i32, stats: *mut u32) -> c_int;
+    pub fn mgx_mission_tick_end(w: *mut mgx_world, antennas: *const u8, max_speed: f64, delta_t: f64, steps: *const u8, n_steps: u32) -> c_int;
+    pub fn mgx_mission_finished(w: *mut mgx_world, robots: *mut i32, capacity: u32, n: *mut u32) -> c_int;
+    pub fn mgx_mission_translations(w: *mut mgx_world, translations: *mut f32, capacity_robots: u32, n_robots: *mut u32) -> c_int;
     pub fn mgx_mission_read(w: *mut mgx_world, translations: *mut f32, targets: *mut i32, finished_tick: *mut i64) -> c_int;
     pub fn mgx_get_belief(w: *mut mgx_world, robot: i32, var_ix: u32, eta: *mut f64, lam: *mut f64, mean: *mut f64, cov: *mut f64, valid: *mut i32) -> c_int;
     pub fn mgx_read_beliefs(w: *mut mgx_world, eta: *mut f64, lam: *mut f64, means: *mut f64) -> c_int;
