@@ -61,6 +61,7 @@ class Simulation:
         self._translation = np.zeros((0, 3), dtype=F)
         self.tick_no, self.next_number, self.K = 0, 1, None
         self.events = []           # (tick, connections created, pairs deleted)
+        self.collisions = {}       # (robot a, robot b), a < b -> {"colliding": bool, "times": int, "aabbs": [...]}
 
     # -- spawn_formation (spawner.rs:415-649) + RobotBundle::new (robot.rs:1134-1356) -------------------
     def _add_robot(self, desc, formation_index):
@@ -160,6 +161,32 @@ class Simulation:
                                         "measured_over": {"secs": int(dt), "nanos": int(round((dt - int(dt)) * 1e9))}})
             r["trk_prev"] = (pos, now)
 
+    # update_robot_robot_collisions (planner/collisions.rs:72-140, FixedUpdate): every pair of live robots, bounding
+    # spheres of their Ball(radius) at the Transform's (x, z) — parry2d 0.13 BoundingSphere::intersects, restated from its
+    # published source (third party, absent from /root/reference): |c_b - c_a|^2 <= (r_a + r_b)^2 in f32 — through the
+    # Free / Colliding state machine of CollisionHistory (:455-495): a Free -> Colliding edge is one collision, recorded with
+    # the intersection of the two balls' AABBs (:113-119).  Robot - environment collisions need the colliders of the
+    # reference's 3-D map generator (environment/map_generator.rs) and parry2d's shape queries: not built (counted 0).
+    def _collide(self, alive, translation):
+        for i, a in enumerate(alive):
+            for b in alive[i + 1:]:
+                ca, cb = translation[a["id"]][[0, 2]], translation[b["id"]][[0, 2]]
+                d = cb - ca
+                rs = a["radius"] + b["radius"]
+                hit = bool(F(d[0] * d[0] + d[1] * d[1]) <= F(rs * rs))
+                key = (a["id"], b["id"])
+                h = self.collisions.get(key)
+                if h is None:
+                    if not hit:
+                        continue  # an entry that has only ever been Free holds nothing the export shows
+                    h = self.collisions[key] = {"colliding": False, "times": 0, "aabbs": []}
+                if hit and not h["colliding"]:
+                    h["times"] += 1
+                    lo = np.maximum(ca - a["radius"], cb - b["radius"])
+                    hi = np.minimum(ca + a["radius"], cb + b["radius"])
+                    h["aabbs"].append({"mins": [float(lo[0]), float(lo[1])], "maxs": [float(hi[0]), float(hi[1])]})
+                h["colliding"] = hit
+
     def _flush_trackers(self, synchronise=False):
         """device missions: the samples of the last tick, taken from the Transforms that tick sent to the host behind its
         launches (complete after the next synchronisation — the next tick's own, or an explicit one here)"""
@@ -167,9 +194,11 @@ class Simulation:
             return
         if synchronise:
             self.w.synchronize()
-        moving, now = self._pending_track
+        moving, now, alive = self._pending_track
         self._pending_track = None
-        self._track(moving, self.w.mission_translations(), now)
+        tr = self.w.mission_translations()
+        self._track(moving, tr, now)
+        self._collide(alive, tr)
 
     def _tick_device(self):
         w = self.w
@@ -193,7 +222,7 @@ class Simulation:
                 ant[[r["id"] for r in live]] = active
         moving = [r for r in live if not r["completed"]]
         w.mission_tick_end(self.steps, float(self.max_speed), float(self.dt32), antennas=ant)
-        self._pending_track = (moving, (self.tick_no + 1) * self.dt_ns * 1e-9)
+        self._pending_track = (moving, (self.tick_no + 1) * self.dt_ns * 1e-9, live)
 
     def tick(self):
         w = self.w
@@ -226,6 +255,7 @@ class Simulation:
             else:
                 w.iterate(self.steps)
             self._track(moving, self._translation, (self.tick_no + 1) * self.dt_ns * 1e-9)
+            self._collide(live, self._translation)
         self.tick_no += 1
 
     def finished(self):
@@ -252,7 +282,7 @@ class Simulation:
             fin = r["finished_at"] if r["finished_at"] is not None else self.elapsed()
             robots[str(r["id"])] = {
                 "radius": float(r["radius"]), "positions": r["positions"], "velocities": r["velocities"],
-                "collisions": {"robots": 0, "environment": 0},
+                "collisions": {"robots": sum(h["times"] for k, h in self.collisions.items() if r["id"] in k), "environment": 0},
                 "messages": {"sent": {"internal": sent_i, "external": sent_e}, "received": {"internal": recv_i, "external": recv_e}},
                 "mission": {"waypoints": [wps[0], wps[-1]], "started_at": r["started_at"], "finished_at": fin,
                             "routes": [{"waypoints": wps, "started_at": r["started_at"], "finished_at": fin}]},
@@ -260,7 +290,12 @@ class Simulation:
         return {"scenario": self.name, "makespan": self.elapsed(), "delta_t": float(self.dt32),
                 "gbp": {"iterations": {"internal": sch["internal"], "external": sch["external"]}}, "robots": robots,
                 "prng_seed": self.cfg["simulation"]["prng-seed"], "config": self.cfg, "obstacles": {},
-                "collisions": {"robots": [], "environment": []}, "goal_areas": {}}
+                "collisions": {"robots": [{"robot_a": a, "robot_b": b, "aabbs": h["aabbs"]} for (a, b), h in sorted(self.collisions.items())],
+                               "environment": []},
+                # goal_areas: the reference registers GoalAreaPlugin but its only system that SPAWNS goal areas
+                # (setup_goal_areas_for_junction_scenario, goal_area.rs:105-119) is commented out of the plugin (:8-11):
+                # the exported map is empty in the reference itself
+                "goal_areas": {}}
 
     def export_json(self, path):
         with open(path, "w", encoding="utf-8") as f:

@@ -122,3 +122,22 @@ def test_scenario_on_a_sharded_world():
                 assert np.array_equal(x, y), t
     assert a.events == b.events and len(a.robots) >= 20
     assert len({sw.plan.owner[r["id"]] for sw in cluster.ranks for r in a.robots}) == 3   # robots live on all three ranks
+
+
+def test_robot_robot_collisions_are_counted_like_the_reference():
+    """update_robot_robot_collisions (planner/collisions.rs:72-140): with the inter-robot factors switched off the robots
+    of the Circle Experiment drive through each other at the centre — the Free -> Colliding edges are counted once per
+    contact, engine (Transforms on the device, samples one tick behind) and oracle (host loop) export the same."""
+    def blind(sc):
+        f = sc["formation"]["formations"][0]
+        f["robots"] = 6
+        f["initial-position"]["shape"]["radius"] = 14.0
+        f["waypoints"][0]["shape"]["radius"] = 14.0
+        sc["config"]["gbp"]["factors-enabled"]["interrobot"] = False
+    s = _run_both("Circle Experiment", 40, tweak=blind)
+    ex = s.export()
+    total = sum(r["collisions"]["robots"] for r in ex["robots"].values())
+    pairs = ex["collisions"]["robots"]
+    assert total > 0 and total == 2 * sum(len(p["aabbs"]) for p in pairs)       # every collision counts for both robots
+    assert all(p["robot_a"] < p["robot_b"] and all(a["mins"][0] <= a["maxs"][0] for a in p["aabbs"]) for p in pairs)
+    assert ex["goal_areas"] == {} and ex["collisions"]["environment"] == []

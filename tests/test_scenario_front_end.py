@@ -265,3 +265,20 @@ def test_schedules_follow_the_config(scenarios):
     sc = scenarios["Circle Experiment"]
     s = sim.Simulation(sc, oracle.OracleWorld(config.world_params(sc["config"])))
     assert s.steps == hostlib.schedule(hostlib.SCHEDULE_INTERLEAVE_EVENLY, 50, 10) and len(s.steps) == 50
+
+
+def test_collision_state_machine_counts_contacts_once():
+    """CollisionHistory (planner/collisions.rs:455-495) through sim.Simulation._collide: Free -> Colliding is one collision,
+    staying in contact is not another, parting and touching again is; the bounding-sphere predicate is <= in f32"""
+    s = sim.Simulation.__new__(sim.Simulation)
+    s.collisions = {}
+    F = np.float32
+    a, b = {"id": 0, "radius": F(1.0)}, {"id": 1, "radius": F(1.5)}
+
+    def at(x):
+        return np.array([[0.0, -1.5, 0.0], [x, -1.5, 0.0]], dtype=F)
+    for x, times in ((3.0, 0), (2.5, 1), (2.0, 1), (2.6, 1), (2.4, 2), (0.0, 2)):   # 2.5 = r_a + r_b: touching counts
+        s._collide([a, b], at(x))
+        assert s.collisions.get((0, 1), {"times": 0})["times"] == times, x
+    h = s.collisions[(0, 1)]
+    assert len(h["aabbs"]) == 2 and h["aabbs"][0] == {"mins": [1.0, -1.0], "maxs": [1.0, 1.0]}
