@@ -168,24 +168,26 @@ class Simulation:
     # the intersection of the two balls' AABBs (:113-119).  Robot - environment collisions need the colliders of the
     # reference's 3-D map generator (environment/map_generator.rs) and parry2d's shape queries: not built (counted 0).
     def _collide(self, alive, translation):
-        for i, a in enumerate(alive):
-            for b in alive[i + 1:]:
-                ca, cb = translation[a["id"]][[0, 2]], translation[b["id"]][[0, 2]]
-                d = cb - ca
-                rs = a["radius"] + b["radius"]
-                hit = bool(F(d[0] * d[0] + d[1] * d[1]) <= F(rs * rs))
-                key = (a["id"], b["id"])
-                h = self.collisions.get(key)
-                if h is None:
-                    if not hit:
-                        continue  # an entry that has only ever been Free holds nothing the export shows
-                    h = self.collisions[key] = {"colliding": False, "times": 0, "aabbs": []}
-                if hit and not h["colliding"]:
-                    h["times"] += 1
-                    lo = np.maximum(ca - a["radius"], cb - b["radius"])
-                    hi = np.minimum(ca + a["radius"], cb + b["radius"])
-                    h["aabbs"].append({"mins": [float(lo[0]), float(lo[1])], "maxs": [float(hi[0]), float(hi[1])]})
-                h["colliding"] = hit
+        if len(alive) < 2:
+            return
+        ids = np.array([r["id"] for r in alive])
+        rad = np.array([r["radius"] for r in alive], dtype=F)
+        pos = np.ascontiguousarray(translation[ids][:, [0, 2]], dtype=F)
+        d = pos[None, :, :] - pos[:, None, :]                        # d[i, j] = c_j - c_i (f32)
+        rs = rad[:, None] + rad[None, :]
+        hit = np.triu(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] <= rs * rs, k=1)
+        now = {(int(ids[i]), int(ids[j])): (i, j) for i, j in zip(*np.nonzero(hit))}
+        for key, h in self.collisions.items():                      # Colliding -> Free
+            if h["colliding"] and key not in now:
+                h["colliding"] = False
+        for key, (i, j) in now.items():                             # Free -> Colliding: one collision, with the AABBs' intersection
+            h = self.collisions.setdefault(key, {"colliding": False, "times": 0, "aabbs": []})
+            if not h["colliding"]:
+                h["colliding"] = True
+                h["times"] += 1
+                lo = np.maximum(pos[i] - rad[i], pos[j] - rad[j])
+                hi = np.minimum(pos[i] + rad[i], pos[j] + rad[j])
+                h["aabbs"].append({"mins": [float(lo[0]), float(lo[1])], "maxs": [float(hi[0]), float(hi[1])]})
 
     def _flush_trackers(self, synchronise=False):
         """device missions: the samples of the last tick, taken from the Transforms that tick sent to the host behind its
