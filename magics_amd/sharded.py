@@ -154,7 +154,10 @@ class ShardedWorld:
         g = len(plan.owner)
         owner = g % plan.world_size if owner is None else int(owner)
         local = owner == plan.rank
-        rid = self.world.add_robot(mean0, prior_diag, dt, radius, path=path if local else None, order_key=g, ghost=not local)
+        # order key: above every key the scenario handed out (they need not be 0 .. n-1), the same on every rank
+        self._next_key = max(getattr(self, "_next_key", 0), max((rb["order_key"] for rb in self.sc["robots"]), default=-1) + 1, g)
+        key, self._next_key = self._next_key, self._next_key + 1
+        rid = self.world.add_robot(mean0, prior_diag, dt, radius, path=path if local else None, order_key=key, ghost=not local)
         assert rid == g
         plan.owner = np.append(plan.owner, owner)
         if local:
@@ -284,8 +287,22 @@ class ShardedWorld:
         if self.plan.world_size == 1 or self.direct:  # direct: the engine exchanges inside the launch sequence
             return
         self.pack()
+        foreign = self._collective_on_another_stream()
+        if foreign:      # pack ran on the world's stream, the collective runs on torch's current one: order them
+            self.world.synchronize()
         self.comm.all_to_all(self.recv_buf, self.send_buf, self.recv_counts, self.send_counts)
+        if foreign:
+            import torch
+            torch.cuda.current_stream().synchronize()
         self.unpack()
+
+    def _collective_on_another_stream(self):
+        """the device buffers travel through torch.distributed on torch's CURRENT stream; pack / unpack run on the world's"""
+        buf = self.send_buf
+        if buf is None or not getattr(buf, "is_cuda", False):
+            return False
+        import torch
+        return int(torch.cuda.current_stream().cuda_stream) != int(getattr(self.world, "stream_handle", 0) or 0)
 
     def sweep_segment(self, ext, n_int, next_ext=False):
         hints = hostlib.HINT_NEXT_STARTS_EXTERNAL if (ext and next_ext) else 0

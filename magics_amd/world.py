@@ -44,6 +44,7 @@ class World:
         self._chk(self._L.mgx_world_create(C.byref(self._p), C.byref(h)))
         self._w = h
         self._next_key = 0
+        self.stream_handle = 0  # raw HIP stream every launch of this world goes to (0: the default stream)
         if stream is not None:
             self.set_stream(stream)
 
@@ -62,6 +63,7 @@ class World:
     def set_stream(self, stream):
         """``stream``: raw hipStream_t value (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
         self._chk(self._L.mgx_set_stream(self._w, C.c_void_p(int(stream))))
+        self.stream_handle = int(stream)
 
     def synchronize(self):
         self._chk(self._L.mgx_synchronize(self._w))
