@@ -307,8 +307,12 @@ int mgx_num_robots(mgx_world *w, uint32_t *n_robots, uint32_t *n_variables);
  * counts = {sent internal, sent external, received internal, received external}, summed over the
  * nodes the graph holds now (a deleted inter-robot factor takes its counts with it).  The counts
  * depend only on topology, enabled kinds, antenna / idle flags and iteration counts, so they are
- * kept on the host (launches are logged, no device work).  Unsharded worlds only. */
+ * kept on the host (launches are logged, no device work). */
 int mgx_message_counts(mgx_world *w, int32_t robot, uint64_t counts[4]);
+/* Sharded worlds keep the counters too (for the robots a rank OWNS), provided the rank's mirror holds every connection a
+ * local robot takes part in — also the ones it owns towards robots of other ranks (mgx_ir_connect with a ghost target:
+ * bookkeeping only, no device edge) — and is told the prior changes other ranks apply to its ghosts: */
+int mgx_note_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, const uint32_t *var_ix);
 
 /* ---- multi-GPU halo (one exchange per external iteration) ----------------- */
 /* Number of f64 words of one robot's halo record with K variables. */

@@ -628,7 +628,9 @@ static void flush_counts(mgx_world *w) {
     for (const IrConn &c : w->conns) { own[(size_t)c.owner]++; foreign[(size_t)c.other]++; }
     for (size_t r = 0; r < n; r++) {
         Robot &rb = w->robots[r];
-        if (rb.ghost) continue;
+        // ghosts too: on a sharded world every rank sees the same launches and holds every robot's flags, so the sweeps a
+        // ghost has run (what its variables answered to the factors local robots own) are known here; only the totals of
+        // the ghost's own graph are its owner's business
         const bool idle = rb.idle != 0, radio = rb.antenna && !idle;
         uint64_t nIf = 0, trk = 0;
         int64_t itf = rb.cnt_itf;
@@ -655,6 +657,7 @@ static void flush_counts(mgx_world *w) {
             }
         }
         rb.cnt_itf = itf;
+        if (rb.ghost) continue;
         const uint64_t s_int = 2ull * (K - 1) + 2ull * (K - 2) + (uint64_t)(K - 1) * own[r], s_ext = (uint64_t)(K - 1) * foreign[r];
         // internal factor sweeps: one message per inbox key of every updated factor, received by the variables
         rb.cnt[0] += nIf * (dynf + obsf) + trk * trkf;
@@ -2415,6 +2418,17 @@ int mgx_reset_tracking_factors(mgx_world *w, int32_t robot) {
     return MGX_OK;
 }
 
+// Sharded worlds: a prior change applied on ANOTHER rank (to a robot that is a ghost here) still delivers a message to the
+// inter-robot factors local robots own on that variable (variable.rs:210-221): the counters are told, nothing else happens.
+int mgx_note_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, const uint32_t *var_ix) {
+    if (!w || (n && (!robots || !var_ix))) return fail(MGX_ERR_INVALID, "null argument");
+    for (uint32_t i = 0; i < n; i++)
+        if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size() || (int)var_ix[i] >= w->K) return fail(MGX_ERR_INVALID, "bad (robot, variable) at %u", i);
+    for (uint32_t i = 0; i < n; i++)
+        if (!w->robots[(size_t)robots[i]].removed) log_change_prior(w, robots[i], (int)var_ix[i]);
+    return MGX_OK;
+}
+
 int mgx_change_prior(mgx_world *w, int32_t robot, uint32_t var_ix, const double mean[4]) {
     return mgx_change_priors(w, 1, &robot, &var_ix, mean);
 }
@@ -2457,8 +2471,7 @@ int mgx_read_variable_means(mgx_world *w, uint32_t var_ix, double *means) {
 // FactorGraph::messages_sent / messages_received (factorgraph.rs:876-890) of one robot's graph
 int mgx_message_counts(mgx_world *w, int32_t robot, uint64_t counts[4]) {
     if (!w || !counts || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
-    for (const Robot &r : w->robots)
-        if (r.ghost) return fail(MGX_ERR_STATE, "message counts are kept for unsharded worlds only");
+    if (w->robots[(size_t)robot].ghost) return fail(MGX_ERR_INVALID, "robot %d is a ghost here: its graph is counted on the rank that owns it", robot);
     flush_counts(w);
     const Robot &rb = w->robots[(size_t)robot];
     for (int c = 0; c < 4; c++) counts[c] = rb.cnt[c];

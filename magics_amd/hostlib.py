@@ -142,6 +142,7 @@ SYMBOLS = {
                                  C.POINTER(C.c_int32)]),
     "mgx_read_beliefs": (C.c_int, [_V, c_double_p, c_double_p, c_double_p]),
     "mgx_message_counts": (C.c_int, [_V, C.c_int32, C.POINTER(C.c_uint64)]),
+    "mgx_note_change_priors": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
     "mgx_read_means": (C.c_int, [_V, c_double_p]),
     "mgx_read_variable_means": (C.c_int, [_V, C.c_uint32, c_double_p]),
     "mgx_rccl_unique_id": (C.c_int, [C.c_char_p]),

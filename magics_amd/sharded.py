@@ -106,12 +106,18 @@ class ShardedWorld:
             rb = sc["robots"][g]
             self.lid[g] = w.add_robot(rb["mean0"], rb["prior_diag"], rb["dt"], rb["radius"], path=rb["path"],
                                       order_key=rb["order_key"])
-        for g in plan.ghosts:
+        # ghosts: the owners of the connections evaluated here (their records arrive by the exchange) and — bookkeeping only,
+        # for the MessageCount of the local graphs — the targets of connections local robots own towards other ranks
+        out_targets = sorted({b for a, b, _ in sc["ir"] if plan.owner[a] == rank and plan.owner[b] != rank} - set(plan.ghosts))
+        for g in list(plan.ghosts) + out_targets:
             rb = sc["robots"][g]
             self.lid[g] = w.add_robot(rb["mean0"], rb["prior_diag"], rb["dt"], rb["radius"], path=None,
                                       order_key=rb["order_key"], ghost=True)
-        for a, b, n0 in plan.connections:
-            w.ir_connect(self.lid[a], self.lid[b], n0)
+        # every connection a local robot takes part in, in the order create_interrobot_factors made them (the node slots of
+        # an owner's graph follow it): the ones whose target is local get device edges, the others exist on the host mirror only
+        for a, b, n0 in sc["ir"]:
+            if plan.owner[b] == rank or plan.owner[a] == rank:
+                w.ir_connect(self.lid[a], self.lid[b], n0)
         words = w.halo_words(plan.K)
         self.send_counts = [len(l) * words for l in plan.send_lists]
         self.recv_counts = [len(l) * words for l in plan.recv_lists]
@@ -208,11 +214,25 @@ class ShardedWorld:
     def update_priors(self, robots, waypoints_xy, time_scale, what, max_speed, delta_t):
         robots = np.asarray(robots)
         mine = np.nonzero(self.plan.owner[robots] == self.plan.rank)[0]
+        self._note_foreign_prior_changes(robots, what)
         if len(mine):
             local_ids = np.array([self.lid[int(g)] for g in robots[mine]], dtype=np.int32)
             self.world.update_priors(robots=local_ids, waypoints_xy=np.asarray(waypoints_xy)[mine],
                                      time_scale=np.asarray(time_scale)[mine], what=np.asarray(what)[mine], max_speed=max_speed,
                                      delta_t=delta_t)
+
+    def _note_foreign_prior_changes(self, robots, what):
+        """the prior updates other ranks apply to robots that are ghosts here deliver to factors local robots own: counters"""
+        rs, vs = [], []
+        for g, wh in zip(np.asarray(robots), np.asarray(what)):
+            g = int(g)
+            if self.plan.owner[g] != self.plan.rank and g in self.lid:
+                if wh & 1:
+                    rs.append(self.lid[g]); vs.append(self.plan.K - 1)
+                if wh & 2:
+                    rs.append(self.lid[g]); vs.append(0)
+        if rs and hasattr(self.world, "note_change_priors"):
+            self.world.note_change_priors(rs, vs)
 
     def set_antennas(self, robots, active):
         self.world.set_antennas(robots, active)  # flags of every robot live on every rank
@@ -224,7 +244,10 @@ class ShardedWorld:
         return self.world.connections(robot)
 
     def message_counts(self, robot):
-        return (0, 0, 0, 0)  # MessageCount is kept for unsharded worlds only (include/mgx.h)
+        """MessageCount of a robot this rank owns (None for the others: their owner counts them)"""
+        if self.plan.owner[robot] != self.plan.rank:
+            return None
+        return self.world.message_counts(self.lid[robot])
 
     # -- direct exchange wiring ----------------------------------------------------------------------
     def direct_setup(self, export_ipc):
@@ -297,12 +320,19 @@ class ShardedWorld:
         self.unpack()
 
     def _collective_on_another_stream(self):
-        """the device buffers travel through torch.distributed on torch's CURRENT stream; pack / unpack run on the world's"""
+        """the device buffers travel through torch.distributed on torch's CURRENT stream; pack / unpack run on the world's
+        (decided once per world stream: this sits in the per-iteration path of the host-driven exchange)"""
+        key = int(getattr(self.world, "stream_handle", 0) or 0)
+        cached = getattr(self, "_foreign_stream", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
         buf = self.send_buf
-        if buf is None or not getattr(buf, "is_cuda", False):
-            return False
-        import torch
-        return int(torch.cuda.current_stream().cuda_stream) != int(getattr(self.world, "stream_handle", 0) or 0)
+        foreign = False
+        if buf is not None and getattr(buf, "is_cuda", False):
+            import torch
+            foreign = int(torch.cuda.current_stream().cuda_stream) != key
+        self._foreign_stream = (key, foreign)
+        return foreign
 
     def sweep_segment(self, ext, n_int, next_ext=False):
         hints = hostlib.HINT_NEXT_STARTS_EXTERNAL if (ext and next_ext) else 0
@@ -331,6 +361,8 @@ class ShardedWorld:
     def change_prior(self, robot, var_ix, mean):
         if self.plan.owner[robot] == self.plan.rank:
             self.world.change_prior(self.lid[robot], var_ix, mean)
+        elif robot in self.lid and hasattr(self.world, "note_change_priors"):
+            self.world.note_change_priors([self.lid[robot]], [var_ix])  # counters of the local factors attached to it
 
     def set_enabled(self, mask):
         """change_factor_enabled on every rank (collective): an exchange first, so that the ghosts' records the
@@ -569,6 +601,7 @@ class LocalCluster:
         robots = np.asarray(robots)
         for sw in self.ranks:
             mine = np.nonzero(sw.plan.owner[robots] == sw.plan.rank)[0]
+            sw._note_foreign_prior_changes(robots, what)
             if len(mine):
                 local_ids = np.array([sw.lid[int(g)] for g in robots[mine]], dtype=np.int32)  # rank-local ids (equal to the global ones on a dynamic world)
                 sw.world.update_priors(robots=local_ids, waypoints_xy=np.asarray(waypoints_xy)[mine],
@@ -595,7 +628,11 @@ class LocalCluster:
         return outs[0]
 
     def message_counts(self, robot):
-        return (0, 0, 0, 0)  # MessageCount is kept for unsharded worlds only (include/mgx.h)
+        for sw in self.ranks:
+            c = sw.message_counts(robot)
+            if c is not None:
+                return c
+        raise KeyError(robot)
 
     def set_antenna(self, robot, active):
         for sw in self.ranks:

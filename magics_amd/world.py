@@ -291,6 +291,13 @@ class World:
         self._chk(self._L.mgx_last_launch_count(self._w, C.byref(n)))
         return n.value
 
+    def note_change_priors(self, robots, var_ix):
+        """counters only: prior changes another rank applied to robots that are ghosts here (mgx_note_change_priors)"""
+        r, v = np.ascontiguousarray(robots, dtype=np.int32), np.ascontiguousarray(var_ix, dtype=np.uint32)
+        if len(r):
+            self._chk(self._L.mgx_note_change_priors(self._w, len(r), r.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                     v.ctypes.data_as(C.POINTER(C.c_uint32))))
+
     def message_counts(self, robot):
         """(sent internal, sent external, received internal, received external) of one graph."""
         out = (C.c_uint64 * 4)()

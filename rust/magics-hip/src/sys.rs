@@ -141,6 +141,7 @@ extern "C" {
     pub fn mgx_read_variable_means(w: *mut mgx_world, var_ix: u32, means: *mut f64) -> c_int;
     pub fn mgx_num_robots(w: *mut mgx_world, n_robots: *mut u32, n_variables: *mut u32) -> c_int;
     pub fn mgx_message_counts(w: *mut mgx_world, robot: i32, counts: *mut u64) -> c_int;
+    pub fn mgx_note_change_priors(w: *mut mgx_world, n: u32, robots: *const i32, var_ix: *const u32) -> c_int;
     pub fn mgx_halo_words(k: u32) -> u32;
     pub fn mgx_halo_plan(w: *mut mgx_world, n_send: u32, send_robots: *const i32, n_recv: u32, recv_ghosts: *const i32) -> c_int;
     pub fn mgx_halo_plan_from_connections(w: *mut mgx_world, rank_of: *const i32, n_robots: u32, my_rank: i32, n_ranks: u32, send_counts: *mut u32, recv_counts: *mut u32) -> c_int;

@@ -240,3 +240,35 @@ def test_rank_that_owns_no_robot_yet():
         assert np.array_equal(dc.translation, dr.translation), tick
     assert np.array_equal(cluster.read_variable_means(0), ref.read_variable_means(0))
     assert_identical(cluster, ref, what="a rank with ghosts only")
+
+
+def test_message_counts_on_a_sharded_world():
+    """MessageCount (factorgraph/mod.rs:29-137) of every robot, kept by the rank that owns it: the rank's mirror holds every
+    connection its robots take part in (those towards other ranks as bookkeeping only) and is told the prior changes other
+    ranks apply to its ghosts — same counts as the single-world oracle through gating, prior changes and driver ticks."""
+    n = 36
+    sc = S.grid_scenario(n, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
+    cluster = sharded.LocalCluster(sc, 3, World)
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    boundary = sorted({g for sw in cluster.ranks for g in sw.plan.ghosts})
+    tick = S.tick_inputs(sc)
+
+    def same(what):
+        for r in range(n):
+            assert cluster.message_counts(r) == ref.message_counts(r), (what, r, cluster.message_counts(r), ref.message_counts(r))
+
+    def both(fn):
+        fn(cluster)
+        fn(ref)
+    same("after construction")
+    both(lambda w: w.iterate([3, 3, 1, 2, 3]))
+    same("first iterations")
+    both(lambda w: (w.set_antenna(boundary[0], False), w.set_idle(boundary[1], True),
+                    w.change_prior(boundary[2], 9, np.array([0.5, 0.25, 1.0, -1.0])), w.iterate([3, 3, 3])))
+    same("gating + prior change on boundary robots")
+    both(lambda w: (w.set_antenna(boundary[0], True), w.set_idle(boundary[1], False)))
+    for t in range(2):
+        both(lambda w: w.tick(steps=sc["steps"], **tick))
+        same(f"driver tick {t}")
+    assert_identical(cluster, ref, what="sharded world with message counts")
