@@ -182,6 +182,7 @@ def test_sharded_world_follows_its_topology(world_size):
     assert (dc.finished_at >= 0).all() and np.array_equal(dc.finished_at, dr.finished_at)
     assert sum(c for c, _ in events) > n and sum(d for _, d in events) > 0   # connections came and went
     assert len(plans) > 3                                                      # and the exchange lists with them
+    assert dc.summary()["messages"] == dr.summary()["messages"]               # MessageCount of every graph, from its owner's rank
 
 
 def test_sharded_topology_with_comms_failures_and_initial_connections():
@@ -202,6 +203,7 @@ def test_sharded_topology_with_comms_failures_and_initial_connections():
     for tick in range(80):
         assert dc.tick() == dr.tick(), tick
     assert_identical(cluster, ref, what="2 ranks, comms failures, initial connections")
+    assert dc.summary()["messages"] == dr.summary()["messages"]
 
 
 def test_sharded_world_switches_factor_kinds():
