@@ -143,6 +143,17 @@ struct DevWorld {
     unsigned long long *dbg;
 };
 
+// An inter-robot factor created WHILE its kind was switched off dropped the two messages that would have filled its inbox
+// (factor/mod.rs:307-310): once enabled it has no inbox KEYS until its variables deliver again, and FactorNode::update answers
+// keys (factor/mod.rs:336-349,412-449).  The host knows which keys are there (they fill structurally); k_keyless_ir evaluates
+// such a factor in front of the sweep launch: key bit 0 = the owner's variable has delivered, bit 1 = the target's has.
+struct KeylessRec {
+    int32_t edge;       // index into the edge arrays
+    int32_t tgt_robot;  // device index of the target robot (whose workgroup would evaluate the edge)
+    uint32_t keys;
+    uint32_t pad;
+};
+
 // Missions on the device (the driver's reached_waypoint and Transform increment, robot.rs:2080-2176,2309-2335):
 // per robot (device index == robot id: unsharded worlds) its route, the next waypoint, the reached-when rules of
 // formation.yaml and the Bevy Transform it moves.

@@ -1399,7 +1399,7 @@ __global__ void k_thaw_ir(DevWorld w, uint8_t *gate) {
     for (int j = threadIdx.x; j < ne; j += blockDim.x) {
         const int e = ie0 + j;
         const uint8_t g = gate[e];
-        if (!g) continue;
+        if (!g || g == 3) continue;  // 3: a factor that still lacks inbox keys, settled by k_keyless_ir
         const IrEdgeRec er = w.ir_rec[e];
         if (w.snap_epoch[w.cur][er.src_var] != w.ir_thaw_epoch[er.src_var]) {  // the owner has delivered since: live record
             if (g == 2) gate[e] = 1;
@@ -1426,6 +1426,39 @@ __global__ void k_thaw_ir(DevWorld w, uint8_t *gate) {
         w.ir_fv_lam[5 * (size_t)w.NI + e] = ok ? ol[5] : 0.0;
         gate[e] = 2;
     }
+}
+
+// Inter-robot factors that still lack inbox keys (KeylessRec, mgx_dev.h), in front of a launch with an external factor sweep:
+//   no key, or only the owner's variable's: the factor has no entry to answer for the target's variable — nothing is sent,
+//     the message the variable holds stays (factor/mod.rs:412-449 iterates the keys it has);
+//   only the target's variable's: that variable is the factor's ONLY inbox entry, so it sits in slot 0 of the linearisation
+//     point whatever the two graphs' order, the other slot is zeros, and the message to it is marginalised with nothing added
+//     (factor/mod.rs:336-349, marginalise_factor_distance.rs:74-127);
+//   both: the sweep kernel's edge lane evaluates it like any other factor.
+// Edges handled here are marked gate 3 ("on air, settled: neither the edge lane nor k_thaw_ir touches it") for the coming launch.
+__global__ void k_keyless_ir(DevWorld w, uint8_t *gate, int n, const KeylessRec *__restrict__ recs) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const KeylessRec kr = recs[t];
+    const int e = kr.edge;
+    if (!gate[e] || kr.keys == 3u) return;  // owner off the air: nobody evaluates it; complete: the edge lane does
+    const bool radio_b = w.antenna[kr.tgt_robot] != 0 && w.idle[kr.tgt_robot] == 0;
+    if (!radio_b || !(w.enable & 2u)) return;
+    if (kr.keys == 2u) {
+        const IrEdgeRec er = w.ir_rec[e];
+        double b_mu[4], zero4[4] = {0.0, 0.0, 0.0, 0.0}, zero16[16], oe[4], ol[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) zero16[c] = 0.0;
+        ld_soa4(w.ir_bmu, w.NI, e, b_mu);
+        const bool ok = interrobot_message(b_mu, zero4, er.d_safe, er.offset, w.inv_s2_ir, 0, zero4, zero16, oe, ol);
+        w.ir_fv_eta[0 * (size_t)w.NI + e] = ok ? oe[0] : 0.0;
+        w.ir_fv_eta[1 * (size_t)w.NI + e] = ok ? oe[1] : 0.0;
+        w.ir_fv_lam[0 * (size_t)w.NI + e] = ok ? ol[0] : 0.0;
+        w.ir_fv_lam[1 * (size_t)w.NI + e] = ok ? ol[1] : 0.0;
+        w.ir_fv_lam[4 * (size_t)w.NI + e] = ok ? ol[4] : 0.0;
+        w.ir_fv_lam[5 * (size_t)w.NI + e] = ok ? ol[5] : 0.0;
+    }
+    gate[e] = 3;
 }
 
 // halo: the snapshot records (variables 0..K-1: eta, lam, mu; then the K epochs) of whole robots
@@ -1852,6 +1885,11 @@ hipError_t launch_thaw_done(const DevWorld &w, int robot0, int n_robots, int cle
 hipError_t launch_ir_freeze(const DevWorld &w, double *frozen_snap, uint32_t *frozen_epoch, hipStream_t stream) {
     if (w.V <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_ir_freeze, dim3((unsigned)((w.V + 255) / 256)), dim3(256), 0, stream, w, frozen_snap, frozen_epoch);
+    return hipGetLastError();
+}
+hipError_t launch_keyless_ir(const DevWorld &w, uint8_t *gate, int n, const KeylessRec *recs, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_keyless_ir, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, w, gate, n, recs);
     return hipGetLastError();
 }
 hipError_t launch_thaw_ir(const DevWorld &w, uint8_t *gate, hipStream_t stream) {

@@ -44,6 +44,7 @@ hipError_t launch_copy_bytes(uint8_t *dst, const uint8_t *src, size_t n, hipStre
 hipError_t launch_freeze(const DevWorld &w, uint32_t kinds, hipStream_t stream);
 hipError_t launch_ir_freeze(const DevWorld &w, double *frozen_snap, uint32_t *frozen_epoch, hipStream_t stream);
 hipError_t launch_thaw_ir(const DevWorld &w, uint8_t *gate, hipStream_t stream);
+hipError_t launch_keyless_ir(const DevWorld &w, uint8_t *gate, int n, const KeylessRec *recs, hipStream_t stream);
 hipError_t launch_or_bytes(uint8_t *p, int n, uint8_t keep, uint8_t set, hipStream_t stream);
 hipError_t launch_thaw(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, hipStream_t stream);
 hipError_t launch_thaw_done(const DevWorld &w, int robot0, int n_robots, int clear, hipStream_t stream);
@@ -1180,6 +1181,28 @@ static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_ma
         const int out = writes_snap ? 1 - w->d.cur : -1;
         const bool thawing = w->thaw_kinds && (int_mask & PH_INT_FACTOR) && n_int > 0;
         if (thawing) HIP_TRY(launch_thaw(w->d, 0, w->d.R_local, ext_mask, w->stream));
+        if (w->n_keyless > 0 && (ext_mask & PH_EXT_FACTOR) && (w->p.enable_mask & 2u)) {
+            // factors created while their kind was switched off and not yet in possession of both inbox keys (KeylessRec):
+            // the keys fill structurally, so the log says which ones are there now
+            flush_counts(w);
+            std::vector<KeylessRec> recs;
+            for (const IrConn &c : w->conns) {
+                if (c.keys.empty() || c.dev_slot < 0) continue;
+                const int tr = w->dev_of[(size_t)c.other];
+                for (size_t j = 0; j < c.keys.size(); j++)
+                    recs.push_back(KeylessRec{(int32_t)edge_index(w->dev_in_ptr, w->K, tr, (int)j, c.dev_slot), tr, (uint32_t)c.keys[j], 0u});
+            }
+            if (!recs.empty()) {
+                void *hp = nullptr, *dp = nullptr;
+                int slot = 0;
+                HIP_TRY(w->stage.acquire(sizeof(KeylessRec) * recs.size(), &hp, &slot));
+                memcpy(hp, recs.data(), sizeof(KeylessRec) * recs.size());
+                HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+                HIP_TRY(launch_keyless_ir(w->d, w->ir_gate.p, (int)recs.size(), (const KeylessRec *)dp, w->stream));
+                HIP_TRY(w->stage.release(slot, w->stream));
+                w->flags_dirty = true;  // the gate bytes go back to 0 / 1 in front of the next launch
+            }
+        }
         if (w->ir_thaw_active && (ext_mask & PH_EXT_FACTOR) && w->d.NI > 0 && !w->conns.empty())
             HIP_TRY(launch_thaw_ir(w->d, w->ir_gate.p, w->stream));
         HIP_TRY(launch_robot_sweep(w->d, 0, w->d.R_local, ext_mask, int_mask, n_int, out, hints, w->stream));
@@ -1286,7 +1309,7 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
     if (rc != MGX_OK) return rc;
     const DevWorld &d = w->d;
     if (d.R_total != d.R_local || d.ir_max_edges == 0 || w->conns.empty() || !(w->p.enable_mask & 2u)) return 0;
-    if (w->thaw_kinds || w->ir_thaw_active || w->direct.connected || w->rccl.connected) return 0;
+    if (w->thaw_kinds || w->ir_thaw_active || w->n_keyless > 0 || w->direct.connected || w->rccl.connected) return 0;
     if (sweep_lds_bytes(w->K, d.ir_max_edges, true) > 64 * 1024) return 0;
     for (const Launch &l : plan)
         if (l.n_int > 255) return 0;

@@ -15,10 +15,9 @@ from magics_amd import scenarios as S  # noqa: E402
 from parity import make_pair  # noqa: E402
 
 
-# Connections created WHILE inter-robot factors are switched off are outside the domain by default (such
-# a factor starts with an empty inbox and the reference sends nothing to the other robot's variable until that
-# variable has answered once; the engine does not keep that key yet) — MGX_SOAK_CONNECT_WHILE_OFF=1 includes them.
-CONNECT_WHILE_OFF = os.environ.get("MGX_SOAK_CONNECT_WHILE_OFF", "0") == "1"
+# Connections created WHILE inter-robot factors are switched off are part of the mix since round 2 (such a
+# factor starts without inbox keys and answers only the keys it has; k_keyless_ir) — MGX_SOAK_CONNECT_WHILE_OFF=0 leaves them out.
+CONNECT_WHILE_OFF = os.environ.get("MGX_SOAK_CONNECT_WHILE_OFF", "1") == "1"
 # Kinds may be switched off before the world's first iteration (MGX_SOAK_SWITCH_BEFORE_FIRST_ITERATION=0 starts every script
 # with one iteration instead: that was the domain while tracking factors frozen before their first delivery were still wrong).
 SWITCH_FIRST = os.environ.get("MGX_SOAK_SWITCH_BEFORE_FIRST_ITERATION", "1") == "1"
