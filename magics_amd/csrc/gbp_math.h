@@ -37,6 +37,17 @@ MGX_HD void minors_of_removed_row(const double (&r0)[4], const double (&r1)[4], 
         mn[j] = (a * (e * k - f * h) - b * (d * k - f * g)) + c * (d * h - e * g);
     }
 }
+// the first two of them (columns 0, 1)
+MGX_HD void minors_of_removed_row_first2(const double (&r0)[4], const double (&r1)[4], const double (&r2)[4], double (&mn)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int c0 = (j == 0) ? 1 : 0, c1 = 2, c2 = 3;
+        const double a = r0[c0], b = r0[c1], c = r0[c2];
+        const double d = r1[c0], e = r1[c1], f = r1[c2];
+        const double g = r2[c0], h = r2[c1], k = r2[c2];
+        mn[j] = (a * (e * k - f * h) - b * (d * k - f * g)) + c * (d * h - e * g);
+    }
+}
 // cofactors C(i, 0..3) of row i from the minors of that row
 MGX_HD void cofactors_from_minors(int i, const double (&mn)[4], double (&cf)[4]) {
 #pragma unroll
@@ -338,6 +349,78 @@ MGX_HD bool interrobot_message(const double (&x_lo)[4], const double (&x_hi)[4],
     ea[0] = wa0 * rhs; ea[1] = wa1 * rhs; ea[2] = 0.0; ea[3] = 0.0;
     eb[0] = wb0 * rhs + eo[0]; eb[1] = wb1 * rhs + eo[1]; eb[2] = eo[2]; eb[3] = eo[3];
     return schur4(laa, lab, lba, lbb, ea, eb, out_eta, out_lam);
+}
+
+// The same message in the form the engine keeps it (six numbers — eta[0..1] and the position block of lam; the
+// velocity rows and columns of an inter-robot message are structural zeros): only the terms that are not products with a
+// structural zero of the Jacobian blocks are evaluated, each kept output by the same operations in the same order as above.
+//   Lab, Lba, Laa have entries in their top-left 2x2 only, so T = Lab W needs rows 0, 1 of W = Lbb^-1 (ten of the sixteen
+//   cofactors: columns 0, 1 of the cofactor matrix and row 0 for the determinant), eta[r] = ea[r] - T[r][0..3] . eb, and
+//   lam[r][c] = Laa[r][c] - (T[r][0] Lba[0][c] + T[r][1] Lba[1][c]) for r, c < 2; everything else of the dense result is
+//   0 - (sums of x * 0), which is never infinite, so the `Message::empty()` test reads the four kept entries.
+// x + 0.0 * y == x for finite y: the kept numbers equal interrobot_message's unless the dense form meets inf / NaN there
+// (structural zeros).  out: eta0, eta1, lam00, lam01, lam10, lam11.
+MGX_HD bool interrobot_message_compact(const double (&x_lo)[4], const double (&x_hi)[4], double d_safe, double tiny_offset,
+                                       double inv_sigma2, int dst_slot, const double (&eo)[4], const double (&lo)[16],
+                                       double (&out)[6]) {
+    const double dx = x_lo[0] - x_hi[0], dy = x_lo[1] - x_hi[1];
+    if (dx * dx + dy * dy >= d_safe * d_safe) return false;
+    const double d0 = dx + tiny_offset, d1 = dy + tiny_offset;
+    const double r = std::sqrt(d0 * d0 + d1 * d1);
+    double h0 = 0.0, jl0 = 0.0, jl1 = 0.0, jh0 = 0.0, jh1 = 0.0;
+    if (r <= d_safe) {
+        h0 = 1.0 * (1.0 - r / d_safe);
+        const double cl = -1.0 / d_safe / r, ch = 1.0 / d_safe / r;
+        jl0 = cl * d0; jl1 = cl * d1; jh0 = ch * d0; jh1 = ch * d1;
+    }
+    const double jx = (jl0 * x_lo[0] + jh0 * x_hi[0]) + (jl1 * x_lo[1] + jh1 * x_hi[1]);
+    const double rhs = jx + (0.0 - h0);
+    const double ja0 = dst_slot ? jh0 : jl0, ja1 = dst_slot ? jh1 : jl1;
+    const double jb0 = dst_slot ? jl0 : jh0, jb1 = dst_slot ? jl1 : jh1;
+    const double wa0 = ja0 * inv_sigma2, wa1 = ja1 * inv_sigma2;
+    const double wb0 = jb0 * inv_sigma2, wb1 = jb1 * inv_sigma2;
+    double lbb[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) lbb[i] = lo[i];
+    lbb[0] = wb0 * jb0 + lo[0]; lbb[1] = wb0 * jb1 + lo[1]; lbb[4] = wb1 * jb0 + lo[4]; lbb[5] = wb1 * jb1 + lo[5];
+    // rows 0, 1 of W: W[j][i] = C(i, j) / det
+    double cf0[4], c0[4], c1[4];  // cofactors of row 0; columns 0, 1 of the cofactor matrix
+    {
+        const double r0[4] = {lbb[0], lbb[1], lbb[2], lbb[3]}, r1[4] = {lbb[4], lbb[5], lbb[6], lbb[7]};
+        const double r2[4] = {lbb[8], lbb[9], lbb[10], lbb[11]}, r3[4] = {lbb[12], lbb[13], lbb[14], lbb[15]};
+        double mn[4];
+        minors_of_removed_row(r1, r2, r3, mn);
+        cofactors_from_minors(0, mn, cf0);
+        c0[0] = cf0[0]; c1[0] = cf0[1];
+        double m2[2];
+        minors_of_removed_row_first2(r0, r2, r3, m2);
+        c0[1] = -m2[0]; c1[1] = m2[1];
+        minors_of_removed_row_first2(r0, r1, r3, m2);
+        c0[2] = m2[0]; c1[2] = -m2[1];
+        minors_of_removed_row_first2(r0, r1, r2, m2);
+        c0[3] = -m2[0]; c1[3] = m2[1];
+        const double det = det_from_row0(r0, cf0);
+        if (det == 0.0) return false;
+        const double id = 1.0 / det;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { c0[i] = c0[i] * id; c1[i] = c1[i] * id; }  // W[0][i], W[1][i]
+    }
+    const double lab00 = wa0 * jb0, lab01 = wa0 * jb1, lab10 = wa1 * jb0, lab11 = wa1 * jb1;
+    double t0[4], t1[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        t0[c] = lab00 * c0[c] + lab01 * c1[c];
+        t1[c] = lab10 * c0[c] + lab11 * c1[c];
+    }
+    const double eb0 = wb0 * rhs + eo[0], eb1 = wb1 * rhs + eo[1];
+    out[0] = wa0 * rhs - (((t0[0] * eb0 + t0[1] * eb1) + t0[2] * eo[2]) + t0[3] * eo[3]);
+    out[1] = wa1 * rhs - (((t1[0] * eb0 + t1[1] * eb1) + t1[2] * eo[2]) + t1[3] * eo[3]);
+    const double lba00 = wb0 * ja0, lba01 = wb0 * ja1, lba10 = wb1 * ja0, lba11 = wb1 * ja1;
+    out[2] = wa0 * ja0 - (t0[0] * lba00 + t0[1] * lba10);
+    out[3] = wa0 * ja1 - (t0[0] * lba01 + t0[1] * lba11);
+    out[4] = wa1 * ja0 - (t1[0] * lba00 + t1[1] * lba10);
+    out[5] = wa1 * ja1 - (t1[0] * lba01 + t1[1] * lba11);
+    return !(std::isinf(out[2]) || std::isinf(out[3]) || std::isinf(out[4]) || std::isinf(out[5]));
 }
 
 // ---------------------------------------------------------------------------------------

@@ -182,8 +182,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     constexpr bool BIG = KT < 0 || KT > 33;
     STAMP(t_k0);
     const int r = robot0 + xcd_local_index(blockIdx.x, gridDim.x);
-    const int tid = threadIdx.x;
-    const int role = tid >> 6, lane = tid & 63;
+    int tid = threadIdx.x;  // not const: resident launches make them opaque once per segment, see the segment loop
+    const int role = tid >> 6;
+    int lane = tid & 63;
     const int K = KT > 0 ? KT : w.K, E = 4 * K - 6, E1 = E + 1;
     const BlobLayout L(K);
     const int ZCOL = E;  // all-zero message column (absent edges)
@@ -230,9 +231,11 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     const bool bel_dead = ((hints & HINT_LATER_EXT_VARIABLE) && radio) || ((hints & HINT_LATER_INT_VARIABLE) && !idle);
 
     // DYN wave: constant potential blocks of this lane's message
+    // (resident launches fetch them from L2 in every sweep instead: the DYN wave has the time — it computes its messages ahead,
+    // under the hand-off — and the 32 registers are what the segment loop would otherwise spill)
     double maa[4], mab[4], mba[4], mbb[4];
     int dyn_other_var = 0, dyn_other_edge = 0;
-    if (is_dyn) {
+    auto load_dyn_potential = [&](double (&paa)[4], double (&pab)[4], double (&pba)[4], double (&pbb)[4]) __attribute__((always_inline)) {
         const int f = lane % (K - 1), slot = lane / (K - 1);
         const int a2 = 2 * slot, b2 = 2 * (1 - slot);
         const int it = r * (K - 1) + f;
@@ -240,11 +243,15 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                maa[i * 2 + j] = w.dyn_m[(size_t)((a2 + i) * 4 + (a2 + j)) * w.ND + it];
-                mab[i * 2 + j] = w.dyn_m[(size_t)((a2 + i) * 4 + (b2 + j)) * w.ND + it];
-                mba[i * 2 + j] = w.dyn_m[(size_t)((b2 + i) * 4 + (a2 + j)) * w.ND + it];
-                mbb[i * 2 + j] = w.dyn_m[(size_t)((b2 + i) * 4 + (b2 + j)) * w.ND + it];
+                paa[i * 2 + j] = w.dyn_m[(size_t)((a2 + i) * 4 + (a2 + j)) * w.ND + it];
+                pab[i * 2 + j] = w.dyn_m[(size_t)((a2 + i) * 4 + (b2 + j)) * w.ND + it];
+                pba[i * 2 + j] = w.dyn_m[(size_t)((b2 + i) * 4 + (a2 + j)) * w.ND + it];
+                pbb[i * 2 + j] = w.dyn_m[(size_t)((b2 + i) * 4 + (b2 + j)) * w.ND + it];
             }
+    };
+    if (is_dyn) {
+        const int f = lane % (K - 1), slot = lane / (K - 1);
+        if (!PERSIST) load_dyn_potential(maa, mab, mba, mbb);
         dyn_other_var = f + 1 - slot;
         dyn_other_edge = (1 - slot) * (K - 1) + f;
     }
@@ -481,6 +488,11 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // descriptors of the two snapshot buffers for the 16-byte agent-scope accesses of resident launches
     const unsigned snap_bytes = (unsigned)w.V * (unsigned)(SNAP_W * sizeof(double));
     const __amdgpu_buffer_rsrc_t rs_snap[2] = {sc1_rsrc(w.snap[0], PERSIST ? snap_bytes : 0u), sc1_rsrc(w.snap[1], PERSIST ? snap_bytes : 0u)};
+    // resident launches: the response means (ir_bmu) of every edge of variable i that is on air are the variable's mean after the
+    // external variable sweep — kept in LDS (the scratch sums' block, idle between that sweep's finish and the next one's sums)
+    // from one segment to the next; HBM gets them once, after the launch's last external iteration
+    double *s_xmu = s_tmp;
+    bool have_xmu = false;
     auto external_factor_sweep = [&](int k, bool store_fv) __attribute__((always_inline)) {
         const int buf = PERSIST ? ((w.cur + k) & 1) : w.cur;  // snapshot buffer the owners' records are read from
         if (radio && ir_on) {
@@ -498,8 +510,13 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                         er = w.ir_rec[e];
                     }
                     double rec[SNAP_W];
+                    if (have_xmu) {  // the means this robot's external variable sweep of the previous segment answered with
+                        const int i = er.dst & 0xffff;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) b_mu[c] = ld_agent(&w.ir_bmu[(size_t)c * w.NI + e]);
+                        for (int c = 0; c < 4; c++) b_mu[c] = s_xmu[c * K + i];
+                    } else {
+                        ld_soa4(w.ir_bmu, w.NI, e, b_mu);  // written by an earlier launch
+                    }
                     a_present = ld_agent(&w.snap_epoch[buf][er.src_var]) > er.created;
                     const unsigned ro = (unsigned)er.src_var * (unsigned)(SNAP_W * sizeof(double));
 #pragma unroll
@@ -548,34 +565,35 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #pragma unroll
                     for (int c = 0; c < 16; c++) ao_lam[c] = 0.0;
                 }
+                // ONE evaluation for both slot orders (selects on the linearisation point): the lanes of a wave hold edges of
+                // both orders, and a branch around two inlined copies would run both for every wave
                 const int dslot = er.dst >> 16;
-                double oe[4], ol[16];
-                bool ok;
-                if (dslot)
-                    ok = interrobot_message(a_mu, b_mu, er.d_safe, er.offset, w.inv_s2_ir, 1, ao_eta, ao_lam, oe, ol);
-                else
-                    ok = interrobot_message(b_mu, a_mu, er.d_safe, er.offset, w.inv_s2_ir, 0, ao_eta, ao_lam, oe, ol);
-                if (!ok) {
+                double x_lo[4], x_hi[4], o6[6];
 #pragma unroll
-                    for (int c = 0; c < 4; c++) oe[c] = 0.0;
+                for (int c = 0; c < 4; c++) {
+                    x_lo[c] = dslot ? a_mu[c] : b_mu[c];
+                    x_hi[c] = dslot ? b_mu[c] : a_mu[c];
+                }
+                if (!interrobot_message_compact(x_lo, x_hi, er.d_safe, er.offset, w.inv_s2_ir, dslot, ao_eta, ao_lam, o6)) {
 #pragma unroll
-                    for (int c = 0; c < 16; c++) ol[c] = 0.0;
+                    for (int c = 0; c < 6; c++) o6[c] = 0.0;
                 }
                 // HINT_IR_DEAD: the caller's next sweep recomputes these messages before reading them (it
                 // starts with an external factor sweep under the same flags), and this launch reads
                 // them from LDS — then the HBM copy is dead and not stored; likewise every external
                 // iteration of a resident schedule launch but its last one
                 if (store_fv && !(STAGE_IR && (hints & HINT_IR_DEAD))) {
-                    w.ir_fv_eta[0 * (size_t)w.NI + e] = oe[0];
-                    w.ir_fv_eta[1 * (size_t)w.NI + e] = oe[1];
-                    w.ir_fv_lam[0 * (size_t)w.NI + e] = ol[0];
-                    w.ir_fv_lam[1 * (size_t)w.NI + e] = ol[1];
-                    w.ir_fv_lam[4 * (size_t)w.NI + e] = ol[4];
-                    w.ir_fv_lam[5 * (size_t)w.NI + e] = ol[5];
+                    w.ir_fv_eta[0 * (size_t)w.NI + e] = o6[0];
+                    w.ir_fv_eta[1 * (size_t)w.NI + e] = o6[1];
+                    w.ir_fv_lam[0 * (size_t)w.NI + e] = o6[2];
+                    w.ir_fv_lam[1 * (size_t)w.NI + e] = o6[3];
+                    w.ir_fv_lam[4 * (size_t)w.NI + e] = o6[4];
+                    w.ir_fv_lam[5 * (size_t)w.NI + e] = o6[5];
                 }
                 if (STAGE_IR) {
                     double *p = s_ir + j * IR_STRIDE;
-                    p[0] = oe[0]; p[1] = oe[1]; p[2] = ol[0]; p[3] = ol[1]; p[4] = ol[4]; p[5] = ol[5];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) p[c] = o6[c];
                 }
             }
         }
@@ -696,6 +714,13 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     auto dynamic_messages = [&](double *s_out) {
         double me[4], ml[16], oe[4], ol[16];
         const int o = dyn_other_var, oe_ix = dyn_other_edge;
+        double paa[4], pab[4], pba[4], pbb[4];
+        if (PERSIST) {
+            load_dyn_potential(paa, pab, pba, pbb);  // requested first: they travel under the LDS reads below
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) { paa[c] = maa[c]; pab[c] = mab[c]; pba[c] = mba[c]; pbb[c] = mbb[c]; }
+        }
         if (s_epoch[o] > 0) {  // other variable has answered: belief - our last message
 #pragma unroll
             for (int c = 0; c < 4; c++) me[c] = s_snap[c * K + o] - s_fv[c * E1 + oe_ix];
@@ -721,7 +746,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #pragma unroll
             for (int c = 0; c < 16; c++) ml2[c] = pres ? s_snap[(4 + c) * K + o2] - s_fv[(4 + c) * E1 + oe2] : 0.0;
         }
-        if (!dynamic_message(maa, mab, mba, mbb, me, ml, oe, ol)) {
+        if (!dynamic_message(paa, pab, pba, pbb, me, ml, oe, ol)) {
 #pragma unroll
             for (int c = 0; c < 4; c++) oe[c] = 0.0;
 #pragma unroll
@@ -904,6 +929,10 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #define QBEGIN(v)
 #endif
     for (int k = 0; k < nseg; k++) {
+        // Nothing derived from the thread index stays live across segments: left alone, the compiler hoists every per-thread
+        // address and predicate of the loop body in front of the loop and then spills them around the f64 blocks (64 spilled
+        // VGPRs, 244 B of scratch per lane at K = 16); recomputing them per segment is a handful of integer instructions.
+        if (PERSIST) asm volatile("" : "+v"(tid), "+v"(lane));
         const uint32_t ext_k = PERSIST ? (plan.ext[k] ? (PH_EXT_FACTOR | PH_EXT_VARIABLE) : 0u) : ext_mask;
         const uint32_t int_k = PERSIST ? (PH_INT_FACTOR | PH_INT_VARIABLE) : int_mask;
         const int n_int_k = PERSIST ? (int)plan.n_int[k] : n_int;
@@ -954,7 +983,10 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             QSTAMP(6, qt);
             __syncthreads();
             QSTAMP(7, qt);
-            if (radio && ir_on) {
+            if (PERSIST && radio && ir_on && k != last_ext_seg) {
+                if (tid < 4 * K) s_xmu[tid] = s_mu[tid] - 0.0;  // read after the barrier that opens the next segment's factor sweep
+                have_xmu = true;
+            } else if (radio && ir_on) {
                 // responses to the foreign factors attached to our variables, routed to their inbox
                 // (robot.rs:1842-1858): only the mean of that inbox entry is ever used (it sets the
                 // linearisation point; eta / lam of the target side never reach the kept message).
@@ -1405,7 +1437,7 @@ __global__ void k_thaw_ir(DevWorld w, uint8_t *gate) {
             if (g == 2) gate[e] = 1;
             continue;
         }
-        double ao_eta[4], ao_lam[16], a_mu[4], b_mu[4], oe[4], ol[16];
+        double ao_eta[4], ao_lam[16], a_mu[4], b_mu[4], o6[6];
         ld_soa4(w.ir_bmu, w.NI, e, b_mu);
         const bool a_present = w.ir_frozen_epoch[er.src_var] > er.created;
         const double *rec = w.ir_frozen_snap + (size_t)er.src_var * SNAP_W;
@@ -1416,14 +1448,19 @@ __global__ void k_thaw_ir(DevWorld w, uint8_t *gate) {
 #pragma unroll
         for (int c = 0; c < 4; c++) a_mu[c] = a_present ? rec[20 + c] : 0.0;
         const int dslot = er.dst >> 16;
-        const bool ok = dslot ? interrobot_message(a_mu, b_mu, er.d_safe, er.offset, w.inv_s2_ir, 1, ao_eta, ao_lam, oe, ol)
-                              : interrobot_message(b_mu, a_mu, er.d_safe, er.offset, w.inv_s2_ir, 0, ao_eta, ao_lam, oe, ol);
-        w.ir_fv_eta[0 * (size_t)w.NI + e] = ok ? oe[0] : 0.0;
-        w.ir_fv_eta[1 * (size_t)w.NI + e] = ok ? oe[1] : 0.0;
-        w.ir_fv_lam[0 * (size_t)w.NI + e] = ok ? ol[0] : 0.0;
-        w.ir_fv_lam[1 * (size_t)w.NI + e] = ok ? ol[1] : 0.0;
-        w.ir_fv_lam[4 * (size_t)w.NI + e] = ok ? ol[4] : 0.0;
-        w.ir_fv_lam[5 * (size_t)w.NI + e] = ok ? ol[5] : 0.0;
+        double x_lo[4], x_hi[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            x_lo[c] = dslot ? a_mu[c] : b_mu[c];
+            x_hi[c] = dslot ? b_mu[c] : a_mu[c];
+        }
+        const bool ok = interrobot_message_compact(x_lo, x_hi, er.d_safe, er.offset, w.inv_s2_ir, dslot, ao_eta, ao_lam, o6);
+        w.ir_fv_eta[0 * (size_t)w.NI + e] = ok ? o6[0] : 0.0;
+        w.ir_fv_eta[1 * (size_t)w.NI + e] = ok ? o6[1] : 0.0;
+        w.ir_fv_lam[0 * (size_t)w.NI + e] = ok ? o6[2] : 0.0;
+        w.ir_fv_lam[1 * (size_t)w.NI + e] = ok ? o6[3] : 0.0;
+        w.ir_fv_lam[4 * (size_t)w.NI + e] = ok ? o6[4] : 0.0;
+        w.ir_fv_lam[5 * (size_t)w.NI + e] = ok ? o6[5] : 0.0;
         gate[e] = 2;
     }
 }
