@@ -874,6 +874,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // loads, s_sleep in between); a wait that outlasts the wall-clock bound raises the world's abort word, which
     // releases every waiter: the launch then ends with wrong beliefs and the host reports it (never a hung GPU).
     auto wait_for_peers = [&](int k) __attribute__((always_inline)) {
+#ifdef MGX_EXP_NOWAIT
+        return;
+#endif
         if (PERSIST && radio && ir_on && role == ROLE_UV) {
             const unsigned long long want = plan.flag_base + (unsigned long long)k;
             const int q1 = w.peer_ptr[r + 1];
