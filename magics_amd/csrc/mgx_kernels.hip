@@ -221,6 +221,13 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     const bool is_obs = role == ROLE_UV && lane < K - 2;
     const bool is_trk = role == ROLE_UV && lane >= K - 2 && lane < 2 * (K - 2);
     const bool is_var = role == ROLE_UV && lane < K;
+    // Horizons of at most 16 variables: the belief finish runs on FOUR lanes per variable (lane (q, i) computes cofactor row q of
+    // variable i, variable_finish_quad), and in resident launches the whole variable sweep — inbox sums and finish — stays on the
+    // UV wave with no workgroup barrier in between (FUSED).
+    constexpr bool QUADFIN = KT > 0 && 4 * KT <= 64;
+    constexpr bool FUSED = PERSIST && QUADFIN;
+    const int sum_t = FUSED ? (role == ROLE_UV ? lane : 4 * K) : tid;        // (variable, row) this thread sums: t = rr * K + i
+    const int sum_step = FUSED ? 4 * K : SWEEP_BLOCK;
     // which variable sweep of this launch is the robot's last one (its belief goes out)
     bool plan_int = false, plan_ext = false;  // PERSIST: some segment has internal iterations / an external iteration
     if (PERSIST)
@@ -478,7 +485,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         for (int t = tid; t < 20 * E1; t += SWEEP_BLOCK) s_sh[t] = s_fv[t];
         __syncthreads();
     }
-    uint32_t my_epoch = (tid < 4 * K) ? s_epoch[tid % K] : 0u;  // deliveries of the variable this thread sums
+    uint32_t my_epoch = (sum_t < 4 * K) ? s_epoch[sum_t % K] : 0u;  // deliveries of the variable this thread sums
     STAMP(t_staged);
 
     // ======================= external factor sweep (pull form) ================================
@@ -610,7 +617,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // also the (eta, lam) of the responses to own-graph factors (:301-330, factorgraph.rs:771-786).
     // s_out receives the sums ([20][K] image: the snapshot for internal sweeps).
     auto variable_sums = [&](double *s_out, bool internal, bool last) {
-        for (int t = tid; t < 4 * K; t += SWEEP_BLOCK) {
+        for (int t = sum_t; t < 4 * K; t += sum_step) {
             const int rr = t / K, i = t - rr * K;  // consecutive lanes -> consecutive variables: conflict-free LDS rows
             uint32_t epoch_reg = (4 * K <= SWEEP_BLOCK) ? my_epoch : s_epoch[i];
             const int es[4] = {(i >= 1) ? (K - 1) + (i - 1) : ZCOL, (i <= K - 2) ? i : ZCOL,
@@ -704,6 +711,71 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         if (internal) {
 #pragma unroll
             for (int c = 0; c < 4; c++) s_snap[(20 + c) * K + lane] = mu[c];
+        }
+    };
+
+    // The same on four lanes per variable (UV wave, lane = q * K + i): lane (q, i) computes the cofactors of row q from the three
+    // other rows — the expression inv4 evaluates for that row — i.e. column q of the covariance; the determinant comes from the
+    // q == 0 lane, the four columns meet in the covariance image in LDS, and lane (q, i) reads row q back for component q of
+    // the mean.  Every number is produced by the operations of belief_update in the same order.
+    auto variable_finish_quad = [&](const double *s_in, bool internal) {
+        const int q = lane / K, i = lane - q * K;
+        double eta[4], lam[16];
+#pragma unroll
+        for (int c = 0; c < 4; c++) eta[c] = s_in[c * K + i];
+#pragma unroll
+        for (int c = 0; c < 16; c++) lam[c] = s_in[(4 + c) * K + i];
+        double mu_q = s_mu[q * K + i];
+        bool not_zero = false;
+#pragma unroll
+        for (int c = 0; c < 16; c++) not_zero = not_zero || (lam[c] > 1e-6);
+        double r0[4], r1[4], r2[4], mn[4], cf[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            r0[c] = (q == 0) ? lam[4 + c] : lam[c];
+            r1[c] = (q <= 1) ? lam[8 + c] : lam[4 + c];
+            r2[c] = (q <= 2) ? lam[12 + c] : lam[8 + c];
+        }
+        minors_of_removed_row(r0, r1, r2, mn);
+#pragma unroll
+        for (int j = 0; j < 4; j++) cf[j] = ((q + j) & 1) ? -mn[j] : mn[j];
+        const double row0[4] = {lam[0], lam[1], lam[2], lam[3]};
+        const double det = __shfl(det_from_row0(row0, cf), i, 64);  // lane i is (q == 0, i)
+        const bool ok = not_zero && det != 0.0;
+        const double id = 1.0 / det;
+        double col[4];  // cov[j][q]
+        bool fin_own = true;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            col[j] = cf[j] * id;
+            fin_own = fin_own && std::isfinite(col[j]);
+        }
+        unsigned long long bad = __ballot(!fin_own);
+        bad |= (bad >> K) | (bad >> (2 * K)) | (bad >> (3 * K));
+        const bool fin = ((bad >> i) & 1ull) == 0ull;
+        if (ok) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) s_cov[(j * 4 + q) * K + i] = col[j];
+            __builtin_amdgcn_wave_barrier();  // one wave: its LDS reads below follow its LDS writes above
+            if (fin) {
+                double cq[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) cq[c] = s_cov[(q * 4 + c) * K + i];
+                mu_q = ((cq[0] * eta[0] + cq[1] * eta[1]) + cq[2] * eta[2]) + cq[3] * eta[3];
+                s_mu[q * K + i] = mu_q;
+            }
+            if (q == 0) {
+                s_valid[i] = fin ? 1 : 0;
+                s_covset[i] = 1;
+            }
+        }
+        if (internal) s_snap[(20 + q) * K + i] = mu_q;
+    };
+    auto finish = [&](const double *s_in, bool internal) __attribute__((always_inline)) {
+        if constexpr (QUADFIN) {
+            if (role == ROLE_UV && lane < 4 * K) variable_finish_quad(s_in, internal);
+        } else {
+            if (is_var) variable_finish(s_in, internal);
         }
     };
 
@@ -962,7 +1034,55 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #endif
         // ======================= external variable sweep ==========================================
         prefired = false;
-        if (ext_k & PH_EXT_VARIABLE) {
+        if constexpr (FUSED) {
+            // Resident launches, K <= 16.  The UV wave runs the whole external variable sweep — inbox sums, then the finish on
+            // four lanes per variable — with no workgroup barrier inside; a factor sweep of this segment's first internal
+            // iteration that was not computed ahead goes into the shadow block next to it (DYN wave: dynamic messages, UV
+            // wave after its finish: unary factors), and the shadow is adopted by exchanging the two blocks' roles.
+            if ((ext_k & PH_EXT_VARIABLE) && radio) {
+                const bool ext_is_last = last_seg && n_int_k == 0;
+                double *s_sum = ext_is_last ? s_prior : s_tmp;
+                prefired = !early && n_int_k > 0 && !idle && (int_k & PH_INT_FACTOR) && skip0 == 0u;
+                const bool keep_means = ir_on && k != last_ext_seg;
+                if (role == ROLE_UV) {
+                    variable_sums(s_sum, false, false);  // reads the messages of the last internal factor sweep (s_fv)
+                    QSTAMP(4, qt);
+                    finish(s_sum, false);
+                    // the response means stay in LDS for the next segment's factor sweep (same wave: these writes follow the
+                    // finish's reads of the eta sums they overwrite)
+                    if (keep_means && lane < 4 * K) s_xmu[lane] = s_mu[lane] - 0.0;
+                    if (prefired) unary_messages(0u, s_sh, itf);
+                } else if (prefired && is_dyn && (w.enable & 1u)) {
+                    dynamic_messages(s_sh);
+                }
+                QSTAMP(6, qt);
+                if (keep_means) {
+                    have_xmu = true;
+                } else if (ir_on) {  // the launch's last external iteration: the means go to HBM (robot.rs:1842-1858)
+                    __syncthreads();
+                    for (int j = tid; j < ne; j += SWEEP_BLOCK) {
+                        const int e = ie0 + j;
+                        int dst;
+                        if (j == tid) {
+                            if (!pf_gate) continue;
+                            dst = pf_dst;
+                        } else {
+                            if (!w.ir_gate[e]) continue;
+                            dst = w.ir_rec[e].dst;
+                        }
+                        const int i = dst & 0xffff;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = s_mu[c * K + i] - 0.0;
+                    }
+                }
+                if (prefired) __syncthreads();  // both waves' columns of the shadow are complete
+            }
+            if (early || prefired) {  // adopt the factor sweep that was computed into the shadow
+                double *t_ = s_fv;
+                s_fv = s_sh;
+                s_sh = t_;
+            }
+        } else if (ext_k & PH_EXT_VARIABLE) {
             // beliefs are recomputed, nothing is delivered to own factors (factorgraph.rs:794-826): the
             // sums go to the belief image if this is the robot's last sweep of the launch, else to scratch
             // (the image doubles as the prior, which every later sweep of the launch still needs)
@@ -1017,7 +1137,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         if (k == 0) { t_extv = __builtin_readcyclecounter(); t_loop0 = t_extv; rt0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
         // ======================= internal iterations ==============================================
-        if (PERSIST && early && !((ext_k & PH_EXT_VARIABLE) && radio)) {  // no external variable sweep ran: adopt here
+        if (PERSIST && !FUSED && early && !((ext_k & PH_EXT_VARIABLE) && radio)) {  // no external variable sweep ran: adopt here
             adopt_early(tid, SWEEP_BLOCK);
             __syncthreads();
         }
@@ -1031,7 +1151,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 if (is_dyn && (w.enable & 1u) && !(it == 0 && (skip0 & 1u))) dynamic_messages(s_fv);
                 // UV wave: first the belief of the previous sweep (mean, covariance) that the unary
                 // factors linearise at — same wave, so its LDS writes precede their LDS reads
-                if (pending && is_var) variable_finish(s_snap, true);
+                if (pending) finish(s_snap, true);
                 pending = false;
                 unary_messages(it == 0 ? skip0 : 0u, s_fv, itf);
                 itf += 1;
@@ -1064,7 +1184,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         if (PERSIST && !last_seg) {
             QSTAMP(9, qt);
             if (role == ROLE_UV) {
-                if (pending && is_var) variable_finish(s_snap, true);
+                if (pending) finish(s_snap, true);
                 QSTAMP(10, qt);
                 __builtin_amdgcn_wave_barrier();  // the wave's LDS writes (means) precede its LDS reads below
                 const int ob = (w.cur + k + 1) & 1;
@@ -1103,7 +1223,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         // already writes back what that does not touch — the factor -> variable messages and the belief
         // (eta, lam) image, three quarters of the robot's output.
         if (role == ROLE_UV) {
-            if (pending && is_var) variable_finish(s_snap, true);
+            if (pending) finish(s_snap, true);
         } else {
             copy_words_wave(blob + L.fv(), s_fv, 20 * E1, lane);
             if (any_sweep && !bel_dead) copy_words_wave(blob + L.bel(), s_prior, 20 * K, lane);
