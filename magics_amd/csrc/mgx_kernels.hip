@@ -200,7 +200,8 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     int32_t *s_irp = (int32_t *)(s_epoch + ((K + 1) & ~1));  // [3][K+1] inbox ranges of foreign factors
     int32_t *s_covset = s_irp + ((3 * (K + 1) + 1) & ~1);     // [K] this launch recomputed the variable's covariance
     // resident launches: shadow of s_fv that takes the factor sweep computed AHEAD of the external iteration it follows
-    double *s_sh = (double *)(s_covset + ((K + 1) & ~1));     // [20][E1] (PERSIST only)
+    int32_t *s_xok = s_covset + ((K + 1) & ~1);               // [K] (PERSIST only) outcome of a concurrent external belief update
+    double *s_sh = (double *)(s_xok + (PERSIST ? ((K + 1) & ~1) : 0));  // [20][E1] (PERSIST only)
     double *s_ir = s_sh + (PERSIST ? 20 * E1 : 0);            // [ne][IR_STRIDE] inter-robot messages (STAGE_IR)
 
     double *blob = w.blob + (size_t)r * w.BS;
@@ -500,8 +501,14 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // from one segment to the next; HBM gets them once, after the launch's last external iteration
     double *s_xmu = s_tmp;
     bool have_xmu = false;
+#ifdef MGX_STAMPS
+    unsigned long long q_arrive = 0ull, t_edges0 = 0ull;  // cycles from the start of the factor sweep until the thread's record is there
+#endif
     auto external_factor_sweep = [&](int k, bool store_fv) __attribute__((always_inline)) {
         const int buf = PERSIST ? ((w.cur + k) & 1) : w.cur;  // snapshot buffer the owners' records are read from
+#ifdef MGX_STAMPS
+        t_edges0 = __builtin_readcyclecounter();
+#endif
         if (radio && ir_on) {
             for (int j = tid; j < ne; j += SWEEP_BLOCK) {
                 const int e = ie0 + j;
@@ -528,6 +535,10 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     const unsigned ro = (unsigned)er.src_var * (unsigned)(SNAP_W * sizeof(double));
 #pragma unroll
                     for (int c = 0; c < SNAP_W / 2; c++) ld16_agent(rs_snap[buf], ro + 16u * c, rec[2 * c], rec[2 * c + 1]);
+#ifdef MGX_STAMPS
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (j == tid) { const unsigned long long _n = __builtin_readcyclecounter(); q_arrive += _n - t_edges0; }
+#endif
 #pragma unroll
                     for (int c = 0; c < 4; c++) ao_eta[c] = rec[c];
 #pragma unroll
@@ -616,8 +627,8 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // the prior is never -0.0, so this equals skipping the entry.  For an internal sweep the sums are
     // also the (eta, lam) of the responses to own-graph factors (:301-330, factorgraph.rs:771-786).
     // s_out receives the sums ([20][K] image: the snapshot for internal sweeps).
-    auto variable_sums = [&](double *s_out, bool internal, bool last) {
-        for (int t = sum_t; t < 4 * K; t += sum_step) {
+    auto variable_sums_from = [&](int t_first, int t_step, double *s_out, bool internal, bool last) __attribute__((always_inline)) {
+        for (int t = t_first; t < 4 * K; t += t_step) {
             const int rr = t / K, i = t - rr * K;  // consecutive lanes -> consecutive variables: conflict-free LDS rows
             uint32_t epoch_reg = (4 * K <= SWEEP_BLOCK) ? my_epoch : s_epoch[i];
             const int es[4] = {(i >= 1) ? (K - 1) + (i - 1) : ZCOL, (i <= K - 2) ? i : ZCOL,
@@ -688,6 +699,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             }
         }
     };
+    auto variable_sums = [&](double *s_out, bool internal, bool last) __attribute__((always_inline)) {
+        variable_sums_from(sum_t, sum_step, s_out, internal, last);
+    };
     // Second half of the variable update: covariance, validity and mean from (eta, lam)
     // (variable.rs:273-297), one lane per variable; for an internal sweep the mean also completes the
     // snapshot (the responses' mean, :317).
@@ -718,14 +732,15 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // other rows — the expression inv4 evaluates for that row — i.e. column q of the covariance; the determinant comes from the
     // q == 0 lane, the four columns meet in the covariance image in LDS, and lane (q, i) reads row q back for component q of
     // the mean.  Every number is produced by the operations of belief_update in the same order.
-    auto variable_finish_quad = [&](const double *s_in, bool internal) {
+    // core: (eta, lam) of variable i from s_in; when the precision is neither "zero" nor singular (ok) the covariance goes to
+    // cov_img ([16][K]) and, if it is finite (fin), mu_q becomes component q of the new mean
+    auto quad_core = [&](const double *s_in, double *cov_img, bool &ok, bool &fin, double &mu_q) __attribute__((always_inline)) {
         const int q = lane / K, i = lane - q * K;
         double eta[4], lam[16];
 #pragma unroll
         for (int c = 0; c < 4; c++) eta[c] = s_in[c * K + i];
 #pragma unroll
         for (int c = 0; c < 16; c++) lam[c] = s_in[(4 + c) * K + i];
-        double mu_q = s_mu[q * K + i];
         bool not_zero = false;
 #pragma unroll
         for (int c = 0; c < 16; c++) not_zero = not_zero || (lam[c] > 1e-6);
@@ -741,7 +756,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         for (int j = 0; j < 4; j++) cf[j] = ((q + j) & 1) ? -mn[j] : mn[j];
         const double row0[4] = {lam[0], lam[1], lam[2], lam[3]};
         const double det = __shfl(det_from_row0(row0, cf), i, 64);  // lane i is (q == 0, i)
-        const bool ok = not_zero && det != 0.0;
+        ok = not_zero && det != 0.0;
         const double id = 1.0 / det;
         double col[4];  // cov[j][q]
         bool fin_own = true;
@@ -752,18 +767,26 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         }
         unsigned long long bad = __ballot(!fin_own);
         bad |= (bad >> K) | (bad >> (2 * K)) | (bad >> (3 * K));
-        const bool fin = ((bad >> i) & 1ull) == 0ull;
+        fin = ((bad >> i) & 1ull) == 0ull;
         if (ok) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) s_cov[(j * 4 + q) * K + i] = col[j];
+            for (int j = 0; j < 4; j++) cov_img[(j * 4 + q) * K + i] = col[j];
             __builtin_amdgcn_wave_barrier();  // one wave: its LDS reads below follow its LDS writes above
             if (fin) {
                 double cq[4];
 #pragma unroll
-                for (int c = 0; c < 4; c++) cq[c] = s_cov[(q * 4 + c) * K + i];
+                for (int c = 0; c < 4; c++) cq[c] = cov_img[(q * 4 + c) * K + i];
                 mu_q = ((cq[0] * eta[0] + cq[1] * eta[1]) + cq[2] * eta[2]) + cq[3] * eta[3];
-                s_mu[q * K + i] = mu_q;
             }
+        }
+    };
+    auto variable_finish_quad = [&](const double *s_in, bool internal) {
+        const int q = lane / K, i = lane - q * K;
+        double mu_q = s_mu[q * K + i];
+        bool ok, fin;
+        quad_core(s_in, s_cov, ok, fin, mu_q);
+        if (ok) {
+            if (fin) s_mu[q * K + i] = mu_q;
             if (q == 0) {
                 s_valid[i] = fin ? 1 : 0;
                 s_covset[i] = 1;
@@ -945,16 +968,28 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // end of this segment overwrites.  One lane per peer polls that robot's progress word (relaxed agent-scope
     // loads, s_sleep in between); a wait that outlasts the wall-clock bound raises the world's abort word, which
     // releases every waiter: the launch then ends with wrong beliefs and the host reports it (never a hung GPU).
+    // The peer list does not change during the launch: lane l of the polling wave keeps peer l (the one it polls in every
+    // segment) in a register — looked up per segment, the three dependent loads in front of the first look at a progress
+    // word (list range, peer, its antenna / idle flags) were a microsecond of pure latency on the hand-off.
+    int my_peer = -1, peer_q0 = 0, peer_q1 = 0;
+    if (PERSIST && radio && ir_on && role == ROLE_UV) {
+        peer_q0 = w.peer_ptr[r];
+        peer_q1 = w.peer_ptr[r + 1];
+        if (peer_q0 + lane < peer_q1) {
+            const int pr = w.peer_idx[peer_q0 + lane];
+            if (w.antenna[pr] && !w.idle[pr]) my_peer = pr;  // not on air: neither reads our records nor has its own read
+        }
+    }
     auto wait_for_peers = [&](int k) __attribute__((always_inline)) {
-#ifdef MGX_EXP_NOWAIT
-        return;
-#endif
         if (PERSIST && radio && ir_on && role == ROLE_UV) {
             const unsigned long long want = plan.flag_base + (unsigned long long)k;
-            const int q1 = w.peer_ptr[r + 1];
-            for (int q = w.peer_ptr[r] + lane; q < q1; q += 64) {
-                const int pr = w.peer_idx[q];
-                if (!w.antenna[pr] || w.idle[pr]) continue;  // not on air: neither reads our records nor has its own read
+            for (int q = peer_q0 + lane; q < peer_q1; q += 64) {
+                int pr = my_peer;
+                if (q != peer_q0 + lane) {  // more than 64 peers: the rest is looked up
+                    pr = w.peer_idx[q];
+                    if (!w.antenna[pr] || w.idle[pr]) pr = -1;
+                }
+                if (pr < 0) continue;
                 const long long t0 = wall_clock64();
                 unsigned spins = 0;
                 while (__hip_atomic_load(&w.sweep_flag[pr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
@@ -973,6 +1008,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     };
 
     bool prefired = false;  // both waves already ran the factor sweep of internal iteration 0
+    bool par_done = false;  // resident, K <= 16: this segment's two variable sweeps ran side by side
     bool pending = false;   // the last internal sums still await their finish (mean, covariance)
     // resident launches: the factor sweep of the coming segment's first internal iteration has been computed into
     // s_sh at the end of the previous segment, under the publish / wait latency of the hand-off (it reads nothing an
@@ -1039,7 +1075,87 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             // four lanes per variable — with no workgroup barrier inside; a factor sweep of this segment's first internal
             // iteration that was not computed ahead goes into the shadow block next to it (DYN wave: dynamic messages, UV
             // wave after its finish: unary factors), and the shadow is adopted by exchanging the two blocks' roles.
-            if ((ext_k & PH_EXT_VARIABLE) && radio) {
+            // The steady state of an alternating schedule (external iteration, ONE internal iteration whose factor sweep was
+            // computed ahead): the two variable sweeps read the same inboxes but for the internal factors' messages — the
+            // external one the old block, the internal one the shadow — and neither reads what the other writes, EXCEPT that
+            // a belief update which finds its precision "zero", singular or its covariance non-finite keeps the state the
+            // previous update left.  So they run side by side: the DYN wave the external sweep, into shadow images (means
+            // = the response means of the next factor sweep, covariance, outcome), the UV wave the internal one, keeping its
+            // means and flags back until the barrier; only a variable whose internal update did not go through looks at the
+            // external sweep's outcome afterwards.  Takes a whole variable sweep off the chain from record to publication.
+            par_done = (ext_k & PH_EXT_VARIABLE) && radio && early && n_int_k == 1;
+            if (par_done) {
+                const bool is_last = k == last_int_seg && last_seg;
+                const int q = lane / K, i = lane - q * K;  // lanes < 4 K of either wave
+                bool ok_i = false, fin_i = false;
+                double mu_i = 0.0;
+                if (role == ROLE_UV) {  // the messages computed ahead are this sweep's
+                    double *t_ = s_fv;
+                    s_fv = s_sh;
+                    s_sh = t_;
+                    variable_sums(s_snap, true, is_last);
+                    QSTAMP(4, qt);
+                    if (lane < 4 * K) quad_core(s_snap, s_cov, ok_i, fin_i, mu_i);
+                } else {
+                    if (lane < 4 * K) {
+                        variable_sums_from(lane, 4 * K, s_tmp, false, false);
+                        QSTAMP(4, qt);
+                        double mu_x = s_mu[q * K + i];  // the state before this segment: the UV wave stores after the barrier
+                        bool ok_x, fin_x;
+                        quad_core(s_tmp, s_tmp + 4 * K, ok_x, fin_x, mu_x);  // covariance over the lam sums it has read
+                        s_xmu[q * K + i] = mu_x - 0.0;                        // likewise over the eta sums
+                        if (q == 0) s_xok[i] = (ok_x ? 1 : 0) | (fin_x ? 2 : 0);
+                    }
+                    double *t_ = s_fv;
+                    s_fv = s_sh;
+                    s_sh = t_;
+                }
+                QSTAMP(6, qt);
+                __syncthreads();
+                QSTAMP(7, qt);
+                if (role == ROLE_UV && lane < 4 * K) {
+                    double mu_fin = mu_i;
+                    const int xs = s_xok[i];
+                    if (!(ok_i && fin_i)) {  // variable.rs:273-297 kept what the external update left
+                        mu_fin = s_xmu[q * K + i];
+                        if (!ok_i && (xs & 1)) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) s_cov[(j * 4 + q) * K + i] = s_tmp[(4 + j * 4 + q) * K + i];
+                        }
+                    }
+                    s_mu[q * K + i] = mu_fin;
+                    s_snap[(20 + q) * K + i] = mu_fin;
+                    if (q == 0) {
+                        if (ok_i) {
+                            s_valid[i] = fin_i ? 1 : 0;
+                            s_covset[i] = 1;
+                        } else if (xs & 1) {
+                            s_valid[i] = (xs & 2) ? 1 : 0;
+                            s_covset[i] = 1;
+                        }
+                    }
+                }
+                if (ir_on && k != last_ext_seg) {
+                    have_xmu = true;
+                } else if (ir_on) {  // the launch's last external iteration: the response means go to HBM (robot.rs:1842-1858)
+                    for (int j = tid; j < ne; j += SWEEP_BLOCK) {
+                        const int e = ie0 + j;
+                        int dst;
+                        if (j == tid) {
+                            if (!pf_gate) continue;
+                            dst = pf_dst;
+                        } else {
+                            if (!w.ir_gate[e]) continue;
+                            dst = w.ir_rec[e].dst;
+                        }
+                        const int iv = dst & 0xffff;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = s_xmu[c * K + iv];
+                    }
+                }
+                itf += 1;  // the factor sweep that was computed ahead
+                early = false;
+            } else if ((ext_k & PH_EXT_VARIABLE) && radio) {
                 const bool ext_is_last = last_seg && n_int_k == 0;
                 double *s_sum = ext_is_last ? s_prior : s_tmp;
                 prefired = !early && n_int_k > 0 && !idle && (int_k & PH_INT_FACTOR) && skip0 == 0u;
@@ -1143,7 +1259,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         }
         if (PERSIST && early) prefired = true;
         early = false;
-        for (int it = 0; it < n_int_k && !idle; it++) {
+        for (int it = 0; it < n_int_k && !idle && !par_done; it++) {
             STAMP(t0);
             if ((int_k & PH_INT_FACTOR) && it == 0 && prefired) {
                 itf += 1;  // this sweep ran next to the external variable sweep, in front of that block's last barrier
@@ -1241,6 +1357,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 d[0] = p_wait; d[1] = p_extf; d[2] = p_extv; d[3] = p_int; d[4] = p_pub;
                 unsigned long long *d2 = w.dbg + (size_t)(gridDim.x + 4) * 16 + ((size_t)blockIdx.x * 2 + role) * 16;
                 for (int i = 0; i < 16; i++) d2[i] = q[i];
+                d2[14] = q_arrive;
             }
         }
 #endif
@@ -1871,7 +1988,7 @@ size_t sweep_lds_bytes(int K, int ir_edges, bool resident) {  // resident: + the
     const BlobLayout L(K);
     const int io = L.inout_words() + (L.inout_words() & 1);
     return sizeof(double) * (size_t)((SNAP_W + 20 + 20) * K + io + IR_STRIDE * ir_edges + (resident ? 20 * L.E1 : 0)) +
-           4 * (size_t)(2 * ((K + 1) & ~1) + ((3 * (K + 1) + 1) & ~1));
+           4 * (size_t)((resident ? 3 : 2) * ((K + 1) & ~1) + ((3 * (K + 1) + 1) & ~1));
 }
 size_t sweep_lds_bytes(int K, int ir_edges) { return sweep_lds_bytes(K, ir_edges, false); }
 bool sweep_supports(int K) { return K >= 3 && 2 * (K - 1) <= 128; }  // beyond 33 variables: two dynamic messages per lane

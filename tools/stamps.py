@@ -48,7 +48,7 @@ for name, kw in (("config2", dict(interrobot=False)), ("config3", dict(interrobo
             print(f"config3 resident {rn}: per launch (10 iterations) cycles: wait {wt:.0f}  ext factor {ef:.0f}  ext variable {ev:.0f}  internal {it_:.0f}  "
                   f"finish+publish {pb:.0f}  staging {stg:.0f}  whole kernel {whole:.0f}  (wait max {a[:, role, 0].max():.0f} min {a[:, role, 0].min():.0f})")
             names = ["poll", "poll barrier", "ext factor edges", "its barrier", "ext var sums", "barrier", "ext finish | adopt", "barrier", "response means",
-                     "(internal)", "int finish", "publish stores", "drain", "early factor sweep", "-", "-"]
+                     "(internal)", "int finish", "publish stores", "drain", "early factor sweep", "records there (from sweep start)", "-"]
             m = sub[:1000, role, :].mean(axis=0) / 10.0
             print("   per iteration: " + "  ".join(f"{nm} {v:.0f}" for nm, v in zip(names, m) if nm != "-"))
         continue
