@@ -163,11 +163,34 @@ __device__ __forceinline__ void ld16_agent(__amdgpu_buffer_rsrc_t rs, unsigned b
     a = __hiloint2double((int)v.y, (int)v.x);
     b = __hiloint2double((int)v.w, (int)v.z);
 }
+__device__ __forceinline__ v4u32 ld16_agent_raw(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16);
+}
 __device__ __forceinline__ void st16_agent(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, double a, double b) {
     v4u32 v;
     v.x = (unsigned)__double2loint(a); v.y = (unsigned)__double2hiint(a);
     v.z = (unsigned)__double2loint(b); v.w = (unsigned)__double2hiint(b);
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, 16);
+}
+
+// 4 x 4 transposition inside every quad of lanes: on entry lane v holds x[s] = item (s, v), on exit lane s holds x[v] = item (s, v)
+// — two butterfly stages of DPP quad permutes, no LDS.
+__device__ __forceinline__ void quad_transpose4(unsigned (&x)[4], int lane) {
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+#pragma unroll
+    for (int p = 0; p < 4; p += 2) {  // lanes v, v ^ 1 exchange x[p + 1] of the even lane with x[p] of the odd one
+        const unsigned send = b0 ? x[p] : x[p + 1];
+        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xf, 0xf, true);  // quad_perm [1, 0, 3, 2]
+        x[p] = b0 ? recv : x[p];
+        x[p + 1] = b0 ? x[p + 1] : recv;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++) {  // lanes v, v ^ 2 exchange x[p + 2] of the lower lane with x[p] of the upper one
+        const unsigned send = b1 ? x[p] : x[p + 2];
+        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);  // quad_perm [2, 3, 0, 1]
+        x[p] = b1 ? recv : x[p];
+        x[p + 2] = b1 ? x[p + 2] : recv;
+    }
 }
 
 // PERSIST: the launch runs a whole schedule (SegPlan, mgx_dev.h) instead of one segment.
@@ -510,6 +533,46 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         t_edges0 = __builtin_readcyclecounter();
 #endif
         if (radio && ir_on) {
+            // Resident launches: the owners' records of every thread's first edge are fetched by QUADS of lanes — for each of
+            // its four lanes' records in turn, lane v of a quad asks for bytes [64 t + 16 v, + 16), t = 0..2, so that the four
+            // requests of a quad are one contiguous 64 bytes — and handed to their edge lanes by a 4 x 4 transposition inside
+            // the quad.  One lane fetching its own 192 bytes makes sixty-four scattered 16-byte requests per load instruction,
+            // and the gather was bound by their number: 0.45 us per 16 bytes per lane at 1000 robots, 5 us of an iteration
+            // (experiments/README.md); the same bytes by quads take a quarter of that.
+            double grec[SNAP_W];
+            if (PERSIST) {
+                const bool mine = tid < ne && pf_gate == 1;
+                const unsigned ro_mine = mine ? (unsigned)pf_er.src_var * (unsigned)(SNAP_W * sizeof(double)) : 0u;  // no edge: record 0, unused
+                v4u32 R[4][3];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+                    const int ctl = s4 * 0x55;  // quad_perm [s4, s4, s4, s4]: the record of lane s4 of the quad
+                    unsigned rb;
+                    if (s4 == 0) rb = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0x00, 0xf, 0xf, true);
+                    else if (s4 == 1) rb = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0x55, 0xf, 0xf, true);
+                    else if (s4 == 2) rb = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0xAA, 0xf, 0xf, true);
+                    else rb = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0xFF, 0xf, 0xf, true);
+                    (void)ctl;
+#pragma unroll
+                    for (int t3 = 0; t3 < 3; t3++) R[s4][t3] = ld16_agent_raw(rs_snap[buf], rb + 64u * t3 + 16u * (unsigned)(lane & 3));
+                }
+#pragma unroll
+                for (int t3 = 0; t3 < 3; t3++) {
+                    unsigned dw[4][4];  // [dword of the 16 bytes][record s -> piece v]
+#pragma unroll
+                    for (int wd = 0; wd < 4; wd++) {
+                        unsigned x[4] = {R[0][t3][wd], R[1][t3][wd], R[2][t3][wd], R[3][t3][wd]};
+                        quad_transpose4(x, lane);
+#pragma unroll
+                        for (int v = 0; v < 4; v++) dw[wd][v] = x[v];
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        grec[2 * (4 * t3 + v)] = __hiloint2double((int)dw[1][v], (int)dw[0][v]);
+                        grec[2 * (4 * t3 + v) + 1] = __hiloint2double((int)dw[3][v], (int)dw[2][v]);
+                    }
+                }
+            }
             for (int j = tid; j < ne; j += SWEEP_BLOCK) {
                 const int e = ie0 + j;
                 IrEdgeRec er;
@@ -533,8 +596,13 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     }
                     a_present = ld_agent(&w.snap_epoch[buf][er.src_var]) > er.created;
                     const unsigned ro = (unsigned)er.src_var * (unsigned)(SNAP_W * sizeof(double));
+                    if (j == tid) {
 #pragma unroll
-                    for (int c = 0; c < SNAP_W / 2; c++) ld16_agent(rs_snap[buf], ro + 16u * c, rec[2 * c], rec[2 * c + 1]);
+                        for (int c = 0; c < SNAP_W; c++) rec[c] = grec[c];
+                    } else {  // robots with more edges than threads
+#pragma unroll
+                        for (int c = 0; c < SNAP_W / 2; c++) ld16_agent(rs_snap[buf], ro + 16u * c, rec[2 * c], rec[2 * c + 1]);
+                    }
 #ifdef MGX_STAMPS
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (j == tid) { const unsigned long long _n = __builtin_readcyclecounter(); q_arrive += _n - t_edges0; }
@@ -1030,9 +1098,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     unsigned long long c_f = 0, c_fb = 0, c_v = 0, c_vb = 0, t_extf = t_staged, t_extv = t_staged, t_loop0 = t_staged;
     unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long p_wait = 0, p_extf = 0, p_extv = 0, p_int = 0, p_pub = 0;  // resident launches: cycles per stage, all segments
-    unsigned long long q[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // ... and inside the stages
+    unsigned long long qs[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // ... and inside the stages
 #define PSTAMP(v) const unsigned long long v = __builtin_readcyclecounter()
-#define QSTAMP(i, since) do { const unsigned long long _n = __builtin_readcyclecounter(); q[i] += _n - (since); (since) = _n; } while (0)
+#define QSTAMP(i, since) do { const unsigned long long _n = __builtin_readcyclecounter(); qs[i] += _n - (since); (since) = _n; } while (0)
 #define QBEGIN(v) unsigned long long v = __builtin_readcyclecounter()
 #else
 #define PSTAMP(v)
@@ -1356,7 +1424,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             if (PERSIST) {
                 d[0] = p_wait; d[1] = p_extf; d[2] = p_extv; d[3] = p_int; d[4] = p_pub;
                 unsigned long long *d2 = w.dbg + (size_t)(gridDim.x + 4) * 16 + ((size_t)blockIdx.x * 2 + role) * 16;
-                for (int i = 0; i < 16; i++) d2[i] = q[i];
+                for (int i = 0; i < 16; i++) d2[i] = qs[i];
                 d2[14] = q_arrive;
             }
         }
