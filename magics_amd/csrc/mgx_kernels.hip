@@ -324,6 +324,44 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         pf_er = w.ir_rec[ie0 + tid];
         pf_dst = pf_er.dst;
     }
+    // The owners' records of the threads' edges are fetched by QUADS of lanes: for each of its four lanes' records in turn, lane v
+    // of a quad asks for bytes [64 t + 16 v, + 16), t = 0..2 — the four requests of a quad are one contiguous 64 bytes — and a
+    // 4 x 4 transposition inside the quad hands every lane its own record.  One lane fetching its own 192 bytes makes sixty-four
+    // scattered 16-byte requests per load instruction, and the gather was bound by their number: 0.45 us per 16 bytes per lane
+    // at 1000 robots, 5 us of an iteration (experiments/README.md); the same bytes by quads take a quarter of that.  Every lane of
+    // the wave takes part (a lane without an edge passes offset 0: record 0 is fetched and dropped).
+    auto quad_gather = [&](auto fetch, unsigned ro_mine, double (&out)[SNAP_W]) __attribute__((always_inline)) {
+        v4u32 R[4][3];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            unsigned rb;  // the record of lane s4 of the quad
+            if (s4 == 0) rb = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0x00, 0xf, 0xf, true);
+            else if (s4 == 1) rb = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0x55, 0xf, 0xf, true);
+            else if (s4 == 2) rb = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0xAA, 0xf, 0xf, true);
+            else rb = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0xFF, 0xf, 0xf, true);
+#pragma unroll
+            for (int t3 = 0; t3 < 3; t3++) R[s4][t3] = fetch(rb + 64u * t3 + 16u * (unsigned)(lane & 3));
+        }
+#pragma unroll
+        for (int t3 = 0; t3 < 3; t3++) {
+            unsigned dw[4][4];  // [dword of the 16 bytes][piece v of the lane's own record]
+#pragma unroll
+            for (int wd = 0; wd < 4; wd++) {
+                unsigned x[4] = {R[0][t3][wd], R[1][t3][wd], R[2][t3][wd], R[3][t3][wd]};
+                quad_transpose4(x, lane);
+#pragma unroll
+                for (int v = 0; v < 4; v++) dw[wd][v] = x[v];
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                out[2 * (4 * t3 + v)] = __hiloint2double((int)dw[1][v], (int)dw[0][v]);
+                out[2 * (4 * t3 + v) + 1] = __hiloint2double((int)dw[3][v], (int)dw[2][v]);
+            }
+        }
+    };
+    auto fetch_plain = [&](unsigned off) __attribute__((always_inline)) {  // records written by an earlier launch
+        return *reinterpret_cast<const v4u32 *>(reinterpret_cast<const char *>(w.snap[w.cur]) + off);
+    };
     // per-variable words (K <= 64 < threads: one pass)
     uint32_t r_epoch = 0;
     int r_irp[3] = {0, 0, 0};
@@ -364,16 +402,10 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             r_ir[4] = w.ir_fv_lam[4 * (size_t)w.NI + e];
             r_ir[5] = w.ir_fv_lam[5 * (size_t)w.NI + e];
         }
-        if (do_extf && tid < ne && pf_gate == 1) {  // the owner's record (other robot, HBM / L2)
-            pf_on = true;
-            pf_present = w.snap_epoch[w.cur][pf_er.src_var] > pf_er.created;
-            const double2 *rec = reinterpret_cast<const double2 *>(w.snap[w.cur] + (size_t)pf_er.src_var * SNAP_W);
-#pragma unroll
-            for (int c = 0; c < SNAP_W / 2; c++) {  // absent (not yet delivered) records are zeroed when used
-                const double2 q = rec[c];
-                pf_rec[2 * c] = q.x;
-                pf_rec[2 * c + 1] = q.y;
-            }
+        if (do_extf) {  // the owners' records (other robots, HBM / L2); absent (not yet delivered) ones are zeroed when used
+            pf_on = tid < ne && pf_gate == 1;
+            if (pf_on) pf_present = w.snap_epoch[w.cur][pf_er.src_var] > pf_er.created;
+            quad_gather(fetch_plain, pf_on ? (unsigned)pf_er.src_var * (unsigned)(SNAP_W * sizeof(double)) : 0u, pf_rec);
         }
     };
     {
@@ -533,60 +565,31 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         t_edges0 = __builtin_readcyclecounter();
 #endif
         if (radio && ir_on) {
-            // Resident launches: the owners' records of every thread's first edge are fetched by QUADS of lanes — for each of
-            // its four lanes' records in turn, lane v of a quad asks for bytes [64 t + 16 v, + 16), t = 0..2, so that the four
-            // requests of a quad are one contiguous 64 bytes — and handed to their edge lanes by a 4 x 4 transposition inside
-            // the quad.  One lane fetching its own 192 bytes makes sixty-four scattered 16-byte requests per load instruction,
-            // and the gather was bound by their number: 0.45 us per 16 bytes per lane at 1000 robots, 5 us of an iteration
-            // (experiments/README.md); the same bytes by quads take a quarter of that.
-            double grec[SNAP_W];
-            if (PERSIST) {
-                const bool mine = tid < ne && pf_gate == 1;
-                const unsigned ro_mine = mine ? (unsigned)pf_er.src_var * (unsigned)(SNAP_W * sizeof(double)) : 0u;  // no edge: record 0, unused
-                v4u32 R[4][3];
-#pragma unroll
-                for (int s4 = 0; s4 < 4; s4++) {
-                    const int ctl = s4 * 0x55;  // quad_perm [s4, s4, s4, s4]: the record of lane s4 of the quad
-                    unsigned rb;
-                    if (s4 == 0) rb = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0x00, 0xf, 0xf, true);
-                    else if (s4 == 1) rb = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0x55, 0xf, 0xf, true);
-                    else if (s4 == 2) rb = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0xAA, 0xf, 0xf, true);
-                    else rb = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0xFF, 0xf, 0xf, true);
-                    (void)ctl;
-#pragma unroll
-                    for (int t3 = 0; t3 < 3; t3++) R[s4][t3] = ld16_agent_raw(rs_snap[buf], rb + 64u * t3 + 16u * (unsigned)(lane & 3));
-                }
-#pragma unroll
-                for (int t3 = 0; t3 < 3; t3++) {
-                    unsigned dw[4][4];  // [dword of the 16 bytes][record s -> piece v]
-#pragma unroll
-                    for (int wd = 0; wd < 4; wd++) {
-                        unsigned x[4] = {R[0][t3][wd], R[1][t3][wd], R[2][t3][wd], R[3][t3][wd]};
-                        quad_transpose4(x, lane);
-#pragma unroll
-                        for (int v = 0; v < 4; v++) dw[wd][v] = x[v];
-                    }
-#pragma unroll
-                    for (int v = 0; v < 4; v++) {
-                        grec[2 * (4 * t3 + v)] = __hiloint2double((int)dw[1][v], (int)dw[0][v]);
-                        grec[2 * (4 * t3 + v) + 1] = __hiloint2double((int)dw[3][v], (int)dw[2][v]);
-                    }
-                }
-            }
-            for (int j = tid; j < ne; j += SWEEP_BLOCK) {
+            auto fetch_sc1 = [&](unsigned off) __attribute__((always_inline)) { return ld16_agent_raw(rs_snap[buf], off); };
+            for (int j0 = 0; j0 < ne; j0 += SWEEP_BLOCK) {  // rounds of the whole workgroup: every lane takes part in the gather
+                const int j = j0 + tid;
                 const int e = ie0 + j;
-                IrEdgeRec er;
+                IrEdgeRec er{};
                 double ao_eta[4], ao_lam[16], a_mu[4], b_mu[4];
                 bool a_present;
-                if (PERSIST) {  // records published by other workgroups of THIS launch: agent-scope (sc1) loads, 16 bytes each
-                    if (j == tid) {
-                        if (pf_gate != 1) continue;
-                        er = pf_er;
-                    } else {
-                        if (w.ir_gate[e] != 1) continue;
+                // the round's record, unless it was prefetched while staging (launch-per-segment path, first round)
+                double grec[SNAP_W];
+                bool mine = false;
+                if (PERSIST || j0 > 0) {
+                    if (j0 == 0) {
+                        mine = tid < ne && pf_gate == 1;
+                        if (mine) er = pf_er;
+                    } else if (j < ne && w.ir_gate[e] == 1) {  // robots with more edges than threads
+                        mine = true;
                         er = w.ir_rec[e];
                     }
-                    double rec[SNAP_W];
+                    const unsigned ro_mine = mine ? (unsigned)er.src_var * (unsigned)(SNAP_W * sizeof(double)) : 0u;
+                    if (PERSIST) quad_gather(fetch_sc1, ro_mine, grec);  // published by other workgroups of THIS launch: agent scope
+                    else quad_gather(fetch_plain, ro_mine, grec);
+                    if (!mine) continue;
+                }
+
+                if (PERSIST) {
                     if (have_xmu) {  // the means this robot's external variable sweep of the previous segment answered with
                         const int i = er.dst & 0xffff;
 #pragma unroll
@@ -594,26 +597,26 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     } else {
                         ld_soa4(w.ir_bmu, w.NI, e, b_mu);  // written by an earlier launch
                     }
-                    a_present = ld_agent(&w.snap_epoch[buf][er.src_var]) > er.created;
-                    const unsigned ro = (unsigned)er.src_var * (unsigned)(SNAP_W * sizeof(double));
-                    if (j == tid) {
-#pragma unroll
-                        for (int c = 0; c < SNAP_W; c++) rec[c] = grec[c];
-                    } else {  // robots with more edges than threads
-#pragma unroll
-                        for (int c = 0; c < SNAP_W / 2; c++) ld16_agent(rs_snap[buf], ro + 16u * c, rec[2 * c], rec[2 * c + 1]);
+                    // has the owner's variable answered this factor yet?  Once it has it stays so: the thread's first edge
+                    // remembers (one scattered 4-byte request per lane and iteration less)
+                    if (j0 == 0 && pf_present) {
+                        a_present = true;
+                    } else {
+                        a_present = ld_agent(&w.snap_epoch[buf][er.src_var]) > er.created;
+                        if (j0 == 0) pf_present = a_present;
                     }
 #ifdef MGX_STAMPS
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (j == tid) { const unsigned long long _n = __builtin_readcyclecounter(); q_arrive += _n - t_edges0; }
+                    if (j0 == 0) { const unsigned long long _n = __builtin_readcyclecounter(); q_arrive += _n - t_edges0; }
 #endif
 #pragma unroll
-                    for (int c = 0; c < 4; c++) ao_eta[c] = rec[c];
+                    for (int c = 0; c < 4; c++) ao_eta[c] = grec[c];
 #pragma unroll
-                    for (int c = 0; c < 16; c++) ao_lam[c] = rec[4 + c];
+                    for (int c = 0; c < 16; c++) ao_lam[c] = grec[4 + c];
 #pragma unroll
-                    for (int c = 0; c < 4; c++) a_mu[c] = rec[20 + c];
-                } else if (j == tid) {  // operands prefetched during staging
+                    for (int c = 0; c < 4; c++) a_mu[c] = grec[20 + c];
+                } else if (j0 == 0) {  // operands prefetched during staging
+                    if (j >= ne) continue;
                     if (!pf_on) continue;  // the owner did not run its external factor sweep
                     er = pf_er;
                     a_present = pf_present;
@@ -626,24 +629,14 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #pragma unroll
                     for (int c = 0; c < 4; c++) a_mu[c] = pf_rec[20 + c];
                 } else {
-                    if (w.ir_gate[e] != 1) continue;
-                    er = w.ir_rec[e];
                     ld_soa4(w.ir_bmu, w.NI, e, b_mu);
                     a_present = w.snap_epoch[w.cur][er.src_var] > er.created;
-                    const double2 *rec2 = reinterpret_cast<const double2 *>(w.snap[w.cur] + (size_t)er.src_var * SNAP_W);
-                    double rec[SNAP_W];
 #pragma unroll
-                    for (int c = 0; c < SNAP_W / 2; c++) {
-                        const double2 q = rec2[c];
-                        rec[2 * c] = q.x;
-                        rec[2 * c + 1] = q.y;
-                    }
+                    for (int c = 0; c < 4; c++) ao_eta[c] = grec[c];
 #pragma unroll
-                    for (int c = 0; c < 4; c++) ao_eta[c] = rec[c];
+                    for (int c = 0; c < 16; c++) ao_lam[c] = grec[4 + c];
 #pragma unroll
-                    for (int c = 0; c < 16; c++) ao_lam[c] = rec[4 + c];
-#pragma unroll
-                    for (int c = 0; c < 4; c++) a_mu[c] = rec[20 + c];
+                    for (int c = 0; c < 4; c++) a_mu[c] = grec[20 + c];
                 }
                 if (!a_present) {  // the owner's variable has not answered this factor yet: empty inbox entry
 #pragma unroll
