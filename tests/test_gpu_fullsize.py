@@ -129,3 +129,23 @@ def test_config4_full_size_junction_tiles_tracking_without_interrobot_stays_fini
     sc = S.junction_scenario(4000, 32, tiles=20, interrobot=False)
     assert sc["params"]["enable_mask"] == 13 and not sc["ir"]
     _two_ticks(sc, finite=True)
+
+
+@pytest.mark.parametrize("K,n", [(16, 400), (12, 150), (10, 64)])
+def test_resident_launch_through_non_finite_beliefs(K, n):
+    """Inter-robot + tracking factors on the grid leave the finite range within a tick in the reference's own arithmetic (DESIGN.md
+    §2) — here at horizons of at most 16 variables, where a resident schedule launch runs the external and the internal variable
+    sweep side by side and a belief update that finds its precision "zero", singular or its covariance non-finite has to fall back
+    on what the other sweep left (variable.rs:273-297): identical wherever the oracle holds a number, tick after tick."""
+    sc = S.grid_scenario(n, K, interrobot=True, tracking=True)
+    eng, ref = World(sc["params"]), oracle.OracleWorld(sc["params"], threads=ORACLE_THREADS)
+    assert S.populate(eng, sc) == S.populate(ref, sc)
+    tick = S.tick_inputs(sc)
+    worst = 0.0
+    for t in range(6):
+        for w in (eng, ref):
+            w.tick(steps=sc["steps"], **tick)
+        assert eng.last_launch_count() == 1  # the resident path
+        worst = max(worst, assert_identical_where_finite(eng, ref, what=f"{sc['name']} K={K} tick {t}", max_nan_only_mismatch=5e-3))
+    if K == 16:
+        assert worst > 0.0  # this one does leave the finite range: the fall-back was exercised
