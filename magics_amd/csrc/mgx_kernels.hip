@@ -2102,10 +2102,26 @@ hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint3
 // How many workgroups of the resident kernel the device holds at once (0: this world's shape has no resident
 // form: no inter-robot edges, or too many per robot to stage in LDS).  Every workgroup of such a launch waits for
 // its neighbours INSIDE the launch, so all of them have to be resident together.
+// A workgroup may take up to the CU's whole 160 KB of LDS (MI355X_MICROARCH.md); beyond 64 KB the kernel has to be told.
+constexpr size_t RESIDENT_LDS_MAX = 160 * 1024;
+size_t sweep_resident_lds_max() { return RESIDENT_LDS_MAX; }
+template <int KT>
+static bool resident_allow_lds(size_t staged) {
+    if (staged <= 64 * 1024) return true;
+    static size_t allowed = 0;  // per instantiation
+    if (staged <= allowed) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_robot_sweep<KT, IR_STAGED, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)staged) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    allowed = staged;
+    return true;
+}
 template <int KT>
 static int resident_capacity_k(const DevWorld &w) {
     const size_t staged = sweep_lds_bytes(w.K, w.ir_max_edges, true);
-    if (w.ir_max_edges == 0 || staged > 64 * 1024) return 0;
+    if (w.ir_max_edges == 0 || staged > RESIDENT_LDS_MAX || !resident_allow_lds<KT>(staged)) return 0;
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
@@ -2123,6 +2139,7 @@ hipError_t launch_robot_schedule(const DevWorld &w, int n_robots, const SegPlan 
     if (n_robots <= 0 || plan.n <= 0) return hipSuccess;
     const size_t staged = sweep_lds_bytes(w.K, w.ir_max_edges, true);
 #define MGX_DO(KT)                                                                                                                 \
+    if (!resident_allow_lds<KT>(staged)) return hipErrorInvalidValue;                                                              \
     hipLaunchKernelGGL((k_robot_sweep<KT, IR_STAGED, true>), dim3(n_robots), dim3(SWEEP_BLOCK), staged, stream, w, 0, 0u, 0u, 0, -1, \
                        0u, plan)
     MGX_FOR_K(w.K, MGX_DO)

@@ -33,6 +33,7 @@ bool sweep_supports(int K);
 hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, uint32_t int_mask, int n_int,
                               int snap_out, uint32_t hints, hipStream_t stream);
 int sweep_resident_capacity(const DevWorld &w);
+size_t sweep_resident_lds_max();
 hipError_t launch_robot_schedule(const DevWorld &w, int n_robots, const SegPlan &plan, hipStream_t stream);
 hipError_t launch_change_prior(const DevWorld &w, int n, const int32_t *robots, const uint32_t *vars, const double *means,
                                hipStream_t stream);
@@ -1310,7 +1311,7 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
     const DevWorld &d = w->d;
     if (d.R_total != d.R_local || d.ir_max_edges == 0 || w->conns.empty() || !(w->p.enable_mask & 2u)) return 0;
     if (w->thaw_kinds || w->ir_thaw_active || w->n_keyless > 0 || w->direct.connected || w->rccl.connected) return 0;
-    if (sweep_lds_bytes(w->K, d.ir_max_edges, true) > 64 * 1024) return 0;
+    if (sweep_lds_bytes(w->K, d.ir_max_edges, true) > sweep_resident_lds_max()) return 0;
     for (const Launch &l : plan)
         if (l.n_int > 255) return 0;
     if (w->resident_cap < 0) w->resident_cap = sweep_resident_capacity(d);

@@ -149,3 +149,23 @@ def test_resident_launch_through_non_finite_beliefs(K, n):
         worst = max(worst, assert_identical_where_finite(eng, ref, what=f"{sc['name']} K={K} tick {t}", max_nan_only_mismatch=5e-3))
     if K == 16:
         assert worst > 0.0  # this one does leave the finite range: the fall-back was exercised
+
+
+@pytest.mark.parametrize("K,tracking", [(32, False), (32, True), (21, False)])
+def test_resident_launch_beyond_64_kb_of_lds_and_128_edges(K, tracking):
+    """Long horizons on the crowded grid: an interior robot has 8 x (K - 1) > 128 inter-robot edges (a second round of the
+    edge lanes, gathered by quads like the first) and, at K = 32, 75 KB of LDS per resident workgroup (the kernel is told to
+    accept more than 64 KB) — the whole schedule still runs as one launch and matches the oracle."""
+    sc = S.grid_scenario(144, K, interrobot=True, tracking=tracking)
+    assert max(np.bincount([b for _, b, _ in sc["ir"]])) * (K - 1) > 128
+    eng, ref = World(sc["params"]), oracle.OracleWorld(sc["params"], threads=ORACLE_THREADS)
+    assert S.populate(eng, sc) == S.populate(ref, sc)
+    tick = S.tick_inputs(sc)
+    for t in range(3):
+        for w in (eng, ref):
+            w.tick(steps=sc["steps"], **tick)
+        assert eng.last_launch_count() == 1
+        if tracking:
+            assert_identical_where_finite(eng, ref, what=f"{sc['name']} tick {t}", max_nan_only_mismatch=5e-3)
+        else:
+            assert_identical(eng, ref, what=f"{sc['name']} tick {t}")
