@@ -423,6 +423,23 @@ struct mgx_world {
     DevBuf<float> nb_pos;
     DevBuf<int32_t> nb_cnt, nb_bucket_cnt, nb_bucket_ptr, nb_cursor, nb_members, nb_special, nb_nspecial, nb_ptr, nb_idx;
     size_t nb_last_total = 0;  // rows of the last search: sizes the speculative second pass of the next one
+    // pinned host memory the search's positions go up from and its rows come back into: copies to and from pageable memory
+    // (std::vector) are staged by the runtime, tens of microseconds each
+    struct PinBuf {
+        void *p = nullptr;
+        size_t cap = 0;
+        ~PinBuf() { if (p) (void)hipHostFree(p); }
+        hipError_t reserve(size_t bytes) {
+            if (bytes <= cap) return hipSuccess;
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+            cap = 0;
+            const size_t want = bytes + bytes / 2 + 4096;
+            const hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+            if (e == hipSuccess) cap = want;
+            return e;
+        }
+    } nb_pin;
 };
 
 static size_t edge_index(const std::vector<int32_t> &in_ptr, int K, int r, int j, int slot);
@@ -1787,27 +1804,34 @@ static int neighbours(mgx_world *w, const float *pos, float radius, uint32_t met
             ms.alive_dirty = false;
         }
         HIP_TRY(launch_mission_positions(ms.d, n, ms.alive_d.p, w->nb_pos.p, s));
-    } else if (n) {
-        HIP_TRY(hipMemcpyAsync(w->nb_pos.p, pos, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    }
+    ptr.assign((size_t)n + 1, 0);
+    const size_t guess = std::min(w->nb_idx.cap, w->nb_last_total + w->nb_last_total / 4 + 64);
+    // pinned layout: [3 n floats: positions up] [n + 1 ints: row pointers down] [guess ints: rows down]
+    const size_t off_ptr = sizeof(float) * 3 * (size_t)std::max(n, 1), off_idx = off_ptr + sizeof(int32_t) * ((size_t)n + 1);
+    HIP_TRY(w->nb_pin.reserve(off_idx + sizeof(int32_t) * guess));
+    char *pin = static_cast<char *>(w->nb_pin.p);
+    if (!from_missions && n) {
+        memcpy(pin, pos, sizeof(float) * 3 * (size_t)n);
+        HIP_TRY(hipMemcpyAsync(w->nb_pos.p, pin, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
     }
     HIP_TRY(neighbours_count(w->nb_pos.p, n, radius, grid, M, w->nb_cnt.p, w->nb_bucket_cnt.p, w->nb_bucket_ptr.p, w->nb_cursor.p,
                              w->nb_members.p, w->nb_special.p, w->nb_nspecial.p, w->nb_ptr.p, s));
     // The second pass needs the total to size its output — one more host round trip.  Instead it runs right
     // away into the buffer left from the last search (the kernels leave it alone if the rows do not fit), and
     // rows and counts come back together; only a total beyond the guess costs the second trip.
-    ptr.assign((size_t)n + 1, 0);
-    const size_t guess = std::min(w->nb_idx.cap, w->nb_last_total + w->nb_last_total / 4 + 64);
     if (guess > 0 && w->nb_idx.p)
         HIP_TRY(neighbours_fill(w->nb_pos.p, n, radius, grid, M, w->nb_bucket_ptr.p, w->nb_members.p, w->nb_special.p,
                                 w->nb_nspecial.p, w->nb_ptr.p, w->nb_idx.p, (int32_t)guess, s));
-    HIP_TRY(hipMemcpyAsync(ptr.data(), w->nb_ptr.p, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, s));
-    idx.assign(guess, 0);
-    if (guess > 0 && w->nb_idx.p) HIP_TRY(hipMemcpyAsync(idx.data(), w->nb_idx.p, sizeof(int32_t) * guess, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(pin + off_ptr, w->nb_ptr.p, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, s));
+    if (guess > 0 && w->nb_idx.p) HIP_TRY(hipMemcpyAsync(pin + off_idx, w->nb_idx.p, sizeof(int32_t) * guess, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    memcpy(ptr.data(), pin + off_ptr, sizeof(int32_t) * ((size_t)n + 1));
     const size_t total = (size_t)ptr[(size_t)n];
     w->nb_last_total = total;
     if (total <= guess && (w->nb_idx.p || total == 0)) {
         idx.resize(total);
+        if (total) memcpy(idx.data(), pin + off_idx, sizeof(int32_t) * total);
     } else {
         idx.assign(total, 0);
         HIP_TRY(w->nb_idx.reserve(total));
