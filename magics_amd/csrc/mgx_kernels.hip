@@ -437,6 +437,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = src[t];
         }
         for (int t = tid; t < K; t += SWEEP_BLOCK) s_covset[t] = 0;
+        if (STAGE_IR && tid < IR_STRIDE) s_ir[ne * IR_STRIDE + tid] = 0.0;  // the all-zero message behind the last edge
         if (tid < K) {
             s_epoch[tid] = r_epoch;
             if (HAS_IR) {
@@ -714,6 +715,27 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             auto ir_rows = [&](int e_from, int e_to) {
                 // compact messages: rows 0, 1 add eta[rr], lam[rr][0], lam[rr][1]; rows 2, 3 only zeros
                 if (!HAS_IR || rr >= 2) return;
+                if (STAGE_IR) {
+                    // staged messages: a batch that runs past the end reads the all-zero slot behind the robot's last edge
+                    // (x + 0.0 == x, as for the absent own edges above) — no clamps, no conditional adds, 32-bit LDS offsets
+                    for (int e = e_from; e < e_to; e += 4) {  // four messages are fetched before the adds
+                        double m[4][3];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int b = ((e + u < e_to) ? e + u - ie0 : ne) * IR_STRIDE;
+                            m[u][0] = s_ir[b + rr];
+                            m[u][1] = s_ir[b + 2 + 2 * rr];
+                            m[u][2] = s_ir[b + 3 + 2 * rr];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            acc[0] += m[u][0];
+                            acc[1] += m[u][1];
+                            acc[2] += m[u][2];
+                        }
+                    }
+                    return;
+                }
                 for (int e = e_from; e < e_to; e += 4) {  // four messages are fetched before the adds
                     double m[4][3];
 #pragma unroll
@@ -2048,7 +2070,7 @@ __global__ void k_copy_bytes(uint8_t *__restrict__ dst, const uint8_t *__restric
 size_t sweep_lds_bytes(int K, int ir_edges, bool resident) {  // resident: + the shadow of the factor -> variable messages
     const BlobLayout L(K);
     const int io = L.inout_words() + (L.inout_words() & 1);
-    return sizeof(double) * (size_t)((SNAP_W + 20 + 20) * K + io + IR_STRIDE * ir_edges + (resident ? 20 * L.E1 : 0)) +
+    return sizeof(double) * (size_t)((SNAP_W + 20 + 20) * K + io + IR_STRIDE * (ir_edges + 1) + (resident ? 20 * L.E1 : 0)) +
            4 * (size_t)((resident ? 3 : 2) * ((K + 1) & ~1) + ((3 * (K + 1) + 1) & ~1));
 }
 size_t sweep_lds_bytes(int K, int ir_edges) { return sweep_lds_bytes(K, ir_edges, false); }
