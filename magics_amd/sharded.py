@@ -152,9 +152,10 @@ class ShardedWorld:
         self.direct = False
         self.replan()
 
-    def add_robot(self, mean0, prior_diag, dt, radius, path=None, owner=None):
+    def add_robot(self, mean0, prior_diag, dt, radius, path=None, owner=None, order_key=None):
         """A robot joins a world that follows its topology (a formation spawns): every rank calls this with the
-        same arguments; the robot is real on its owner's rank (default: round robin) and a ghost everywhere else."""
+        same arguments; the robot is real on its owner's rank (default: round robin) and a ghost everywhere else.
+        order_key: the graph's place in the Entity order (the same on every rank); default: behind every key so far."""
         assert self.dynamic
         plan = self.plan
         g = len(plan.owner)
@@ -162,7 +163,10 @@ class ShardedWorld:
         local = owner == plan.rank
         # order key: above every key the scenario handed out (they need not be 0 .. n-1), the same on every rank
         self._next_key = max(getattr(self, "_next_key", 0), max((rb["order_key"] for rb in self.sc["robots"]), default=-1) + 1, g)
-        key, self._next_key = self._next_key, self._next_key + 1
+        if order_key is None:
+            key, self._next_key = self._next_key, self._next_key + 1
+        else:
+            key, self._next_key = int(order_key), max(self._next_key, int(order_key) + 1)
         rid = self.world.add_robot(mean0, prior_diag, dt, radius, path=path if local else None, order_key=key, ghost=not local)
         assert rid == g
         plan.owner = np.append(plan.owner, owner)
@@ -573,8 +577,8 @@ class LocalCluster:
         for sw in self.ranks:
             sw.set_environment(env)
 
-    def add_robot(self, mean0, prior_diag, dt, radius, path=None, owner=None):
-        ids = [sw.add_robot(mean0, prior_diag, dt, radius, path=path, owner=owner) for sw in self.ranks]
+    def add_robot(self, mean0, prior_diag, dt, radius, path=None, owner=None, order_key=None):
+        ids = [sw.add_robot(mean0, prior_diag, dt, radius, path=path, owner=owner, order_key=order_key) for sw in self.ranks]
         assert all(i == ids[0] for i in ids)
         self.n_robots, self.K = ids[0] + 1, np.asarray(mean0).shape[0]
         return ids[0]

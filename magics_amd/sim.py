@@ -62,6 +62,7 @@ class Simulation:
         self.tick_no, self.next_number, self.K = 0, 1, None
         self.events = []           # (tick, connections created, pairs deleted)
         self.collisions = {}       # (robot a, robot b), a < b -> {"colliding": bool, "times": int, "aabbs": [...]}
+        self.entities = spawner.EntityAllocator()  # the robots' Entity bits = their graphs' order (id.rs:19-54)
 
     # -- spawn_formation (spawner.rs:415-649) + RobotBundle::new (robot.rs:1134-1356) -------------------
     def _add_robot(self, desc, formation_index):
@@ -73,7 +74,8 @@ class Simulation:
         if self.K is None:
             self.K = len(desc["timesteps"])
         path = np.array([s[:2] for s in states], dtype=np.float32)  # the route's positions (robot.rs:1310-1315)
-        rid = self.w.add_robot(mean0, prior, dt, float(desc["radius"]), path=path)
+        key = self.entities.alloc()
+        rid = self.w.add_robot(mean0, prior, dt, float(desc["radius"]), path=path, order_key=key)
         assert rid == len(self.robots)
         t0 = F(desc["radius"]) / F(2.0) / F(rb["target-speed"])
         self.robots.append({"id": rid, "formation": formation_index, "radius": F(desc["radius"]), "waypoints": [s.copy() for s in states],
@@ -81,7 +83,7 @@ class Simulation:
                             "time_scale": float(self.dt32 / t0), "colour": desc["colour"], "rng": desc["rng"],
                             "strategy": desc["planning-strategy"], "reach": desc["waypoint-reached-when-intersects"],
                             "finish": desc["finished-when-intersects"], "positions": [], "velocities": [], "travelled": 0.0,
-                            "trk_elapsed": 0, "trk_prev": None})
+                            "trk_elapsed": 0, "trk_prev": None, "entity": key})
         self._translation = np.vstack([self._translation, np.array([[states[0][0], -1.5, states[0][1]]], dtype=F)])  # spawner.rs:548
         if self.dev:
             me = self.robots[-1]
@@ -142,6 +144,7 @@ class Simulation:
                     r["completed"], r["finished_at"] = True, self.elapsed()
                     if self.despawn:
                         self.w.remove_robot(r["id"])
+                        self.entities.free(r["entity"])
                         r["alive"] = False
 
     # PositionTracker / VelocityTracker (planner/tracking.rs:104-122,189-218; 100 ms timers, spawner.rs:620-621):
@@ -215,6 +218,7 @@ class Simulation:
             r["completed"], r["finished_at"] = True, self.elapsed()
             if self.despawn:
                 r["alive"] = False
+                self.entities.free(r["entity"])
         live = [r for r in self.robots if r["alive"]]
         ant = None
         if live:

@@ -219,3 +219,31 @@ def spawn_formation(formation, config, world_dims, rng):
                        "waypoint-reached-when-intersects": formation["waypoint-reached-when-intersects"],
                        "finished-when-intersects": formation["finished-when-intersects"]})
     return robots
+
+
+class EntityAllocator:
+    """Bevy 0.13's `Entities` allocator restricted to the robots (bevy_ecs/src/entity/mod.rs: `alloc` pops the `pending` list
+    of freed indices last-freed-first and hands the index out with the generation `free` raised; a fresh index starts at
+    generation 1).  An Entity orders by `to_bits()` = generation << 32 | index — GENERATION first — and that order is the order
+    of the factor graphs (FactorGraphId = Entity, id.rs:19-54: inbox order, slot order of an inter-robot factor).  So a robot
+    spawned into a reused index sorts behind every first-generation robot, and two robots of the same later generation sort
+    by index, i.e. possibly against their spawn order.  The reference's other entities (meshes, waypoints, UI) take indices
+    from the same allocator and are not modelled: between robots of one generation the real application may order differently;
+    a host that has the real entities passes `Entity::to_bits()` as `order_key` (INTEGRATION.md)."""
+
+    def __init__(self):
+        self.generation, self.pending = [], []
+
+    def alloc(self):
+        if self.pending:
+            i = self.pending.pop()
+        else:
+            i = len(self.generation)
+            self.generation.append(1)
+        return (self.generation[i] << 32) | i
+
+    def free(self, bits):
+        i = int(bits) & 0xffffffff
+        assert self.generation[i] == int(bits) >> 32, "stale entity"
+        self.generation[i] += 1
+        self.pending.append(i)

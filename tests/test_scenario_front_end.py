@@ -282,3 +282,21 @@ def test_collision_state_machine_counts_contacts_once():
         assert s.collisions.get((0, 1), {"times": 0})["times"] == times, x
     h = s.collisions[(0, 1)]
     assert len(h["aabbs"]) == 2 and h["aabbs"][0] == {"mins": [1.0, -1.0], "maxs": [1.0, 1.0]}
+
+
+def test_entity_allocator_orders_like_bevy():
+    """Bevy 0.13 `Entities`: freed indices come back last-freed-first with the generation raised, and an Entity orders by
+    generation first (to_bits) — the order of the factor graphs (id.rs:19-54)."""
+    from magics_amd.spawner import EntityAllocator
+    a = EntityAllocator()
+    e = [a.alloc() for _ in range(4)]
+    assert e == [(1 << 32) | i for i in range(4)] and e == sorted(e)
+    a.free(e[1])
+    a.free(e[3])
+    x, y, z = a.alloc(), a.alloc(), a.alloc()          # index 3 (last freed) first, then 1, then a fresh one
+    assert (x & 0xffffffff, x >> 32) == (3, 2) and (y & 0xffffffff, y >> 32) == (1, 2) and (z & 0xffffffff, z >> 32) == (4, 1)
+    assert max(e) < y < x                              # reused indices sort behind every first-generation entity ...
+    assert z < y                                       # ... a fresh first-generation one before them, whenever it is spawned ...
+    assert y < x                                       # ... and within a generation the index decides, against the spawn order here
+    with pytest.raises(AssertionError):
+        a.free(e[1])                                   # stale handle
