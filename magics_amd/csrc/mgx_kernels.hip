@@ -1176,7 +1176,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     double *t_ = s_fv;
                     s_fv = s_sh;
                     s_sh = t_;
-                    variable_sums(s_snap, true, is_last);
+                    // (the robot's last sweep leaves its sums in the belief image as well — after the barrier: the other wave is
+                    // still reading that image as the prior)
+                    variable_sums(s_snap, true, false);
                     QSTAMP(4, qt);
                     if (lane < 4 * K) quad_core(s_snap, s_cov, ok_i, fin_i, mu_i);
                 } else {
@@ -1208,6 +1210,11 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     }
                     s_mu[q * K + i] = mu_fin;
                     s_snap[(20 + q) * K + i] = mu_fin;
+                    if (is_last) {  // row q of (eta, lam): what this lane summed
+                        s_prior[q * K + i] = s_snap[q * K + i];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) s_prior[(4 + q * 4 + c) * K + i] = s_snap[(4 + q * 4 + c) * K + i];
+                    }
                     if (q == 0) {
                         if (ok_i) {
                             s_valid[i] = fin_i ? 1 : 0;
@@ -1236,6 +1243,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                         for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = s_xmu[c * K + iv];
                     }
                 }
+                if (is_last) __syncthreads();  // the tail's write-back (other wave) reads the belief image
                 itf += 1;  // the factor sweep that was computed ahead
                 early = false;
             } else if ((ext_k & PH_EXT_VARIABLE) && radio) {
