@@ -381,10 +381,22 @@ struct mgx_world {
         long long tick_no = 0;
         bool in_tick = false;                // between mgx_mission_tick_begin and _end
         std::vector<int32_t> last_finished;  // robots whose mission completed in the last begin, ascending
+        float search_radius = 0.f;           // what the last tick's topology pass searched with: the coming tick's search is enqueued
+        uint32_t search_method = 0;          //   with the same (mgx_mission_tick_end), used if the next begin asks for the same
+        bool search_known = false;
         float *tr_host = nullptr;            // pinned: Transforms after the last tick's move (valid after the next synchronisation)
         size_t tr_cap = 0, tr_n = 0;
         DevMission d{};
     } mission;
+    // a neighbour search that has been enqueued and not collected yet (neighbours_enqueue / neighbours_collect)
+    struct PendingSearch {
+        bool valid = false, compact = false, grid = false;
+        int n = 0, n_all = 0;
+        std::vector<int> alive;
+        size_t guess = 0, off_ptr = 0, off_idx = 0;
+        float radius = 0.f;
+        uint32_t method = 0, M = 0;
+    } mission_search;  // the coming tick's search, enqueued by mgx_mission_tick_end
     uint32_t last_sweep_launches = 0;  // sweep-kernel launches of the last mgx_iterate / mgx_tick call (mgx_last_launch_count)
     // message counters are advanced lazily: launches and prior changes are only logged here
     struct CountEntry { uint8_t ext, in; int n_int, robot; uint64_t times; };
@@ -1758,12 +1770,18 @@ int mgx_ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
 
 // device neighbour search -> host CSR, rows ascending in order key
 // pos == nullptr: the positions come from the device-resident Transforms of the missions (mgx_mission_tick)
-static int neighbours(mgx_world *w, const float *pos, float radius, uint32_t method, std::vector<int32_t> &ptr,
-                      std::vector<int32_t> &idx) {
+// Two halves: everything that is enqueued (positions up, the counting and filling kernels, rows down into pinned memory) and,
+// behind a synchronisation of the stream, the host side (a second filling pass if the rows outgrew the guess, ids and order).
+// mgx_mission_tick enqueues the search of the NEXT tick in front of this tick's GBP schedule — the Transforms it looks at are
+// final once the prior updates have moved them — so its rows are on the host long before that tick's one synchronisation.
+static int neighbours_enqueue(mgx_world *w, const float *pos, float radius, uint32_t method, mgx_world::PendingSearch &ps) {
     if (!device_ok()) return fail(MGX_ERR_NO_DEVICE, "no HIP device");
+    w->mission_search.valid = false;  // the buffers below are shared: whatever was waiting in them is gone
+    ps.valid = false;
     const int n_all = (int)w->robots.size();
     const bool from_missions = pos == nullptr;
-    std::vector<int> alive;  // removed robots are in no query: search the others, map back
+    std::vector<int> &alive = ps.alive;  // removed robots are in no query: search the others, map back
+    alive.clear();
     std::vector<float> packed;
     for (int r = 0; r < n_all; r++) {
         // ghosts take part: a sharded world that follows a changing topology holds EVERY robot of the
@@ -1805,7 +1823,6 @@ static int neighbours(mgx_world *w, const float *pos, float radius, uint32_t met
         }
         HIP_TRY(launch_mission_positions(ms.d, n, ms.alive_d.p, w->nb_pos.p, s));
     }
-    ptr.assign((size_t)n + 1, 0);
     const size_t guess = std::min(w->nb_idx.cap, w->nb_last_total + w->nb_last_total / 4 + 64);
     // pinned layout: [3 n floats: positions up] [n + 1 ints: row pointers down] [guess ints: rows down]
     const size_t off_ptr = sizeof(float) * 3 * (size_t)std::max(n, 1), off_idx = off_ptr + sizeof(int32_t) * ((size_t)n + 1);
@@ -1825,22 +1842,35 @@ static int neighbours(mgx_world *w, const float *pos, float radius, uint32_t met
                                 w->nb_nspecial.p, w->nb_ptr.p, w->nb_idx.p, (int32_t)guess, s));
     HIP_TRY(hipMemcpyAsync(pin + off_ptr, w->nb_ptr.p, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, s));
     if (guess > 0 && w->nb_idx.p) HIP_TRY(hipMemcpyAsync(pin + off_idx, w->nb_idx.p, sizeof(int32_t) * guess, hipMemcpyDeviceToHost, s));
+    ps.n = n; ps.n_all = n_all; ps.compact = compact; ps.guess = guess; ps.off_ptr = off_ptr; ps.off_idx = off_idx;
+    ps.radius = radius; ps.method = method; ps.grid = grid; ps.M = M;
+    ps.valid = true;
+    return MGX_OK;
+}
+static int neighbours_collect(mgx_world *w, mgx_world::PendingSearch &ps, std::vector<int32_t> &ptr, std::vector<int32_t> &idx) {
+    hipStream_t s = w->stream;
+    const int n = ps.n, n_all = ps.n_all;
+    const std::vector<int> &alive = ps.alive;
+    const size_t guess = ps.guess;
+    char *pin = static_cast<char *>(w->nb_pin.p);
+    ps.valid = false;
     HIP_TRY(hipStreamSynchronize(s));
-    memcpy(ptr.data(), pin + off_ptr, sizeof(int32_t) * ((size_t)n + 1));
+    ptr.assign((size_t)n + 1, 0);
+    memcpy(ptr.data(), pin + ps.off_ptr, sizeof(int32_t) * ((size_t)n + 1));
     const size_t total = (size_t)ptr[(size_t)n];
     w->nb_last_total = total;
     if (total <= guess && (w->nb_idx.p || total == 0)) {
         idx.resize(total);
-        if (total) memcpy(idx.data(), pin + off_idx, sizeof(int32_t) * total);
+        if (total) memcpy(idx.data(), pin + ps.off_idx, sizeof(int32_t) * total);
     } else {
         idx.assign(total, 0);
         HIP_TRY(w->nb_idx.reserve(total));
-        HIP_TRY(neighbours_fill(w->nb_pos.p, n, radius, grid, M, w->nb_bucket_ptr.p, w->nb_members.p, w->nb_special.p,
+        HIP_TRY(neighbours_fill(w->nb_pos.p, n, ps.radius, ps.grid, ps.M, w->nb_bucket_ptr.p, w->nb_members.p, w->nb_special.p,
                                 w->nb_nspecial.p, w->nb_ptr.p, w->nb_idx.p, (int32_t)total, s));
         HIP_TRY(hipMemcpyAsync(idx.data(), w->nb_idx.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
-    if (compact) {  // back to world robot ids, empty rows for the removed ones
+    if (ps.compact) {  // back to world robot ids, empty rows for the removed ones
         for (int32_t &j : idx) j = alive[(size_t)j];
         std::vector<int32_t> full((size_t)n_all + 1, 0);
         for (int a = 0; a < n; a++) full[(size_t)alive[(size_t)a] + 1] = ptr[(size_t)a + 1] - ptr[(size_t)a];
@@ -1854,6 +1884,12 @@ static int neighbours(mgx_world *w, const float *pos, float radius, uint32_t met
             std::sort(idx.begin() + ptr[(size_t)r], idx.begin() + ptr[(size_t)r + 1],
                       [&](int a, int b) { return w->robots[(size_t)a].order_key < w->robots[(size_t)b].order_key; });
     return MGX_OK;
+}
+static int neighbours(mgx_world *w, const float *pos, float radius, uint32_t method, std::vector<int32_t> &ptr,
+                      std::vector<int32_t> &idx) {
+    mgx_world::PendingSearch ps;
+    const int rc = neighbours_enqueue(w, pos, radius, method, ps);
+    return rc != MGX_OK ? rc : neighbours_collect(w, ps, ptr, idx);
 }
 
 int mgx_neighbours(mgx_world *w, const float *positions_xyz, float radius, uint32_t method, int32_t *row_ptr, int32_t *neighbours_out,
@@ -2068,6 +2104,7 @@ int mgx_mission_tick_begin(mgx_world *w, float comms_radius, uint32_t method, ui
     if (ms.dirty || ms.has.size() != w->robots.size()) {
         if (ms.uploaded && !ms.dirty && (rc = mission_download(w)) != MGX_OK) return rc;
         if ((rc = mission_upload(w)) != MGX_OK) return rc;
+        w->mission_search.valid = false;  // the host has touched the missions: Transforms may have moved
     }
     const int R = (int)w->robots.size();
     hipStream_t s = w->stream;
@@ -2079,9 +2116,25 @@ int mgx_mission_tick_begin(mgx_world *w, float comms_radius, uint32_t method, ui
     HIP_TRY(hipHostGetDevicePointer(&evd, ms.ev_host, 0));
     HIP_TRY(launch_mission_reached(w->d, ms.d, R, ms.tick_no, (unsigned int *)evd, s));
     std::vector<int32_t> ptr, idx;
-    rc = neighbours(w, nullptr, comms_radius, method, ptr, idx);
+    // the search itself was enqueued by the last tick's end, in front of its GBP schedule, if nothing has changed since: the same
+    // radius and method, the same robots alive (this tick's despawns are taken out of the rows below either way)
+    mgx_world::PendingSearch &pf = w->mission_search;
+    bool prefetched = pf.valid && pf.radius == comms_radius && pf.method == method && pf.n_all == R;
+    if (prefetched) {
+        size_t a = 0;
+        for (int r = 0; r < R && prefetched; r++)
+            if (!w->robots[(size_t)r].removed) {
+                if (a >= pf.alive.size() || pf.alive[a] != r) prefetched = false;
+                a++;
+            }
+        if (a != pf.alive.size()) prefetched = false;
+    }
+    rc = prefetched ? neighbours_collect(w, pf, ptr, idx) : neighbours(w, nullptr, comms_radius, method, ptr, idx);
     if (rc != MGX_OK) return rc;
-    tm.lap("reached + search");
+    ms.search_radius = comms_radius;
+    ms.search_method = method;
+    ms.search_known = true;
+    tm.lap(prefetched ? "reached + rows of the search enqueued last tick" : "reached + search");
     // robots that reached their last waypoint this tick: despawned before the topology systems see them (robot.rs:2172) —
     // the search still looked at them, so they are taken out of its rows here
     const unsigned n_fin = ms.ev_host[0];
@@ -2166,6 +2219,9 @@ int mgx_mission_tick_end(mgx_world *w, const uint8_t *antennas, double max_speed
     }
     HIP_TRY(hipMemcpyAsync(ms.tr_host, ms.translation_d.p, sizeof(float) * 3 * (size_t)R, hipMemcpyDeviceToHost, s));
     ms.tr_n = (size_t)R;
+    // update_robot_neighbours of the COMING tick (robot.rs:1362-1384): the Transforms it looks at are final now, so the search goes
+    // in front of this tick's GBP schedule and its rows reach the host while that runs
+    if (ms.search_known && (rc = neighbours_enqueue(w, nullptr, ms.search_radius, ms.search_method, w->mission_search)) != MGX_OK) return rc;
     for (int r = 0; r < R; r++) {  // message counters: the prior changes of the robots that move (what the device decides too)
         const Robot &rb = w->robots[(size_t)r];
         if (rb.removed || rb.ghost || !ms.has[(size_t)r] || ms.finished_tick[(size_t)r] >= 0) continue;
