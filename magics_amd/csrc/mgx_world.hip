@@ -2197,6 +2197,7 @@ int mgx_mission_tick_end(mgx_world *w, const uint8_t *antennas, double max_speed
         if (changed) w->flags_dirty = true;
     }
     if ((rc = commit(w)) != MGX_OK) return rc;  // edge tables / flags of what the pass changed
+    tm.lap("antennas + commit");
     // the two prior updates + the Transform increment, from the device's own mission state; then iterate_gbp_v2
     {
         void *hp = nullptr, *dp = nullptr;
@@ -2221,7 +2222,9 @@ int mgx_mission_tick_end(mgx_world *w, const uint8_t *antennas, double max_speed
     ms.tr_n = (size_t)R;
     // update_robot_neighbours of the COMING tick (robot.rs:1362-1384): the Transforms it looks at are final now, so the search goes
     // in front of this tick's GBP schedule and its rows reach the host while that runs
+    tm.lap("prepare");
     if (ms.search_known && (rc = neighbours_enqueue(w, nullptr, ms.search_radius, ms.search_method, w->mission_search)) != MGX_OK) return rc;
+    tm.lap("search of the coming tick enqueued");
     for (int r = 0; r < R; r++) {  // message counters: the prior changes of the robots that move (what the device decides too)
         const Robot &rb = w->robots[(size_t)r];
         if (rb.removed || rb.ghost || !ms.has[(size_t)r] || ms.finished_tick[(size_t)r] >= 0) continue;
@@ -2229,6 +2232,7 @@ int mgx_mission_tick_end(mgx_world *w, const uint8_t *antennas, double max_speed
         log_change_prior(w, r, 0);
     }
     w->stale_kinds |= ~w->p.enable_mask & 15u;
+    tm.lap("counter log");
     const std::vector<Launch> plan = plan_launches(steps, n_steps);
     w->last_sweep_launches = 0;
     const bool fuse = !plan.empty() && plan[0].ext == 0 && plan[0].n_int > 0 && w->thaw_kinds == 0;
