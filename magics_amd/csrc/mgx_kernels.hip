@@ -849,7 +849,8 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             fin_own = fin_own && std::isfinite(col[j]);
         }
         unsigned long long bad = __ballot(!fin_own);
-        bad |= (bad >> K) | (bad >> (2 * K)) | (bad >> (3 * K));
+        constexpr int KS = QUADFIN ? KT : 1;  // (instantiated, never run, for longer horizons: keep the shift counts in range)
+        bad |= (bad >> KS) | (bad >> (2 * KS)) | (bad >> (3 * KS));
         fin = ((bad >> i) & 1ull) == 0ull;
         if (ok) {
 #pragma unroll
