@@ -169,3 +169,19 @@ def test_resident_launch_beyond_64_kb_of_lds_and_128_edges(K, tracking):
             assert_identical_where_finite(eng, ref, what=f"{sc['name']} tick {t}", max_nan_only_mismatch=5e-3)
         else:
             assert_identical(eng, ref, what=f"{sc['name']} tick {t}")
+
+
+def test_resident_launch_with_one_directional_connections():
+    """Connections that exist in one direction only (the reference's bookkeeping can leave them so): the robot whose records are
+    read has no edge of its own towards the reader, which it must still wait for before it overwrites the buffer the reader
+    uses (the peer table is the symmetric closure) — whole schedules as one launch, bit-identical."""
+    sc = S.grid_scenario(400, 16, interrobot=True)
+    sc = dict(sc, ir=[(a, b, n0) for a, b, n0 in sc["ir"] if (a < b) == ((a + b) % 3 != 0)])
+    eng, ref = World(sc["params"]), oracle.OracleWorld(sc["params"], threads=ORACLE_THREADS)
+    assert S.populate(eng, sc) == S.populate(ref, sc)
+    tick = S.tick_inputs(sc)
+    for t in range(5):
+        for w in (eng, ref):
+            w.tick(steps=sc["steps"], **tick)
+        assert eng.last_launch_count() == 1
+        assert_identical(eng, ref, what=f"one-directional connections, tick {t}")
