@@ -2108,10 +2108,12 @@ static void launch_k(const DevWorld &w, int robot0, int n_robots, uint32_t ext_m
 #define MGX_FOR_K(K_, DO)                                                     \
     switch (K_) {                                                             \
     case 10: DO(10); break;                                                   \
+    case 11: DO(11); break; /* Tracking Factor Showcase */                    \
     case 12: DO(12); break; /* Junction Twoway */                             \
     case 13: DO(13); break; /* Junction Experiment */                         \
     case 16: DO(16); break;                                                   \
     case 17: DO(17); break; /* Merge, Iteration Amount */                     \
+    case 20: DO(20); break; /* Schedules Experiment */                        \
     case 21: DO(21); break; /* Circle Experiment */                           \
     case 32: DO(32); break;                                                   \
     case 35: DO(35); break; /* Communications Failure */                      \
