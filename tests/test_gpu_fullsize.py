@@ -15,12 +15,16 @@ reference's arithmetic itself leaves the finite range on this combination of fac
 oracle holds a number, and the same workload WITHOUT inter-robot factors — which stays finite — must
 be bit-identical outright.
 """
+import os
+
 import numpy as np
 import pytest
 
 import oracle
 from magics_amd import World, scenarios as S, sharded
 from parity import assert_identical, assert_identical_where_finite
+
+RESIDENT = os.environ.get("MGX_PERSISTENT", "1") != "0"  # MGX_PERSISTENT=0 runs the same tests on the launch-per-segment path
 
 pytestmark = pytest.mark.gpu
 
@@ -145,7 +149,7 @@ def test_resident_launch_through_non_finite_beliefs(K, n):
     for t in range(6):
         for w in (eng, ref):
             w.tick(steps=sc["steps"], **tick)
-        assert eng.last_launch_count() == 1  # the resident path
+        assert eng.last_launch_count() == 1 or not RESIDENT  # the resident path
         worst = max(worst, assert_identical_where_finite(eng, ref, what=f"{sc['name']} K={K} tick {t}", max_nan_only_mismatch=5e-3))
     if K == 16:
         assert worst > 0.0  # this one does leave the finite range: the fall-back was exercised
@@ -164,7 +168,7 @@ def test_resident_launch_beyond_64_kb_of_lds_and_128_edges(K, tracking):
     for t in range(3):
         for w in (eng, ref):
             w.tick(steps=sc["steps"], **tick)
-        assert eng.last_launch_count() == 1
+        assert eng.last_launch_count() == 1 or not RESIDENT
         if tracking:
             assert_identical_where_finite(eng, ref, what=f"{sc['name']} tick {t}", max_nan_only_mismatch=5e-3)
         else:
@@ -183,5 +187,5 @@ def test_resident_launch_with_one_directional_connections():
     for t in range(5):
         for w in (eng, ref):
             w.tick(steps=sc["steps"], **tick)
-        assert eng.last_launch_count() == 1
+        assert eng.last_launch_count() == 1 or not RESIDENT
         assert_identical(eng, ref, what=f"one-directional connections, tick {t}")
