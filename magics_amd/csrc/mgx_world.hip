@@ -1574,7 +1574,9 @@ static int ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
 // same effect as ir_disconnect(a, b) for each pair in order.
 static void ir_disconnect_batch(mgx_world *w, const std::vector<std::pair<int, int>> &pairs) {
     if (pairs.empty()) return;
+    StageTimer tm("ir_disconnect_batch");
     flush_counts(w);
+    tm.lap("flush_counts");
     const size_t n = w->robots.size();
     std::vector<int32_t> out_ptr(n + 1, 0);  // connections by owner
     for (const IrConn &c : w->conns) out_ptr[(size_t)c.owner + 1]++;
@@ -1604,6 +1606,7 @@ static void ir_disconnect_batch(mgx_world *w, const std::vector<std::pair<int, i
             k++;
         }
     w->conns.resize(k);
+    tm.lap("connection list");
     if (w->n_keyless > 0) {  // some of them may just have gone
         w->n_keyless = 0;
         for (const IrConn &c : w->conns) w->n_keyless += c.keys.empty() ? 0 : 1;
