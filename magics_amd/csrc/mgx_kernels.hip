@@ -1352,6 +1352,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         if (PERSIST && early) prefired = true;
         early = false;
         for (int it = 0; it < n_int_k && !idle && !par_done; it++) {
+            asm volatile("" : "+v"(tid), "+v"(lane));  // as at the top of a segment: nothing per-thread hoisted out of this loop either
             STAMP(t0);
             if ((int_k & PH_INT_FACTOR) && it == 0 && prefired) {
                 itf += 1;  // this sweep ran next to the external variable sweep, in front of that block's last barrier
