@@ -214,11 +214,12 @@ int mgx_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, const uin
  * variable.rs:350-360; FactorNode::empty_inbox, factor/mod.rs:480-483) for one robot's graph: every variable's belief mean
  * becomes means[i] and its belief precision diag(sigma) — first_last_sigma for variables 0 and K-1, inbetween_sigma for the
  * others, used as the reference uses them (AS the diagonal, +inf allowed) — and every message in the variables' inboxes and
- * in the inboxes of the graph's own factors becomes empty.  means: [K][4].  mgx_reset_tracking_factors:
+ * in the inboxes of the graph's own factors becomes empty.  means: [n_means][4]; n_means must equal the graph's number of
+ * variables K (the reference asserts it, factorgraph.rs:1548: MGX_ERR_INVALID otherwise, nothing read).  mgx_reset_tracking_factors:
  * FactorGraph::reset_tracking_factors (factorgraph.rs:1566-1590) — the graph's tracking factors skip their next ten
  * updates (tracking.rs:153-155,362-371).  The reference calls the pair (means, 1e30, +inf) when a global path arrives
  * (robot.rs:766-769); rare, so the engine re-lays the device state out on the next launch. */
-int mgx_reset_variables(mgx_world *w, int32_t robot, const double *means, double first_last_sigma,
+int mgx_reset_variables(mgx_world *w, int32_t robot, const double *means, uint32_t n_means, double first_last_sigma,
                         double inbetween_sigma);
 int mgx_reset_tracking_factors(mgx_world *w, int32_t robot);
 
@@ -410,6 +411,36 @@ int mgx_halo_direct_connect(mgx_world *w, uint32_t n_peers, const uint32_t *send
 int mgx_halo_direct_exchange(mgx_world *w, uint32_t what);
 int mgx_halo_direct_status(mgx_world *w, uint64_t *exchanges, uint64_t *failed_exchange);
 int mgx_halo_direct_disconnect(mgx_world *w);
+
+/* ---- resident schedule launches on sharded worlds ----------------------------------------------------------------------
+ * (replaces, like the exchanges above, the serial external phase and routing of robot.rs:1803-1859 and
+ * factorgraph.rs:719-760 — here without ANY launch boundary or exchange kernel between the iterations of a schedule.)
+ * A world whose robots all fit the device at once runs a whole mgx_iterate / mgx_tick schedule as ONE launch (one workgroup per
+ * robot, resident for the schedule; neighbouring workgroups hand their snapshot records over inside the launch).  With the
+ * calls below the same holds for a SHARDED world: every rank owns a GHOST AREA — fine-grained device memory holding, for each
+ * ghost robot, its snapshot records and delivery counts for the two buffer parities and one progress word — which the ghosts'
+ * owner ranks map (mgx_ipc_export / mgx_ipc_open across processes, raw pointers inside one process) and store into from
+ * inside their own resident launch: a boundary robot's workgroup writes its records at the end of every segment into its own
+ * rank's buffers AND (system-scope, over xGMI) into the ghost area of every rank that holds it as a ghost, then that ghost's
+ * progress word; the workgroups there poll it like the word of a local neighbour.  One exchange per external iteration as
+ * before (robot.rs:1803-1859), with no host work and no kernel boundary.  A schedule that OPENS with an external iteration
+ * takes the direct exchange (above) in front of the launch, so mgx_halo_direct_* has to be connected too.
+ *   1. mgx_halo_resident_setup (after mgx_halo_plan and mgx_halo_direct_setup / _connect): allocates the ghost area; returns its
+ *      address, the number of ghost slots, this rank's buffer parity and segment count (both advance in lockstep on all ranks:
+ *      every rank issues the same schedules), the slot of every entry of the receive list (recv_slots[n_recv]) and whether
+ *      this rank CAN run resident launches (eligible: inter-robot factors staged in LDS, every local robot's workgroup resident
+ *      at once).  The ranks agree on that — all or none.
+ *   2. mgx_halo_resident_connect with one entry per (local robot of the send list, rank that receives it): that rank's area,
+ *      number of ghost slots, the robot's slot there, that rank's parity and segment count as returned by ITS setup.
+ * From then on mgx_iterate / mgx_tick run eligible schedules as one launch per rank (mgx_last_launch_count == 1); all ranks
+ * must have connected (a rank that waits for a peer which never publishes gives up after MGX_RESIDENT_TIMEOUT_MS, default
+ * 2000, and reports MGX_ERR_STATE — never a hung GPU).  A change of the world's layout (robots added / removed) disconnects. */
+int mgx_halo_resident_setup(mgx_world *w, void **area_base, uint32_t *n_ghost_slots, uint32_t *parity, uint64_t *segment_count,
+                            int32_t *recv_slots, int32_t *eligible);
+int mgx_halo_resident_connect(mgx_world *w, uint32_t n_targets, const int32_t *robots, void *const *peer_area_base,
+                              const uint32_t *peer_ghost_slots, const uint32_t *peer_slot, const uint32_t *peer_parity,
+                              const uint64_t *peer_segment_count);
+int mgx_halo_resident_disconnect(mgx_world *w);
 /* hipIpcGetMemHandle / hipIpcOpenMemHandle / hipIpcCloseMemHandle on the addresses above
  * (64-byte handles), so the host side needs no HIP binding of its own. */
 int mgx_ipc_export(const void *dev_ptr, uint8_t handle[64]);

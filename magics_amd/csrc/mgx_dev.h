@@ -59,6 +59,17 @@ struct IrSlotRec {
     uint64_t first_number;  // robot_number of the factor on variable 1 (robot.rs:1527)
 };
 
+// Resident schedule launches of a SHARDED world: where the snapshot records of a local robot that another rank holds as a ghost
+// go at the end of a segment — addresses inside that rank's ghost area (peer-mapped, fine-grained), indexed by THIS rank's
+// buffer parity; the consumer's progress word for the ghost, and what has to be added to this rank's segment count to speak
+// the consumer's (each rank counts the segments of its own resident launches).
+struct XPushRec {
+    unsigned long long snap[2];   // [K][24] f64
+    unsigned long long epoch[2];  // [K] u32
+    unsigned long long flag;      // one u64
+    unsigned long long flag_delta;
+};
+
 struct DevWorld {
     int R_local, R_total, K, E;
     int V, EI, ND, NT, NI;
@@ -139,6 +150,15 @@ struct DevWorld {
     const int32_t *peer_idx;          // device robot indices
     unsigned long long *sweep_abort;  // device memory
     unsigned long long *sweep_err;    // host-mapped
+    // Resident schedule launches of a sharded world (k_robot_sweep<.., PERSIST, SHARD>).  This rank's GHOST AREA is fine-grained
+    // device memory that the ghosts' owner ranks store into from inside their launches (peer-mapped: hipIpc across processes):
+    // the ghosts' snapshot records and delivery counts for the two buffer parities and one progress word per ghost (ghost g =
+    // device robot R_local + g), all read here with system-scope loads.  xp_*: the local robots other ranks hold as ghosts.
+    const double *gsnap[2];           // [NG * K][24]
+    const uint32_t *gepoch[2];        // [NG * K]
+    const unsigned long long *gflag;  // [NG]
+    const int32_t *xp_ptr;            // [R_local + 1] push targets of each local robot (most have none)
+    const XPushRec *xp_rec;
     // diagnostic builds only (-DMGX_STAMPS, tools/stamps.py): per-workgroup phase cycle sums
     unsigned long long *dbg;
 };

@@ -1,0 +1,1566 @@
+// mgx_sweep.h — the sweep kernel of the GBP engine (k_robot_sweep) and the device helpers every kernel file shares.
+// Included by mgx_kernels.hip (the small kernels) and by mgx_sweep_inst.hip (the instantiations, several translation units).
+//
+// k_robot_sweep: ONE 128-THREAD WORKGROUP PER ROBOT, TWO ROLE-SPECIALISED WAVES.
+// The robot's whole factor graph (its private state blob: priors, beliefs, factor->variable
+// messages; its snapshot records; the inter-robot messages attached to its variables) is staged in
+// LDS once per launch by straight 16-byte copies and stays there for every phase the launch runs: an optional external phase
+// (external_factor_iteration + routing + external_variable_iteration,
+// factorgraph.rs:719-760,794-826, robot.rs:1803-1859) followed by `n_int` internal iterations
+// (internal_factor_iteration + internal_variable_iteration, factorgraph.rs:688-714,762-790).
+//
+//   wave 0 (DYN)  factor phase: one lane per dynamic-factor MESSAGE (2(K-1) lanes), one 4x4 Schur
+//                 complement each
+//   wave 1 (UV)   factor phase: mean / covariance of the previous sweep (one lane per variable: 4x4
+//                 inverse), then one lane per obstacle / tracking factor
+//   both waves    variable phase: inbox sums, one lane per (variable, row);
+//                 external factor sweep: one lane per incoming inter-robot edge ("pull" form: every
+//                 factor F_AB is evaluated by the workgroup of its only consumer B)
+//
+// A dynamic factor never reads a mean, so the expensive half of a variable update (inverse, mean) of
+// sweep t runs in the UV wave NEXT TO the dynamic messages of sweep t+1 in the DYN wave.  One wave
+// alone issues an f64 VALU instruction only every ~8 cycles, so what bounds an iteration is the
+// longest dependent instruction stream per robot, not lane count: the design shortens that stream.
+// All per-variable state lives in LDS, not registers, so each wave stays within 256 VGPRs.  Each
+// phase is a Jacobi sweep separated by workgroup barriers only.  Robots couple only through the
+// inter-robot edges, which gather the OTHER robot's 192-byte snapshot records from buffer `cur` in
+// HBM while this launch writes buffer `1 - cur`: no inter-workgroup synchronisation inside a launch.
+//
+// Arithmetic: gbp_math.h, compiled with -ffp-contract=off so that results are bit-identical to
+// the scalar f64 reference semantics.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gbp_math.h"
+#include "mgx_dev.h"
+
+namespace mgx {
+
+constexpr int SWEEP_BLOCK = 128;
+enum { ROLE_DYN = 0, ROLE_UV = 1 };
+
+__device__ __forceinline__ void ld_soa4(const double *base, int stride, int item, double (&o)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) o[c] = base[(size_t)c * stride + item];
+}
+__device__ __forceinline__ void ld_soa16(const double *base, int stride, int item, double (&o)[16]) {
+#pragma unroll
+    for (int c = 0; c < 16; c++) o[c] = base[(size_t)c * stride + item];
+}
+__device__ __forceinline__ void st_soa4(double *base, int stride, int item, const double (&o)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) base[(size_t)c * stride + item] = o[c];
+}
+__device__ __forceinline__ void st_soa16(double *base, int stride, int item, const double (&o)[16]) {
+#pragma unroll
+    for (int c = 0; c < 16; c++) base[(size_t)c * stride + item] = o[c];
+}
+
+extern __shared__ double lds[];
+
+// In-kernel cycle stamps exist only in the diagnostic build (never in libmgx.so): they go to a
+// buffer of their own and no output value depends on them.
+#ifdef MGX_STAMPS
+#define STAMP(var) unsigned long long var = __builtin_readcyclecounter()
+#define STAMP_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(acc, a, b)
+#endif
+
+// STAGE_IR: the robot's incoming inter-robot messages are kept in LDS ([20][n_edges]); otherwise
+// (a robot with too many edges for LDS) they are read from HBM / L2 in every variable sweep.
+// KT: horizon length K as a compile-time constant (0 = read it from the world): with K fixed every
+// LDS access is base + immediate offset, which keeps the address arithmetic out of the VGPR budget.
+// Compact inter-robot messages.  The factor's Jacobian touches the two positions only
+// (interrobot.rs:149-159), so J^T L J and J^T L (..) vanish outside the position rows / columns,
+// and so does the Schur complement towards either variable: Lab has two non-zero rows and columns,
+// hence Lab W Lba and Lab W eb live in the top-left 2x2 block / first two entries — as exact zeros
+// as long as the arithmetic stays finite (0 * x is 0; tests/test_oracle_known_answers.py checks it
+// on the oracle's full 20-entry messages).  Such a message is six numbers: eta0, eta1, lam00,
+// lam01, lam10, lam11; only those are computed, stored and summed (x + 0 == x).  With NaN / inf in
+// play the reference would smear NaNs over the other entries (0 * NaN); that is one of the places
+// where a non-finite world is not reproduced (known deviations).
+constexpr int IR_STRIDE = 7;  // one staged inter-robot message: 6 f64 + 1 pad (bank spread)
+// IRM, how a launch treats inter-robot messages: the world has no inter-robot edges at all (every
+// trace of them is compiled out: configs[1] runs this), they are read from HBM / L2 in every
+// variable sweep (a robot with too many edges for LDS), or they are staged in LDS.
+enum { IR_NONE = 0, IR_GLOBAL = 1, IR_STAGED = 2 };
+
+// Workgroups are handed to the eight XCDs round-robin by workgroup id, and each XCD has its own L2.
+// Robots are numbered along the grid, so inter-robot neighbours have nearby ids: giving XCD k the
+// k-th CONTIGUOUS eighth of the robots (instead of every eighth robot) lets the snapshot records that
+// several neighbours gather be fetched into that XCD's L2 once.  Bijection of [0, n) for any n.
+constexpr int N_XCD = 8;
+__device__ __forceinline__ int xcd_local_index(int block, int n) {
+    const int xcd = block % N_XCD, idx = block / N_XCD;
+    // workgroups with id = k (mod 8): ceil((n - k) / 8) of them; robots of XCD k start after those of 0..k-1
+    int start = 0;
+    for (int k = 0; k < xcd; k++) start += (n - k + N_XCD - 1) / N_XCD;
+    return start + idx;
+}
+
+// straight copies between a robot's blob in HBM and its LDS image, 16 bytes per lane
+__device__ __forceinline__ void copy_words(double *dst, const double *src, int n, int tid) {
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    double2 *d2 = reinterpret_cast<double2 *>(dst);
+    for (int t = tid; t < (n >> 1); t += SWEEP_BLOCK) d2[t] = s2[t];
+    if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
+}
+
+// HBM -> LDS with every load of the thread in flight before its first LDS store: a copy loop that
+// waits for each 16 bytes before asking for the next costs one memory round trip per iteration, and
+// staging is a handful of such loops.  N (f64 words) is a compile-time constant: the loops unroll into
+// independent loads held in registers.
+template <int N>
+struct StageRegs {
+    static constexpr int N2 = N / 2, ITERS = (N2 + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+    double2 v[ITERS];
+    double last;
+    __device__ __forceinline__ void load(const double *src, int tid) {
+        const double2 *s2 = reinterpret_cast<const double2 *>(src);
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const int t = tid + it * SWEEP_BLOCK;
+            v[it] = (t < N2) ? s2[t] : make_double2(0.0, 0.0);
+        }
+        last = ((N & 1) && tid == 0) ? src[N - 1] : 0.0;
+    }
+    __device__ __forceinline__ void store(double *dst, int tid) const {
+        double2 *d2 = reinterpret_cast<double2 *>(dst);
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const int t = tid + it * SWEEP_BLOCK;
+            if (t < N2) d2[t] = v[it];
+        }
+        if ((N & 1) && tid == 0) dst[N - 1] = last;
+    }
+};
+
+// the same, issued by one wave (64 lanes)
+__device__ __forceinline__ void copy_words_wave(double *dst, const double *src, int n, int lane) {
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    double2 *d2 = reinterpret_cast<double2 *>(dst);
+    for (int t = lane; t < (n >> 1); t += 64) d2[t] = s2[t];
+    if ((n & 1) && lane == 0) dst[n - 1] = src[n - 1];
+}
+
+// Accesses to what ANOTHER workgroup of the same launch writes or reads (resident schedule launches): relaxed
+// agent-scope atomics = global_load / global_store ... sc1 — they bypass this CU's L1 and write through the XCD's L2,
+// which is what makes a record published by one workgroup readable by another without cache maintenance
+// (MI355X_MICROARCH.md, inter-workgroup visibility: all-sc1 stores and loads, every storing wave drains vmcnt,
+// one lane signals behind a workgroup barrier, the consumer polls that word and loads behind a barrier).
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The same for 16 bytes: raw buffer accesses with aux = 16 (sc1); the descriptor is built from wave-uniform values.
+typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sc1_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void ld16_agent(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, double &a, double &b) {
+    const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16);
+    a = __hiloint2double((int)v.y, (int)v.x);
+    b = __hiloint2double((int)v.w, (int)v.z);
+}
+__device__ __forceinline__ v4u32 ld16_agent_raw(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16);
+}
+__device__ __forceinline__ void st16_agent(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, double a, double b) {
+    v4u32 v;
+    v.x = (unsigned)__double2loint(a); v.y = (unsigned)__double2hiint(a);
+    v.z = (unsigned)__double2loint(b); v.w = (unsigned)__double2hiint(b);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, 16);
+}
+
+// The same at SYSTEM scope (aux = sc0 | sc1): fine-grained memory that another GPU stores into or reads from over xGMI (the
+// ghost areas of sharded resident launches).
+__device__ __forceinline__ v4u32 ld16_system_raw(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 17);
+}
+__device__ __forceinline__ void st16_system(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, double a, double b) {
+    v4u32 v;
+    v.x = (unsigned)__double2loint(a); v.y = (unsigned)__double2hiint(a);
+    v.z = (unsigned)__double2loint(b); v.w = (unsigned)__double2hiint(b);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, 17);
+}
+// a buffer descriptor over [base, base + bytes) from a pointer every lane of the wave holds (made scalar here)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(unsigned long long base, unsigned bytes) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base & 0xffffffffull));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+}
+
+// 4 x 4 transposition inside every quad of lanes: on entry lane v holds x[s] = item (s, v), on exit lane s holds x[v] = item (s, v)
+// — two butterfly stages of DPP quad permutes, no LDS.
+__device__ __forceinline__ void quad_transpose4(unsigned (&x)[4], int lane) {
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+#pragma unroll
+    for (int p = 0; p < 4; p += 2) {  // lanes v, v ^ 1 exchange x[p + 1] of the even lane with x[p] of the odd one
+        const unsigned send = b0 ? x[p] : x[p + 1];
+        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xf, 0xf, true);  // quad_perm [1, 0, 3, 2]
+        x[p] = b0 ? recv : x[p];
+        x[p + 1] = b0 ? x[p + 1] : recv;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++) {  // lanes v, v ^ 2 exchange x[p + 2] of the lower lane with x[p] of the upper one
+        const unsigned send = b1 ? x[p] : x[p + 2];
+        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);  // quad_perm [2, 3, 0, 1]
+        x[p] = b1 ? recv : x[p];
+        x[p + 2] = b1 ? x[p + 2] : recv;
+    }
+}
+
+// PERSIST: the launch runs a whole schedule (SegPlan, mgx_dev.h) instead of one segment.
+// SHARD (resident launches of a sharded world): the snapshot records of ghost robots arrive INSIDE the launch — their owners'
+// ranks store them into this rank's peer-mapped ghost area and this rank's boundary robots store theirs into the peers'.
+template <int KT, int IRM, bool PERSIST, bool SHARD = false>
+__global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int robot0, uint32_t ext_mask, uint32_t int_mask,
+                                                             int n_int, int snap_out, uint32_t hints, const SegPlan plan) {
+    constexpr bool HAS_IR = IRM != IR_NONE, STAGE_IR = IRM == IR_STAGED;
+    static_assert(!PERSIST || IRM == IR_STAGED, "resident schedule launches exist for worlds with staged inter-robot messages");
+    static_assert(!SHARD || PERSIST, "ghost records arrive in-launch only in resident schedule launches");
+    const int nseg = PERSIST ? plan.n : 1;
+    // KT > 0: horizon length fixed at compile time; 0: read from the world (K <= 33); -1: read from the world, any K.
+    // BIG: more than 64 dynamic-factor messages / tracking factors per robot (K > 33): some lanes carry two.
+    constexpr bool BIG = KT < 0 || KT > 33;
+    STAMP(t_k0);
+    const int r = robot0 + xcd_local_index(blockIdx.x, gridDim.x);
+    int tid = threadIdx.x;  // not const: resident launches make them opaque once per segment, see the segment loop
+    const int role = tid >> 6;
+    int lane = tid & 63;
+    const int K = KT > 0 ? KT : w.K, E = 4 * K - 6, E1 = E + 1;
+    const BlobLayout L(K);
+    const int ZCOL = E;  // all-zero message column (absent edges)
+    double *s_snap = lds;                                 // [24][K] variable -> own-factor snapshots
+    double *s_prior = s_snap + SNAP_W * K;                // [20][K] prior eta, lam (belief after the last sweep)
+    double *s_tmp = s_prior + 20 * K;                     // [20][K] scratch sums (external sweep)
+    double *s_io = s_tmp + 20 * K;                        // image of the blob's in/out region:
+    double *s_cov = s_io;                                 //   [16][K] belief covariance
+    double *s_mu = s_io + 16 * K;                         //   [4][K]  belief mean
+    double *s_fv = s_io + 20 * K;                         //   [20][E1] factor -> variable messages
+    int32_t *s_valid = (int32_t *)(s_io + 20 * K + 20 * E1);  // [K]
+    uint32_t *s_epoch = (uint32_t *)(s_io + L.inout_words() + (L.inout_words() & 1));  // [K] deliveries
+    int32_t *s_irp = (int32_t *)(s_epoch + ((K + 1) & ~1));  // [3][K+1] inbox ranges of foreign factors
+    int32_t *s_covset = s_irp + ((3 * (K + 1) + 1) & ~1);     // [K] this launch recomputed the variable's covariance
+    // resident launches: shadow of s_fv that takes the factor sweep computed AHEAD of the external iteration it follows
+    int32_t *s_xok = s_covset + ((K + 1) & ~1);               // [K] (PERSIST only) outcome of a concurrent external belief update
+    double *s_sh = (double *)(s_xok + (PERSIST ? ((K + 1) & ~1) : 0));  // [20][E1] (PERSIST only)
+    double *s_ir = s_sh + (PERSIST ? 20 * E1 : 0);            // [ne][IR_STRIDE] inter-robot messages (STAGE_IR)
+
+    double *blob = w.blob + (size_t)r * w.BS;
+    const int v0 = r * K;
+    const int ie0 = HAS_IR ? w.ir_var_ptr[v0] : 0, ne = HAS_IR ? w.ir_var_ptr[v0 + K] - ie0 : 0;
+    const bool ir_on = HAS_IR && (w.enable & 2u) != 0;
+    const int n_dyn = 2 * (K - 1);
+    // kinds whose first internal factor sweep of this launch has already been computed from the inbox they
+    // froze with (k_thaw, mgx_set_enabled); the pointer is null unless some robot is thawing
+    const uint32_t skip0 = w.skip0 ? (uint32_t)w.skip0[r] : 0u;
+    const bool idle = w.idle[r] != 0;
+    const bool radio = (w.antenna[r] != 0) && !idle;
+
+    int itf = w.iter_factor[r];  // iteration_count.factor (every lane applies the same increments)
+
+    // ---- roles ------------------------------------------------------------------------------------
+    const bool is_dyn = role == ROLE_DYN && lane < n_dyn;
+    const bool is_obs = role == ROLE_UV && lane < K - 2;
+    const bool is_trk = role == ROLE_UV && lane >= K - 2 && lane < 2 * (K - 2);
+    const bool is_var = role == ROLE_UV && lane < K;
+    // Horizons of at most 16 variables: the belief finish runs on FOUR lanes per variable (lane (q, i) computes cofactor row q of
+    // variable i, variable_finish_quad), and in resident launches the whole variable sweep — inbox sums and finish — stays on the
+    // UV wave with no workgroup barrier in between (FUSED).
+    constexpr bool QUADFIN = KT > 0 && 4 * KT <= 64;
+    constexpr bool FUSED = PERSIST && QUADFIN;
+    const int sum_t = FUSED ? (role == ROLE_UV ? lane : 4 * K) : tid;        // (variable, row) this thread sums: t = rr * K + i
+    const int sum_step = FUSED ? 4 * K : SWEEP_BLOCK;
+    // which variable sweep of this launch is the robot's last one (its belief goes out)
+    bool plan_int = false, plan_ext = false;  // PERSIST: some segment has internal iterations / an external iteration
+    if (PERSIST)
+        for (int k = 0; k < nseg; k++) { plan_int = plan_int || plan.n_int[k] > 0; plan_ext = plan_ext || plan.ext[k] != 0; }
+    const bool has_int_var = PERSIST ? (plan_int && !idle) : ((int_mask & PH_INT_VARIABLE) && n_int > 0 && !idle);
+    const bool any_sweep = has_int_var || ((PERSIST ? plan_ext : (ext_mask & PH_EXT_VARIABLE) != 0) && radio);
+    // a later launch of the same call rewrites this robot's belief image: this one's copy is never read
+    const bool bel_dead = ((hints & HINT_LATER_EXT_VARIABLE) && radio) || ((hints & HINT_LATER_INT_VARIABLE) && !idle);
+
+    // DYN wave: constant potential blocks of this lane's message
+    // (resident launches fetch them from L2 in every sweep instead: the DYN wave has the time — it computes its messages ahead,
+    // under the hand-off — and the 32 registers are what the segment loop would otherwise spill)
+    double maa[4], mab[4], mba[4], mbb[4];
+    int dyn_other_var = 0, dyn_other_edge = 0;
+    auto load_dyn_potential = [&](double (&paa)[4], double (&pab)[4], double (&pba)[4], double (&pbb)[4]) __attribute__((always_inline)) {
+        const int f = lane % (K - 1), slot = lane / (K - 1);
+        const int a2 = 2 * slot, b2 = 2 * (1 - slot);
+        const int it = r * (K - 1) + f;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                paa[i * 2 + j] = w.dyn_m[(size_t)((a2 + i) * 4 + (a2 + j)) * w.ND + it];
+                pab[i * 2 + j] = w.dyn_m[(size_t)((a2 + i) * 4 + (b2 + j)) * w.ND + it];
+                pba[i * 2 + j] = w.dyn_m[(size_t)((b2 + i) * 4 + (a2 + j)) * w.ND + it];
+                pbb[i * 2 + j] = w.dyn_m[(size_t)((b2 + i) * 4 + (b2 + j)) * w.ND + it];
+            }
+    };
+    if (is_dyn) {
+        const int f = lane % (K - 1), slot = lane / (K - 1);
+        if (!PERSIST) load_dyn_potential(maa, mab, mba, mbb);
+        dyn_other_var = f + 1 - slot;
+        dyn_other_edge = (1 - slot) * (K - 1) + f;
+    }
+    // obstacle factors: four lanes per factor when they fit one wave and no tracking lanes are needed
+    const bool obs_rows = (4 * (K - 2) <= 64) && !(w.enable & 8u);
+    // UV wave, factor phase (otherwise): obstacle lanes [0, K-2), tracking lanes [K-2, 2(K-2))
+    const int uvar = (is_trk ? lane - (K - 2) : lane) + 1;  // variable of the unary factor
+    const int uedge = n_dyn + lane;                         // its internal-edge column
+    int trk_rec = 0;
+    float trk_lp[2] = {0.f, 0.f};
+    double trk_lv = 0.0;
+    const int trk_item = r * (K - 2) + (uvar - 1);
+    if (is_trk) {
+        trk_rec = w.trk_record[trk_item];
+        trk_lp[0] = w.trk_last_pos[trk_item];
+        trk_lp[1] = w.trk_last_pos[(size_t)w.NT + trk_item];
+        trk_lv = w.trk_last_val[trk_item];
+    }
+
+    // ---- operands of the external factor sweep, requested AROUND the staging copies ------------------
+    // An edge lane needs a chain of dependent loads (gate / constants -> the owner's delivery count and
+    // snapshot record); started here they travel while the blob is staged, instead of after the barrier.
+    // Each thread prefetches its first edge (robots have at most a few more edges than threads).
+    const bool do_extf = !PERSIST && HAS_IR && (ext_mask & PH_EXT_FACTOR) && radio && ir_on;
+    bool pf_on = false, pf_present = false;
+    IrEdgeRec pf_er{};
+    double pf_bmu[4] = {0.0, 0.0, 0.0, 0.0}, pf_rec[SNAP_W];
+#pragma unroll
+    for (int c = 0; c < SNAP_W; c++) pf_rec[c] = 0.0;
+    uint8_t pf_gate = 0;
+    int pf_dst = 0;
+    if (HAS_IR && tid < ne) pf_gate = w.ir_gate[ie0 + tid];
+    if (do_extf && tid < ne) {
+        pf_er = w.ir_rec[ie0 + tid];
+        pf_dst = pf_er.dst;
+        ld_soa4(w.ir_bmu, w.NI, ie0 + tid, pf_bmu);
+    }
+    if (PERSIST && tid < ne) {  // resident launches: the edge's constants stay in registers for every external iteration
+        pf_er = w.ir_rec[ie0 + tid];
+        pf_dst = pf_er.dst;
+    }
+    // The owners' records of the threads' edges are fetched by QUADS of lanes: for each of its four lanes' records in turn, lane v
+    // of a quad asks for bytes [64 t + 16 v, + 16), t = 0..2 — the four requests of a quad are one contiguous 64 bytes — and a
+    // 4 x 4 transposition inside the quad hands every lane its own record.  One lane fetching its own 192 bytes makes sixty-four
+    // scattered 16-byte requests per load instruction, and the gather was bound by their number: 0.45 us per 16 bytes per lane
+    // at 1000 robots, 5 us of an iteration (experiments/README.md); the same bytes by quads take a quarter of that.  Every lane of
+    // the wave takes part (a lane without an edge passes offset 0: record 0 is fetched and dropped).
+    auto quad_gather = [&](auto fetch, unsigned ro_mine, double (&out)[SNAP_W]) __attribute__((always_inline)) {
+        v4u32 R[4][3];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            unsigned rb;  // the record of lane s4 of the quad
+            if (s4 == 0) rb = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0x00, 0xf, 0xf, true);
+            else if (s4 == 1) rb = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0x55, 0xf, 0xf, true);
+            else if (s4 == 2) rb = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0xAA, 0xf, 0xf, true);
+            else rb = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0xFF, 0xf, 0xf, true);
+#pragma unroll
+            for (int t3 = 0; t3 < 3; t3++) R[s4][t3] = fetch(rb + 64u * t3 + 16u * (unsigned)(lane & 3));
+        }
+#pragma unroll
+        for (int t3 = 0; t3 < 3; t3++) {
+            unsigned dw[4][4];  // [dword of the 16 bytes][piece v of the lane's own record]
+#pragma unroll
+            for (int wd = 0; wd < 4; wd++) {
+                unsigned x[4] = {R[0][t3][wd], R[1][t3][wd], R[2][t3][wd], R[3][t3][wd]};
+                quad_transpose4(x, lane);
+#pragma unroll
+                for (int v = 0; v < 4; v++) dw[wd][v] = x[v];
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                out[2 * (4 * t3 + v)] = __hiloint2double((int)dw[1][v], (int)dw[0][v]);
+                out[2 * (4 * t3 + v) + 1] = __hiloint2double((int)dw[3][v], (int)dw[2][v]);
+            }
+        }
+    };
+    auto fetch_plain = [&](unsigned off) __attribute__((always_inline)) {  // records written by an earlier launch
+        return *reinterpret_cast<const v4u32 *>(reinterpret_cast<const char *>(w.snap[w.cur]) + off);
+    };
+    // per-variable words (K <= 64 < threads: one pass)
+    uint32_t r_epoch = 0;
+    int r_irp[3] = {0, 0, 0};
+    if (tid < K) {
+        r_epoch = w.snap_epoch[w.cur][v0 + tid];
+        if (HAS_IR) {
+            r_irp[0] = w.ir_var_ptr[v0 + tid];
+            r_irp[1] = w.ir_var_mid[v0 + tid];
+            r_irp[2] = w.ir_var_ptr[v0 + tid + 1];
+        }
+    }
+    // mgx_tick: this robot's prior updates (waypoint, time scale, what) and, lane c < 20 of each wave, entry c of
+    // the belief (eta, lam) the variable it updates holds in HBM — wave 0: the horizon variable, wave 1: variable 0
+    double u_rec[4] = {0.0, 0.0, 0.0, 0.0}, u_bel = 0.0;
+    if (w.upd) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) u_rec[c] = w.upd[(size_t)r * 4 + c];
+        if (lane < 20) u_bel = blob[L.bel() + lane * K + (role == 0 ? K - 1 : 0)];
+    }
+    // messages that this launch's external factor sweep recomputes before anyone reads them are not fetched
+    const bool recompute = (PERSIST ? plan.ext[0] != 0 : (ext_mask & PH_EXT_FACTOR) != 0) && radio && ir_on;
+    double r_ir[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    bool r_ir_on = false;
+
+    // ---- stage the robot in LDS (all 128 threads) -----------------------------------------------
+    // Constant-K instantiations: TWO memory round trips for the whole stage.  First every load that
+    // needs no other load's result (prior, mean | messages | valid, own snapshot records, and above the
+    // first link of the edge chain), then the chain's second link, then the LDS stores.  The covariance
+    // is output only (a variable whose covariance this launch does not recompute keeps the HBM copy).
+    auto chain_second_link = [&]() {
+        if (STAGE_IR && tid < ne && !(recompute && pf_gate == 1)) {  // the thread's first staged inter-robot message
+            const size_t e = (size_t)(ie0 + tid);
+            r_ir_on = true;
+            r_ir[0] = w.ir_fv_eta[0 * (size_t)w.NI + e];
+            r_ir[1] = w.ir_fv_eta[1 * (size_t)w.NI + e];
+            r_ir[2] = w.ir_fv_lam[0 * (size_t)w.NI + e];
+            r_ir[3] = w.ir_fv_lam[1 * (size_t)w.NI + e];
+            r_ir[4] = w.ir_fv_lam[4 * (size_t)w.NI + e];
+            r_ir[5] = w.ir_fv_lam[5 * (size_t)w.NI + e];
+        }
+        if (do_extf) {  // the owners' records (other robots, HBM / L2); absent (not yet delivered) ones are zeroed when used
+            pf_on = tid < ne && pf_gate == 1;
+            if (pf_on) pf_present = w.snap_epoch[w.cur][pf_er.src_var] > pf_er.created;
+            quad_gather(fetch_plain, pf_on ? (unsigned)pf_er.src_var * (unsigned)(SNAP_W * sizeof(double)) : 0u, pf_rec);
+        }
+    };
+    {
+        const double *src = w.snap[w.cur] + (size_t)v0 * SNAP_W;
+        if constexpr (KT > 0) {
+            StageRegs<20 * KT> r_prior;
+            StageRegs<BlobLayout(KT).inout_words() - 16 * KT> r_io;
+            constexpr int IT = (SNAP_W * KT + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+            double r_snap[IT];
+            r_prior.load(blob + L.prior(), tid);
+            r_io.load(blob + L.mu(), tid);
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int t = tid + it * SWEEP_BLOCK;
+                r_snap[it] = (t < SNAP_W * K) ? src[t] : 0.0;
+            }
+            chain_second_link();
+            r_prior.store(s_prior, tid);
+            r_io.store(s_mu, tid);
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int t = tid + it * SWEEP_BLOCK;
+                if (t < SNAP_W * K) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = r_snap[it];
+            }
+        } else {
+            copy_words(s_prior, blob + L.prior(), 20 * K, tid);
+            chain_second_link();
+            copy_words(s_mu, blob + L.mu(), L.inout_words() - 16 * K, tid);
+            for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = src[t];
+        }
+        for (int t = tid; t < K; t += SWEEP_BLOCK) s_covset[t] = 0;
+        if (STAGE_IR && tid < IR_STRIDE) s_ir[ne * IR_STRIDE + tid] = 0.0;  // the all-zero message behind the last edge
+        if (tid < K) {
+            s_epoch[tid] = r_epoch;
+            if (HAS_IR) {
+                s_irp[tid] = r_irp[0];
+                s_irp[(K + 1) + tid] = r_irp[1];
+                s_irp[2 * (K + 1) + tid] = r_irp[2];
+            }
+        }
+        if (STAGE_IR) {
+            if (r_ir_on) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) s_ir[tid * IR_STRIDE + c] = r_ir[c];
+            }
+            for (int j = tid + SWEEP_BLOCK; j < ne; j += SWEEP_BLOCK) {  // robots with more edges than threads
+                if (recompute && w.ir_gate[ie0 + j] == 1) continue;
+                const size_t e = (size_t)(ie0 + j);
+                double m[6];
+                m[0] = w.ir_fv_eta[0 * (size_t)w.NI + e];
+                m[1] = w.ir_fv_eta[1 * (size_t)w.NI + e];
+                m[2] = w.ir_fv_lam[0 * (size_t)w.NI + e];
+                m[3] = w.ir_fv_lam[1 * (size_t)w.NI + e];
+                m[4] = w.ir_fv_lam[4 * (size_t)w.NI + e];
+                m[5] = w.ir_fv_lam[5 * (size_t)w.NI + e];
+#pragma unroll
+                for (int c = 0; c < 6; c++) s_ir[j * IR_STRIDE + c] = m[c];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- mgx_tick: update_prior_of_horizon_state (wave 0, variable K-1) and update_prior_of_current_state_v3
+    // (wave 1, variable 0) on the staged image, each ending in change_prior of that variable
+    // (robot.rs:2182-2338, variable.rs:203-230; same arithmetic as k_update_priors / apply_change_prior).  For
+    // K >= 3 the two touch disjoint state, and nobody else reads this robot's snapshot in a launch without an
+    // external factor sweep, so the change needs no other synchronisation than the barrier below.
+    if (w.upd) {
+        const uint32_t what = (uint32_t)u_rec[3];
+        const int i = role == 0 ? K - 1 : 0;
+        if (role == 0 ? (what & 1u) : (what & 2u)) {
+            double m[4];
+            if (role == 0) {
+                const double ex = s_mu[0 * K + i], ey = s_mu[1 * K + i];         // estimated position (:2242)
+                double hx = u_rec[0] - ex, hy = u_rec[1] - ey;                    // horizon2waypoint
+                const double dist = std::sqrt(hx * hx + hy * hy);                 // euclidean_norm
+                double nx = hx, ny = hy;                                           // .normalized(): unchanged if |.| is 0 / inf
+                if (!(dist == 0.0 || std::isinf(dist))) { nx = hx / dist; ny = hy / dist; }
+                const double sp = (w.upd_max_speed < dist || dist != dist) ? w.upd_max_speed : dist;  // Float::min(max_speed, dist)
+                const double vx = sp * nx, vy = sp * ny;                           // new_velocity
+                m[0] = ex + vx * w.upd_delta_t; m[1] = ey + vy * w.upd_delta_t; m[2] = vx; m[3] = vy;  // (:2253-2256)
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const double m0 = s_mu[c * K + 0], m1 = s_mu[c * K + 1];
+                    m[c] = m0 + u_rec[2] * (m1 - m0);                              // (:2309-2316)
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // every lane has read the means before lanes 4..7 overwrite them
+            if (lane < 4) {  // prior eta = prior lam . mean (:204), in LDS and in the blob (the sweep never writes priors back)
+                double pl[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) pl[c] = s_prior[(4 + lane * 4 + c) * K + i];
+                const double pe = ((pl[0] * m[0] + pl[1] * m[1]) + pl[2] * m[2]) + pl[3] * m[3];
+                s_prior[lane * K + i] = pe;
+                blob[L.prior() + lane * K + i] = pe;
+            } else if (lane < 8) {  // belief mean (:206) and the mean of the message the variable sends (:210-221)
+                const double mc = lane == 4 ? m[0] : (lane == 5 ? m[1] : (lane == 6 ? m[2] : m[3]));
+                s_mu[(lane - 4) * K + i] = mc;
+                s_snap[(20 + lane - 4) * K + i] = mc;
+            } else if (lane == 8) {
+                s_epoch[i] += 1;
+            }
+            if (lane < 20) s_snap[lane * K + i] = u_bel;  // (stale eta, stale lam) of that message
+            // every inbox message of the variable becomes empty (:224-227)
+            const int es[4] = {(i >= 1) ? (K - 1) + (i - 1) : -1, (i <= K - 2) ? i : -1,
+                               (i >= 1 && i <= K - 2) ? n_dyn + (i - 1) : -1, (i >= 1 && i <= K - 2) ? n_dyn + (K - 2) + (i - 1) : -1};
+            for (int t = lane; t < 80; t += 64) {
+                const int col = es[t & 3];
+                if (col >= 0) s_fv[(t >> 2) * E1 + col] = 0.0;
+            }
+            if (HAS_IR) {  // foreign inter-robot factors attached to the variable: their message goes, they get the new mean
+                const int x0 = w.ir_var_ptr[v0 + i], x1 = w.ir_var_ptr[v0 + i + 1];
+                for (int e = x0 + lane; e < x1; e += 64) {
+                    if (w.enable & 2u) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = m[c];
+                    }
+                    w.ir_fv_eta[0 * (size_t)w.NI + e] = 0.0;
+                    w.ir_fv_eta[1 * (size_t)w.NI + e] = 0.0;
+                    w.ir_fv_lam[0 * (size_t)w.NI + e] = 0.0;
+                    w.ir_fv_lam[1 * (size_t)w.NI + e] = 0.0;
+                    w.ir_fv_lam[4 * (size_t)w.NI + e] = 0.0;
+                    w.ir_fv_lam[5 * (size_t)w.NI + e] = 0.0;
+                    if (STAGE_IR) {
+#pragma unroll
+                        for (int c = 0; c < 6; c++) s_ir[(e - ie0) * IR_STRIDE + c] = 0.0;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (PERSIST) {  // columns no sweep recomputes (disabled kinds, tracking in front of its gate) must be equal in both
+        for (int t = tid; t < 20 * E1; t += SWEEP_BLOCK) s_sh[t] = s_fv[t];
+        __syncthreads();
+    }
+    uint32_t my_epoch = (sum_t < 4 * K) ? s_epoch[sum_t % K] : 0u;  // deliveries of the variable this thread sums
+    STAMP(t_staged);
+
+    // ======================= external factor sweep (pull form) ================================
+    // factorgraph.rs:745-754 keeps only the message to the other graph's variable, so F_AB is
+    // evaluated here, at B, from A's snapshot record and B's last response mean.
+    // k: segment of a resident schedule launch (0 otherwise); store_fv: the HBM copy of the messages is needed
+    // descriptors of the two snapshot buffers for the 16-byte agent-scope accesses of resident launches
+    const unsigned snap_bytes = (unsigned)w.V * (unsigned)(SNAP_W * sizeof(double));
+    const __amdgpu_buffer_rsrc_t rs_snap[2] = {sc1_rsrc(w.snap[0], PERSIST ? snap_bytes : 0u), sc1_rsrc(w.snap[1], PERSIST ? snap_bytes : 0u)};
+    // sharded worlds: the ghosts' records of segments k > 0 come from this rank's ghost area (their owners' ranks store them there
+    // from inside their own launches), marked by the top bit of the byte offset a lane asks for
+    constexpr unsigned GHOST_BIT = 0x80000000u;
+    const int VL = w.R_local * K;  // first ghost variable
+    const unsigned gsnap_bytes = SHARD ? (unsigned)(w.V - VL) * (unsigned)(SNAP_W * sizeof(double)) : 0u;
+    const __amdgpu_buffer_rsrc_t rs_gsnap[2] = {sc1_rsrc(SHARD ? w.gsnap[0] : nullptr, gsnap_bytes), sc1_rsrc(SHARD ? w.gsnap[1] : nullptr, gsnap_bytes)};
+    // resident launches: the response means (ir_bmu) of every edge of variable i that is on air are the variable's mean after the
+    // external variable sweep — kept in LDS (the scratch sums' block, idle between that sweep's finish and the next one's sums)
+    // from one segment to the next; HBM gets them once, after the launch's last external iteration
+    double *s_xmu = s_tmp;
+    bool have_xmu = false;
+#ifdef MGX_STAMPS
+    unsigned long long q_arrive = 0ull, t_edges0 = 0ull;  // cycles from the start of the factor sweep until the thread's record is there
+#endif
+    auto external_factor_sweep = [&](int k, bool store_fv) __attribute__((always_inline)) {
+        const int buf = PERSIST ? ((w.cur + k) & 1) : w.cur;  // snapshot buffer the owners' records are read from
+#ifdef MGX_STAMPS
+        t_edges0 = __builtin_readcyclecounter();
+#endif
+        if (radio && ir_on) {
+            auto fetch_sc1 = [&](unsigned off) __attribute__((always_inline)) {
+                if constexpr (SHARD) {
+                    if (off & GHOST_BIT) return ld16_system_raw(rs_gsnap[buf], off & ~GHOST_BIT);
+                }
+                return ld16_agent_raw(rs_snap[buf], off);
+            };
+            for (int j0 = 0; j0 < ne; j0 += SWEEP_BLOCK) {  // rounds of the whole workgroup: every lane takes part in the gather
+                const int j = j0 + tid;
+                const int e = ie0 + j;
+                IrEdgeRec er{};
+                double ao_eta[4], ao_lam[16], a_mu[4], b_mu[4];
+                bool a_present;
+                // the round's record, unless it was prefetched while staging (launch-per-segment path, first round)
+                double grec[SNAP_W];
+                bool mine = false;
+                if (PERSIST || j0 > 0) {
+                    if (j0 == 0) {
+                        mine = tid < ne && pf_gate == 1;
+                        if (mine) er = pf_er;
+                    } else if (j < ne && w.ir_gate[e] == 1) {  // robots with more edges than threads
+                        mine = true;
+                        er = w.ir_rec[e];
+                    }
+                    // (segment 0 of a sharded launch reads the ghosts' plain copies, filled by the exchange in front of the launch)
+                    const bool ghost_src = SHARD && k > 0 && mine && er.src_var >= VL;
+                    const unsigned ro_mine = !mine ? 0u : ghost_src ? ((unsigned)(er.src_var - VL) * (unsigned)(SNAP_W * sizeof(double))) | GHOST_BIT
+                                                                   : (unsigned)er.src_var * (unsigned)(SNAP_W * sizeof(double));
+                    if (PERSIST) quad_gather(fetch_sc1, ro_mine, grec);  // published by other workgroups of THIS launch: agent scope
+                    else quad_gather(fetch_plain, ro_mine, grec);
+                    if (!mine) continue;
+                }
+
+                if (PERSIST) {
+                    if (have_xmu) {  // the means this robot's external variable sweep of the previous segment answered with
+                        const int i = er.dst & 0xffff;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) b_mu[c] = s_xmu[c * K + i];
+                    } else {
+                        ld_soa4(w.ir_bmu, w.NI, e, b_mu);  // written by an earlier launch
+                    }
+                    // has the owner's variable answered this factor yet?  Once it has it stays so: the thread's first edge
+                    // remembers (one scattered 4-byte request per lane and iteration less)
+                    if (j0 == 0 && pf_present) {
+                        a_present = true;
+                    } else {
+                        if (SHARD && k > 0 && er.src_var >= VL)
+                            a_present = __hip_atomic_load(&w.gepoch[buf][er.src_var - VL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) > er.created;
+                        else
+                            a_present = ld_agent(&w.snap_epoch[buf][er.src_var]) > er.created;
+                        if (j0 == 0) pf_present = a_present;
+                    }
+#ifdef MGX_STAMPS
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (j0 == 0) { const unsigned long long _n = __builtin_readcyclecounter(); q_arrive += _n - t_edges0; }
+#endif
+#pragma unroll
+                    for (int c = 0; c < 4; c++) ao_eta[c] = grec[c];
+#pragma unroll
+                    for (int c = 0; c < 16; c++) ao_lam[c] = grec[4 + c];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) a_mu[c] = grec[20 + c];
+                } else if (j0 == 0) {  // operands prefetched during staging
+                    if (j >= ne) continue;
+                    if (!pf_on) continue;  // the owner did not run its external factor sweep
+                    er = pf_er;
+                    a_present = pf_present;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) b_mu[c] = pf_bmu[c];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) ao_eta[c] = pf_rec[c];
+#pragma unroll
+                    for (int c = 0; c < 16; c++) ao_lam[c] = pf_rec[4 + c];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) a_mu[c] = pf_rec[20 + c];
+                } else {
+                    ld_soa4(w.ir_bmu, w.NI, e, b_mu);
+                    a_present = w.snap_epoch[w.cur][er.src_var] > er.created;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) ao_eta[c] = grec[c];
+#pragma unroll
+                    for (int c = 0; c < 16; c++) ao_lam[c] = grec[4 + c];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) a_mu[c] = grec[20 + c];
+                }
+                if (!a_present) {  // the owner's variable has not answered this factor yet: empty inbox entry
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { ao_eta[c] = 0.0; a_mu[c] = 0.0; }
+#pragma unroll
+                    for (int c = 0; c < 16; c++) ao_lam[c] = 0.0;
+                }
+                // ONE evaluation for both slot orders (selects on the linearisation point): the lanes of a wave hold edges of
+                // both orders, and a branch around two inlined copies would run both for every wave
+                const int dslot = er.dst >> 16;
+                double x_lo[4], x_hi[4], o6[6];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    x_lo[c] = dslot ? a_mu[c] : b_mu[c];
+                    x_hi[c] = dslot ? b_mu[c] : a_mu[c];
+                }
+                if (!interrobot_message_compact(x_lo, x_hi, er.d_safe, er.offset, w.inv_s2_ir, dslot, ao_eta, ao_lam, o6)) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) o6[c] = 0.0;
+                }
+                // HINT_IR_DEAD: the caller's next sweep recomputes these messages before reading them (it
+                // starts with an external factor sweep under the same flags), and this launch reads
+                // them from LDS — then the HBM copy is dead and not stored; likewise every external
+                // iteration of a resident schedule launch but its last one
+                if (store_fv && !(STAGE_IR && (hints & HINT_IR_DEAD))) {
+                    w.ir_fv_eta[0 * (size_t)w.NI + e] = o6[0];
+                    w.ir_fv_eta[1 * (size_t)w.NI + e] = o6[1];
+                    w.ir_fv_lam[0 * (size_t)w.NI + e] = o6[2];
+                    w.ir_fv_lam[1 * (size_t)w.NI + e] = o6[3];
+                    w.ir_fv_lam[4 * (size_t)w.NI + e] = o6[4];
+                    w.ir_fv_lam[5 * (size_t)w.NI + e] = o6[5];
+                }
+                if (STAGE_IR) {
+                    double *p = s_ir + j * IR_STRIDE;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) p[c] = o6[c];
+                }
+            }
+        }
+        if (radio) itf += 1;  // iteration_count.factor of the robot's own external sweep (factorgraph.rs:757)
+    };
+
+    // Inbox sums of a variable sweep, one lane per (variable, row): lane (i, rr) accumulates eta[rr] and
+    // lam[rr][0..3] in the reference's inbox order (BTreeMap<FactorId, _>, id.rs:19-54): factors of
+    // graphs with a lower key, own factors by node index (dynamic i-1, dynamic i, obstacle, tracking;
+    // own inter-robot factors are forever empty), then factors of graphs with a higher key — each
+    // element sees exactly the additions of VariableNode::update_belief... (variable.rs:254-271).
+    // Absent edges read the all-zero column: x + 0.0 == x exactly and a running sum that starts from
+    // the prior is never -0.0, so this equals skipping the entry.  For an internal sweep the sums are
+    // also the (eta, lam) of the responses to own-graph factors (:301-330, factorgraph.rs:771-786).
+    // s_out receives the sums ([20][K] image: the snapshot for internal sweeps).
+    auto variable_sums_from = [&](int t_first, int t_step, double *s_out, bool internal, bool last) __attribute__((always_inline)) {
+        for (int t = t_first; t < 4 * K; t += t_step) {
+            const int rr = t / K, i = t - rr * K;  // consecutive lanes -> consecutive variables: conflict-free LDS rows
+            uint32_t epoch_reg = (4 * K <= SWEEP_BLOCK) ? my_epoch : s_epoch[i];
+            const int es[4] = {(i >= 1) ? (K - 1) + (i - 1) : ZCOL, (i <= K - 2) ? i : ZCOL,
+                               (i >= 1 && i <= K - 2) ? n_dyn + (i - 1) : ZCOL,
+                               (i >= 1 && i <= K - 2) ? n_dyn + (K - 2) + (i - 1) : ZCOL};
+            // all 25 LDS operands of the own-graph part are fetched before the first add: one LDS
+            // round trip instead of one per message
+            double pr[5], ms[4][5];
+            pr[0] = s_prior[rr * K + i];
+#pragma unroll
+            for (int c = 0; c < 4; c++) pr[1 + c] = s_prior[(4 + rr * 4 + c) * K + i];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                ms[q][0] = s_fv[rr * E1 + es[q]];
+#pragma unroll
+                for (int c = 0; c < 4; c++) ms[q][1 + c] = s_fv[(4 + rr * 4 + c) * E1 + es[q]];
+            }
+            double acc[5];  // eta[rr], lam[rr][0..3]
+#pragma unroll
+            for (int c = 0; c < 5; c++) acc[c] = pr[c];
+            const int x0 = HAS_IR ? s_irp[i] : 0, xm = HAS_IR ? s_irp[(K + 1) + i] : 0, x1 = HAS_IR ? s_irp[2 * (K + 1) + i] : 0;
+            auto ir_rows = [&](int e_from, int e_to) {
+                // compact messages: rows 0, 1 add eta[rr], lam[rr][0], lam[rr][1]; rows 2, 3 only zeros
+                if (!HAS_IR || rr >= 2) return;
+                if (STAGE_IR) {
+                    // staged messages: a batch that runs past the end reads the all-zero slot behind the robot's last edge
+                    // (x + 0.0 == x, as for the absent own edges above) — no clamps, no conditional adds, 32-bit LDS offsets
+                    for (int e = e_from; e < e_to; e += 4) {  // four messages are fetched before the adds
+                        double m[4][3];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int b = ((e + u < e_to) ? e + u - ie0 : ne) * IR_STRIDE;
+                            m[u][0] = s_ir[b + rr];
+                            m[u][1] = s_ir[b + 2 + 2 * rr];
+                            m[u][2] = s_ir[b + 3 + 2 * rr];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            acc[0] += m[u][0];
+                            acc[1] += m[u][1];
+                            acc[2] += m[u][2];
+                        }
+                    }
+                    return;
+                }
+                for (int e = e_from; e < e_to; e += 4) {  // four messages are fetched before the adds
+                    double m[4][3];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int ee = (e + u < e_to) ? e + u : e;  // clamp: the value is not added
+                        if (STAGE_IR) {
+                            const double *p = s_ir + (ee - ie0) * IR_STRIDE;
+                            m[u][0] = p[rr];
+                            m[u][1] = p[2 + 2 * rr];
+                            m[u][2] = p[3 + 2 * rr];
+                        } else {
+                            m[u][0] = w.ir_fv_eta[(size_t)rr * w.NI + ee];
+                            m[u][1] = w.ir_fv_lam[(size_t)(rr * 4) * w.NI + ee];
+                            m[u][2] = w.ir_fv_lam[(size_t)(rr * 4 + 1) * w.NI + ee];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (e + u < e_to) {
+                            acc[0] += m[u][0];
+                            acc[1] += m[u][1];
+                            acc[2] += m[u][2];
+                        }
+                }
+            };
+            ir_rows(x0, xm);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int c = 0; c < 5; c++) acc[c] += ms[q][c];
+            ir_rows(xm, x1);
+            s_out[rr * K + i] = acc[0];
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_out[(4 + rr * 4 + c) * K + i] = acc[1 + c];
+            if (internal && rr == 0) {
+                s_epoch[i] = ++epoch_reg;  // register copy when each thread owns one (variable, row)
+                if (4 * K <= SWEEP_BLOCK) my_epoch = epoch_reg;
+            }
+            if (last && s_out != s_prior) {  // the prior is not needed again in this launch: its LDS image
+                                             // carries the belief (eta, lam) to the write-back
+                s_prior[rr * K + i] = acc[0];
+#pragma unroll
+                for (int c = 0; c < 4; c++) s_prior[(4 + rr * 4 + c) * K + i] = acc[1 + c];
+            }
+        }
+    };
+    auto variable_sums = [&](double *s_out, bool internal, bool last) __attribute__((always_inline)) {
+        variable_sums_from(sum_t, sum_step, s_out, internal, last);
+    };
+    // Second half of the variable update: covariance, validity and mean from (eta, lam)
+    // (variable.rs:273-297), one lane per variable; for an internal sweep the mean also completes the
+    // snapshot (the responses' mean, :317).
+    auto variable_finish = [&](const double *s_in, bool internal) {
+        double b_eta[4], b_lam[16], mu[4], cov[16];
+#pragma unroll
+        for (int c = 0; c < 4; c++) b_eta[c] = s_in[c * K + lane];
+#pragma unroll
+        for (int c = 0; c < 16; c++) b_lam[c] = s_in[(4 + c) * K + lane];
+#pragma unroll
+        for (int c = 0; c < 4; c++) mu[c] = s_mu[c * K + lane];
+        int valid = s_valid[lane];
+        if (belief_update(b_eta, b_lam, mu, cov, valid)) {  // covariance (and maybe mean) changed
+#pragma unroll
+            for (int c = 0; c < 16; c++) s_cov[c * K + lane] = cov[c];
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_mu[c * K + lane] = mu[c];
+            s_valid[lane] = valid;
+            s_covset[lane] = 1;
+        }
+        if (internal) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_snap[(20 + c) * K + lane] = mu[c];
+        }
+    };
+
+    // The same on four lanes per variable (UV wave, lane = q * K + i): lane (q, i) computes the cofactors of row q from the three
+    // other rows — the expression inv4 evaluates for that row — i.e. column q of the covariance; the determinant comes from the
+    // q == 0 lane, the four columns meet in the covariance image in LDS, and lane (q, i) reads row q back for component q of
+    // the mean.  Every number is produced by the operations of belief_update in the same order.
+    // core: (eta, lam) of variable i from s_in; when the precision is neither "zero" nor singular (ok) the covariance goes to
+    // cov_img ([16][K]) and, if it is finite (fin), mu_q becomes component q of the new mean
+    auto quad_core = [&](const double *s_in, double *cov_img, bool &ok, bool &fin, double &mu_q) __attribute__((always_inline)) {
+        const int q = lane / K, i = lane - q * K;
+        double eta[4], lam[16];
+#pragma unroll
+        for (int c = 0; c < 4; c++) eta[c] = s_in[c * K + i];
+#pragma unroll
+        for (int c = 0; c < 16; c++) lam[c] = s_in[(4 + c) * K + i];
+        bool not_zero = false;
+#pragma unroll
+        for (int c = 0; c < 16; c++) not_zero = not_zero || (lam[c] > 1e-6);
+        double r0[4], r1[4], r2[4], mn[4], cf[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            r0[c] = (q == 0) ? lam[4 + c] : lam[c];
+            r1[c] = (q <= 1) ? lam[8 + c] : lam[4 + c];
+            r2[c] = (q <= 2) ? lam[12 + c] : lam[8 + c];
+        }
+        minors_of_removed_row(r0, r1, r2, mn);
+#pragma unroll
+        for (int j = 0; j < 4; j++) cf[j] = ((q + j) & 1) ? -mn[j] : mn[j];
+        const double row0[4] = {lam[0], lam[1], lam[2], lam[3]};
+        const double det = __shfl(det_from_row0(row0, cf), i, 64);  // lane i is (q == 0, i)
+        ok = not_zero && det != 0.0;
+        const double id = 1.0 / det;
+        double col[4];  // cov[j][q]
+        bool fin_own = true;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            col[j] = cf[j] * id;
+            fin_own = fin_own && std::isfinite(col[j]);
+        }
+        unsigned long long bad = __ballot(!fin_own);
+        constexpr int KS = QUADFIN ? KT : 1;  // (instantiated, never run, for longer horizons: keep the shift counts in range)
+        bad |= (bad >> KS) | (bad >> (2 * KS)) | (bad >> (3 * KS));
+        fin = ((bad >> i) & 1ull) == 0ull;
+        if (ok) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) cov_img[(j * 4 + q) * K + i] = col[j];
+            __builtin_amdgcn_wave_barrier();  // one wave: its LDS reads below follow its LDS writes above
+            if (fin) {
+                double cq[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) cq[c] = cov_img[(q * 4 + c) * K + i];
+                mu_q = ((cq[0] * eta[0] + cq[1] * eta[1]) + cq[2] * eta[2]) + cq[3] * eta[3];
+            }
+        }
+    };
+    auto variable_finish_quad = [&](const double *s_in, bool internal) {
+        const int q = lane / K, i = lane - q * K;
+        double mu_q = s_mu[q * K + i];
+        bool ok, fin;
+        quad_core(s_in, s_cov, ok, fin, mu_q);
+        if (ok) {
+            if (fin) s_mu[q * K + i] = mu_q;
+            if (q == 0) {
+                s_valid[i] = fin ? 1 : 0;
+                s_covset[i] = 1;
+            }
+        }
+        if (internal) s_snap[(20 + q) * K + i] = mu_q;
+    };
+    auto finish = [&](const double *s_in, bool internal) __attribute__((always_inline)) {
+        if constexpr (QUADFIN) {
+            if (role == ROLE_UV && lane < 4 * K) variable_finish_quad(s_in, internal);
+        } else {
+            if (is_var) variable_finish(s_in, internal);
+        }
+    };
+
+    // Internal factor sweep, DYN wave: one lane per dynamic-factor message.  The two messages of one
+    // factor read each other's previous value; both lanes sit in the SAME wave, whose LDS reads all
+    // issue before its LDS writes, so no barrier is needed between reading the old and writing the new
+    // messages.  Reads s_snap, s_epoch and the dynamic columns of s_fv only.
+    auto dynamic_messages = [&](double *s_out) {
+        double me[4], ml[16], oe[4], ol[16];
+        const int o = dyn_other_var, oe_ix = dyn_other_edge;
+        double paa[4], pab[4], pba[4], pbb[4];
+        if (PERSIST) {
+            load_dyn_potential(paa, pab, pba, pbb);  // requested first: they travel under the LDS reads below
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) { paa[c] = maa[c]; pab[c] = mab[c]; pba[c] = mba[c]; pbb[c] = mbb[c]; }
+        }
+        if (s_epoch[o] > 0) {  // other variable has answered: belief - our last message
+#pragma unroll
+            for (int c = 0; c < 4; c++) me[c] = s_snap[c * K + o] - s_fv[c * E1 + oe_ix];
+#pragma unroll
+            for (int c = 0; c < 16; c++) ml[c] = s_snap[(4 + c) * K + o] - s_fv[(4 + c) * E1 + oe_ix];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) me[c] = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; c++) ml[c] = 0.0;
+        }
+        // Horizons beyond 33 variables (BIG instantiations only) have more messages than the wave has lanes:
+        // lane l also computes message l + 64.  Its operands are read here, before ANY message of this sweep
+        // is written — the partner of a second-pass message may be a first-pass message.
+        double me2[4], ml2[16];
+        const int lane2 = lane + 64;
+        const bool has2 = BIG && lane2 < n_dyn;
+        if (has2) {
+            const int f2 = lane2 % (K - 1), slot2 = lane2 / (K - 1), o2 = f2 + 1 - slot2, oe2 = (1 - slot2) * (K - 1) + f2;
+            const bool pres = s_epoch[o2] > 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) me2[c] = pres ? s_snap[c * K + o2] - s_fv[c * E1 + oe2] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; c++) ml2[c] = pres ? s_snap[(4 + c) * K + o2] - s_fv[(4 + c) * E1 + oe2] : 0.0;
+        }
+        if (!dynamic_message(paa, pab, pba, pbb, me, ml, oe, ol)) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) oe[c] = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; c++) ol[c] = 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) s_out[c * E1 + lane] = oe[c];
+#pragma unroll
+        for (int c = 0; c < 16; c++) s_out[(4 + c) * E1 + lane] = ol[c];
+        if (has2) {  // potential blocks of the second message straight from HBM / L2: a rare shape, not worth registers
+            const int f2 = lane2 % (K - 1), slot2 = lane2 / (K - 1), a2 = 2 * slot2, b2 = 2 * (1 - slot2), it2 = r * (K - 1) + f2;
+            double naa[4], nab[4], nba[4], nbb[4];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    naa[i * 2 + j] = w.dyn_m[(size_t)((a2 + i) * 4 + (a2 + j)) * w.ND + it2];
+                    nab[i * 2 + j] = w.dyn_m[(size_t)((a2 + i) * 4 + (b2 + j)) * w.ND + it2];
+                    nba[i * 2 + j] = w.dyn_m[(size_t)((b2 + i) * 4 + (a2 + j)) * w.ND + it2];
+                    nbb[i * 2 + j] = w.dyn_m[(size_t)((b2 + i) * 4 + (b2 + j)) * w.ND + it2];
+                }
+            if (!dynamic_message(naa, nab, nba, nbb, me2, ml2, oe, ol)) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) oe[c] = 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; c++) ol[c] = 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_out[c * E1 + lane2] = oe[c];
+#pragma unroll
+            for (int c = 0; c < 16; c++) s_out[(4 + c) * E1 + lane2] = ol[c];
+        }
+    };
+
+    // Unary factors of an internal factor sweep, UV wave: obstacle factors (four lanes each when they fit) and
+    // tracking factors.  Reads the snapshot means and delivery counts, writes its own message columns.
+    // skip: kinds whose sweep k_thaw has already computed (first sweep after mgx_set_enabled only).
+    const SdfView sdf = make_sdf_view(w.sdf, w.sdf_w, w.sdf_h, w.world_w, w.world_h);
+    auto unary_messages = [&](uint32_t skip, double *s_out, int itf_gate) __attribute__((always_inline)) {
+        if (obs_rows) {
+            // four lanes per obstacle factor: lane q samples tap q and writes row q of the message
+            if (role == ROLE_UV && lane < 4 * (K - 2) && (w.enable & 4u) && !(skip & 4u)) {
+                const int j = lane >> 2, q = lane & 3, var = j + 1, col = n_dyn + j;
+                double x0[4];
+                const bool pres = s_epoch[var] > 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) x0[c] = pres ? s_snap[(20 + c) * K + var] : 0.0;
+                const long long idx = obstacle_tap(sdf, x0[0], x0[1], w.obs_delta, q);
+                const double hq = (idx >= 0) ? sdf_value(w.sdf[idx]) : 0.0;
+                double h[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) h[t] = __shfl(hq, (lane & ~3) + t, 64);
+                double eta_q, lam_q[4];
+                obstacle_message_row(h, w.obs_delta, w.inv_s2_obs, x0, q, eta_q, lam_q);
+                s_out[q * E1 + col] = eta_q;
+#pragma unroll
+                for (int c = 0; c < 4; c++) s_out[(4 + q * 4 + c) * E1 + col] = lam_q[c];
+            }
+        } else if (is_obs && (w.enable & 4u) && !(skip & 4u)) {
+            double x0[4], oe[4], ol[16];
+            const bool pres = s_epoch[uvar] > 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) x0[c] = pres ? s_snap[(20 + c) * K + uvar] : 0.0;
+            long long idx[4];
+            obstacle_taps(sdf, x0[0], x0[1], w.obs_delta, idx);
+            double h[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) h[q] = (idx[q] >= 0) ? sdf_value(w.sdf[idx[q]]) : 0.0;
+            obstacle_message(h, w.obs_delta, w.inv_s2_obs, x0, oe, ol);
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_out[c * E1 + uedge] = oe[c];
+#pragma unroll
+            for (int c = 0; c < 16; c++) s_out[(4 + c) * E1 + uedge] = ol[c];
+        }
+        if (is_trk && (w.enable & 8u) && itf_gate >= 10 && !(skip & 8u)) {  // factorgraph.rs:701
+            double x0[4], oe[4], ol[16];
+#pragma unroll
+            for (int c = 0; c < 4; c++) x0[c] = s_snap[(20 + c) * K + uvar];
+            const int p0 = w.path_ptr[r], np = w.path_ptr[r + 1] - p0;
+            if (!tracking_update(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, trk_rec,
+                                  trk_lp, trk_lv, oe, ol)) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) oe[c] = 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; c++) ol[c] = 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_out[c * E1 + uedge] = oe[c];
+#pragma unroll
+            for (int c = 0; c < 16; c++) s_out[(4 + c) * E1 + uedge] = ol[c];
+        }
+        // horizons beyond 33 variables: tracking factors K-2+64 .. 2(K-2)-1 have no lane of their own; lanes
+        // 0 .. of the UV wave take them on, with their state in HBM (BIG instantiations only)
+        if (BIG && role == ROLE_UV && lane + 64 >= K - 2 && lane + 64 < 2 * (K - 2) && (w.enable & 8u) && itf_gate >= 10 &&
+            !(skip & 8u)) {
+            const int j2 = lane + 64 - (K - 2), var2 = j2 + 1, col2 = n_dyn + (K - 2) + j2, item2 = r * (K - 2) + j2;
+            double x0[4], oe[4], ol[16];
+#pragma unroll
+            for (int c = 0; c < 4; c++) x0[c] = s_snap[(20 + c) * K + var2];
+            int rec2 = w.trk_record[item2];
+            float lp2[2] = {w.trk_last_pos[item2], w.trk_last_pos[(size_t)w.NT + item2]};
+            double lv2 = w.trk_last_val[item2];
+            const int p0 = w.path_ptr[r], np = w.path_ptr[r + 1] - p0;
+            if (!tracking_update(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, rec2, lp2, lv2, oe, ol)) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) oe[c] = 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; c++) ol[c] = 0.0;
+            }
+            w.trk_record[item2] = rec2;
+            w.trk_last_pos[item2] = lp2[0];
+            w.trk_last_pos[(size_t)w.NT + item2] = lp2[1];
+            w.trk_last_val[item2] = lv2;
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_out[c * E1 + col2] = oe[c];
+#pragma unroll
+            for (int c = 0; c < 16; c++) s_out[(4 + c) * E1 + col2] = ol[c];
+        }
+    };
+
+    // Resident schedule launch: in front of the external iteration of segment k, wait until every robot this one
+    // exchanges snapshot records with (and that is on air) has completed segment k - 1 — its records for this
+    // iteration are then published, and it has finished reading ours of the iteration before, whose buffer the
+    // end of this segment overwrites.  One lane per peer polls that robot's progress word (relaxed agent-scope
+    // loads, s_sleep in between); a wait that outlasts the wall-clock bound raises the world's abort word, which
+    // releases every waiter: the launch then ends with wrong beliefs and the host reports it (never a hung GPU).
+    // The peer list does not change during the launch: lane l of the polling wave keeps peer l (the one it polls in every
+    // segment) in a register — looked up per segment, the three dependent loads in front of the first look at a progress
+    // word (list range, peer, its antenna / idle flags) were a microsecond of pure latency on the hand-off.
+    int my_peer = -1, peer_q0 = 0, peer_q1 = 0;
+    if (PERSIST && radio && ir_on && role == ROLE_UV) {
+        peer_q0 = w.peer_ptr[r];
+        peer_q1 = w.peer_ptr[r + 1];
+        if (peer_q0 + lane < peer_q1) {
+            const int pr = w.peer_idx[peer_q0 + lane];
+            if (w.antenna[pr] && !w.idle[pr]) my_peer = pr;  // not on air: neither reads our records nor has its own read
+        }
+    }
+    // ghosts_only (sharded worlds, see the end of a segment): look at the peers on other ranks only
+    auto progress_of = [&](int pr) __attribute__((always_inline)) {
+        if (SHARD && pr >= w.R_local)  // a ghost: its owner's rank stores the word into this rank's ghost area
+            return __hip_atomic_load(&w.gflag[pr - w.R_local], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return __hip_atomic_load(&w.sweep_flag[pr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto wait_for_progress = [&](unsigned long long want, bool ghosts_only) __attribute__((always_inline)) {
+        if (PERSIST && radio && ir_on && role == ROLE_UV) {
+            for (int q = peer_q0 + lane; q < peer_q1; q += 64) {
+                int pr = my_peer;
+                if (q != peer_q0 + lane) {  // more than 64 peers: the rest is looked up
+                    pr = w.peer_idx[q];
+                    if (!w.antenna[pr] || w.idle[pr]) pr = -1;
+                }
+                if (pr < 0 || (ghosts_only && pr < w.R_local)) continue;
+                const long long t0 = wall_clock64();
+                unsigned spins = 0;
+                while (progress_of(pr) < want) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if ((++spins & 31u) == 0u) {
+                        if (__hip_atomic_load(w.sweep_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+                        if (wall_clock64() - t0 > plan.timeout_ticks) {
+                            __hip_atomic_store(w.sweep_abort, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(w.sweep_err, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    auto wait_for_peers = [&](int k) __attribute__((always_inline)) { wait_for_progress(plan.flag_base + (unsigned long long)k, false); };
+    // sharded worlds: the ranks that hold this robot as a ghost
+    int xp0 = 0, xp1 = 0;
+    if (SHARD && role == ROLE_UV) {
+        xp0 = w.xp_ptr[r];
+        xp1 = w.xp_ptr[r + 1];
+    }
+
+    bool prefired = false;  // both waves already ran the factor sweep of internal iteration 0
+    bool par_done = false;  // resident, K <= 16: this segment's two variable sweeps ran side by side
+    bool pending = false;   // the last internal sums still await their finish (mean, covariance)
+    // resident launches: the factor sweep of the coming segment's first internal iteration has been computed into
+    // s_sh at the end of the previous segment, under the publish / wait latency of the hand-off (it reads nothing an
+    // external iteration produces: snapshots of the last INTERNAL variable sweep and the factors' own last messages)
+    bool early = false;
+    auto adopt_early = [&](int t0, int step) __attribute__((always_inline)) {  // s_sh -> s_fv, columns 0 .. E-1
+        for (int t = t0; t < 20 * E; t += step) {
+            const int c = t / E, e = t - c * E;
+            s_fv[c * E1 + e] = s_sh[c * E1 + e];
+        }
+    };
+    int last_int_seg = -1, last_ext_seg = -1;  // PERSIST: last segment with internal iterations / an external iteration
+    if (PERSIST)
+        for (int k = 0; k < nseg; k++) {
+            if (plan.n_int[k] > 0) last_int_seg = k;
+            if (plan.ext[k]) last_ext_seg = k;
+        }
+#ifdef MGX_STAMPS
+    unsigned long long c_f = 0, c_fb = 0, c_v = 0, c_vb = 0, t_extf = t_staged, t_extv = t_staged, t_loop0 = t_staged;
+    unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long p_wait = 0, p_extf = 0, p_extv = 0, p_int = 0, p_pub = 0;  // resident launches: cycles per stage, all segments
+    unsigned long long qs[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // ... and inside the stages
+#define PSTAMP(v) const unsigned long long v = __builtin_readcyclecounter()
+#define QSTAMP(i, since) do { const unsigned long long _n = __builtin_readcyclecounter(); qs[i] += _n - (since); (since) = _n; } while (0)
+#define QBEGIN(v) unsigned long long v = __builtin_readcyclecounter()
+#else
+#define PSTAMP(v)
+#define QSTAMP(i, since)
+#define QBEGIN(v)
+#endif
+    for (int k = 0; k < nseg; k++) {
+        // Nothing derived from the thread index stays live across segments: left alone, the compiler hoists every per-thread
+        // address and predicate of the loop body in front of the loop and then spills them around the f64 blocks (64 spilled
+        // VGPRs, 244 B of scratch per lane at K = 16); recomputing them per segment is a handful of integer instructions.
+        if (PERSIST) asm volatile("" : "+v"(tid), "+v"(lane));
+        const uint32_t ext_k = PERSIST ? (plan.ext[k] ? (PH_EXT_FACTOR | PH_EXT_VARIABLE) : 0u) : ext_mask;
+        const uint32_t int_k = PERSIST ? (PH_INT_FACTOR | PH_INT_VARIABLE) : int_mask;
+        const int n_int_k = PERSIST ? (int)plan.n_int[k] : n_int;
+        const bool last_seg = k == nseg - 1;
+        // ======================= external factor sweep ============================================
+        PSTAMP(ps0);
+        QBEGIN(qt);
+        if (PERSIST && ext_k && k > 0) {  // k == 0: the launch boundary has published everything
+            wait_for_peers(k);
+            QSTAMP(0, qt);
+            __syncthreads();
+            QSTAMP(1, qt);
+        }
+        PSTAMP(ps1);
+        if (ext_k & PH_EXT_FACTOR) {
+            external_factor_sweep(k, !PERSIST || k == last_ext_seg);
+            QSTAMP(2, qt);
+            __syncthreads();
+            QSTAMP(3, qt);
+        }
+        PSTAMP(ps2);
+#ifdef MGX_STAMPS
+        if (k == 0) t_extf = __builtin_readcyclecounter();
+#endif
+        // ======================= external variable sweep ==========================================
+        prefired = false;
+        if constexpr (FUSED) {
+            // Resident launches, K <= 16.  The UV wave runs the whole external variable sweep — inbox sums, then the finish on
+            // four lanes per variable — with no workgroup barrier inside; a factor sweep of this segment's first internal
+            // iteration that was not computed ahead goes into the shadow block next to it (DYN wave: dynamic messages, UV
+            // wave after its finish: unary factors), and the shadow is adopted by exchanging the two blocks' roles.
+            // The steady state of an alternating schedule (external iteration, ONE internal iteration whose factor sweep was
+            // computed ahead): the two variable sweeps read the same inboxes but for the internal factors' messages — the
+            // external one the old block, the internal one the shadow — and neither reads what the other writes, EXCEPT that
+            // a belief update which finds its precision "zero", singular or its covariance non-finite keeps the state the
+            // previous update left.  So they run side by side: the DYN wave the external sweep, into shadow images (means
+            // = the response means of the next factor sweep, covariance, outcome), the UV wave the internal one, keeping its
+            // means and flags back until the barrier; only a variable whose internal update did not go through looks at the
+            // external sweep's outcome afterwards.  Takes a whole variable sweep off the chain from record to publication.
+            par_done = (ext_k & PH_EXT_VARIABLE) && radio && early && n_int_k == 1;
+            if (par_done) {
+                const bool is_last = k == last_int_seg && last_seg;
+                const int q = lane / K, i = lane - q * K;  // lanes < 4 K of either wave
+                bool ok_i = false, fin_i = false;
+                double mu_i = 0.0;
+                if (role == ROLE_UV) {  // the messages computed ahead are this sweep's
+                    double *t_ = s_fv;
+                    s_fv = s_sh;
+                    s_sh = t_;
+                    // (the robot's last sweep leaves its sums in the belief image as well — after the barrier: the other wave is
+                    // still reading that image as the prior)
+                    variable_sums(s_snap, true, false);
+                    QSTAMP(4, qt);
+                    if (lane < 4 * K) quad_core(s_snap, s_cov, ok_i, fin_i, mu_i);
+                } else {
+                    if (lane < 4 * K) {
+                        variable_sums_from(lane, 4 * K, s_tmp, false, false);
+                        QSTAMP(4, qt);
+                        double mu_x = s_mu[q * K + i];  // the state before this segment: the UV wave stores after the barrier
+                        bool ok_x, fin_x;
+                        quad_core(s_tmp, s_tmp + 4 * K, ok_x, fin_x, mu_x);  // covariance over the lam sums it has read
+                        s_xmu[q * K + i] = mu_x - 0.0;                        // likewise over the eta sums
+                        if (q == 0) s_xok[i] = (ok_x ? 1 : 0) | (fin_x ? 2 : 0);
+                    }
+                    double *t_ = s_fv;
+                    s_fv = s_sh;
+                    s_sh = t_;
+                }
+                QSTAMP(6, qt);
+                __syncthreads();
+                QSTAMP(7, qt);
+                if (role == ROLE_UV && lane < 4 * K) {
+                    double mu_fin = mu_i;
+                    const int xs = s_xok[i];
+                    if (!(ok_i && fin_i)) {  // variable.rs:273-297 kept what the external update left
+                        mu_fin = s_xmu[q * K + i];
+                        if (!ok_i && (xs & 1)) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) s_cov[(j * 4 + q) * K + i] = s_tmp[(4 + j * 4 + q) * K + i];
+                        }
+                    }
+                    s_mu[q * K + i] = mu_fin;
+                    s_snap[(20 + q) * K + i] = mu_fin;
+                    if (is_last) {  // row q of (eta, lam): what this lane summed
+                        s_prior[q * K + i] = s_snap[q * K + i];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) s_prior[(4 + q * 4 + c) * K + i] = s_snap[(4 + q * 4 + c) * K + i];
+                    }
+                    if (q == 0) {
+                        if (ok_i) {
+                            s_valid[i] = fin_i ? 1 : 0;
+                            s_covset[i] = 1;
+                        } else if (xs & 1) {
+                            s_valid[i] = (xs & 2) ? 1 : 0;
+                            s_covset[i] = 1;
+                        }
+                    }
+                }
+                if (ir_on && k != last_ext_seg) {
+                    have_xmu = true;
+                } else if (ir_on) {  // the launch's last external iteration: the response means go to HBM (robot.rs:1842-1858)
+                    for (int j = tid; j < ne; j += SWEEP_BLOCK) {
+                        const int e = ie0 + j;
+                        int dst;
+                        if (j == tid) {
+                            if (!pf_gate) continue;
+                            dst = pf_dst;
+                        } else {
+                            if (!w.ir_gate[e]) continue;
+                            dst = w.ir_rec[e].dst;
+                        }
+                        const int iv = dst & 0xffff;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = s_xmu[c * K + iv];
+                    }
+                }
+                if (is_last) __syncthreads();  // the tail's write-back (other wave) reads the belief image
+                itf += 1;  // the factor sweep that was computed ahead
+                early = false;
+            } else if ((ext_k & PH_EXT_VARIABLE) && radio) {
+                const bool ext_is_last = last_seg && n_int_k == 0;
+                double *s_sum = ext_is_last ? s_prior : s_tmp;
+                prefired = !early && n_int_k > 0 && !idle && (int_k & PH_INT_FACTOR) && skip0 == 0u;
+                const bool keep_means = ir_on && k != last_ext_seg;
+                if (role == ROLE_UV) {
+                    variable_sums(s_sum, false, false);  // reads the messages of the last internal factor sweep (s_fv)
+                    QSTAMP(4, qt);
+                    finish(s_sum, false);
+                    // the response means stay in LDS for the next segment's factor sweep (same wave: these writes follow the
+                    // finish's reads of the eta sums they overwrite)
+                    if (keep_means && lane < 4 * K) s_xmu[lane] = s_mu[lane] - 0.0;
+                    if (prefired) unary_messages(0u, s_sh, itf);
+                } else if (prefired && is_dyn && (w.enable & 1u)) {
+                    dynamic_messages(s_sh);
+                }
+                QSTAMP(6, qt);
+                if (keep_means) {
+                    have_xmu = true;
+                } else if (ir_on) {  // the launch's last external iteration: the means go to HBM (robot.rs:1842-1858)
+                    __syncthreads();
+                    for (int j = tid; j < ne; j += SWEEP_BLOCK) {
+                        const int e = ie0 + j;
+                        int dst;
+                        if (j == tid) {
+                            if (!pf_gate) continue;
+                            dst = pf_dst;
+                        } else {
+                            if (!w.ir_gate[e]) continue;
+                            dst = w.ir_rec[e].dst;
+                        }
+                        const int i = dst & 0xffff;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = s_mu[c * K + i] - 0.0;
+                    }
+                }
+                if (prefired) __syncthreads();  // both waves' columns of the shadow are complete
+            }
+            if (early || prefired) {  // adopt the factor sweep that was computed into the shadow
+                double *t_ = s_fv;
+                s_fv = s_sh;
+                s_sh = t_;
+            }
+        } else if (ext_k & PH_EXT_VARIABLE) {
+            // beliefs are recomputed, nothing is delivered to own factors (factorgraph.rs:794-826): the
+            // sums go to the belief image if this is the robot's last sweep of the launch, else to scratch
+            // (the image doubles as the prior, which every later sweep of the launch still needs)
+            const bool ext_is_last = PERSIST ? (last_seg && n_int_k == 0) : !has_int_var;
+            double *s_sum = ext_is_last ? s_prior : s_tmp;
+            if (radio) variable_sums(s_sum, false, false);
+            QSTAMP(4, qt);
+            __syncthreads();
+            QSTAMP(5, qt);
+            // The first internal factor sweep of this segment does not depend on anything the external
+            // sweeps produce (a dynamic factor reads the snapshot of the last INTERNAL variable sweep and
+            // its own previous messages): the DYN wave computes its messages now, next to the UV wave's
+            // mean / covariance of the external variable sweep (one 4x4 inverse per variable either way).
+            // The unary factors do not either (they linearise at the means of the last INTERNAL sweep): the UV wave
+            // runs them right after its finish instead of idling until the DYN wave is done.
+            prefired = !early && radio && n_int_k > 0 && !idle && (int_k & PH_INT_FACTOR) && skip0 == 0u;  // same for the whole workgroup
+            if (prefired && is_dyn && (w.enable & 1u)) dynamic_messages(s_fv);
+            if (PERSIST && early && radio && role == ROLE_DYN) adopt_early(lane, 64);  // the sums above were the last readers of the old messages
+            if (radio && is_var) variable_finish(s_sum, false);
+            if (prefired) unary_messages(0u, s_fv, itf);
+            QSTAMP(6, qt);
+            __syncthreads();
+            QSTAMP(7, qt);
+            if (PERSIST && radio && ir_on && k != last_ext_seg) {
+                if (tid < 4 * K) s_xmu[tid] = s_mu[tid] - 0.0;  // read after the barrier that opens the next segment's factor sweep
+                have_xmu = true;
+            } else if (radio && ir_on) {
+                // responses to the foreign factors attached to our variables, routed to their inbox
+                // (robot.rs:1842-1858): only the mean of that inbox entry is ever used (it sets the
+                // linearisation point; eta / lam of the target side never reach the kept message).
+                // Plain stores of LDS values: nothing in this launch but the storing thread itself reads them
+                // (the means are next written after the barrier that ends the coming factor sweep / by nobody).
+                for (int j = tid; j < ne; j += SWEEP_BLOCK) {
+                    const int e = ie0 + j;
+                    int dst;
+                    if (j == tid && (do_extf || PERSIST)) {  // gate and constants of the thread's first edge are in registers
+                        if (!pf_gate) continue;
+                        dst = pf_dst;
+                    } else {
+                        if (!w.ir_gate[e]) continue;  // the owner cannot receive
+                        dst = w.ir_rec[e].dst;
+                    }
+                    const int i = dst & 0xffff;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = s_mu[c * K + i] - 0.0;
+                }
+            }
+        }
+        QSTAMP(8, qt);
+        PSTAMP(ps3);
+#ifdef MGX_STAMPS
+        if (k == 0) { t_extv = __builtin_readcyclecounter(); t_loop0 = t_extv; rt0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+        // ======================= internal iterations ==============================================
+        if (PERSIST && !FUSED && early && !((ext_k & PH_EXT_VARIABLE) && radio)) {  // no external variable sweep ran: adopt here
+            adopt_early(tid, SWEEP_BLOCK);
+            __syncthreads();
+        }
+        if (PERSIST && early) prefired = true;
+        early = false;
+        for (int it = 0; it < n_int_k && !idle && !par_done; it++) {
+            asm volatile("" : "+v"(tid), "+v"(lane));  // as at the top of a segment: nothing per-thread hoisted out of this loop either
+            STAMP(t0);
+            if ((int_k & PH_INT_FACTOR) && it == 0 && prefired) {
+                itf += 1;  // this sweep ran next to the external variable sweep, in front of that block's last barrier
+            } else if (int_k & PH_INT_FACTOR) {
+                if (is_dyn && (w.enable & 1u) && !(it == 0 && (skip0 & 1u))) dynamic_messages(s_fv);
+                // UV wave: first the belief of the previous sweep (mean, covariance) that the unary
+                // factors linearise at — same wave, so its LDS writes precede their LDS reads
+                if (pending) finish(s_snap, true);
+                pending = false;
+                unary_messages(it == 0 ? skip0 : 0u, s_fv, itf);
+                itf += 1;
+                STAMP(t1);
+                __syncthreads();
+                STAMP(t2);
+                STAMP_ADD(c_f, t0, t1);
+                STAMP_ADD(c_fb, t1, t2);
+            }
+            STAMP(t3);
+            if (int_k & PH_INT_VARIABLE) {
+                // the robot's last sweep of the launch leaves its sums in the belief image as well (a robot that is
+                // off the air runs no external sweep: its last one is the last internal iteration of the schedule)
+                const bool is_last = it == n_int_k - 1 && (!PERSIST || (k == last_int_seg && (last_seg || !radio)));
+                variable_sums(s_snap, true, is_last);
+                pending = true;
+                STAMP(t4);
+                __syncthreads();
+                STAMP(t5);
+                STAMP_ADD(c_v, t3, t4);
+                STAMP_ADD(c_vb, t4, t5);
+            }
+        }
+        // ======================= end of a segment of a resident schedule launch ====================
+        // The snapshot records of this robot (what its variables last sent to their own factors: all that another
+        // robot's inter-robot factors read) go out for the external iteration that opens the next segment: into the
+        // buffer nobody reads during this segment, write-through, every wave drained, then the progress word.
+        PSTAMP(ps4);
+        // ONE wave does all of it (the one that completes the means), so it may signal for itself after its own drain.
+        if (PERSIST && !last_seg) {
+            QSTAMP(9, qt);
+            if (role == ROLE_UV) {
+                if (pending) finish(s_snap, true);
+                QSTAMP(10, qt);
+                __builtin_amdgcn_wave_barrier();  // the wave's LDS writes (means) precede its LDS reads below
+                const int ob = (w.cur + k + 1) & 1;
+                const unsigned base = (unsigned)v0 * (unsigned)(SNAP_W * sizeof(double));
+                for (int t = lane; t < (SNAP_W / 2) * K; t += 64) {  // 16 bytes = components 2c, 2c + 1 of variable i
+                    const int i = t / (SNAP_W / 2), c = t - i * (SNAP_W / 2);
+                    st16_agent(rs_snap[ob], base + (unsigned)(i * SNAP_W + 2 * c) * 8u, s_snap[(2 * c) * K + i], s_snap[(2 * c + 1) * K + i]);
+                }
+                for (int t = lane; t < K; t += 64) st_agent(&w.snap_epoch[ob][v0 + t], s_epoch[t]);
+                QSTAMP(11, qt);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                QSTAMP(12, qt);
+                if (lane == 0)
+                    __hip_atomic_store(&w.sweep_flag[r], plan.flag_base + (unsigned long long)k + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (SHARD && xp1 > xp0) {
+                    // A boundary robot of a sharded world: the same records go into the ghost area of every rank that holds this
+                    // robot as a ghost (system-scope write-through stores over xGMI), drained, then the ghost's progress word there.
+                    // Nothing orders two RANKS' launches: the parity written here is the one those ranks' robots read in the LAST
+                    // external iteration of the previous launch, so in segment 0 wait until they are through with it (they say so
+                    // at the end of their launch, below); in later segments the wait in front of the external iteration has.
+                    if (k == 0) wait_for_progress(plan.flag_base, true);
+                    for (int t = xp0; t < xp1; t++) {
+                        const XPushRec xr = w.xp_rec[t];
+                        const __amdgpu_buffer_rsrc_t rs_x = uniform_rsrc(xr.snap[ob], (unsigned)K * (unsigned)(SNAP_W * sizeof(double)));
+                        for (int t2 = lane; t2 < (SNAP_W / 2) * K; t2 += 64) {
+                            const int i = t2 / (SNAP_W / 2), c = t2 - i * (SNAP_W / 2);
+                            st16_system(rs_x, (unsigned)(i * SNAP_W + 2 * c) * 8u, s_snap[(2 * c) * K + i], s_snap[(2 * c + 1) * K + i]);
+                        }
+                        uint32_t *xe = reinterpret_cast<uint32_t *>(xr.epoch[ob]);
+                        for (int t2 = lane; t2 < K; t2 += 64) __hip_atomic_store(&xe[t2], s_epoch[t2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0)
+                        for (int t = xp0; t < xp1; t++) {
+                            const XPushRec xr = w.xp_rec[t];
+                            __hip_atomic_store(reinterpret_cast<unsigned long long *>(xr.flag), plan.flag_base + xr.flag_delta + (unsigned long long)k + 1ull,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                }
+            }
+            pending = false;
+            // the factor sweep that opens the next segment's internal iterations, while the records travel: the DYN wave
+            // starts at once (a dynamic factor reads no mean), the UV wave after its publish.  The tracking factors' gate
+            // (factorgraph.rs:701) counts the external factor sweep that the reference runs in between.
+            early = plan.n_int[k + 1] > 0 && !idle && skip0 == 0u;
+            if (early) {
+                if (is_dyn && (w.enable & 1u)) dynamic_messages(s_sh);
+                unary_messages(0u, s_sh, itf + ((plan.ext[k + 1] && radio) ? 1 : 0));
+            }
+            QSTAMP(13, qt);
+        }
+#ifdef MGX_STAMPS
+        {
+            PSTAMP(ps5);
+            p_wait += ps1 - ps0; p_extf += ps2 - ps1; p_extv += ps3 - ps2; p_int += ps4 - ps3; p_pub += ps5 - ps4;
+        }
+#endif
+    }
+    {
+        // Tail: the UV wave completes the last variable sweep (mean, covariance) while the DYN wave
+        // already writes back what that does not touch — the factor -> variable messages and the belief
+        // (eta, lam) image, three quarters of the robot's output.
+        if (role == ROLE_UV) {
+            if (pending) finish(s_snap, true);
+        } else {
+            copy_words_wave(blob + L.fv(), s_fv, 20 * E1, lane);
+            if (any_sweep && !bel_dead) copy_words_wave(blob + L.bel(), s_prior, 20 * K, lane);
+        }
+        __syncthreads();
+#ifdef MGX_STAMPS
+        if (w.dbg && lane == 0) {  // per wave: cycles in factor phase, its barrier, variable phase, its barrier
+            unsigned long long *d = w.dbg + ((size_t)blockIdx.x * 2 + role) * 8;
+            d[0] = c_f; d[1] = c_fb; d[2] = c_v; d[3] = c_vb; d[4] = __builtin_readcyclecounter() - t_loop0;
+            d[5] = __builtin_amdgcn_s_memrealtime() - rt0;  // 100 MHz ticks over the same span
+            d[6] = t_staged - t_k0;
+            d[0] = (d[0] & 0xffffffffull) | ((t_extf - t_staged) << 32);  // external factor sweep (high word)
+            d[1] = (d[1] & 0xffffffffull) | ((t_extv - t_extf) << 32);    // external variable sweep (high word)
+            if (PERSIST) {
+                d[0] = p_wait; d[1] = p_extf; d[2] = p_extv; d[3] = p_int; d[4] = p_pub;
+                unsigned long long *d2 = w.dbg + (size_t)(gridDim.x + 4) * 16 + ((size_t)blockIdx.x * 2 + role) * 16;
+                for (int i = 0; i < 16; i++) d2[i] = qs[i];
+                d2[14] = q_arrive;
+            }
+        }
+#endif
+    }
+    if (PERSIST) snap_out = (w.cur + nseg) & 1;  // where the records of the schedule's last sweep go (the host follows)
+    if (SHARD && role == ROLE_UV && lane == 0) {  // "through with this launch's reads of your records": see the end of a segment
+        for (int t = xp0; t < xp1; t++) {
+            const XPushRec xr = w.xp_rec[t];
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(xr.flag), plan.flag_base + xr.flag_delta + (unsigned long long)nseg,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+
+    // ---- write back: straight copies of the LDS images ----------------------------------------------
+    for (int t = tid; t < 16 * K; t += SWEEP_BLOCK)  // covariance of the variables that recomputed it
+        if (s_covset[t % K]) blob[L.cov() + t] = s_cov[t];
+    copy_words(blob + L.mu(), s_mu, 4 * K, tid);
+    copy_words(blob + L.valid(), (const double *)s_valid, K, tid);
+    if (snap_out >= 0) {
+        double *dst = w.snap[snap_out] + (size_t)v0 * SNAP_W;
+        for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) dst[t] = s_snap[(t % SNAP_W) * K + (t / SNAP_W)];
+        for (int t = tid; t < K; t += SWEEP_BLOCK) w.snap_epoch[snap_out][v0 + t] = s_epoch[t];
+    }
+    if (is_trk) {
+        w.trk_record[trk_item] = trk_rec;
+        w.trk_last_pos[trk_item] = trk_lp[0];
+        w.trk_last_pos[(size_t)w.NT + trk_item] = trk_lp[1];
+        w.trk_last_val[trk_item] = trk_lv;
+    }
+    if (tid == 0) w.iter_factor[r] = itf;
+#ifdef MGX_STAMPS
+    if (w.dbg && lane == 0) w.dbg[((size_t)blockIdx.x * 2 + role) * 8 + 7] = __builtin_readcyclecounter() - t_k0;  // whole kernel
+#endif
+}
+
+}  // namespace mgx

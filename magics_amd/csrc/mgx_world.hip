@@ -32,9 +32,9 @@ int blob_words(int K);
 bool sweep_supports(int K);
 hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint32_t ext_mask, uint32_t int_mask, int n_int,
                               int snap_out, uint32_t hints, hipStream_t stream);
-int sweep_resident_capacity(const DevWorld &w);
+int sweep_resident_capacity(const DevWorld &w, bool sharded);
 size_t sweep_resident_lds_max();
-hipError_t launch_robot_schedule(const DevWorld &w, int n_robots, const SegPlan &plan, hipStream_t stream);
+hipError_t launch_robot_schedule(const DevWorld &w, int n_robots, const SegPlan &plan, bool sharded, bool cooperative, hipStream_t stream);
 hipError_t launch_change_prior(const DevWorld &w, int n, const int32_t *robots, const uint32_t *vars, const double *means,
                                hipStream_t stream);
 hipError_t launch_update_priors(const DevWorld &w, int n, const int32_t *robots, const double *waypoints, const double *time_scale,
@@ -356,6 +356,7 @@ struct mgx_world {
     unsigned long long *sweep_err_host = nullptr;  // host-mapped; non-zero once a wait inside a resident launch gave up
     unsigned long long flag_base = 0;              // every progress word is below or at this value between launches
     int resident_cap = -1;                         // workgroups of the resident kernel the device holds at once (-1: not asked yet)
+    int resident_cap_sharded = -1;                 // the same for the instantiation that takes ghost records in-launch
     bool peers_valid = false;
     // missions on the device (mgx_mission_*): host copies of what mgx_mission_set gave, the device arrays, the
     // host-mapped event list of robots that reached their last waypoint, and the tick counter
@@ -423,6 +424,16 @@ struct mgx_world {
         DevBuf<unsigned long long> dst[2], peer_flags, ready;  // ready: the exchange workgroup 0 of the wait kernel has announced
         DevBuf<unsigned int> done;
     } direct;
+    // resident schedule launches of a sharded world (mgx_halo_resident_*): this rank's ghost area (fine-grained; the ghosts'
+    // owner ranks store into it from inside their launches) and where the records of this rank's boundary robots go
+    struct ResidentHalo {
+        void *area = nullptr;
+        size_t bytes = 0;
+        int n_ghosts = 0;
+        bool connected = false;
+        DevBuf<int32_t> xp_ptr;
+        DevBuf<XPushRec> xp_rec;
+    } xres;
     // halo exchange through RCCL inside the library (grouped ncclSend / ncclRecv on the world's stream)
     struct RcclHalo {
         void *comm = nullptr;
@@ -936,6 +947,9 @@ static int retopo(mgx_world *w) {
     DevWorld &d = w->d;
     d.NI = (int)NIs;
     d.ir_rec = w->ir_rec.p; d.ir_fv_eta = w->ir_fv_eta.p; d.ir_fv_lam = w->ir_fv_lam.p; d.ir_bmu = w->ir_bmu.p;
+    // the resident kernel's LDS per workgroup (hence workgroups per CU) follows the largest number of edges on one robot:
+    // a capacity asked for a sparser topology says nothing about this one
+    if (t.ir_max_edges != d.ir_max_edges) w->resident_cap = w->resident_cap_sharded = -1;
     d.ir_max_edges = t.ir_max_edges;
     for (IrConn &c : w->conns) c.dev_slot = -1;
     for (size_t g = 0; g < n_slots; g++) {
@@ -1159,7 +1173,9 @@ static int commit(mgx_world *w) {
     w->peers_valid = false;
     w->sweep_flag_buf.n = 0;  // progress words of resident launches: re-created (zero) for the new device arrays
     w->flag_base = 0;
-    w->resident_cap = -1;
+    w->resident_cap = w->resident_cap_sharded = -1;
+    w->xres.connected = false;  // ghost slots and progress words belonged to the old layout: the ranks wire them again
+    d.gsnap[0] = d.gsnap[1] = nullptr; d.gepoch[0] = d.gepoch[1] = nullptr; d.gflag = nullptr; d.xp_ptr = nullptr; d.xp_rec = nullptr;
     if (!w->sweep_err_host) {  // the word device code reports a wait that gave up in (resident launches, direct halo waits)
         HIP_TRY(hipHostMalloc((void **)&w->sweep_err_host, sizeof(unsigned long long), hipHostMallocMapped));
         *w->sweep_err_host = 0ull;
@@ -1293,14 +1309,19 @@ static int ensure_resident_tables(mgx_world *w) {
         w->flag_base = 0;
     }
     if (!w->peers_valid) {
+        // (lists of the LOCAL robots; a ghost — device index >= R — appears in them as a peer, its word lives in the ghost area)
         std::vector<int32_t> ptr(R + 1, 0);
-        for (const IrConn &c : w->conns) { ptr[(size_t)w->dev_of[(size_t)c.owner] + 1]++; ptr[(size_t)w->dev_of[(size_t)c.other] + 1]++; }
+        for (const IrConn &c : w->conns) {
+            const size_t o = (size_t)w->dev_of[(size_t)c.owner], t = (size_t)w->dev_of[(size_t)c.other];
+            if (o < R) ptr[o + 1]++;
+            if (t < R) ptr[t + 1]++;
+        }
         for (size_t r = 0; r < R; r++) ptr[r + 1] += ptr[r];
         std::vector<int32_t> idx((size_t)ptr[R]), fill(ptr.begin(), ptr.end() - 1);
         for (const IrConn &c : w->conns) {
             const int o = w->dev_of[(size_t)c.owner], t = w->dev_of[(size_t)c.other];
-            idx[(size_t)fill[(size_t)o]++] = t;
-            idx[(size_t)fill[(size_t)t]++] = o;
+            if ((size_t)o < R) idx[(size_t)fill[(size_t)o]++] = t;
+            if ((size_t)t < R) idx[(size_t)fill[(size_t)t]++] = o;
         }
         std::vector<int32_t> uptr(R + 1, 0), uidx;
         uidx.reserve(idx.size());
@@ -1338,15 +1359,27 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
     const DevWorld &d = w->d;
-    if (d.R_total != d.R_local || d.ir_max_edges == 0 || w->conns.empty() || !(w->p.enable_mask & 2u)) return 0;
-    if (w->thaw_kinds || w->ir_thaw_active || w->n_keyless > 0 || w->direct.connected || w->rccl.connected) return 0;
-    if (sweep_lds_bytes(w->K, d.ir_max_edges, true) > sweep_resident_lds_max()) return 0;
+    // a sharded world: the ranks have agreed (mgx_halo_resident_connect) that ghost records travel inside the launches
+    const bool sharded = w->xres.connected;
+    if ((d.R_total != d.R_local && !sharded) || d.ir_max_edges == 0 || w->conns.empty() || !(w->p.enable_mask & 2u)) return 0;
+    if (w->thaw_kinds || w->ir_thaw_active || w->n_keyless > 0 || ((w->direct.connected || w->rccl.connected) && !sharded)) return 0;
     for (const Launch &l : plan)
         if (l.n_int > 255) return 0;
-    if (w->resident_cap < 0) w->resident_cap = sweep_resident_capacity(d);
-    if (d.R_local > w->resident_cap) return 0;
+    if (sharded && plan[0].ext && !w->direct.connected) return 0;  // the exchange in front of the launch is the direct one
+    // (so far every rank of a sharded world decides alike: same schedule, same world-wide switches; what follows is this rank's own)
+    if (sweep_lds_bytes(w->K, d.ir_max_edges, true) > sweep_resident_lds_max())
+        return sharded ? fail(MGX_ERR_STATE, "resident launches were agreed on with the other ranks, but this rank's robots no longer fit LDS") : 0;
+    int &cap = sharded ? w->resident_cap_sharded : w->resident_cap;
+    if (cap < 0) cap = sweep_resident_capacity(d, sharded);
+    if (d.R_local > cap)
+        return sharded ? fail(MGX_ERR_STATE, "resident launches were agreed on with the other ranks, but only %d of this rank's %d workgroups "
+                                             "are resident at once", cap, d.R_local) : 0;
     rc = ensure_resident_tables(w);
     if (rc != MGX_OK) return rc;
+    if (sharded && plan[0].ext) {  // segment 0 reads the ghosts' plain copies: one direct exchange in front of the launch
+        rc = direct_exchange(w);
+        if (rc != MGX_OK) return rc;
+    }
     static const long long timeout_ticks = [] {
         const char *e = getenv("MGX_RESIDENT_TIMEOUT_MS");
         const long long ms = e ? atoll(e) : 2000;
@@ -1363,7 +1396,7 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
         }
         sp.flag_base = w->flag_base;
         sp.timeout_ticks = timeout_ticks;
-        HIP_TRY(launch_robot_schedule(w->d, w->d.R_local, sp, w->stream));
+        HIP_TRY(launch_robot_schedule(w->d, w->d.R_local, sp, sharded, false, w->stream));
         w->last_sweep_launches++;
         w->d.upd = nullptr;  // mgx_tick's prior updates ride in the first launch only
         w->d.cur = (w->d.cur + sp.n) & 1;
@@ -1408,6 +1441,7 @@ int mgx_world_destroy(mgx_world *w) {
     if (w->rccl.comm && g_rccl.ok) (void)g_rccl.comm_destroy(w->rccl.comm);
     if (w->direct.recv) (void)hipFree(w->direct.recv);
     if (w->direct.flags) (void)hipFree(w->direct.flags);
+    if (w->xres.area) (void)hipFree(w->xres.area);
     if (w->sweep_err_host) (void)hipHostFree(w->sweep_err_host);
     if (w->mission.ev_host) (void)hipHostFree(w->mission.ev_host);
     if (w->mission.tr_host) (void)hipHostFree(w->mission.tr_host);
@@ -2488,9 +2522,11 @@ int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *wayp
 //                               restarts with the count.
 // A rare call (the reference makes it when a global path has been found, robot.rs:700-790): the device state is pulled,
 // edited on the host mirror and laid out again by the next launch.
-int mgx_reset_variables(mgx_world *w, int32_t robot, const double *means, double first_last_sigma, double inbetween_sigma) {
+int mgx_reset_variables(mgx_world *w, int32_t robot, const double *means, uint32_t n_means, double first_last_sigma, double inbetween_sigma) {
     if (!w || !means || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
     if (w->robots[(size_t)robot].ghost || w->robots[(size_t)robot].removed) return fail(MGX_ERR_INVALID, "robot %d is not a live local robot", robot);
+    if ((int)n_means != w->robots[(size_t)robot].K)  // factorgraph.rs:1548 asserts variable_indices.len() == means.len()
+        return fail(MGX_ERR_INVALID, "%u means for a graph of %d variables", n_means, w->robots[(size_t)robot].K);
     int rc = pull(w);
     if (rc != MGX_OK) return rc;
     flush_counts(w);
@@ -2923,6 +2959,121 @@ int mgx_halo_direct_disconnect(mgx_world *w) {
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     HIP_TRY(hipStreamSynchronize(w->stream));
     w->direct.connected = false;
+    return MGX_OK;
+}
+
+// ---- resident schedule launches on sharded worlds (include/mgx.h) -----------------------------------------
+// Layout of a ghost area for NG ghost slots of K variables: records of parity 0, records of parity 1 (NG * K * 24 f64
+// each), delivery counts of parity 0 / 1 (NG * K u32 each, padded to 16 bytes), NG progress words.  Both ends compute it.
+namespace {
+struct GhostAreaLayout {
+    size_t snap[2], epoch[2], flag, bytes;
+    GhostAreaLayout(size_t ng, size_t K) {
+        const size_t S = ng * K * SNAP_W * sizeof(double), E = (ng * K * sizeof(uint32_t) + 15) & ~(size_t)15;
+        snap[0] = 0; snap[1] = S;
+        epoch[0] = 2 * S; epoch[1] = 2 * S + E;
+        flag = 2 * S + 2 * E;
+        bytes = flag + std::max<size_t>(ng, 1) * sizeof(unsigned long long);
+    }
+};
+}  // namespace
+
+int mgx_halo_resident_setup(mgx_world *w, void **area_base, uint32_t *n_ghost_slots, uint32_t *parity, uint64_t *segment_count,
+                            int32_t *recv_slots, int32_t *eligible) {
+    if (!w || !area_base || !n_ghost_slots || !parity || !segment_count || !eligible) return fail(MGX_ERR_INVALID, "null argument");
+    int rc = halo_commit(w);
+    if (rc != MGX_OK) return rc;
+    if (w->conns_dirty || w->flags_dirty) { rc = commit(w); if (rc != MGX_OK) return rc; }
+    if (!w->halo_recv.empty() && !recv_slots) return fail(MGX_ERR_INVALID, "null argument");
+    mgx_world::ResidentHalo &xr = w->xres;
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    xr.connected = false;
+    if (xr.area) { (void)hipFree(xr.area); xr.area = nullptr; }
+    const DevWorld &d = w->d;
+    const int NG = d.R_total - d.R_local;
+    // can this rank run its schedules as resident launches at all?
+    bool ok = resident_enabled() && d.ir_max_edges > 0 && !w->conns.empty() && (w->p.enable_mask & 2u) &&
+              sweep_lds_bytes(w->K, d.ir_max_edges, true) <= sweep_resident_lds_max();
+    if (ok) {
+        if (w->resident_cap_sharded < 0) w->resident_cap_sharded = sweep_resident_capacity(d, true);
+        ok = d.R_local <= w->resident_cap_sharded;
+    }
+    rc = ensure_resident_tables(w);  // settles this rank's segment count (progress words are created here)
+    if (rc != MGX_OK) return rc;
+    const GhostAreaLayout L((size_t)NG, (size_t)w->K);
+    // fine-grained: coherent with stores arriving from other GPUs / processes while kernels run
+    HIP_TRY(hipExtMallocWithFlags(&xr.area, L.bytes, hipDeviceMallocFinegrained));
+    xr.bytes = L.bytes;
+    xr.n_ghosts = NG;
+    HIP_TRY(hipMemsetAsync(xr.area, 0, L.bytes, w->stream));
+    {   // every ghost "has completed" what this rank's segment count says: nothing of an earlier launch is still being read
+        std::vector<unsigned long long> f((size_t)std::max(NG, 1), w->flag_base);
+        HIP_TRY(hipMemcpyAsync((char *)xr.area + L.flag, f.data(), sizeof(unsigned long long) * f.size(), hipMemcpyHostToDevice, w->stream));
+        HIP_TRY(hipStreamSynchronize(w->stream));
+    }
+    for (size_t i = 0; i < w->halo_recv.size(); i++) recv_slots[i] = w->dev_of[(size_t)w->halo_recv[i]] - d.R_local;
+    *area_base = xr.area;
+    *n_ghost_slots = (uint32_t)NG;
+    *parity = (uint32_t)d.cur;
+    *segment_count = w->flag_base;
+    *eligible = ok ? 1 : 0;
+    return MGX_OK;
+}
+
+int mgx_halo_resident_connect(mgx_world *w, uint32_t n_targets, const int32_t *robots, void *const *peer_area_base,
+                              const uint32_t *peer_ghost_slots, const uint32_t *peer_slot, const uint32_t *peer_parity,
+                              const uint64_t *peer_segment_count) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    if (n_targets && (!robots || !peer_area_base || !peer_ghost_slots || !peer_slot || !peer_parity || !peer_segment_count))
+        return fail(MGX_ERR_INVALID, "null argument");
+    mgx_world::ResidentHalo &xr = w->xres;
+    if (!xr.area) return fail(MGX_ERR_STATE, "mgx_halo_resident_setup first");
+    if (!w->dev_valid || w->dirty) return fail(MGX_ERR_STATE, "the world's layout changed since mgx_halo_resident_setup");
+    DevWorld &d = w->d;
+    const size_t R = (size_t)d.R_local, K = (size_t)w->K;
+    std::vector<std::pair<int, XPushRec>> recs;
+    recs.reserve(n_targets);
+    for (uint32_t t = 0; t < n_targets; t++) {
+        if (robots[t] < 0 || (size_t)robots[t] >= w->robots.size() || w->robots[(size_t)robots[t]].ghost)
+            return fail(MGX_ERR_INVALID, "target %u: robot %d is not a local robot", t, robots[t]);
+        if (!peer_area_base[t] || peer_slot[t] >= peer_ghost_slots[t] || peer_parity[t] > 1u)
+            return fail(MGX_ERR_INVALID, "target %u: bad area / slot / parity", t);
+        const GhostAreaLayout L((size_t)peer_ghost_slots[t], K);
+        const unsigned long long base = (unsigned long long)(uintptr_t)peer_area_base[t];
+        const unsigned x = ((unsigned)d.cur ^ peer_parity[t]) & 1u;  // this rank's parity p is the consumer's p ^ x (both flip together)
+        XPushRec r;
+        for (unsigned p = 0; p < 2; p++) {
+            r.snap[p] = base + L.snap[p ^ x] + (size_t)peer_slot[t] * K * SNAP_W * sizeof(double);
+            r.epoch[p] = base + L.epoch[p ^ x] + (size_t)peer_slot[t] * K * sizeof(uint32_t);
+        }
+        r.flag = base + L.flag + (size_t)peer_slot[t] * sizeof(unsigned long long);
+        r.flag_delta = peer_segment_count[t] - w->flag_base;  // modulo 2^64
+        recs.emplace_back(w->dev_of[(size_t)robots[t]], r);
+    }
+    std::stable_sort(recs.begin(), recs.end(), [](const std::pair<int, XPushRec> &a, const std::pair<int, XPushRec> &b) { return a.first < b.first; });
+    std::vector<int32_t> ptr(R + 1, 0);
+    std::vector<XPushRec> flat(std::max<size_t>(recs.size(), 1));
+    for (size_t i = 0; i < recs.size(); i++) { ptr[(size_t)recs[i].first + 1]++; flat[i] = recs[i].second; }
+    for (size_t r = 0; r < R; r++) ptr[r + 1] += ptr[r];
+    HIP_TRY(xr.xp_ptr.upload(ptr, w->stream));
+    HIP_TRY(xr.xp_rec.upload(flat, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    const GhostAreaLayout Lm((size_t)xr.n_ghosts, K);
+    for (int p = 0; p < 2; p++) {
+        d.gsnap[p] = (const double *)((const char *)xr.area + Lm.snap[p]);
+        d.gepoch[p] = (const uint32_t *)((const char *)xr.area + Lm.epoch[p]);
+    }
+    d.gflag = (const unsigned long long *)((const char *)xr.area + Lm.flag);
+    d.xp_ptr = xr.xp_ptr.p;
+    d.xp_rec = xr.xp_rec.p;
+    xr.connected = true;
+    return MGX_OK;
+}
+
+int mgx_halo_resident_disconnect(mgx_world *w) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    w->xres.connected = false;
     return MGX_OK;
 }
 

@@ -129,18 +129,22 @@ class DeviceDriver:
         self._alive = np.ones(n_robots, dtype=bool)
 
     def tick(self):
-        ant = None
-        if self.failure_draws is not None:
-            # the reference draws one value per robot alive AFTER this tick's despawns, in id order (robot.rs:1599):
-            # the draws are indexed by position in that list, which only the tick itself knows — so the caller's
-            # stream is consumed against the alive set as of the last tick minus what completes now; with despawning
-            # off (the only use so far) the set never changes
+        if self.failure_draws is None:
+            self.next_number, created, deleted, finished = self.w.mission_tick(
+                self.comms_radius, self.next_number, self.steps, self.max_speed, self.delta_t, despawn_finished=self.despawn, antennas=None)
+        else:
+            # the reference draws one value per robot alive AFTER this tick's despawns, in id order (robot.rs:1593-1601 runs
+            # behind the despawn of the robots that reached their last waypoint): the tick's first half says who completed,
+            # the draws are made for the robots that are left, the second half applies them (as sim.py does)
+            self.next_number, created, deleted, fin = self.w.mission_tick_begin(self.comms_radius, self.next_number,
+                                                                                despawn_finished=self.despawn)
+            if self.despawn and len(fin):
+                self._alive[np.asarray(fin, dtype=np.int64)] = False
             live = np.nonzero(self._alive)[0]
             d = np.asarray(self.failure_draws(self.tick_no, len(live)), dtype=np.uint8)
             ant = np.ones(self.n, dtype=np.uint8)
             ant[live] = d
-        self.next_number, created, deleted, finished = self.w.mission_tick(
-            self.comms_radius, self.next_number, self.steps, self.max_speed, self.delta_t, despawn_finished=self.despawn, antennas=ant)
+            self.w.mission_tick_end(self.steps, self.max_speed, self.delta_t, antennas=ant)
         self.tick_no += 1
         self._finished_dirty = True
         return created, deleted

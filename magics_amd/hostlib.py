@@ -153,10 +153,14 @@ SYMBOLS = {
     "mgx_halo_direct_exchange": (C.c_int, [_V, C.c_uint32]),
     "mgx_halo_direct_status": (C.c_int, [_V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mgx_halo_direct_disconnect": (C.c_int, [_V]),
+    "mgx_halo_resident_setup": (C.c_int, [_V, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                          C.c_void_p, C.POINTER(C.c_int32)]),
+    "mgx_halo_resident_connect": (C.c_int, [_V, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgx_halo_resident_disconnect": (C.c_int, [_V]),
     "mgx_ipc_export": (C.c_int, [C.c_void_p, C.c_char_p]),
     "mgx_ipc_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "mgx_ipc_close": (C.c_int, [C.c_void_p]),
-    "mgx_reset_variables": (C.c_int, [_V, C.c_int32, c_double_p, C.c_double, C.c_double]),
+    "mgx_reset_variables": (C.c_int, [_V, C.c_int32, c_double_p, C.c_uint32, C.c_double, C.c_double]),
     "mgx_reset_tracking_factors": (C.c_int, [_V, C.c_int32]),
     "mgx_mission_set": (C.c_int, [_V, C.c_int32, C.c_void_p]),
     "mgx_mission_tick": (C.c_int, [_V, C.c_float, C.c_uint32, C.POINTER(C.c_uint64), C.c_int32, C.c_void_p, C.c_double, C.c_double,

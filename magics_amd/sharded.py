@@ -291,8 +291,46 @@ class ShardedWorld:
         self.world.halo_direct_connect(first, base, nrec, off, slot)
         self.direct = True
 
+    # -- resident schedule launches: ghost records travel INSIDE the launches ---------------------------
+    def resident_setup(self, export_ipc):
+        """Allocate this rank's ghost area (after the direct exchange is wired); returns what the peers need to know:
+        where it is, how many ghost slots it has, the slot of every robot this rank receives, this rank's buffer parity
+        and segment count, and whether this rank can run resident launches at all (the ranks go all or none)."""
+        plan = self.plan
+        flat = [g for l in plan.recv_lists for g in l]
+        area, ng, par, seg, slots, ok = self.world.halo_resident_setup(len(flat))
+        info = dict(rank=plan.rank, n_ghosts=ng, parity=par, segments=seg, eligible=ok, slots=dict(zip(flat, slots)))
+        if export_ipc:
+            info["area_handle"] = hostlib.ipc_export(area)
+        else:
+            info["area_ptr"] = area
+        return info
+
+    def resident_connect(self, infos):
+        """infos[q]: what rank q published in resident_setup (handles are opened here)."""
+        plan = self.plan
+        self._opened = getattr(self, "_opened", [])
+        robots, area, ngs, slot, par, seg = [], [], [], [], [], []
+        for q in range(plan.world_size):
+            if not plan.send_lists[q]:
+                continue
+            inf = infos[q]
+            if "area_ptr" in inf:
+                a = inf["area_ptr"]
+            else:
+                a = hostlib.ipc_open(inf["area_handle"])
+                self._opened.append(a)
+            for g in plan.send_lists[q]:
+                robots.append(self.lid[g]); area.append(a); ngs.append(inf["n_ghosts"]); slot.append(inf["slots"][g])
+                par.append(inf["parity"]); seg.append(inf["segments"])
+        self.world.halo_resident_connect(robots, area, ngs, slot, par, seg)
+        self.resident = True
+
     def direct_close(self):
         """Call on every rank, after a barrier: nobody may still be pushing into a closed area."""
+        if getattr(self, "resident", False):
+            self.world.halo_resident_disconnect()
+            self.resident = False
         if getattr(self, "rccl", False):
             self.world.halo_rccl_disconnect()
             self.direct = self.rccl = False
@@ -420,11 +458,41 @@ def connect_direct(sw, comm):
     comm.barrier()
 
 
-def connect(sw, comm, transport="auto"):
+def _connect_resident(sw, comm, all_ok):
+    """On top of a wired direct exchange: the ghost areas for resident schedule launches.  Every rank reports whether it can
+    run them; only if ALL can (and all succeed in mapping their consumers' areas) are they switched on — a rank that ran
+    resident launches next to one that did not would wait for records that never come."""
+    info = None
+    try:
+        info = sw.resident_setup(export_ipc=True)
+    except Exception:  # noqa: BLE001
+        info = None
+    infos = comm.all_gather_object(info)
+    if any(i is None or not i["eligible"] for i in infos):
+        return False
+    try:
+        sw.resident_connect({i["rank"]: i for i in infos})
+        ok = True
+    except Exception:  # noqa: BLE001
+        ok = False
+    if all_ok(ok):
+        comm.barrier()
+        sw.transport = "direct+resident"
+        return True
+    if ok:
+        sw.world.halo_resident_disconnect()
+        sw.resident = False
+    comm.barrier()
+    return False
+
+
+def connect(sw, comm, transport="auto", resident=True):
     """Wire the exchange of a multi-process sharded world, in-engine transports first (one C call per tick, no host
     work per exchange): "direct" (peer-mapped stores through hipIpc) -> "rccl" (grouped ncclSend / ncclRecv enqueued by
     the engine) -> "collective" (pack / all_to_all_single / unpack driven from the host: the fallback that only needs
-    `comm`).  Collective: every rank calls it with the same arguments; after every step the ranks agree on whether ALL
+    `comm`).  With "direct" wired and `resident`, the ranks then try to agree on resident schedule launches ("direct+resident":
+    ghost records and progress words travel inside ONE launch per schedule and rank, include/mgx.h).
+    Collective: every rank calls it with the same arguments; after every step the ranks agree on whether ALL
     of them succeeded, so a failure on one rank moves every rank to the next transport instead of leaving the others
     waiting.  Returns the transport in use (also `sw.transport`)."""
     if sw.plan.world_size == 1 or comm is None:
@@ -447,6 +515,8 @@ def connect(sw, comm, transport="auto"):
                     err = e
                 infos = comm.all_gather_object(info)
                 if any(i is None for i in infos):
+                    comm.barrier()
+                    sw.direct_close()  # the ranks whose set-up succeeded free their areas (nobody has mapped them yet)
                     continue
                 try:
                     sw.direct_connect({i["rank"]: i for i in infos})
@@ -456,6 +526,8 @@ def connect(sw, comm, transport="auto"):
                 if all_ok(ok):
                     comm.barrier()
                     sw.transport = "direct"
+                    if resident:
+                        _connect_resident(sw, comm, all_ok)
                     return sw.transport
                 comm.barrier()
                 sw.direct_close()
@@ -525,7 +597,7 @@ class LocalCluster:
     """All ranks of a sharded world inside ONE process (one GPU): used by the tests to check the
     ghost / halo numerics against the unsharded world without a multi-GPU node."""
 
-    def __init__(self, sc, world_size, world_factory, owner=None, tensor_factory=None, direct=False, dynamic=False):
+    def __init__(self, sc, world_size, world_factory, owner=None, tensor_factory=None, direct=False, dynamic=False, resident=False):
         """direct=True: the ranks exchange through peer-mapped stores (same address space, no IPC);
         `world_factory` must then give every rank its OWN stream — a rank's wait kernel would block
         a shared stream before the other rank's stores are even enqueued.
@@ -535,10 +607,21 @@ class LocalCluster:
         self.ranks = [ShardedWorld(sc, r, world_size, world_factory, comm=None, owner=owner,
                                    tensor_factory=tensor_factory, dynamic=dynamic) for r in range(world_size)]
         self.n_robots, self.K = len(sc["robots"]), sc.get("K")
+        self.resident = False
         if direct and world_size > 1:
             infos = {sw.plan.rank: sw.direct_setup(export_ipc=False) for sw in self.ranks}
             for sw in self.ranks:
                 sw.direct_connect(infos)
+            if resident:
+                # resident=True: every rank's workgroups have to be on the device TOGETHER (each rank a stream of its own on
+                # a hardware queue of its own, and all ranks' robots within the device's resident slots)
+                for sw in self.ranks:
+                    sw.world.sweep(0, 0, 0)
+                infos = {sw.plan.rank: sw.resident_setup(export_ipc=False) for sw in self.ranks}
+                if all(i["eligible"] for i in infos.values()):
+                    for sw in self.ranks:
+                        sw.resident_connect(infos)
+                    self.resident = True
 
     def _exchange(self):
         for sw in self.ranks:
@@ -560,6 +643,13 @@ class LocalCluster:
 
     def iterate(self, steps):
         segs = segments(steps)
+        if self.resident and len(segs) >= 2:
+            if segs[0][0]:  # a schedule that opens with an external iteration: its exchange, all pushes first
+                for sw in self.ranks:
+                    sw.world.halo_direct_exchange(hostlib.HALO_PUSH)
+            for sw in self.ranks:  # one launch per rank, each on its own stream: they run side by side
+                sw.world.iterate(steps)
+            return
         for k, (ext, n_int) in enumerate(segs):
             if ext and len(self.ranks) > 1:
                 if self.ranks[0].direct:

@@ -186,8 +186,8 @@ class World:
 
     def reset_variables(self, robot, means, first_last_sigma=1e30, inbetween_sigma=float("inf")):
         """FactorGraph::reset_variables (factorgraph.rs:1541-1564); the defaults are the reference's call (robot.rs:768)."""
-        m = _f64(means)
-        self._chk(self._L.mgx_reset_variables(self._w, robot, _dp(m), float(first_last_sigma), float(inbetween_sigma)))
+        m = _f64(means).reshape(-1, 4)
+        self._chk(self._L.mgx_reset_variables(self._w, robot, _dp(m), len(m), float(first_last_sigma), float(inbetween_sigma)))
 
     def reset_tracking_factors(self, robot):
         """FactorGraph::reset_tracking_factors (factorgraph.rs:1566-1590)."""
@@ -366,6 +366,30 @@ class World:
 
     def halo_direct_disconnect(self):
         self._chk(self._L.mgx_halo_direct_disconnect(self._w))
+
+    # resident schedule launches on sharded worlds (ghost records travel inside the launches; see include/mgx.h)
+    def halo_resident_setup(self, n_recv):
+        """Allocates this rank's ghost area.  Returns (area address, ghost slots, parity, segment count, slot of every entry of
+        the receive list, eligible)."""
+        area, ng, par, seg, ok = C.c_void_p(), C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_int32()
+        slots = np.zeros(max(int(n_recv), 1), dtype=np.int32)
+        self._chk(self._L.mgx_halo_resident_setup(self._w, C.byref(area), C.byref(ng), C.byref(par), C.byref(seg), slots.ctypes.data, C.byref(ok)))
+        return area.value, ng.value, par.value, seg.value, slots[:n_recv].tolist(), bool(ok.value)
+
+    def halo_resident_connect(self, robots, peer_area, peer_ghost_slots, peer_slot, peer_parity, peer_segment_count):
+        n = len(robots)
+        a = np.ascontiguousarray(robots, dtype=np.int32)
+        b = np.ascontiguousarray(peer_area, dtype=np.uint64)
+        c = np.ascontiguousarray(peer_ghost_slots, dtype=np.uint32)
+        d = np.ascontiguousarray(peer_slot, dtype=np.uint32)
+        e = np.ascontiguousarray(peer_parity, dtype=np.uint32)
+        f = np.ascontiguousarray(peer_segment_count, dtype=np.uint64)
+        assert b.size == c.size == d.size == e.size == f.size == n
+        self._chk(self._L.mgx_halo_resident_connect(self._w, n, a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, e.ctypes.data,
+                                                    f.ctypes.data))
+
+    def halo_resident_disconnect(self):
+        self._chk(self._L.mgx_halo_resident_disconnect(self._w))
 
     def halo_plan(self, send_robots, recv_ghosts):
         a = np.ascontiguousarray(send_robots, dtype=np.int32)

@@ -195,7 +195,11 @@ impl FactorGraph {
     /// `FactorGraph::reset_variables(&means, first_last_sigma, inbetween_sigma)` (factorgraph.rs:1541-1564); the
     /// reference's call is `(means, 1e30, Float::INFINITY)` (robot.rs:768)
     pub fn reset_variables(&mut self, means: &[[f64; 4]], first_last_sigma: f64, inbetween_sigma: f64) -> Result<(), MgxError> {
-        check(unsafe { sys::mgx_reset_variables(self.world.raw, self.robot, means.as_ptr().cast(), first_last_sigma, inbetween_sigma) })
+        // the slice's length travels with it: the library rejects a count that is not the graph's number of variables
+        // (the reference asserts it, factorgraph.rs:1548), so a short slice is an error, never an out-of-bounds read
+        check(unsafe {
+            sys::mgx_reset_variables(self.world.raw, self.robot, means.as_ptr().cast(), means.len() as u32, first_last_sigma, inbetween_sigma)
+        })
     }
     /// `FactorGraph::reset_tracking_factors` (factorgraph.rs:1566-1590)
     pub fn reset_tracking_factors(&mut self) -> Result<(), MgxError> {

@@ -124,7 +124,7 @@ extern "C" {
     pub fn mgx_external_variable_iteration(w: *mut mgx_world, robot: i32) -> c_int;
     pub fn mgx_change_prior(w: *mut mgx_world, robot: i32, var_ix: u32, mean: *const f64) -> c_int;
     pub fn mgx_change_priors(w: *mut mgx_world, n: u32, robots: *const i32, var_ix: *const u32, means: *const f64) -> c_int;
-    pub fn mgx_reset_variables(w: *mut mgx_world, robot: i32, means: *const f64, first_last_sigma: f64, inbetween_sigma: f64) -> c_int;
+    pub fn mgx_reset_variables(w: *mut mgx_world, robot: i32, means: *const f64, n_means: u32, first_last_sigma: f64, inbetween_sigma: f64) -> c_int;
     pub fn mgx_reset_tracking_factors(w: *mut mgx_world, robot: i32) -> c_int;
     pub fn mgx_update_priors(w: *mut mgx_world, n: u32, robots: *const i32, waypoints_xy: *const f64, time_scale: *const f64, what: *const u8, max_speed: f64, delta_t: f64) -> c_int;
     pub fn mgx_tick(w: *mut mgx_world, n: u32, robots: *const i32, waypoints_xy: *const f64, time_scale: *const f64, what: *const u8, max_speed: f64, delta_t: f64, steps: *const u8, n_steps: u32) -> c_int;
@@ -160,6 +160,9 @@ extern "C" {
     pub fn mgx_halo_direct_exchange(w: *mut mgx_world, what: u32) -> c_int;
     pub fn mgx_halo_direct_status(w: *mut mgx_world, exchanges: *mut u64, failed_exchange: *mut u64) -> c_int;
     pub fn mgx_halo_direct_disconnect(w: *mut mgx_world) -> c_int;
+    pub fn mgx_halo_resident_setup(w: *mut mgx_world, area_base: *mut *mut c_void, n_ghost_slots: *mut u32, parity: *mut u32, segment_count: *mut u64, recv_slots: *mut i32, eligible: *mut i32) -> c_int;
+    pub fn mgx_halo_resident_connect(w: *mut mgx_world, n_targets: u32, robots: *const i32, peer_area_base: *const *mut c_void, peer_ghost_slots: *const u32, peer_slot: *const u32, peer_parity: *const u32, peer_segment_count: *const u64) -> c_int;
+    pub fn mgx_halo_resident_disconnect(w: *mut mgx_world) -> c_int;
     pub fn mgx_ipc_export(dev_ptr: *const c_void, handle: *mut u8) -> c_int;
     pub fn mgx_ipc_open(handle: *const u8, dev_ptr: *mut *mut c_void) -> c_int;
     pub fn mgx_ipc_close(dev_ptr: *mut c_void) -> c_int;

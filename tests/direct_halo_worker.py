@@ -1,6 +1,7 @@
 """One rank of the multi-process direct-halo test (tests/test_gpu_direct_halo_mp.py): every rank
 is its own process on cuda:0, the control plane is gloo, the data plane is hipIpc-mapped
-peer stores.  usage: direct_halo_worker.py RANK WORLD_SIZE PORT OUT.npz"""
+peer stores.  usage: direct_halo_worker.py RANK WORLD_SIZE PORT OUT.npz [direct | direct+resident]
+(direct+resident: the ghost records travel inside ONE resident launch per schedule and rank)"""
 import os
 import sys
 
@@ -10,6 +11,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, ws, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    mode = sys.argv[5] if len(sys.argv) > 5 else "direct"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(ws))
     import numpy as np
     import torch
@@ -20,7 +22,8 @@ def main():
     sc = S.grid_scenario(64, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
     comm = sharded.TorchDistComm()
     sw = sharded.ShardedWorld(sc, rank, ws, World, comm=comm)
-    assert sharded.connect(sw, comm) == "direct"  # the default wiring: in-engine transports first
+    got = sharded.connect(sw, comm, resident=mode == "direct+resident")  # the default wiring: in-engine transports first
+    assert got == mode, got
     steps = sc["steps"] + [1, 1, 2, 3, 2]
     boundary = sorted({g for r in range(ws) for g in sharded.ShardPlan(sc, r, ws).ghosts})
     for tick in range(3):
@@ -30,9 +33,10 @@ def main():
         if tick == 2:
             sw.set_antenna(boundary[0], True)
         sw.iterate(steps)
+    launches = sw.world.last_launch_count()
     ids, eta, lam, mu = sw.read_beliefs()
     n = sw.world.halo_direct_status()
-    np.savez(out, ids=np.array(ids), eta=eta, lam=lam, mu=mu, n=n)
+    np.savez(out, ids=np.array(ids), eta=eta, lam=lam, mu=mu, n=n, launches=launches)
     dist.barrier()
     sw.direct_close()
     dist.destroy_process_group()

@@ -23,12 +23,14 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-@pytest.mark.parametrize("world_size", [2, 3])
-def test_ranks_in_separate_processes(world_size, tmp_path):
+@pytest.mark.parametrize("world_size,mode", [(2, "direct"), (3, "direct"), (2, "direct+resident"), (3, "direct+resident")])
+def test_ranks_in_separate_processes(world_size, mode, tmp_path):
+    """mode "direct+resident": every rank's schedule is ONE resident launch and the ghost records cross the process
+    boundary inside it (hipIpc-mapped ghost areas, system-scope stores and polls)."""
     port = _free_port()
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(world_size)]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MGX_HALO_TIMEOUT_MS="20000")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "direct_halo_worker.py"), str(r), str(world_size), port, outs[r]],
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MGX_HALO_TIMEOUT_MS="20000", MGX_RESIDENT_TIMEOUT_MS="20000")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "direct_halo_worker.py"), str(r), str(world_size), port, outs[r], mode],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world_size)]
     logs = []
     try:
@@ -55,11 +57,14 @@ def test_ranks_in_separate_processes(world_size, tmp_path):
             ref.set_antenna(boundary[0], True)
         ref.iterate(steps)
     eta_r, lam_r, mu_r = ref.read_beliefs()
-    n_ext = 3 * sum(1 for s in steps if s & 2)
+    # exchanges by the push / wait kernels: one per external iteration — or none at all when the schedule (which opens with an
+    # internal iteration) runs as one resident launch
+    n_ext = 3 * sum(1 for s in steps if s & 2) if mode == "direct" else 0
     seen = 0
     for o in outs:
         d = np.load(o)
         assert int(d["n"]) == n_ext
+        assert int(d["launches"]) == (1 if mode == "direct+resident" else len(sharded.segments(steps)))
         for j, g in enumerate(d["ids"]):
             sl, dl = slice(g * K, (g + 1) * K), slice(j * K, (j + 1) * K)
             assert np.array_equal(d["eta"][dl], eta_r[sl]) and np.array_equal(d["lam"][dl], lam_r[sl]) and np.array_equal(d["mu"][dl], mu_r[sl]), (o, g)

@@ -5,7 +5,7 @@ and through the ten skipped tracking updates that follow."""
 import numpy as np
 import pytest
 
-from magics_amd import scenarios as S
+from magics_amd import World, hostlib, scenarios as S
 from parity import assert_identical, both, make_pair
 
 pytestmark = pytest.mark.gpu
@@ -63,3 +63,16 @@ def test_tracking_timeout_changes_the_result():
         assert all(np.array_equal(x, y, equal_nan=True) for a, b in zip(ce, cr) for x, y in zip(a, b))
         outs.append(ce[1][2])
     assert not np.array_equal(outs[0], outs[1])
+
+
+def test_reset_variables_checks_the_number_of_means():
+    """the reference asserts variable_indices.len() == means.len() (factorgraph.rs:1548): a short list is an error, not a read
+    past its end"""
+    sc = S.grid_scenario(4, 10, interrobot=False)
+    eng = World(sc["params"])
+    S.populate(eng, sc)
+    with pytest.raises(hostlib.MgxError):
+        eng.reset_variables(0, np.zeros((9, 4)))
+    with pytest.raises(hostlib.MgxError):
+        eng.reset_variables(0, np.zeros((11, 4)))
+    eng.reset_variables(0, np.zeros((10, 4)))

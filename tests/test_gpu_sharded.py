@@ -274,3 +274,68 @@ def test_message_counts_on_a_sharded_world():
         both(lambda w: w.tick(steps=sc["steps"], **tick))
         same(f"driver tick {t}")
     assert_identical(cluster, ref, what="sharded world with message counts")
+
+
+# ---- resident schedule launches on sharded worlds: ghost records travel INSIDE the launches -----------------------------
+@pytest.mark.parametrize("world_size,n,K", [(2, 64, 10), (3, 96, 16), (4, 400, 16)])
+def test_resident_launches_on_a_sharded_world(world_size, n, K):
+    """Every rank runs its schedule as ONE launch (mgx_last_launch_count == 1): boundary robots store their snapshot records and
+    progress words straight into the other ranks' ghost areas at the end of every segment, and the workgroups there poll those
+    words like a local neighbour's.  Several ticks (the parities and segment counts carry over), schedules that open with an
+    internal and with an external iteration, and a schedule too short to be resident in between: beliefs of the single-world
+    oracle, bit for bit."""
+    sc = S.grid_scenario(n, K, interrobot=True, pitch=2.5, comm_radius=5.0)
+    make, streams = _own_stream_factory()
+    cluster = sharded.LocalCluster(sc, world_size, make, direct=True, resident=True)
+    assert cluster.resident and all(sw.resident for sw in cluster.ranks)
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    scripts = [sc["steps"], sc["steps"], [2, 3, 3, 1, 3], [3], sc["steps"] + [1, 1, 2, 3, 2], [2, 2, 3]]
+    for tick, steps in enumerate(scripts):
+        cluster.iterate(steps)
+        ref.iterate(steps)
+        for sw in cluster.ranks:
+            sw.synchronize()  # raises if a wait inside a launch gave up
+            want = 1 if len(sharded.segments(steps)) >= 2 else len(sharded.segments(steps))
+            assert sw.world.last_launch_count() == want, (tick, sw.plan.rank, sw.world.last_launch_count())
+        assert_identical(cluster, ref, what=f"resident launches, {world_size} ranks, tick {tick}")
+
+
+def test_resident_sharded_gating_and_prior_changes():
+    sc = S.grid_scenario(36, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
+    make, streams = _own_stream_factory()
+    cluster = sharded.LocalCluster(sc, 3, make, direct=True, resident=True)
+    assert cluster.resident
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    boundary = sorted({g for sw in cluster.ranks for g in sw.plan.ghosts})
+
+    def script(w):
+        w.iterate([3, 3, 3])
+        w.set_antenna(boundary[0], False)
+        w.set_idle(boundary[1], True)
+        w.change_prior(boundary[2], 9, np.array([0.5, 0.25, 1.0, -1.0]))
+        w.iterate([3, 3, 3])
+        w.set_antenna(boundary[0], True)
+        w.set_idle(boundary[1], False)
+        w.iterate([3, 3])
+        w.iterate([2, 3, 3])
+    script(cluster)
+    script(ref)
+    for sw in cluster.ranks:
+        sw.synchronize()
+    assert_identical(cluster, ref, what="resident sharded launches, gating + change_prior on boundary robots")
+
+
+def test_resident_sharded_reports_a_missing_rank(monkeypatch):
+    """A rank that never launches its side: the others' workgroups give up after the bound and the world says so."""
+    monkeypatch.setenv("MGX_RESIDENT_TIMEOUT_MS", "300")
+    from magics_amd import hostlib
+    sc = S.grid_scenario(36, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
+    make, streams = _own_stream_factory()
+    cluster = sharded.LocalCluster(sc, 2, make, direct=True, resident=True)
+    assert cluster.resident
+    lonely = cluster.ranks[0]
+    lonely.world.iterate([3, 3, 3])  # rank 1 never runs
+    with pytest.raises(hostlib.MgxError):
+        lonely.synchronize()

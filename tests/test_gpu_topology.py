@@ -258,3 +258,29 @@ def test_full_size_world_with_jittering_positions():
     assert changed > 7000 + 100          # the initial pass plus real churn afterwards
     assert all(eng.connections(r) == ref.connections(r) for r in range(0, 1000, 37))
     assert_identical(eng, ref, what="1000 robots, jittering positions, 4 ticks")
+
+
+def test_resident_capacity_follows_the_topology():
+    """A world that densifies: with 8 neighbours per robot a K = 16 workgroup of the resident kernel takes under 40 KB of LDS (four
+    per CU, 1024 slots) and 900 robots run their schedule as ONE launch; once robots have 20 neighbours the workgroup needs more
+    (three per CU, 768 slots) and the same 900 robots no longer fit — the capacity asked for the sparse topology must not be
+    reused, or the launch waits for workgroups that never become resident (round 2's advisor finding).  The engine has to take
+    the launch-per-segment path by itself: same beliefs as the oracle, no error."""
+    n, K = 900, 16
+    sc = S.grid_scenario(n, K, interrobot=True, comm_radius=0.01)
+    assert not sc["ir"]
+    eng, ref = make_pair(sc)
+    pos = np.array([[rb["pos"][0], 0.5, rb["pos"][1]] for rb in sc["robots"]], dtype=np.float32)
+    nxt = 1
+    launches = []
+    for radius in (8.0, 11.5, 11.5):
+        out_e = eng.update_topology(pos, radius, nxt)
+        out_r = ref.update_topology(pos, radius, nxt)
+        assert out_e == out_r
+        nxt = out_e[0]
+        for w in (eng, ref):
+            w.iterate(sc["steps"])
+        launches.append(eng.last_launch_count())
+        eng.synchronize()  # raises if a wait inside a resident launch gave up
+        assert_identical(eng, ref, what=f"comms radius {radius}")
+    assert launches[0] == 1 and launches[1] == len(sc["steps"]) + 1 and launches[2] == launches[1], launches

@@ -16,12 +16,10 @@ from magics_amd.world import World  # noqa: E402
 out = os.path.join(ROOT, "gpurun_out", "libmgx_stamps.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 import __graft_entry__ as _ge  # noqa: E402
-srcs = [os.path.join(ROOT, "magics_amd", "csrc", f) for f in _ge.SOURCES]
 if os.environ.get("MGX_STAMPS_LIB"):  # a prebuilt -DMGX_STAMPS library (experiments)
     out = os.environ["MGX_STAMPS_LIB"]
 else:
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                    "-DMGX_STAMPS", "-o", out] + srcs, check=True)
+    _ge.build_library(out, ["-ffp-contract=off"], extra_defines=["-DMGX_STAMPS"])
 hostlib.LIB_PATH = out
 hostlib._libs.clear()
 n_iter = 10
