@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s peak, 
 # = half the guide's 157.3 TFLOP/s FP32 vector figure; as an issue rate: one f64 VALU wave-instruction per SIMD per 4 clocks
 F64_VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4.0
 SCHEDULE_LEN = 10
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 
 def parse():
@@ -57,6 +57,7 @@ def parse():
                     help="N > 1 only: seconds a phase with collectives may take before the run is abandoned (non-zero exit)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--fma", action="store_true", help="use the FMA-contracting build (not the product)")
+    ap.add_argument("--no-resident", action="store_true", help="N > 1: keep the direct transport on its push / wait kernels (no resident launches)")
     ap.add_argument("--role", default="main", choices=["main", "direct-child", "rccl-child"],
                     help="*-child: one rank of an isolated measurement of the sharded workload with the exchange inside the "
                          "engine (direct: peer-mapped stores; rccl: grouped ncclSend / ncclRecv), spawned by the main role")
@@ -162,45 +163,74 @@ def cpu_baseline(sc, seconds):
     }
 
 
+def kernel_digest():
+    """content hash of what the sweep kernel is compiled from: a counter profile belongs to ONE such state"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("mgx_sweep.h", "gbp_math.h", "mgx_dev.h", "mgx_sweep_inst.hip"):
+        with open(os.path.join(ROOT, "magics_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:20]
+
+
 def profiled(key):
-    """What rocprofv3 measured for this round's build (profiles/traffic_r02.json, written by tools/profile_round.py from
-    separate --pmc passes of THIS command): HBM bytes per dispatch (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
-    correction + WRITE_SIZE) and the SQ instruction counters.  None when the file or the key is absent."""
+    """What rocprofv3 measured for THIS build of the sweep kernel (profiles/traffic_<tag>.json, written by tools/profile_round.py
+    from separate --pmc passes of this command): HBM bytes per dispatch (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
+    correction + WRITE_SIZE) and the SQ instruction counters.  (None, reason) when there is no such file, no such key, or the
+    file was made from other kernel sources than the ones this library was built from — stale counters are not quoted."""
+    path = os.path.join(ROOT, "profiles", f"traffic_{PROFILE_TAG}.json")
     try:
-        with open(os.path.join(ROOT, "profiles", f"traffic_{PROFILE_TAG}.json")) as f:
-            return json.load(f)[key]
+        with open(path) as f:
+            d = json.load(f)
     except Exception:  # noqa: BLE001
-        return None
+        return None, f"profiles/traffic_{PROFILE_TAG}.json is absent"
+    if d.get("_kernel_digest") != kernel_digest():
+        return None, (f"profiles/traffic_{PROFILE_TAG}.json was measured on other kernel sources (digest {d.get('_kernel_digest')}) than this "
+                      f"build's ({kernel_digest()}): re-run tools/profile_round.sh")
+    if key not in d:
+        return None, f"no counters for '{key}' in profiles/traffic_{PROFILE_TAG}.json"
+    return d[key], ""
 
 
-def roofline(kernel, alg_bytes_per_launch, launches, dev_seconds, prof_key, iterations_per_launch):
-    """The contract's roofline object (algorithmic bytes per launch / live launch duration) plus what makes it
-    physical: HBM bytes actually moved per launch (rocprofv3 PMC, from profiles/) and the f64 VALU issue rate."""
+def roofline(kernel, alg_bytes_per_launch, launches, dev_seconds, prof_key, iterations_per_launch, prof_note=""):
+    """What bounds the dominant kernel, as a FRACTION of a physical peak: the larger of (measured HBM bytes per launch / 8 TB/s)
+    and (measured f64 VALU wave-instructions per launch / one per SIMD per 4 clocks), divided by the live launch duration (HIP
+    events on the launch stream).  The counters come from this round's rocprofv3 --pmc passes of this command (profiles/).
+    `work_rate_contract` keeps SURVEY §8d's figure — algorithmic bytes per launch / launch duration — which is a work rate in the
+    survey's byte model, not a bandwidth: the graphs stay in LDS across the iterations of a launch, so it can exceed the peak."""
     avg = dev_seconds / launches
     ach = alg_bytes_per_launch / avg / 1e9
-    out = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-           "algorithmic_bytes_per_launch": alg_bytes_per_launch, "iterations_per_launch": iterations_per_launch,
-           "avg_launch_us": round(avg * 1e6, 3),
-           "note": "contract figure: SURVEY §8d algorithmic bytes (every live message / belief read and written once per "
-                   "sweep) / live launch duration from HIP events on the launch stream.  The robots' graphs stay in LDS across "
-                   "the iterations of a launch, so most of those bytes never cross HBM and frac can exceed 1: it is a "
-                   "work-rate expressed in the survey's byte model, not a bandwidth.  hbm_measured_* and compute below are "
-                   "the physical picture."}
-    p = profiled(prof_key)
-    if p:
-        traffic = int((2 * p["fetch_kib"] + p["write_kib"]) * 1024)
-        out["traffic"] = traffic
-        out["traffic_source"] = p.get("source", f"profiles/{PROFILE_TAG}_*: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes")
-        out["hbm_measured_gbs"] = round(traffic / avg / 1e9, 1)
-        out["hbm_measured_frac"] = round(traffic / avg / 1e9 / HBM_PEAK_GBS, 4)
-        if p.get("valu_wave_instr"):
-            rate = p["valu_wave_instr"] / avg
-            out["compute"] = {"bound": "f64 VALU issue", "valu_wave_instr_per_launch": p["valu_wave_instr"],
-                              "achieved_wave_instr_per_s": round(rate, 1), "peak_wave_instr_per_s": F64_VALU_WAVE_INSTR_PER_S,
-                              "frac": round(rate / F64_VALU_WAVE_INSTR_PER_S, 4), "valu_busy_pct": p.get("valu_busy_pct"),
-                              "note": "SQ_INSTS_VALU per launch (rocprofv3 --pmc, profiles/) / live launch duration against one f64 "
-                                      "VALU wave-instruction per SIMD per 4 clocks (1024 SIMDs x 2.4 GHz): the kernel's real bound"}
+    out = {"bound": None, "kernel": kernel, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+           "avg_launch_us": round(avg * 1e6, 3), "iterations_per_launch": iterations_per_launch,
+           "work_rate_contract": {"achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                  "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                                  "note": "SURVEY §8d algorithmic bytes (every live message / belief read and written once per sweep) / live "
+                                          "launch duration: a work rate in the survey's byte model, not a bandwidth (state stays in LDS across "
+                                          "the iterations of a launch)"}}
+    p, why = profiled(prof_key) if prof_key else (None, "no counter profile for this shape")
+    if not p:
+        out["note"] = "no physical roofline: " + why
+        return out
+    traffic = int((2 * p["fetch_kib"] + p["write_kib"]) * 1024)
+    t_hbm = traffic / (HBM_PEAK_GBS * 1e9)
+    hbm = {"bytes_per_launch": traffic, "gbs": round(traffic / avg / 1e9, 1), "peak_gbs": HBM_PEAK_GBS, "frac": round(t_hbm / avg, 4),
+           "traffic_over_algorithmic": round(traffic / alg_bytes_per_launch, 4)}
+    out["traffic"] = traffic
+    out["hbm"] = hbm
+    cands = [("hbm", t_hbm, round(traffic / avg / 1e9, 1), HBM_PEAK_GBS, "GB/s")]
+    if p.get("valu_wave_instr"):
+        t_valu = p["valu_wave_instr"] / F64_VALU_WAVE_INSTR_PER_S
+        rate = p["valu_wave_instr"] / avg
+        out["valu"] = {"wave_instr_per_launch": p["valu_wave_instr"], "g_wave_instr_per_s": round(rate / 1e9, 2),
+                       "peak_g_wave_instr_per_s": round(F64_VALU_WAVE_INSTR_PER_S / 1e9, 1), "frac": round(t_valu / avg, 4),
+                       "valu_active_pct_of_wave_cycles": p.get("valu_busy_pct"), "wait_pct_of_wave_cycles": p.get("wait_pct"),
+                       "note": "SQ_INSTS_VALU per launch against one f64 VALU wave-instruction per SIMD per 4 clocks (1024 SIMDs x 2.4 GHz)"}
+        cands.append(("valu-f64-issue", t_valu, round(rate / 1e9, 2), round(F64_VALU_WAVE_INSTR_PER_S / 1e9, 1), "G wave-instr/s"))
+    b = max(cands, key=lambda c: c[1])
+    out.update({"bound": b[0], "achieved": b[2], "peak": b[3], "unit": b[4], "frac": round(b[1] / avg, 4)})
+    out["traffic_source"] = p.get("source", f"profiles/{PROFILE_TAG}_*: rocprofv3 --pmc, separate passes") + (f" — {prof_note}" if prof_note else "")
+    out["note"] = ("frac = max(HBM time of the measured traffic at 8 TB/s, issue time of the measured f64 VALU wave-instructions) / live launch "
+                   "duration; the rest of the launch is latency (dependent phases of one workgroup, hand-offs between neighbours)")
     return out
 
 
@@ -210,6 +240,7 @@ def transport_child(a):
     stores over xGMI + device-side arrival counters, include/mgx.h) or RCCL grouped send / recv enqueued by
     mgx_iterate.  Runs as a child process of each bench rank so that nothing it does can take the collective
     measurement down.  Control plane: gloo."""
+    import numpy as np
     import torch
     import torch.distributed as dist
     rank, world_size = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -225,28 +256,29 @@ def transport_child(a):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return int(t[0]) == 1
 
-    out, sw, err = {}, None, ""
+    out, sw, err, got = {}, None, "", None
     try:
         sc2 = S.grid_scenario(n_tot, K, interrobot=True, seed=805)
         comm = sharded.TorchDistComm()
         sw = sharded.ShardedWorld(sc2, rank, world_size, lambda p: World(p, stream=stream, fma=a.fma), comm=comm)
         sw.world.sweep(0, 0, 0)
-        info = sw.direct_setup(export_ipc=True) if a.role == "direct-child" else None
     except Exception as e:  # noqa: BLE001
         err = f"{type(e).__name__}: {e}"
     if not agree(not err):
         out = {"error": err or "another rank failed to set up"}
     elif a.role == "direct-child":
-        infos = comm.all_gather_object(info)
+        # peer-mapped stores first, and on top of them resident schedule launches (ghost records travel inside ONE launch per
+        # schedule and rank); sharded.connect makes the ranks agree after every step
         try:
-            sw.direct_connect({i["rank"]: i for i in infos})
+            got = sharded.connect(sw, comm, "direct", resident=not a.no_resident)
         except Exception as e:  # noqa: BLE001
             err = f"{type(e).__name__}: {e}"
-        if not agree(not err):
-            out = {"error": err or "another rank failed to map its peers"}
+        if not agree(not err and got is not None and got.startswith("direct")):
+            out = {"error": err or f"the direct transport is not available (got {got})"}
     else:
         try:
             sharded.connect_rccl(sw, comm)  # collective (ncclCommInitRank); a failure on one rank ends in the deadline
+            got = "rccl"
         except Exception as e:  # noqa: BLE001
             err = f"{type(e).__name__}: {e}"
         if not agree(not err):
@@ -254,7 +286,20 @@ def transport_child(a):
     if not out:
         def sync():
             sw.synchronize()  # mgx_synchronize: raises if a wait on the device gave up
+        verified = None
         try:
+            # the same two ticks on a world whose exchange is driven from the host (pack / all-to-all-v over the control plane /
+            # unpack): the in-engine transport has to leave bit-identical beliefs
+            ref = sharded.ShardedWorld(sc2, rank, world_size, lambda p: World(p, stream=stream, fma=a.fma),
+                                       comm=sharded.TorchDistComm(stage_through_host=True))
+            for _ in range(2):
+                sw.iterate(sc2["steps"])
+                ref.iterate(sc2["steps"])
+            sync()
+            ref.synchronize()
+            same = all(np.array_equal(x, y) for x, y in zip(sw.read_beliefs()[1:], ref.read_beliefs()[1:]))
+            verified = agree(same)
+            del ref
             walls, devs = timed(torch, dist, sw.iterate, sc2["steps"], a, True, red_dev="cpu", sync=sync)
         except Exception as e:  # noqa: BLE001
             err = f"{type(e).__name__}: {e}"
@@ -263,10 +308,16 @@ def transport_child(a):
             out = {"error": err or "another rank timed out"}
         else:
             res = summary(walls, devs, a.steps, units_per_step=world_size)
+            sw.iterate(sc2["steps"])
+            n_launch = sw.world.last_launch_count()
             n_ex = sw.world.halo_direct_status() if a.role == "direct-child" else None  # exchanges run; raises if one timed out
-            out = {"value": round(res["value"], 2), "exchanges": n_ex, "ms_per_step": res["ms_per_step"], "device_ms_per_step": res["device_ms_per_step"],
-                   "spread": res["spread"],
-                   "exchange": ("direct: peer-mapped stores into the consumers' receive areas (hipIpc) + device-side arrival "
+            out = {"value": round(res["value"], 2), "transport": got, "verified_against_host_driven_exchange": verified,
+                   "launches_per_tick": n_launch, "exchanges": n_ex, "ms_per_step": res["ms_per_step"],
+                   "device_ms_per_step": res["device_ms_per_step"], "spread": res["spread"],
+                   "exchange": ("direct+resident: ONE launch per schedule and rank; boundary robots store their snapshot records and progress "
+                                "words into the other ranks' peer-mapped ghost areas from inside it (hipIpc, system-scope stores), no exchange "
+                                "kernel, no collective" if got == "direct+resident" else
+                                "direct: peer-mapped stores into the consumers' receive areas (hipIpc) + device-side arrival "
                                 "counters, one C call per tick, no collective") if a.role == "direct-child" else
                                "RCCL inside the engine: grouped ncclSend / ncclRecv per external iteration on the launch stream, "
                                "one C call per tick",
@@ -290,9 +341,11 @@ def run_children(a, rank, local_rank, world_size, role, port_shift):
                MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + port_shift),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.setdefault("MGX_HALO_TIMEOUT_MS", "2000")
+    env.setdefault("MGX_RESIDENT_TIMEOUT_MS", "2000")
     cmd = [sys.executable, os.path.abspath(__file__), "--role", role, "--gpus", str(world_size), "--steps", str(a.steps),
            "--warmup", str(a.warmup), "--repeats", str(a.repeats), "--preheat-ms", str(a.preheat_ms),
-           "--robots-per-gpu", str(a.robots_per_gpu), "--horizon", str(a.horizon)] + (["--fma"] if a.fma else [])
+           "--robots-per-gpu", str(a.robots_per_gpu), "--horizon", str(a.horizon)] + (["--fma"] if a.fma else []) + (
+               ["--no-resident"] if a.no_resident else [])
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=a.deadline)
     except subprocess.TimeoutExpired:
@@ -453,6 +506,26 @@ def main():
         os._exit(3)
     D = len(sc2["ir"]) / n_tot
     bytes2 = S.algorithmic_bytes_per_robot_iter(K, D) * n_loc  # per GPU per iteration
+
+    def agree(flag):  # every rank says yes?
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=red_dev)
+        if multi:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t[0]) == 1
+
+    # ---- N > 1: the in-engine transports are PROBED in child processes first (a transport that cannot map its peers on this
+    # node, or faults, takes a child down, not the bench); the one that ran there and left the beliefs of the host-driven
+    # exchange is then wired and measured HERE, in the bench process, and gives the headline
+    children, probe_ok = {}, False
+    if multi and not a.no_children:
+        children["direct"] = run_children(a, rank, local_rank, world_size, "direct-child", 23)
+        if backend == "nccl":  # the in-library RCCL transport needs one GPU per rank
+            children["rccl_in_engine"] = run_children(a, rank, local_rank, world_size, "rccl-child", 41)
+        r = children["direct"] if rank == 0 else None
+        flag = [bool(isinstance(r, dict) and isinstance(r.get("value"), (int, float)) and r.get("verified_against_host_driven_exchange"))]
+        dist.broadcast_object_list(flag, src=0)
+        probe_ok = flag[0]
+
     walls, devs = timed(torch, dist, sw.iterate, sc2["steps"], a, multi, red_dev)
     sw.iterate(sc2["steps"])
     resident = sw.world.last_launch_count() == 1  # the engine ran the 10-step schedule as ONE resident launch
@@ -461,46 +534,110 @@ def main():
     transport = "none (one GPU)" if not multi else "collective (torch.distributed all_to_all_single over RCCL, host-driven)"
     sw.synchronize()
     guard.cancel()
-    # launches per 10-step tick: ONE when the whole schedule runs as a resident launch (N = 1), else 11 ([I], 9 x [E I], [E])
+
+    in_engine = None
+    if multi and probe_ok:
+        guard = _Deadline(a.deadline, rank, line)
+        sw_in, got, err = None, None, ""
+        try:
+            sw_in = sharded.ShardedWorld(sc2, rank, world_size, lambda p: World(p, stream=stream, fma=a.fma), comm=comm)
+            sw_in.world.sweep(0, 0, 0)
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        if agree(not err):
+            try:
+                got = sharded.connect(sw_in, comm, "direct", resident=not a.no_resident)  # the ranks agree after every step
+            except Exception as e:  # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
+            if agree(not err and got is not None and got.startswith("direct")):
+                import numpy as np
+                verified = False
+                try:
+                    ref = sharded.ShardedWorld(sc2, rank, world_size, lambda p: World(p, stream=stream, fma=a.fma), comm=comm)
+                    for _ in range(2):  # the same two ticks with the exchange driven from the host: bit-identical beliefs
+                        sw_in.iterate(sc2["steps"])
+                        ref.iterate(sc2["steps"])
+                    sw_in.synchronize()
+                    ref.synchronize()
+                    same = all(np.array_equal(x, y) for x, y in zip(sw_in.read_beliefs()[1:], ref.read_beliefs()[1:]))
+                    del ref
+                except Exception as e:  # noqa: BLE001
+                    err, same = f"{type(e).__name__}: {e}", False
+                verified = agree(same)
+                walls_i = devs_i = None
+                if verified:
+                    try:
+                        walls_i, devs_i = timed(torch, dist, sw_in.iterate, sc2["steps"], a, True, red_dev, sync=sw_in.synchronize)
+                        sw_in.iterate(sc2["steps"])
+                        sw_in.synchronize()
+                    except Exception as e:  # noqa: BLE001
+                        err = f"{type(e).__name__}: {e}"
+                if verified and agree(not err):
+                    ri = summary(walls_i, devs_i, a.steps, units_per_step=world_size)
+                    in_engine = {"transport": got, "result": ri, "launches_per_tick": sw_in.world.last_launch_count()}
+                    by_transport[got + " (in the bench process)"] = round(ri["value"], 2)
+        if in_engine is None and rank == 0:
+            line["in_engine_in_process"] = {"error": err or "another rank failed, or the beliefs differed from the host-driven exchange's"}
+        if sw_in is not None:
+            dist.barrier()
+            sw_in.direct_close()
+        guard.cancel()
+
+    # launches per 10-step tick: ONE when the whole schedule runs as a resident launch, else 11 ([I], 9 x [E I], [E])
+    head = r2
+    if in_engine is not None:
+        head = in_engine["result"]
+        resident = in_engine["launches_per_tick"] == 1
+        transport = {"direct+resident": "direct+resident: ONE resident launch per schedule and rank; boundary robots store their snapshot records "
+                                        "and progress words into the other ranks' peer-mapped ghost areas from inside it (xGMI, system-scope "
+                                        "stores), no exchange kernel, no collective, no host work between the iterations",
+                     "direct": "direct (peer-mapped stores over xGMI + device-side arrival counters, in-engine, one C call per tick)"}[in_engine["transport"]]
     ticks = -(-a.steps // SCHEDULE_LEN)
     launches = ticks if resident else a.steps + ticks
     it_per_launch = SCHEDULE_LEN if resident else 1
-    kernel = "k_robot_sweep<16,2,true> (whole schedule resident)" if resident else "k_robot_sweep<16,2,false> (one iteration per launch)"
+    kernel = (("k_robot_sweep<16,2,true,shard>" if multi else "k_robot_sweep<16,2,true>") + " (whole schedule resident)") if resident else \
+        "k_robot_sweep<16,2,false> (one iteration per launch)"
     line.update({
-        "value": round(r2["value"], 2), "ms_per_step": r2["ms_per_step"], "device_ms_per_step": r2["device_ms_per_step"],
-        "spread": r2["spread"],
+        "value": round(head["value"], 2), "ms_per_step": head["ms_per_step"], "device_ms_per_step": head["device_ms_per_step"],
+        "spread": head["spread"],
         "config": {"workload": f"BASELINE configs[{'2' if not multi else '3 layout'}]: synthetic {n_tot} robots x {K} horizon, dynamics + "
                                f"obstacle + inter-robot factors (comm radius 8, {D:.2f} neighbours/robot), seed 805, 10/10 schedule",
                    "robots_per_gpu": n_loc, "horizon": K, "robots_total": n_tot,
                    "parallelism": (f"robots sharded over {world_size} GPUs in (y, x) strips, one exchange of boundary snapshot records "
-                                   "per external iteration") if multi else "1 GPU: the 10-step schedule is ONE resident launch, "
-                                   "neighbouring workgroups hand their snapshot records over inside it" if resident else "1 GPU",
+                                   "per external iteration" + (", inside ONE resident launch per schedule and rank" if resident else "")) if multi else
+                                  "1 GPU: the 10-step schedule is ONE resident launch, neighbouring workgroups hand their snapshot records "
+                                  "over inside it" if resident else "1 GPU",
                    "ghost_robots_this_rank": len(sw.plan.ghosts)},
-        "roofline": roofline(kernel, bytes2 * it_per_launch, launches, r2["device_s_median"],
-                             ("config2_resident" if resident else "config2") if (full_size and not multi) else "", it_per_launch),
+        "roofline": roofline(kernel, bytes2 * it_per_launch, launches, head["device_s_median"],
+                             ("config2_resident" if resident else "config2") if full_size else "", it_per_launch,
+                             prof_note="counters of the N = 1 instantiation of the same per-GPU workload" if multi else ""),
     })
-
-    # ---- the same sharded workload with the exchange inside the engine, isolated in child processes -----------------
-    if multi and not a.no_children:
-        children = {}
-        children["direct"] = run_children(a, rank, local_rank, world_size, "direct-child", 23)
-        if backend == "nccl":  # the in-library RCCL transport needs one GPU per rank
-            children["rccl_in_engine"] = run_children(a, rank, local_rank, world_size, "rccl-child", 41)
-        if rank == 0:
-            line["in_engine_transports"] = children
-            labels = {"direct": "direct (peer-mapped stores over xGMI, in-engine, one C call per tick)",
-                      "rccl_in_engine": "RCCL grouped send / recv enqueued by the engine (one C call per tick)"}
-            for key, r in children.items():
-                if isinstance(r, dict) and isinstance(r.get("value"), (int, float)):
-                    by_transport[key] = r["value"]
-                    if r["value"] > line["value"]:  # the transports carry the same exchange: the headline is the fastest that ran
-                        line["value"], line["ms_per_step"], line["device_ms_per_step"] = r["value"], r["ms_per_step"], r.get("device_ms_per_step")
-                        line["spread"] = r.get("spread")
-                        transport = labels[key]
-                        if r.get("device_ms_per_step"):
-                            dev_s = r["device_ms_per_step"] * 1e-3 * a.steps
-                            line["roofline"] = roofline(kernel, bytes2 * it_per_launch, launches, dev_s, "", it_per_launch)
+    if multi and rank == 0 and children:
+        line["in_engine_transports"] = children  # the probes (isolated child processes)
+        for key, r in children.items():
+            if isinstance(r, dict) and isinstance(r.get("value"), (int, float)):
+                by_transport[key + " (child process)"] = r["value"]
     line["transport"], line["by_transport"] = transport, by_transport
+
+    # ---- N = 1: the same workload with resident launches switched off for THIS world (one launch per iteration): what a
+    # rank of a sharded world would pay WITHOUT the in-launch hand-off, so that the scaling curve separates the cost of
+    # the exchange from the loss of residency
+    if not multi and resident:
+        try:
+            w_seg = World(sc2["params"], stream=stream, fma=a.fma)
+            S.populate(w_seg, sc2)
+            w_seg.set_resident_launches(False)
+            walls_s, devs_s = timed(torch, dist, w_seg.iterate, sc2["steps"], a, False, red_dev)
+            w_seg.iterate(sc2["steps"])
+            rs = summary(walls_s, devs_s, a.steps)
+            line["launch_per_segment"] = {"value": round(rs["value"], 2), "ms_per_step": rs["ms_per_step"], "device_ms_per_step": rs["device_ms_per_step"],
+                                          "launches_per_tick": w_seg.last_launch_count(),
+                                          "what": "the same 1000 x 16 inter-robot workload with mgx_set_resident_launches(world, 0): one launch per "
+                                                  "[external iteration] internal* segment (= MGX_PERSISTENT=0)"}
+            w_seg.synchronize()
+            del w_seg
+        except Exception as e:  # noqa: BLE001
+            line["launch_per_segment"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- N = 1 extras: whole driver ticks, topology churn, a reference scenario end to end ----------------------------
     if not multi and not a.no_extras:

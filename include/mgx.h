@@ -179,6 +179,10 @@ int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n);
  * neighbours inside it); otherwise one launch per [external iteration] internal* segment.  MGX_PERSISTENT=0 in
  * the environment forces the latter.  Diagnostic (bench.py prices its roofline per launch with it). */
 int mgx_last_launch_count(mgx_world *w, uint32_t *n_launches);
+/* Per-world switch for the above (default: on): 0 keeps every schedule of THIS world on the launch-per-segment path — what
+ * MGX_PERSISTENT=0 does for the whole process.  For measuring one against the other; results are identical either way.
+ * On a sharded world with resident launches agreed on (mgx_halo_resident_connect) every rank has to switch alike. */
+int mgx_set_resident_launches(mgx_world *w, int32_t enabled);
 
 /* The launch primitive the calls above and below are built on: one device pass per robot
  * that runs the external phases in `external_phases` (bit0 = external factor sweep + routing,

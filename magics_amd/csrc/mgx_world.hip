@@ -355,6 +355,7 @@ struct mgx_world {
     DevBuf<int32_t> peer_ptr_dev, peer_idx_dev;
     unsigned long long *sweep_err_host = nullptr;  // host-mapped; non-zero once a wait inside a resident launch gave up
     unsigned long long flag_base = 0;              // every progress word is below or at this value between launches
+    bool resident_off = false;                     // mgx_set_resident_launches(w, 0)
     int resident_cap = -1;                         // workgroups of the resident kernel the device holds at once (-1: not asked yet)
     int resident_cap_sharded = -1;                 // the same for the instantiation that takes ghost records in-launch
     bool peers_valid = false;
@@ -1355,7 +1356,7 @@ static int ensure_resident_tables(mgx_world *w) {
 // launch-per-segment path), negative = error.  Eligible: inter-robot factors enabled and staged in LDS, every robot
 // local (no ghosts: their records arrive between launches), nothing thawing, and every workgroup co-resident.
 static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
-    if (!resident_enabled() || plan.size() < 2) return 0;
+    if (!resident_enabled() || w->resident_off || plan.size() < 2) return 0;
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
     const DevWorld &d = w->d;
@@ -2580,6 +2581,11 @@ int mgx_change_prior(mgx_world *w, int32_t robot, uint32_t var_ix, const double 
     return mgx_change_priors(w, 1, &robot, &var_ix, mean);
 }
 
+int mgx_set_resident_launches(mgx_world *w, int32_t enabled) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    w->resident_off = enabled == 0;
+    return MGX_OK;
+}
 int mgx_last_launch_count(mgx_world *w, uint32_t *n_launches) {
     if (!w || !n_launches) return fail(MGX_ERR_INVALID, "null argument");
     *n_launches = w->last_sweep_launches;

@@ -172,6 +172,7 @@ SYMBOLS = {
     "mgx_mission_read": (C.c_int, [_V, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_num_robots": (C.c_int, [_V, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mgx_last_launch_count": (C.c_int, [_V, C.POINTER(C.c_uint32)]),
+    "mgx_set_resident_launches": (C.c_int, [_V, C.c_int32]),
     "mgx_halo_words": (C.c_uint32, [C.c_uint32]),
     "mgx_halo_plan": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_int32)]),
     "mgx_halo_plan_from_connections": (C.c_int, [_V, C.POINTER(C.c_int32), C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32),

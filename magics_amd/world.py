@@ -285,6 +285,10 @@ class World:
         self._chk(self._L.mgx_mission_read(self._w, tr.ctypes.data, tg.ctypes.data, fin.ctypes.data))
         return tr, tg, fin
 
+    def set_resident_launches(self, enabled):
+        """per-world switch: False keeps every schedule on the launch-per-segment path (mgx_set_resident_launches)"""
+        self._chk(self._L.mgx_set_resident_launches(self._w, 1 if enabled else 0))
+
     def last_launch_count(self):
         """sweep-kernel launches of the last iterate / tick call (1: the whole schedule ran as one resident launch)"""
         n = C.c_uint32()

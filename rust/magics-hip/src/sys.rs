@@ -117,6 +117,7 @@ extern "C" {
     pub fn mgx_connections(w: *mut mgx_world, robot: i32, others: *mut i32, capacity: u32, n: *mut u32) -> c_int;
     pub fn mgx_iterate(w: *mut mgx_world, steps: *const u8, n: u32) -> c_int;
     pub fn mgx_last_launch_count(w: *mut mgx_world, n_launches: *mut u32) -> c_int;
+    pub fn mgx_set_resident_launches(w: *mut mgx_world, enabled: i32) -> c_int;
     pub fn mgx_sweep(w: *mut mgx_world, robot: i32, external_phases: u32, internal_phases: u32, n_internal: u32, hints: u32) -> c_int;
     pub fn mgx_internal_factor_iteration(w: *mut mgx_world, robot: i32) -> c_int;
     pub fn mgx_internal_variable_iteration(w: *mut mgx_world, robot: i32) -> c_int;

@@ -97,7 +97,8 @@ def test_bench_direct_child_role(tmp_path):
         assert p.returncode == 0, outs[r][1].decode(errors="replace")[-3000:]
     res = json.loads([ln for ln in outs[0][0].decode().splitlines() if ln.startswith("{")][-1])
     assert "error" not in res, res
-    assert res["value"] > 0 and res["exchanges"] > 0 and res["ghost_robots_this_rank"] > 0
+    assert res["value"] > 0 and res["ghost_robots_this_rank"] > 0
+    assert res["transport"] == "direct+resident" and res["launches_per_tick"] == 1 and res["verified_against_host_driven_exchange"], res
 
 
 def test_bench_two_rank_control_flow_dry_run():
@@ -121,6 +122,11 @@ def test_bench_two_rank_control_flow_dry_run():
     # the headline is the SHARDED inter-robot workload (288 robots over two ranks, ghosts on each), configs[1] beside it
     assert d["config"]["robots_total"] == 288 and d["config"]["ghost_robots_this_rank"] > 0
     assert d["configs1"]["value"] > 0 and d["by_transport"]["collective"] > 0
-    assert d["in_engine_transports"]["direct"].get("value", 0) > 0, d["in_engine_transports"]["direct"]
-    assert d["by_transport"]["direct"] == d["in_engine_transports"]["direct"]["value"]
-    assert d["value"] == max(d["by_transport"].values())
+    # the probe (child processes): peer-mapped stores + resident schedule launches, beliefs equal to the host-driven exchange's
+    probe = d["in_engine_transports"]["direct"]
+    assert probe.get("value", 0) > 0 and probe["transport"] == "direct+resident" and probe["verified_against_host_driven_exchange"], probe
+    assert probe["launches_per_tick"] == 1
+    # ... and the headline: the same transport wired and measured in the bench process itself
+    assert d["transport"].startswith("direct+resident"), d.get("in_engine_in_process", d["transport"])
+    assert d["value"] == d["by_transport"]["direct+resident (in the bench process)"]
+    assert "resident" in d["roofline"]["kernel"]

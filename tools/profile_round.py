@@ -37,15 +37,22 @@ def durations(d):
     return {k: (sum(v[len(v) // 5:]) / len(v[len(v) // 5:]), len(v)) for k, v in acc.items()}
 
 
+def kernel_digest():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench.kernel_digest()
+
+
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     g = os.path.join(ROOT, "gpurun_out", tag)
     prof = os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
     out = [f"# rocprofv3 summary — {tag}", "",
            "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-extras` "
-           "(tools/profile_round.sh; MI355X).  `<16, 0, false>`: configs[1], 10 iterations per dispatch; `<16, 2, true>`: configs[2], the 10-step "
-           "schedule as ONE resident dispatch; `<16, 2, false>` (second run, `MGX_PERSISTENT=0`): configs[2], one iteration per dispatch.", ""]
+           "(tools/profile_round.sh; MI355X).  `<16, 0, false, false>`: configs[1], 10 iterations per dispatch; `<16, 2, true, false>`: configs[2], "
+           "the 10-step schedule as ONE resident dispatch; `<16, 2, false, false>` (second run, `MGX_PERSISTENT=0`): configs[2], one iteration per "
+           "dispatch (template arguments: horizon, inter-robot message mode, resident, sharded).", ""]
     for sub, name in (("_kt", "kernel_stats"), ("_kt_np", "kernel_stats_launch_per_iteration"), ("_cfg", "configs_kernel_stats")):
         f = glob.glob(os.path.join(g + sub, "**", "*kernel_stats.csv"), recursive=True)
         if f:
@@ -57,19 +64,21 @@ def main():
             out.append("")
     dur = durations(g + "_kt")
     dur.update({k + " (MGX_PERSISTENT=0)": v for k, v in durations(g + "_kt_np").items()})
+    dur.update({k + " (the driver's command: --gpus 1 --steps 20 --warmup 5)": v for k, v in durations(g + "_kt_driver").items()})
     out += ["## steady-state dispatch durations (kernel trace)", "", "| instantiation | dispatches | avg us |", "|---|---|---|"]
     for k, (avg, n) in sorted(dur.items()):
         out.append(f"| k_robot_sweep{k} | {n} | {avg:.2f} |")
-    traffic = {"_source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, tools/profile_round.sh) on `python3 bench.py "
+    traffic = {"_kernel_digest": kernel_digest(), "_source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, tools/profile_round.sh) on `python3 bench.py "
                           f"--steps 200 --warmup 50 --no-cpu-baseline --no-extras`, MI355X, round {tag}.  KiB per dispatch as reported; per "
                           "MI355X_MICROARCH.md (HBM section) gfx950 FETCH_SIZE counts half the bytes of wide 16-B-per-lane streaming reads, so "
                           "bench.py doubles the reads (an upper bound here: part of the staging uses 8-B loads)."}
-    keys = {"<16, 0, false>": ("config1", ""), "<16, 2, true>": ("config2_resident", ""), "<16, 2, false>": ("config2", "_np")}
+    keys = {"<16, 0, false, false>": ("config1", ""), "<16, 2, true, false>": ("config2_resident", ""), "<16, 2, false, false>": ("config2", "_np")}
     out += ["", "## PMC per dispatch (separate passes)", "", "| instantiation | FETCH_SIZE KiB | WRITE_SIZE KiB | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU x4 / SQ_BUSY_CYCLES x4 | SQ_WAIT_ANY / SQ_WAVE_CYCLES |", "|---|---|---|---|---|---|"]
     for inst, (key, suf) in keys.items():
         f = per_kernel(g + "_pmc_FETCH_SIZE" + suf, "FETCH_SIZE").get(inst)
         w = per_kernel(g + "_pmc_WRITE_SIZE" + suf, "WRITE_SIZE").get(inst)
         sq = {c: per_kernel(g + "_pmc_SQ_INSTS_VALU" + suf, c).get(inst) for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY")}
+        d_us = (dur.get(inst + (" (MGX_PERSISTENT=0)" if suf else "")) or (None, 0))[0]
         if f is None or w is None:
             continue
         ent = {"fetch_kib": round(f, 1), "write_kib": round(w, 1), "source": f"profiles/{tag}_summary.md (rocprofv3 --pmc, separate passes)"}
@@ -80,12 +89,35 @@ def main():
                 # SQ_ACTIVE_INST_VALU: quad-cycles summed over the SIMDs; SQ_BUSY_CYCLES: quad-cycles summed over the shader engines' SQs
                 busy = sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"] * 100.0
                 ent["valu_busy_pct"] = round(busy, 1)
+            if sq["SQ_WAIT_ANY"] and sq["SQ_WAVE_CYCLES"]:
+                ent["wait_pct"] = round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"] * 100.0, 1)
+        if d_us:
+            ent["kernel_trace_avg_us"] = round(d_us, 2)
         traffic[key] = ent
         out.append(f"| k_robot_sweep{inst} | {f:.1f} | {w:.1f} | {sq['SQ_INSTS_VALU'] or 0:.4g} | VALU active {busy or 0:.1f} % of wave-cycles | "
                    f"{(sq['SQ_WAIT_ANY'] or 0) / (sq['SQ_WAVE_CYCLES'] or 1) * 100:.0f} % waiting |")
+    # the K = 32 instantiations (tools/bench_configs.py under the same three counter passes)
+    cdur = durations(g + "_cfg")
+    if cdur:
+        out += ["", "## K = 32 and the other BASELINE shapes: PMC per dispatch (tools/bench_configs.py, separate passes)", "",
+                "| instantiation | dispatches | avg us | FETCH_SIZE KiB | WRITE_SIZE KiB | SQ_INSTS_VALU | VALU active % of wave-cycles | waiting % |", "|---|---|---|---|---|---|---|---|"]
+        cf, cw = per_kernel(g + "_cfg_pmc_FETCH_SIZE", "FETCH_SIZE"), per_kernel(g + "_cfg_pmc_WRITE_SIZE", "WRITE_SIZE")
+        csq = {c: per_kernel(g + "_cfg_pmc_SQ_INSTS_VALU", c) for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY")}
+        for inst, (avg, n) in sorted(cdur.items()):
+            wc = csq["SQ_WAVE_CYCLES"].get(inst) or 0
+            out.append(f"| k_robot_sweep{inst} | {n} | {avg:.2f} | {cf.get(inst, 0):.1f} | {cw.get(inst, 0):.1f} | {csq['SQ_INSTS_VALU'].get(inst, 0):.4g} | "
+                       f"{(csq['SQ_ACTIVE_INST_VALU'].get(inst, 0) / wc * 100) if wc else 0:.1f} | {(csq['SQ_WAIT_ANY'].get(inst, 0) / wc * 100) if wc else 0:.0f} |")
+            traffic["configs" + inst] = {"fetch_kib": round(cf.get(inst, 0), 1), "write_kib": round(cw.get(inst, 0), 1),
+                                         "valu_wave_instr": round(csq["SQ_INSTS_VALU"].get(inst, 0)), "kernel_trace_avg_us": round(avg, 2),
+                                         "note": "mean over every dispatch of this instantiation in tools/bench_configs.py (several shapes share one)"}
     json.dump(traffic, open(os.path.join(prof, f"traffic_{tag}.json"), "w"), indent=1)
     for f in glob.glob(g + "_kt.json"):
         shutil.copy(f, os.path.join(prof, f"{tag}_bench_under_rocprof.json"))
+    for f in glob.glob(g + "_kt_driver.json"):  # the bench line of the driver's command from the same box, beside its dispatch durations
+        shutil.copy(f, os.path.join(prof, f"{tag}_driver_command_bench_line.json"))
+    f = glob.glob(os.path.join(g + "_kt_driver", "**", "*kernel_stats.csv"), recursive=True)
+    if f:
+        shutil.copy(f[0], os.path.join(prof, f"{tag}_driver_command_kernel_stats.csv"))
     cfg = g + "_cfg.log"
     if os.path.exists(cfg):
         out += ["", "## every BASELINE config on one MI355X (`tools/bench_configs.py` under rocprofv3 --kernel-trace --stats)", ""]
