@@ -150,6 +150,13 @@ struct DevWorld {
     const int32_t *peer_idx;          // device robot indices
     unsigned long long *sweep_abort;  // device memory
     unsigned long long *sweep_err;    // host-mapped
+    // ... and the launch's residency census (SegPlan): one word per workgroup of a resident launch, "I have started launch
+    // number ..." (monotonic, never reset, nobody shares a word: plain write-through stores); the launch's go / abort decision
+    // (launch number * 4 + state) in device memory and its host-mapped copy, which the host looks at before it enqueues
+    // anything behind the launch
+    unsigned long long *census;          // [R_local + 1]
+    unsigned long long *decision;        // device memory
+    unsigned long long *decision_host;   // host-mapped
     // Resident schedule launches of a sharded world (k_robot_sweep<.., PERSIST, SHARD>).  This rank's GHOST AREA is fine-grained
     // device memory that the ghosts' owner ranks store into from inside their launches (peer-mapped: hipIpc across processes):
     // the ghosts' snapshot records and delivery counts for the two buffer parities and one progress word per ghost (ghost g =
@@ -209,7 +216,16 @@ struct SegPlan {
     uint8_t n_int[MAX_SEGS];       // internal iterations that follow
     unsigned long long flag_base;  // every progress word holds at least this much when the launch starts
     long long timeout_ticks;       // 100 MHz wall-clock ticks a wait may take before it gives up (reported, never a hang)
+    // Residency census.  Every workgroup of the launch waits for neighbours inside it, and a plain (or cooperative) launch
+    // promises co-residency to nobody — another tenant of the GPU can hold the CUs the tail of the grid needs, for as long as
+    // the head spins.  So every workgroup signs in when it starts, and before anything that cannot be taken back is written
+    // the launch's extra workgroup decides for all: everybody signed in within census_ticks -> go; otherwise abort — every
+    // workgroup (also those that start later) returns at once, the world is as it was, and the host runs the schedule launch
+    // by launch instead.
+    unsigned long long launch_seq;        // number of this resident launch (census and decision words are monotonic in it); 0: no census
+    long long census_ticks;
 };
+constexpr unsigned RESIDENT_GO = 1u, RESIDENT_ABORT = 2u;
 
 // launch hints
 constexpr uint32_t HINT_IR_DEAD = 1u;  // the next sweep recomputes every inter-robot message this one computes

@@ -227,7 +227,40 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // BIG: more than 64 dynamic-factor messages / tracking factors per robot (K > 33): some lanes carry two.
     constexpr bool BIG = KT < 0 || KT > 33;
     STAMP(t_k0);
-    const int r = robot0 + xcd_local_index(blockIdx.x, gridDim.x);
+    // resident launches: "this workgroup has started" (SegPlan: residency census) — a word of its own, a plain write-through
+    // store: nothing contended is outstanding when the staging loads are waited for
+    const bool census = PERSIST && plan.launch_seq != 0ull;
+    if (census && threadIdx.x == 0) __hip_atomic_store(&w.census[blockIdx.x], plan.launch_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ... and the launch's LAST workgroup owns no robot: it is the decider.  Dispatched behind every robot's workgroup, it
+    // finds every word signed within a microsecond of the launch's start when the whole grid is on the device — while the
+    // robots' workgroups are still staging — and says go; if they are not all signed within the bound it says abort.  Either
+    // way by compare-and-swap on a word that is monotonic in the launch number (no launch resets it).
+    if (census && blockIdx.x == gridDim.x - 1) {
+        const unsigned long long seq = plan.launch_seq;
+        const long long t0 = wall_clock64();
+        for (;;) {
+            int missing = 0;
+            for (unsigned b2 = threadIdx.x; b2 < gridDim.x; b2 += SWEEP_BLOCK)
+                missing |= __hip_atomic_load(&w.census[b2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq ? 1 : 0;
+            const bool all = __syncthreads_or(missing) == 0;
+            int done = 0;
+            if (threadIdx.x == 0) {
+                unsigned long long v = __hip_atomic_load(w.decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned want = all ? RESIDENT_GO : (wall_clock64() - t0 > plan.census_ticks ? RESIDENT_ABORT : 0u);
+                if ((v >> 2) == seq) {
+                    done = 1;  // a workgroup that gave up on this one has decided
+                } else if (want) {
+                    if (__hip_atomic_compare_exchange_strong(w.decision, &v, seq * 4ull + want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        __hip_atomic_store(w.decision_host, seq * 4ull + want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    done = 1;  // (lost the exchange: somebody else's decision stands)
+                }
+            }
+            if (__syncthreads_or(done)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        return;
+    }
+    const int r = robot0 + xcd_local_index(blockIdx.x, census ? gridDim.x - 1 : gridDim.x);
     int tid = threadIdx.x;  // not const: resident launches make them opaque once per segment, see the segment loop
     const int role = tid >> 6;
     int lane = tid & 63;
@@ -431,6 +464,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             quad_gather(fetch_plain, pf_on ? (unsigned)pf_er.src_var * (unsigned)(SNAP_W * sizeof(double)) : 0u, pf_rec);
         }
     };
+    unsigned long long early_decision = 0ull;  // resident launches: the go / abort word as it stands when the staging loads are back
     {
         const double *src = w.snap[w.cur] + (size_t)v0 * SNAP_W;
         if constexpr (KT > 0) {
@@ -446,6 +480,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 r_snap[it] = (t < SNAP_W * K) ? src[t] : 0.0;
             }
             chain_second_link();
+            if (census && BIG && tid == 0) early_decision = __hip_atomic_load(w.decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             r_prior.store(s_prior, tid);
             r_io.store(s_mu, tid);
 #pragma unroll
@@ -456,6 +491,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         } else {
             copy_words(s_prior, blob + L.prior(), 20 * K, tid);
             chain_second_link();
+            if (census && BIG && tid == 0) early_decision = __hip_atomic_load(w.decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             copy_words(s_mu, blob + L.mu(), L.inout_words() - 16 * K, tid);
             for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = src[t];
         }
@@ -490,6 +526,37 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         }
     }
     __syncthreads();
+    // ---- residency census (SegPlan): go or abort, before anything that cannot be taken back has been written ------------------
+    // The decision is made by the launch's extra workgroup while this one stages (see the top of the kernel).  It is consumed
+    // at the END of segment 0, in front of the first publication — by then it is microseconds old, the look costs nothing —
+    // because nothing a workgroup does before that point survives an abort or hurts: LDS and registers are simply dropped, and
+    // the one thing written to HBM, mgx_tick's prior updates right below, is a function of state the launch has not changed
+    // (means, beliefs), so the launch-by-launch re-run writes the same values again.  Horizons beyond 33 variables keep part of
+    // their tracking factors' state in HBM and update it inside the sweeps: they look right here, after staging (the look was
+    // issued in front of the staging stores).  Still undecided when looked at: poll; a decider that never started (four times
+    // the bound) is an abort too, by compare-and-swap so that nobody can decide differently.
+    constexpr bool CENSUS_EARLY = BIG;
+    auto census_says_abort = [&](unsigned long long v) __attribute__((always_inline)) {
+        int abort_launch = 0;
+        if (tid == 0) {
+            const unsigned long long seq = plan.launch_seq;
+            const long long t0 = wall_clock64();
+            while ((v >> 2) != seq) {
+                __builtin_amdgcn_s_sleep(1);
+                v = __hip_atomic_load(w.decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 2) != seq && wall_clock64() - t0 > 4 * plan.census_ticks) {
+                    if (__hip_atomic_compare_exchange_strong(w.decision, &v, seq * 4ull + RESIDENT_ABORT, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(w.decision_host, seq * 4ull + RESIDENT_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        v = seq * 4ull + RESIDENT_ABORT;
+                    }
+                }
+            }
+            abort_launch = (v & 3ull) == RESIDENT_ABORT ? 1 : 0;
+        }
+        return __syncthreads_or(abort_launch) != 0;
+    };
+    if (census && CENSUS_EARLY && census_says_abort(early_decision)) return;  // nothing has been written: the world is as it was
     // ---- mgx_tick: update_prior_of_horizon_state (wave 0, variable K-1) and update_prior_of_current_state_v3
     // (wave 1, variable 0) on the staged image, each ending in change_prior of that variable
     // (robot.rs:2182-2338, variable.rs:203-230; same arithmetic as k_update_priors / apply_change_prior).  For
@@ -1435,6 +1502,11 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 STAMP_ADD(c_v, t3, t4);
                 STAMP_ADD(c_vb, t4, t5);
             }
+        }
+        // segment 0 of a resident launch is through: go or abort (see the residency census above) before anything is published
+        if (census && !CENSUS_EARLY && k == 0) {
+            const unsigned long long v = tid == 0 ? __hip_atomic_load(w.decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            if (census_says_abort(v)) return;
         }
         // ======================= end of a segment of a resident schedule launch ====================
         // The snapshot records of this robot (what its variables last sent to their own factors: all that another

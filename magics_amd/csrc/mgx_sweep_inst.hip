@@ -99,16 +99,17 @@ template <int KT>
 static hipError_t resident_launch_k(const DevWorld &w, int n_robots, const SegPlan &plan, bool cooperative, hipStream_t stream) {
     const size_t staged = sweep_lds_bytes(w.K, w.ir_max_edges, true);
     if (!resident_allow_lds<KT>(staged)) return hipErrorInvalidValue;
+    const int grid = n_robots + (plan.launch_seq != 0ull ? 1 : 0);  // + the residency census' decider workgroup (mgx_sweep.h)
     if (cooperative) {  // the launch-time check of the grid against the occupancy query; same residency as a plain launch
         DevWorld wa = w;
         SegPlan pa = plan;
         int robot0 = 0, n_int = 0, snap_out = -1;
         uint32_t ext_mask = 0u, int_mask = 0u, hints = 0u;
         void *args[] = {&wa, &robot0, &ext_mask, &int_mask, &n_int, &snap_out, &hints, &pa};
-        return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&k_robot_sweep<KT, IR_STAGED, true, SHARDED>), dim3(n_robots),
+        return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&k_robot_sweep<KT, IR_STAGED, true, SHARDED>), dim3(grid),
                                           dim3(SWEEP_BLOCK), args, (unsigned int)staged, stream);
     }
-    hipLaunchKernelGGL((k_robot_sweep<KT, IR_STAGED, true, SHARDED>), dim3(n_robots), dim3(SWEEP_BLOCK), staged, stream, w, 0, 0u, 0u, 0,
+    hipLaunchKernelGGL((k_robot_sweep<KT, IR_STAGED, true, SHARDED>), dim3(grid), dim3(SWEEP_BLOCK), staged, stream, w, 0, 0u, 0u, 0,
                        -1, 0u, plan);
     return hipGetLastError();
 }

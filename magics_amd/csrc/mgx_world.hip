@@ -356,6 +356,24 @@ struct mgx_world {
     unsigned long long *sweep_err_host = nullptr;  // host-mapped; non-zero once a wait inside a resident launch gave up
     unsigned long long flag_base = 0;              // every progress word is below or at this value between launches
     bool resident_off = false;                     // mgx_set_resident_launches(w, 0)
+    // residency census of resident launches (SegPlan, mgx_dev.h): cumulative per-group counts the device counters reach, the
+    // launch number, and the launch the host has enqueued but not yet seen decided (go / abort)
+    DevBuf<unsigned long long> census_buf, decision_buf;
+    unsigned long long *decision_host = nullptr;   // host-mapped
+    unsigned long long launch_seq = 0;
+    struct PendingResident {
+        bool active = false;
+        unsigned long long seq = 0;
+        std::vector<std::pair<uint32_t, int>> segs;  // (external phases, internal iterations) of the launch's segments
+        std::vector<uint32_t> hints;
+        int cur_before = 0;
+        unsigned long long flag_base_before = 0;
+        const double *upd = nullptr;  // mgx_tick: the prior updates that ride in the launch (pinned ring slot, still valid)
+        double upd_max_speed = 0.0, upd_delta_t = 0.0;
+    } pending;
+    int resident_backoff = 0;   // schedules that skip the resident form after an aborted launch
+    int resident_backoff_len = 0;
+    uint64_t resident_aborts = 0;
     int resident_cap = -1;                         // workgroups of the resident kernel the device holds at once (-1: not asked yet)
     int resident_cap_sharded = -1;                 // the same for the instantiation that takes ghost records in-launch
     bool peers_valid = false;
@@ -573,8 +591,10 @@ static void blob_unpack(Robot &rb, const double *b) {
 }
 
 // ---- pull: device -> host mirror ----------------------------------------------------------------
+static int confirm_resident(mgx_world *w);
 static int pull(mgx_world *w) {
     if (!w->dev_valid) return MGX_OK;
+    if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     const int K = w->K;
     const size_t NT = (size_t)w->d.NT, NI = (size_t)w->d.NI, BS = (size_t)w->d.BS;
     std::vector<double> bl, sn, tlv, ife, ifl, ibm;
@@ -661,7 +681,9 @@ static int pull(mgx_world *w) {
 // contents (a skipped factor still "sends" its empty messages, factor/mod.rs:353-367).  So the
 // launches are only logged, and the counters are brought up to date whenever one of those inputs
 // is about to change or a count is asked for.
+static int confirm_resident(mgx_world *w);
 static void flush_counts(mgx_world *w) {
+    if (w->pending.active) (void)confirm_resident(w);  // the launch's entries join the log once it is known to have run
     if (w->clog.empty() && w->cp_dirty.empty()) return;
     const int K = w->K;
     const size_t n = w->robots.size();
@@ -970,8 +992,10 @@ static int retopo(mgx_world *w) {
     return rc_flags;
 }
 
+static int confirm_resident(mgx_world *w);
 static int commit(mgx_world *w) {
     if (!device_ok()) return fail(MGX_ERR_NO_DEVICE, "no usable HIP device (this library has no CPU path)");
+    if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     if (!w->dirty) {
         if (w->conns_dirty) return retopo(w);
         if (w->flags_dirty) return upload_flags(w);
@@ -1202,7 +1226,56 @@ static int check_device_error(mgx_world *w) {
 // ---- launches -----------------------------------------------------------------------------------------
 static int direct_exchange(mgx_world *w);
 static int rccl_exchange(mgx_world *w);
-static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_mask, int n_int, uint32_t hints = 0) {
+static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_mask, int n_int, uint32_t hints = 0);
+static void log_launch(mgx_world *w, int robot, uint32_t ext_mask, uint32_t int_mask, int n_int);
+
+// A resident schedule launch decides for itself, before it writes anything, whether all its workgroups are on the device
+// together (SegPlan: residency census) — and if another tenant of the GPU holds the CUs its tail needs, it returns at once
+// and leaves the world untouched.  The host must not put anything behind a launch whose decision it has not seen (what
+// follows would run on the wrong state), so every entry point that enqueues work or reads state comes through here first:
+// the decision falls within microseconds of the launch's START, so in a stream of ticks the host simply stays ONE launch
+// ahead of the device instead of many.  An aborted launch is run again on the launch-per-segment path, and the next few
+// schedules skip the resident form (doubling back-off while the GPU stays shared).
+static int confirm_resident(mgx_world *w) {
+    mgx_world::PendingResident &pd = w->pending;
+    if (!pd.active) return MGX_OK;
+    const StageTimer clock("confirm");
+    const double t0 = StageTimer::now();
+    unsigned long long v = 0;
+    for (unsigned spins = 0;; spins++) {
+        v = __atomic_load_n(w->decision_host, __ATOMIC_ACQUIRE);
+        if ((v >> 2) >= pd.seq) break;
+        if ((spins & 0xfffffu) == 0xfffffu && StageTimer::now() - t0 > 30e6) {
+            // 30 s: the launch never started (a stuck stream): nothing sensible is left to do.  (No runtime call in this loop:
+            // a stream query per look made the runtime put markers between the launches.)
+            pd.active = false;
+            return fail(MGX_ERR_STATE, "resident launch %llu was never decided (the stream does not advance)", pd.seq);
+        }
+    }
+    pd.active = false;
+    if ((v >> 2) == pd.seq && (v & 3ull) == RESIDENT_ABORT) {
+        // nothing happened on the device: take the host's bookkeeping back and run the same schedule launch by launch
+        w->resident_aborts++;
+        w->resident_backoff_len = std::min(std::max(2 * w->resident_backoff_len, 8), 4096);
+        w->resident_backoff = w->resident_backoff_len;
+        w->d.cur = pd.cur_before;
+        w->flag_base = pd.flag_base_before;
+        w->last_sweep_launches = 0;
+        bool first = true;
+        for (size_t k = 0; k < pd.segs.size(); k++) {
+            if (first && pd.upd) { w->d.upd = pd.upd; w->d.upd_max_speed = pd.upd_max_speed; w->d.upd_delta_t = pd.upd_delta_t; }
+            const int rc = sweep(w, -1, pd.segs[k].first, pd.segs[k].second ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, pd.segs[k].second, pd.hints[k]);
+            w->d.upd = nullptr;
+            first = false;
+            if (rc != MGX_OK) return rc;
+        }
+        return MGX_OK;
+    }
+    w->resident_backoff_len = 0;
+    for (const auto &sg : pd.segs) log_launch(w, -1, sg.first, sg.second ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, sg.second);
+    return MGX_OK;
+}
+static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_mask, int n_int, uint32_t hints) {
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
     if ((rc = check_device_error(w)) != MGX_OK) return rc;
@@ -1309,6 +1382,25 @@ static int ensure_resident_tables(mgx_world *w) {
         HIP_TRY(hipMemsetAsync(w->sweep_flag_buf.p, 0, sizeof(unsigned long long) * R, s));
         w->flag_base = 0;
     }
+    if (w->census_buf.n < R + 1) {  // residency census: one word per workgroup of a launch (never reset: monotonic in the launch number)
+        std::vector<unsigned long long> z(R + 1 + R / 4 + 64, 0ull);
+        HIP_TRY(w->census_buf.upload(z, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (!w->decision_buf.p) {  // the decision word and its host-mapped copy
+        std::vector<unsigned long long> z1(1, 0ull);
+        HIP_TRY(w->decision_buf.upload(z1, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipHostMalloc((void **)&w->decision_host, sizeof(unsigned long long), hipHostMallocMapped));
+        *w->decision_host = 0ull;
+    }
+    {
+        void *dp = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dp, w->decision_host, 0));
+        w->d.census = w->census_buf.p;
+        w->d.decision = w->decision_buf.p;
+        w->d.decision_host = (unsigned long long *)dp;
+    }
     if (!w->peers_valid) {
         // (lists of the LOCAL robots; a ghost — device index >= R — appears in them as a peer, its word lives in the ghost area)
         std::vector<int32_t> ptr(R + 1, 0);
@@ -1359,6 +1451,10 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
     if (!resident_enabled() || w->resident_off || plan.size() < 2) return 0;
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
+    if (w->resident_backoff > 0) {  // a recent launch found the GPU shared (residency census): launch by launch for a while
+        w->resident_backoff--;
+        return 0;
+    }
     const DevWorld &d = w->d;
     // a sharded world: the ranks have agreed (mgx_halo_resident_connect) that ghost records travel inside the launches
     const bool sharded = w->xres.connected;
@@ -1372,15 +1468,11 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
         return sharded ? fail(MGX_ERR_STATE, "resident launches were agreed on with the other ranks, but this rank's robots no longer fit LDS") : 0;
     int &cap = sharded ? w->resident_cap_sharded : w->resident_cap;
     if (cap < 0) cap = sweep_resident_capacity(d, sharded);
-    if (d.R_local > cap)
+    if (d.R_local + (sharded ? 0 : 1) > cap)  // (+ the residency census' decider workgroup: one slot kept free for it)
         return sharded ? fail(MGX_ERR_STATE, "resident launches were agreed on with the other ranks, but only %d of this rank's %d workgroups "
                                              "are resident at once", cap, d.R_local) : 0;
     rc = ensure_resident_tables(w);
     if (rc != MGX_OK) return rc;
-    if (sharded && plan[0].ext) {  // segment 0 reads the ghosts' plain copies: one direct exchange in front of the launch
-        rc = direct_exchange(w);
-        if (rc != MGX_OK) return rc;
-    }
     static const long long timeout_ticks = [] {
         const char *e = getenv("MGX_RESIDENT_TIMEOUT_MS");
         const long long ms = e ? atoll(e) : 2000;
@@ -1397,15 +1489,66 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
         }
         sp.flag_base = w->flag_base;
         sp.timeout_ticks = timeout_ticks;
-        HIP_TRY(launch_robot_schedule(w->d, w->d.R_local, sp, sharded, false, w->stream));
+        // residency census + clean abort (SegPlan): single-rank worlds — the ranks of a sharded world would have to abort
+        // together, they keep the plain bound on every wait
+        static const long long census_ticks = [] {
+            const char *e = getenv("MGX_RESIDENT_CENSUS_US");
+            const long long us = e ? atoll(e) : 200;
+            return (us > 0 ? us : 200) * 100ll;  // 100 MHz wall clock
+        }();
+        static const bool census_on = [] { const char *e = getenv("MGX_RESIDENT_CENSUS"); return !(e && e[0] == '0'); }();
+        const bool census = !sharded && census_on;  // MGX_RESIDENT_CENSUS=0: plain bound on every wait, as on sharded worlds
+        if (census) {
+            if (i0 > 0 && (rc = confirm_resident(w)) != MGX_OK) return rc;  // the previous part of this schedule
+            if (i0 > 0 && w->resident_backoff > 0) {  // ... was sent back: the rest follows it launch by launch
+                for (size_t i = i0; i < plan.size(); i++)
+                    if ((rc = sweep(w, -1, plan[i].ext, plan[i].n_int ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, plan[i].n_int, plan[i].hints)) != MGX_OK) return rc;
+                return 1;
+            }
+            sp.launch_seq = ++w->launch_seq;
+            sp.census_ticks = census_ticks;
+        }
+        if (sharded && sp.ext[0]) {  // segment 0 reads the ghosts' plain copies: one direct exchange in front of the launch
+            rc = direct_exchange(w);
+            if (rc != MGX_OK) return rc;
+        }
+        // MGX_COOPERATIVE=1: hipLaunchCooperativeKernel — the runtime checks the grid against the occupancy query at launch
+        // time (same residency as a plain launch, +15..19 us of host time per launch: MI355X_MICROARCH.md); a grid it turns
+        // down takes the launch-per-segment path from now on instead of waiting for workgroups that never become resident
+        static const bool cooperative = [] { const char *e = getenv("MGX_COOPERATIVE"); return e && e[0] == '1'; }();
+        const hipError_t le = launch_robot_schedule(w->d, w->d.R_local, sp, sharded, cooperative, w->stream);
+        if (le != hipSuccess) {
+            (void)hipGetLastError();
+            if (cooperative && le == hipErrorCooperativeLaunchTooLarge && i0 == 0 && !sharded) {
+                cap = 0;  // until the topology (hence the workgroup's LDS) changes
+                return 0;
+            }
+            return fail(MGX_ERR_HIP, "resident schedule launch: %s", hipGetErrorString(le));
+        }
         w->last_sweep_launches++;
+        if (census) {  // what confirm_resident needs to take the launch back and run it again launch by launch
+            mgx_world::PendingResident &pd = w->pending;
+            pd.active = true;
+            pd.seq = sp.launch_seq;
+            pd.segs.clear();
+            pd.hints.clear();
+            for (int k = 0; k < sp.n; k++) {
+                const Launch &l = plan[i0 + (size_t)k];
+                pd.segs.emplace_back(l.ext, l.n_int);
+                pd.hints.push_back(l.hints);
+            }
+            pd.cur_before = w->d.cur;
+            pd.flag_base_before = w->flag_base;
+            pd.upd = w->d.upd; pd.upd_max_speed = w->d.upd_max_speed; pd.upd_delta_t = w->d.upd_delta_t;
+        }
         w->d.upd = nullptr;  // mgx_tick's prior updates ride in the first launch only
         w->d.cur = (w->d.cur + sp.n) & 1;
         w->flag_base += (unsigned long long)sp.n;
-        for (int k = 0; k < sp.n; k++) {
-            const Launch &l = plan[i0 + (size_t)k];
-            log_launch(w, -1, l.ext, l.n_int ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, l.n_int);
-        }
+        if (!census)
+            for (int k = 0; k < sp.n; k++) {
+                const Launch &l = plan[i0 + (size_t)k];
+                log_launch(w, -1, l.ext, l.n_int ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, l.n_int);
+            }
     }
     return 1;
 }
@@ -1443,6 +1586,7 @@ int mgx_world_destroy(mgx_world *w) {
     if (w->direct.recv) (void)hipFree(w->direct.recv);
     if (w->direct.flags) (void)hipFree(w->direct.flags);
     if (w->xres.area) (void)hipFree(w->xres.area);
+    if (w->decision_host) (void)hipHostFree(w->decision_host);
     if (w->sweep_err_host) (void)hipHostFree(w->sweep_err_host);
     if (w->mission.ev_host) (void)hipHostFree(w->mission.ev_host);
     if (w->mission.tr_host) (void)hipHostFree(w->mission.tr_host);
@@ -1460,6 +1604,7 @@ int mgx_set_stream(mgx_world *w, void *hip_stream) {
 int mgx_synchronize(mgx_world *w) {
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (!device_ok()) return fail(MGX_ERR_NO_DEVICE, "no usable HIP device");
+    if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     HIP_TRY(hipStreamSynchronize(w->stream));
     return check_device_error(w);
 }
@@ -2588,6 +2733,7 @@ int mgx_set_resident_launches(mgx_world *w, int32_t enabled) {
 }
 int mgx_last_launch_count(mgx_world *w, uint32_t *n_launches) {
     if (!w || !n_launches) return fail(MGX_ERR_INVALID, "null argument");
+    if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     *n_launches = w->last_sweep_launches;
     return MGX_OK;
 }
@@ -2624,6 +2770,7 @@ int mgx_read_variable_means(mgx_world *w, uint32_t var_ix, double *means) {
 // FactorGraph::messages_sent / messages_received (factorgraph.rs:876-890) of one robot's graph
 int mgx_message_counts(mgx_world *w, int32_t robot, uint64_t counts[4]) {
     if (!w || !counts || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
+    if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     if (w->robots[(size_t)robot].ghost) return fail(MGX_ERR_INVALID, "robot %d is a ghost here: its graph is counted on the rank that owns it", robot);
     flush_counts(w);
     const Robot &rb = w->robots[(size_t)robot];
@@ -2748,6 +2895,7 @@ int mgx_halo_plan_from_connections(mgx_world *w, const int32_t *rank_of, uint32_
 }
 
 static int halo_commit(mgx_world *w) {
+    if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     // Changed connections alone (conns_dirty) are left to the next sweep: an exchange does not read the
     // edge tables, and the edges created by a topology pass must find the ghosts' records of the exchange
     // that follows the pass (their creation epoch is the owner's delivery count at that moment).

@@ -250,7 +250,10 @@ def lib(fma=None):
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
         _preload_hip_runtime()
         L = C.CDLL(path)
+        experiment = not key and "MGX_LIB" in os.environ  # an older / diagnostic build named by MGX_LIB may lack newer entry points
         for name, (res, args) in SYMBOLS.items():
+            if experiment and not hasattr(L, name):
+                continue
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

@@ -285,12 +285,21 @@ def junction_environment(tiles):
 
 
 def junction_scenario(n_robots, K=32, tiles=None, comm_radius=20.0, seed=805, target_speed=5.0, radius=1.0,
-                      n_internal=10, n_external=10, tracking=True, interrobot=True):
+                      n_internal=10, n_external=10, tracking=True, interrobot=True, connect_after_ticks=1):
     """BASELINE.json configs[4] (SURVEY.md §8d "Config 5"): a `tiles` x `tiles` grid of two-way
     crossroads rasterised by the env_to_png rule ON THE DEVICE (World.set_environment), robots on
     the lanes of config/scenarios/Junction Twoway/formation.yaml (4 m off the centre line, entering
     from the four sides, turning left / right or driving across), each with its 2-3 point lane
-    polyline as tracking path, Junction Twoway sigmas and communication radius."""
+    polyline as tracking path, Junction Twoway sigmas and communication radius.
+
+    connect_after_ticks (default 1): the robots run that many driver ticks on their own before the inter-robot factors are
+    created — the order the reference's driver works in (create_interrobot_factors, robot.rs:1441-1586, hooks up robots that
+    have been iterating since they spawned; a factor starts from its target's current belief, :1549-1585).  `populate` does
+    it: the pairs are in sc["ir_late"], sc["ir"] (connected before the first sweep) is empty.  With inter-robot AND tracking
+    factors on robots that have never iterated, the reference's own arithmetic leaves the finite range within a tick (the first
+    inter-robot messages are Schur complements of rank-1 blocks next to the rounding residue of the dynamics factors, DESIGN.md
+    §2); after one tick on their own the beliefs are formed and the same 4000 x 32 world stays finite.  0: everything at once
+    (what a sharded world, which plans its ghosts from sc["ir"], is built from)."""
     rng = SplitMix64(seed)
     per_tile = 10
     if tiles is None:
@@ -335,7 +344,9 @@ def junction_scenario(n_robots, K=32, tiles=None, comm_radius=20.0, seed=805, ta
     params = dict(JUNCTION_PARAMS, enable_mask=enable)
     ir = number_ir_pairs(neighbour_pairs(pos, comm_radius) if interrobot else [], K)
     steps = hostlib.schedule(hostlib.SCHEDULE_CENTERED, n_internal, n_external if interrobot else 0)
-    return dict(params=params, env=junction_environment(tiles), sdf=None, robots=robots, ir=ir, steps=steps, K=K, positions=pos,
+    late = connect_after_ticks > 0 and bool(ir)
+    return dict(params=params, env=junction_environment(tiles), sdf=None, robots=robots, ir=[] if late else ir, ir_late=ir if late else [],
+                connect_after_ticks=connect_after_ticks if late else 0, steps=steps, K=K, positions=pos,
                 target_speed=target_speed, name=f"junction{n_robots}x{K}+{tiles}x{tiles}tiles")
 
 
@@ -361,6 +372,12 @@ def populate(world, sc, robots=None):
                                    order_key=rb["order_key"]))
     for a, b, n0 in sc["ir"]:
         world.ir_connect(ids[a], ids[b], n0)
+    if sc.get("ir_late"):  # robots that have iterated on their own before they meet (junction_scenario, connect_after_ticks)
+        tick = tick_inputs(sc)
+        for _ in range(sc["connect_after_ticks"]):
+            world.tick(steps=sc["steps"], **tick)
+        for a, b, n0 in sc["ir_late"]:
+            world.ir_connect(ids[a], ids[b], n0)
     return ids
 
 

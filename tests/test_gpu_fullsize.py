@@ -106,11 +106,14 @@ def _two_ticks(sc, finite=False):
 
 
 def test_config4_full_size_junction_tiles():
+    """BASELINE configs[4] as SURVEY §8d words it, at full size, in the regime where the reference's arithmetic holds numbers: the
+    robots iterate one tick on their own before create_interrobot_factors hooks them up (the reference's driver order; see
+    scenarios.junction_scenario) — dynamic + obstacle + inter-robot + tracking factors, 4000 x 32: bit-identical, every belief finite."""
     sc = S.junction_scenario(4000, 32, tiles=20)
     assert len(sc["robots"]) == 4000 and sc["K"] == 32 and sc["params"]["enable_mask"] == 15
     assert all(rb["path"] is not None and len(rb["path"]) >= 2 for rb in sc["robots"])
-    assert len(sc["ir"]) > 4000
-    eng, ref = _two_ticks(sc)
+    assert len(sc["ir_late"]) > 4000 and not sc["ir"] and sc["connect_after_ticks"] == 1
+    eng, ref = _two_ticks(sc, finite=True)
     # the tracking factors did fire: switching them off changes the result
     sc2 = dict(sc, params=dict(sc["params"], enable_mask=7))
     off = World(sc2["params"])
@@ -119,6 +122,15 @@ def test_config4_full_size_junction_tiles():
     for _ in range(2):
         off.tick(steps=sc2["steps"], **tick)
     assert not np.array_equal(off.read_beliefs()[2], eng.read_beliefs()[2], equal_nan=True)
+
+
+def test_config4_everything_at_once_leaves_the_finite_range_identically():
+    """the robustness variant: inter-robot AND tracking factors on robots that have never iterated — the reference's arithmetic
+    itself goes through 1e+100 to inf / NaN within a tick; engine and oracle agree wherever the oracle holds a number"""
+    sc = S.junction_scenario(4000, 32, tiles=20, connect_after_ticks=0)
+    assert len(sc["ir"]) > 4000
+    eng, ref = _two_ticks(sc)
+    assert not all(np.isfinite(x).all() for x in ref.read_beliefs())
 
 
 def test_config4_full_size_grid():
@@ -189,3 +201,33 @@ def test_resident_launch_with_one_directional_connections():
             w.tick(steps=sc["steps"], **tick)
         assert eng.last_launch_count() == 1 or not RESIDENT
         assert_identical(eng, ref, what=f"one-directional connections, tick {t}")
+
+
+def test_resident_launch_next_to_another_tenant_of_the_gpu():
+    """Every workgroup of a resident schedule launch waits for its neighbours INSIDE the launch, and a plain launch promises
+    co-residency to nobody: here a second stream of the process keeps the CUs busy with f64 matrix products while a 1000-robot
+    world ticks, so that part of a resident launch's grid cannot start (measured: without the residency census such a launch
+    waits until its 2 s bound and leaves the world invalid — the workgroups that spin hold what the other tenant's next
+    workgroups need, and the tail of the grid queues behind those).  With the census the launch notices before it has written
+    anything, returns, and the host runs that schedule launch by launch (and the next few, backing off): the beliefs are the
+    oracle's, bit for bit, and no error is raised."""
+    import torch
+    sc = S.grid_scenario(1000, 16, interrobot=True)
+    eng, ref = World(sc["params"]), oracle.OracleWorld(sc["params"], threads=ORACLE_THREADS)
+    assert S.populate(eng, sc) == S.populate(ref, sc)
+    tick = S.tick_inputs(sc)
+    hog = torch.cuda.Stream()
+    a = torch.randn(3072, 3072, dtype=torch.float64, device="cuda")
+    with torch.cuda.stream(hog):
+        for _ in range(6):  # ~0.1 s of other work in flight on the second stream
+            a = (a @ a) * 1e-3
+    for t in range(3):
+        eng.tick(steps=sc["steps"], **tick)
+        with torch.cuda.stream(hog):
+            a = (a @ a) * 1e-3
+        assert eng.last_launch_count() in (1, len(sc["steps"]) + 1)  # resident, or sent back and run launch by launch
+    eng.synchronize()  # raises if a wait inside a resident launch gave up
+    hog.synchronize()
+    for t in range(3):
+        ref.tick(steps=sc["steps"], **tick)
+    assert_identical(eng, ref, what="resident launches next to a second stream's matrix products")

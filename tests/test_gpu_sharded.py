@@ -133,7 +133,7 @@ def test_rccl_transport_loads_and_runs_with_one_rank():
 def test_sharded_junction_scenario_rasterises_on_every_rank():
     """BASELINE configs[4] in small, sharded: every rank rasterises the crossroads itself
     (mgx_world_set_environment) and the cluster's beliefs equal the single-world oracle's."""
-    sc = S.junction_scenario(60, 12, tiles=2)
+    sc = S.junction_scenario(60, 12, tiles=2, connect_after_ticks=0)  # a sharded world plans its ghosts from sc["ir"]
     cluster = sharded.LocalCluster(sc, 3, World)
     assert any(sw.plan.ghosts for sw in cluster.ranks)
     ref = oracle.OracleWorld(sc["params"])
