@@ -10,7 +10,9 @@
 // separation alone exceeds the radius).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
+#include <limits>
 
 #include "gbp_math.h"
 
@@ -25,6 +27,16 @@ __device__ __forceinline__ bool in_comms_range(float ax, float ay, float az, flo
     const float s = (float)((double)(float)((double)px + (double)py) + (double)pz);
     const float d = (float)sqrt((double)s);
     return !(radius < d);
+}
+
+// the same predicate with the f32 operations spelled as round-to-nearest intrinsics (never contracted either); squared form:
+// sqrt is monotone and correctly rounded, so !(radius < sqrt(s)) == !(r2_hi < s) for the largest f32 r2_hi whose root does
+// not exceed radius — the caller passes that threshold (threshold_of), and a NaN s (or radius) still answers "in range"
+// exactly as the comparison above does
+__device__ __forceinline__ bool in_comms_range_sq(float ax, float ay, float az, float bx, float by, float bz, float s_max) {
+    const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+    const float s = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    return !(s_max < s);
 }
 
 __device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
@@ -67,6 +79,87 @@ __global__ void __launch_bounds__(256) k_pairs(const float *__restrict__ pos, in
             }
     }
     if (!FILL && live) cnt[i] = m;
+}
+
+// ---- all pairs, ONE pass, rows of a fixed capacity (small worlds) ------------------------------------
+// A world of a few thousand robots is searched faster by one small kernel than by the six launches and three clears
+// of the grid: one 64-lane workgroup per 64 robots, positions of j tiled through LDS, row i written in place
+// (rows[i * cap + m], ascending j) and counted; a row that outgrows `cap` keeps counting, and the host repeats the
+// search with a larger capacity (it remembers the largest row).  One wave, a handful of registers and < 1 KB of LDS per
+// workgroup: the kernel finds room on a device whose CUs are otherwise taken by a resident schedule launch, so a search
+// enqueued beside that launch (on a stream of its own) does not have to wait for it.
+// Four lanes per robot (sixteen robots per workgroup): of every tile of 64 candidates lane l tests candidates 16 l .. 16 l + 15, so the
+// four lanes' hits, one lane after the other, are ascending in j.
+__global__ void __launch_bounds__(64) k_pairs_rows(const float *__restrict__ pos, int n, float s_max, int32_t cap,
+                                                   int32_t *__restrict__ cnt, int32_t *__restrict__ rows) {
+    __shared__ float tile[64 * 3];
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 2), l = threadIdx.x & 3;
+    const bool live = i < n;
+    const float ax = live ? pos[3 * i] : 0.f, ay = live ? pos[3 * i + 1] : 0.f, az = live ? pos[3 * i + 2] : 0.f;
+    int m = 0;  // hits of robot i so far (the same in its four lanes)
+    int32_t *row = rows + (size_t)(live ? i : 0) * (size_t)cap;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int nj = min(64, n - j0);
+        __syncthreads();
+#pragma unroll 1
+        for (int q = threadIdx.x; q < 3 * nj; q += 64) tile[q] = pos[3 * j0 + q];  // (three trips at most)
+        __syncthreads();
+        unsigned hits = 0u;
+#pragma unroll 1
+        for (int k = 0; k < 16; k++) {  // (not unrolled: the kernel has to stay within 32 registers, see above)
+            const int q = 16 * l + k, j = j0 + q;
+            if (live && q < nj && j != i && in_comms_range_sq(ax, ay, az, tile[3 * q], tile[3 * q + 1], tile[3 * q + 2], s_max)) hits |= 1u << k;
+        }
+        const int c = __popc(hits);
+        int before = 0, all = 0;  // hits of the lower lanes of the quad, of the whole quad
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            const int co = __shfl(c, (threadIdx.x & ~3) + o, 64);
+            before += o < l ? co : 0;
+            all += co;
+        }
+        int at = m + before;
+        while (hits) {
+            const int k = __ffs(hits) - 1;
+            hits &= hits - 1u;
+            if (at < cap) row[at] = j0 + 16 * l + k;
+            at++;
+        }
+        m += all;
+    }
+    if (live && l == 0) cnt[i] = m;
+}
+// the largest f32 s with RN_f32(sqrt(s)) <= radius (see in_comms_range_sq); NaN radius -> NaN (everybody in range), radius < 0 ->
+// negative (nobody but NaN distances)
+static float squared_threshold(float radius) {
+    if (radius != radius) return radius;
+    if (radius < 0.f) return -1.f;
+    if (std::isinf(radius)) return radius;
+    auto root = [](float s) { return (float)std::sqrt((double)s); };
+    float s = (float)((double)radius * (double)radius);
+    if (std::isinf(s)) s = std::numeric_limits<float>::max();
+    while (root(s) > radius) s = std::nextafter(s, -1.f);
+    for (;;) {
+        const float up = std::nextafter(s, std::numeric_limits<float>::infinity());
+        if (std::isinf(up) || root(up) > radius) break;
+        s = up;
+    }
+    return s;
+}
+// positions from the callers' pinned block into device memory, by a kernel as small as the search itself (every workgroup of
+// the search reads all of them: over the host link that would be the search's whole time)
+__global__ void __launch_bounds__(64) k_stage_positions(const float *__restrict__ src, float *__restrict__ dst, int n3) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t < n3) dst[t] = src[t];
+}
+hipError_t neighbours_rows(const float *pos, int n, float radius, int32_t cap, int32_t *cnt, int32_t *rows, hipStream_t s, float *stage) {
+    if (n <= 0) return hipSuccess;
+    if (stage) {
+        hipLaunchKernelGGL(k_stage_positions, dim3((unsigned)((3 * n + 63) / 64)), dim3(64), 0, s, pos, stage, 3 * n);
+        pos = stage;
+    }
+    hipLaunchKernelGGL(k_pairs_rows, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, s, pos, n, squared_threshold(radius), cap, cnt, rows);
+    return hipGetLastError();
 }
 
 // ---- hash grid ------------------------------------------------------------------------------------

@@ -17,6 +17,7 @@
 #include <dlfcn.h>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -73,6 +74,7 @@ hipError_t neighbours_count(const float *pos, int n, float radius, bool grid, ui
 hipError_t neighbours_fill(const float *pos, int n, float radius, bool grid, uint32_t M, const int32_t *bucket_ptr,
                            const int32_t *members, const int32_t *special, const int32_t *n_special, const int32_t *ptr,
                            int32_t *idx, int32_t cap, hipStream_t s);
+hipError_t neighbours_rows(const float *pos, int n, float radius, int32_t cap, int32_t *cnt, int32_t *rows, hipStream_t s, float *stage);
 }  // namespace mgx
 
 using namespace mgx;
@@ -226,7 +228,6 @@ struct Robot {
         if (!free_nodes.empty()) { const int ix = free_nodes.back(); free_nodes.pop_back(); return ix; }
         return n_nodes++;
     }
-    std::vector<int> connected;  // RobotConnections::robots_connected_with (robot.rs:515-531), ascending order key
     // MessageCount of the graph's permanent nodes (variables, dynamic / obstacle / tracking factors):
     // sent internal, sent external, received internal, received external (factorgraph/mod.rs:29-137)
     uint64_t cnt[4] = {0, 0, 0, 0};
@@ -247,16 +248,20 @@ struct IrEdge {  // one InterRobotFactor, kept at its target variable
     bool fresh = true;  // created since the last commit: state is initialised at commit
 };
 struct IrConn {  // K-1 factors owner -> other
+    // (what the per-tick host passes over ALL connections read — counters, table rebuild — sits in the first cache line)
     int owner, other;
+    int32_t dev_slot = -1;  // slot of this connection in its target's incoming list on the device (-1: not there)
+    bool has_fresh = true;  // some edge still carries `fresh` (created since the device tables were last laid out)
     uint64_t first_number;
-    std::vector<IrEdge> edges;  // index i-1 for variable i
-    std::vector<int> node;      // node slot of each factor in the owner's graph
     uint64_t cnt[4] = {0, 0, 0, 0};  // MessageCount summed over the K-1 factors
     // Sum over the factors of how often each one's node slot occurs in the owner's
     // interrobot_factor_indices: that list is never pruned (factorgraph.rs:729-733), so a factor in a
     // re-used slot is updated once per occurrence in every external sweep — same message, but every
     // update counts as sent / received.
     uint64_t updates_per_sweep = 0;
+    int node_first = 0, node_last = 0;  // node[0], node.back(): what orders two connections of one owner in an inbox
+    std::vector<IrEdge> edges;  // index i-1 for variable i
+    std::vector<int> node;      // node slot of each factor in the owner's graph
     // Factors created while their kind is switched off drop the two messages that would have filled their inbox
     // (factor/mod.rs:307-310), and FactorNode::update answers inbox KEYS: once enabled, such a factor sends nothing to
     // a variable that has not delivered to it yet.  The messages themselves are handled on the device (delivery
@@ -264,8 +269,40 @@ struct IrConn {  // K-1 factors owner -> other
     // bit 1 = the foreign variable's; `uses` = the factor's share of updates_per_sweep.  Empty: every key is there.
     std::vector<uint8_t> keys;
     std::vector<uint32_t> uses;
-    int32_t dev_slot = -1;  // slot of this connection in its target's incoming list on the device (-1: not there)
-    bool has_fresh = true;  // some edge still carries `fresh` (created since the device tables were last laid out)
+};
+
+// RobotConnections::robots_connected_with of every robot (robot.rs:515-531), ascending order key — ONE contiguous pool, rows of a
+// fixed capacity: the topology pass walks every robot's set every tick, and a thousand separately allocated vectors are a
+// thousand cache misses.  `keys`: the robots' order keys, compact, for the merges of that pass.
+struct ConnSets {
+    int cap = 16;
+    std::vector<int32_t> ids, cnt;
+    std::vector<uint64_t> keys;
+    void ensure(size_t n) {
+        if (cnt.size() < n) { cnt.resize(n, 0); ids.resize(n * (size_t)cap, 0); }
+    }
+    int32_t *row(size_t r) { return ids.data() + r * (size_t)cap; }
+    const int32_t *row(size_t r) const { return ids.data() + r * (size_t)cap; }
+    void grow() {
+        const int nc = cap * 2;
+        std::vector<int32_t> ni(cnt.size() * (size_t)nc, 0);
+        for (size_t r = 0; r < cnt.size(); r++) std::copy(row(r), row(r) + cnt[r], ni.begin() + (long)(r * (size_t)nc));
+        ids.swap(ni);
+        cap = nc;
+    }
+    bool has(size_t r, int id) const { return std::find(row(r), row(r) + cnt[r], id) != row(r) + cnt[r]; }
+    void insert_sorted(size_t r, int id) {  // keeps the row ascending in order key
+        if (cnt[r] == cap) grow();
+        int32_t *b = row(r), *e = b + cnt[r];
+        int32_t *at = std::upper_bound(b, e, id, [&](int x, int y) { return keys[(size_t)x] < keys[(size_t)y]; });
+        std::copy_backward(at, e, e + 1);
+        *at = id;
+        cnt[r]++;
+    }
+    void erase(size_t r, int id) {
+        int32_t *b = row(r), *e = b + cnt[r];
+        cnt[r] = (int32_t)(std::remove(b, e, id) - b);
+    }
 };
 
 // RCCL, resolved at run time (no link-time dependency): the copy already in the process (a host that
@@ -314,6 +351,7 @@ struct mgx_world {
     mgx_params p{};
     std::vector<Robot> robots;  // ids = indices; ghosts may interleave on the host, device order below
     std::vector<IrConn> conns;
+    ConnSets sets;  // robots_connected_with of every robot
     std::vector<uint8_t> sdf_red;
     uint32_t sdf_w = 0, sdf_h = 0;
     double world_w = 1.0, world_h = 1.0;
@@ -410,7 +448,11 @@ struct mgx_world {
     } mission;
     // a neighbour search that has been enqueued and not collected yet (neighbours_enqueue / neighbours_collect)
     struct PendingSearch {
+        hipStream_t stream = nullptr;  // where it was enqueued
         bool valid = false, compact = false, grid = false;
+        bool rows = false;  // the one-pass kernel with rows of a fixed capacity (small worlds, AUTO)
+        bool from_missions = false;
+        int row_cap = 0;
         int n = 0, n_all = 0;
         std::vector<int> alive;
         size_t guess = 0, off_ptr = 0, off_idx = 0;
@@ -465,6 +507,9 @@ struct mgx_world {
     DevBuf<float> nb_pos;
     DevBuf<int32_t> nb_cnt, nb_bucket_cnt, nb_bucket_ptr, nb_cursor, nb_members, nb_special, nb_nspecial, nb_ptr, nb_idx;
     size_t nb_last_total = 0;  // rows of the last search: sizes the speculative second pass of the next one
+    int nb_row_cap = 16;       // one-pass searches: capacity of a row (grown to what the largest row needed)
+    hipStream_t search_stream = nullptr, nb_last_stream = nullptr;  // searches over host-supplied positions run beside the world's stream
+    bool nb_last_stream_set = false;
     // pinned host memory the search's positions go up from and its rows come back into: copies to and from pageable memory
     // (std::vector) are staged by the runtime, tens of microseconds each
     struct PinBuf {
@@ -477,7 +522,7 @@ struct mgx_world {
             p = nullptr;
             cap = 0;
             const size_t want = bytes + bytes / 2 + 4096;
-            const hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+            const hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);  // the one-pass search reads and writes it in place
             if (e == hipSuccess) cap = want;
             return e;
         }
@@ -739,7 +784,7 @@ static void flush_counts(mgx_world *w) {
             c.cnt[2] += nIv[(size_t)c.owner] * (uint64_t)(K - 1);            // own variables' responses (internal sweeps)
             if (radio_a) c.cnt[3] += nEv[(size_t)c.other] * (uint64_t)(K - 1);  // the foreign variables' responses (robot.rs:1842-1858)
             uint64_t to_own = nEf[(size_t)c.owner] * c.updates_per_sweep, to_foreign = to_own;  // external factor sweeps: one message per key
-            if (!c.keys.empty()) {  // some keys are still missing: replay the log in order until they are all there
+            if (w->n_keyless > 0 && !c.keys.empty()) {  // some keys are still missing: replay the log in order until they are all there
                 to_own = to_foreign = 0;
                 for (const mgx_world::CountEntry &e : w->clog) {
                     if (e.robot >= 0 && e.robot != c.owner) continue;  // per-robot launches run internal sweeps only
@@ -878,8 +923,8 @@ static void build_incoming(const mgx_world *w, int R_local, Incoming &t) {
             const IrConn &ca = w->conns[(size_t)a], &cb = w->conns[(size_t)b];
             const uint64_t ka = w->robots[(size_t)ca.owner].order_key, kb = w->robots[(size_t)cb.owner].order_key;
             if (ka != kb) return ka < kb;
-            if ((ca.node[0] < cb.node[0]) != (ca.node.back() < cb.node.back())) t.blocks_ok = false;
-            return ca.node[0] < cb.node[0];
+            if ((ca.node_first < cb.node_first) != (ca.node_last < cb.node_last)) t.blocks_ok = false;
+            return ca.node_first < cb.node_first;
         };
         for (int a = 1; a < n_in; a++) {  // insertion sort: a handful of connections per robot
             const int32_t v = seg[a];
@@ -987,7 +1032,14 @@ static int retopo(mgx_world *w) {
     w->conns_dirty = false;
     w->peers_valid = false;
     tm.lap("slot bookkeeping");
-    const int rc_flags = upload_flags(w);  // the gate bytes follow the edges
+    int rc_flags = MGX_OK;  // the gate bytes follow the edges (the robots' own flags only when they changed too)
+    if (w->flags_dirty) {
+        rc_flags = upload_flags(w);
+    } else {
+        HIP_TRY(w->ir_gate.reserve(NIs));
+        HIP_TRY(launch_edge_gates((int)NI, w->ir_rec.p, w->antenna.p, w->idle.p, w->ir_gate.p, s));
+        d.ir_gate = w->ir_gate.p;
+    }
     tm.lap("flags + gates");
     return rc_flags;
 }
@@ -1239,7 +1291,7 @@ static void log_launch(mgx_world *w, int robot, uint32_t ext_mask, uint32_t int_
 static int confirm_resident(mgx_world *w) {
     mgx_world::PendingResident &pd = w->pending;
     if (!pd.active) return MGX_OK;
-    const StageTimer clock("confirm");
+    StageTimer clock("confirm");
     const double t0 = StageTimer::now();
     unsigned long long v = 0;
     for (unsigned spins = 0;; spins++) {
@@ -1253,6 +1305,7 @@ static int confirm_resident(mgx_world *w) {
         }
     }
     pd.active = false;
+    clock.lap((v & 3ull) == RESIDENT_ABORT ? "launch ABORTED" : "launch decided: go");
     if ((v >> 2) == pd.seq && (v & 3ull) == RESIDENT_ABORT) {
         // nothing happened on the device: take the host's bookkeeping back and run the same schedule launch by launch
         w->resident_aborts++;
@@ -1586,6 +1639,7 @@ int mgx_world_destroy(mgx_world *w) {
     if (w->direct.recv) (void)hipFree(w->direct.recv);
     if (w->direct.flags) (void)hipFree(w->direct.flags);
     if (w->xres.area) (void)hipFree(w->xres.area);
+    if (w->search_stream) { (void)hipStreamSynchronize(w->search_stream); (void)hipStreamDestroy(w->search_stream); }
     if (w->decision_host) (void)hipHostFree(w->decision_host);
     if (w->sweep_err_host) (void)hipHostFree(w->sweep_err_host);
     if (w->mission.ev_host) (void)hipHostFree(w->mission.ev_host);
@@ -1686,7 +1740,9 @@ int mgx_robot_add(mgx_world *w, const mgx_robot_desc *d, int32_t *robot_id) {
         rb.trk_last_pos[2 * j + 1] = (float)d->mean0[4 * (j + 1) + 1];
     }
     if (d->n_path && d->path_xy) rb.path.assign(d->path_xy, d->path_xy + 2 * (size_t)d->n_path);
+    w->sets.keys.push_back(rb.order_key);
     w->robots.push_back(std::move(rb));
+    w->sets.ensure(w->robots.size());
     w->K = K;
     w->dirty = true;
     if (robot_id) *robot_id = (int32_t)w->robots.size() - 1;
@@ -1719,6 +1775,8 @@ static int ir_connect(mgx_world *w, int32_t owner, int32_t other, uint64_t first
         if (keyless) { c.keys.push_back(0); c.uses.push_back(u); }
     }
     if (keyless) w->n_keyless++;
+    c.node_first = c.node.front();
+    c.node_last = c.node.back();
     w->conns.push_back(std::move(c));
     w->conns_dirty = true;
     return MGX_OK;
@@ -1752,17 +1810,29 @@ static int ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
 
 // Several (a, b) deletions in one sweep over the connections (a topology pass deletes dozens):
 // same effect as ir_disconnect(a, b) for each pair in order.
-static void ir_disconnect_batch(mgx_world *w, const std::vector<std::pair<int, int>> &pairs) {
+// the connections listed by owner (what a batch of deletions looks its pairs up in)
+struct OwnerLists {
+    std::vector<int32_t> out_ptr, out;
+    bool valid = false;
+    void build(const mgx_world *w) {
+        const size_t n = w->robots.size();
+        out_ptr.assign(n + 1, 0);
+        for (const IrConn &c : w->conns) out_ptr[(size_t)c.owner + 1]++;
+        for (size_t r = 0; r < n; r++) out_ptr[r + 1] += out_ptr[r];
+        out.resize(w->conns.size());
+        std::vector<int32_t> fill(out_ptr.begin(), out_ptr.end() - 1);
+        for (size_t ci = 0; ci < w->conns.size(); ci++) out[(size_t)fill[(size_t)w->conns[ci].owner]++] = (int32_t)ci;
+        valid = true;
+    }
+};
+static void ir_disconnect_batch(mgx_world *w, const std::vector<std::pair<int, int>> &pairs, OwnerLists *prebuilt = nullptr) {
     if (pairs.empty()) return;
     StageTimer tm("ir_disconnect_batch");
     flush_counts(w);
     tm.lap("flush_counts");
-    const size_t n = w->robots.size();
-    std::vector<int32_t> out_ptr(n + 1, 0);  // connections by owner
-    for (const IrConn &c : w->conns) out_ptr[(size_t)c.owner + 1]++;
-    for (size_t r = 0; r < n; r++) out_ptr[r + 1] += out_ptr[r];
-    std::vector<int32_t> out(w->conns.size()), fill(out_ptr.begin(), out_ptr.end() - 1);
-    for (size_t ci = 0; ci < w->conns.size(); ci++) out[(size_t)fill[(size_t)w->conns[ci].owner]++] = (int32_t)ci;
+    OwnerLists own_lists;
+    if (!prebuilt || !prebuilt->valid) { own_lists.build(w); prebuilt = &own_lists; }
+    const std::vector<int32_t> &out_ptr = prebuilt->out_ptr, &out = prebuilt->out;
     std::vector<uint8_t> dead(w->conns.size(), 0);
     for (const auto &pr : pairs)
         for (int side = 0; side < 2; side++) {
@@ -1779,13 +1849,20 @@ static void ir_disconnect_batch(mgx_world *w, const std::vector<std::pair<int, i
             std::vector<int> &fr = w->robots[(size_t)self].free_nodes;
             fr.insert(fr.end(), gone.begin(), gone.end());
         }
-    size_t k = 0;
-    for (size_t ci = 0; ci < w->conns.size(); ci++)
-        if (!dead[ci]) {
-            if (k != ci) w->conns[k] = std::move(w->conns[ci]);
-            k++;
+    // the list's order carries no meaning (inbox order comes from order keys and node slots, build_incoming): the last
+    // survivors fill the holes
+    {
+        size_t lo = 0, hi = w->conns.size();
+        for (;;) {
+            while (lo < hi && !dead[lo]) lo++;
+            while (hi > lo && dead[hi - 1]) hi--;
+            if (lo >= hi) break;
+            w->conns[lo] = std::move(w->conns[hi - 1]);  // dead[lo], alive[hi - 1]
+            dead[lo] = 0;
+            hi--;
         }
-    w->conns.resize(k);
+        w->conns.resize(hi);
+    }
     tm.lap("connection list");
     if (w->n_keyless > 0) {  // some of them may just have gone
         w->n_keyless = 0;
@@ -1806,7 +1883,7 @@ int mgx_robot_remove(mgx_world *w, int32_t robot) {
     rb.removed = true;
     rb.idle = 1;
     rb.antenna = 0;
-    rb.connected.clear();
+    w->sets.cnt[(size_t)robot] = 0;
     w->flags_dirty = true;
     w->mission.alive_dirty = true;
     return MGX_OK;
@@ -1926,28 +2003,20 @@ int mgx_set_antennas(mgx_world *w, uint32_t n, const int32_t *robots, const uint
 }
 
 // ---- dynamic inter-robot topology (robot.rs:1362-1586) -----------------------------------------------
-static void sort_by_key(const mgx_world *w, std::vector<int> &v) {  // BTreeSet<Entity> order
-    std::sort(v.begin(), v.end(), [&](int a, int b) { return w->robots[(size_t)a].order_key < w->robots[(size_t)b].order_key; });
-}
 
 // The fine-grained calls keep robots_connected_with in step, as create_/delete_interrobot_factors
 // do (robot.rs:1406-1408,1546), so that they can be mixed with mgx_update_topology.
 int mgx_ir_connect(mgx_world *w, int32_t owner, int32_t other, uint64_t first_robot_number) {
     int rc = ir_connect(w, owner, other, first_robot_number);
     if (rc != MGX_OK) return rc;
-    std::vector<int> &cw = w->robots[(size_t)owner].connected;
-    if (std::find(cw.begin(), cw.end(), other) == cw.end()) {
-        cw.push_back(other);
-        sort_by_key(w, cw);
-    }
+    if (!w->sets.has((size_t)owner, other)) w->sets.insert_sorted((size_t)owner, other);
     return MGX_OK;
 }
 int mgx_ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
     int rc = ir_disconnect(w, a, b);
     if (rc != MGX_OK) return rc;
-    std::vector<int> &ca = w->robots[(size_t)a].connected, &cb = w->robots[(size_t)b].connected;
-    ca.erase(std::remove(ca.begin(), ca.end(), b), ca.end());
-    cb.erase(std::remove(cb.begin(), cb.end(), a), cb.end());
+    w->sets.erase((size_t)a, b);
+    w->sets.erase((size_t)b, a);
     return MGX_OK;
 }
 
@@ -1984,7 +2053,18 @@ static int neighbours_enqueue(mgx_world *w, const float *pos, float radius, uint
     if (!usable_radius) grid = false;  // radius <= 0 / NaN / inf: every pair has to see the predicate
     uint32_t M = 64;
     while (M < 2u * (uint32_t)std::max(n, 1)) M <<= 1;
+    // A search over positions the CALLER hands in reads nothing of the world's device state: it runs on a stream of its own,
+    // next to whatever the world's stream is still busy with (the previous tick's GBP schedule), instead of behind it.
+    // (The missions' search reads the device's Transforms, which the tick's kernels move: that one stays in stream order.)
     hipStream_t s = w->stream;
+    if (!from_missions) {
+        if (!w->search_stream) HIP_TRY(hipStreamCreateWithFlags(&w->search_stream, hipStreamNonBlocking));
+        s = w->search_stream;
+    }
+    if (w->nb_last_stream_set && w->nb_last_stream != s) HIP_TRY(hipStreamSynchronize(w->nb_last_stream));  // the scratch buffers are shared
+    w->nb_last_stream = s;
+    w->nb_last_stream_set = true;
+    ps.stream = s;
     HIP_TRY(w->nb_pos.reserve((size_t)3 * std::max(n, 1)));
     HIP_TRY(w->nb_cnt.reserve((size_t)std::max(n, 1)));
     HIP_TRY(w->nb_ptr.reserve((size_t)n + 1));
@@ -2006,6 +2086,28 @@ static int neighbours_enqueue(mgx_world *w, const float *pos, float radius, uint
         }
         HIP_TRY(launch_mission_positions(ms.d, n, ms.alive_d.p, w->nb_pos.p, s));
     }
+    // small worlds (AUTO): ONE small kernel, rows of a fixed capacity written in place, no scans (mgx_topology.hip)
+    const bool rows_mode = method == MGX_NEIGHBOURS_AUTO && n > 0 && n <= 4096;
+    if (rows_mode) {
+        const int cap = w->nb_row_cap;
+        const size_t off_cnt = sizeof(float) * 3 * (size_t)n, off_rows = off_cnt + sizeof(int32_t) * (size_t)n;
+        HIP_TRY(w->nb_pin.reserve(off_rows + sizeof(int32_t) * (size_t)n * (size_t)cap));
+        HIP_TRY(w->nb_idx.reserve((size_t)n * (size_t)cap));
+        char *pin = static_cast<char *>(w->nb_pin.p);
+        // no copies at all: the kernel reads the callers' positions from the pinned block and writes counts and rows into it
+        // (a copy is a launch of its own — a blit kernel too big to find room beside a resident schedule launch)
+        void *dpin = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dpin, pin, 0));
+        char *dp = static_cast<char *>(dpin);
+        if (!from_missions) memcpy(pin, pos, sizeof(float) * 3 * (size_t)n);
+        HIP_TRY(neighbours_rows(from_missions ? w->nb_pos.p : reinterpret_cast<const float *>(dp), n, radius, cap,
+                                reinterpret_cast<int32_t *>(dp + off_cnt), reinterpret_cast<int32_t *>(dp + off_rows), s, nullptr));
+        ps.n = n; ps.n_all = n_all; ps.compact = compact; ps.guess = 0; ps.off_ptr = off_cnt; ps.off_idx = off_rows;
+        ps.radius = radius; ps.method = method; ps.grid = false; ps.M = M; ps.rows = true; ps.row_cap = cap; ps.from_missions = from_missions;
+        ps.valid = true;
+        return MGX_OK;
+    }
+    ps.rows = false;
     const size_t guess = std::min(w->nb_idx.cap, w->nb_last_total + w->nb_last_total / 4 + 64);
     // pinned layout: [3 n floats: positions up] [n + 1 ints: row pointers down] [guess ints: rows down]
     const size_t off_ptr = sizeof(float) * 3 * (size_t)std::max(n, 1), off_idx = off_ptr + sizeof(int32_t) * ((size_t)n + 1);
@@ -2031,13 +2133,44 @@ static int neighbours_enqueue(mgx_world *w, const float *pos, float radius, uint
     return MGX_OK;
 }
 static int neighbours_collect(mgx_world *w, mgx_world::PendingSearch &ps, std::vector<int32_t> &ptr, std::vector<int32_t> &idx) {
-    hipStream_t s = w->stream;
+    hipStream_t s = ps.stream;
     const int n = ps.n, n_all = ps.n_all;
     const std::vector<int> &alive = ps.alive;
     const size_t guess = ps.guess;
     char *pin = static_cast<char *>(w->nb_pin.p);
     ps.valid = false;
     HIP_TRY(hipStreamSynchronize(s));
+    if (ps.rows) {
+        int cap = ps.row_cap;
+        const int32_t *cnt = reinterpret_cast<const int32_t *>(pin + ps.off_ptr);
+        int32_t longest = 0;
+        for (int i = 0; i < n; i++) longest = std::max(longest, cnt[i]);
+        if (longest > cap) {  // a row outgrew its capacity: once more with room (the world remembers)
+            while (cap < longest) cap *= 2;
+            w->nb_row_cap = cap;
+            const size_t off_rows = ps.off_ptr + sizeof(int32_t) * (size_t)n;
+            // the pinned block grows: the callers' positions it holds move along (a mission's are on the device)
+            std::vector<float> keep;
+            if (!ps.from_missions) keep.assign(reinterpret_cast<const float *>(pin), reinterpret_cast<const float *>(pin) + 3 * (size_t)n);
+            HIP_TRY(w->nb_pin.reserve(off_rows + sizeof(int32_t) * (size_t)n * (size_t)cap));
+            pin = static_cast<char *>(w->nb_pin.p);
+            if (!ps.from_missions) memcpy(pin, keep.data(), sizeof(float) * keep.size());
+            void *dpin = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&dpin, pin, 0));
+            char *dp = static_cast<char *>(dpin);
+            HIP_TRY(neighbours_rows(ps.from_missions ? w->nb_pos.p : reinterpret_cast<const float *>(dp), n, ps.radius, cap,
+                                    reinterpret_cast<int32_t *>(dp + ps.off_ptr), reinterpret_cast<int32_t *>(dp + off_rows), s, nullptr));
+            HIP_TRY(hipStreamSynchronize(s));
+            cnt = reinterpret_cast<const int32_t *>(pin + ps.off_ptr);
+        }
+        const int32_t *rows = reinterpret_cast<const int32_t *>(pin + ps.off_ptr + sizeof(int32_t) * (size_t)n);
+        ptr.assign((size_t)n + 1, 0);
+        for (int i = 0; i < n; i++) ptr[(size_t)i + 1] = ptr[(size_t)i] + cnt[i];
+        idx.resize((size_t)ptr[(size_t)n]);
+        for (int i = 0; i < n; i++)
+            if (cnt[i]) memcpy(idx.data() + ptr[(size_t)i], rows + (size_t)i * (size_t)cap, sizeof(int32_t) * (size_t)cnt[i]);
+        w->nb_last_total = idx.size();
+    } else {
     ptr.assign((size_t)n + 1, 0);
     memcpy(ptr.data(), pin + ps.off_ptr, sizeof(int32_t) * ((size_t)n + 1));
     const size_t total = (size_t)ptr[(size_t)n];
@@ -2052,6 +2185,7 @@ static int neighbours_collect(mgx_world *w, mgx_world::PendingSearch &ps, std::v
                                 w->nb_nspecial.p, w->nb_ptr.p, w->nb_idx.p, (int32_t)total, s));
         HIP_TRY(hipMemcpyAsync(idx.data(), w->nb_idx.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+    }
     }
     if (ps.compact) {  // back to world robot ids, empty rows for the removed ones
         for (int32_t &j : idx) j = alive[(size_t)j];
@@ -2092,16 +2226,17 @@ int mgx_neighbours(mgx_world *w, const float *positions_xyz, float radius, uint3
 
 int mgx_connections(mgx_world *w, int32_t robot, int32_t *others, uint32_t capacity, uint32_t *n) {
     if (!w || !n || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
-    const std::vector<int> &c = w->robots[(size_t)robot].connected;
-    *n = (uint32_t)c.size();
+    const int32_t *c = w->sets.row((size_t)robot);
+    const size_t nc = (size_t)w->sets.cnt[(size_t)robot];
+    *n = (uint32_t)nc;
     if (!others) return MGX_OK;
-    if (c.size() > capacity) return fail(MGX_ERR_INVALID, "capacity too small");
-    for (size_t i = 0; i < c.size(); i++) others[i] = c[i];
+    if (nc > capacity) return fail(MGX_ERR_INVALID, "capacity too small");
+    for (size_t i = 0; i < nc; i++) others[i] = c[i];
     return MGX_OK;
 }
 
 static int topology_bookkeeping(mgx_world *w, std::vector<int32_t> &ptr, std::vector<int32_t> &idx, uint64_t *robot_number_next,
-                                uint32_t *stats, StageTimer &tm);
+                                uint32_t *stats, StageTimer &tm, OwnerLists *own_lists);
 int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, uint32_t method, uint64_t *robot_number_next,
                         uint32_t *stats) {
     if (!w || !positions_xyz || !robot_number_next) return fail(MGX_ERR_INVALID, "null argument");
@@ -2109,18 +2244,42 @@ int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, 
     if (method > MGX_NEIGHBOURS_GRID) return fail(MGX_ERR_INVALID, "bad method");
     std::vector<int32_t> ptr, idx;
     StageTimer tm("update_topology");
-    int rc = neighbours(w, positions_xyz, radius, method, ptr, idx);  // update_robot_neighbours, robot.rs:1362-1384
+    // update_robot_neighbours (robot.rs:1362-1384): the search is enqueued (a small world's search runs BESIDE the GBP schedule
+    // of the tick before, on a stream of its own), and while the device gets to it the host does what does not need its
+    // result: the connections are listed by owner.  The message counters are brought up to date behind it (the pass is
+    // about to change who sends to whom): they wait for the last resident launch to be decided, which it is by then.
+    mgx_world::PendingSearch ps;
+    int rc = neighbours_enqueue(w, positions_xyz, radius, method, ps);
+    if (rc != MGX_OK) return rc;
+    tm.lap("search enqueued");
+    OwnerLists own_lists;
+    own_lists.build(w);
+    tm.lap("owner lists (under the search)");
+    // (under the search too, if the last resident launch has been decided by now — waiting for that here would only
+    // trade one wait for another)
+    const bool counters_early = !w->pending.active || (__atomic_load_n(w->decision_host, __ATOMIC_ACQUIRE) >> 2) >= w->pending.seq;
+    if (counters_early) {
+        flush_counts(w);
+        tm.lap("message counters (under the search)");
+    }
+    rc = neighbours_collect(w, ps, ptr, idx);
     if (rc != MGX_OK) return rc;
     tm.lap("neighbour search");
-    return topology_bookkeeping(w, ptr, idx, robot_number_next, stats, tm);
+    if (!counters_early) {
+        flush_counts(w);
+        tm.lap("message counters");
+    }
+    return topology_bookkeeping(w, ptr, idx, robot_number_next, stats, tm, &own_lists);
 }
 // delete_interrobot_factors + create_interrobot_factors on the search's result (rows per robot id, ascending)
 static int topology_bookkeeping(mgx_world *w, std::vector<int32_t> &ptr, std::vector<int32_t> &idx, uint64_t *robot_number_next,
-                                uint32_t *stats, StageTimer &tm) {
+                                uint32_t *stats, StageTimer &tm, OwnerLists *own_lists) {
     int rc = MGX_OK;
     const int n = (int)w->robots.size();
     uint32_t created = 0, deleted = 0;
-    auto in_range = [&](int r, int o) { return std::find(idx.begin() + ptr[(size_t)r], idx.begin() + ptr[(size_t)r + 1], o) != idx.begin() + ptr[(size_t)r + 1]; };
+    // a robot's row of the search and its connection set are both ascending in order key (BTreeSet<Entity>): merges
+    ConnSets &cs = w->sets;
+    auto key = [&](int x) { return cs.keys[(size_t)x]; };
 
     // delete_interrobot_factors (robot.rs:1386-1439).  The pairs pass through a
     // HashMap<RobotId, RobotId> filled with `extend` (:1391,1400-1404): one entry per robot, the
@@ -2130,43 +2289,51 @@ static int topology_bookkeeping(mgx_world *w, std::vector<int32_t> &ptr, std::ve
     std::vector<int> victim((size_t)n, -1);
     for (int r = 0; r < n; r++) {
         if (w->robots[(size_t)r].removed) continue;  // not in the query any more
-        std::vector<int> &cw = w->robots[(size_t)r].connected;
-        size_t kept = 0;
-        for (size_t q = 0; q < cw.size(); q++) {
+        int32_t *cw = cs.row((size_t)r);
+        const int32_t n_cw = cs.cnt[(size_t)r];
+        int32_t kept = 0;
+        int32_t j = ptr[(size_t)r];
+        const int32_t j1 = ptr[(size_t)r + 1];
+        for (int32_t q = 0; q < n_cw; q++) {
             const int o = cw[q];
-            if (in_range(r, o)) cw[kept++] = o;
+            while (j < j1 && key(idx[(size_t)j]) < key(o)) j++;
+            if (j < j1 && idx[(size_t)j] == o) cw[kept++] = o;  // still in range
             else victim[(size_t)r] = o;
         }
-        cw.resize(kept);
+        cs.cnt[(size_t)r] = kept;
     }
     {
         std::vector<std::pair<int, int>> pairs;
         for (int r = 0; r < n; r++)
             if (victim[(size_t)r] >= 0) pairs.emplace_back(r, victim[(size_t)r]);
         tm.lap("out-of-range scan");
-        ir_disconnect_batch(w, pairs);
+        ir_disconnect_batch(w, pairs, own_lists);
         deleted = (uint32_t)pairs.size();
         tm.lap("delete");
     }
 
     // create_interrobot_factors (robot.rs:1441-1586): new = within range \ connected, ascending,
     // snapshotted for every robot first (:1449-1461); K-1 robot numbers per connection (:1527)
-    std::vector<std::vector<int>> fresh((size_t)n);
+    std::vector<std::pair<int, int>> fresh;  // (robot, new neighbour), robots ascending, neighbours in row order
     for (int r = 0; r < n; r++) {
-        const std::vector<int> &cw = w->robots[(size_t)r].connected;
-        for (int32_t q = ptr[(size_t)r]; q < ptr[(size_t)r + 1]; q++)
-            if (std::find(cw.begin(), cw.end(), idx[(size_t)q]) == cw.end()) fresh[(size_t)r].push_back(idx[(size_t)q]);
+        const int32_t *cw = cs.row((size_t)r);
+        const int32_t n_cw = cs.cnt[(size_t)r];
+        int32_t q = 0;
+        for (int32_t j = ptr[(size_t)r]; j < ptr[(size_t)r + 1]; j++) {
+            const int o = idx[(size_t)j];
+            while (q < n_cw && key(cw[q]) < key(o)) q++;
+            if (!(q < n_cw && cw[q] == o)) fresh.emplace_back(r, o);
+        }
     }
     tm.lap("fresh scan");
-    for (int r = 0; r < n; r++)
-        for (int o : fresh[(size_t)r]) {
-            rc = ir_connect(w, r, o, *robot_number_next);
-            if (rc != MGX_OK) return rc;
-            *robot_number_next += (uint64_t)(w->K - 1);
-            w->robots[(size_t)r].connected.push_back(o);  // :1546
-            sort_by_key(w, w->robots[(size_t)r].connected);
-            created++;
-        }
+    for (const auto &f : fresh) {
+        const int r = f.first, o = f.second;
+        rc = ir_connect(w, r, o, *robot_number_next);
+        if (rc != MGX_OK) return rc;
+        *robot_number_next += (uint64_t)(w->K - 1);
+        cs.insert_sorted((size_t)r, o);  // :1546
+        created++;
+    }
     tm.lap("create");
     if (stats) { stats[0] = created; stats[1] = deleted; }
     return MGX_OK;
@@ -2347,7 +2514,7 @@ int mgx_mission_tick_begin(mgx_world *w, float comms_radius, uint32_t method, ui
         }
     }
     uint32_t st[2] = {0, 0};
-    rc = topology_bookkeeping(w, ptr, idx, robot_number_next, st, tm);
+    rc = topology_bookkeeping(w, ptr, idx, robot_number_next, st, tm, nullptr);
     if (rc != MGX_OK) return rc;
     if (stats) { stats[0] = st[0]; stats[1] = st[1]; stats[2] = n_fin; }
     ms.in_tick = true;
@@ -2613,7 +2780,9 @@ int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *wayp
     for (uint32_t i = 0; i < n; i++)
         if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size() || w->robots[(size_t)robots[i]].ghost || w->robots[(size_t)robots[i]].removed || (what[i] & ~3u))
             return fail(MGX_ERR_INVALID, "bad entry %u", i);
+    StageTimer tmk("tick");
     int rc = commit(w);
+    tmk.lap("commit (confirm + table rebuild)");
     if (rc != MGX_OK) return rc;
     const size_t RL = (size_t)w->d.R_local;
     void *hp = nullptr, *dp = nullptr;
@@ -2629,9 +2798,11 @@ int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *wayp
     }
     HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
     w->stale_kinds |= ~w->p.enable_mask & 15u;
+    tmk.lap("update records + counter log");
     {   // the whole tick as one resident launch when the world qualifies: the prior updates ride in it all the same
         w->d.upd = (const double *)dp; w->d.upd_max_speed = max_speed; w->d.upd_delta_t = delta_t;
         const int resident = run_resident(w, plan);
+        tmk.lap("resident launch enqueued");
         if (resident != 0) {
             w->d.upd = nullptr;
             hipError_t e = w->stage.release(slot, w->stream);

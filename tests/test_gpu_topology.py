@@ -284,3 +284,17 @@ def test_resident_capacity_follows_the_topology():
         eng.synchronize()  # raises if a wait inside a resident launch gave up
         assert_identical(eng, ref, what=f"comms radius {radius}")
     assert launches[0] == 1 and launches[1] == len(sc["steps"]) + 1 and launches[2] == launches[1], launches
+
+
+def test_one_pass_search_grows_its_rows():
+    """AUTO on a small world is ONE kernel that writes rows of a fixed capacity in place; a row that outgrows the capacity makes
+    the search run again with more room (and the pinned block it reads the callers' positions from may move)."""
+    n = 400
+    eng, ref, _ = bare_pair(n)
+    rng = np.random.default_rng(3)
+    for radius, spread in ((1.0, 30.0), (6.0, 10.0), (40.0, 10.0), (2.0, 30.0)):  # up to every robot in every row
+        pos = rng.uniform(-spread, spread, size=(n, 3)).astype(np.float32)
+        want = ref.neighbours(pos, radius)
+        for method in (hostlib.NEIGHBOURS_AUTO, PAIRS, GRID):
+            assert same_csr(eng.neighbours(pos, radius, method), want), (radius, method)
+    assert int(np.diff(want[0]).max()) < n
