@@ -1597,7 +1597,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             d[1] = (d[1] & 0xffffffffull) | ((t_extv - t_extf) << 32);    // external variable sweep (high word)
             if (PERSIST) {
                 d[0] = p_wait; d[1] = p_extf; d[2] = p_extv; d[3] = p_int; d[4] = p_pub;
-                unsigned long long *d2 = w.dbg + (size_t)(gridDim.x + 4) * 16 + ((size_t)blockIdx.x * 2 + role) * 16;
+                unsigned long long *d2 = w.dbg + (size_t)((census ? gridDim.x - 1 : gridDim.x) + 4) * 16 + ((size_t)blockIdx.x * 2 + role) * 16;
                 for (int i = 0; i < 16; i++) d2[i] = qs[i];
                 d2[14] = q_arrive;
             }
