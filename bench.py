@@ -518,11 +518,13 @@ def main():
     # exchange is then wired and measured HERE, in the bench process, and gives the headline
     children, probe_ok = {}, False
     if multi and not a.no_children:
+        guard.cancel()  # the children carry their own bound (run_children); the phases with collectives get a fresh one below
         children["direct"] = run_children(a, rank, local_rank, world_size, "direct-child", 23)
         if backend == "nccl":  # the in-library RCCL transport needs one GPU per rank
             children["rccl_in_engine"] = run_children(a, rank, local_rank, world_size, "rccl-child", 41)
         r = children["direct"] if rank == 0 else None
         flag = [bool(isinstance(r, dict) and isinstance(r.get("value"), (int, float)) and r.get("verified_against_host_driven_exchange"))]
+        guard = _Deadline(a.deadline, rank, line)
         dist.broadcast_object_list(flag, src=0)
         probe_ok = flag[0]
 

@@ -1943,6 +1943,17 @@ int mgx_set_enabled(mgx_world *w, uint32_t kind_mask) {
     if (((off & 2u) || ((on & 2u) & w->stale_kinds)) && !w->robots.empty()) {
         int rc = commit(w);
         if (rc != MGX_OK) return rc;
+        // A sharded world with the exchange inside the engine: the records frozen here and the delivery counts thawed against
+        // include the ghosts', which must be their owners' CURRENT ones — the plain copies are as old as the last exchange
+        // kernel (resident launches never touch them: the ghosts' records travel inside those).  Every rank switches
+        // together (ShardedWorld.set_enabled), so the exchange is one all ranks take part in.
+        if (w->direct.connected) {
+            rc = direct_exchange(w);
+            if (rc != MGX_OK) return rc;
+        } else if (w->rccl.connected) {
+            rc = rccl_exchange(w);
+            if (rc != MGX_OK) return rc;
+        }
         const size_t V = (size_t)w->d.V;
         if (!w->ir_frozen_live) {  // never frozen before: nothing was ever received (kind off since the world began)
             std::vector<double> z(24 * V, 0.0);

@@ -712,7 +712,13 @@ class LocalCluster:
 
     def set_enabled(self, mask):
         if len(self.ranks) > 1:
-            self._exchange()
+            if self.ranks[0].direct:
+                # the engine exchanges by itself when inter-robot factors are switched (the ghosts' plain copies are as old as the
+                # last exchange kernel): all pushes before the first wait, as in iterate
+                for sw in self.ranks:
+                    sw.world.halo_direct_exchange(hostlib.HALO_PUSH)
+            else:
+                self._exchange()
         for sw in self.ranks:
             sw.world.set_enabled(mask)
 

@@ -339,3 +339,30 @@ def test_resident_sharded_reports_a_missing_rank(monkeypatch):
     lonely.world.iterate([3, 3, 3])  # rank 1 never runs
     with pytest.raises(hostlib.MgxError):
         lonely.synchronize()
+
+
+def test_resident_sharded_switching_of_inter_robot_factors():
+    """Inter-robot factors switched off and on again on a sharded world whose ghost records travel inside resident launches: what
+    the factors freeze with and thaw against are the ghosts' CURRENT records (the engine exchanges them when the kind is switched:
+    the ghosts' plain copies are as old as the last exchange kernel), and the schedules that thaw run launch by launch."""
+    sc = S.grid_scenario(64, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
+    make, streams = _own_stream_factory()
+    cluster = sharded.LocalCluster(sc, 3, make, direct=True, resident=True)
+    assert cluster.resident
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    on = sc["params"]["enable_mask"]
+
+    def script(w):
+        w.iterate(sc["steps"])
+        w.iterate([1, 3, 1])          # ends with an internal iteration: the last exchange is one sweep old
+        w.set_enabled(on & ~S.EN_IR)
+        w.iterate([3, 3, 1])
+        w.set_enabled(on)
+        w.iterate([3, 3])
+        w.iterate(sc["steps"])
+    script(cluster)
+    script(ref)
+    for sw in cluster.ranks:
+        sw.synchronize()
+    assert_identical(cluster, ref, what="resident sharded launches, inter-robot factors switched off and on")
