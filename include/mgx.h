@@ -181,8 +181,15 @@ int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n);
 int mgx_last_launch_count(mgx_world *w, uint32_t *n_launches);
 /* Per-world switch for the above (default: on): 0 keeps every schedule of THIS world on the launch-per-segment path — what
  * MGX_PERSISTENT=0 does for the whole process.  For measuring one against the other; results are identical either way.
- * On a sharded world with resident launches agreed on (mgx_halo_resident_connect) every rank has to switch alike. */
+ * On a sharded world with resident launches agreed on (mgx_halo_resident_connect) every rank has to switch alike.
+ * 2 (diagnostic): on, but this world DECLINES every resident launch — on a sharded world whose ranks agree on every schedule
+ * it says no where the others look (mgx_halo_resident_connect), so every rank takes the fall-back; elsewhere like 0. */
 int mgx_set_resident_launches(mgx_world *w, int32_t enabled);
+/* Whether factors switched back on (mgx_set_enabled) are still taking their first updates from the inboxes they froze with
+ * (or inter-robot factors created while their kind was off still lack inbox keys): such schedules run launch by launch.
+ * On a sharded world this depends on the flags of the robots THIS rank holds, so the ranks ask each other (any rank still
+ * thawing keeps resident launches off on all of them: magics_amd/sharded.py does it after set_enabled). */
+int mgx_is_thawing(mgx_world *w, int32_t *thawing);
 
 /* The launch primitive the calls above and below are built on: one device pass per robot
  * that runs the external phases in `external_phases` (bit0 = external factor sweep + routing,
@@ -436,15 +443,47 @@ int mgx_halo_direct_disconnect(mgx_world *w);
  *      at once).  The ranks agree on that — all or none.
  *   2. mgx_halo_resident_connect with one entry per (local robot of the send list, rank that receives it): that rank's area,
  *      number of ghost slots, the robot's slot there, that rank's parity and segment count as returned by ITS setup.
+ *      coordinator_area / n_ranks: the area of rank 0 as this rank maps it (rank 0: its own) and the number of ranks of the
+ *      world.  The first word of that area is where the ranks AGREE on every schedule: the launches of one schedule wait for
+ *      each other's records, so they go ahead together or not at all.  Each rank's launch signs in there once all its own
+ *      workgroups are on the device; the last rank to sign in says go; a rank that has waited MGX_RESIDENT_CENSUS_SHARDED_US
+ *      (default 5000) for the others, or whose own workgroups do not all arrive (another tenant holds the CUs), or that cannot
+ *      run this schedule as a resident launch at all, says abort — by system-scope compare-and-swap on that one word, so every
+ *      rank reads the same answer before any of them has written anything.  After an abort every rank's world is as it was
+ *      and the schedule runs launch by launch with the direct exchange (the engine does that by itself, see
+ *      mgx_resident_outcome; the next few schedules skip the resident form — the same ones on every rank).
+ *      coordinator_area NULL or n_ranks < 2: no agreement; a rank whose peers never start then gives up after
+ *      MGX_RESIDENT_TIMEOUT_MS (default 2000) and reports MGX_ERR_STATE with the world invalid — never a hung GPU.
  * From then on mgx_iterate / mgx_tick run eligible schedules as one launch per rank (mgx_last_launch_count == 1); all ranks
- * must have connected (a rank that waits for a peer which never publishes gives up after MGX_RESIDENT_TIMEOUT_MS, default
- * 2000, and reports MGX_ERR_STATE — never a hung GPU).  A change of the world's layout (robots added / removed) disconnects. */
+ * must have connected.  A change of the world's layout (robots added / removed) disconnects. */
 int mgx_halo_resident_setup(mgx_world *w, void **area_base, uint32_t *n_ghost_slots, uint32_t *parity, uint64_t *segment_count,
                             int32_t *recv_slots, int32_t *eligible);
 int mgx_halo_resident_connect(mgx_world *w, uint32_t n_targets, const int32_t *robots, void *const *peer_area_base,
                               const uint32_t *peer_ghost_slots, const uint32_t *peer_slot, const uint32_t *peer_parity,
-                              const uint64_t *peer_segment_count);
+                              const uint64_t *peer_segment_count, void *coordinator_area, uint32_t n_ranks);
 int mgx_halo_resident_disconnect(mgx_world *w);
+/* What became of the resident launch the last mgx_iterate enqueued (it decides within microseconds of its start whether it goes
+ * ahead: residency census, and on sharded worlds the ranks' agreement above).  Waits for that decision.
+ *   MGX_RESIDENT_NONE      nothing was pending (the call ran launch by launch, or its outcome has been taken already)
+ *   MGX_RESIDENT_RAN       the launch goes ahead
+ *   MGX_RESIDENT_DECLINED  the launch returned without touching the world, and the schedule has NOT been run: the caller
+ *                          issues the same mgx_iterate again (it now takes the launch-by-launch path).
+ * Nobody has to call this: every other entry point looks at the pending decision first and, after a declined launch, runs the
+ * schedule launch by launch itself.  It exists for hosts that drive SEVERAL ranks from one thread (magics_amd/sharded.py:
+ * LocalCluster): there the ranks' launch-by-launch exchanges must be enqueued in lockstep — all pushes before the first wait
+ * — which a re-run inside one rank's call cannot do.  Only after mgx_iterate (a declined mgx_tick is re-run by the engine). */
+#define MGX_RESIDENT_NONE 0
+#define MGX_RESIDENT_RAN 1
+#define MGX_RESIDENT_DECLINED 2
+int mgx_resident_outcome(mgx_world *w, int32_t *outcome);
+/* Whether mgx_iterate(w, steps, n) would be issued as a resident launch now — on a sharded world whose ranks agree on every
+ * schedule (mgx_halo_resident_connect): whether every rank takes it to that agreement (the same answer on every rank) — rather
+ * than launch by launch.  For hosts that have to know in advance which form a schedule takes (LocalCluster, as above). */
+int mgx_resident_ready(mgx_world *w, const uint8_t *steps, uint32_t n, int32_t *ready);
+/* Resident launches of this world so far, how many of them were declined (see above; each is followed by a back-off during
+ * which schedules skip the resident form), and what is left of the current back-off, in world-wide external iterations run
+ * launch by launch (0: the next eligible schedule is tried as a resident launch).  Any pointer may be NULL. */
+int mgx_resident_stats(mgx_world *w, uint64_t *launches, uint64_t *declined, uint32_t *backoff);
 /* hipIpcGetMemHandle / hipIpcOpenMemHandle / hipIpcCloseMemHandle on the addresses above
  * (64-byte handles), so the host side needs no HIP binding of its own. */
 int mgx_ipc_export(const void *dev_ptr, uint8_t handle[64]);

@@ -166,6 +166,10 @@ struct DevWorld {
     const unsigned long long *gflag;  // [NG]
     const int32_t *xp_ptr;            // [R_local + 1] push targets of each local robot (most have none)
     const XPushRec *xp_rec;
+    // ... and the word on which the RANKS agree whether their launches of one schedule go ahead (SegPlan: agree_seq): it lives
+    // in the ghost area of rank 0, every rank reaches it through its peer mapping, system-scope compare-and-swap only
+    unsigned long long *agree;
+    int32_t n_ranks;
     // diagnostic builds only (-DMGX_STAMPS, tools/stamps.py): per-workgroup phase cycle sums
     unsigned long long *dbg;
 };
@@ -224,8 +228,38 @@ struct SegPlan {
     // by launch instead.
     unsigned long long launch_seq;        // number of this resident launch (census and decision words are monotonic in it); 0: no census
     long long census_ticks;
+    // Sharded worlds: the ranks' launches of one schedule wait for each other's ghost records, so they go ahead together or
+    // not at all.  agree_seq numbers the schedule (the same on every rank; 0: this world has no other ranks).  A rank whose
+    // census is complete signs in on the agreement word (DevWorld::agree: schedule number << 16 | state << 14 | ranks signed
+    // in); the last one to sign in turns the word to go, a rank that has waited census_ticks for the others — or whose own
+    // workgroups are not all there — turns it to abort, both by compare-and-swap, so that every rank reads the same answer.
+    unsigned long long agree_seq;
 };
 constexpr unsigned RESIDENT_GO = 1u, RESIDENT_ABORT = 2u;
+
+// One look at / one move on the agreement word of a sharded world's resident launches (SegPlan::agree_seq).
+// action 0: look; 1: sign in (the caller's census is complete — once per launch); 2: vote abort.
+// Returns the word's state for schedule L: 0 while undecided, RESIDENT_GO or RESIDENT_ABORT.
+constexpr int AGREE_LOOK = 0, AGREE_SIGN_IN = 1, AGREE_ABORT = 2;
+__device__ inline unsigned agree_on_launch(unsigned long long *word, unsigned long long L, unsigned n_ranks, int action) {
+    unsigned long long cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (;;) {
+        const unsigned long long cl = cur >> 16;
+        const unsigned st = (unsigned)(cur >> 14) & 3u, cnt = (unsigned)cur & 0x3fffu;
+        if (cl == L && st) return st;
+        if (cl > L) return RESIDENT_ABORT;  // the other ranks are a schedule ahead: cannot happen while the ranks run the same calls
+        if (action == AGREE_LOOK) return 0u;
+        unsigned long long nw;
+        if (action == AGREE_SIGN_IN) {
+            const unsigned c = (cl == L ? cnt : 0u) + 1u;
+            nw = (L << 16) | ((unsigned long long)(c >= n_ranks ? RESIDENT_GO : 0u) << 14) | c;
+        } else {
+            nw = (L << 16) | ((unsigned long long)RESIDENT_ABORT << 14) | (cl == L ? cnt : 0u);
+        }
+        if (__hip_atomic_compare_exchange_strong(word, &cur, nw, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
+            return (unsigned)(nw >> 14) & 3u;
+    }
+}
 
 // launch hints
 constexpr uint32_t HINT_IR_DEAD = 1u;  // the next sweep recomputes every inter-robot message this one computes

@@ -674,6 +674,20 @@ hipError_t launch_robot_schedule(const DevWorld &w, int n_robots, const SegPlan 
     return e;
 }
 
+// A rank of a sharded world that cannot run the schedule the ranks are about to run as resident launches (SegPlan::agree_seq)
+// says so where the others look: abort on the agreement word, and the same in its own decision words, so that its host takes
+// the launch-by-launch path through the same door as theirs.
+__global__ void k_agree_abort(DevWorld w, unsigned long long launch_seq, unsigned long long agree_seq) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (agree_seq != 0ull) (void)agree_on_launch(w.agree, agree_seq, (unsigned)w.n_ranks, AGREE_ABORT);
+    __hip_atomic_store(w.decision, launch_seq * 4ull + RESIDENT_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w.decision_host, launch_seq * 4ull + RESIDENT_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_agree_abort(const DevWorld &w, const SegPlan &plan, hipStream_t stream) {
+    hipLaunchKernelGGL(k_agree_abort, dim3(1), dim3(64), 0, stream, w, plan.launch_seq, plan.agree_seq);
+    return hipGetLastError();
+}
+
 hipError_t launch_change_prior(const DevWorld &w, int n, const int32_t *robots, const uint32_t *vars, const double *means,
                                hipStream_t stream) {
     if (n <= 0) return hipSuccess;

@@ -238,6 +238,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     if (census && blockIdx.x == gridDim.x - 1) {
         const unsigned long long seq = plan.launch_seq;
         const long long t0 = wall_clock64();
+        // sharded worlds: this rank's answer is the RANKS' answer (SegPlan::agree_seq) — complete here means signed in there
+        const bool ranks = SHARD && plan.agree_seq != 0ull;
+        bool signed_in = false;
         for (;;) {
             int missing = 0;
             for (unsigned b2 = threadIdx.x; b2 < gridDim.x; b2 += SWEEP_BLOCK)
@@ -246,7 +249,16 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             int done = 0;
             if (threadIdx.x == 0) {
                 unsigned long long v = __hip_atomic_load(w.decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned want = all ? RESIDENT_GO : (wall_clock64() - t0 > plan.census_ticks ? RESIDENT_ABORT : 0u);
+                const bool late = wall_clock64() - t0 > plan.census_ticks;
+                unsigned want;
+                if (!ranks) {
+                    want = all ? RESIDENT_GO : (late ? RESIDENT_ABORT : 0u);
+                } else if (all && !signed_in) {
+                    want = agree_on_launch(w.agree, plan.agree_seq, (unsigned)w.n_ranks, AGREE_SIGN_IN);
+                    signed_in = true;
+                } else {
+                    want = agree_on_launch(w.agree, plan.agree_seq, (unsigned)w.n_ranks, late ? AGREE_ABORT : AGREE_LOOK);
+                }
                 if ((v >> 2) == seq) {
                     done = 1;  // a workgroup that gave up on this one has decided
                 } else if (want) {
@@ -257,6 +269,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             }
             if (__syncthreads_or(done)) break;
             __builtin_amdgcn_s_sleep(1);
+            if (ranks) __builtin_amdgcn_s_sleep(8);  // (the word is another rank's memory)
         }
         return;
     }
@@ -545,6 +558,11 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 __builtin_amdgcn_s_sleep(1);
                 v = __hip_atomic_load(w.decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((v >> 2) != seq && wall_clock64() - t0 > 4 * plan.census_ticks) {
+                    // (sharded worlds: only if the ranks' word says abort too — with this vote it does unless every rank,
+                    // hence this one's decider, has signed in: then the decider is alive and about to say so here)
+                    if (SHARD && plan.agree_seq != 0ull &&
+                        agree_on_launch(w.agree, plan.agree_seq, (unsigned)w.n_ranks, AGREE_ABORT) != RESIDENT_ABORT)
+                        continue;
                     if (__hip_atomic_compare_exchange_strong(w.decision, &v, seq * 4ull + RESIDENT_ABORT, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_AGENT)) {
                         __hip_atomic_store(w.decision_host, seq * 4ull + RESIDENT_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -36,6 +36,7 @@ hipError_t launch_robot_sweep(const DevWorld &w, int robot0, int n_robots, uint3
 int sweep_resident_capacity(const DevWorld &w, bool sharded);
 size_t sweep_resident_lds_max();
 hipError_t launch_robot_schedule(const DevWorld &w, int n_robots, const SegPlan &plan, bool sharded, bool cooperative, hipStream_t stream);
+hipError_t launch_agree_abort(const DevWorld &w, const SegPlan &plan, hipStream_t stream);
 hipError_t launch_change_prior(const DevWorld &w, int n, const int32_t *robots, const uint32_t *vars, const double *means,
                                hipStream_t stream);
 hipError_t launch_update_priors(const DevWorld &w, int n, const int32_t *robots, const double *waypoints, const double *time_scale,
@@ -394,6 +395,7 @@ struct mgx_world {
     unsigned long long *sweep_err_host = nullptr;  // host-mapped; non-zero once a wait inside a resident launch gave up
     unsigned long long flag_base = 0;              // every progress word is below or at this value between launches
     bool resident_off = false;                     // mgx_set_resident_launches(w, 0)
+    bool resident_decline = false;                 // mgx_set_resident_launches(w, 2)
     // residency census of resident launches (SegPlan, mgx_dev.h): cumulative per-group counts the device counters reach, the
     // launch number, and the launch the host has enqueued but not yet seen decided (go / abort)
     DevBuf<unsigned long long> census_buf, decision_buf;
@@ -406,12 +408,16 @@ struct mgx_world {
         std::vector<uint32_t> hints;
         int cur_before = 0;
         unsigned long long flag_base_before = 0;
+        bool partial = false;  // the launch is not the first of its schedule (more than MAX_SEGS segments)
         const double *upd = nullptr;  // mgx_tick: the prior updates that ride in the launch (pinned ring slot, still valid)
         double upd_max_speed = 0.0, upd_delta_t = 0.0;
     } pending;
-    int resident_backoff = 0;   // schedules that skip the resident form after an aborted launch
+    // after a declined launch the schedules skip the resident form for a while: counted in world-wide external iterations that
+    // ran launch by launch (whoever drives them: the engine's own schedules or a host's mgx_sweep calls — on a sharded world
+    // every rank runs the same ones, so every rank comes back to the resident form with the same schedule)
+    int resident_backoff = 0;
     int resident_backoff_len = 0;
-    uint64_t resident_aborts = 0;
+    uint64_t resident_aborts = 0, resident_launches = 0;
     int resident_cap = -1;                         // workgroups of the resident kernel the device holds at once (-1: not asked yet)
     int resident_cap_sharded = -1;                 // the same for the instantiation that takes ghost records in-launch
     bool peers_valid = false;
@@ -494,6 +500,11 @@ struct mgx_world {
         bool connected = false;
         DevBuf<int32_t> xp_ptr;
         DevBuf<XPushRec> xp_rec;
+        // the ranks' agreement on every schedule's launches (SegPlan::agree_seq): the word (in rank 0's area), the number of
+        // ranks that sign in on it, and the number of the last schedule this rank took there — the same on every rank
+        unsigned long long *agree = nullptr;
+        int n_ranks = 0;
+        unsigned long long agree_seq = 0;
     } xres;
     // halo exchange through RCCL inside the library (grouped ncclSend / ncclRecv on the world's stream)
     struct RcclHalo {
@@ -636,7 +647,7 @@ static void blob_unpack(Robot &rb, const double *b) {
 }
 
 // ---- pull: device -> host mirror ----------------------------------------------------------------
-static int confirm_resident(mgx_world *w);
+static int confirm_resident(mgx_world *w, bool rerun = true, int32_t *outcome = nullptr);
 static int pull(mgx_world *w) {
     if (!w->dev_valid) return MGX_OK;
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
@@ -726,7 +737,7 @@ static int pull(mgx_world *w) {
 // contents (a skipped factor still "sends" its empty messages, factor/mod.rs:353-367).  So the
 // launches are only logged, and the counters are brought up to date whenever one of those inputs
 // is about to change or a count is asked for.
-static int confirm_resident(mgx_world *w);
+
 static void flush_counts(mgx_world *w) {
     if (w->pending.active) (void)confirm_resident(w);  // the launch's entries join the log once it is known to have run
     if (w->clog.empty() && w->cp_dirty.empty()) return;
@@ -1044,7 +1055,7 @@ static int retopo(mgx_world *w) {
     return rc_flags;
 }
 
-static int confirm_resident(mgx_world *w);
+
 static int commit(mgx_world *w) {
     if (!device_ok()) return fail(MGX_ERR_NO_DEVICE, "no usable HIP device (this library has no CPU path)");
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
@@ -1253,6 +1264,7 @@ static int commit(mgx_world *w) {
     w->resident_cap = w->resident_cap_sharded = -1;
     w->xres.connected = false;  // ghost slots and progress words belonged to the old layout: the ranks wire them again
     d.gsnap[0] = d.gsnap[1] = nullptr; d.gepoch[0] = d.gepoch[1] = nullptr; d.gflag = nullptr; d.xp_ptr = nullptr; d.xp_rec = nullptr;
+    w->xres.agree = nullptr; d.agree = nullptr; d.n_ranks = 0;
     if (!w->sweep_err_host) {  // the word device code reports a wait that gave up in (resident launches, direct halo waits)
         HIP_TRY(hipHostMalloc((void **)&w->sweep_err_host, sizeof(unsigned long long), hipHostMallocMapped));
         *w->sweep_err_host = 0ull;
@@ -1288,8 +1300,9 @@ static void log_launch(mgx_world *w, int robot, uint32_t ext_mask, uint32_t int_
 // the decision falls within microseconds of the launch's START, so in a stream of ticks the host simply stays ONE launch
 // ahead of the device instead of many.  An aborted launch is run again on the launch-per-segment path, and the next few
 // schedules skip the resident form (doubling back-off while the GPU stays shared).
-static int confirm_resident(mgx_world *w) {
+static int confirm_resident(mgx_world *w, bool rerun, int32_t *outcome) {
     mgx_world::PendingResident &pd = w->pending;
+    if (outcome) *outcome = MGX_RESIDENT_NONE;
     if (!pd.active) return MGX_OK;
     StageTimer clock("confirm");
     const double t0 = StageTimer::now();
@@ -1309,11 +1322,16 @@ static int confirm_resident(mgx_world *w) {
     if ((v >> 2) == pd.seq && (v & 3ull) == RESIDENT_ABORT) {
         // nothing happened on the device: take the host's bookkeeping back and run the same schedule launch by launch
         w->resident_aborts++;
-        w->resident_backoff_len = std::min(std::max(2 * w->resident_backoff_len, 8), 4096);
-        w->resident_backoff = w->resident_backoff_len;
+        w->resident_backoff_len = std::min(std::max(2 * w->resident_backoff_len, 64), 32768);
+        w->resident_backoff = w->resident_backoff_len + (int)pd.segs.size();  // (+ this schedule's own re-run)
         w->d.cur = pd.cur_before;
         w->flag_base = pd.flag_base_before;
         w->last_sweep_launches = 0;
+        if (!rerun && !pd.upd && !pd.partial) {  // mgx_resident_outcome: the caller issues the schedule again
+            if (outcome) *outcome = MGX_RESIDENT_DECLINED;
+            return MGX_OK;
+        }
+        if (outcome) *outcome = MGX_RESIDENT_RAN;  // (by the time the caller looks, it has: launch by launch)
         bool first = true;
         for (size_t k = 0; k < pd.segs.size(); k++) {
             if (first && pd.upd) { w->d.upd = pd.upd; w->d.upd_max_speed = pd.upd_max_speed; w->d.upd_delta_t = pd.upd_delta_t; }
@@ -1325,6 +1343,7 @@ static int confirm_resident(mgx_world *w) {
         return MGX_OK;
     }
     w->resident_backoff_len = 0;
+    if (outcome) *outcome = MGX_RESIDENT_RAN;
     for (const auto &sg : pd.segs) log_launch(w, -1, sg.first, sg.second ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, sg.second);
     return MGX_OK;
 }
@@ -1344,6 +1363,7 @@ static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_ma
         return rc != MGX_OK ? rc : sweep(w, -1, 0, int_mask, n_int, hints & ~HINT_IR_DEAD);
     }
     if (robot < 0) {
+        if (ext_mask && w->resident_backoff > 0) w->resident_backoff--;
         if (w->direct.connected && (ext_mask & PH_EXT_FACTOR)) {  // the inter-robot factors read the ghosts' snapshots
             rc = direct_exchange(w);
             if (rc != MGX_OK) return rc;
@@ -1500,30 +1520,48 @@ static int ensure_resident_tables(mgx_world *w) {
 // Runs the schedule as resident launches if this world qualifies: 1 = done, 0 = not eligible (the caller takes the
 // launch-per-segment path), negative = error.  Eligible: inter-robot factors enabled and staged in LDS, every robot
 // local (no ghosts: their records arrive between launches), nothing thawing, and every workgroup co-resident.
+// the conditions every rank of a sharded world decides alike on: same schedule, same world-wide switches, the same back-off
+// (aborts are the ranks' common answer)
+static bool resident_gate(const mgx_world *w, const std::vector<Launch> &plan) {
+    if (!resident_enabled() || w->resident_off || plan.size() < 2) return false;
+    if (w->resident_backoff > 0) return false;  // a recent launch found the GPU shared (residency census): launch by launch for a while
+    const DevWorld &d = w->d;
+    const bool sharded = w->xres.connected;  // the ranks have agreed (mgx_halo_resident_connect) that ghost records travel inside the launches
+    if ((d.R_total != d.R_local && !sharded) || !(w->p.enable_mask & 2u)) return false;
+    if (((w->direct.connected || w->rccl.connected) && !sharded)) return false;
+    for (const Launch &l : plan)
+        if (l.n_int > 255) return false;
+    if (sharded && plan[0].ext && !w->direct.connected) return false;  // the exchange in front of the launch is the direct one
+    return true;
+}
 static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
     if (!resident_enabled() || w->resident_off || plan.size() < 2) return 0;
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
-    if (w->resident_backoff > 0) {  // a recent launch found the GPU shared (residency census): launch by launch for a while
-        w->resident_backoff--;
-        return 0;
-    }
+    if (!resident_gate(w, plan)) return 0;
     const DevWorld &d = w->d;
-    // a sharded world: the ranks have agreed (mgx_halo_resident_connect) that ghost records travel inside the launches
     const bool sharded = w->xres.connected;
-    if ((d.R_total != d.R_local && !sharded) || d.ir_max_edges == 0 || w->conns.empty() || !(w->p.enable_mask & 2u)) return 0;
-    if (w->thaw_kinds || w->ir_thaw_active || w->n_keyless > 0 || ((w->direct.connected || w->rccl.connected) && !sharded)) return 0;
-    for (const Launch &l : plan)
-        if (l.n_int > 255) return 0;
-    if (sharded && plan[0].ext && !w->direct.connected) return 0;  // the exchange in front of the launch is the direct one
-    // (so far every rank of a sharded world decides alike: same schedule, same world-wide switches; what follows is this rank's own)
-    if (sweep_lds_bytes(w->K, d.ir_max_edges, true) > sweep_resident_lds_max())
-        return sharded ? fail(MGX_ERR_STATE, "resident launches were agreed on with the other ranks, but this rank's robots no longer fit LDS") : 0;
+    // What follows is this rank's own: where the ranks agree on every schedule (xres.agree) a rank
+    // that cannot take part says so THERE — its launch is a single vote, and everybody takes the launch-by-launch path.
+    const bool ranks_agree = sharded && w->xres.agree != nullptr;
+    bool can = d.ir_max_edges > 0 && !w->conns.empty() && !w->thaw_kinds && !w->ir_thaw_active && w->n_keyless == 0 && !w->resident_decline;
+    if (!can && !ranks_agree) return 0;
+    if (can && sweep_lds_bytes(w->K, d.ir_max_edges, true) > sweep_resident_lds_max()) {
+        if (!sharded) return 0;
+        if (!ranks_agree) return fail(MGX_ERR_STATE, "resident launches were agreed on with the other ranks, but this rank's robots no longer fit LDS");
+        can = false;
+    }
     int &cap = sharded ? w->resident_cap_sharded : w->resident_cap;
-    if (cap < 0) cap = sweep_resident_capacity(d, sharded);
-    if (d.R_local + (sharded ? 0 : 1) > cap)  // (+ the residency census' decider workgroup: one slot kept free for it)
-        return sharded ? fail(MGX_ERR_STATE, "resident launches were agreed on with the other ranks, but only %d of this rank's %d workgroups "
-                                             "are resident at once", cap, d.R_local) : 0;
+    if (can) {
+        if (cap < 0) cap = sweep_resident_capacity(d, sharded);
+        if (d.R_local + 1 > cap) {  // (+ the residency census' decider workgroup: one slot kept free for it)
+            if (!sharded) return 0;
+            if (!ranks_agree && d.R_local > cap)
+                return fail(MGX_ERR_STATE, "resident launches were agreed on with the other ranks, but only %d of this rank's %d workgroups "
+                                           "are resident at once", cap, d.R_local);
+            if (ranks_agree) can = false;
+        }
+    }
     rc = ensure_resident_tables(w);
     if (rc != MGX_OK) return rc;
     static const long long timeout_ticks = [] {
@@ -1542,15 +1580,20 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
         }
         sp.flag_base = w->flag_base;
         sp.timeout_ticks = timeout_ticks;
-        // residency census + clean abort (SegPlan): single-rank worlds — the ranks of a sharded world would have to abort
-        // together, they keep the plain bound on every wait
+        // residency census + clean abort (SegPlan); the ranks of a sharded world abort together, on the word they agree on
+        // (without one — mgx_halo_resident_connect without a coordinator — they keep the plain bound on every wait)
         static const long long census_ticks = [] {
             const char *e = getenv("MGX_RESIDENT_CENSUS_US");
             const long long us = e ? atoll(e) : 200;
             return (us > 0 ? us : 200) * 100ll;  // 100 MHz wall clock
         }();
+        static const long long census_ticks_sharded = [] {  // the ranks' hosts do not launch at the same instant
+            const char *e = getenv("MGX_RESIDENT_CENSUS_SHARDED_US");
+            const long long us = e ? atoll(e) : 5000;
+            return (us > 0 ? us : 5000) * 100ll;
+        }();
         static const bool census_on = [] { const char *e = getenv("MGX_RESIDENT_CENSUS"); return !(e && e[0] == '0'); }();
-        const bool census = !sharded && census_on;  // MGX_RESIDENT_CENSUS=0: plain bound on every wait, as on sharded worlds
+        const bool census = sharded ? ranks_agree : census_on;  // MGX_RESIDENT_CENSUS=0: plain bound on every wait
         if (census) {
             if (i0 > 0 && (rc = confirm_resident(w)) != MGX_OK) return rc;  // the previous part of this schedule
             if (i0 > 0 && w->resident_backoff > 0) {  // ... was sent back: the rest follows it launch by launch
@@ -1559,7 +1602,8 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
                 return 1;
             }
             sp.launch_seq = ++w->launch_seq;
-            sp.census_ticks = census_ticks;
+            sp.census_ticks = sharded ? census_ticks_sharded : census_ticks;
+            if (ranks_agree) sp.agree_seq = ++w->xres.agree_seq;
         }
         if (sharded && sp.ext[0]) {  // segment 0 reads the ghosts' plain copies: one direct exchange in front of the launch
             rc = direct_exchange(w);
@@ -1569,7 +1613,8 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
         // time (same residency as a plain launch, +15..19 us of host time per launch: MI355X_MICROARCH.md); a grid it turns
         // down takes the launch-per-segment path from now on instead of waiting for workgroups that never become resident
         static const bool cooperative = [] { const char *e = getenv("MGX_COOPERATIVE"); return e && e[0] == '1'; }();
-        const hipError_t le = launch_robot_schedule(w->d, w->d.R_local, sp, sharded, cooperative, w->stream);
+        const hipError_t le = can ? launch_robot_schedule(w->d, w->d.R_local, sp, sharded, cooperative, w->stream)
+                                  : launch_agree_abort(w->d, sp, w->stream);
         if (le != hipSuccess) {
             (void)hipGetLastError();
             if (cooperative && le == hipErrorCooperativeLaunchTooLarge && i0 == 0 && !sharded) {
@@ -1579,10 +1624,12 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
             return fail(MGX_ERR_HIP, "resident schedule launch: %s", hipGetErrorString(le));
         }
         w->last_sweep_launches++;
+        w->resident_launches++;
         if (census) {  // what confirm_resident needs to take the launch back and run it again launch by launch
             mgx_world::PendingResident &pd = w->pending;
             pd.active = true;
             pd.seq = sp.launch_seq;
+            pd.partial = i0 > 0;
             pd.segs.clear();
             pd.hints.clear();
             for (int k = 0; k < sp.n; k++) {
@@ -2595,6 +2642,7 @@ int mgx_mission_tick_end(mgx_world *w, const uint8_t *antennas, double max_speed
     w->stale_kinds |= ~w->p.enable_mask & 15u;
     tm.lap("counter log");
     const std::vector<Launch> plan = plan_launches(steps, n_steps);
+    if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }  // (a declined launch is run again here: not this call's launches)
     w->last_sweep_launches = 0;
     const bool fuse = !plan.empty() && plan[0].ext == 0 && plan[0].n_int > 0 && w->thaw_kinds == 0;
     if (!fuse) {
@@ -2694,6 +2742,7 @@ static std::vector<Launch> plan_launches(const uint8_t *steps, uint32_t n) {
 int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n) {
     if (!w || (!steps && n)) return fail(MGX_ERR_INVALID, "null argument");
     const std::vector<Launch> plan = plan_launches(steps, n);
+    if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }  // (a declined launch is run again here: not this call's launches)
     w->last_sweep_launches = 0;
     const int resident = run_resident(w, plan);
     if (resident != 0) return resident < 0 ? resident : MGX_OK;
@@ -2782,6 +2831,7 @@ int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *wayp
              const uint8_t *what, double max_speed, double delta_t, const uint8_t *steps, uint32_t n_steps) {
     if (!w || (!steps && n_steps) || (n && (!robots || !waypoints_xy || !time_scale || !what))) return fail(MGX_ERR_INVALID, "null argument");
     const std::vector<Launch> plan = plan_launches(steps, n_steps);
+    if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }  // (a declined launch is run again here: not this call's launches)
     w->last_sweep_launches = 0;
     const bool fuse = n > 0 && !plan.empty() && plan[0].ext == 0 && plan[0].n_int > 0 && w->thaw_kinds == 0 && w->K >= 3;
     if (!fuse) {
@@ -2911,6 +2961,12 @@ int mgx_change_prior(mgx_world *w, int32_t robot, uint32_t var_ix, const double 
 int mgx_set_resident_launches(mgx_world *w, int32_t enabled) {
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     w->resident_off = enabled == 0;
+    w->resident_decline = enabled == 2;
+    return MGX_OK;
+}
+int mgx_is_thawing(mgx_world *w, int32_t *thawing) {
+    if (!w || !thawing) return fail(MGX_ERR_INVALID, "null argument");
+    *thawing = (w->thaw_kinds || w->ir_thaw_active || w->n_keyless > 0) ? 1 : 0;
     return MGX_OK;
 }
 int mgx_last_launch_count(mgx_world *w, uint32_t *n_launches) {
@@ -3303,12 +3359,13 @@ int mgx_halo_direct_disconnect(mgx_world *w) {
 // each), delivery counts of parity 0 / 1 (NG * K u32 each, padded to 16 bytes), NG progress words.  Both ends compute it.
 namespace {
 struct GhostAreaLayout {
+    static constexpr size_t agree = 0, HEAD = 64;  // the ranks' agreement word (used in rank 0's area only) has the first line to itself
     size_t snap[2], epoch[2], flag, bytes;
     GhostAreaLayout(size_t ng, size_t K) {
         const size_t S = ng * K * SNAP_W * sizeof(double), E = (ng * K * sizeof(uint32_t) + 15) & ~(size_t)15;
-        snap[0] = 0; snap[1] = S;
-        epoch[0] = 2 * S; epoch[1] = 2 * S + E;
-        flag = 2 * S + 2 * E;
+        snap[0] = HEAD; snap[1] = HEAD + S;
+        epoch[0] = HEAD + 2 * S; epoch[1] = HEAD + 2 * S + E;
+        flag = HEAD + 2 * S + 2 * E;
         bytes = flag + std::max<size_t>(ng, 1) * sizeof(unsigned long long);
     }
 };
@@ -3324,6 +3381,8 @@ int mgx_halo_resident_setup(mgx_world *w, void **area_base, uint32_t *n_ghost_sl
     mgx_world::ResidentHalo &xr = w->xres;
     HIP_TRY(hipStreamSynchronize(w->stream));
     xr.connected = false;
+    xr.agree = nullptr;
+    w->d.agree = nullptr;
     if (xr.area) { (void)hipFree(xr.area); xr.area = nullptr; }
     const DevWorld &d = w->d;
     const int NG = d.R_total - d.R_local;
@@ -3332,7 +3391,7 @@ int mgx_halo_resident_setup(mgx_world *w, void **area_base, uint32_t *n_ghost_sl
               sweep_lds_bytes(w->K, d.ir_max_edges, true) <= sweep_resident_lds_max();
     if (ok) {
         if (w->resident_cap_sharded < 0) w->resident_cap_sharded = sweep_resident_capacity(d, true);
-        ok = d.R_local <= w->resident_cap_sharded;
+        ok = d.R_local + 1 <= w->resident_cap_sharded;  // (+ the launch's decider workgroup)
     }
     rc = ensure_resident_tables(w);  // settles this rank's segment count (progress words are created here)
     if (rc != MGX_OK) return rc;
@@ -3358,8 +3417,9 @@ int mgx_halo_resident_setup(mgx_world *w, void **area_base, uint32_t *n_ghost_sl
 
 int mgx_halo_resident_connect(mgx_world *w, uint32_t n_targets, const int32_t *robots, void *const *peer_area_base,
                               const uint32_t *peer_ghost_slots, const uint32_t *peer_slot, const uint32_t *peer_parity,
-                              const uint64_t *peer_segment_count) {
+                              const uint64_t *peer_segment_count, void *coordinator_area, uint32_t n_ranks) {
     if (!w) return fail(MGX_ERR_INVALID, "null world");
+    if (n_ranks > 0x3fffu) return fail(MGX_ERR_INVALID, "at most %u ranks", 0x3fffu);
     if (n_targets && (!robots || !peer_area_base || !peer_ghost_slots || !peer_slot || !peer_parity || !peer_segment_count))
         return fail(MGX_ERR_INVALID, "null argument");
     mgx_world::ResidentHalo &xr = w->xres;
@@ -3402,14 +3462,54 @@ int mgx_halo_resident_connect(mgx_world *w, uint32_t n_targets, const int32_t *r
     d.gflag = (const unsigned long long *)((const char *)xr.area + Lm.flag);
     d.xp_ptr = xr.xp_ptr.p;
     d.xp_rec = xr.xp_rec.p;
+    // the ranks' agreement word: first word of rank 0's area (zeroed by its setup; schedules are numbered from 1 on every rank)
+    xr.agree = coordinator_area && n_ranks >= 2 ? (unsigned long long *)((char *)coordinator_area + GhostAreaLayout::agree) : nullptr;
+    xr.n_ranks = xr.agree ? (int)n_ranks : 0;
+    xr.agree_seq = 0;
+    d.agree = xr.agree;
+    d.n_ranks = xr.n_ranks;
     xr.connected = true;
     return MGX_OK;
 }
 
 int mgx_halo_resident_disconnect(mgx_world *w) {
     if (!w) return fail(MGX_ERR_INVALID, "null world");
+    if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     HIP_TRY(hipStreamSynchronize(w->stream));
     w->xres.connected = false;
+    w->xres.agree = nullptr;
+    w->d.agree = nullptr;
+    return MGX_OK;
+}
+
+int mgx_resident_outcome(mgx_world *w, int32_t *outcome) {
+    if (!w || !outcome) return fail(MGX_ERR_INVALID, "null argument");
+    return confirm_resident(w, false, outcome);
+}
+
+int mgx_resident_ready(mgx_world *w, const uint8_t *steps, uint32_t n, int32_t *ready) {
+    if (!w || !ready || (!steps && n)) return fail(MGX_ERR_INVALID, "null argument");
+    int rc = commit(w);
+    if (rc != MGX_OK) return rc;
+    *ready = resident_gate(w, plan_launches(steps, n)) ? 1 : 0;
+    if (*ready && !(w->xres.connected && w->xres.agree)) {  // nobody to agree with: what this world's own launch needs
+        const DevWorld &d = w->d;
+        const bool sharded = w->xres.connected;
+        int &cap = sharded ? w->resident_cap_sharded : w->resident_cap;
+        bool can = d.ir_max_edges > 0 && !w->conns.empty() && !w->thaw_kinds && !w->ir_thaw_active && w->n_keyless == 0 && !w->resident_decline &&
+                   sweep_lds_bytes(w->K, d.ir_max_edges, true) <= sweep_resident_lds_max();
+        if (can && cap < 0) cap = sweep_resident_capacity(d, sharded);
+        *ready = can && d.R_local + 1 <= cap ? 1 : 0;
+    }
+    return MGX_OK;
+}
+
+int mgx_resident_stats(mgx_world *w, uint64_t *launches, uint64_t *declined, uint32_t *backoff) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
+    if (launches) *launches = w->resident_launches;
+    if (declined) *declined = w->resident_aborts;
+    if (backoff) *backoff = (uint32_t)w->resident_backoff;
     return MGX_OK;
 }
 

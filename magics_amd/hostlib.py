@@ -25,6 +25,7 @@ SCHEDULE_HALF_BEGINNING_HALF_END = 4
 STEP_INTERNAL = 1
 STEP_EXTERNAL = 2
 NEIGHBOURS_AUTO, NEIGHBOURS_PAIRS, NEIGHBOURS_GRID = 0, 1, 2
+RESIDENT_NONE, RESIDENT_RAN, RESIDENT_DECLINED = 0, 1, 2
 HALO_PUSH, HALO_WAIT = 1, 2
 HINT_NEXT_STARTS_EXTERNAL = 1
 
@@ -155,7 +156,11 @@ SYMBOLS = {
     "mgx_halo_direct_disconnect": (C.c_int, [_V]),
     "mgx_halo_resident_setup": (C.c_int, [_V, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                           C.c_void_p, C.POINTER(C.c_int32)]),
-    "mgx_halo_resident_connect": (C.c_int, [_V, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgx_halo_resident_connect": (C.c_int, [_V, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_uint32]),
+    "mgx_resident_outcome": (C.c_int, [_V, C.POINTER(C.c_int32)]),
+    "mgx_resident_ready": (C.c_int, [_V, C.c_char_p, C.c_uint32, C.POINTER(C.c_int32)]),
+    "mgx_resident_stats": (C.c_int, [_V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "mgx_halo_resident_disconnect": (C.c_int, [_V]),
     "mgx_ipc_export": (C.c_int, [C.c_void_p, C.c_char_p]),
     "mgx_ipc_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -173,6 +178,7 @@ SYMBOLS = {
     "mgx_num_robots": (C.c_int, [_V, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mgx_last_launch_count": (C.c_int, [_V, C.POINTER(C.c_uint32)]),
     "mgx_set_resident_launches": (C.c_int, [_V, C.c_int32]),
+    "mgx_is_thawing": (C.c_int, [_V, C.POINTER(C.c_int32)]),
     "mgx_halo_words": (C.c_uint32, [C.c_uint32]),
     "mgx_halo_plan": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_int32)]),
     "mgx_halo_plan_from_connections": (C.c_int, [_V, C.POINTER(C.c_int32), C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32),

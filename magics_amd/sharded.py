@@ -299,6 +299,7 @@ class ShardedWorld:
         plan = self.plan
         flat = [g for l in plan.recv_lists for g in l]
         area, ng, par, seg, slots, ok = self.world.halo_resident_setup(len(flat))
+        self._own_area = area
         info = dict(rank=plan.rank, n_ghosts=ng, parity=par, segments=seg, eligible=ok, slots=dict(zip(flat, slots)))
         if export_ipc:
             info["area_handle"] = hostlib.ipc_export(area)
@@ -306,24 +307,35 @@ class ShardedWorld:
             info["area_ptr"] = area
         return info
 
-    def resident_connect(self, infos):
-        """infos[q]: what rank q published in resident_setup (handles are opened here)."""
+    def resident_connect(self, infos, agree=True):
+        """infos[q]: what rank q published in resident_setup (handles are opened here).  Rank 0's area doubles as the place
+        where the ranks agree on every schedule's launches (include/mgx.h: coordinator_area), so every rank maps it."""
         plan = self.plan
         self._opened = getattr(self, "_opened", [])
+        mapped = {}
+
+        def area_of(q):
+            if q not in mapped:
+                inf = infos[q]
+                if "area_ptr" in inf:
+                    mapped[q] = inf["area_ptr"]
+                elif q == plan.rank:
+                    mapped[q] = self._own_area
+                else:
+                    mapped[q] = hostlib.ipc_open(inf["area_handle"])
+                    self._opened.append(mapped[q])
+            return mapped[q]
         robots, area, ngs, slot, par, seg = [], [], [], [], [], []
         for q in range(plan.world_size):
             if not plan.send_lists[q]:
                 continue
             inf = infos[q]
-            if "area_ptr" in inf:
-                a = inf["area_ptr"]
-            else:
-                a = hostlib.ipc_open(inf["area_handle"])
-                self._opened.append(a)
+            a = area_of(q)
             for g in plan.send_lists[q]:
                 robots.append(self.lid[g]); area.append(a); ngs.append(inf["n_ghosts"]); slot.append(inf["slots"][g])
                 par.append(inf["parity"]); seg.append(inf["segments"])
-        self.world.halo_resident_connect(robots, area, ngs, slot, par, seg)
+        self.world.halo_resident_connect(robots, area, ngs, slot, par, seg, coordinator_area=area_of(0) if agree else None,
+                                         n_ranks=plan.world_size if agree else 0)
         self.resident = True
 
     def direct_close(self):
@@ -383,6 +395,8 @@ class ShardedWorld:
     # -- World-like interface over global robot ids -------------------------------------------------
     def iterate(self, steps):
         if self.direct or self.plan.world_size == 1:
+            if getattr(self, "_thaw_watch", False):
+                self._settle_resident()
             self.world.iterate(steps)  # one C call: launches (and exchanges) are sequenced by the engine
             return
         segs = segments(steps)
@@ -412,6 +426,19 @@ class ShardedWorld:
         if not self.direct:
             self.exchange()
         self.world.set_enabled(mask)
+        self._settle_resident()
+
+    def _settle_resident(self):
+        """Whether a schedule may run as one resident launch has to come out the same on every rank (a rank that went resident
+        next to one that did not would wait for records that never come), and "factors are still thawing" depends on the flags of
+        the robots a rank holds.  So after a switch of factor kinds resident launches are off everywhere until NO rank is thawing
+        any more (asked over the control plane in front of every schedule while that lasts)."""
+        if not getattr(self, "resident", False):
+            return
+        mine = self.world.is_thawing()
+        anyone = any(self.comm.all_gather_object(mine)) if self.comm is not None else mine
+        self.world.set_resident_launches(not anyone)
+        self._thaw_watch = anyone
 
     def read_beliefs(self):
         """(global robot ids of the local robots, eta, lam, means) of this rank."""
@@ -597,7 +624,8 @@ class LocalCluster:
     """All ranks of a sharded world inside ONE process (one GPU): used by the tests to check the
     ghost / halo numerics against the unsharded world without a multi-GPU node."""
 
-    def __init__(self, sc, world_size, world_factory, owner=None, tensor_factory=None, direct=False, dynamic=False, resident=False):
+    def __init__(self, sc, world_size, world_factory, owner=None, tensor_factory=None, direct=False, dynamic=False, resident=False,
+                 agree=True):
         """direct=True: the ranks exchange through peer-mapped stores (same address space, no IPC);
         `world_factory` must then give every rank its OWN stream — a rank's wait kernel would block
         a shared stream before the other rank's stores are even enqueued.
@@ -620,8 +648,9 @@ class LocalCluster:
                 infos = {sw.plan.rank: sw.resident_setup(export_ipc=False) for sw in self.ranks}
                 if all(i["eligible"] for i in infos.values()):
                     for sw in self.ranks:
-                        sw.resident_connect(infos)
+                        sw.resident_connect(infos, agree=agree)
                     self.resident = True
+                    self.agree = agree
 
     def _exchange(self):
         for sw in self.ranks:
@@ -643,13 +672,27 @@ class LocalCluster:
 
     def iterate(self, steps):
         segs = segments(steps)
-        if self.resident and len(segs) >= 2:
+        if getattr(self, "_thaw_watch", False):
+            self._settle_resident()
+        # (a schedule the engines would run launch by launch — too short, inter-robot factors off, backing off after a declined
+        # launch — is driven from here, in lockstep: see below)
+        if self.resident and not getattr(self, "_thaw_watch", False) and self.ranks[0].world.resident_ready(steps):
             if segs[0][0]:  # a schedule that opens with an external iteration: its exchange, all pushes first
                 for sw in self.ranks:
                     sw.world.halo_direct_exchange(hostlib.HALO_PUSH)
             for sw in self.ranks:  # one launch per rank, each on its own stream: they run side by side
                 sw.world.iterate(steps)
-            return
+            # ... if the device takes them side by side: the launches find out by themselves and agree on one answer
+            # (include/mgx.h: mgx_halo_resident_connect).  After a "no" every world is as it was, and the schedule runs launch
+            # by launch below — from here, not inside each rank's next call: one thread drives all ranks, and their exchanges
+            # must be enqueued in lockstep (all pushes before the first wait).
+            if not self.agree:
+                return
+            outcomes = [sw.world.resident_outcome() for sw in self.ranks]
+            assert all(o == outcomes[0] for o in outcomes), f"the ranks' launches disagree: {outcomes}"
+            if outcomes[0] != hostlib.RESIDENT_DECLINED:
+                return
+            self.declined = getattr(self, "declined", 0) + 1
         for k, (ext, n_int) in enumerate(segs):
             if ext and len(self.ranks) > 1:
                 if self.ranks[0].direct:
@@ -721,6 +764,16 @@ class LocalCluster:
                 self._exchange()
         for sw in self.ranks:
             sw.world.set_enabled(mask)
+        self._settle_resident()
+
+    def _settle_resident(self):
+        """see ShardedWorld._settle_resident: resident launches are off on every rank while any rank is thawing"""
+        if not self.resident:
+            return
+        anyone = any(sw.world.is_thawing() for sw in self.ranks)
+        for sw in self.ranks:
+            sw.world.set_resident_launches(not anyone)
+        self._thaw_watch = anyone
 
     def connections(self, robot):
         outs = [sw.world.connections(robot) for sw in self.ranks]

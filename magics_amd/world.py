@@ -287,7 +287,31 @@ class World:
 
     def set_resident_launches(self, enabled):
         """per-world switch: False keeps every schedule on the launch-per-segment path (mgx_set_resident_launches)"""
-        self._chk(self._L.mgx_set_resident_launches(self._w, 1 if enabled else 0))
+        self._chk(self._L.mgx_set_resident_launches(self._w, 2 if enabled == "decline" else 1 if enabled else 0))
+
+    def resident_outcome(self):
+        """what became of the resident launch of the last iterate (hostlib.RESIDENT_NONE / _RAN / _DECLINED: issue it again)"""
+        o = C.c_int32()
+        self._chk(self._L.mgx_resident_outcome(self._w, C.byref(o)))
+        return o.value
+
+    def resident_ready(self, steps):
+        """whether iterate(steps) would go out as a resident launch now (mgx_resident_ready)"""
+        b, r = bytes(int(x) for x in steps), C.c_int32()
+        self._chk(self._L.mgx_resident_ready(self._w, b, len(b), C.byref(r)))
+        return bool(r.value)
+
+    def resident_stats(self):
+        """(resident launches so far, declined ones, what is left of the back-off after the last declined one)"""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        self._chk(self._L.mgx_resident_stats(self._w, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def is_thawing(self):
+        """factors switched back on are still resuming from their frozen inboxes (mgx_is_thawing)"""
+        t = C.c_int32()
+        self._chk(self._L.mgx_is_thawing(self._w, C.byref(t)))
+        return bool(t.value)
 
     def last_launch_count(self):
         """sweep-kernel launches of the last iterate / tick call (1: the whole schedule ran as one resident launch)"""
@@ -380,7 +404,9 @@ class World:
         self._chk(self._L.mgx_halo_resident_setup(self._w, C.byref(area), C.byref(ng), C.byref(par), C.byref(seg), slots.ctypes.data, C.byref(ok)))
         return area.value, ng.value, par.value, seg.value, slots[:n_recv].tolist(), bool(ok.value)
 
-    def halo_resident_connect(self, robots, peer_area, peer_ghost_slots, peer_slot, peer_parity, peer_segment_count):
+    def halo_resident_connect(self, robots, peer_area, peer_ghost_slots, peer_slot, peer_parity, peer_segment_count,
+                              coordinator_area=None, n_ranks=0):
+        """coordinator_area: rank 0's ghost area as this rank maps it — where the ranks agree on every schedule's launches"""
         n = len(robots)
         a = np.ascontiguousarray(robots, dtype=np.int32)
         b = np.ascontiguousarray(peer_area, dtype=np.uint64)
@@ -390,7 +416,7 @@ class World:
         f = np.ascontiguousarray(peer_segment_count, dtype=np.uint64)
         assert b.size == c.size == d.size == e.size == f.size == n
         self._chk(self._L.mgx_halo_resident_connect(self._w, n, a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, e.ctypes.data,
-                                                    f.ctypes.data))
+                                                    f.ctypes.data, coordinator_area, int(n_ranks)))
 
     def halo_resident_disconnect(self):
         self._chk(self._L.mgx_halo_resident_disconnect(self._w))

@@ -118,6 +118,7 @@ extern "C" {
     pub fn mgx_iterate(w: *mut mgx_world, steps: *const u8, n: u32) -> c_int;
     pub fn mgx_last_launch_count(w: *mut mgx_world, n_launches: *mut u32) -> c_int;
     pub fn mgx_set_resident_launches(w: *mut mgx_world, enabled: i32) -> c_int;
+    pub fn mgx_is_thawing(w: *mut mgx_world, thawing: *mut i32) -> c_int;
     pub fn mgx_sweep(w: *mut mgx_world, robot: i32, external_phases: u32, internal_phases: u32, n_internal: u32, hints: u32) -> c_int;
     pub fn mgx_internal_factor_iteration(w: *mut mgx_world, robot: i32) -> c_int;
     pub fn mgx_internal_variable_iteration(w: *mut mgx_world, robot: i32) -> c_int;
@@ -162,8 +163,11 @@ extern "C" {
     pub fn mgx_halo_direct_status(w: *mut mgx_world, exchanges: *mut u64, failed_exchange: *mut u64) -> c_int;
     pub fn mgx_halo_direct_disconnect(w: *mut mgx_world) -> c_int;
     pub fn mgx_halo_resident_setup(w: *mut mgx_world, area_base: *mut *mut c_void, n_ghost_slots: *mut u32, parity: *mut u32, segment_count: *mut u64, recv_slots: *mut i32, eligible: *mut i32) -> c_int;
-    pub fn mgx_halo_resident_connect(w: *mut mgx_world, n_targets: u32, robots: *const i32, peer_area_base: *const *mut c_void, peer_ghost_slots: *const u32, peer_slot: *const u32, peer_parity: *const u32, peer_segment_count: *const u64) -> c_int;
+    pub fn mgx_halo_resident_connect(w: *mut mgx_world, n_targets: u32, robots: *const i32, peer_area_base: *const *mut c_void, peer_ghost_slots: *const u32, peer_slot: *const u32, peer_parity: *const u32, peer_segment_count: *const u64, coordinator_area: *mut c_void, n_ranks: u32) -> c_int;
     pub fn mgx_halo_resident_disconnect(w: *mut mgx_world) -> c_int;
+    pub fn mgx_resident_outcome(w: *mut mgx_world, outcome: *mut i32) -> c_int;
+    pub fn mgx_resident_ready(w: *mut mgx_world, steps: *const u8, n: u32, ready: *mut i32) -> c_int;
+    pub fn mgx_resident_stats(w: *mut mgx_world, launches: *mut u64, declined: *mut u64, backoff: *mut u32) -> c_int;
     pub fn mgx_ipc_export(dev_ptr: *const c_void, handle: *mut u8) -> c_int;
     pub fn mgx_ipc_open(handle: *const u8, dev_ptr: *mut *mut c_void) -> c_int;
     pub fn mgx_ipc_close(dev_ptr: *mut c_void) -> c_int;

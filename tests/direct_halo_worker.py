@@ -1,6 +1,6 @@
 """One rank of the multi-process direct-halo test (tests/test_gpu_direct_halo_mp.py): every rank
 is its own process on cuda:0, the control plane is gloo, the data plane is hipIpc-mapped
-peer stores.  usage: direct_halo_worker.py RANK WORLD_SIZE PORT OUT.npz [direct | direct+resident]
+peer stores.  usage: direct_halo_worker.py RANK WORLD_SIZE PORT OUT.npz [direct | direct+resident | direct+resident+decline]
 (direct+resident: the ghost records travel inside ONE resident launch per schedule and rank)"""
 import os
 import sys
@@ -22,6 +22,8 @@ def main():
     sc = S.grid_scenario(64, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
     comm = sharded.TorchDistComm()
     sw = sharded.ShardedWorld(sc, rank, ws, World, comm=comm)
+    decline = mode.endswith("+decline")  # the last rank says no to the resident launch of tick 1: every rank falls back
+    mode = mode.replace("+decline", "")
     got = sharded.connect(sw, comm, resident=mode == "direct+resident")  # the default wiring: in-engine transports first
     assert got == mode, got
     steps = sc["steps"] + [1, 1, 2, 3, 2]
@@ -32,11 +34,16 @@ def main():
             sw.change_prior(boundary[2], 9, np.array([0.5, 0.25, 1.0, -1.0]))
         if tick == 2:
             sw.set_antenna(boundary[0], True)
+        if decline and rank == ws - 1:
+            sw.world.set_resident_launches("decline" if tick == 1 else True)
         sw.iterate(steps)
+        if decline and tick == 0:
+            assert sw.world.resident_stats()[:2] == (1, 0), sw.world.resident_stats()
     launches = sw.world.last_launch_count()
+    stats = sw.world.resident_stats()
     ids, eta, lam, mu = sw.read_beliefs()
     n = sw.world.halo_direct_status()
-    np.savez(out, ids=np.array(ids), eta=eta, lam=lam, mu=mu, n=n, launches=launches)
+    np.savez(out, ids=np.array(ids), eta=eta, lam=lam, mu=mu, n=n, launches=launches, stats=np.array(stats, dtype=np.int64))
     dist.barrier()
     sw.direct_close()
     dist.destroy_process_group()

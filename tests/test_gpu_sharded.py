@@ -46,16 +46,26 @@ def test_local_cluster_gating_and_prior_changes():
     assert_identical(cluster, ref, what="3 ranks, gating + change_prior on boundary robots")
 
 
+_RANK_STREAMS = []  # one stream per rank, created once and reused by every test of this module
+
+
 def _own_stream_factory():
-    """Every rank of a direct-exchange cluster needs its own stream (see LocalCluster)."""
+    """Every rank of a direct-exchange cluster needs its own stream (see LocalCluster) — and the ranks of a cluster whose
+    ghost records travel inside resident launches need streams the device runs SIDE BY SIDE: HIP maps streams onto a few
+    hardware queues, two kernels of one queue run one after the other, and a resident launch that waits for a rank behind it in
+    its own queue waits until its bound (seen in a soak run that took fresh streams from torch's pool for every script: 3 of 56
+    clusters).  So the same four streams — the first ones this process creates — serve every test.  (One process per GPU, the
+    real deployment, has no such coupling: every process has queues of its own.)"""
     import torch
-    streams = []
+    used = []
 
     def make(params):
-        st = torch.cuda.Stream()
-        streams.append(st)
+        if len(used) == len(_RANK_STREAMS):
+            _RANK_STREAMS.append(torch.cuda.Stream())
+        st = _RANK_STREAMS[len(used)]
+        used.append(st)
         return World(params, stream=st.cuda_stream)
-    return make, streams
+    return make, used
 
 
 @pytest.mark.parametrize("world_size", [2, 3])
@@ -292,13 +302,59 @@ def test_resident_launches_on_a_sharded_world(world_size, n, K):
     S.populate(ref, sc)
     scripts = [sc["steps"], sc["steps"], [2, 3, 3, 1, 3], [3], sc["steps"] + [1, 1, 2, 3, 2], [2, 2, 3]]
     for tick, steps in enumerate(scripts):
+        declined = getattr(cluster, "declined", 0)
+        backing_off = cluster.ranks[0].world.resident_stats()[2] > 0
         cluster.iterate(steps)
         ref.iterate(steps)
         for sw in cluster.ranks:
             sw.synchronize()  # raises if a wait inside a launch gave up
             want = 1 if len(sharded.segments(steps)) >= 2 else len(sharded.segments(steps))
-            assert sw.world.last_launch_count() == want, (tick, sw.plan.rank, sw.world.last_launch_count())
+            # (the ranks' launches run side by side only if the device takes them so — one process, streams that may share a
+            # hardware queue: if not, they find out, agree on "no" and the schedule runs launch by launch: counted, not failed)
+            if getattr(cluster, "declined", 0) == declined and not backing_off:
+                assert sw.world.last_launch_count() == want, (tick, sw.plan.rank, sw.world.last_launch_count())
         assert_identical(cluster, ref, what=f"resident launches, {world_size} ranks, tick {tick}")
+    print(f"{world_size} ranks: {getattr(cluster, 'declined', 0)} of {len(scripts)} schedules declined")
+
+
+def test_resident_sharded_rank_declines():
+    """The ranks' launches of one schedule go ahead together or not at all: one rank that says no (here: told to; in the field: its
+    workgroups do not all get onto the device, or its launch has not started when the others have waited long enough) says it on
+    the word all ranks look at before they write anything.  Every world is then as it was, the schedule runs launch by launch,
+    the following ones too (the back-off, the same on every rank) — and when that has run out they are resident launches again.
+    Beliefs of the single-world oracle throughout."""
+    sc = S.grid_scenario(48, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
+    make, streams = _own_stream_factory()
+    cluster = sharded.LocalCluster(sc, 3, make, direct=True, resident=True)
+    assert cluster.resident
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+
+    def both(steps, what):
+        cluster.iterate(steps)
+        ref.iterate(steps)
+        for sw in cluster.ranks:
+            sw.synchronize()
+        assert_identical(cluster, ref, what=what)
+    both(sc["steps"], "before")
+    before = [sw.world.resident_stats() for sw in cluster.ranks]
+    cluster.ranks[1].world.set_resident_launches("decline")
+    both([2, 3, 3, 1, 3], "the declined schedule (opens with an external iteration: its exchange ran in front of the launch)")
+    after = [sw.world.resident_stats() for sw in cluster.ranks]
+    assert cluster.declined >= 1
+    assert all(a[1] == b[1] + 1 for a, b in zip(after, before)), (before, after)  # every rank counts the same declined launch
+    assert len({a[2] for a in after}) == 1 and after[0][2] > 0                      # ... and backs off alike
+    cluster.ranks[1].world.set_resident_launches(True)
+    n = 0
+    while cluster.ranks[0].world.resident_stats()[2] > 0:
+        both(sc["steps"], f"backing off, schedule {n}")
+        assert all(sw.world.resident_stats()[0] == a[0] for sw, a in zip(cluster.ranks, after))  # no resident launch meanwhile
+        n += 1
+        assert n < 40
+    declined = cluster.declined
+    both(sc["steps"], "resident again")
+    if cluster.declined == declined:
+        assert all(sw.world.resident_stats()[0] == a[0] + 1 and sw.world.last_launch_count() == 1 for sw, a in zip(cluster.ranks, after))
 
 
 def test_resident_sharded_gating_and_prior_changes():
@@ -327,16 +383,36 @@ def test_resident_sharded_gating_and_prior_changes():
     assert_identical(cluster, ref, what="resident sharded launches, gating + change_prior on boundary robots")
 
 
-def test_resident_sharded_reports_a_missing_rank(monkeypatch):
-    """A rank that never launches its side: the others' workgroups give up after the bound and the world says so."""
-    monkeypatch.setenv("MGX_RESIDENT_TIMEOUT_MS", "300")
+def test_resident_sharded_survives_a_missing_rank():
+    """A rank that never launches its side: the launch of the other waits for it on the ranks' agreement word — before it has
+    written anything — gives up after the bound (MGX_RESIDENT_CENSUS_SHARDED_US) and returns: DECLINED, the world as it was."""
     from magics_amd import hostlib
     sc = S.grid_scenario(36, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
     make, streams = _own_stream_factory()
     cluster = sharded.LocalCluster(sc, 2, make, direct=True, resident=True)
     assert cluster.resident
     lonely = cluster.ranks[0]
-    lonely.world.iterate([3, 3, 3])  # rank 1 never runs
+    before = lonely.read_beliefs()
+    lonely.world.iterate([1, 3, 3])  # rank 1 never runs (a schedule that opens with an internal iteration: no exchange in front)
+    assert lonely.world.resident_outcome() == hostlib.RESIDENT_DECLINED
+    assert lonely.world.resident_outcome() == hostlib.RESIDENT_NONE
+    lonely.synchronize()
+    after = lonely.read_beliefs()
+    assert all(np.array_equal(a, b) for a, b in zip(before[1:], after[1:]))
+    assert lonely.world.resident_stats()[1] == 1
+
+
+def test_resident_sharded_without_agreement_reports_a_missing_rank(monkeypatch):
+    """Wired without a coordinator (mgx_halo_resident_connect: coordinator_area NULL) there is no agreement: a rank whose peer
+    never launches gives up after the bound on its waits and the world says so."""
+    monkeypatch.setenv("MGX_RESIDENT_TIMEOUT_MS", "300")
+    from magics_amd import hostlib
+    sc = S.grid_scenario(36, 10, interrobot=True, pitch=2.5, comm_radius=5.0)
+    make, streams = _own_stream_factory()
+    cluster = sharded.LocalCluster(sc, 2, make, direct=True, resident=True, agree=False)
+    assert cluster.resident
+    lonely = cluster.ranks[0]
+    lonely.world.iterate([1, 3, 3])  # rank 1 never runs (a schedule that opens with an internal iteration: no exchange in front)
     with pytest.raises(hostlib.MgxError):
         lonely.synchronize()
 
