@@ -83,49 +83,93 @@ __global__ void __launch_bounds__(256) k_pairs(const float *__restrict__ pos, in
 
 // ---- all pairs, ONE pass, rows of a fixed capacity (small worlds) ------------------------------------
 // A world of a few thousand robots is searched faster by one small kernel than by the six launches and three clears
-// of the grid: one 64-lane workgroup per 64 robots, positions of j tiled through LDS, row i written in place
-// (rows[i * cap + m], ascending j) and counted; a row that outgrows `cap` keeps counting, and the host repeats the
-// search with a larger capacity (it remembers the largest row).  One wave, a handful of registers and < 1 KB of LDS per
-// workgroup: the kernel finds room on a device whose CUs are otherwise taken by a resident schedule launch, so a search
-// enqueued beside that launch (on a stream of its own) does not have to wait for it.
-// Four lanes per robot (sixteen robots per workgroup): of every tile of 64 candidates lane l tests candidates 16 l .. 16 l + 15, so the
-// four lanes' hits, one lane after the other, are ascending in j.
-__global__ void __launch_bounds__(64) k_pairs_rows(const float *__restrict__ pos, int n, float s_max, int32_t cap,
-                                                   int32_t *__restrict__ cnt, int32_t *__restrict__ rows) {
-    __shared__ float tile[64 * 3];
-    const int i = blockIdx.x * 16 + (threadIdx.x >> 2), l = threadIdx.x & 3;
-    const bool live = i < n;
-    const float ax = live ? pos[3 * i] : 0.f, ay = live ? pos[3 * i + 1] : 0.f, az = live ? pos[3 * i + 2] : 0.f;
-    int m = 0;  // hits of robot i so far (the same in its four lanes)
-    int32_t *row = rows + (size_t)(live ? i : 0) * (size_t)cap;
-    for (int j0 = 0; j0 < n; j0 += 64) {
-        const int nj = min(64, n - j0);
-        __syncthreads();
-#pragma unroll 1
-        for (int q = threadIdx.x; q < 3 * nj; q += 64) tile[q] = pos[3 * j0 + q];  // (three trips at most)
-        __syncthreads();
-        unsigned hits = 0u;
-#pragma unroll 1
-        for (int k = 0; k < 16; k++) {  // (not unrolled: the kernel has to stay within 32 registers, see above)
-            const int q = 16 * l + k, j = j0 + q;
-            if (live && q < nj && j != i && in_comms_range_sq(ax, ay, az, tile[3 * q], tile[3 * q + 1], tile[3 * q + 2], s_max)) hits |= 1u << k;
-        }
-        const int c = __popc(hits);
-        int before = 0, all = 0;  // hits of the lower lanes of the quad, of the whole quad
+// of the grid.  The positions are the CALLER's, in a pinned block the kernel reads over the host link (a copy would be a
+// launch of its own), so what the kernel costs is link round trips, not arithmetic: every workgroup fetches ALL positions
+// in a few goes — 16-byte loads, six per lane in flight together — into LDS (structure of arrays), and only then compares
+// (the first version pulled them tile by tile, three dependent trips per tile of 64: 90 us for 1000 robots on an idle
+// device, most of a tick).  One wave = 16 robots x 4 lanes per workgroup.  Lane l of a robot's quad tests candidates
+// 4 k + l (neighbouring LDS words: no bank conflicts), 64 of them per pass; the quad then exchanges its four hit masks, and
+// every lane writes its own hits at their rank among all four masks — row i (rows[i * cap + m]) comes out ascending in j.
+// A row that outgrows `cap` keeps counting, and the host repeats the search with a larger capacity (it remembers the
+// largest row).  Beside a resident schedule launch: that kernel's two waves per SIMD leave 16 registers, so a search wave only
+// fits where a CU holds three of its workgroups instead of four — 1000 robots leave 24 such CUs, 47 KB of LDS each; one-wave
+// workgroups with 12 KB (1000 robots) all find room there at once (four-wave workgroups did not: measured, they finished
+// when the launch did).
+constexpr int ROWS_BLOCK = 64;
+// L lanes per robot (4 or 2): 16 or 32 robots per workgroup.  A world that fills the device with its resident launch (1000 robots:
+// 125 of an XCD's 128 workgroup slots) leaves three CUs per XCD one workgroup short, and each of those took two search waves at
+// a time (measured: 63 workgroups — eight per XCD — finished with the launch, 120 us; up to 993 resident workgroups they ran beside
+// it in 37 us), so between 512 and 1024 robots the search is 32 workgroups of two lanes per robot: four per XCD.
+template <int L>
+__global__ void __launch_bounds__(ROWS_BLOCK) k_pairs_rows(const float *__restrict__ pos, int n, float s_max, int32_t cap,
+                                                           int32_t *__restrict__ cnt, int32_t *__restrict__ rows) {
+    constexpr int ROBOTS = ROWS_BLOCK / L;
+    extern __shared__ float lds_pos[];
+    const int npad = (n + 3) & ~3;
+    float *X = lds_pos, *Y = lds_pos + npad, *Z = lds_pos + 2 * npad;
+    {   // 3 n floats, 16 bytes at a time (the block is 16-byte aligned; the last, partial group goes float by float)
+        const int n3 = 3 * n, n4 = n3 >> 2;
+        const float4 *p4 = reinterpret_cast<const float4 *>(pos);
+        constexpr int INFLIGHT = 6;
+        for (int g0 = 0; g0 < n4; g0 += ROWS_BLOCK * INFLIGHT) {
+            float4 v[INFLIGHT];
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
-            const int co = __shfl(c, (threadIdx.x & ~3) + o, 64);
-            before += o < l ? co : 0;
-            all += co;
+            for (int u = 0; u < INFLIGHT; u++) {
+                const int g = g0 + u * ROWS_BLOCK + (int)threadIdx.x;
+                v[u] = g < n4 ? p4[g] : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < INFLIGHT; u++) {
+                const int g = g0 + u * ROWS_BLOCK + (int)threadIdx.x;
+                if (g < n4) {
+                    const float c[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int e = 4 * g + q, j = e / 3, a = e - 3 * j;
+                        (a == 0 ? X : a == 1 ? Y : Z)[j] = c[q];
+                    }
+                }
+            }
         }
-        int at = m + before;
-        while (hits) {
-            const int k = __ffs(hits) - 1;
-            hits &= hits - 1u;
-            if (at < cap) row[at] = j0 + 16 * l + k;
-            at++;
+        for (int e = 4 * n4 + (int)threadIdx.x; e < n3; e += ROWS_BLOCK) {
+            const int j = e / 3, a = e - 3 * j;
+            (a == 0 ? X : a == 1 ? Y : Z)[j] = pos[e];
         }
-        m += all;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * ROBOTS + (int)threadIdx.x / L, l = (int)threadIdx.x % L;
+    const bool live = i < n;
+    const int ii = live ? i : 0;
+    const float ax = X[ii], ay = Y[ii], az = Z[ii];
+    int m = 0;  // hits of robot i so far (the same in all its lanes)
+    int32_t *row = rows + (size_t)ii * (size_t)cap;
+    const int group0 = (int)threadIdx.x - l;
+    for (int j0 = 0; j0 < n; j0 += 64 * L) {
+        unsigned long long hits = 0ull;
+#pragma unroll 4
+        for (int k = 0; k < 64; k++) {
+            const int j = j0 + L * k + l;
+            if (j < n && j != i && in_comms_range_sq(ax, ay, az, X[j], Y[j], Z[j], s_max)) hits |= 1ull << k;
+        }
+        if (!live) hits = 0ull;
+        unsigned long long mk[L];
+#pragma unroll
+        for (int o = 0; o < L; o++) {
+            const unsigned lo = (unsigned)__shfl((int)(unsigned)hits, group0 + o, 64), hi = (unsigned)__shfl((int)(unsigned)(hits >> 32), group0 + o, 64);
+            mk[o] = ((unsigned long long)hi << 32) | lo;
+        }
+        unsigned long long mine = hits;
+        while (mine) {
+            const int k = __ffsll((long long)mine) - 1;
+            mine &= mine - 1ull;
+            const unsigned long long below = (1ull << k) - 1ull;
+            int at = m;
+#pragma unroll
+            for (int o = 0; o < L; o++) at += __popcll(mk[o] & below) + (o < l ? (int)((mk[o] >> k) & 1ull) : 0);
+            if (at < cap) row[at] = j0 + L * k + l;
+        }
+#pragma unroll
+        for (int o = 0; o < L; o++) m += __popcll(mk[o]);
     }
     if (live && l == 0) cnt[i] = m;
 }
@@ -158,7 +202,12 @@ hipError_t neighbours_rows(const float *pos, int n, float radius, int32_t cap, i
         hipLaunchKernelGGL(k_stage_positions, dim3((unsigned)((3 * n + 63) / 64)), dim3(64), 0, s, pos, stage, 3 * n);
         pos = stage;
     }
-    hipLaunchKernelGGL(k_pairs_rows, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, s, pos, n, squared_threshold(radius), cap, cnt, rows);
+    const size_t lds = sizeof(float) * 3 * (size_t)((n + 3) & ~3);  // <= 48 KB: the host takes this kernel for n <= 4096
+    const float s_max = squared_threshold(radius);
+    if (n > 512 && n <= 1024)
+        hipLaunchKernelGGL(k_pairs_rows<2>, dim3((unsigned)((n + 31) / 32)), dim3(ROWS_BLOCK), lds, s, pos, n, s_max, cap, cnt, rows);
+    else
+        hipLaunchKernelGGL(k_pairs_rows<4>, dim3((unsigned)((n + 15) / 16)), dim3(ROWS_BLOCK), lds, s, pos, n, s_max, cap, cnt, rows);
     return hipGetLastError();
 }
 

@@ -279,6 +279,8 @@ struct ConnSets {
     int cap = 16;
     std::vector<int32_t> ids, cnt;
     std::vector<uint64_t> keys;
+    std::vector<uint8_t> ghost;   // the robots' ghost flags and radii, compact like the keys (fixed when a robot is added): the
+    std::vector<double> radius;   // per-tick passes over all connections read them instead of the robots themselves
     void ensure(size_t n) {
         if (cnt.size() < n) { cnt.resize(n, 0); ids.resize(n * (size_t)cap, 0); }
     }
@@ -391,7 +393,9 @@ struct mgx_world {
     StageRing stage;  // packed per-tick arguments
     // resident schedule launches (SegPlan, mgx_dev.h): progress words, peer lists, the abort / error words
     DevBuf<unsigned long long> sweep_flag_buf, sweep_abort_buf;
-    DevBuf<int32_t> peer_ptr_dev, peer_idx_dev;
+    DevBuf<int32_t> peer_ptr_dev;  // [R + 1 row pointers | entries]
+    size_t peer_idx_off = 0;
+    std::vector<int32_t> peer_fill;
     unsigned long long *sweep_err_host = nullptr;  // host-mapped; non-zero once a wait inside a resident launch gave up
     unsigned long long flag_base = 0;              // every progress word is below or at this value between launches
     bool resident_off = false;                     // mgx_set_resident_launches(w, 0)
@@ -533,7 +537,8 @@ struct mgx_world {
             p = nullptr;
             cap = 0;
             const size_t want = bytes + bytes / 2 + 4096;
-            const hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);  // the one-pass search reads and writes it in place
+            static const bool nc = [] { const char *v = getenv("MGX_PIN_NONCOHERENT"); return v && v[0] == '1'; }();
+            const hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped | (nc ? hipHostMallocNonCoherent : 0u));  // the one-pass search reads and writes it in place
             if (e == hipSuccess) cap = want;
             return e;
         }
@@ -745,14 +750,19 @@ static void flush_counts(mgx_world *w) {
     const size_t n = w->robots.size();
     const uint32_t en = w->p.enable_mask;
     const uint64_t dynf = (en & 1u) ? 2ull * (K - 1) : 0, obsf = (en & 4u) ? (uint64_t)(K - 2) : 0, trkf = (en & 8u) ? (uint64_t)(K - 2) : 0;
-    std::vector<uint64_t> own(n, 0), foreign(n, 0), nIv(n, 0), nEf(n, 0), nEv(n, 0);
-    for (const IrConn &c : w->conns) { own[(size_t)c.owner]++; foreign[(size_t)c.other]++; }
+    // Three passes: the robots (what each one's sweeps were, from the log), ONE pass over the connections (everything a connection
+    // counts, and what it contributes to its robots — a world with inter-robot factors has eight connections per robot, and
+    // the topology pass brings the counters up to date every tick), the robots again.  What the connection pass needs of a
+    // robot sits in compact arrays: a Robot is a dozen vectors wide.
+    std::vector<uint64_t> own(n, 0), foreign(n, 0), nIv(n, 0), nEf(n, 0), nEv(n, 0), nIfv(n, 0), trkv(n, 0), recv3(n, 0), on_ir;
+    std::vector<uint8_t> flags(n, 0);  // bit 0: on air (antenna and not idle), bit 1: idle
     for (size_t r = 0; r < n; r++) {
         Robot &rb = w->robots[r];
         // ghosts too: on a sharded world every rank sees the same launches and holds every robot's flags, so the sweeps a
         // ghost has run (what its variables answered to the factors local robots own) are known here; only the totals of
         // the ghost's own graph are its owner's business
         const bool idle = rb.idle != 0, radio = rb.antenna && !idle;
+        flags[r] = (uint8_t)((radio ? 1 : 0) | (idle ? 2 : 0));
         uint64_t nIf = 0, trk = 0;
         int64_t itf = rb.cnt_itf;
         for (const mgx_world::CountEntry &e : w->clog) {
@@ -778,48 +788,13 @@ static void flush_counts(mgx_world *w) {
             }
         }
         rb.cnt_itf = itf;
-        if (rb.ghost) continue;
-        const uint64_t s_int = 2ull * (K - 1) + 2ull * (K - 2) + (uint64_t)(K - 1) * own[r], s_ext = (uint64_t)(K - 1) * foreign[r];
-        // internal factor sweeps: one message per inbox key of every updated factor, received by the variables
-        rb.cnt[0] += nIf * (dynf + obsf) + trk * trkf;
-        rb.cnt[2] += nIf * (dynf + obsf) + trk * trkf;
-        // variable sweeps answer every inbox key; only own-graph, enabled factors receive (internal sweeps)
-        rb.cnt[0] += (nIv[r] + nEv[r]) * s_int;
-        rb.cnt[1] += (nIv[r] + nEv[r]) * s_ext;
-        rb.cnt[2] += nIv[r] * (dynf + obsf + trkf);
+        nIfv[r] = nIf;
+        trkv[r] = trk;
     }
-    if (en & 2u)
-        for (IrConn &c : w->conns) {
-            const Robot &a = w->robots[(size_t)c.owner], &b = w->robots[(size_t)c.other];
-            const bool radio_a = a.antenna && !a.idle, radio_b = b.antenna && !b.idle;
-            c.cnt[2] += nIv[(size_t)c.owner] * (uint64_t)(K - 1);            // own variables' responses (internal sweeps)
-            if (radio_a) c.cnt[3] += nEv[(size_t)c.other] * (uint64_t)(K - 1);  // the foreign variables' responses (robot.rs:1842-1858)
-            uint64_t to_own = nEf[(size_t)c.owner] * c.updates_per_sweep, to_foreign = to_own;  // external factor sweeps: one message per key
-            if (w->n_keyless > 0 && !c.keys.empty()) {  // some keys are still missing: replay the log in order until they are all there
-                to_own = to_foreign = 0;
-                for (const mgx_world::CountEntry &e : w->clog) {
-                    if (e.robot >= 0 && e.robot != c.owner) continue;  // per-robot launches run internal sweeps only
-                    for (uint64_t rep = 0; rep < e.times; rep++) {
-                        if (e.robot < 0 && (e.ext & 1u) && radio_a)
-                            for (size_t f = 0; f < c.keys.size(); f++) { to_own += c.uses[f] * (c.keys[f] & 1u); to_foreign += c.uses[f] * ((c.keys[f] >> 1) & 1u); }
-                        if (e.robot < 0 && (e.ext & 2u) && radio_a && radio_b)
-                            for (uint8_t &k : c.keys) k |= 2u;
-                        if ((e.in & 2u) && e.n_int > 0 && !a.idle)
-                            for (uint8_t &k : c.keys) k |= 1u;
-                        if ((e.in & 1u) && e.n_int > 1 && !a.idle) (void)0;  // internal factor sweeps do not touch these factors
-                    }
-                }
-                bool all = true;
-                for (uint8_t k : c.keys) all = all && k == 3u;
-                if (all) { c.keys.clear(); c.uses.clear(); w->n_keyless--; }
-            }
-            c.cnt[0] += to_own;
-            c.cnt[1] += to_foreign;
-            if (radio_b) w->robots[(size_t)c.other].cnt[3] += to_foreign;  // delivered (robot.rs:1813-1831)
-        }
     // change_prior (variable.rs:203-230): its sends stay in a local counter; the connected factors receive
-    if (!w->cp_dirty.empty()) {
-        std::vector<uint64_t> on_ir(n, 0);  // per robot: prior changes of variables that carry inter-robot factors (i >= 1)
+    const bool any_cp = !w->cp_dirty.empty();
+    if (any_cp) {
+        on_ir.assign(n, 0);  // per robot: prior changes of variables that carry inter-robot factors (i >= 1)
         for (uint32_t key : w->cp_dirty) {
             const size_t r = key / (uint32_t)K;
             const int i = (int)(key % (uint32_t)K);
@@ -830,13 +805,59 @@ static void flush_counts(mgx_world *w) {
             rb.cnt[2] += c * (((en & 1u) ? dyn_here : 0) + ((i >= 1 && i <= K - 2) ? (uint64_t)(((en & 4u) != 0) + ((en & 8u) != 0)) : 0));
             if (i >= 1) on_ir[r] += c;  // one inter-robot factor per connection hangs on this variable
         }
-        if (en & 2u)
-            for (IrConn &c : w->conns) {
-                c.cnt[2] += on_ir[(size_t)c.owner];  // the owner's own variable delivers to its factor
-                c.cnt[3] += on_ir[(size_t)c.other];  // the foreign variable delivers to it
-            }
         w->cp_dirty.clear();
     }
+    const bool ir_counts = (en & 2u) != 0, log_any = !w->clog.empty();
+    for (IrConn &c : w->conns) {
+        const size_t o = (size_t)c.owner, t = (size_t)c.other;
+        own[o]++;
+        foreign[t]++;
+        if (!ir_counts) continue;
+        if (any_cp) {
+            c.cnt[2] += on_ir[o];  // the owner's own variable delivers to its factor
+            c.cnt[3] += on_ir[t];  // the foreign variable delivers to it
+        }
+        if (!log_any && !(w->n_keyless > 0 && !c.keys.empty())) continue;
+        const bool radio_a = (flags[o] & 1u) != 0, radio_b = (flags[t] & 1u) != 0;
+        c.cnt[2] += nIv[o] * (uint64_t)(K - 1);               // own variables' responses (internal sweeps)
+        if (radio_a) c.cnt[3] += nEv[t] * (uint64_t)(K - 1);  // the foreign variables' responses (robot.rs:1842-1858)
+        uint64_t to_own = nEf[o] * c.updates_per_sweep, to_foreign = to_own;  // external factor sweeps: one message per key
+        if (w->n_keyless > 0 && !c.keys.empty()) {  // some keys are still missing: replay the log in order until they are all there
+            const bool a_idle = (flags[o] & 2u) != 0;
+            to_own = to_foreign = 0;
+            for (const mgx_world::CountEntry &e : w->clog) {
+                if (e.robot >= 0 && e.robot != c.owner) continue;  // per-robot launches run internal sweeps only
+                for (uint64_t rep = 0; rep < e.times; rep++) {
+                    if (e.robot < 0 && (e.ext & 1u) && radio_a)
+                        for (size_t f = 0; f < c.keys.size(); f++) { to_own += c.uses[f] * (c.keys[f] & 1u); to_foreign += c.uses[f] * ((c.keys[f] >> 1) & 1u); }
+                    if (e.robot < 0 && (e.ext & 2u) && radio_a && radio_b)
+                        for (uint8_t &k : c.keys) k |= 2u;
+                    if ((e.in & 2u) && e.n_int > 0 && !a_idle)
+                        for (uint8_t &k : c.keys) k |= 1u;
+                }
+            }
+            bool all = true;
+            for (uint8_t k : c.keys) all = all && k == 3u;
+            if (all) { c.keys.clear(); c.uses.clear(); w->n_keyless--; }
+        }
+        c.cnt[0] += to_own;
+        c.cnt[1] += to_foreign;
+        if (radio_b) recv3[t] += to_foreign;  // delivered (robot.rs:1813-1831)
+    }
+    if (log_any)
+        for (size_t r = 0; r < n; r++) {
+            Robot &rb = w->robots[r];
+            rb.cnt[3] += recv3[r];
+            if (rb.ghost) continue;
+            const uint64_t s_int = 2ull * (K - 1) + 2ull * (K - 2) + (uint64_t)(K - 1) * own[r], s_ext = (uint64_t)(K - 1) * foreign[r];
+            // internal factor sweeps: one message per inbox key of every updated factor, received by the variables
+            rb.cnt[0] += nIfv[r] * (dynf + obsf) + trkv[r] * trkf;
+            rb.cnt[2] += nIfv[r] * (dynf + obsf) + trkv[r] * trkf;
+            // variable sweeps answer every inbox key; only own-graph, enabled factors receive (internal sweeps)
+            rb.cnt[0] += (nIv[r] + nEv[r]) * s_int;
+            rb.cnt[1] += (nIv[r] + nEv[r]) * s_ext;
+            rb.cnt[2] += nIv[r] * (dynf + obsf + trkf);
+        }
     w->clog.clear();
 }
 static void log_launch(mgx_world *w, int robot, uint32_t ext_mask, uint32_t int_mask, int n_int) {
@@ -917,22 +938,27 @@ static size_t edge_index(const std::vector<int32_t> &in_ptr, int K, int r, int j
 }
 static void build_incoming(const mgx_world *w, int R_local, Incoming &t) {
     const int K = w->K;
+    const uint64_t *key = w->sets.keys.data();  // (compact copies of the robots' order keys and ghost flags: a Robot is a dozen vectors wide)
+    const uint8_t *ghost = w->sets.ghost.data();
+    const int32_t *dev_of = w->dev_of.data();
+    const IrConn *conns = w->conns.data();
+    const size_t n_conns = w->conns.size();
     t.in_ptr.assign((size_t)R_local + 1, 0);
     t.mid.assign((size_t)std::max(R_local, 1), 0);
-    for (const IrConn &c : w->conns)
-        if (!w->robots[(size_t)c.other].ghost) t.in_ptr[(size_t)w->dev_of[(size_t)c.other] + 1]++;  // ghost target: another rank's
+    for (size_t ci = 0; ci < n_conns; ci++)
+        if (!ghost[(size_t)conns[ci].other]) t.in_ptr[(size_t)dev_of[(size_t)conns[ci].other] + 1]++;  // ghost target: another rank's
     for (int r = 0; r < R_local; r++) t.in_ptr[(size_t)r + 1] += t.in_ptr[(size_t)r];
     t.in_list.assign((size_t)t.in_ptr[(size_t)R_local], 0);
     std::vector<int32_t> fill(t.in_ptr.begin(), t.in_ptr.end() - 1);
-    for (size_t ci = 0; ci < w->conns.size(); ci++)
-        if (!w->robots[(size_t)w->conns[ci].other].ghost) t.in_list[(size_t)fill[(size_t)w->dev_of[(size_t)w->conns[ci].other]]++] = (int32_t)ci;
+    for (size_t ci = 0; ci < n_conns; ci++)
+        if (!ghost[(size_t)conns[ci].other]) t.in_list[(size_t)fill[(size_t)dev_of[(size_t)conns[ci].other]]++] = (int32_t)ci;
     t.ir_max_edges = 0;
     for (int r = 0; r < R_local; r++) {
         int32_t *seg = t.in_list.data() + t.in_ptr[(size_t)r];
         const int n_in = t.in_ptr[(size_t)r + 1] - t.in_ptr[(size_t)r];
         auto before = [&](int32_t a, int32_t b) {
-            const IrConn &ca = w->conns[(size_t)a], &cb = w->conns[(size_t)b];
-            const uint64_t ka = w->robots[(size_t)ca.owner].order_key, kb = w->robots[(size_t)cb.owner].order_key;
+            const IrConn &ca = conns[(size_t)a], &cb = conns[(size_t)b];
+            const uint64_t ka = key[(size_t)ca.owner], kb = key[(size_t)cb.owner];
             if (ka != kb) return ka < kb;
             if ((ca.node_first < cb.node_first) != (ca.node_last < cb.node_last)) t.blocks_ok = false;
             return ca.node_first < cb.node_first;
@@ -943,10 +969,10 @@ static void build_incoming(const mgx_world *w, int R_local, Incoming &t) {
             while (b > 0 && before(v, seg[b - 1])) { seg[b] = seg[b - 1]; b--; }
             seg[b] = v;
         }
-        const uint64_t own_key = w->robots[(size_t)w->robot_of[(size_t)r]].order_key;
+        const uint64_t own_key = key[(size_t)w->robot_of[(size_t)r]];
         int mid = n_in;  // first connection whose owner has a HIGHER key than the target
         for (int q = n_in - 1; q >= 0; q--)
-            if (w->robots[(size_t)w->conns[(size_t)seg[q]].owner].order_key > own_key) mid = q;
+            if (key[(size_t)conns[(size_t)seg[q]].owner] > own_key) mid = q;
         t.mid[(size_t)r] = mid;
         t.ir_max_edges = std::max(t.ir_max_edges, n_in * (K - 1));
     }
@@ -983,13 +1009,12 @@ static int retopo(mgx_world *w) {
     std::vector<IrSlotRec> slots(std::max<size_t>(n_slots, 1));
     for (size_t g = 0; g < n_slots; g++) {
         const IrConn &c = w->conns[(size_t)t.in_list[g]];
-        const Robot &ow = w->robots[(size_t)c.owner], &ot = w->robots[(size_t)c.other];
         IrSlotRec &sl = slots[g];
         sl.tgt_robot = w->dev_of[(size_t)c.other];
         sl.src_robot = w->dev_of[(size_t)c.owner];
         sl.old_slot = c.dev_slot;
-        sl.flags = (ot.order_key > ow.order_key) ? 1 : 0;
-        sl.d_safe = w->p.safety_multiplier * ow.radius;
+        sl.flags = (w->sets.keys[(size_t)c.other] > w->sets.keys[(size_t)c.owner]) ? 1 : 0;
+        sl.d_safe = w->p.safety_multiplier * w->sets.radius[(size_t)c.owner];
         sl.first_number = c.first_number;
     }
     tm.lap("slot records");
@@ -1475,46 +1500,44 @@ static int ensure_resident_tables(mgx_world *w) {
         w->d.decision_host = (unsigned long long *)dp;
     }
     if (!w->peers_valid) {
-        // (lists of the LOCAL robots; a ghost — device index >= R — appears in them as a peer, its word lives in the ghost area)
-        std::vector<int32_t> ptr(R + 1, 0);
-        for (const IrConn &c : w->conns) {
-            const size_t o = (size_t)w->dev_of[(size_t)c.owner], t = (size_t)w->dev_of[(size_t)c.other];
+        // (lists of the LOCAL robots; a ghost — device index >= R — appears in them as a peer, its word lives in the ghost area.)
+        // A list is what its robot's polling lanes walk, nothing more: its order carries no meaning and a robot that is both the
+        // owner of an incoming and the target of an outgoing connection — the rule — may stand in it twice (two lanes look at
+        // the same word).  So the table is two passes over the connections, written straight into the pinned block it travels
+        // in ([R + 1 row pointers | entries], ONE copy): a world that follows its topology builds it every tick.
+        const size_t n_conns = w->conns.size();
+        const IrConn *conns = w->conns.data();
+        const int32_t *dev_of = w->dev_of.data();
+        void *hp = nullptr;
+        int slot = 0;
+        const size_t words = R + 1 + std::max<size_t>(2 * n_conns, 1);
+        HIP_TRY(w->stage.acquire(sizeof(int32_t) * words, &hp, &slot));
+        int32_t *ptr = (int32_t *)hp, *idx = ptr + R + 1;
+        std::fill(ptr, ptr + R + 1, 0);
+        for (size_t ci = 0; ci < n_conns; ci++) {
+            const size_t o = (size_t)dev_of[(size_t)conns[ci].owner], t = (size_t)dev_of[(size_t)conns[ci].other];
             if (o < R) ptr[o + 1]++;
             if (t < R) ptr[t + 1]++;
         }
         for (size_t r = 0; r < R; r++) ptr[r + 1] += ptr[r];
-        std::vector<int32_t> idx((size_t)ptr[R]), fill(ptr.begin(), ptr.end() - 1);
-        for (const IrConn &c : w->conns) {
-            const int o = w->dev_of[(size_t)c.owner], t = w->dev_of[(size_t)c.other];
+        std::vector<int32_t> &fill = w->peer_fill;
+        fill.assign(ptr, ptr + R);
+        for (size_t ci = 0; ci < n_conns; ci++) {
+            const int o = dev_of[(size_t)conns[ci].owner], t = dev_of[(size_t)conns[ci].other];
             if ((size_t)o < R) idx[(size_t)fill[(size_t)o]++] = t;
             if ((size_t)t < R) idx[(size_t)fill[(size_t)t]++] = o;
         }
-        std::vector<int32_t> uptr(R + 1, 0), uidx;
-        uidx.reserve(idx.size());
-        for (size_t r = 0; r < R; r++) {
-            std::sort(idx.begin() + ptr[r], idx.begin() + ptr[r + 1]);
-            for (int q = ptr[r]; q < ptr[r + 1]; q++)
-                if (q == ptr[r] || idx[(size_t)q] != idx[(size_t)q - 1]) uidx.push_back(idx[(size_t)q]);
-            uptr[r + 1] = (int32_t)uidx.size();
-        }
-        if (uidx.empty()) uidx.push_back(0);
-        const size_t b_ptr = sizeof(int32_t) * uptr.size(), b_idx = sizeof(int32_t) * uidx.size();
-        void *hp = nullptr;
-        int slot = 0;
-        HIP_TRY(w->stage.acquire(b_ptr + b_idx, &hp, &slot));
-        memcpy(hp, uptr.data(), b_ptr);
-        memcpy((char *)hp + b_ptr, uidx.data(), b_idx);
-        HIP_TRY(w->peer_ptr_dev.reserve(uptr.size()));
-        HIP_TRY(w->peer_idx_dev.reserve(uidx.size()));
-        HIP_TRY(hipMemcpyAsync(w->peer_ptr_dev.p, hp, b_ptr, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(w->peer_idx_dev.p, (char *)hp + b_ptr, b_idx, hipMemcpyHostToDevice, s));
+        if (ptr[R] == 0) idx[0] = 0;
+        HIP_TRY(w->peer_ptr_dev.reserve(words));
+        HIP_TRY(hipMemcpyAsync(w->peer_ptr_dev.p, hp, sizeof(int32_t) * (R + 1 + (size_t)std::max(ptr[R], 1)), hipMemcpyHostToDevice, s));
         HIP_TRY(w->stage.release(slot, s));
+        w->peer_idx_off = R + 1;
         w->peers_valid = true;
     }
     w->d.sweep_flag = w->sweep_flag_buf.p;
     w->d.sweep_abort = w->sweep_abort_buf.p;
     w->d.peer_ptr = w->peer_ptr_dev.p;
-    w->d.peer_idx = w->peer_idx_dev.p;
+    w->d.peer_idx = w->peer_ptr_dev.p + w->peer_idx_off;
     return MGX_OK;
 }
 // Runs the schedule as resident launches if this world qualifies: 1 = done, 0 = not eligible (the caller takes the
@@ -1539,6 +1562,7 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
     if (!resident_gate(w, plan)) return 0;
+    StageTimer tr("resident");
     const DevWorld &d = w->d;
     const bool sharded = w->xres.connected;
     // What follows is this rank's own: where the ranks agree on every schedule (xres.agree) a rank
@@ -1562,8 +1586,10 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
             if (ranks_agree) can = false;
         }
     }
+    tr.lap("gate + capacity");
     rc = ensure_resident_tables(w);
     if (rc != MGX_OK) return rc;
+    tr.lap("peer tables");
     static const long long timeout_ticks = [] {
         const char *e = getenv("MGX_RESIDENT_TIMEOUT_MS");
         const long long ms = e ? atoll(e) : 2000;
@@ -1788,6 +1814,8 @@ int mgx_robot_add(mgx_world *w, const mgx_robot_desc *d, int32_t *robot_id) {
     }
     if (d->n_path && d->path_xy) rb.path.assign(d->path_xy, d->path_xy + 2 * (size_t)d->n_path);
     w->sets.keys.push_back(rb.order_key);
+    w->sets.ghost.push_back(rb.ghost ? 1 : 0);
+    w->sets.radius.push_back(rb.radius);
     w->robots.push_back(std::move(rb));
     w->sets.ensure(w->robots.size());
     w->K = K;
@@ -2116,7 +2144,16 @@ static int neighbours_enqueue(mgx_world *w, const float *pos, float radius, uint
     // (The missions' search reads the device's Transforms, which the tick's kernels move: that one stays in stream order.)
     hipStream_t s = w->stream;
     if (!from_missions) {
-        if (!w->search_stream) HIP_TRY(hipStreamCreateWithFlags(&w->search_stream, hipStreamNonBlocking));
+        // (never beside a resident launch that is still getting onto the device: the search's waves would take slots its last
+        // workgroups need — see mgx_update_topology)
+        if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
+        if (!w->search_stream) {
+            static const bool prio = [] { const char *e = getenv("MGX_SEARCH_PRIORITY"); return e && e[0] == '1'; }();
+            int lo = 0, hi = 0;
+            if (prio) HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            if (prio) HIP_TRY(hipStreamCreateWithPriority(&w->search_stream, hipStreamNonBlocking, hi));
+            else HIP_TRY(hipStreamCreateWithFlags(&w->search_stream, hipStreamNonBlocking));
+        }
         s = w->search_stream;
     }
     if (w->nb_last_stream_set && w->nb_last_stream != s) HIP_TRY(hipStreamSynchronize(w->nb_last_stream));  // the scratch buffers are shared
@@ -2302,31 +2339,26 @@ int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, 
     if (method > MGX_NEIGHBOURS_GRID) return fail(MGX_ERR_INVALID, "bad method");
     std::vector<int32_t> ptr, idx;
     StageTimer tm("update_topology");
-    // update_robot_neighbours (robot.rs:1362-1384): the search is enqueued (a small world's search runs BESIDE the GBP schedule
-    // of the tick before, on a stream of its own), and while the device gets to it the host does what does not need its
-    // result: the connections are listed by owner.  The message counters are brought up to date behind it (the pass is
-    // about to change who sends to whom): they wait for the last resident launch to be decided, which it is by then.
+    // update_robot_neighbours (robot.rs:1362-1384).  A small world's search runs BESIDE the GBP schedule of the tick before, on a
+    // stream of its own — but it must not get onto the device before that schedule's resident launch has all its workgroups
+    // there: enqueued a few microseconds behind the launch, its waves took slots the launch's last workgroups needed, the
+    // residency census said no and the tick ran launch by launch (seen: three of sixty ticks, 0.8 ms each).  So the host
+    // lists the connections by owner first — that needs nothing from the device — and only then, with the launch decided
+    // (microseconds after its start), enqueues the search; the message counters are brought up to date under it (the pass
+    // is about to change who sends to whom).
+    OwnerLists own_lists;
+    own_lists.build(w);
+    tm.lap("owner lists");
+    if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     mgx_world::PendingSearch ps;
     int rc = neighbours_enqueue(w, positions_xyz, radius, method, ps);
     if (rc != MGX_OK) return rc;
     tm.lap("search enqueued");
-    OwnerLists own_lists;
-    own_lists.build(w);
-    tm.lap("owner lists (under the search)");
-    // (under the search too, if the last resident launch has been decided by now — waiting for that here would only
-    // trade one wait for another)
-    const bool counters_early = !w->pending.active || (__atomic_load_n(w->decision_host, __ATOMIC_ACQUIRE) >> 2) >= w->pending.seq;
-    if (counters_early) {
-        flush_counts(w);
-        tm.lap("message counters (under the search)");
-    }
+    flush_counts(w);
+    tm.lap("message counters (under the search)");
     rc = neighbours_collect(w, ps, ptr, idx);
     if (rc != MGX_OK) return rc;
     tm.lap("neighbour search");
-    if (!counters_early) {
-        flush_counts(w);
-        tm.lap("message counters");
-    }
     return topology_bookkeeping(w, ptr, idx, robot_number_next, stats, tm, &own_lists);
 }
 // delete_interrobot_factors + create_interrobot_factors on the search's result (rows per robot id, ascending)

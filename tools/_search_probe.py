@@ -1,0 +1,27 @@
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+import torch  # noqa
+from magics_amd import World, scenarios as S
+sc = S.grid_scenario(1000, 16, interrobot=True, seed=805)
+sc["ir"] = []
+w = World(sc["params"]); S.populate(w, sc)
+rng = np.random.default_rng(805)
+base = np.array([[rb["pos"][0], 0.5, rb["pos"][1]] for rb in sc["robots"]], dtype=np.float32)
+tk = S.tick_inputs(sc)
+nxt, _, _ = w.update_topology(base, 8.0, 1)
+w.iterate(sc["steps"]); w.synchronize()
+for i in range(6):
+    pos = base + rng.normal(0, 0.15, size=base.shape).astype(np.float32)
+    w.synchronize()
+    print("--- idle GPU", flush=True)
+    nxt, c, d = w.update_topology(pos, 8.0, nxt)
+    w.tick(steps=sc["steps"], **tk)
+w.synchronize()
+ts = []
+for i in range(30):
+    pos = base + rng.normal(0, 0.15, size=base.shape).astype(np.float32)
+    t0 = time.perf_counter()
+    w.neighbours(pos, 8.0)
+    ts.append((time.perf_counter() - t0) * 1e6)
+print("neighbours() x2 searches, idle GPU: median %.1f us, min %.1f" % (np.median(ts), min(ts)))

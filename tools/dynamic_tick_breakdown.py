@@ -4,7 +4,8 @@ import numpy as np
 sys.path.insert(0, ".")
 import torch  # noqa
 from magics_amd import World, scenarios as S
-sc = S.grid_scenario(1000, 16, interrobot=True, seed=805)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+sc = S.grid_scenario(N, 16, interrobot=True, seed=805)
 sc["ir"] = []
 w = World(sc["params"]); S.populate(w, sc)
 rng = np.random.default_rng(805)
