@@ -287,6 +287,7 @@ def transport_child(a):
         def sync():
             sw.synchronize()  # mgx_synchronize: raises if a wait on the device gave up
         verified = None
+        declined_note = ""
         try:
             # the same two ticks on a world whose exchange is driven from the host (pack / all-to-all-v over the control plane /
             # unpack): the in-engine transport has to leave bit-identical beliefs
@@ -300,6 +301,12 @@ def transport_child(a):
             same = all(np.array_equal(x, y) for x, y in zip(sw.read_beliefs()[1:], ref.read_beliefs()[1:]))
             verified = agree(same)
             del ref
+            # resident launches the ranks could not agree on (a rank late, crowded out, the agreement word out of reach) cost
+            # a wait each before they fall back: if the two ticks above saw any, the measurement is the plain direct transport's
+            if got == "direct+resident" and not agree(sw.world.resident_stats()[1] == 0):
+                sw.world.set_resident_launches(False)
+                got = "direct"
+                declined_note = "resident launches were declined by the ranks' agreement during verification: switched off"
             walls, devs = timed(torch, dist, sw.iterate, sc2["steps"], a, True, red_dev="cpu", sync=sync)
         except Exception as e:  # noqa: BLE001
             err = f"{type(e).__name__}: {e}"
@@ -322,6 +329,11 @@ def transport_child(a):
                                "RCCL inside the engine: grouped ncclSend / ncclRecv per external iteration on the launch stream, "
                                "one C call per tick",
                    "ghost_robots_this_rank": len(sw.plan.ghosts)}
+            if got.startswith("direct"):
+                st = sw.world.resident_stats()
+                out["resident_launches"], out["resident_declined"] = int(st[0]), int(st[1])
+            if declined_note:
+                out["note"] = declined_note
     if rank == 0:
         print(json.dumps(out), flush=True)
     dist.barrier()
@@ -567,6 +579,12 @@ def main():
                     err, same = f"{type(e).__name__}: {e}", False
                 verified = agree(same)
                 walls_i = devs_i = None
+                if verified and got == "direct+resident" and not agree(sw_in.world.resident_stats()[1] == 0):
+                    # (see the probe: declined launches cost a wait each — measure the plain direct transport instead)
+                    sw_in.world.set_resident_launches(False)
+                    got = "direct"
+                    if rank == 0:
+                        line["in_engine_note"] = "resident launches were declined by the ranks' agreement during verification: switched off"
                 if verified:
                     try:
                         walls_i, devs_i = timed(torch, dist, sw_in.iterate, sc2["steps"], a, True, red_dev, sync=sw_in.synchronize)
@@ -576,8 +594,11 @@ def main():
                         err = f"{type(e).__name__}: {e}"
                 if verified and agree(not err):
                     ri = summary(walls_i, devs_i, a.steps, units_per_step=world_size)
-                    in_engine = {"transport": got, "result": ri, "launches_per_tick": sw_in.world.last_launch_count()}
+                    in_engine = {"transport": got, "result": ri, "launches_per_tick": sw_in.world.last_launch_count(),
+                                 "resident_stats": [int(x) for x in sw_in.world.resident_stats()]}
                     by_transport[got + " (in the bench process)"] = round(ri["value"], 2)
+                    if rank == 0:  # (resident launches so far, declined by the ranks' agreement, back-off left)
+                        line["in_engine_resident_stats"] = in_engine["resident_stats"]
         if in_engine is None and rank == 0:
             line["in_engine_in_process"] = {"error": err or "another rank failed, or the beliefs differed from the host-driven exchange's"}
         if sw_in is not None:
