@@ -230,9 +230,9 @@ struct SegPlan {
     long long census_ticks;
     // Sharded worlds: the ranks' launches of one schedule wait for each other's ghost records, so they go ahead together or
     // not at all.  agree_seq numbers the schedule (the same on every rank; 0: this world has no other ranks).  A rank whose
-    // census is complete signs in on the agreement word (DevWorld::agree: schedule number << 16 | state << 14 | ranks signed
-    // in); the last one to sign in turns the word to go, a rank that has waited census_ticks for the others — or whose own
-    // workgroups are not all there — turns it to abort, both by compare-and-swap, so that every rank reads the same answer.
+    // census is complete signs in on the agreement word (DevWorld::agree, agree_on_launch below); the last one to sign in
+    // turns the word to go, a rank that has waited census_ticks for the others — or whose own workgroups are not all there —
+    // turns it to abort, both by compare-and-swap, so that every rank reads the same answer.
     unsigned long long agree_seq;
 };
 constexpr unsigned RESIDENT_GO = 1u, RESIDENT_ABORT = 2u;
@@ -240,21 +240,27 @@ constexpr unsigned RESIDENT_GO = 1u, RESIDENT_ABORT = 2u;
 // One look at / one move on the agreement word of a sharded world's resident launches (SegPlan::agree_seq).
 // action 0: look; 1: sign in (the caller's census is complete — once per launch); 2: vote abort.
 // Returns the word's state for schedule L: 0 while undecided, RESIDENT_GO or RESIDENT_ABORT.
+// The word: schedule number << 18 | outcome of the schedule before << 16 | state << 14 | ranks signed in.  The outcome of the
+// schedule before rides along because ranks that share no robots do not wait for each other: one of them can be through
+// schedule L and sign in for L + 1 before a slow rank's decider has looked at L's outcome — which it then still finds.
 constexpr int AGREE_LOOK = 0, AGREE_SIGN_IN = 1, AGREE_ABORT = 2;
 __device__ inline unsigned agree_on_launch(unsigned long long *word, unsigned long long L, unsigned n_ranks, int action) {
     unsigned long long cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (;;) {
-        const unsigned long long cl = cur >> 16;
-        const unsigned st = (unsigned)(cur >> 14) & 3u, cnt = (unsigned)cur & 0x3fffu;
+        const unsigned long long cl = cur >> 18;
+        const unsigned prev = (unsigned)(cur >> 16) & 3u, st = (unsigned)(cur >> 14) & 3u, cnt = (unsigned)cur & 0x3fffu;
         if (cl == L && st) return st;
-        if (cl > L) return RESIDENT_ABORT;  // the other ranks are a schedule ahead: cannot happen while the ranks run the same calls
+        if (cl == L + 1ull && prev) return prev;
+        if (cl > L) return RESIDENT_ABORT;  // more than a schedule behind: only after this rank was given up on
         if (action == AGREE_LOOK) return 0u;
+        // (a word of an earlier schedule: the first move of schedule L carries that one's outcome along)
+        const unsigned long long carry = (unsigned long long)(cl == L ? prev : (cl + 1ull == L ? st : RESIDENT_ABORT)) << 16;
         unsigned long long nw;
         if (action == AGREE_SIGN_IN) {
             const unsigned c = (cl == L ? cnt : 0u) + 1u;
-            nw = (L << 16) | ((unsigned long long)(c >= n_ranks ? RESIDENT_GO : 0u) << 14) | c;
+            nw = (L << 18) | carry | ((unsigned long long)(c >= n_ranks ? RESIDENT_GO : 0u) << 14) | c;
         } else {
-            nw = (L << 16) | ((unsigned long long)RESIDENT_ABORT << 14) | (cl == L ? cnt : 0u);
+            nw = (L << 18) | carry | ((unsigned long long)RESIDENT_ABORT << 14) | (cl == L ? cnt : 0u);
         }
         if (__hip_atomic_compare_exchange_strong(word, &cur, nw, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
             return (unsigned)(nw >> 14) & 3u;

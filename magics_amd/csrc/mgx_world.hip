@@ -3451,7 +3451,7 @@ int mgx_halo_resident_connect(mgx_world *w, uint32_t n_targets, const int32_t *r
                               const uint32_t *peer_ghost_slots, const uint32_t *peer_slot, const uint32_t *peer_parity,
                               const uint64_t *peer_segment_count, void *coordinator_area, uint32_t n_ranks) {
     if (!w) return fail(MGX_ERR_INVALID, "null world");
-    if (n_ranks > 0x3fffu) return fail(MGX_ERR_INVALID, "at most %u ranks", 0x3fffu);
+    if (n_ranks > 0x3fffu) return fail(MGX_ERR_INVALID, "at most %u ranks", 0x3fffu);  // (the agreement word counts them in 14 bits)
     if (n_targets && (!robots || !peer_area_base || !peer_ghost_slots || !peer_slot || !peer_parity || !peer_segment_count))
         return fail(MGX_ERR_INVALID, "null argument");
     mgx_world::ResidentHalo &xr = w->xres;

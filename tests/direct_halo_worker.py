@@ -1,6 +1,6 @@
 """One rank of the multi-process direct-halo test (tests/test_gpu_direct_halo_mp.py): every rank
 is its own process on cuda:0, the control plane is gloo, the data plane is hipIpc-mapped
-peer stores.  usage: direct_halo_worker.py RANK WORLD_SIZE PORT OUT.npz [direct | direct+resident | direct+resident+decline]
+peer stores.  usage: direct_halo_worker.py RANK WORLD_SIZE PORT OUT.npz [direct | direct+resident | direct+resident+decline | direct+resident+late]
 (direct+resident: the ghost records travel inside ONE resident launch per schedule and rank)"""
 import os
 import sys
@@ -23,7 +23,8 @@ def main():
     comm = sharded.TorchDistComm()
     sw = sharded.ShardedWorld(sc, rank, ws, World, comm=comm)
     decline = mode.endswith("+decline")  # the last rank says no to the resident launch of tick 1: every rank falls back
-    mode = mode.replace("+decline", "")
+    late = mode.endswith("+late")        # the last rank starts tick 1 long after the others have given up waiting for it
+    mode = mode.replace("+decline", "").replace("+late", "")
     got = sharded.connect(sw, comm, resident=mode == "direct+resident")  # the default wiring: in-engine transports first
     assert got == mode, got
     steps = sc["steps"] + [1, 1, 2, 3, 2]
@@ -36,8 +37,14 @@ def main():
             sw.set_antenna(boundary[0], True)
         if decline and rank == ws - 1:
             sw.world.set_resident_launches("decline" if tick == 1 else True)
+        if late and tick == 1:
+            sw.synchronize()
+            dist.barrier()
+            if rank == ws - 1:
+                import time
+                time.sleep(0.08)
         sw.iterate(steps)
-        if decline and tick == 0:
+        if (decline or late) and tick == 0:
             assert sw.world.resident_stats()[:2] == (1, 0), sw.world.resident_stats()
     launches = sw.world.last_launch_count()
     stats = sw.world.resident_stats()

@@ -24,13 +24,15 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world_size,mode", [(2, "direct"), (3, "direct"), (2, "direct+resident"), (3, "direct+resident"),
-                                             (3, "direct+resident+decline")])
+                                             (3, "direct+resident+decline"), (3, "direct+resident+late")])
 def test_ranks_in_separate_processes(world_size, mode, tmp_path):
     """mode "direct+resident": every rank's schedule is ONE resident launch and the ghost records cross the process
     boundary inside it (hipIpc-mapped ghost areas, system-scope stores and polls).
     "+decline": the last rank says no to the launch of the second tick — on the word in rank 0's area where the ranks agree on
     every schedule, so ALL ranks' launches return with their worlds untouched, every engine runs that schedule launch by launch
-    with the direct exchange, and the third tick (inside the back-off) runs launch by launch on every rank too."""
+    with the direct exchange, and the third tick (inside the back-off) runs launch by launch on every rank too.
+    "+late": the last rank issues the second tick 80 ms after the others — whose launches have given up waiting for it on that word
+    (MGX_RESIDENT_CENSUS_SHARDED_US, 5 ms) and returned; its own launch finds their "no" and returns as well."""
     port = _free_port()
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(world_size)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MGX_HALO_TIMEOUT_MS="20000", MGX_RESIDENT_TIMEOUT_MS="20000")
@@ -63,13 +65,13 @@ def test_ranks_in_separate_processes(world_size, mode, tmp_path):
     eta_r, lam_r, mu_r = ref.read_beliefs()
     # exchanges by the push / wait kernels: one per external iteration — or none at all when the schedule (which opens with an
     # internal iteration) runs as one resident launch
-    n_ext = {"direct": 3, "direct+resident": 0, "direct+resident+decline": 2}[mode] * sum(1 for s in steps if s & 2)
+    n_ext = {"direct": 3, "direct+resident": 0, "direct+resident+decline": 2, "direct+resident+late": 2}[mode] * sum(1 for s in steps if s & 2)
     seen = 0
     for o in outs:
         d = np.load(o)
         assert int(d["n"]) == n_ext
         assert int(d["launches"]) == (1 if mode == "direct+resident" else len(sharded.segments(steps)))
-        if mode.endswith("+decline"):  # (resident launches, declined ones, back-off left) — the same on every rank
+        if mode.endswith("+decline") or mode.endswith("+late"):  # (resident launches, declined ones, back-off left) — the same on every rank
             assert d["stats"][0] == 2 and d["stats"][1] == 1 and d["stats"][2] > 0, d["stats"]
         for j, g in enumerate(d["ids"]):
             sl, dl = slice(g * K, (g + 1) * K), slice(j * K, (j + 1) * K)
