@@ -231,3 +231,32 @@ def test_resident_launch_next_to_another_tenant_of_the_gpu():
     for t in range(3):
         ref.tick(steps=sc["steps"], **tick)
     assert_identical(eng, ref, what="resident launches next to a second stream's matrix products")
+
+
+def test_resident_launch_queries_and_the_declining_world():
+    """mgx_resident_ready / _outcome / _stats on a world of its own: which form a schedule takes is known before it is issued, what
+    became of its launch after; a world told to decline (mgx_set_resident_launches(w, 2)) runs launch by launch like one told not
+    to try — beliefs of the oracle either way."""
+    from magics_amd import hostlib
+    sc = S.grid_scenario(144, 16, interrobot=True)
+    eng, ref = World(sc["params"]), oracle.OracleWorld(sc["params"])
+    assert S.populate(eng, sc) == S.populate(ref, sc)
+    assert eng.resident_ready(sc["steps"]) and not eng.resident_ready([1]) and not eng.resident_ready([])  # (one segment: nothing to keep resident for)
+    assert eng.resident_outcome() == hostlib.RESIDENT_NONE
+    eng.iterate(sc["steps"])
+    assert eng.resident_outcome() == hostlib.RESIDENT_RAN and eng.resident_outcome() == hostlib.RESIDENT_NONE
+    assert eng.resident_stats() == (1, 0, 0) and eng.last_launch_count() == 1
+    eng.set_resident_launches("decline")
+    assert not eng.resident_ready(sc["steps"])
+    eng.iterate(sc["steps"])
+    assert eng.resident_outcome() == hostlib.RESIDENT_NONE and eng.last_launch_count() == len(sc["steps"]) + 1
+    eng.set_resident_launches(False)
+    assert not eng.resident_ready(sc["steps"])
+    eng.iterate(sc["steps"])
+    eng.set_resident_launches(True)
+    eng.iterate(sc["steps"])
+    assert eng.resident_stats() == (2, 0, 0) and eng.last_launch_count() == 1
+    for _ in range(4):
+        ref.iterate(sc["steps"])
+    eng.synchronize()
+    assert_identical(eng, ref, what="resident, declining, switched off, resident again")
