@@ -91,16 +91,15 @@ __global__ void __launch_bounds__(256) k_pairs(const float *__restrict__ pos, in
 // 4 k + l (neighbouring LDS words: no bank conflicts), 64 of them per pass; the quad then exchanges its four hit masks, and
 // every lane writes its own hits at their rank among all four masks — row i (rows[i * cap + m]) comes out ascending in j.
 // A row that outgrows `cap` keeps counting, and the host repeats the search with a larger capacity (it remembers the
-// largest row).  Beside a resident schedule launch: that kernel's two waves per SIMD leave 16 registers, so a search wave only
-// fits where a CU holds three of its workgroups instead of four — 1000 robots leave 24 such CUs, 47 KB of LDS each; one-wave
-// workgroups with 12 KB (1000 robots) all find room there at once (four-wave workgroups did not: measured, they finished
-// when the launch did).
-constexpr int ROWS_BLOCK = 64;
-// L lanes per robot (4 or 2): 16 or 32 robots per workgroup.  A world that fills the device with its resident launch (1000 robots:
-// 125 of an XCD's 128 workgroup slots) leaves three CUs per XCD one workgroup short, and each of those took two search waves at
-// a time (measured: 63 workgroups — eight per XCD — finished with the launch, 120 us; up to 993 resident workgroups they ran beside
-// it in 37 us), so between 512 and 1024 robots the search is 32 workgroups of two lanes per robot: four per XCD.
-template <int L>
+// largest row).
+// L lanes per robot, ROWS_BLOCK threads per workgroup.  Two shapes.  <4, 64>: one wave, 16 robots — the default.  <2, 128>: two waves,
+// 64 robots, SIXTEEN workgroups for up to 1024 robots — the worlds that fill the device with their resident launch: 1000 robots
+// take 125 of an XCD's 128 workgroup slots, and what such a launch leaves is two or three HOLES per XCD, each the shape of one of its
+// own workgroups (two waves on two SIMDs, 40 KB of LDS) and each good for ONE workgroup of another kernel, whatever its size
+// (measured with the one-wave kernel cut down to a part of the robots: 4, 8 and 16 workgroups ran beside the launch in 37 us, 24
+// and more — also 32 of two lanes per robot, and 16 of FOUR waves — finished when the launch did, 110 us later).  So the search
+// of such a world is sixteen workgroups in the shape of the holes.
+template <int L, int ROWS_BLOCK>
 __global__ void __launch_bounds__(ROWS_BLOCK) k_pairs_rows(const float *__restrict__ pos, int n, float s_max, int32_t cap,
                                                            int32_t *__restrict__ cnt, int32_t *__restrict__ rows) {
     constexpr int ROBOTS = ROWS_BLOCK / L;
@@ -143,7 +142,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) k_pairs_rows(const float *__restri
     const float ax = X[ii], ay = Y[ii], az = Z[ii];
     int m = 0;  // hits of robot i so far (the same in all its lanes)
     int32_t *row = rows + (size_t)ii * (size_t)cap;
-    const int group0 = (int)threadIdx.x - l;
+    const int group0 = ((int)threadIdx.x & 63) - l;  // (lane of the group's first member within its wave)
     for (int j0 = 0; j0 < n; j0 += 64 * L) {
         unsigned long long hits = 0ull;
 #pragma unroll 4
@@ -205,9 +204,9 @@ hipError_t neighbours_rows(const float *pos, int n, float radius, int32_t cap, i
     const size_t lds = sizeof(float) * 3 * (size_t)((n + 3) & ~3);  // <= 48 KB: the host takes this kernel for n <= 4096
     const float s_max = squared_threshold(radius);
     if (n > 512 && n <= 1024)
-        hipLaunchKernelGGL(k_pairs_rows<2>, dim3((unsigned)((n + 31) / 32)), dim3(ROWS_BLOCK), lds, s, pos, n, s_max, cap, cnt, rows);
+        hipLaunchKernelGGL((k_pairs_rows<2, 128>), dim3((unsigned)((n + 63) / 64)), dim3(128), lds, s, pos, n, s_max, cap, cnt, rows);
     else
-        hipLaunchKernelGGL(k_pairs_rows<4>, dim3((unsigned)((n + 15) / 16)), dim3(ROWS_BLOCK), lds, s, pos, n, s_max, cap, cnt, rows);
+        hipLaunchKernelGGL((k_pairs_rows<4, 64>), dim3((unsigned)((n + 15) / 16)), dim3(64), lds, s, pos, n, s_max, cap, cnt, rows);
     return hipGetLastError();
 }
 
