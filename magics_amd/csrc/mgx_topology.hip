@@ -172,6 +172,180 @@ __global__ void __launch_bounds__(ROWS_BLOCK) k_pairs_rows(const float *__restri
     }
     if (live && l == 0) cnt[i] = m;
 }
+// ---- hash grid, ONE pass, rows of a fixed capacity (worlds of up to 1024 robots, a usable radius) ----------------------------
+// The all-pairs kernel above tests a million pairs for a thousand robots; beside a resident launch, sharing its SIMDs, that is
+// 70 us.  Here every workgroup (128 threads, two lanes per robot: sixteen workgroups for 1000 robots — they fit the holes such a
+// launch leaves, see above) builds the SAME hash grid of all robots in its LDS — cells of radius x 1.001 over x and z, 1024
+// buckets, counting sort — and a robot then looks at the 3 x 3 cells around its own: a candidate counts if its TRUE cell is the
+// one being looked at (two of the nine cells may share a bucket: no candidate is seen twice, none of another cell is taken for
+// one of these), it is not the robot itself, and the predicate — the squared one of the all-pairs kernel — holds.  Robots with
+// a non-finite coordinate are in no cell: every robot looks at all of them as well, and they look at everybody (a NaN distance
+// is "in range", as in the reference).  Same rows as the all-pairs scan by construction: the grid only leaves out pairs whose
+// x or z separation alone exceeds the radius.  The two lanes of a robot share the nine cells and note their hits in LDS as they come
+// (bucket order); the first lane then takes both lists into registers, sorts them (odd-even transposition, a dozen hits per
+// robot) and writes the row; more than `cap`
+// hits are counted only (the host then repeats the search with more room — beyond 32 per row with the all-pairs kernel).
+constexpr int GRID_BLOCK = 128, GRID_ROBOTS = GRID_BLOCK / 2, GRID_M = 1024;
+template <int REG>
+__global__ void __launch_bounds__(GRID_BLOCK) k_grid_rows(const float *__restrict__ pos, int n, float s_max, double inv_cell, int32_t cap,
+                                                          int32_t *__restrict__ cnt, int32_t *__restrict__ rows) {
+    extern __shared__ float lds_pos[];
+    const int npad = (n + 3) & ~3;
+    float *X = lds_pos, *Y = lds_pos + npad, *Z = lds_pos + 2 * npad;
+    int32_t *CX = reinterpret_cast<int32_t *>(lds_pos + 3 * npad);  // [n] cell of every robot (x, z); INT_MIN for the non-finite ones
+    int32_t *CZ = CX + npad;
+    int32_t *start = CZ + npad;          // [GRID_M + 1]
+    int32_t *fill = start + GRID_M + 1;  // [GRID_M] counts, then cursors
+    int32_t *members = fill + GRID_M;    // [n]
+    int32_t *special = members + npad;   // [n]
+    int32_t *part = special + npad;      // [GRID_BLOCK]
+    int32_t *hit = part + GRID_BLOCK;    // [GRID_BLOCK][REG] the hits of this workgroup's robots as they are found
+    __shared__ int32_t n_special;
+    const int tid = (int)threadIdx.x;
+    {   // all positions, 16 bytes at a time (see k_pairs_rows)
+        const int n3 = 3 * n, n4 = n3 >> 2;
+        const float4 *p4 = reinterpret_cast<const float4 *>(pos);
+        constexpr int INFLIGHT = 6;
+        for (int g0 = 0; g0 < n4; g0 += GRID_BLOCK * INFLIGHT) {
+            float4 v[INFLIGHT];
+#pragma unroll
+            for (int u = 0; u < INFLIGHT; u++) {
+                const int g = g0 + u * GRID_BLOCK + tid;
+                v[u] = g < n4 ? p4[g] : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < INFLIGHT; u++) {
+                const int g = g0 + u * GRID_BLOCK + tid;
+                if (g < n4) {
+                    const float c[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int e = 4 * g + q, j = e / 3, a = e - 3 * j;
+                        (a == 0 ? X : a == 1 ? Y : Z)[j] = c[q];
+                    }
+                }
+            }
+        }
+        for (int e = 4 * n4 + tid; e < n3; e += GRID_BLOCK) {
+            const int j = e / 3, a = e - 3 * j;
+            (a == 0 ? X : a == 1 ? Y : Z)[j] = pos[e];
+        }
+    }
+    for (int b = tid; b < GRID_M; b += GRID_BLOCK) fill[b] = 0;
+    if (tid == 0) n_special = 0;
+    __syncthreads();
+    // counting sort by bucket
+    for (int j = tid; j < n; j += GRID_BLOCK) {
+        if (finite3(X[j], Y[j], Z[j])) {
+            const int cx = cell_of(X[j], inv_cell), cz = cell_of(Z[j], inv_cell);
+            CX[j] = cx;
+            CZ[j] = cz;
+            atomicAdd(&fill[bucket_of(cx, cz, GRID_M - 1)], 1);
+        } else {
+            CX[j] = CZ[j] = (int32_t)0x80000000;  // (no cell of a finite robot: cell_of clamps to +-2^30)
+            special[atomicAdd(&n_special, 1)] = j;
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int PER = GRID_M / GRID_BLOCK;
+        int32_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; q++) sum += fill[tid * PER + q];
+        part[tid] = sum;
+        __syncthreads();
+        for (int d = 1; d < GRID_BLOCK; d <<= 1) {
+            const int32_t v = tid >= d ? part[tid - d] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        int32_t run = part[tid] - sum;
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            start[tid * PER + q] = run;
+            run += fill[tid * PER + q];
+            fill[tid * PER + q] = 0;
+        }
+        if (tid == GRID_BLOCK - 1) start[GRID_M] = run;
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += GRID_BLOCK)
+        if (CX[j] != (int32_t)0x80000000) {
+            const uint32_t b = bucket_of(CX[j], CZ[j], GRID_M - 1);
+            members[start[b] + atomicAdd(&fill[b], 1)] = j;
+        }
+    __syncthreads();
+    // two lanes per robot: lane h looks at cells h, h + 2, ... of the nine (and lane 1 at the non-finite robots)
+    const int i = blockIdx.x * GRID_ROBOTS + (tid >> 1), h = tid & 1;
+    const bool live = i < n;
+    const int ii = live ? i : 0;
+    const float ax = X[ii], ay = Y[ii], az = Z[ii];
+    int32_t *row = rows + (size_t)ii * (size_t)cap;
+    const bool wild = !finite3(ax, ay, az);
+    int m = 0;
+    if (live && wild && h == 0) {  // compared with everybody, ascending by construction
+        for (int j = 0; j < n; j++)
+            if (j != i && in_comms_range_sq(ax, ay, az, X[j], Y[j], Z[j], s_max)) {
+                if (m < cap) row[m] = j;
+                m++;
+            }
+        cnt[i] = m;
+    }
+    int32_t *mine = hit + tid * REG;  // (a lane's own REG words)
+    if (live && !wild) {
+        const int cx = CX[i], cz = CZ[i];
+        for (int c = h; c < 9; c += 2) {
+            const int tx = cx + c / 3 - 1, tz = cz + c % 3 - 1;
+            const uint32_t b = bucket_of(tx, tz, GRID_M - 1);
+            const int q1 = start[b + 1];
+            for (int q = start[b]; q < q1; q++) {
+                const int j = members[q];
+                // its TRUE cell is the one being looked at, it is not the robot itself, and it is in range
+                if (CX[j] == tx && CZ[j] == tz && j != i && in_comms_range_sq(ax, ay, az, X[j], Y[j], Z[j], s_max)) {
+                    if (m < REG) mine[m] = j;
+                    m++;
+                }
+            }
+        }
+        if (h == 1) {
+            const int ns = n_special;
+            for (int q = 0; q < ns; q++) {
+                const int j = special[q];
+                if (in_comms_range_sq(ax, ay, az, X[j], Y[j], Z[j], s_max)) {  // (j != i: this robot is finite)
+                    if (m < REG) mine[m] = j;
+                    m++;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int m_other = __shfl_xor(m, 1, 64);
+    if (!live || wild || h == 1) return;
+    const int m0 = m, m1 = m_other;
+    m = m0 + m1;
+    cnt[i] = m;
+    if (m > cap || m > REG) return;  // the host repeats the search with more room: nobody reads this row
+    // the row in ascending order: the hits came in bucket order — into registers, an odd-even transposition sort, out
+    const int32_t *theirs = mine + REG;
+    int32_t keep[REG];
+#pragma unroll
+    for (int p = 0; p < REG; p++) keep[p] = p < m0 ? mine[p] : (p < m ? theirs[p - m0] : 0x7fffffff);
+#pragma unroll
+    for (int round = 0; round < REG; round++) {
+#pragma unroll
+        for (int p = round & 1; p + 1 < REG; p += 2) {
+            const int32_t lo = min(keep[p], keep[p + 1]), hi = max(keep[p], keep[p + 1]);
+            keep[p] = lo;
+            keep[p + 1] = hi;
+        }
+        if (round >= m) break;  // (m entries are in order after m rounds; the padding sits behind them from the start)
+    }
+#pragma unroll
+    for (int p = 0; p < REG; p++)
+        if (p < m) row[p] = keep[p];
+}
+
 // the largest f32 s with RN_f32(sqrt(s)) <= radius (see in_comms_range_sq); NaN radius -> NaN (everybody in range), radius < 0 ->
 // negative (nobody but NaN distances)
 static float squared_threshold(float radius) {
@@ -201,8 +375,17 @@ hipError_t neighbours_rows(const float *pos, int n, float radius, int32_t cap, i
         hipLaunchKernelGGL(k_stage_positions, dim3((unsigned)((3 * n + 63) / 64)), dim3(64), 0, s, pos, stage, 3 * n);
         pos = stage;
     }
-    const size_t lds = sizeof(float) * 3 * (size_t)((n + 3) & ~3);  // <= 48 KB: the host takes this kernel for n <= 4096
+    const size_t npad = (size_t)((n + 3) & ~3);
+    const size_t lds = sizeof(float) * 3 * npad;  // <= 48 KB: the host takes this kernel for n <= 4096
     const float s_max = squared_threshold(radius);
+    if (n <= GRID_M && cap <= 32 && std::isfinite(radius) && radius > 0.f) {  // the grid in LDS (a usable radius, room for the rows in registers)
+        const double inv_cell = 1.0 / ((double)radius * 1.001);
+        auto lds_grid = [&](size_t reg) { return lds + sizeof(int32_t) * ((size_t)GRID_M + 1 + GRID_M + 4 * npad + GRID_BLOCK + GRID_BLOCK * reg); };
+        const dim3 grid((unsigned)((n + GRID_ROBOTS - 1) / GRID_ROBOTS));
+        if (cap <= 16) hipLaunchKernelGGL(k_grid_rows<16>, grid, dim3(GRID_BLOCK), lds_grid(16), s, pos, n, s_max, inv_cell, cap, cnt, rows);
+        else hipLaunchKernelGGL(k_grid_rows<32>, grid, dim3(GRID_BLOCK), lds_grid(32), s, pos, n, s_max, inv_cell, cap, cnt, rows);
+        return hipGetLastError();
+    }
     if (n > 512 && n <= 1024)
         hipLaunchKernelGGL((k_pairs_rows<2, 128>), dim3((unsigned)((n + 63) / 64)), dim3(128), lds, s, pos, n, s_max, cap, cnt, rows);
     else
