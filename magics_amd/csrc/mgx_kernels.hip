@@ -533,9 +533,11 @@ __global__ void k_mission_prepare(DevWorld w, DevMission m, int n, const uint8_t
 // and creation epoch over from the arrays being replaced; a new one starts empty, created at the
 // owner variable's current delivery count, with the target variable's current belief mean as the
 // response it has seen (robot.rs:1549-1585).  The constant record of every edge is derived here too.
+// gate (may be null): the edge's gate byte — its owner is on air — written along (the flags themselves have not changed)
 __global__ void k_edge_rebuild(DevWorld w, int n_slots, const IrSlotRec *__restrict__ slots, const int32_t *__restrict__ in_new,
                                const int32_t *__restrict__ in_old, int stride_new, IrEdgeRec *__restrict__ recs,
-                               double *__restrict__ fv_eta, double *__restrict__ fv_lam, double *__restrict__ bmu) {
+                               double *__restrict__ fv_eta, double *__restrict__ fv_lam, double *__restrict__ bmu,
+                               uint8_t *__restrict__ gate) {
     const int K1 = w.K - 1;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_slots * K1) return;
@@ -577,6 +579,27 @@ __global__ void k_edge_rebuild(DevWorld w, int n_slots, const IrSlotRec *__restr
         rec.created = w.snap_epoch[w.cur][rec.src_var];
     }
     recs[e] = rec;
+    if (gate) gate[e] = (w.antenna[rec.src_robot] && !w.idle[rec.src_robot]) ? 1 : 0;
+}
+// The host's tables of a topology change — slot records, per-robot slot ranges, the lower / higher key split — travel in ONE pinned
+// block; this kernel takes them apart into their device arrays (16 bytes per thread, the block read once over the host link)
+// and derives the per-variable tables (k_var_tables) from the block itself in the same launch: one launch instead of three
+// copies and one launch on the host's critical path (a world that follows its topology pays for every call, every tick).
+__global__ void k_retopo_unpack(const uint4 *__restrict__ src, int n16_slots, int n16_ptr, int n16_mid, uint4 *__restrict__ slots,
+                                uint4 *__restrict__ in_ptr_dst, uint4 *__restrict__ mid_dst, int R, int K, int32_t *__restrict__ var_ptr,
+                                int32_t *__restrict__ var_mid) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n16_slots) slots[t] = src[t];
+    else if (t < n16_slots + n16_ptr) in_ptr_dst[t - n16_slots] = src[t];
+    else if (t < n16_slots + n16_ptr + n16_mid) mid_dst[t - n16_slots - n16_ptr] = src[t];
+    if (t > R * K) return;
+    const int32_t *in_ptr = reinterpret_cast<const int32_t *>(src + n16_slots), *in_mid = reinterpret_cast<const int32_t *>(src + n16_slots + n16_ptr);
+    if (t == R * K) { var_ptr[t] = (K - 1) * in_ptr[R]; return; }
+    const int r = t / K, i = t - r * K;
+    const int n_in = in_ptr[r + 1] - in_ptr[r], base = (K - 1) * in_ptr[r];
+    const int p = (i == 0) ? base : base + (i - 1) * n_in;  // variable 0 carries no inter-robot factor
+    var_ptr[t] = p;
+    var_mid[t] = (i == 0) ? p : p + in_mid[r];
 }
 // CSR over variables (and the lower-key / higher-key split) from the per-robot slot lists
 __global__ void k_var_tables(int R, int K, const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_mid,
@@ -740,11 +763,19 @@ hipError_t launch_mission_prepare(const DevWorld &w, const DevMission &m, int n,
     return hipGetLastError();
 }
 hipError_t launch_edge_rebuild(const DevWorld &w, int n_slots, const IrSlotRec *slots, const int32_t *in_new, const int32_t *in_old,
-                               int stride_new, IrEdgeRec *recs, double *fv_eta, double *fv_lam, double *bmu, hipStream_t stream) {
+                               int stride_new, IrEdgeRec *recs, double *fv_eta, double *fv_lam, double *bmu, uint8_t *gate, hipStream_t stream) {
     const int total = n_slots * (w.K - 1);
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_edge_rebuild, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, n_slots, slots, in_new, in_old,
-                       stride_new, recs, fv_eta, fv_lam, bmu);
+                       stride_new, recs, fv_eta, fv_lam, bmu, gate);
+    return hipGetLastError();
+}
+// src: [slots | in_ptr | mid], every part padded to 16 bytes (device-visible pinned memory)
+hipError_t launch_retopo_unpack(const void *src, size_t b_slots, size_t b_ptr, size_t b_mid, void *slots, void *in_ptr, void *mid, int R, int K,
+                                int32_t *var_ptr, int32_t *var_mid, hipStream_t stream) {
+    const int n16 = (int)((b_slots + b_ptr + b_mid) / 16), need = std::max(n16, R * K + 1);
+    hipLaunchKernelGGL(k_retopo_unpack, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, stream, (const uint4 *)src, (int)(b_slots / 16),
+                       (int)(b_ptr / 16), (int)(b_mid / 16), (uint4 *)slots, (uint4 *)in_ptr, (uint4 *)mid, R, K, var_ptr, var_mid);
     return hipGetLastError();
 }
 hipError_t launch_var_tables(int R, int K, const int32_t *in_ptr, const int32_t *in_mid, int32_t *var_ptr, int32_t *var_mid,

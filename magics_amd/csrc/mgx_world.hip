@@ -56,8 +56,10 @@ hipError_t launch_mission_reached(const DevWorld &w, const DevMission &m, int n,
 hipError_t launch_mission_positions(const DevMission &m, int n, const int32_t *alive, float *out, hipStream_t stream);
 hipError_t launch_mission_prepare(const DevWorld &w, const DevMission &m, int n, const uint8_t *moving, double *rec, int32_t *robots,
                                   double *waypoints, double *time_scale, uint8_t *what, hipStream_t stream);
+hipError_t launch_retopo_unpack(const void *src, size_t b_slots, size_t b_ptr, size_t b_mid, void *slots, void *in_ptr, void *mid, int R, int K,
+                                int32_t *var_ptr, int32_t *var_mid, hipStream_t stream);
 hipError_t launch_edge_rebuild(const DevWorld &w, int n_slots, const IrSlotRec *slots, const int32_t *in_new, const int32_t *in_old,
-                               int stride_new, IrEdgeRec *recs, double *fv_eta, double *fv_lam, double *bmu, hipStream_t stream);
+                               int stride_new, IrEdgeRec *recs, double *fv_eta, double *fv_lam, double *bmu, uint8_t *gate, hipStream_t stream);
 hipError_t launch_var_tables(int R, int K, const int32_t *in_ptr, const int32_t *in_mid, int32_t *var_ptr, int32_t *var_mid,
                              hipStream_t stream);
 hipError_t launch_edge_gates(int n, const IrEdgeRec *recs, const uint8_t *antenna, const uint8_t *idle, uint8_t *gate, hipStream_t stream);
@@ -1019,28 +1021,33 @@ static int retopo(mgx_world *w) {
     }
     tm.lap("slot records");
     hipStream_t s = w->stream;
-    // the three host tables travel through one pinned block of the argument ring: true asynchronous copies, and
-    // no synchronisation at the end of the rebuild (the block is released by an event after the kernels)
-    const size_t b_slots = sizeof(IrSlotRec) * slots.size(), b_ptr = sizeof(int32_t) * t.in_ptr.size(), b_mid = sizeof(int32_t) * t.mid.size();
-    void *hp = nullptr;
+    // the three host tables travel through one pinned block of the argument ring (every part padded to 16 bytes); ONE kernel
+    // takes it apart into the device arrays and derives the per-variable tables from it (k_retopo_unpack), a second one lays the
+    // edges out and — the robots' flags unchanged — writes their gate bytes along: two launches, no copies, no synchronisation
+    // (the block is released by an event after the kernels)
+    auto pad16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    const size_t b_slots = pad16(sizeof(IrSlotRec) * slots.size()), b_ptr = pad16(sizeof(int32_t) * t.in_ptr.size()),
+                 b_mid = pad16(sizeof(int32_t) * t.mid.size());
+    void *hp = nullptr, *dp = nullptr;
     int ring_slot = 0;
     HIP_TRY(w->stage.acquire(b_slots + b_ptr + b_mid, &hp, &ring_slot));
-    memcpy(hp, slots.data(), b_slots);
-    memcpy((char *)hp + b_slots, t.in_ptr.data(), b_ptr);
-    memcpy((char *)hp + b_slots + b_ptr, t.mid.data(), b_mid);
-    HIP_TRY(w->slot_recs.reserve(slots.size()));
-    HIP_TRY(w->in_ptr_dev_b.reserve(t.in_ptr.size()));
-    HIP_TRY(w->in_mid_dev.reserve(t.mid.size()));
-    HIP_TRY(hipMemcpyAsync(w->slot_recs.p, hp, b_slots, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(w->in_ptr_dev_b.p, (char *)hp + b_slots, b_ptr, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(w->in_mid_dev.p, (char *)hp + b_slots + b_ptr, b_mid, hipMemcpyHostToDevice, s));
+    memcpy(hp, slots.data(), sizeof(IrSlotRec) * slots.size());
+    memcpy((char *)hp + b_slots, t.in_ptr.data(), sizeof(int32_t) * t.in_ptr.size());
+    memcpy((char *)hp + b_slots + b_ptr, t.mid.data(), sizeof(int32_t) * t.mid.size());
+    HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+    HIP_TRY(w->slot_recs.reserve(b_slots / sizeof(IrSlotRec) + 1));
+    HIP_TRY(w->in_ptr_dev_b.reserve(b_ptr / sizeof(int32_t)));
+    HIP_TRY(w->in_mid_dev.reserve(b_mid / sizeof(int32_t)));
     HIP_TRY(w->ir_rec_b.reserve(NIs));
     HIP_TRY(w->ir_fv_eta_b.reserve(4 * NIs));
     HIP_TRY(w->ir_fv_lam_b.reserve(16 * NIs));
     HIP_TRY(w->ir_bmu_b.reserve(4 * NIs));
+    const bool gates_along = !w->flags_dirty;
+    if (gates_along) HIP_TRY(w->ir_gate.reserve(NIs));
+    HIP_TRY(launch_retopo_unpack(dp, b_slots, b_ptr, b_mid, w->slot_recs.p, w->in_ptr_dev_b.p, w->in_mid_dev.p, R_local, K, w->ir_var_ptr.p,
+                                 w->ir_var_mid.p, s));
     HIP_TRY(launch_edge_rebuild(w->d, (int)n_slots, w->slot_recs.p, w->in_ptr_dev_b.p, w->in_ptr_dev.p, (int)NIs, w->ir_rec_b.p,
-                                w->ir_fv_eta_b.p, w->ir_fv_lam_b.p, w->ir_bmu_b.p, s));
-    HIP_TRY(launch_var_tables(R_local, K, w->in_ptr_dev_b.p, w->in_mid_dev.p, w->ir_var_ptr.p, w->ir_var_mid.p, s));
+                                w->ir_fv_eta_b.p, w->ir_fv_lam_b.p, w->ir_bmu_b.p, gates_along ? w->ir_gate.p : nullptr, s));
     HIP_TRY(w->stage.release(ring_slot, s));
     tm.lap("uploads + launches");
     w->ir_rec.swap(w->ir_rec_b);
@@ -1072,9 +1079,8 @@ static int retopo(mgx_world *w) {
     if (w->flags_dirty) {
         rc_flags = upload_flags(w);
     } else {
-        HIP_TRY(w->ir_gate.reserve(NIs));
-        HIP_TRY(launch_edge_gates((int)NI, w->ir_rec.p, w->antenna.p, w->idle.p, w->ir_gate.p, s));
-        d.ir_gate = w->ir_gate.p;
+        if (NI == 0) HIP_TRY(hipMemsetAsync(w->ir_gate.p, 0, NIs, s));
+        d.ir_gate = w->ir_gate.p;  // (written by k_edge_rebuild)
     }
     tm.lap("flags + gates");
     return rc_flags;
