@@ -585,13 +585,14 @@ __global__ void k_edge_rebuild(DevWorld w, int n_slots, const IrSlotRec *__restr
 // block; this kernel takes them apart into their device arrays (16 bytes per thread, the block read once over the host link)
 // and derives the per-variable tables (k_var_tables) from the block itself in the same launch: one launch instead of three
 // copies and one launch on the host's critical path (a world that follows its topology pays for every call, every tick).
-__global__ void k_retopo_unpack(const uint4 *__restrict__ src, int n16_slots, int n16_ptr, int n16_mid, uint4 *__restrict__ slots,
-                                uint4 *__restrict__ in_ptr_dst, uint4 *__restrict__ mid_dst, int R, int K, int32_t *__restrict__ var_ptr,
-                                int32_t *__restrict__ var_mid) {
+__global__ void k_retopo_unpack(const uint4 *__restrict__ src, int n16_slots, int n16_ptr, int n16_mid, int n16_peers, uint4 *__restrict__ slots,
+                                uint4 *__restrict__ in_ptr_dst, uint4 *__restrict__ mid_dst, uint4 *__restrict__ peers_dst, int R, int K,
+                                int32_t *__restrict__ var_ptr, int32_t *__restrict__ var_mid) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n16_slots) slots[t] = src[t];
     else if (t < n16_slots + n16_ptr) in_ptr_dst[t - n16_slots] = src[t];
     else if (t < n16_slots + n16_ptr + n16_mid) mid_dst[t - n16_slots - n16_ptr] = src[t];
+    else if (t < n16_slots + n16_ptr + n16_mid + n16_peers) peers_dst[t - n16_slots - n16_ptr - n16_mid] = src[t];  // (the resident kernel's peer table)
     if (t > R * K) return;
     const int32_t *in_ptr = reinterpret_cast<const int32_t *>(src + n16_slots), *in_mid = reinterpret_cast<const int32_t *>(src + n16_slots + n16_ptr);
     if (t == R * K) { var_ptr[t] = (K - 1) * in_ptr[R]; return; }
@@ -770,12 +771,13 @@ hipError_t launch_edge_rebuild(const DevWorld &w, int n_slots, const IrSlotRec *
                        stride_new, recs, fv_eta, fv_lam, bmu, gate);
     return hipGetLastError();
 }
-// src: [slots | in_ptr | mid], every part padded to 16 bytes (device-visible pinned memory)
-hipError_t launch_retopo_unpack(const void *src, size_t b_slots, size_t b_ptr, size_t b_mid, void *slots, void *in_ptr, void *mid, int R, int K,
-                                int32_t *var_ptr, int32_t *var_mid, hipStream_t stream) {
-    const int n16 = (int)((b_slots + b_ptr + b_mid) / 16), need = std::max(n16, R * K + 1);
+// src: [slots | in_ptr | mid | peers], every part padded to 16 bytes (device-visible pinned memory)
+hipError_t launch_retopo_unpack(const void *src, size_t b_slots, size_t b_ptr, size_t b_mid, size_t b_peers, void *slots, void *in_ptr, void *mid,
+                                void *peers, int R, int K, int32_t *var_ptr, int32_t *var_mid, hipStream_t stream) {
+    const int n16 = (int)((b_slots + b_ptr + b_mid + b_peers) / 16), need = std::max(n16, R * K + 1);
     hipLaunchKernelGGL(k_retopo_unpack, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, stream, (const uint4 *)src, (int)(b_slots / 16),
-                       (int)(b_ptr / 16), (int)(b_mid / 16), (uint4 *)slots, (uint4 *)in_ptr, (uint4 *)mid, R, K, var_ptr, var_mid);
+                       (int)(b_ptr / 16), (int)(b_mid / 16), (int)(b_peers / 16), (uint4 *)slots, (uint4 *)in_ptr, (uint4 *)mid, (uint4 *)peers, R,
+                       K, var_ptr, var_mid);
     return hipGetLastError();
 }
 hipError_t launch_var_tables(int R, int K, const int32_t *in_ptr, const int32_t *in_mid, int32_t *var_ptr, int32_t *var_mid,

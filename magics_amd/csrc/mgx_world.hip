@@ -56,8 +56,8 @@ hipError_t launch_mission_reached(const DevWorld &w, const DevMission &m, int n,
 hipError_t launch_mission_positions(const DevMission &m, int n, const int32_t *alive, float *out, hipStream_t stream);
 hipError_t launch_mission_prepare(const DevWorld &w, const DevMission &m, int n, const uint8_t *moving, double *rec, int32_t *robots,
                                   double *waypoints, double *time_scale, uint8_t *what, hipStream_t stream);
-hipError_t launch_retopo_unpack(const void *src, size_t b_slots, size_t b_ptr, size_t b_mid, void *slots, void *in_ptr, void *mid, int R, int K,
-                                int32_t *var_ptr, int32_t *var_mid, hipStream_t stream);
+hipError_t launch_retopo_unpack(const void *src, size_t b_slots, size_t b_ptr, size_t b_mid, size_t b_peers, void *slots, void *in_ptr, void *mid,
+                                void *peers, int R, int K, int32_t *var_ptr, int32_t *var_mid, hipStream_t stream);
 hipError_t launch_edge_rebuild(const DevWorld &w, int n_slots, const IrSlotRec *slots, const int32_t *in_new, const int32_t *in_old,
                                int stride_new, IrEdgeRec *recs, double *fv_eta, double *fv_lam, double *bmu, uint8_t *gate, hipStream_t stream);
 hipError_t launch_var_tables(int R, int K, const int32_t *in_ptr, const int32_t *in_mid, int32_t *var_ptr, int32_t *var_mid,
@@ -539,8 +539,7 @@ struct mgx_world {
             p = nullptr;
             cap = 0;
             const size_t want = bytes + bytes / 2 + 4096;
-            static const bool nc = [] { const char *v = getenv("MGX_PIN_NONCOHERENT"); return v && v[0] == '1'; }();
-            const hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped | (nc ? hipHostMallocNonCoherent : 0u));  // the one-pass search reads and writes it in place
+            const hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);  // the one-pass search reads and writes it in place
             if (e == hipSuccess) cap = want;
             return e;
         }
@@ -931,6 +930,9 @@ static int upload_flags(mgx_world *w) {
 // lives at  (K-1) * in_ptr[r] + (i-1) * n_in(r) + q.
 struct Incoming {
     std::vector<int32_t> in_ptr, in_list, mid;
+    // on request: the resident kernel's peer table (ensure_resident_tables) from the same two passes over the connections —
+    // [R + 1 row pointers | entries]: for every local robot the owners of its incoming and the targets of its outgoing connections
+    std::vector<int32_t> peers;
     int ir_max_edges = 0;
     bool blocks_ok = true;
 };
@@ -938,22 +940,45 @@ static size_t edge_index(const std::vector<int32_t> &in_ptr, int K, int r, int j
     const int n_in = in_ptr[(size_t)r + 1] - in_ptr[(size_t)r];
     return (size_t)(K - 1) * (size_t)in_ptr[(size_t)r] + (size_t)j * (size_t)n_in + (size_t)(slot - in_ptr[(size_t)r]);
 }
-static void build_incoming(const mgx_world *w, int R_local, Incoming &t) {
+static void build_incoming(const mgx_world *w, int R_local, Incoming &t, bool want_peers = false) {
     const int K = w->K;
     const uint64_t *key = w->sets.keys.data();  // (compact copies of the robots' order keys and ghost flags: a Robot is a dozen vectors wide)
     const uint8_t *ghost = w->sets.ghost.data();
     const int32_t *dev_of = w->dev_of.data();
     const IrConn *conns = w->conns.data();
-    const size_t n_conns = w->conns.size();
-    t.in_ptr.assign((size_t)R_local + 1, 0);
+    const size_t n_conns = w->conns.size(), R = (size_t)R_local;
+    t.in_ptr.assign(R + 1, 0);
     t.mid.assign((size_t)std::max(R_local, 1), 0);
-    for (size_t ci = 0; ci < n_conns; ci++)
-        if (!ghost[(size_t)conns[ci].other]) t.in_ptr[(size_t)dev_of[(size_t)conns[ci].other] + 1]++;  // ghost target: another rank's
-    for (int r = 0; r < R_local; r++) t.in_ptr[(size_t)r + 1] += t.in_ptr[(size_t)r];
-    t.in_list.assign((size_t)t.in_ptr[(size_t)R_local], 0);
-    std::vector<int32_t> fill(t.in_ptr.begin(), t.in_ptr.end() - 1);
-    for (size_t ci = 0; ci < n_conns; ci++)
-        if (!ghost[(size_t)conns[ci].other]) t.in_list[(size_t)fill[(size_t)dev_of[(size_t)conns[ci].other]]++] = (int32_t)ci;
+    int32_t *pp = nullptr;
+    if (want_peers) {
+        t.peers.assign(R + 1 + std::max<size_t>(2 * n_conns, 1), 0);
+        pp = t.peers.data();
+    }
+    for (size_t ci = 0; ci < n_conns; ci++) {
+        const size_t o = (size_t)dev_of[(size_t)conns[ci].owner], tt = (size_t)dev_of[(size_t)conns[ci].other];
+        if (!ghost[(size_t)conns[ci].other]) t.in_ptr[tt + 1]++;  // ghost target: another rank's
+        if (pp) {
+            if (o < R) pp[o + 1]++;
+            if (tt < R) pp[tt + 1]++;
+        }
+    }
+    for (size_t r = 0; r < R; r++) t.in_ptr[r + 1] += t.in_ptr[r];
+    t.in_list.assign((size_t)t.in_ptr[R], 0);
+    std::vector<int32_t> fill(t.in_ptr.begin(), t.in_ptr.end() - 1), pfill;
+    if (pp) {
+        for (size_t r = 0; r < R; r++) pp[r + 1] += pp[r];
+        pfill.assign(pp, pp + R);
+    }
+    int32_t *pidx = pp ? pp + R + 1 : nullptr;
+    for (size_t ci = 0; ci < n_conns; ci++) {
+        const int o = dev_of[(size_t)conns[ci].owner], tt = dev_of[(size_t)conns[ci].other];
+        if (!ghost[(size_t)conns[ci].other]) t.in_list[(size_t)fill[(size_t)tt]++] = (int32_t)ci;
+        if (pp) {
+            if ((size_t)o < R) pidx[(size_t)pfill[(size_t)o]++] = tt;
+            if ((size_t)tt < R) pidx[(size_t)pfill[(size_t)tt]++] = o;
+        }
+    }
+    if (pp) t.peers.resize(R + 1 + (size_t)std::max(pp[R], 1));
     t.ir_max_edges = 0;
     for (int r = 0; r < R_local; r++) {
         int32_t *seg = t.in_list.data() + t.in_ptr[(size_t)r];
@@ -1004,13 +1029,18 @@ static int retopo(mgx_world *w) {
     const int K = w->K, R_local = w->d.R_local;
     StageTimer tm("retopo");
     Incoming t;
-    build_incoming(w, R_local, t);
+    // (a world whose schedules can run as resident launches gets that kernel's peer table from the same passes, in the same block)
+    const bool want_peers = (w->d.R_total == w->d.R_local || w->xres.connected) && (w->p.enable_mask & 2u) && w->sweep_flag_buf.p;
+    build_incoming(w, R_local, t, want_peers);
     tm.lap("build_incoming");
     if (!t.blocks_ok) return fail(MGX_ERR_STATE, "internal: node slots of two connections interleave");
     const size_t n_slots = t.in_list.size(), NI = n_slots * (size_t)(K - 1), NIs = std::max<size_t>(NI, 1);
     std::vector<IrSlotRec> slots(std::max<size_t>(n_slots, 1));
+    if (n_slots != w->conns.size())  // (connections towards a ghost are another rank's: no slot here; all others are rewritten below)
+        for (IrConn &c : w->conns)
+            if (w->sets.ghost[(size_t)c.other]) c.dev_slot = -1;
     for (size_t g = 0; g < n_slots; g++) {
-        const IrConn &c = w->conns[(size_t)t.in_list[g]];
+        IrConn &c = w->conns[(size_t)t.in_list[g]];
         IrSlotRec &sl = slots[g];
         sl.tgt_robot = w->dev_of[(size_t)c.other];
         sl.src_robot = w->dev_of[(size_t)c.owner];
@@ -1018,6 +1048,11 @@ static int retopo(mgx_world *w) {
         sl.flags = (w->sets.keys[(size_t)c.other] > w->sets.keys[(size_t)c.owner]) ? 1 : 0;
         sl.d_safe = w->p.safety_multiplier * w->sets.radius[(size_t)c.owner];
         sl.first_number = c.first_number;
+        c.dev_slot = (int32_t)g;  // (from here on the connection's slot in the tables being built)
+        if (c.has_fresh) {
+            for (IrEdge &ed : c.edges) ed.fresh = false;
+            c.has_fresh = false;
+        }
     }
     tm.lap("slot records");
     hipStream_t s = w->stream;
@@ -1027,13 +1062,17 @@ static int retopo(mgx_world *w) {
     // (the block is released by an event after the kernels)
     auto pad16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
     const size_t b_slots = pad16(sizeof(IrSlotRec) * slots.size()), b_ptr = pad16(sizeof(int32_t) * t.in_ptr.size()),
-                 b_mid = pad16(sizeof(int32_t) * t.mid.size());
+                 b_mid = pad16(sizeof(int32_t) * t.mid.size()), b_peers = pad16(sizeof(int32_t) * t.peers.size());
     void *hp = nullptr, *dp = nullptr;
     int ring_slot = 0;
-    HIP_TRY(w->stage.acquire(b_slots + b_ptr + b_mid, &hp, &ring_slot));
+    HIP_TRY(w->stage.acquire(b_slots + b_ptr + b_mid + b_peers, &hp, &ring_slot));
     memcpy(hp, slots.data(), sizeof(IrSlotRec) * slots.size());
     memcpy((char *)hp + b_slots, t.in_ptr.data(), sizeof(int32_t) * t.in_ptr.size());
     memcpy((char *)hp + b_slots + b_ptr, t.mid.data(), sizeof(int32_t) * t.mid.size());
+    if (b_peers) {
+        memcpy((char *)hp + b_slots + b_ptr + b_mid, t.peers.data(), sizeof(int32_t) * t.peers.size());
+        HIP_TRY(w->peer_ptr_dev.reserve(b_peers / sizeof(int32_t)));
+    }
     HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
     HIP_TRY(w->slot_recs.reserve(b_slots / sizeof(IrSlotRec) + 1));
     HIP_TRY(w->in_ptr_dev_b.reserve(b_ptr / sizeof(int32_t)));
@@ -1044,8 +1083,8 @@ static int retopo(mgx_world *w) {
     HIP_TRY(w->ir_bmu_b.reserve(4 * NIs));
     const bool gates_along = !w->flags_dirty;
     if (gates_along) HIP_TRY(w->ir_gate.reserve(NIs));
-    HIP_TRY(launch_retopo_unpack(dp, b_slots, b_ptr, b_mid, w->slot_recs.p, w->in_ptr_dev_b.p, w->in_mid_dev.p, R_local, K, w->ir_var_ptr.p,
-                                 w->ir_var_mid.p, s));
+    HIP_TRY(launch_retopo_unpack(dp, b_slots, b_ptr, b_mid, b_peers, w->slot_recs.p, w->in_ptr_dev_b.p, w->in_mid_dev.p,
+                                 b_peers ? w->peer_ptr_dev.p : nullptr, R_local, K, w->ir_var_ptr.p, w->ir_var_mid.p, s));
     HIP_TRY(launch_edge_rebuild(w->d, (int)n_slots, w->slot_recs.p, w->in_ptr_dev_b.p, w->in_ptr_dev.p, (int)NIs, w->ir_rec_b.p,
                                 w->ir_fv_eta_b.p, w->ir_fv_lam_b.p, w->ir_bmu_b.p, gates_along ? w->ir_gate.p : nullptr, s));
     HIP_TRY(w->stage.release(ring_slot, s));
@@ -1062,18 +1101,14 @@ static int retopo(mgx_world *w) {
     // a capacity asked for a sparser topology says nothing about this one
     if (t.ir_max_edges != d.ir_max_edges) w->resident_cap = w->resident_cap_sharded = -1;
     d.ir_max_edges = t.ir_max_edges;
-    for (IrConn &c : w->conns) c.dev_slot = -1;
-    for (size_t g = 0; g < n_slots; g++) {
-        IrConn &c = w->conns[(size_t)t.in_list[g]];
-        c.dev_slot = (int32_t)g;
-        if (c.has_fresh) {
-            for (IrEdge &ed : c.edges) ed.fresh = false;
-            c.has_fresh = false;
-        }
-    }
     w->dev_in_ptr = t.in_ptr;
     w->conns_dirty = false;
-    w->peers_valid = false;
+    w->peers_valid = b_peers != 0;
+    if (b_peers) {
+        w->peer_idx_off = (size_t)R_local + 1;
+        w->d.peer_ptr = w->peer_ptr_dev.p;
+        w->d.peer_idx = w->peer_ptr_dev.p + w->peer_idx_off;
+    }
     tm.lap("slot bookkeeping");
     int rc_flags = MGX_OK;  // the gate bytes follow the edges (the robots' own flags only when they changed too)
     if (w->flags_dirty) {
@@ -2150,16 +2185,13 @@ static int neighbours_enqueue(mgx_world *w, const float *pos, float radius, uint
     // (The missions' search reads the device's Transforms, which the tick's kernels move: that one stays in stream order.)
     hipStream_t s = w->stream;
     if (!from_missions) {
-        // (never beside a resident launch that is still getting onto the device: the search's waves would take slots its last
-        // workgroups need — see mgx_update_topology)
-        if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
-        if (!w->search_stream) {
-            static const bool prio = [] { const char *e = getenv("MGX_SEARCH_PRIORITY"); return e && e[0] == '1'; }();
-            int lo = 0, hi = 0;
-            if (prio) HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            if (prio) HIP_TRY(hipStreamCreateWithPriority(&w->search_stream, hipStreamNonBlocking, hi));
-            else HIP_TRY(hipStreamCreateWithFlags(&w->search_stream, hipStreamNonBlocking));
-        }
+        // Never beside a resident launch that is still getting onto the device, unless both fit: the search's waves would take
+        // slots the launch's last workgroups need (see mgx_update_topology).  The grid search of a small world is one workgroup
+        // per 64 robots, each good for one of the launch's workgroup slots: with room for all of them the search goes out at once.
+        const bool grid_rows = method == MGX_NEIGHBOURS_AUTO && n > 0 && n <= 1024 && usable_radius && w->nb_row_cap <= 32;
+        const bool fits_beside = grid_rows && !w->xres.connected && w->resident_cap > 0 && w->d.R_local + 1 + (n + 63) / 64 <= w->resident_cap;
+        if (w->pending.active && !fits_beside) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
+        if (!w->search_stream) HIP_TRY(hipStreamCreateWithFlags(&w->search_stream, hipStreamNonBlocking));
         s = w->search_stream;
     }
     if (w->nb_last_stream_set && w->nb_last_stream != s) HIP_TRY(hipStreamSynchronize(w->nb_last_stream));  // the scratch buffers are shared
@@ -2352,14 +2384,21 @@ int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, 
     // lists the connections by owner first — that needs nothing from the device — and only then, with the launch decided
     // (microseconds after its start), enqueues the search; the message counters are brought up to date under it (the pass
     // is about to change who sends to whom).
+    // (owner lists first only if the search has to wait for the launch's decision anyway: otherwise it gets their head start)
+    const bool decided = !w->pending.active || (__atomic_load_n(w->decision_host, __ATOMIC_ACQUIRE) >> 2) >= w->pending.seq;
     OwnerLists own_lists;
-    own_lists.build(w);
-    tm.lap("owner lists");
-    if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
+    if (!decided) {
+        own_lists.build(w);
+        tm.lap("owner lists");
+    }
     mgx_world::PendingSearch ps;
-    int rc = neighbours_enqueue(w, positions_xyz, radius, method, ps);
+    int rc = neighbours_enqueue(w, positions_xyz, radius, method, ps);  // (waits for the launch to be decided first if it has to)
     if (rc != MGX_OK) return rc;
     tm.lap("search enqueued");
+    if (decided) {
+        own_lists.build(w);
+        tm.lap("owner lists (under the search)");
+    }
     flush_counts(w);
     tm.lap("message counters (under the search)");
     rc = neighbours_collect(w, ps, ptr, idx);
