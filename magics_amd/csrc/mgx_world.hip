@@ -283,6 +283,7 @@ struct ConnSets {
     std::vector<uint64_t> keys;
     std::vector<uint8_t> ghost;   // the robots' ghost flags and radii, compact like the keys (fixed when a robot is added): the
     std::vector<double> radius;   // per-tick passes over all connections read them instead of the robots themselves
+    std::vector<uint8_t> removed; // ... and Robot::removed (mgx_robot_remove)
     void ensure(size_t n) {
         if (cnt.size() < n) { cnt.resize(n, 0); ids.resize(n * (size_t)cap, 0); }
     }
@@ -352,6 +353,22 @@ constexpr int NCCL_FLOAT64 = 8;  // ncclFloat64 (rccl.h)
 
 }  // namespace
 
+// Incoming inter-robot connections of every local robot in inbox key order (graph key, node index
+// — message.rs / id.rs:19-117), and the split between lower-key and higher-key owners.  Each
+// connection hangs one factor on every variable 1..K-1 of its target, and the order is the same for
+// all of them: by owner key, and for two connections of one owner by node slot — a connection's K-1
+// slots are one block of consecutive indices (fresh, or a whole vacated block: alloc_node), so
+// comparing the first slots orders the whole blocks.  Edge (variable i, list position q) of robot r
+// lives at  (K-1) * in_ptr[r] + (i-1) * n_in(r) + q.
+struct Incoming {
+    std::vector<int32_t> in_ptr, in_list, mid;
+    // on request: the resident kernel's peer table (ensure_resident_tables) from the same two passes over the connections —
+    // [R + 1 row pointers | entries]: for every local robot the owners of its incoming and the targets of its outgoing connections
+    std::vector<int32_t> peers;
+    std::vector<int32_t> fill, pfill;  // scratch of build_incoming
+    int ir_max_edges = 0;
+    bool blocks_ok = true;
+};
 struct mgx_world {
     mgx_params p{};
     std::vector<Robot> robots;  // ids = indices; ghosts may interleave on the host, device order below
@@ -427,6 +444,12 @@ struct mgx_world {
     int resident_cap = -1;                         // workgroups of the resident kernel the device holds at once (-1: not asked yet)
     int resident_cap_sharded = -1;                 // the same for the instantiation that takes ghost records in-launch
     bool peers_valid = false;
+    // what the per-tick table rebuild reads of EVERY connection, 16 bytes apiece beside the connections themselves (168 bytes and
+    // four vectors each): kept in step wherever the list changes (ir_connect, ir_disconnect, ir_disconnect_batch)
+    struct ConnHot { int32_t owner, other, node_first, node_last; };
+    std::vector<ConnHot> conn_hot;
+    Incoming retopo_tables;               // retopo's host tables and slot records (storage kept from tick to tick)
+    std::vector<IrSlotRec> retopo_slots;
     // missions on the device (mgx_mission_*): host copies of what mgx_mission_set gave, the device arrays, the
     // host-mapped event list of robots that reached their last waypoint, and the tick counter
     struct Mission {
@@ -921,21 +944,6 @@ static int upload_flags(mgx_world *w) {
     return MGX_OK;
 }
 
-// Incoming inter-robot connections of every local robot in inbox key order (graph key, node index
-// — message.rs / id.rs:19-117), and the split between lower-key and higher-key owners.  Each
-// connection hangs one factor on every variable 1..K-1 of its target, and the order is the same for
-// all of them: by owner key, and for two connections of one owner by node slot — a connection's K-1
-// slots are one block of consecutive indices (fresh, or a whole vacated block: alloc_node), so
-// comparing the first slots orders the whole blocks.  Edge (variable i, list position q) of robot r
-// lives at  (K-1) * in_ptr[r] + (i-1) * n_in(r) + q.
-struct Incoming {
-    std::vector<int32_t> in_ptr, in_list, mid;
-    // on request: the resident kernel's peer table (ensure_resident_tables) from the same two passes over the connections —
-    // [R + 1 row pointers | entries]: for every local robot the owners of its incoming and the targets of its outgoing connections
-    std::vector<int32_t> peers;
-    int ir_max_edges = 0;
-    bool blocks_ok = true;
-};
 static size_t edge_index(const std::vector<int32_t> &in_ptr, int K, int r, int j, int slot) {
     const int n_in = in_ptr[(size_t)r + 1] - in_ptr[(size_t)r];
     return (size_t)(K - 1) * (size_t)in_ptr[(size_t)r] + (size_t)j * (size_t)n_in + (size_t)(slot - in_ptr[(size_t)r]);
@@ -945,11 +953,13 @@ static void build_incoming(const mgx_world *w, int R_local, Incoming &t, bool wa
     const uint64_t *key = w->sets.keys.data();  // (compact copies of the robots' order keys and ghost flags: a Robot is a dozen vectors wide)
     const uint8_t *ghost = w->sets.ghost.data();
     const int32_t *dev_of = w->dev_of.data();
-    const IrConn *conns = w->conns.data();
+    const mgx_world::ConnHot *conns = w->conn_hot.data();  // (owner, other, first and last node slot of every connection)
     const size_t n_conns = w->conns.size(), R = (size_t)R_local;
     t.in_ptr.assign(R + 1, 0);
     t.mid.assign((size_t)std::max(R_local, 1), 0);
     int32_t *pp = nullptr;
+    t.blocks_ok = true;
+    t.peers.clear();
     if (want_peers) {
         t.peers.assign(R + 1 + std::max<size_t>(2 * n_conns, 1), 0);
         pp = t.peers.data();
@@ -964,7 +974,8 @@ static void build_incoming(const mgx_world *w, int R_local, Incoming &t, bool wa
     }
     for (size_t r = 0; r < R; r++) t.in_ptr[r + 1] += t.in_ptr[r];
     t.in_list.assign((size_t)t.in_ptr[R], 0);
-    std::vector<int32_t> fill(t.in_ptr.begin(), t.in_ptr.end() - 1), pfill;
+    std::vector<int32_t> &fill = t.fill, &pfill = t.pfill;
+    fill.assign(t.in_ptr.begin(), t.in_ptr.end() - 1);
     if (pp) {
         for (size_t r = 0; r < R; r++) pp[r + 1] += pp[r];
         pfill.assign(pp, pp + R);
@@ -984,7 +995,7 @@ static void build_incoming(const mgx_world *w, int R_local, Incoming &t, bool wa
         int32_t *seg = t.in_list.data() + t.in_ptr[(size_t)r];
         const int n_in = t.in_ptr[(size_t)r + 1] - t.in_ptr[(size_t)r];
         auto before = [&](int32_t a, int32_t b) {
-            const IrConn &ca = conns[(size_t)a], &cb = conns[(size_t)b];
+            const mgx_world::ConnHot &ca = conns[(size_t)a], &cb = conns[(size_t)b];
             const uint64_t ka = key[(size_t)ca.owner], kb = key[(size_t)cb.owner];
             if (ka != kb) return ka < kb;
             if ((ca.node_first < cb.node_first) != (ca.node_last < cb.node_last)) t.blocks_ok = false;
@@ -1028,14 +1039,17 @@ static int upload_flags(mgx_world *w);
 static int retopo(mgx_world *w) {
     const int K = w->K, R_local = w->d.R_local;
     StageTimer tm("retopo");
-    Incoming t;
+    // (the tables are rebuilt every tick by a world that follows its topology: their storage stays with the world — a quarter of a
+    // megabyte of slot records from the allocator every tick is page faults)
+    Incoming &t = w->retopo_tables;
     // (a world whose schedules can run as resident launches gets that kernel's peer table from the same passes, in the same block)
     const bool want_peers = (w->d.R_total == w->d.R_local || w->xres.connected) && (w->p.enable_mask & 2u) && w->sweep_flag_buf.p;
     build_incoming(w, R_local, t, want_peers);
     tm.lap("build_incoming");
     if (!t.blocks_ok) return fail(MGX_ERR_STATE, "internal: node slots of two connections interleave");
     const size_t n_slots = t.in_list.size(), NI = n_slots * (size_t)(K - 1), NIs = std::max<size_t>(NI, 1);
-    std::vector<IrSlotRec> slots(std::max<size_t>(n_slots, 1));
+    std::vector<IrSlotRec> &slots = w->retopo_slots;
+    slots.resize(std::max<size_t>(n_slots, 1));
     if (n_slots != w->conns.size())  // (connections towards a ghost are another rank's: no slot here; all others are rewritten below)
         for (IrConn &c : w->conns)
             if (w->sets.ghost[(size_t)c.other]) c.dev_slot = -1;
@@ -1857,6 +1871,7 @@ int mgx_robot_add(mgx_world *w, const mgx_robot_desc *d, int32_t *robot_id) {
     w->sets.keys.push_back(rb.order_key);
     w->sets.ghost.push_back(rb.ghost ? 1 : 0);
     w->sets.radius.push_back(rb.radius);
+    w->sets.removed.push_back(0);
     w->robots.push_back(std::move(rb));
     w->sets.ensure(w->robots.size());
     w->K = K;
@@ -1893,6 +1908,7 @@ static int ir_connect(mgx_world *w, int32_t owner, int32_t other, uint64_t first
     if (keyless) w->n_keyless++;
     c.node_first = c.node.front();
     c.node_last = c.node.back();
+    w->conn_hot.push_back(mgx_world::ConnHot{c.owner, c.other, c.node_first, c.node_last});
     w->conns.push_back(std::move(c));
     w->conns_dirty = true;
     return MGX_OK;
@@ -1916,6 +1932,8 @@ static int ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
     w->conns.erase(std::remove_if(w->conns.begin(), w->conns.end(),
                                   [&](const IrConn &c) { return (c.owner == a && c.other == b) || (c.owner == b && c.other == a); }),
                    w->conns.end());
+    w->conn_hot.clear();
+    for (const IrConn &c : w->conns) w->conn_hot.push_back(mgx_world::ConnHot{c.owner, c.other, c.node_first, c.node_last});
     if (w->n_keyless > 0) {  // some of them may just have gone
         w->n_keyless = 0;
         for (const IrConn &c : w->conns) w->n_keyless += c.keys.empty() ? 0 : 1;
@@ -1974,10 +1992,12 @@ static void ir_disconnect_batch(mgx_world *w, const std::vector<std::pair<int, i
             while (hi > lo && dead[hi - 1]) hi--;
             if (lo >= hi) break;
             w->conns[lo] = std::move(w->conns[hi - 1]);  // dead[lo], alive[hi - 1]
+            w->conn_hot[lo] = w->conn_hot[hi - 1];
             dead[lo] = 0;
             hi--;
         }
         w->conns.resize(hi);
+        w->conn_hot.resize(hi);
     }
     tm.lap("connection list");
     if (w->n_keyless > 0) {  // some of them may just have gone
@@ -1997,6 +2017,7 @@ int mgx_robot_remove(mgx_world *w, int32_t robot) {
     if (rb.removed) return fail(MGX_ERR_STATE, "robot %d already removed", robot);
     flush_counts(w);
     rb.removed = true;
+    w->sets.removed[(size_t)robot] = 1;
     rb.idle = 1;
     rb.antenna = 0;
     w->sets.cnt[(size_t)robot] = 0;
@@ -2421,46 +2442,44 @@ static int topology_bookkeeping(mgx_world *w, std::vector<int32_t> &ptr, std::ve
     // LAST out-of-range id (largest key) wins; every out-of-range id leaves robots_connected_with
     // (:1406-1408) whether or not its factors get deleted.  The map's iteration order is
     // unspecified in the reference; ascending robot id here.
+    // (one merge per robot does both halves of the pass — a robot's row of the search and its connection set are ascending in
+    // order key: what is in the set and not in the row is out of range; what is in the row and not in the set is a new
+    // neighbour, create_interrobot_factors' snapshot (robot.rs:1449-1461: within range \ connected, taken for every robot
+    // before anything is created; the deletions in between leave the sets alone).)
     std::vector<int> victim((size_t)n, -1);
+    std::vector<std::pair<int, int>> fresh;  // (robot, new neighbour), robots ascending, neighbours in row order
     for (int r = 0; r < n; r++) {
-        if (w->robots[(size_t)r].removed) continue;  // not in the query any more
         int32_t *cw = cs.row((size_t)r);
         const int32_t n_cw = cs.cnt[(size_t)r];
-        int32_t kept = 0;
+        const bool gone = w->sets.removed[(size_t)r] != 0;  // not in the query any more: its set stays as it is
+        int32_t kept = 0, q = 0;
         int32_t j = ptr[(size_t)r];
         const int32_t j1 = ptr[(size_t)r + 1];
-        for (int32_t q = 0; q < n_cw; q++) {
-            const int o = cw[q];
-            while (j < j1 && key(idx[(size_t)j]) < key(o)) j++;
-            if (j < j1 && idx[(size_t)j] == o) cw[kept++] = o;  // still in range
-            else victim[(size_t)r] = o;
+        while (q < n_cw || j < j1) {
+            if (j >= j1 || (q < n_cw && key(cw[q]) < key(idx[(size_t)j]))) {  // connected, not in range
+                if (gone) cw[kept++] = cw[q];
+                else victim[(size_t)r] = cw[q];
+                q++;
+            } else if (q >= n_cw || key(idx[(size_t)j]) < key(cw[q])) {  // in range, not connected
+                fresh.emplace_back(r, idx[(size_t)j]);
+                j++;
+            } else {  // both
+                cw[kept++] = cw[q];
+                q++;
+                j++;
+            }
         }
         cs.cnt[(size_t)r] = kept;
     }
+    tm.lap("range scan");
     {
         std::vector<std::pair<int, int>> pairs;
         for (int r = 0; r < n; r++)
             if (victim[(size_t)r] >= 0) pairs.emplace_back(r, victim[(size_t)r]);
-        tm.lap("out-of-range scan");
         ir_disconnect_batch(w, pairs, own_lists);
         deleted = (uint32_t)pairs.size();
         tm.lap("delete");
     }
-
-    // create_interrobot_factors (robot.rs:1441-1586): new = within range \ connected, ascending,
-    // snapshotted for every robot first (:1449-1461); K-1 robot numbers per connection (:1527)
-    std::vector<std::pair<int, int>> fresh;  // (robot, new neighbour), robots ascending, neighbours in row order
-    for (int r = 0; r < n; r++) {
-        const int32_t *cw = cs.row((size_t)r);
-        const int32_t n_cw = cs.cnt[(size_t)r];
-        int32_t q = 0;
-        for (int32_t j = ptr[(size_t)r]; j < ptr[(size_t)r + 1]; j++) {
-            const int o = idx[(size_t)j];
-            while (q < n_cw && key(cw[q]) < key(o)) q++;
-            if (!(q < n_cw && cw[q] == o)) fresh.emplace_back(r, o);
-        }
-    }
-    tm.lap("fresh scan");
     for (const auto &f : fresh) {
         const int r = f.first, o = f.second;
         rc = ir_connect(w, r, o, *robot_number_next);
