@@ -2934,8 +2934,8 @@ int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *wayp
         int rc = mgx_update_priors(w, n, robots, waypoints_xy, time_scale, what, max_speed, delta_t);
         return rc != MGX_OK ? rc : mgx_iterate(w, steps, n_steps);
     }
-    for (uint32_t i = 0; i < n; i++)
-        if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size() || w->robots[(size_t)robots[i]].ghost || w->robots[(size_t)robots[i]].removed || (what[i] & ~3u))
+    for (uint32_t i = 0; i < n; i++)  // (the robots' ghost / removed flags from their compact copies)
+        if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size() || w->sets.ghost[(size_t)robots[i]] || w->sets.removed[(size_t)robots[i]] || (what[i] & ~3u))
             return fail(MGX_ERR_INVALID, "bad entry %u", i);
     StageTimer tmk("tick");
     int rc = commit(w);
