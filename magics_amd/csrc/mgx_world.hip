@@ -253,8 +253,7 @@ struct IrEdge {  // one InterRobotFactor, kept at its target variable
 struct IrConn {  // K-1 factors owner -> other
     // (what the per-tick host passes over ALL connections read — counters, table rebuild — sits in the first cache line)
     int owner, other;
-    int32_t dev_slot = -1;  // slot of this connection in its target's incoming list on the device (-1: not there)
-    bool has_fresh = true;  // some edge still carries `fresh` (created since the device tables were last laid out)
+    // (its slot in the target's incoming list on the device and "some edge is still fresh" live in mgx_world::conn_hot)
     uint64_t first_number;
     uint64_t cnt[4] = {0, 0, 0, 0};  // MessageCount summed over the K-1 factors
     // Sum over the factors of how often each one's node slot occurs in the owner's
@@ -446,7 +445,12 @@ struct mgx_world {
     bool peers_valid = false;
     // what the per-tick table rebuild reads of EVERY connection, 16 bytes apiece beside the connections themselves (168 bytes and
     // four vectors each): kept in step wherever the list changes (ir_connect, ir_disconnect, ir_disconnect_batch)
-    struct ConnHot { int32_t owner, other, node_first, node_last; };
+    struct ConnHot {
+        int32_t owner, other, node_first, node_last;
+        uint64_t first_number;
+        int32_t dev_slot;   // slot of this connection in its target's incoming list on the device (-1: not there) — kept HERE only
+        uint8_t has_fresh;  // some edge still carries `fresh` (created since the device tables were last laid out) — kept HERE only
+    };
     std::vector<ConnHot> conn_hot;
     Incoming retopo_tables;               // retopo's host tables and slot records (storage kept from tick to tick)
     std::vector<IrSlotRec> retopo_slots;
@@ -743,10 +747,12 @@ static int pull(mgx_world *w) {
             rb.thaw = thw[dr];
         }
     }
-    for (IrConn &c : w->conns)
+    for (size_t ci = 0; ci < w->conns.size(); ci++) {
+        IrConn &c = w->conns[ci];
+        const int32_t dev_slot = w->conn_hot[ci].dev_slot;
         for (size_t j = 0; j < c.edges.size(); j++) {
-            if (c.dev_slot < 0) continue;  // created since the tables were built: nothing on the device yet
-            const size_t e = edge_index(w->dev_in_ptr, w->K, w->dev_of[(size_t)c.other], (int)j, c.dev_slot);
+            if (dev_slot < 0) continue;  // created since the tables were built: nothing on the device yet
+            const size_t e = edge_index(w->dev_in_ptr, w->K, w->dev_of[(size_t)c.other], (int)j, dev_slot);
             IrEdge &ed = c.edges[j];
             gather(ife, NI, e, ed.fv_eta, 4);
             gather(ifl, NI, e, ed.fv_lam, 16);
@@ -757,6 +763,7 @@ static int pull(mgx_world *w) {
             for (int q = 0; q < 16; q++)
                 if ((q >> 2) >= 2 || (q & 3) >= 2) ed.fv_lam[q] = 0.0;
         }
+    }
     return MGX_OK;
 }
 
@@ -1050,11 +1057,12 @@ static int retopo(mgx_world *w) {
     const size_t n_slots = t.in_list.size(), NI = n_slots * (size_t)(K - 1), NIs = std::max<size_t>(NI, 1);
     std::vector<IrSlotRec> &slots = w->retopo_slots;
     slots.resize(std::max<size_t>(n_slots, 1));
+    mgx_world::ConnHot *hot = w->conn_hot.data();  // (slot words, robot numbers and the "fresh" marks sit in the connections' mirror)
     if (n_slots != w->conns.size())  // (connections towards a ghost are another rank's: no slot here; all others are rewritten below)
-        for (IrConn &c : w->conns)
-            if (w->sets.ghost[(size_t)c.other]) c.dev_slot = -1;
+        for (size_t ci = 0; ci < w->conn_hot.size(); ci++)
+            if (w->sets.ghost[(size_t)hot[ci].other]) hot[ci].dev_slot = -1;
     for (size_t g = 0; g < n_slots; g++) {
-        IrConn &c = w->conns[(size_t)t.in_list[g]];
+        mgx_world::ConnHot &c = hot[(size_t)t.in_list[g]];
         IrSlotRec &sl = slots[g];
         sl.tgt_robot = w->dev_of[(size_t)c.other];
         sl.src_robot = w->dev_of[(size_t)c.owner];
@@ -1064,8 +1072,8 @@ static int retopo(mgx_world *w) {
         sl.first_number = c.first_number;
         c.dev_slot = (int32_t)g;  // (from here on the connection's slot in the tables being built)
         if (c.has_fresh) {
-            for (IrEdge &ed : c.edges) ed.fresh = false;
-            c.has_fresh = false;
+            for (IrEdge &ed : w->conns[(size_t)t.in_list[g]].edges) ed.fresh = false;
+            c.has_fresh = 0;
         }
     }
     tm.lap("slot records");
@@ -1181,10 +1189,10 @@ static int commit(mgx_world *w) {
     const size_t n_slots = t.in_list.size(), NI = n_slots * (size_t)(K - 1), NIs = std::max<size_t>(NI, 1);
     std::vector<IrEdgeRec> recs(NIs, IrEdgeRec{0, 0, 0, 0, 0.0, 0.0});
     std::vector<double> ife(4 * NIs, 0.0), ifl(16 * NIs, 0.0), ibm(4 * NIs, 0.0);
-    for (IrConn &c : w->conns) c.dev_slot = -1;
+    for (mgx_world::ConnHot &h : w->conn_hot) h.dev_slot = -1;
     for (size_t g = 0; g < n_slots; g++) {
         IrConn &c = w->conns[(size_t)t.in_list[g]];
-        c.dev_slot = (int32_t)g;
+        w->conn_hot[(size_t)t.in_list[g]].dev_slot = (int32_t)g;
         const int r = w->dev_of[(size_t)c.other];
         for (int j = 0; j < K - 1; j++) {
             const size_t e = edge_index(t.in_ptr, K, r, j, (int)g);
@@ -1459,11 +1467,13 @@ static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_ma
             // the keys fill structurally, so the log says which ones are there now
             flush_counts(w);
             std::vector<KeylessRec> recs;
-            for (const IrConn &c : w->conns) {
-                if (c.keys.empty() || c.dev_slot < 0) continue;
+            for (size_t ci = 0; ci < w->conns.size(); ci++) {
+                const IrConn &c = w->conns[ci];
+                const int32_t dev_slot = w->conn_hot[ci].dev_slot;
+                if (c.keys.empty() || dev_slot < 0) continue;
                 const int tr = w->dev_of[(size_t)c.other];
                 for (size_t j = 0; j < c.keys.size(); j++)
-                    recs.push_back(KeylessRec{(int32_t)edge_index(w->dev_in_ptr, w->K, tr, (int)j, c.dev_slot), tr, (uint32_t)c.keys[j], 0u});
+                    recs.push_back(KeylessRec{(int32_t)edge_index(w->dev_in_ptr, w->K, tr, (int)j, dev_slot), tr, (uint32_t)c.keys[j], 0u});
             }
             if (!recs.empty()) {
                 void *hp = nullptr, *dp = nullptr;
@@ -1908,7 +1918,7 @@ static int ir_connect(mgx_world *w, int32_t owner, int32_t other, uint64_t first
     if (keyless) w->n_keyless++;
     c.node_first = c.node.front();
     c.node_last = c.node.back();
-    w->conn_hot.push_back(mgx_world::ConnHot{c.owner, c.other, c.node_first, c.node_last});
+    w->conn_hot.push_back(mgx_world::ConnHot{c.owner, c.other, c.node_first, c.node_last, c.first_number, -1, 1});
     w->conns.push_back(std::move(c));
     w->conns_dirty = true;
     return MGX_OK;
@@ -1932,8 +1942,9 @@ static int ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
     w->conns.erase(std::remove_if(w->conns.begin(), w->conns.end(),
                                   [&](const IrConn &c) { return (c.owner == a && c.other == b) || (c.owner == b && c.other == a); }),
                    w->conns.end());
-    w->conn_hot.clear();
-    for (const IrConn &c : w->conns) w->conn_hot.push_back(mgx_world::ConnHot{c.owner, c.other, c.node_first, c.node_last});
+    w->conn_hot.erase(std::remove_if(w->conn_hot.begin(), w->conn_hot.end(),
+                                     [&](const mgx_world::ConnHot &c) { return (c.owner == a && c.other == b) || (c.owner == b && c.other == a); }),
+                      w->conn_hot.end());
     if (w->n_keyless > 0) {  // some of them may just have gone
         w->n_keyless = 0;
         for (const IrConn &c : w->conns) w->n_keyless += c.keys.empty() ? 0 : 1;
@@ -2187,7 +2198,7 @@ static int neighbours_enqueue(mgx_world *w, const float *pos, float radius, uint
         // ghosts take part: a sharded world that follows a changing topology holds EVERY robot of the
         // scenario (its own ones and ghost copies of all others) and is handed all positions, so that
         // the connection bookkeeping below runs identically on every rank
-        if (!w->robots[(size_t)r].removed) alive.push_back(r);
+        if (!w->sets.removed[(size_t)r]) alive.push_back(r);
     }
     const bool compact = (int)alive.size() != n_all;
     if (compact && !from_missions) {
@@ -2348,8 +2359,8 @@ static int neighbours_collect(mgx_world *w, mgx_world::PendingSearch &ps, std::v
         for (int r = 0; r < n_all; r++) full[(size_t)r + 1] += full[(size_t)r];
         ptr.swap(full);
     }
-    bool monotone = true;  // ids ascending == keys ascending?
-    for (int r = 1; r < n_all && monotone; r++) monotone = w->robots[(size_t)r - 1].order_key < w->robots[(size_t)r].order_key;
+    bool monotone = true;  // ids ascending == keys ascending?  (the keys' compact copies: fixed when a robot is added)
+    for (int r = 1; r < n_all && monotone; r++) monotone = w->sets.keys[(size_t)r - 1] < w->sets.keys[(size_t)r];
     if (!monotone)
         for (int r = 0; r < n_all; r++)
             std::sort(idx.begin() + ptr[(size_t)r], idx.begin() + ptr[(size_t)r + 1],
