@@ -1,3 +1,6 @@
+"""Diagnostics: from a `rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d DIR -- python3 tools/dynamic_tick_breakdown.py`
+run, the medians of the last twenty ticks: duration of the neighbour search kernel and of the resident schedule launch, the host's
+wait for the search, the tick period.  usage: python tools/trace_summary.py DIR"""
 import csv, glob, sys
 d = sys.argv[1]
 k = list(csv.DictReader(open(glob.glob(d + "/*/*kernel_trace.csv")[0])))
