@@ -156,6 +156,12 @@ public:
         check(mgx_tick(w_, (uint32_t)robots.size(), robots.data(), waypoints_xy.data(), time_scale.data(), what.data(), max_speed,
                        delta_t, steps.data(), (uint32_t)steps.size()));
     }
+    /// how the last iterate_gbp_v2 / tick ran: sweep-kernel launches (1 = the whole schedule as one resident launch)
+    uint32_t last_launch_count() {
+        uint32_t n = 0;
+        check(mgx_last_launch_count(w_, &n));
+        return n;
+    }
     /// FactorGraph::change_factor_enabled (factorgraph.rs:1529-1539) for every graph: MGX_FACTOR_* bits
     void change_factor_enabled(uint32_t kind_mask) { check(mgx_set_enabled(w_, kind_mask)); }
     std::pair<uint32_t, uint32_t> update_topology(const std::vector<std::array<float, 3>> &translations, float comms_radius,

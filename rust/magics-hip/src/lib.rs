@@ -95,6 +95,18 @@ impl World {
     pub fn iterate(&self, steps: &[u8]) -> Result<(), MgxError> {
         check(unsafe { sys::mgx_iterate(self.raw, steps.as_ptr(), steps.len() as u32) })
     }
+    /// How the last `iterate` / `tick` ran: sweep-kernel launches (1 = the whole schedule as one resident launch).
+    pub fn last_launch_count(&self) -> Result<u32, MgxError> {
+        let mut n = 0u32;
+        check(unsafe { sys::mgx_last_launch_count(self.raw, &mut n) })?;
+        Ok(n)
+    }
+    /// (resident launches so far, those declined before they wrote anything, what is left of the back-off)
+    pub fn resident_stats(&self) -> Result<(u64, u64, u32), MgxError> {
+        let (mut launches, mut declined, mut backoff) = (0u64, 0u64, 0u32);
+        check(unsafe { sys::mgx_resident_stats(self.raw, &mut launches, &mut declined, &mut backoff) })?;
+        Ok((launches, declined, backoff))
+    }
     /// One FixedUpdate of the planner chain (robot.rs:86-103): `update_prior_of_horizon_state` +
     /// `update_prior_of_current_state_v3` for the listed robots, then `iterate_gbp_v2` over `steps`.
     /// `what[i]`: bit 0 = horizon prior, bit 1 = current prior.
