@@ -407,7 +407,7 @@ int mgx_halo_rccl_disconnect(mgx_world *w);
  *      send_first[p+1]): the consumer's area, its size in records, the offset of this rank's
  *      segment in it and this rank's counter there.  Producers and consumers of a rank must be the
  *      same set of peers (inter-robot factors come in pairs, robot.rs:1490-1541).
- * A wait that exceeds MGX_HALO_TIMEOUT_MS (default 5000) gives up, leaves the ghosts untouched
+ * A wait that exceeds MGX_HALO_TIMEOUT_MS (default 20000) gives up, leaves the ghosts untouched
  * and is reported by mgx_halo_direct_status (never a hung GPU). */
 int mgx_halo_direct_setup(mgx_world *w, uint32_t n_sources, void **recv_base, void **flag_base);
 int mgx_halo_direct_connect(mgx_world *w, uint32_t n_peers, const uint32_t *send_first,
@@ -447,7 +447,7 @@ int mgx_halo_direct_disconnect(mgx_world *w);
  *      world.  The first word of that area is where the ranks AGREE on every schedule: the launches of one schedule wait for
  *      each other's records, so they go ahead together or not at all.  Each rank's launch signs in there once all its own
  *      workgroups are on the device; the last rank to sign in says go; a rank that has waited MGX_RESIDENT_CENSUS_SHARDED_US
- *      (default 5000) for the others, or whose own workgroups do not all arrive (another tenant holds the CUs), or that cannot
+ *      (default 20000) for the others, or whose own workgroups do not all arrive (another tenant holds the CUs), or that cannot
  *      run this schedule as a resident launch at all, says abort — by system-scope compare-and-swap on that one word, so every
  *      rank reads the same answer before any of them has written anything.  After an abort every rank's world is as it was
  *      and the schedule runs launch by launch with the direct exchange (the engine does that by itself, see

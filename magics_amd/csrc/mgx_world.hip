@@ -1680,8 +1680,8 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
         }();
         static const long long census_ticks_sharded = [] {  // the ranks' hosts do not launch at the same instant
             const char *e = getenv("MGX_RESIDENT_CENSUS_SHARDED_US");
-            const long long us = e ? atoll(e) : 5000;
-            return (us > 0 ? us : 5000) * 100ll;
+            const long long us = e ? atoll(e) : 20000;
+            return (us > 0 ? us : 20000) * 100ll;
         }();
         static const bool census_on = [] { const char *e = getenv("MGX_RESIDENT_CENSUS"); return !(e && e[0] == '0'); }();
         const bool census = sharded ? ranks_agree : census_on;  // MGX_RESIDENT_CENSUS=0: plain bound on every wait

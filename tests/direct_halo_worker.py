@@ -42,7 +42,7 @@ def main():
             dist.barrier()
             if rank == ws - 1:
                 import time
-                time.sleep(0.08)
+                time.sleep(0.3)
         sw.iterate(steps)
         if (decline or late) and tick == 0:
             assert sw.world.resident_stats()[:2] == (1, 0), sw.world.resident_stats()

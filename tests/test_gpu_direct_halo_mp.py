@@ -31,11 +31,14 @@ def test_ranks_in_separate_processes(world_size, mode, tmp_path):
     "+decline": the last rank says no to the launch of the second tick — on the word in rank 0's area where the ranks agree on
     every schedule, so ALL ranks' launches return with their worlds untouched, every engine runs that schedule launch by launch
     with the direct exchange, and the third tick (inside the back-off) runs launch by launch on every rank too.
-    "+late": the last rank issues the second tick 80 ms after the others — whose launches have given up waiting for it on that word
-    (MGX_RESIDENT_CENSUS_SHARDED_US, 5 ms) and returned; its own launch finds their "no" and returns as well."""
+    "+late": the last rank issues the second tick 0.3 s after the others — whose launches have given up waiting for it on that word
+    (MGX_RESIDENT_CENSUS_SHARDED_US, here 20 ms) and returned; its own launch finds their "no" and returns as well."""
     port = _free_port()
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(world_size)]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MGX_HALO_TIMEOUT_MS="20000", MGX_RESIDENT_TIMEOUT_MS="20000")
+    # (how long the ranks' launches wait for each other before they all fall back: generous where every schedule is expected to
+    # run as one launch — three processes share the one GPU of a test box —, short where a rank is 0.3 s late on purpose)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MGX_HALO_TIMEOUT_MS="20000", MGX_RESIDENT_TIMEOUT_MS="20000",
+               MGX_RESIDENT_CENSUS_SHARDED_US="20000" if mode.endswith("+late") else "500000")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "direct_halo_worker.py"), str(r), str(world_size), port, outs[r], mode],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world_size)]
     logs = []
@@ -89,7 +92,7 @@ def test_bench_direct_child_role(tmp_path):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
-                   MGX_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", MGX_HALO_TIMEOUT_MS="20000")
+                   MGX_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", MGX_HALO_TIMEOUT_MS="20000", MGX_RESIDENT_CENSUS_SHARDED_US="500000")
         procs.append(subprocess.Popen([sys.executable, bench, "--role", "direct-child", "--gpus", "2", "--steps", "80", "--warmup", "20",
                                        "--robots-per-gpu", "100", "--horizon", "10"], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE))
@@ -117,7 +120,7 @@ def test_bench_two_rank_control_flow_dry_run():
     import json
     bench = os.path.join(os.path.dirname(HERE), "bench.py")
     env = dict(os.environ, MGX_BENCH_BACKEND="gloo", MGX_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               MGX_HALO_TIMEOUT_MS="20000")
+               MGX_HALO_TIMEOUT_MS="20000", MGX_RESIDENT_CENSUS_SHARDED_US="500000")  # (both ranks share one GPU here)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", _free_port(), bench, "--gpus", "2", "--steps", "60", "--warmup", "20", "--robots-per-gpu", "144",
            "--horizon", "10", "--deadline", "150", "--repeats", "3"]

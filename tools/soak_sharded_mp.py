@@ -67,7 +67,7 @@ def worker(rank, ws, port, budget):
             if op == 4 and rank == who:
                 sw.world.set_resident_launches("decline")  # this rank says no: every rank's launch returns untouched
             if op == 5 and rank == who:
-                time.sleep(0.02)  # ... or comes too late for the others
+                time.sleep(0.06)  # ... or comes too late for the others
             before = sw.world.resident_stats()
             sw.iterate(steps)
             if ref is not None:
@@ -104,7 +104,7 @@ def worker(rank, ws, port, budget):
     if rank == 0:
         print(f"soak sharded mp: {done} random scripts on {ws} processes sharing one GPU (transport {got}), seeds 7000..{seed - 1}: rank 0 saw "
               f"{tot[0][0]} schedules run as ONE launch per rank and {tot[0][1]} declined by the ranks' agreement (a rank said no, or came "
-              f"20 ms late) and re-run launch by launch by every engine; {'all bit-identical to the single-world oracle' if not failed else str(failed) + ' MISMATCHED'}; "
+              f"60 ms late) and re-run launch by launch by every engine; {'all bit-identical to the single-world oracle' if not failed else str(failed) + ' MISMATCHED'}; "
               f"{dropped} more drove the oracle itself to NaN / inf ({time.time() - t0:.0f} s)", flush=True)
     dist.destroy_process_group()
     sys.exit(1 if failed else 0)
