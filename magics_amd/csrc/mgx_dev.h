@@ -59,14 +59,29 @@ struct IrSlotRec {
     uint64_t first_number;  // robot_number of the factor on variable 1 (robot.rs:1527)
 };
 
-// Resident schedule launches of a SHARDED world: where the snapshot records of a local robot that another rank holds as a ghost
+// EXCHANGE RECORDS of resident schedule launches — the hand-off between neighbouring robots' workgroups (and, on sharded worlds,
+// between GPUs).  What an inter-robot factor F_AB reads of its owner A is the message A's variable sends it: (eta, lam, mu) — of
+// which the factor's arithmetic touches eta, lam and the two position means (interrobot.rs:149-159: the Jacobian has no velocity
+// columns) — and whether that variable has delivered at all (its delivery count).  At the end of a segment every robot publishes,
+// per variable, ONE 256-byte record of sixteen 16-byte chunks; chunk c = { D[3c], D[3c+1], D[3c+2], sequence word } where D[0..47]
+// are the 24 f64 of the snapshot record as (low, high) dword pairs, except D[44] = the variable's delivery count (the low half of
+// mu[2], a velocity mean nobody reads, gives way; D[45..47] ride along unread).  A 16-byte aligned store is one transaction, so a
+// chunk whose sequence word is the expected one carries that publication's payload: consumers POLL THE CHUNKS THEMSELVES — no
+// drain of the producer's stores, no progress word, no dependent second trip (experiments/handoff/records.hip, form B: half the
+// hand-off time of "records, acknowledgements, progress word, then the loads").  Sequence word: bit 31 set (memory that was only
+// ever zeroed never validates) | the low 31 bits of the consumer's count of the segment the record is for; compared for
+// equality.  Two parities of records per variable, written alternately (a producer is never two publications ahead of a
+// consumer: it needs that consumer's record of the segment in between — see wait_for_peers in mgx_sweep.h for the one-sided case).
+constexpr int XREC_CHUNKS = 16, XREC_BYTES = 16 * XREC_CHUNKS, XREC_EPOCH_DWORD = 44;
+__host__ __device__ constexpr uint32_t xrec_seq(unsigned long long count) { return 0x80000000u | (uint32_t)(count & 0x7fffffffull); }
+
+// Resident schedule launches of a SHARDED world: where the exchange records of a local robot that another rank holds as a ghost
 // go at the end of a segment — addresses inside that rank's ghost area (peer-mapped, fine-grained), indexed by THIS rank's
 // buffer parity; the consumer's progress word for the ghost, and what has to be added to this rank's segment count to speak
 // the consumer's (each rank counts the segments of its own resident launches).
 struct XPushRec {
-    unsigned long long snap[2];   // [K][24] f64
-    unsigned long long epoch[2];  // [K] u32
-    unsigned long long flag;      // one u64
+    unsigned long long xrec[2];  // [K][XREC_BYTES]
+    unsigned long long flag;     // one u64
     unsigned long long flag_delta;
 };
 
@@ -141,10 +156,13 @@ struct DevWorld {
 
     double inv_s2_obs, inv_s2_ir, inv_s2_trk, trk_pad, trk_attr;
 
-    // Resident schedule launches (k_robot_sweep<.., PERSIST>, SegPlan below): one progress word per local robot
-    // ("segments of resident launches completed", monotonic over the life of the device arrays), the robots each
-    // one exchanges snapshot records with (owners of its incoming edges and targets of its outgoing ones, CSR),
-    // and two words for a wait that gave up: [0] device-side "stop waiting", [1] a host-mapped copy the host reads
+    // Resident schedule launches (k_robot_sweep<.., PERSIST>, SegPlan below): the exchange records of the local robots' variables
+    // (above; two parities), one progress word per local robot ("segments of resident launches completed", monotonic over the
+    // life of the device arrays — polled inside a launch only by a robot that READS this one's records without being read by it,
+    // the reference's one-sided connections), the robots each one exchanges records with (owners of its incoming edges and
+    // targets of its outgoing ones, CSR), and two words for a wait that gave up: [0] device-side "stop waiting", [1] a
+    // host-mapped copy the host reads
+    unsigned char *xrec[2];           // [R_local * K][XREC_BYTES]
     unsigned long long *sweep_flag;   // [R_local]
     const int32_t *peer_ptr;          // [R_local + 1]
     const int32_t *peer_idx;          // device robot indices
@@ -159,10 +177,9 @@ struct DevWorld {
     unsigned long long *decision_host;   // host-mapped
     // Resident schedule launches of a sharded world (k_robot_sweep<.., PERSIST, SHARD>).  This rank's GHOST AREA is fine-grained
     // device memory that the ghosts' owner ranks store into from inside their launches (peer-mapped: hipIpc across processes):
-    // the ghosts' snapshot records and delivery counts for the two buffer parities and one progress word per ghost (ghost g =
-    // device robot R_local + g), all read here with system-scope loads.  xp_*: the local robots other ranks hold as ghosts.
-    const double *gsnap[2];           // [NG * K][24]
-    const uint32_t *gepoch[2];        // [NG * K]
+    // the ghosts' exchange records for the two buffer parities and one progress word per ghost (ghost g = device robot
+    // R_local + g), all read here with system-scope loads.  xp_*: the local robots other ranks hold as ghosts.
+    const unsigned char *gxrec[2];    // [NG * K][XREC_BYTES]
     const unsigned long long *gflag;  // [NG]
     const int32_t *xp_ptr;            // [R_local + 1] push targets of each local robot (most have none)
     const XPushRec *xp_rec;

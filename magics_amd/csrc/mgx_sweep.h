@@ -58,6 +58,17 @@ __device__ __forceinline__ void st_soa16(double *base, int stride, int item, con
 
 extern __shared__ double lds[];
 
+// An edge's constants in registers: loaded as two 16-byte pieces and kept as five scalars, never as an aggregate — a copy of the
+// 32-byte record that is chosen between a register copy and memory ends up as a pointer choice, and the register copy in scratch.
+#define MGX_EDGE_REGS(p) int p##_src_var = 0, p##_dst = 0; uint32_t p##_created = 0u; double p##_d_safe = 0.0, p##_offset = 0.0
+#define MGX_EDGE_LOAD(p, ptr)                                                                                     \
+    do {                                                                                                          \
+        const int4 a_ = *reinterpret_cast<const int4 *>(ptr);                                                     \
+        const double2 b_ = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(ptr) + 16);          \
+        p##_src_var = a_.x; p##_created = (uint32_t)a_.z; p##_dst = a_.w; p##_d_safe = b_.x; p##_offset = b_.y;   \
+    } while (0)
+#define MGX_EDGE_COPY(p, q) do { p##_src_var = q##_src_var; p##_created = q##_created; p##_dst = q##_dst; p##_d_safe = q##_d_safe; p##_offset = q##_offset; } while (0)
+
 // In-kernel cycle stamps exist only in the diagnostic build (never in libmgx.so): they go to a
 // buffer of their own and no output value depends on them.
 #ifdef MGX_STAMPS
@@ -184,6 +195,26 @@ __device__ __forceinline__ void st16_system(__amdgpu_buffer_rsrc_t rs, unsigned 
     v4u32 v;
     v.x = (unsigned)__double2loint(a); v.y = (unsigned)__double2hiint(a);
     v.z = (unsigned)__double2loint(b); v.w = (unsigned)__double2hiint(b);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, 17);
+}
+// four dwords as they are (exchange records: three payload dwords and the sequence word, mgx_dev.h); `sbase` is a wave-uniform
+// byte offset that rides in the instruction's scalar operand (the parity of the records: ONE descriptor serves both)
+__device__ __forceinline__ v4u32 ld16_agent_raw(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, unsigned sbase) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, (int)sbase, 16);
+}
+__device__ __forceinline__ v4u32 ld16_system_raw(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, unsigned sbase) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, (int)sbase, 17);
+}
+// (stores: the wave-uniform part is ADDED to the per-lane offset, never passed in the scalar operand.  A buffer store of more than
+// 8 bytes reads its data registers some cycles after issue; the compiler keeps the next VALU write of those registers away from
+// it — except behind a store with an SGPR soffset, which older parts issued a cycle later (GCNHazardRecognizer: "this hazard only
+// exists if the instruction is not using a register in the soffset field").  On gfx950 that exemption does not hold: with the
+// parity in soffset, lanes 32..47 of one publication in ~10^4 went out with the NEXT chunk's payload under a valid sequence word
+// — found with a per-record checksum, experiments/README.md.)
+__device__ __forceinline__ void st16_agent_raw(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, unsigned sbase, v4u32 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(byte_off + sbase), 0, 16);
+}
+__device__ __forceinline__ void st16_system_raw(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, v4u32 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)byte_off, 0, 17);
 }
 // a buffer descriptor over [base, base + bytes) from a pointer every lane of the wave holds (made scalar here)
@@ -377,7 +408,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // Each thread prefetches its first edge (robots have at most a few more edges than threads).
     const bool do_extf = !PERSIST && HAS_IR && (ext_mask & PH_EXT_FACTOR) && radio && ir_on;
     bool pf_on = false, pf_present = false;
-    IrEdgeRec pf_er{};
+    MGX_EDGE_REGS(pf_er);
     double pf_bmu[4] = {0.0, 0.0, 0.0, 0.0}, pf_rec[SNAP_W];
 #pragma unroll
     for (int c = 0; c < SNAP_W; c++) pf_rec[c] = 0.0;
@@ -385,13 +416,13 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     int pf_dst = 0;
     if (HAS_IR && tid < ne) pf_gate = w.ir_gate[ie0 + tid];
     if (do_extf && tid < ne) {
-        pf_er = w.ir_rec[ie0 + tid];
-        pf_dst = pf_er.dst;
+        MGX_EDGE_LOAD(pf_er, &w.ir_rec[ie0 + tid]);
+        pf_dst = pf_er_dst;
         ld_soa4(w.ir_bmu, w.NI, ie0 + tid, pf_bmu);
     }
     if (PERSIST && tid < ne) {  // resident launches: the edge's constants stay in registers for every external iteration
-        pf_er = w.ir_rec[ie0 + tid];
-        pf_dst = pf_er.dst;
+        MGX_EDGE_LOAD(pf_er, &w.ir_rec[ie0 + tid]);
+        pf_dst = pf_er_dst;
     }
     // The owners' records of the threads' edges are fetched by QUADS of lanes: for each of its four lanes' records in turn, lane v
     // of a quad asks for bytes [64 t + 16 v, + 16), t = 0..2 — the four requests of a quad are one contiguous 64 bytes — and a
@@ -473,8 +504,8 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         }
         if (do_extf) {  // the owners' records (other robots, HBM / L2); absent (not yet delivered) ones are zeroed when used
             pf_on = tid < ne && pf_gate == 1;
-            if (pf_on) pf_present = w.snap_epoch[w.cur][pf_er.src_var] > pf_er.created;
-            quad_gather(fetch_plain, pf_on ? (unsigned)pf_er.src_var * (unsigned)(SNAP_W * sizeof(double)) : 0u, pf_rec);
+            if (pf_on) pf_present = w.snap_epoch[w.cur][pf_er_src_var] > pf_er_created;
+            quad_gather(fetch_plain, pf_on ? (unsigned)pf_er_src_var * (unsigned)(SNAP_W * sizeof(double)) : 0u, pf_rec);
         }
     };
     unsigned long long early_decision = 0ull;  // resident launches: the go / abort word as it stands when the staging loads are back
@@ -657,15 +688,87 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // factorgraph.rs:745-754 keeps only the message to the other graph's variable, so F_AB is
     // evaluated here, at B, from A's snapshot record and B's last response mean.
     // k: segment of a resident schedule launch (0 otherwise); store_fv: the HBM copy of the messages is needed
-    // descriptors of the two snapshot buffers for the 16-byte agent-scope accesses of resident launches
-    const unsigned snap_bytes = (unsigned)w.V * (unsigned)(SNAP_W * sizeof(double));
-    const __amdgpu_buffer_rsrc_t rs_snap[2] = {sc1_rsrc(w.snap[0], PERSIST ? snap_bytes : 0u), sc1_rsrc(w.snap[1], PERSIST ? snap_bytes : 0u)};
+    // ONE descriptor over the two parities of exchange records (mgx_dev.h: contiguous), for the 16-byte agent-scope accesses of
+    // resident launches; the parity is a scalar offset of the access
+    const int VL = w.R_local * K;  // first ghost variable
+    const unsigned xrec_bytes = PERSIST ? (unsigned)VL * (unsigned)XREC_BYTES : 0u;
+    const __amdgpu_buffer_rsrc_t rs_x = sc1_rsrc(PERSIST ? w.xrec[0] : nullptr, 2u * xrec_bytes);
     // sharded worlds: the ghosts' records of segments k > 0 come from this rank's ghost area (their owners' ranks store them there
     // from inside their own launches), marked by the top bit of the byte offset a lane asks for
     constexpr unsigned GHOST_BIT = 0x80000000u;
-    const int VL = w.R_local * K;  // first ghost variable
-    const unsigned gsnap_bytes = SHARD ? (unsigned)(w.V - VL) * (unsigned)(SNAP_W * sizeof(double)) : 0u;
-    const __amdgpu_buffer_rsrc_t rs_gsnap[2] = {sc1_rsrc(SHARD ? w.gsnap[0] : nullptr, gsnap_bytes), sc1_rsrc(SHARD ? w.gsnap[1] : nullptr, gsnap_bytes)};
+    const unsigned gx_bytes = SHARD ? (unsigned)(w.V - VL) * (unsigned)XREC_BYTES : 0u;
+    const __amdgpu_buffer_rsrc_t rs_gx = sc1_rsrc(SHARD ? w.gxrec[0] : nullptr, 2u * gx_bytes);
+    // The gather of a resident launch's segments k > 0: the owners' EXCHANGE RECORDS (mgx_dev.h), polled.  As in quad_gather, lane v of a
+    // quad asks for chunks 4 t + v, t = 0..3, of each of its four lanes' records in turn (the four requests of a quad are one
+    // contiguous 64 bytes); a chunk is there when its sequence word is the expected one, and what is not there yet is asked for
+    // again — only that.  When every lane of the wave holds valid chunks, three transpositions per 64 bytes inside the quad hand each
+    // lane the 45 payload dwords of its own record: (eta, lam) and the two position means in `out`, the delivery count in `deliveries`.
+    // ro_mine: byte offset of the lane's record | 1 (a lane without an edge passes 0: record 0 is fetched once, never validated).
+    // A wait that outlasts the bound raises the world's abort word like any other wait of the launch (reported, never a hang).
+    auto quad_gather_records = [&](auto fetch, unsigned ro_mine, uint32_t seq, double (&out)[SNAP_W], uint32_t &deliveries) __attribute__((always_inline)) {
+        v4u32 R[4][4];
+        unsigned rb[4];
+        rb[0] = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0x00, 0xf, 0xf, true);
+        rb[1] = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0x55, 0xf, 0xf, true);
+        rb[2] = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0xAA, 0xf, 0xf, true);
+        rb[3] = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0xFF, 0xf, 0xf, true);
+        const unsigned piece = 16u * (unsigned)(lane & 3);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+            for (int t4 = 0; t4 < 4; t4++) R[s4][t4] = fetch((rb[s4] & ~1u) + 64u * t4 + piece);
+        long long t0 = 0;
+        for (unsigned spins = 0;; spins++) {
+            bool missing = false;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++) missing = missing || ((rb[s4] & 1u) && R[s4][t4].w != seq);
+            if (__ballot(missing) == 0ull) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (spins == 0u) t0 = wall_clock64();
+            if ((spins & 31u) == 31u) {
+                bool stop = __hip_atomic_load(w.sweep_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+                if (!stop && wall_clock64() - t0 > plan.timeout_ticks) {
+                    __hip_atomic_store(w.sweep_abort, (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(w.sweep_err, (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    stop = true;
+                }
+                if (__ballot(stop) != 0ull) break;  // (the launch ends with wrong beliefs; the host reports it)
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++)
+                    if ((rb[s4] & 1u) && R[s4][t4].w != seq) R[s4][t4] = fetch((rb[s4] & ~1u) + 64u * t4 + piece);
+        }
+        unsigned D[48];  // the lane's own record, dword by dword
+#pragma unroll
+        for (int t4 = 0; t4 < 4; t4++)
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                unsigned x[4] = {R[0][t4][d], R[1][t4][d], R[2][t4][d], R[3][t4][d]};
+                quad_transpose4(x, lane);
+#pragma unroll
+                for (int v = 0; v < 4; v++) D[3 * (4 * t4 + v) + d] = x[v];
+            }
+#pragma unroll
+        for (int n = 0; n < 22; n++) out[n] = __hiloint2double((int)D[2 * n + 1], (int)D[2 * n]);
+        out[22] = 0.0;
+        out[23] = 0.0;
+        deliveries = D[XREC_EPOCH_DWORD];
+#ifdef MGX_XREC_CHECKSUM
+        if (ro_mine & 1u) {
+            unsigned x = 0u;
+#pragma unroll
+            for (int n = 0; n < 45; n++) x ^= D[n];
+            const unsigned want_id = ((ro_mine & ~0x80000001u) / (unsigned)XREC_BYTES);  // variable index
+            if (x != D[45])
+                __hip_atomic_store(w.sweep_err, 0xBAD0000000000000ull | ((unsigned long long)(D[46] & 0xfffffu) << 28) | ((unsigned long long)(want_id & 0xfffffu) << 8) | (seq & 0xffu),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+#endif
+    };
     // resident launches: the response means (ir_bmu) of every edge of variable i that is on air are the variable's mean after the
     // external variable sweep — kept in LDS (the scratch sums' block, idle between that sweep's finish and the next one's sums)
     // from one segment to the next; HBM gets them once, after the launch's last external iteration
@@ -680,41 +783,49 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         t_edges0 = __builtin_readcyclecounter();
 #endif
         if (radio && ir_on) {
-            auto fetch_sc1 = [&](unsigned off) __attribute__((always_inline)) {
+            auto fetch_xrec = [&](unsigned off) __attribute__((always_inline)) {
                 if constexpr (SHARD) {
-                    if (off & GHOST_BIT) return ld16_system_raw(rs_gsnap[buf], off & ~GHOST_BIT);
+                    if (off & GHOST_BIT) return ld16_system_raw(rs_gx, off & ~GHOST_BIT, buf ? gx_bytes : 0u);
                 }
-                return ld16_agent_raw(rs_snap[buf], off);
+                return ld16_agent_raw(rs_x, off, buf ? xrec_bytes : 0u);
             };
+            const uint32_t want_seq = xrec_seq(plan.flag_base + (unsigned long long)k);
             for (int j0 = 0; j0 < ne; j0 += SWEEP_BLOCK) {  // rounds of the whole workgroup: every lane takes part in the gather
                 const int j = j0 + tid;
                 const int e = ie0 + j;
-                IrEdgeRec er{};
+                MGX_EDGE_REGS(er);
                 double ao_eta[4], ao_lam[16], a_mu[4], b_mu[4];
                 bool a_present;
                 // the round's record, unless it was prefetched while staging (launch-per-segment path, first round)
                 double grec[SNAP_W];
+                uint32_t grec_deliveries = 0u;
                 bool mine = false;
                 if (PERSIST || j0 > 0) {
                     if (j0 == 0) {
                         mine = tid < ne && pf_gate == 1;
-                        if (mine) er = pf_er;
+                        if (mine) MGX_EDGE_COPY(er, pf_er);
                     } else if (j < ne && w.ir_gate[e] == 1) {  // robots with more edges than threads
                         mine = true;
-                        er = w.ir_rec[e];
+                        MGX_EDGE_LOAD(er, &w.ir_rec[e]);
                     }
-                    // (segment 0 of a sharded launch reads the ghosts' plain copies, filled by the exchange in front of the launch)
-                    const bool ghost_src = SHARD && k > 0 && mine && er.src_var >= VL;
-                    const unsigned ro_mine = !mine ? 0u : ghost_src ? ((unsigned)(er.src_var - VL) * (unsigned)(SNAP_W * sizeof(double))) | GHOST_BIT
-                                                                   : (unsigned)er.src_var * (unsigned)(SNAP_W * sizeof(double));
-                    if (PERSIST) quad_gather(fetch_sc1, ro_mine, grec);  // published by other workgroups of THIS launch: agent scope
-                    else quad_gather(fetch_plain, ro_mine, grec);
+                    if (PERSIST && k > 0) {
+                        // published by other workgroups of THIS launch (agent scope) or by other ranks' launches into this rank's
+                        // ghost area (system scope): exchange records, polled
+                        const bool ghost_src = SHARD && mine && er_src_var >= VL;
+                        const unsigned ro_mine = !mine ? 0u : ghost_src ? ((unsigned)(er_src_var - VL) * (unsigned)XREC_BYTES) | GHOST_BIT | 1u
+                                                                       : ((unsigned)er_src_var * (unsigned)XREC_BYTES) | 1u;
+                        quad_gather_records(fetch_xrec, ro_mine, want_seq, grec, grec_deliveries);
+                    } else {
+                        // written by an earlier launch (segment 0 of a sharded launch reads the ghosts' plain copies, filled by the
+                        // exchange in front of the launch)
+                        quad_gather(fetch_plain, mine ? (unsigned)er_src_var * (unsigned)(SNAP_W * sizeof(double)) : 0u, grec);
+                    }
                     if (!mine) continue;
                 }
 
                 if (PERSIST) {
                     if (have_xmu) {  // the means this robot's external variable sweep of the previous segment answered with
-                        const int i = er.dst & 0xffff;
+                        const int i = er_dst & 0xffff;
 #pragma unroll
                         for (int c = 0; c < 4; c++) b_mu[c] = s_xmu[c * K + i];
                     } else {
@@ -725,10 +836,8 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     if (j0 == 0 && pf_present) {
                         a_present = true;
                     } else {
-                        if (SHARD && k > 0 && er.src_var >= VL)
-                            a_present = __hip_atomic_load(&w.gepoch[buf][er.src_var - VL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) > er.created;
-                        else
-                            a_present = ld_agent(&w.snap_epoch[buf][er.src_var]) > er.created;
+                        if (k > 0) a_present = grec_deliveries > er_created;  // the delivery count travels in the record
+                        else a_present = w.snap_epoch[buf][er_src_var] > er_created;
                         if (j0 == 0) pf_present = a_present;
                     }
 #ifdef MGX_STAMPS
@@ -744,7 +853,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 } else if (j0 == 0) {  // operands prefetched during staging
                     if (j >= ne) continue;
                     if (!pf_on) continue;  // the owner did not run its external factor sweep
-                    er = pf_er;
+                    MGX_EDGE_COPY(er, pf_er);
                     a_present = pf_present;
 #pragma unroll
                     for (int c = 0; c < 4; c++) b_mu[c] = pf_bmu[c];
@@ -756,7 +865,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     for (int c = 0; c < 4; c++) a_mu[c] = pf_rec[20 + c];
                 } else {
                     ld_soa4(w.ir_bmu, w.NI, e, b_mu);
-                    a_present = w.snap_epoch[w.cur][er.src_var] > er.created;
+                    a_present = w.snap_epoch[w.cur][er_src_var] > er_created;
 #pragma unroll
                     for (int c = 0; c < 4; c++) ao_eta[c] = grec[c];
 #pragma unroll
@@ -772,14 +881,14 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 }
                 // ONE evaluation for both slot orders (selects on the linearisation point): the lanes of a wave hold edges of
                 // both orders, and a branch around two inlined copies would run both for every wave
-                const int dslot = er.dst >> 16;
+                const int dslot = er_dst >> 16;
                 double x_lo[4], x_hi[4], o6[6];
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     x_lo[c] = dslot ? a_mu[c] : b_mu[c];
                     x_hi[c] = dslot ? b_mu[c] : a_mu[c];
                 }
-                if (!interrobot_message_compact(x_lo, x_hi, er.d_safe, er.offset, w.inv_s2_ir, dslot, ao_eta, ao_lam, o6)) {
+                if (!interrobot_message_compact(x_lo, x_hi, er_d_safe, er_offset, w.inv_s2_ir, dslot, ao_eta, ao_lam, o6)) {
 #pragma unroll
                     for (int c = 0; c < 6; c++) o6[c] = 0.0;
                 }
@@ -1171,16 +1280,18 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         }
     };
 
-    // Resident schedule launch: in front of the external iteration of segment k, wait until every robot this one
-    // exchanges snapshot records with (and that is on air) has completed segment k - 1 — its records for this
-    // iteration are then published, and it has finished reading ours of the iteration before, whose buffer the
-    // end of this segment overwrites.  One lane per peer polls that robot's progress word (relaxed agent-scope
-    // loads, s_sleep in between); a wait that outlasts the wall-clock bound raises the world's abort word, which
-    // releases every waiter: the launch then ends with wrong beliefs and the host reports it (never a hung GPU).
-    // The peer list does not change during the launch: lane l of the polling wave keeps peer l (the one it polls in every
-    // segment) in a register — looked up per segment, the three dependent loads in front of the first look at a progress
-    // word (list range, peer, its antenna / idle flags) were a microsecond of pure latency on the hand-off.
+    // Resident schedule launch, flow control.  A robot's records of segment k + 1 overwrite those of segment k - 1 (two parities),
+    // so every robot that reads them must be through with segment k - 1's gather first.  A reader whose OWN records this robot
+    // gathers — the rule: inter-robot factors come in pairs — has said so already: its record of segment k, validated by this
+    // robot's edge lanes, was published behind that gather.  Only a reader this robot does not read (the reference's bookkeeping
+    // can leave a connection one-sided) is asked through its progress word: one lane per such peer polls it in front of segment
+    // k's external iteration (relaxed agent-scope loads, s_sleep in between); a wait that outlasts the wall-clock bound raises
+    // the world's abort word, which releases every waiter: the launch then ends with wrong beliefs and the host reports it
+    // (never a hung GPU).  The peer list (owners of incoming and targets of outgoing connections) does not change during the
+    // launch: lane l keeps peer l in a register, and whether that peer owns one of this robot's incoming connections (the
+    // edges of variable 1 are one per connection; a peer off the air is not polled at all).
     int my_peer = -1, peer_q0 = 0, peer_q1 = 0;
+    bool my_peer_read = false;  // this robot gathers that peer's records in every external iteration
     if (PERSIST && radio && ir_on && role == ROLE_UV) {
         peer_q0 = w.peer_ptr[r];
         peer_q1 = w.peer_ptr[r + 1];
@@ -1188,6 +1299,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             const int pr = w.peer_idx[peer_q0 + lane];
             if (w.antenna[pr] && !w.idle[pr]) my_peer = pr;  // not on air: neither reads our records nor has its own read
         }
+        for (int e = w.ir_var_ptr[v0 + 1]; e < w.ir_var_ptr[v0 + 2]; e++) my_peer_read = my_peer_read || w.ir_rec[e].src_robot == my_peer;
     }
     // ghosts_only (sharded worlds, see the end of a segment): look at the peers on other ranks only
     auto progress_of = [&](int pr) __attribute__((always_inline)) {
@@ -1204,6 +1316,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     if (!w.antenna[pr] || w.idle[pr]) pr = -1;
                 }
                 if (pr < 0 || (ghosts_only && pr < w.R_local)) continue;
+                if (!ghosts_only && q == peer_q0 + lane && my_peer_read) continue;  // its records speak for it (see above)
                 const long long t0 = wall_clock64();
                 unsigned spins = 0;
                 while (progress_of(pr) < want) {
@@ -1273,9 +1386,12 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         PSTAMP(ps0);
         QBEGIN(qt);
         if (PERSIST && ext_k && k > 0) {  // k == 0: the launch boundary has published everything
-            wait_for_peers(k);
+            wait_for_peers(k);  // (one-sided readers only: nobody, as a rule)
             QSTAMP(0, qt);
-            __syncthreads();
+            // The edge lanes read the response means the previous external variable sweep left in LDS: written in front of a
+            // barrier when the two variable sweeps ran side by side (the steady state of an alternating schedule: each wave goes
+            // straight on to its gather), behind the last one otherwise.
+            if (!(FUSED && par_done)) __syncthreads();
             QSTAMP(1, qt);
         }
         PSTAMP(ps1);
@@ -1538,42 +1654,58 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 if (pending) finish(s_snap, true);
                 QSTAMP(10, qt);
                 __builtin_amdgcn_wave_barrier();  // the wave's LDS writes (means) precede its LDS reads below
+                // The robot's EXCHANGE RECORDS (mgx_dev.h) for the external iteration that opens the next segment, into the parity
+                // nobody reads during this segment: lane l stores chunk l % 16 of variables l / 16, l / 16 + 4, .. — three payload
+                // dwords out of two neighbouring f64 of the snapshot image, and the sequence word.  Fire and forget: a chunk
+                // validates itself, so nothing is drained and no word follows the stores on the consumers' critical path.
                 const int ob = (w.cur + k + 1) & 1;
-                const unsigned base = (unsigned)v0 * (unsigned)(SNAP_W * sizeof(double));
-                for (int t = lane; t < (SNAP_W / 2) * K; t += 64) {  // 16 bytes = components 2c, 2c + 1 of variable i
-                    const int i = t / (SNAP_W / 2), c = t - i * (SNAP_W / 2);
-                    st16_agent(rs_snap[ob], base + (unsigned)(i * SNAP_W + 2 * c) * 8u, s_snap[(2 * c) * K + i], s_snap[(2 * c + 1) * K + i]);
+                const unsigned long long next_count = plan.flag_base + (unsigned long long)k + 1ull;
+                const int ch = lane & (XREC_CHUNKS - 1), da = (3 * ch) >> 1;
+                auto chunk_of = [&](int i, uint32_t seq) __attribute__((always_inline)) {
+                    const double A = s_snap[da * K + i], B = s_snap[(da + 1) * K + i];
+                    v4u32 v;
+                    v.x = (ch & 1) ? (unsigned)__double2hiint(A) : (unsigned)__double2loint(A);
+                    v.y = (ch & 1) ? (unsigned)__double2loint(B) : (unsigned)__double2hiint(A);
+                    v.z = (ch & 1) ? (unsigned)__double2hiint(B) : (unsigned)__double2loint(B);
+                    if (3 * ch + 2 == XREC_EPOCH_DWORD) v.z = s_epoch[i];
+#ifdef MGX_XREC_CHECKSUM
+                    {
+                        unsigned x = ch == 15 ? 0u : (v.x ^ v.y ^ v.z);
+                        x ^= (unsigned)__shfl_xor((int)x, 1, 16);
+                        x ^= (unsigned)__shfl_xor((int)x, 2, 16);
+                        x ^= (unsigned)__shfl_xor((int)x, 4, 16);
+                        x ^= (unsigned)__shfl_xor((int)x, 8, 16);
+                        if (ch == 15) { v.x = x; v.y = (unsigned)(r * 64 + i); v.z = 0u; }
+                    }
+#endif
+                    v.w = seq;
+                    return v;
+                };
+                {
+                    const unsigned base = (unsigned)v0 * (unsigned)XREC_BYTES;
+                    const uint32_t seq = xrec_seq(next_count);
+                    for (int t = lane; t < XREC_CHUNKS * K; t += 64) st16_agent_raw(rs_x, base + 16u * (unsigned)t, ob ? xrec_bytes : 0u, chunk_of(t >> 4, seq));
                 }
-                for (int t = lane; t < K; t += 64) st_agent(&w.snap_epoch[ob][v0 + t], s_epoch[t]);
                 QSTAMP(11, qt);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // "through with segment k's gather": for the one-sided readers' sake only (wait_for_peers)
+                if (lane == 0) __hip_atomic_store(&w.sweep_flag[r], next_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 QSTAMP(12, qt);
-                if (lane == 0)
-                    __hip_atomic_store(&w.sweep_flag[r], plan.flag_base + (unsigned long long)k + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (SHARD && xp1 > xp0) {
                     // A boundary robot of a sharded world: the same records go into the ghost area of every rank that holds this
-                    // robot as a ghost (system-scope write-through stores over xGMI), drained, then the ghost's progress word there.
+                    // robot as a ghost (system-scope write-through stores over xGMI), numbered in THAT rank's count of segments.
                     // Nothing orders two RANKS' launches: the parity written here is the one those ranks' robots read in the LAST
                     // external iteration of the previous launch, so in segment 0 wait until they are through with it (they say so
-                    // at the end of their launch, below); in later segments the wait in front of the external iteration has.
+                    // at the end of their launch, below); in later segments their records of the segment in between have.
                     if (k == 0) wait_for_progress(plan.flag_base, true);
                     for (int t = xp0; t < xp1; t++) {
                         const XPushRec xr = w.xp_rec[t];
-                        const __amdgpu_buffer_rsrc_t rs_x = uniform_rsrc(xr.snap[ob], (unsigned)K * (unsigned)(SNAP_W * sizeof(double)));
-                        for (int t2 = lane; t2 < (SNAP_W / 2) * K; t2 += 64) {
-                            const int i = t2 / (SNAP_W / 2), c = t2 - i * (SNAP_W / 2);
-                            st16_system(rs_x, (unsigned)(i * SNAP_W + 2 * c) * 8u, s_snap[(2 * c) * K + i], s_snap[(2 * c + 1) * K + i]);
-                        }
-                        uint32_t *xe = reinterpret_cast<uint32_t *>(xr.epoch[ob]);
-                        for (int t2 = lane; t2 < K; t2 += 64) __hip_atomic_store(&xe[t2], s_epoch[t2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        const __amdgpu_buffer_rsrc_t rs_peer = uniform_rsrc(xr.xrec[ob], (unsigned)K * (unsigned)XREC_BYTES);
+                        const uint32_t seq = xrec_seq(next_count + xr.flag_delta);
+                        for (int t2 = lane; t2 < XREC_CHUNKS * K; t2 += 64) st16_system_raw(rs_peer, 16u * (unsigned)t2, chunk_of(t2 >> 4, seq));
+                        if (lane == 0)
+                            __hip_atomic_store(reinterpret_cast<unsigned long long *>(xr.flag), next_count + xr.flag_delta, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_SYSTEM);
                     }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0)
-                        for (int t = xp0; t < xp1; t++) {
-                            const XPushRec xr = w.xp_rec[t];
-                            __hip_atomic_store(reinterpret_cast<unsigned long long *>(xr.flag), plan.flag_base + xr.flag_delta + (unsigned long long)k + 1ull,
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        }
                 }
             }
             pending = false;

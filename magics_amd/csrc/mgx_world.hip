@@ -411,6 +411,7 @@ struct mgx_world {
     StageRing stage;  // packed per-tick arguments
     // resident schedule launches (SegPlan, mgx_dev.h): progress words, peer lists, the abort / error words
     DevBuf<unsigned long long> sweep_flag_buf, sweep_abort_buf;
+    DevBuf<unsigned char> xrec_buf;  // exchange records of the local robots' variables, two parities (mgx_dev.h)
     DevBuf<int32_t> peer_ptr_dev;  // [R + 1 row pointers | entries]
     size_t peer_idx_off = 0;
     std::vector<int32_t> peer_fill;
@@ -1351,7 +1352,7 @@ static int commit(mgx_world *w) {
     w->flag_base = 0;
     w->resident_cap = w->resident_cap_sharded = -1;
     w->xres.connected = false;  // ghost slots and progress words belonged to the old layout: the ranks wire them again
-    d.gsnap[0] = d.gsnap[1] = nullptr; d.gepoch[0] = d.gepoch[1] = nullptr; d.gflag = nullptr; d.xp_ptr = nullptr; d.xp_rec = nullptr;
+    d.gxrec[0] = d.gxrec[1] = nullptr; d.gflag = nullptr; d.xp_ptr = nullptr; d.xp_rec = nullptr;
     w->xres.agree = nullptr; d.agree = nullptr; d.n_ranks = 0;
     if (!w->sweep_err_host) {  // the word device code reports a wait that gave up in (resident launches, direct halo waits)
         HIP_TRY(hipHostMalloc((void **)&w->sweep_err_host, sizeof(unsigned long long), hipHostMallocMapped));
@@ -1544,6 +1545,16 @@ static int ensure_resident_tables(mgx_world *w) {
         HIP_TRY(w->sweep_flag_buf.reserve(R));
         HIP_TRY(hipMemsetAsync(w->sweep_flag_buf.p, 0, sizeof(unsigned long long) * R, s));
         w->flag_base = 0;
+        // ... and with the segment count the exchange records start over: zeroed, so that no sequence word of an earlier life
+        // of the device arrays validates (a valid word has its top bit set, mgx_dev.h)
+        const size_t xb = R * (size_t)w->K * (size_t)XREC_BYTES;
+        HIP_TRY(w->xrec_buf.reserve(2 * xb));
+        HIP_TRY(hipMemsetAsync(w->xrec_buf.p, 0, 2 * xb, s));
+    }
+    {
+        const size_t xb = R * (size_t)w->K * (size_t)XREC_BYTES;
+        w->d.xrec[0] = w->xrec_buf.p;
+        w->d.xrec[1] = w->xrec_buf.p ? w->xrec_buf.p + xb : nullptr;
     }
     if (w->census_buf.n < R + 1) {  // residency census: one word per workgroup of a launch (never reset: monotonic in the launch number)
         std::vector<unsigned long long> z(R + 1 + R / 4 + 64, 0ull);
@@ -3462,17 +3473,16 @@ int mgx_halo_direct_disconnect(mgx_world *w) {
 }
 
 // ---- resident schedule launches on sharded worlds (include/mgx.h) -----------------------------------------
-// Layout of a ghost area for NG ghost slots of K variables: records of parity 0, records of parity 1 (NG * K * 24 f64
-// each), delivery counts of parity 0 / 1 (NG * K u32 each, padded to 16 bytes), NG progress words.  Both ends compute it.
+// Layout of a ghost area for NG ghost slots of K variables: the agreement word's line, exchange records of parity 0, of parity 1
+// (NG * K * XREC_BYTES each: mgx_dev.h), NG progress words.  Both ends compute it.
 namespace {
 struct GhostAreaLayout {
     static constexpr size_t agree = 0, HEAD = 64;  // the ranks' agreement word (used in rank 0's area only) has the first line to itself
-    size_t snap[2], epoch[2], flag, bytes;
+    size_t xrec[2], flag, bytes;
     GhostAreaLayout(size_t ng, size_t K) {
-        const size_t S = ng * K * SNAP_W * sizeof(double), E = (ng * K * sizeof(uint32_t) + 15) & ~(size_t)15;
-        snap[0] = HEAD; snap[1] = HEAD + S;
-        epoch[0] = HEAD + 2 * S; epoch[1] = HEAD + 2 * S + E;
-        flag = HEAD + 2 * S + 2 * E;
+        const size_t S = ng * K * (size_t)XREC_BYTES;
+        xrec[0] = HEAD; xrec[1] = HEAD + S;
+        flag = HEAD + 2 * S;
         bytes = flag + std::max<size_t>(ng, 1) * sizeof(unsigned long long);
     }
 };
@@ -3545,10 +3555,7 @@ int mgx_halo_resident_connect(mgx_world *w, uint32_t n_targets, const int32_t *r
         const unsigned long long base = (unsigned long long)(uintptr_t)peer_area_base[t];
         const unsigned x = ((unsigned)d.cur ^ peer_parity[t]) & 1u;  // this rank's parity p is the consumer's p ^ x (both flip together)
         XPushRec r;
-        for (unsigned p = 0; p < 2; p++) {
-            r.snap[p] = base + L.snap[p ^ x] + (size_t)peer_slot[t] * K * SNAP_W * sizeof(double);
-            r.epoch[p] = base + L.epoch[p ^ x] + (size_t)peer_slot[t] * K * sizeof(uint32_t);
-        }
+        for (unsigned p = 0; p < 2; p++) r.xrec[p] = base + L.xrec[p ^ x] + (size_t)peer_slot[t] * K * (size_t)XREC_BYTES;
         r.flag = base + L.flag + (size_t)peer_slot[t] * sizeof(unsigned long long);
         r.flag_delta = peer_segment_count[t] - w->flag_base;  // modulo 2^64
         recs.emplace_back(w->dev_of[(size_t)robots[t]], r);
@@ -3562,10 +3569,7 @@ int mgx_halo_resident_connect(mgx_world *w, uint32_t n_targets, const int32_t *r
     HIP_TRY(xr.xp_rec.upload(flat, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
     const GhostAreaLayout Lm((size_t)xr.n_ghosts, K);
-    for (int p = 0; p < 2; p++) {
-        d.gsnap[p] = (const double *)((const char *)xr.area + Lm.snap[p]);
-        d.gepoch[p] = (const uint32_t *)((const char *)xr.area + Lm.epoch[p]);
-    }
+    for (int p = 0; p < 2; p++) d.gxrec[p] = (const unsigned char *)xr.area + Lm.xrec[p];
     d.gflag = (const unsigned long long *)((const char *)xr.area + Lm.flag);
     d.xp_ptr = xr.xp_ptr.p;
     d.xp_rec = xr.xp_rec.p;
