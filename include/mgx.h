@@ -407,7 +407,7 @@ int mgx_halo_rccl_disconnect(mgx_world *w);
  *      send_first[p+1]): the consumer's area, its size in records, the offset of this rank's
  *      segment in it and this rank's counter there.  Producers and consumers of a rank must be the
  *      same set of peers (inter-robot factors come in pairs, robot.rs:1490-1541).
- * A wait that exceeds MGX_HALO_TIMEOUT_MS (default 20000) gives up, leaves the ghosts untouched
+ * A wait that exceeds MGX_HALO_TIMEOUT_MS (default 5000) gives up, leaves the ghosts untouched
  * and is reported by mgx_halo_direct_status (never a hung GPU). */
 int mgx_halo_direct_setup(mgx_world *w, uint32_t n_sources, void **recv_base, void **flag_base);
 int mgx_halo_direct_connect(mgx_world *w, uint32_t n_peers, const uint32_t *send_first,
@@ -455,7 +455,10 @@ int mgx_halo_direct_disconnect(mgx_world *w);
  *      coordinator_area NULL or n_ranks < 2: no agreement; a rank whose peers never start then gives up after
  *      MGX_RESIDENT_TIMEOUT_MS (default 2000) and reports MGX_ERR_STATE with the world invalid — never a hung GPU.
  * From then on mgx_iterate / mgx_tick run eligible schedules as one launch per rank (mgx_last_launch_count == 1); all ranks
- * must have connected.  A change of the world's layout (robots added / removed) disconnects. */
+ * must have connected.  A change of the world's layout (robots added / removed) switches the resident form off on THAT rank
+ * only; the peers may still hold its area mapped and store into it, so wiring again goes: barrier, mgx_halo_resident_disconnect
+ * on every rank, the peers close their mappings, barrier, then setup / connect as above.  A setup while the previous wiring
+ * has not been disconnected is refused (MGX_ERR_STATE). */
 int mgx_halo_resident_setup(mgx_world *w, void **area_base, uint32_t *n_ghost_slots, uint32_t *parity, uint64_t *segment_count,
                             int32_t *recv_slots, int32_t *eligible);
 int mgx_halo_resident_connect(mgx_world *w, uint32_t n_targets, const int32_t *robots, void *const *peer_area_base,

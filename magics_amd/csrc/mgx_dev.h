@@ -256,28 +256,47 @@ constexpr unsigned RESIDENT_GO = 1u, RESIDENT_ABORT = 2u;
 
 // One look at / one move on the agreement word of a sharded world's resident launches (SegPlan::agree_seq).
 // action 0: look; 1: sign in (the caller's census is complete — once per launch); 2: vote abort.
-// Returns the word's state for schedule L: 0 while undecided, RESIDENT_GO or RESIDENT_ABORT.
-// The word: schedule number << 18 | outcome of the schedule before << 16 | state << 14 | ranks signed in.  The outcome of the
-// schedule before rides along because ranks that share no robots do not wait for each other: one of them can be through
-// schedule L and sign in for L + 1 before a slow rank's decider has looked at L's outcome — which it then still finds.
+// Returns the word's state for schedule L: 0 while undecided, RESIDENT_GO or RESIDENT_ABORT — or AGREE_LOST when the word has
+// moved on by more schedules than it remembers (the caller reports it: the ranks' parities and segment counts have parted).
+// The word: schedule number << 28 | outcomes of the AGREE_HISTORY schedules before, two bits each, most recent lowest << 16 |
+// state << 14 | ranks signed in.  The outcomes before ride along because ranks that share no robots do not wait for each other:
+// some of them can be through schedule L, and through later ones declined for this rank's absence, before a slow rank's
+// decider has looked at L's outcome — which it then still finds, as it was decided.  (One remembered outcome was not enough:
+// a rank that had signed in for L without being the last and then stalled two schedules read "abort" for a schedule the
+// others ran.)  A schedule nobody moved on (every rank skipped the resident form: back-off) reads as declined.
 constexpr int AGREE_LOOK = 0, AGREE_SIGN_IN = 1, AGREE_ABORT = 2;
+constexpr int AGREE_HISTORY = 6;
+constexpr unsigned AGREE_LOST = 3u;
 __device__ inline unsigned agree_on_launch(unsigned long long *word, unsigned long long L, unsigned n_ranks, int action) {
+    constexpr unsigned long long HMASK = (1ull << (2 * AGREE_HISTORY)) - 1ull;
+    unsigned long long declined = 0ull;  // "declined" in every remembered place
+    for (int i = 0; i < AGREE_HISTORY; i++) declined |= (unsigned long long)RESIDENT_ABORT << (2 * i);
     unsigned long long cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (;;) {
-        const unsigned long long cl = cur >> 18;
-        const unsigned prev = (unsigned)(cur >> 16) & 3u, st = (unsigned)(cur >> 14) & 3u, cnt = (unsigned)cur & 0x3fffu;
+        const unsigned long long cl = cur >> 28, hist = (cur >> 16) & HMASK;
+        const unsigned st = (unsigned)(cur >> 14) & 3u, cnt = (unsigned)cur & 0x3fffu;
         if (cl == L && st) return st;
-        if (cl == L + 1ull && prev) return prev;
-        if (cl > L) return RESIDENT_ABORT;  // more than a schedule behind: only after this rank was given up on
+        if (cl > L) {  // the word has moved on: what was decided for L is in its history, if L is not too long ago
+            const unsigned long long back = cl - L;
+            if (back > (unsigned long long)AGREE_HISTORY) return AGREE_LOST;
+            const unsigned was = (unsigned)(hist >> (2 * (back - 1ull))) & 3u;
+            return was ? was : AGREE_LOST;
+        }
         if (action == AGREE_LOOK) return 0u;
-        // (a word of an earlier schedule: the first move of schedule L carries that one's outcome along)
-        const unsigned long long carry = (unsigned long long)(cl == L ? prev : (cl + 1ull == L ? st : RESIDENT_ABORT)) << 16;
+        // (a word of an earlier schedule: the first move of schedule L takes that one's outcome, and "declined" for every
+        // schedule in between that nobody moved on, into the history)
+        unsigned long long h = hist;
+        if (cl < L) {
+            const unsigned long long gap = L - cl;
+            h = gap > (unsigned long long)AGREE_HISTORY ? declined
+                : (((hist << 2) | (unsigned long long)(st ? st : RESIDENT_ABORT)) << (2 * (gap - 1ull)) | (declined & ((1ull << (2 * (gap - 1ull))) - 1ull))) & HMASK;
+        }
         unsigned long long nw;
         if (action == AGREE_SIGN_IN) {
             const unsigned c = (cl == L ? cnt : 0u) + 1u;
-            nw = (L << 18) | carry | ((unsigned long long)(c >= n_ranks ? RESIDENT_GO : 0u) << 14) | c;
+            nw = (L << 28) | (h << 16) | ((unsigned long long)(c >= n_ranks ? RESIDENT_GO : 0u) << 14) | c;
         } else {
-            nw = (L << 18) | carry | ((unsigned long long)RESIDENT_ABORT << 14) | (cl == L ? cnt : 0u);
+            nw = (L << 28) | (h << 16) | ((unsigned long long)RESIDENT_ABORT << 14) | (cl == L ? cnt : 0u);
         }
         if (__hip_atomic_compare_exchange_strong(word, &cur, nw, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
             return (unsigned)(nw >> 14) & 3u;

@@ -290,6 +290,10 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 } else {
                     want = agree_on_launch(w.agree, plan.agree_seq, (unsigned)w.n_ranks, late ? AGREE_ABORT : AGREE_LOOK);
                 }
+                if (want == AGREE_LOST) {  // the other ranks are more schedules ahead than the word remembers: this world has parted
+                    __hip_atomic_store(w.sweep_err, plan.agree_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // from theirs (reported)
+                    want = RESIDENT_ABORT;
+                }
                 if ((v >> 2) == seq) {
                     done = 1;  // a workgroup that gave up on this one has decided
                 } else if (want) {
@@ -591,9 +595,11 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 if ((v >> 2) != seq && wall_clock64() - t0 > 4 * plan.census_ticks) {
                     // (sharded worlds: only if the ranks' word says abort too — with this vote it does unless every rank,
                     // hence this one's decider, has signed in: then the decider is alive and about to say so here)
-                    if (SHARD && plan.agree_seq != 0ull &&
-                        agree_on_launch(w.agree, plan.agree_seq, (unsigned)w.n_ranks, AGREE_ABORT) != RESIDENT_ABORT)
-                        continue;
+                    if (SHARD && plan.agree_seq != 0ull) {
+                        const unsigned a = agree_on_launch(w.agree, plan.agree_seq, (unsigned)w.n_ranks, AGREE_ABORT);
+                        if (a == RESIDENT_GO) continue;
+                        if (a == AGREE_LOST) __hip_atomic_store(w.sweep_err, plan.agree_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                     if (__hip_atomic_compare_exchange_strong(w.decision, &v, seq * 4ull + RESIDENT_ABORT, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_AGENT)) {
                         __hip_atomic_store(w.decision_host, seq * 4ull + RESIDENT_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -776,6 +782,12 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     bool have_xmu = false;
 #ifdef MGX_STAMPS
     unsigned long long q_arrive = 0ull, t_edges0 = 0ull;  // cycles from the start of the factor sweep until the thread's record is there
+    // hand-off timeline (100 MHz wall clock, the same on every CU), per robot and segment k: [0] publication of segment k begins,
+    // [1] its stores are issued, [2] the gather of segment k + 1 begins, [3] every record of that gather is there (UV wave)
+    unsigned long long *tl = (PERSIST && w.dbg) ? w.dbg + (size_t)(w.R_local + 4) * 48 + (size_t)r * 64 : nullptr;
+#define TLSTAMP(kk, what) do { if (tl && role == ROLE_UV && lane == 0 && (kk) >= 0 && (kk) < 16) tl[(kk) * 4 + (what)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TLSTAMP(kk, what)
 #endif
     auto external_factor_sweep = [&](int k, bool store_fv) __attribute__((always_inline)) {
         const int buf = PERSIST ? ((w.cur + k) & 1) : w.cur;  // snapshot buffer the owners' records are read from
@@ -814,7 +826,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                         const bool ghost_src = SHARD && mine && er_src_var >= VL;
                         const unsigned ro_mine = !mine ? 0u : ghost_src ? ((unsigned)(er_src_var - VL) * (unsigned)XREC_BYTES) | GHOST_BIT | 1u
                                                                        : ((unsigned)er_src_var * (unsigned)XREC_BYTES) | 1u;
+                        if (j0 == 0) TLSTAMP(k - 1, 2);
                         quad_gather_records(fetch_xrec, ro_mine, want_seq, grec, grec_deliveries);
+                        if (j0 == 0) TLSTAMP(k - 1, 3);
                     } else {
                         // written by an earlier launch (segment 0 of a sharded launch reads the ghosts' plain copies, filled by the
                         // exchange in front of the launch)
@@ -1654,6 +1668,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 if (pending) finish(s_snap, true);
                 QSTAMP(10, qt);
                 __builtin_amdgcn_wave_barrier();  // the wave's LDS writes (means) precede its LDS reads below
+                TLSTAMP(k, 0);
                 // The robot's EXCHANGE RECORDS (mgx_dev.h) for the external iteration that opens the next segment, into the parity
                 // nobody reads during this segment: lane l stores chunk l % 16 of variables l / 16, l / 16 + 4, .. — three payload
                 // dwords out of two neighbouring f64 of the snapshot image, and the sequence word.  Fire and forget: a chunk
@@ -1687,6 +1702,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     for (int t = lane; t < XREC_CHUNKS * K; t += 64) st16_agent_raw(rs_x, base + 16u * (unsigned)t, ob ? xrec_bytes : 0u, chunk_of(t >> 4, seq));
                 }
                 QSTAMP(11, qt);
+                TLSTAMP(k, 1);
                 // "through with segment k's gather": for the one-sided readers' sake only (wait_for_peers)
                 if (lane == 0) __hip_atomic_store(&w.sweep_flag[r], next_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 QSTAMP(12, qt);

@@ -432,9 +432,14 @@ struct mgx_world {
         int cur_before = 0;
         unsigned long long flag_base_before = 0;
         bool partial = false;  // the launch is not the first of its schedule (more than MAX_SEGS segments)
-        const double *upd = nullptr;  // mgx_tick: the prior updates that ride in the launch (pinned ring slot, still valid)
+        const double *upd = nullptr;  // mgx_tick: the prior updates that ride in the launch
+        int upd_slot = -1;            // ... and the pinned ring slot they sit in (-1: device memory of the caller's, mgx_mission_tick):
+                                      // a re-run guards it again — the event behind the declined launch completed at once
         double upd_max_speed = 0.0, upd_delta_t = 0.0;
     } pending;
+    int upd_ring_slot = -1;  // mgx_tick -> run_resident: the ring slot d.upd points into
+    int sticky_rc = 0;       // a declined launch whose re-run failed inside a call that cannot report it (flush_counts): every
+                             // later sweep, read-back and mgx_synchronize reports it (check_device_error)
     // after a declined launch the schedules skip the resident form for a while: counted in world-wide external iterations that
     // ran launch by launch (whoever drives them: the engine's own schedules or a host's mgx_sweep calls — on a sharded world
     // every rank runs the same ones, so every rank comes back to the resident form with the same schedule)
@@ -532,6 +537,7 @@ struct mgx_world {
         size_t bytes = 0;
         int n_ghosts = 0;
         bool connected = false;
+        bool wired = false;  // connect has run and disconnect has not: the peers may hold `area` mapped and store into it
         DevBuf<int32_t> xp_ptr;
         DevBuf<XPushRec> xp_rec;
         // the ranks' agreement on every schedule's launches (SegPlan::agree_seq): the word (in rank 0's area), the number of
@@ -776,7 +782,10 @@ static int pull(mgx_world *w) {
 // is about to change or a count is asked for.
 
 static void flush_counts(mgx_world *w) {
-    if (w->pending.active) (void)confirm_resident(w);  // the launch's entries join the log once it is known to have run
+    if (w->pending.active) {  // the launch's entries join the log once it is known to have run
+        const int rcc = confirm_resident(w);
+        if (rcc != MGX_OK && w->sticky_rc == MGX_OK) w->sticky_rc = rcc;  // (a re-run that failed: reported by whatever runs or reads next)
+    }
     if (w->clog.empty() && w->cp_dirty.empty()) return;
     const int K = w->K;
     const size_t n = w->robots.size();
@@ -1335,7 +1344,8 @@ static int commit(mgx_world *w) {
     d.trk_attr = w->p.tracking_attraction_distance;
 #ifdef MGX_STAMPS
     {
-        std::vector<unsigned long long> z((size_t)(R_local + 4) * 48, 0ull);  // [.. * 16): stages per wave, then 16 sub-stage sums per wave
+        // [.. * 16): stages per wave, then 16 sub-stage sums per wave; behind them the hand-off timeline, 16 segments x 4 per robot
+        std::vector<unsigned long long> z((size_t)(R_local + 4) * 48 + (size_t)R_local * 64, 0ull);
         HIP_TRY(w->dbg.upload(z, s));
         HIP_TRY(hipStreamSynchronize(s));
         d.dbg = w->dbg.p;
@@ -1370,6 +1380,9 @@ static int commit(mgx_world *w) {
 // launch whose neighbour never did: the waiting kernels end (never a hung GPU) but what they computed from stale
 // records is wrong.  Sticky: every later sweep, synchronisation and read-back reports it.
 static int check_device_error(mgx_world *w) {
+    if (w->sticky_rc != MGX_OK)
+        return fail(w->sticky_rc, "a schedule that had to be run again launch by launch (its resident launch was declined) failed with code %d "
+                    "inside a call that edits the graph: the world is behind the schedules issued", w->sticky_rc);
     if (w->sweep_err_host && *w->sweep_err_host != 0ull)
         return fail(MGX_ERR_STATE, "a wait on the device timed out (exchange / progress word %llu): a peer rank or a neighbouring "
                     "workgroup never published its records, the world's beliefs are invalid", *w->sweep_err_host);
@@ -1426,6 +1439,12 @@ static int confirm_resident(mgx_world *w, bool rerun, int32_t *outcome) {
             if (first && pd.upd) { w->d.upd = pd.upd; w->d.upd_max_speed = pd.upd_max_speed; w->d.upd_delta_t = pd.upd_delta_t; }
             const int rc = sweep(w, -1, pd.segs[k].first, pd.segs[k].second ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, pd.segs[k].second, pd.hints[k]);
             w->d.upd = nullptr;
+            if (first && pd.upd && pd.upd_slot >= 0) {
+                // the slot was released behind the declined launch, which returned at once: without this the ring would hand it
+                // out again (or free it) while the kernel just enqueued has yet to read the prior updates
+                const hipError_t e = w->stage.release(pd.upd_slot, w->stream);
+                if (rc == MGX_OK && e != hipSuccess) return fail(MGX_ERR_HIP, "event record: %s", hipGetErrorString(e));
+            }
             first = false;
             if (rc != MGX_OK) return rc;
         }
@@ -1742,6 +1761,7 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
             pd.cur_before = w->d.cur;
             pd.flag_base_before = w->flag_base;
             pd.upd = w->d.upd; pd.upd_max_speed = w->d.upd_max_speed; pd.upd_delta_t = w->d.upd_delta_t;
+            pd.upd_slot = w->d.upd ? w->upd_ring_slot : -1;
         }
         w->d.upd = nullptr;  // mgx_tick's prior updates ride in the first launch only
         w->d.cur = (w->d.cur + sp.n) & 1;
@@ -2980,7 +3000,9 @@ int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *wayp
     tmk.lap("update records + counter log");
     {   // the whole tick as one resident launch when the world qualifies: the prior updates ride in it all the same
         w->d.upd = (const double *)dp; w->d.upd_max_speed = max_speed; w->d.upd_delta_t = delta_t;
+        w->upd_ring_slot = slot;
         const int resident = run_resident(w, plan);
+        w->upd_ring_slot = -1;
         tmk.lap("resident launch enqueued");
         if (resident != 0) {
             w->d.upd = nullptr;
@@ -3497,6 +3519,12 @@ int mgx_halo_resident_setup(mgx_world *w, void **area_base, uint32_t *n_ghost_sl
     if (!w->halo_recv.empty() && !recv_slots) return fail(MGX_ERR_INVALID, "null argument");
     mgx_world::ResidentHalo &xr = w->xres;
     HIP_TRY(hipStreamSynchronize(w->stream));
+    // The area (rank 0's also holds the agreement word) may still be mapped by the peers, whose launches store into it: a layout
+    // change only switches THIS rank's launches off (commit).  It is given back only after a disconnect — which every rank runs
+    // behind a barrier, before any of them sets up again (include/mgx.h; sharded.rewire_resident).
+    if (xr.area && xr.wired)
+        return fail(MGX_ERR_STATE, "mgx_halo_resident_setup: the ghost area of the previous wiring is still connected; call "
+                    "mgx_halo_resident_disconnect on every rank (behind a barrier) first");
     xr.connected = false;
     xr.agree = nullptr;
     w->d.agree = nullptr;
@@ -3580,6 +3608,7 @@ int mgx_halo_resident_connect(mgx_world *w, uint32_t n_targets, const int32_t *r
     d.agree = xr.agree;
     d.n_ranks = xr.n_ranks;
     xr.connected = true;
+    xr.wired = true;
     return MGX_OK;
 }
 
@@ -3588,6 +3617,7 @@ int mgx_halo_resident_disconnect(mgx_world *w) {
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     HIP_TRY(hipStreamSynchronize(w->stream));
     w->xres.connected = false;
+    w->xres.wired = false;
     w->xres.agree = nullptr;
     w->d.agree = nullptr;
     return MGX_OK;

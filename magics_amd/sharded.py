@@ -323,7 +323,7 @@ class ShardedWorld:
                     mapped[q] = self._own_area
                 else:
                     mapped[q] = hostlib.ipc_open(inf["area_handle"])
-                    self._opened.append(mapped[q])
+                    self._opened_areas = getattr(self, "_opened_areas", []) + [mapped[q]]
             return mapped[q]
         robots, area, ngs, slot, par, seg = [], [], [], [], [], []
         for q in range(plan.world_size):
@@ -349,9 +349,17 @@ class ShardedWorld:
         if self.direct:
             self.world.halo_direct_disconnect()
             self.direct = False
-        for ptr in getattr(self, "_opened", []):
+        for ptr in getattr(self, "_opened", []) + getattr(self, "_opened_areas", []):
             hostlib.ipc_close(ptr)
-        self._opened = []
+        self._opened, self._opened_areas = [], []
+
+    def resident_close(self):
+        """The ghost areas only (the direct exchange stays wired).  Call on every rank, after a barrier."""
+        self.world.halo_resident_disconnect()
+        self.resident = False
+        for ptr in getattr(self, "_opened_areas", []):
+            hostlib.ipc_close(ptr)
+        self._opened_areas = []
 
     # -- exchange pieces (a LocalCluster drives them itself) ---------------------------------------
     def pack(self):
@@ -511,6 +519,20 @@ def _connect_resident(sw, comm, all_ok):
         sw.resident = False
     comm.barrier()
     return False
+
+
+def rewire_resident(sw, comm):
+    """Collective: wire the resident launches of a multi-process world again (after a change of some rank's layout switched
+    them off there).  The order matters — a rank's ghost area (rank 0's also holds the agreement word) is stored into by its
+    peers' launches for as long as they hold it mapped: barrier (nobody is inside a launch: every rank has synchronised),
+    disconnect + close the mappings everywhere, barrier, then set up and connect as the first time."""
+    sw.synchronize()
+    comm.barrier()
+    sw.resident_close()
+    comm.barrier()
+    if sw.transport == "direct+resident":
+        sw.transport = "direct"
+    return _connect_resident(sw, comm, lambda ok: all(comm.all_gather_object(bool(ok))))
 
 
 def connect(sw, comm, transport="auto", resident=True):
