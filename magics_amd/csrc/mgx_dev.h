@@ -62,17 +62,26 @@ struct IrSlotRec {
 // EXCHANGE RECORDS of resident schedule launches — the hand-off between neighbouring robots' workgroups (and, on sharded worlds,
 // between GPUs).  What an inter-robot factor F_AB reads of its owner A is the message A's variable sends it: (eta, lam, mu) — of
 // which the factor's arithmetic touches eta, lam and the two position means (interrobot.rs:149-159: the Jacobian has no velocity
-// columns) — and whether that variable has delivered at all (its delivery count).  At the end of a segment every robot publishes,
-// per variable, ONE 256-byte record of sixteen 16-byte chunks; chunk c = { D[3c], D[3c+1], D[3c+2], sequence word } where D[0..47]
-// are the 24 f64 of the snapshot record as (low, high) dword pairs, except D[44] = the variable's delivery count (the low half of
-// mu[2], a velocity mean nobody reads, gives way; D[45..47] ride along unread).  A 16-byte aligned store is one transaction, so a
-// chunk whose sequence word is the expected one carries that publication's payload: consumers POLL THE CHUNKS THEMSELVES — no
-// drain of the producer's stores, no progress word, no dependent second trip (experiments/handoff/records.hip, form B: half the
-// hand-off time of "records, acknowledgements, progress word, then the loads").  Sequence word: bit 31 set (memory that was only
-// ever zeroed never validates) | the low 31 bits of the consumer's count of the segment the record is for; compared for
-// equality.  Two parities of records per variable, written alternately (a producer is never two publications ahead of a
-// consumer: it needs that consumer's record of the segment in between — see wait_for_peers in mgx_sweep.h for the one-sided case).
-constexpr int XREC_CHUNKS = 16, XREC_BYTES = 16 * XREC_CHUNKS, XREC_EPOCH_DWORD = 44;
+// columns) — and whether that variable has delivered at all (its delivery count): 22 f64 and one count, 45 dwords.  At the end of
+// a segment every robot publishes them as FIFTEEN 16-byte chunks per variable; chunk c = { D[3c], D[3c+1], D[3c+2], sequence word }
+// where D[0..43] are the 22 f64 as (low, high) dword pairs and D[44] is the delivery count.  A 16-byte aligned store is one
+// transaction, so a chunk whose sequence word is the expected one carries that publication's payload: consumers POLL THE CHUNKS
+// THEMSELVES — no drain of the producer's stores, no progress word, no dependent second trip (experiments/handoff/records.hip,
+// form B: half the hand-off time of "records, acknowledgements, progress word, then the loads").
+// Layout of a robot's records: CHUNK-MAJOR, [XREC_CHUNKS][K variables][16 bytes].  A connection hangs one factor on each of the
+// variables 1 .. K-1 of its target, so the edge lanes of a consuming workgroup are ordered (owner, variable): consecutive lanes
+// read chunk c of CONSECUTIVE variables of one owner — contiguous 16-byte pieces, each lane its own record, no transposition
+// across lanes — and the publishing wave's stores are one contiguous kilobyte per instruction.
+// Sequence word: bit 31 set (memory that was only ever zeroed never validates) | the low 31 bits of the consumer's count of the
+// segment the record is for; compared for equality.  Two parities of records per robot, written alternately (a producer is
+// never two publications ahead of a consumer: it needs that consumer's record of the segment in between — see wait_for_peers in
+// mgx_sweep.h for the one-sided case).
+#ifdef MGX_XREC_CHECKSUM
+constexpr int XREC_CHUNKS = 16;  // diagnostic build: one more chunk per variable, { xor of the 45 payload dwords, producer's identity, 0 }
+#else
+constexpr int XREC_CHUNKS = 15;
+#endif
+constexpr int XREC_PAYLOAD_DWORDS = 45, XREC_BYTES = 16 * XREC_CHUNKS, XREC_EPOCH_DWORD = 44;  // XREC_BYTES: per variable
 __host__ __device__ constexpr uint32_t xrec_seq(unsigned long long count) { return 0x80000000u | (uint32_t)(count & 0x7fffffffull); }
 
 // Resident schedule launches of a SHARDED world: where the exchange records of a local robot that another rank holds as a ghost
@@ -80,7 +89,7 @@ __host__ __device__ constexpr uint32_t xrec_seq(unsigned long long count) { retu
 // buffer parity; the consumer's progress word for the ghost, and what has to be added to this rank's segment count to speak
 // the consumer's (each rank counts the segments of its own resident launches).
 struct XPushRec {
-    unsigned long long xrec[2];  // [K][XREC_BYTES]
+    unsigned long long xrec[2];  // [XREC_CHUNKS][K][16 bytes]
     unsigned long long flag;     // one u64
     unsigned long long flag_delta;
 };
@@ -162,7 +171,7 @@ struct DevWorld {
     // the reference's one-sided connections), the robots each one exchanges records with (owners of its incoming edges and
     // targets of its outgoing ones, CSR), and two words for a wait that gave up: [0] device-side "stop waiting", [1] a
     // host-mapped copy the host reads
-    unsigned char *xrec[2];           // [R_local * K][XREC_BYTES]
+    unsigned char *xrec[2];           // [R_local][XREC_CHUNKS][K][16 bytes]
     unsigned long long *sweep_flag;   // [R_local]
     const int32_t *peer_ptr;          // [R_local + 1]
     const int32_t *peer_idx;          // device robot indices
@@ -179,7 +188,7 @@ struct DevWorld {
     // device memory that the ghosts' owner ranks store into from inside their launches (peer-mapped: hipIpc across processes):
     // the ghosts' exchange records for the two buffer parities and one progress word per ghost (ghost g = device robot
     // R_local + g), all read here with system-scope loads.  xp_*: the local robots other ranks hold as ghosts.
-    const unsigned char *gxrec[2];    // [NG * K][XREC_BYTES]
+    const unsigned char *gxrec[2];    // [NG][XREC_CHUNKS][K][16 bytes]
     const unsigned long long *gflag;  // [NG]
     const int32_t *xp_ptr;            // [R_local + 1] push targets of each local robot (most have none)
     const XPushRec *xp_rec;

@@ -418,14 +418,27 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     for (int c = 0; c < SNAP_W; c++) pf_rec[c] = 0.0;
     uint8_t pf_gate = 0;
     int pf_dst = 0;
-    if (HAS_IR && tid < ne) pf_gate = w.ir_gate[ie0 + tid];
+    // Which edge an edge lane takes.  The robot's incoming edges sit in the order of its variables' inboxes: variable 1's n_in
+    // edges (one per incoming connection, by owner key), variable 2's, ... (a connection hangs one factor on each of the variables
+    // 1 .. K-1 of its target: ne = n_in (K - 1), edge (variable v, connection c) = (v - 1) n_in + c).  Launch-per-segment kernels
+    // take them as they come, lane q edge q.  Resident launches take them OWNER-MAJOR — lane q = connection q / (K - 1), variable
+    // 1 + q % (K - 1) — so that consecutive lanes read consecutive variables' exchange records of one owner (mgx_dev.h: chunk-major
+    // records, each lane fetches its own, contiguous requests) and both waves hold the same mix of near- and far-horizon factors.
+    const int n_in = (PERSIST && K > 1) ? ne / (K - 1) : 0;
+    auto edge_of_lane = [&](int q) __attribute__((always_inline)) {  // local index of lane q's edge (q < ne)
+        if (!PERSIST) return q;
+        const int c = q / (K - 1);
+        return (q - c * (K - 1)) * n_in + c;
+    };
+    const int my_j = (HAS_IR && tid < ne) ? edge_of_lane(tid) : 0;  // the thread's first edge
+    if (HAS_IR && tid < ne) pf_gate = w.ir_gate[ie0 + my_j];
     if (do_extf && tid < ne) {
-        MGX_EDGE_LOAD(pf_er, &w.ir_rec[ie0 + tid]);
+        MGX_EDGE_LOAD(pf_er, &w.ir_rec[ie0 + my_j]);
         pf_dst = pf_er_dst;
-        ld_soa4(w.ir_bmu, w.NI, ie0 + tid, pf_bmu);
+        ld_soa4(w.ir_bmu, w.NI, ie0 + my_j, pf_bmu);
     }
     if (PERSIST && tid < ne) {  // resident launches: the edge's constants stay in registers for every external iteration
-        MGX_EDGE_LOAD(pf_er, &w.ir_rec[ie0 + tid]);
+        MGX_EDGE_LOAD(pf_er, &w.ir_rec[ie0 + my_j]);
         pf_dst = pf_er_dst;
     }
     // The owners' records of the threads' edges are fetched by QUADS of lanes: for each of its four lanes' records in turn, lane v
@@ -497,7 +510,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     // is output only (a variable whose covariance this launch does not recompute keeps the HBM copy).
     auto chain_second_link = [&]() {
         if (STAGE_IR && tid < ne && !(recompute && pf_gate == 1)) {  // the thread's first staged inter-robot message
-            const size_t e = (size_t)(ie0 + tid);
+            const size_t e = (size_t)(ie0 + my_j);
             r_ir_on = true;
             r_ir[0] = w.ir_fv_eta[0 * (size_t)w.NI + e];
             r_ir[1] = w.ir_fv_eta[1 * (size_t)w.NI + e];
@@ -556,9 +569,10 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         if (STAGE_IR) {
             if (r_ir_on) {
 #pragma unroll
-                for (int c = 0; c < 6; c++) s_ir[tid * IR_STRIDE + c] = r_ir[c];
+                for (int c = 0; c < 6; c++) s_ir[my_j * IR_STRIDE + c] = r_ir[c];
             }
-            for (int j = tid + SWEEP_BLOCK; j < ne; j += SWEEP_BLOCK) {  // robots with more edges than threads
+            for (int q = tid + SWEEP_BLOCK; q < ne; q += SWEEP_BLOCK) {  // robots with more edges than threads
+                const int j = edge_of_lane(q);
                 if (recompute && w.ir_gate[ie0 + j] == 1) continue;
                 const size_t e = (size_t)(ie0 + j);
                 double m[6];
@@ -704,32 +718,29 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     constexpr unsigned GHOST_BIT = 0x80000000u;
     const unsigned gx_bytes = SHARD ? (unsigned)(w.V - VL) * (unsigned)XREC_BYTES : 0u;
     const __amdgpu_buffer_rsrc_t rs_gx = sc1_rsrc(SHARD ? w.gxrec[0] : nullptr, 2u * gx_bytes);
-    // The gather of a resident launch's segments k > 0: the owners' EXCHANGE RECORDS (mgx_dev.h), polled.  As in quad_gather, lane v of a
-    // quad asks for chunks 4 t + v, t = 0..3, of each of its four lanes' records in turn (the four requests of a quad are one
-    // contiguous 64 bytes); a chunk is there when its sequence word is the expected one, and what is not there yet is asked for
-    // again — only that.  When every lane of the wave holds valid chunks, three transpositions per 64 bytes inside the quad hand each
-    // lane the 45 payload dwords of its own record: (eta, lam) and the two position means in `out`, the delivery count in `deliveries`.
-    // ro_mine: byte offset of the lane's record | 1 (a lane without an edge passes 0: record 0 is fetched once, never validated).
-    // A wait that outlasts the bound raises the world's abort word like any other wait of the launch (reported, never a hang).
-    auto quad_gather_records = [&](auto fetch, unsigned ro_mine, uint32_t seq, double (&out)[SNAP_W], uint32_t &deliveries) __attribute__((always_inline)) {
-        v4u32 R[4][4];
-        unsigned rb[4];
-        rb[0] = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0x00, 0xf, 0xf, true);
-        rb[1] = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0x55, 0xf, 0xf, true);
-        rb[2] = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0xAA, 0xf, 0xf, true);
-        rb[3] = (unsigned)__builtin_amdgcn_mov_dpp((int)ro_mine, 0xFF, 0xf, 0xf, true);
-        const unsigned piece = 16u * (unsigned)(lane & 3);
+    // The gather of a resident launch's segments k > 0: the owners' EXCHANGE RECORDS (mgx_dev.h), polled.  Every edge lane asks for
+    // the XREC_CHUNKS chunks of ITS owner variable's record — chunk c of variable i of robot A sits at (A K XREC_CHUNKS + c K + i) 16,
+    // and consecutive lanes hold consecutive variables of one owner, so each load instruction asks for whole runs of (K - 1) x 16
+    // contiguous bytes; a chunk is there when its sequence word is the expected one, and what is not there yet is asked for again —
+    // only that.  The 45 payload dwords need no exchange between lanes: (eta, lam) and the two position means go to `out`, the
+    // delivery count to `deliveries`.  off_mine: byte offset of chunk 0 of the lane's record (top bit: in the ghost area); lanes
+    // without an edge ask for nothing.  A wait that outlasts the bound raises the world's abort word like any other wait of the
+    // launch (reported, never a hang).
+    auto gather_records = [&](auto fetch, bool mine, unsigned off_mine, uint32_t seq, double (&out)[SNAP_W], uint32_t &deliveries) __attribute__((always_inline)) {
+        v4u32 R[XREC_CHUNKS];
+        const unsigned cstride = 16u * (unsigned)K;
 #pragma unroll
-        for (int s4 = 0; s4 < 4; s4++)
+        for (int ch = 0; ch < XREC_CHUNKS; ch++) R[ch] = v4u32{0u, 0u, 0u, 0u};
+        if (mine) {
 #pragma unroll
-            for (int t4 = 0; t4 < 4; t4++) R[s4][t4] = fetch((rb[s4] & ~1u) + 64u * t4 + piece);
+            for (int ch = 0; ch < XREC_CHUNKS; ch++) R[ch] = fetch(off_mine + (unsigned)ch * cstride);
+        }
         long long t0 = 0;
         for (unsigned spins = 0;; spins++) {
             bool missing = false;
 #pragma unroll
-            for (int s4 = 0; s4 < 4; s4++)
-#pragma unroll
-                for (int t4 = 0; t4 < 4; t4++) missing = missing || ((rb[s4] & 1u) && R[s4][t4].w != seq);
+            for (int ch = 0; ch < XREC_CHUNKS; ch++) missing = missing || R[ch].w != seq;
+            missing = missing && mine;
             if (__ballot(missing) == 0ull) break;
             __builtin_amdgcn_s_sleep(2);
             if (spins == 0u) t0 = wall_clock64();
@@ -742,35 +753,27 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 }
                 if (__ballot(stop) != 0ull) break;  // (the launch ends with wrong beliefs; the host reports it)
             }
+            if (missing) {
 #pragma unroll
-            for (int s4 = 0; s4 < 4; s4++)
-#pragma unroll
-                for (int t4 = 0; t4 < 4; t4++)
-                    if ((rb[s4] & 1u) && R[s4][t4].w != seq) R[s4][t4] = fetch((rb[s4] & ~1u) + 64u * t4 + piece);
-        }
-        unsigned D[48];  // the lane's own record, dword by dword
-#pragma unroll
-        for (int t4 = 0; t4 < 4; t4++)
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                unsigned x[4] = {R[0][t4][d], R[1][t4][d], R[2][t4][d], R[3][t4][d]};
-                quad_transpose4(x, lane);
-#pragma unroll
-                for (int v = 0; v < 4; v++) D[3 * (4 * t4 + v) + d] = x[v];
+                for (int ch = 0; ch < XREC_CHUNKS; ch++)
+                    if (R[ch].w != seq) R[ch] = fetch(off_mine + (unsigned)ch * cstride);
             }
+        }
+        auto D = [&](int n) __attribute__((always_inline)) { return R[n / 3][n % 3]; };  // payload dword n
 #pragma unroll
-        for (int n = 0; n < 22; n++) out[n] = __hiloint2double((int)D[2 * n + 1], (int)D[2 * n]);
+        for (int n = 0; n < 22; n++) out[n] = __hiloint2double((int)D(2 * n + 1), (int)D(2 * n));
         out[22] = 0.0;
         out[23] = 0.0;
-        deliveries = D[XREC_EPOCH_DWORD];
+        deliveries = D(XREC_EPOCH_DWORD);
 #ifdef MGX_XREC_CHECKSUM
-        if (ro_mine & 1u) {
+        if (mine) {
             unsigned x = 0u;
 #pragma unroll
-            for (int n = 0; n < 45; n++) x ^= D[n];
-            const unsigned want_id = ((ro_mine & ~0x80000001u) / (unsigned)XREC_BYTES);  // variable index
-            if (x != D[45])
-                __hip_atomic_store(w.sweep_err, 0xBAD0000000000000ull | ((unsigned long long)(D[46] & 0xfffffu) << 28) | ((unsigned long long)(want_id & 0xfffffu) << 8) | (seq & 0xffu),
+            for (int n = 0; n < XREC_PAYLOAD_DWORDS; n++) x ^= D(n);
+            const unsigned o = off_mine & 0x7fffffffu, rob = o / ((unsigned)K * (unsigned)XREC_BYTES);
+            const unsigned want_id = rob * 64u + (o - rob * (unsigned)K * (unsigned)XREC_BYTES) / 16u;  // robot * 64 + variable
+            if (x != R[15].x || R[15].y != want_id)
+                __hip_atomic_store(w.sweep_err, 0xBAD0000000000000ull | ((unsigned long long)(R[15].y & 0xfffffu) << 28) | ((unsigned long long)(want_id & 0xfffffu) << 8) | (seq & 0xffu),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
 #endif
@@ -803,7 +806,8 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             };
             const uint32_t want_seq = xrec_seq(plan.flag_base + (unsigned long long)k);
             for (int j0 = 0; j0 < ne; j0 += SWEEP_BLOCK) {  // rounds of the whole workgroup: every lane takes part in the gather
-                const int j = j0 + tid;
+                const int q = j0 + tid;                                        // edge lane
+                const int j = j0 == 0 ? my_j : (q < ne ? edge_of_lane(q) : 0);  // its edge
                 const int e = ie0 + j;
                 MGX_EDGE_REGS(er);
                 double ao_eta[4], ao_lam[16], a_mu[4], b_mu[4];
@@ -816,7 +820,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     if (j0 == 0) {
                         mine = tid < ne && pf_gate == 1;
                         if (mine) MGX_EDGE_COPY(er, pf_er);
-                    } else if (j < ne && w.ir_gate[e] == 1) {  // robots with more edges than threads
+                    } else if (j0 > 0 && q < ne && w.ir_gate[e] == 1) {  // robots with more edges than threads
                         mine = true;
                         MGX_EDGE_LOAD(er, &w.ir_rec[e]);
                     }
@@ -824,10 +828,10 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                         // published by other workgroups of THIS launch (agent scope) or by other ranks' launches into this rank's
                         // ghost area (system scope): exchange records, polled
                         const bool ghost_src = SHARD && mine && er_src_var >= VL;
-                        const unsigned ro_mine = !mine ? 0u : ghost_src ? ((unsigned)(er_src_var - VL) * (unsigned)XREC_BYTES) | GHOST_BIT | 1u
-                                                                       : ((unsigned)er_src_var * (unsigned)XREC_BYTES) | 1u;
+                        const int sv = mine ? (ghost_src ? er_src_var - VL : er_src_var) : 0, si = sv % K;  // variable si of robot sv / K
+                        const unsigned off_mine = ((unsigned)(sv - si) * (unsigned)XREC_BYTES + 16u * (unsigned)si) | (ghost_src ? GHOST_BIT : 0u);
                         if (j0 == 0) TLSTAMP(k - 1, 2);
-                        quad_gather_records(fetch_xrec, ro_mine, want_seq, grec, grec_deliveries);
+                        gather_records(fetch_xrec, mine, off_mine, want_seq, grec, grec_deliveries);
                         if (j0 == 0) TLSTAMP(k - 1, 3);
                     } else {
                         // written by an earlier launch (segment 0 of a sharded launch reads the ghosts' plain copies, filled by the
@@ -865,7 +869,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #pragma unroll
                     for (int c = 0; c < 4; c++) a_mu[c] = grec[20 + c];
                 } else if (j0 == 0) {  // operands prefetched during staging
-                    if (j >= ne) continue;
+                    if (q >= ne) continue;
                     if (!pf_on) continue;  // the owner did not run its external factor sweep
                     MGX_EDGE_COPY(er, pf_er);
                     a_present = pf_present;
@@ -1496,10 +1500,10 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 if (ir_on && k != last_ext_seg) {
                     have_xmu = true;
                 } else if (ir_on) {  // the launch's last external iteration: the response means go to HBM (robot.rs:1842-1858)
-                    for (int j = tid; j < ne; j += SWEEP_BLOCK) {
-                        const int e = ie0 + j;
+                    for (int q = tid; q < ne; q += SWEEP_BLOCK) {
+                        const int e = ie0 + (q == tid ? my_j : edge_of_lane(q));
                         int dst;
-                        if (j == tid) {
+                        if (q == tid) {
                             if (!pf_gate) continue;
                             dst = pf_dst;
                         } else {
@@ -1535,10 +1539,10 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     have_xmu = true;
                 } else if (ir_on) {  // the launch's last external iteration: the means go to HBM (robot.rs:1842-1858)
                     __syncthreads();
-                    for (int j = tid; j < ne; j += SWEEP_BLOCK) {
-                        const int e = ie0 + j;
+                    for (int q = tid; q < ne; q += SWEEP_BLOCK) {
+                        const int e = ie0 + (q == tid ? my_j : edge_of_lane(q));
                         int dst;
-                        if (j == tid) {
+                        if (q == tid) {
                             if (!pf_gate) continue;
                             dst = pf_dst;
                         } else {
@@ -1590,10 +1594,10 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 // linearisation point; eta / lam of the target side never reach the kept message).
                 // Plain stores of LDS values: nothing in this launch but the storing thread itself reads them
                 // (the means are next written after the barrier that ends the coming factor sweep / by nobody).
-                for (int j = tid; j < ne; j += SWEEP_BLOCK) {
-                    const int e = ie0 + j;
+                for (int q = tid; q < ne; q += SWEEP_BLOCK) {
+                    const int e = ie0 + (q == tid ? my_j : edge_of_lane(q));
                     int dst;
-                    if (j == tid && (do_extf || PERSIST)) {  // gate and constants of the thread's first edge are in registers
+                    if (q == tid && (do_extf || PERSIST)) {  // gate and constants of the thread's first edge are in registers
                         if (!pf_gate) continue;
                         dst = pf_dst;
                     } else {
@@ -1670,36 +1674,35 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 __builtin_amdgcn_wave_barrier();  // the wave's LDS writes (means) precede its LDS reads below
                 TLSTAMP(k, 0);
                 // The robot's EXCHANGE RECORDS (mgx_dev.h) for the external iteration that opens the next segment, into the parity
-                // nobody reads during this segment: lane l stores chunk l % 16 of variables l / 16, l / 16 + 4, .. — three payload
-                // dwords out of two neighbouring f64 of the snapshot image, and the sequence word.  Fire and forget: a chunk
+                // nobody reads during this segment: item t = chunk t / K of variable t % K, at byte 16 t of the robot's block — the
+                // wave's stores are one contiguous kilobyte per instruction, and its LDS reads (three payload dwords out of two
+                // neighbouring f64 rows of the snapshot image) run along the variables, conflict-free.  Fire and forget: a chunk
                 // validates itself, so nothing is drained and no word follows the stores on the consumers' critical path.
                 const int ob = (w.cur + k + 1) & 1;
                 const unsigned long long next_count = plan.flag_base + (unsigned long long)k + 1ull;
-                const int ch = lane & (XREC_CHUNKS - 1), da = (3 * ch) >> 1;
-                auto chunk_of = [&](int i, uint32_t seq) __attribute__((always_inline)) {
-                    const double A = s_snap[da * K + i], B = s_snap[(da + 1) * K + i];
+                auto chunk_of = [&](int t, uint32_t seq) __attribute__((always_inline)) {
+                    const int ch = t / K, i = t - ch * K, da = (3 * ch) >> 1;
                     v4u32 v;
+#ifdef MGX_XREC_CHECKSUM
+                    if (ch == XREC_CHUNKS - 1) {  // the xor of the variable's 45 payload dwords, and who published them
+                        unsigned x = s_epoch[i];
+                        for (int n = 0; n < 22; n++) { const double f = s_snap[n * K + i]; x ^= (unsigned)__double2loint(f) ^ (unsigned)__double2hiint(f); }
+                        v.x = x; v.y = (unsigned)(r * 64 + i); v.z = 0u; v.w = seq;
+                        return v;
+                    }
+#endif
+                    const double A = s_snap[da * K + i], B = s_snap[(da + 1) * K + i];
                     v.x = (ch & 1) ? (unsigned)__double2hiint(A) : (unsigned)__double2loint(A);
                     v.y = (ch & 1) ? (unsigned)__double2loint(B) : (unsigned)__double2hiint(A);
                     v.z = (ch & 1) ? (unsigned)__double2hiint(B) : (unsigned)__double2loint(B);
                     if (3 * ch + 2 == XREC_EPOCH_DWORD) v.z = s_epoch[i];
-#ifdef MGX_XREC_CHECKSUM
-                    {
-                        unsigned x = ch == 15 ? 0u : (v.x ^ v.y ^ v.z);
-                        x ^= (unsigned)__shfl_xor((int)x, 1, 16);
-                        x ^= (unsigned)__shfl_xor((int)x, 2, 16);
-                        x ^= (unsigned)__shfl_xor((int)x, 4, 16);
-                        x ^= (unsigned)__shfl_xor((int)x, 8, 16);
-                        if (ch == 15) { v.x = x; v.y = (unsigned)(r * 64 + i); v.z = 0u; }
-                    }
-#endif
                     v.w = seq;
                     return v;
                 };
                 {
                     const unsigned base = (unsigned)v0 * (unsigned)XREC_BYTES;
                     const uint32_t seq = xrec_seq(next_count);
-                    for (int t = lane; t < XREC_CHUNKS * K; t += 64) st16_agent_raw(rs_x, base + 16u * (unsigned)t, ob ? xrec_bytes : 0u, chunk_of(t >> 4, seq));
+                    for (int t = lane; t < XREC_CHUNKS * K; t += 64) st16_agent_raw(rs_x, base + 16u * (unsigned)t, ob ? xrec_bytes : 0u, chunk_of(t, seq));
                 }
                 QSTAMP(11, qt);
                 TLSTAMP(k, 1);
@@ -1717,7 +1720,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                         const XPushRec xr = w.xp_rec[t];
                         const __amdgpu_buffer_rsrc_t rs_peer = uniform_rsrc(xr.xrec[ob], (unsigned)K * (unsigned)XREC_BYTES);
                         const uint32_t seq = xrec_seq(next_count + xr.flag_delta);
-                        for (int t2 = lane; t2 < XREC_CHUNKS * K; t2 += 64) st16_system_raw(rs_peer, 16u * (unsigned)t2, chunk_of(t2 >> 4, seq));
+                        for (int t2 = lane; t2 < XREC_CHUNKS * K; t2 += 64) st16_system_raw(rs_peer, 16u * (unsigned)t2, chunk_of(t2, seq));
                         if (lane == 0)
                             __hip_atomic_store(reinterpret_cast<unsigned long long *>(xr.flag), next_count + xr.flag_delta, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_SYSTEM);
