@@ -27,6 +27,11 @@
 #define MGX_SET_NAME(base) base##_set2
 #endif
 
+#ifdef MGX_ONLY_K  // diagnostics (an assembly listing of ONE instantiation): -DMGX_ONLY_K=16 with the set that holds it
+#undef MGX_K_LIST
+#define MGX_K_LIST(DO) DO(MGX_ONLY_K)
+#endif
+
 namespace mgx {
 
 size_t sweep_lds_bytes(int K, int ir_edges);

@@ -64,3 +64,27 @@ print("seg  " + "  ".join(f"{k[:-3] if k.endswith('_ns') else k:>32s}" for k in 
 for r in rows:
     print(f"{r['k']:3d}  " + "  ".join(f"{r[k]:32.0f}" for k in keys))
 print("mean " + "  ".join(f"{np.mean([r[k] for r in rows]):32.0f}" for k in keys))
+
+# ---- who paces the lattice: the robots that never wait.  Per robot: mean wait inside the gather, against where it runs and what it computes
+wait = np.array([np.mean([(tl[b, k, 3] - tl[b, k, 2]) for k in range(1, nseg - 1) if tl[b, k, 3] > 0]) * T for b in range(n)])
+own = np.array([np.mean([(tl[b, k, 1] - tl[b, k - 1, 1]) for k in range(2, nseg - 1) if tl[b, k, 1] > 0]) * T for b in range(n)])
+live = tl[:, 15, 0] + tl[:, 15, 1]
+hw = tl[:, 15, 2]
+xcc = (hw >> 32) & 0xf
+cu = (hw >> 8) & 0xf
+sh = (hw >> 12) & 0x1
+se = (hw >> 13) & 0x7
+cu_key = xcc * 1000 + se * 100 + sh * 10 + cu
+per_cu = {k: int((cu_key == k).sum()) for k in np.unique(cu_key)}
+load = np.array([per_cu[k] for k in cu_key])
+deg = np.array([len(x) for x in nb])
+print(f"\nper robot: wait inside the gather {wait.mean():.0f} ns mean, p10 {np.percentile(wait, 10):.0f}, p50 {np.percentile(wait, 50):.0f}, p90 {np.percentile(wait, 90):.0f}; "
+      f"robots that wait < 300 ns: {(wait < 300).sum()}")
+for name, v in (("workgroups on the robot's CU", load), ("incoming connections", deg), ("factors inside the safety distance (both waves, segment 5)", live)):
+    print(f"  by {name}:")
+    for x in np.unique(v):
+        sel = v == x
+        print(f"    {int(x):4d}: {int(sel.sum()):5d} robots, wait {wait[sel].mean():6.0f} ns (p10 {np.percentile(wait[sel], 10):6.0f})")
+print("  CUs by workgroups held:", {c: list(per_cu.values()).count(c) for c in sorted(set(per_cu.values()))}, "XCDs:", {int(x): int((xcc == x).sum()) for x in np.unique(xcc)})
+slow = np.argsort(wait)[:40]
+print("  the 40 robots that wait least: connections", np.bincount(deg[slow]).tolist(), "live factors mean", live[slow].mean(), "vs all", live.mean(), "CU load", np.bincount(load[slow]).tolist())
