@@ -38,6 +38,19 @@ namespace mgx {
 
 constexpr int SWEEP_BLOCK = 128;
 enum { ROLE_DYN = 0, ROLE_UV = 1 };
+// FOUR WAVES PER ROBOT (resident launches, horizons of at most 16 variables; -DMGX_WIDE=1).  What bounds a resident launch is the
+// dependent chain of ONE robot's iteration — gather, inter-robot factors, inbox sums, beliefs, publication — with the factor sweep
+// of the coming internal iteration on the same two waves (measured by delaying single points of the kernel: the whole loop of the
+// UV wave is critical).  With four waves the two chain waves keep the chain (DYN: external variable sweep, UV: internal one + the
+// publication), wave 2 computes the dynamic factors' messages and wave 3 the unary factors' — beside the hand-off, the gather and the
+// inter-robot factors of the chain waves instead of in front of them.
+#ifndef MGX_WIDE
+#define MGX_WIDE 0
+#endif
+template <int KT, bool PERSIST>
+constexpr int sweep_waves() { return (MGX_WIDE && PERSIST && KT > 0 && 4 * KT <= 64) ? 4 : 2; }
+template <int KT, bool PERSIST>
+constexpr int sweep_threads() { return 64 * sweep_waves<KT, PERSIST>(); }
 
 __device__ __forceinline__ void ld_soa4(const double *base, int stride, int item, double (&o)[4]) {
 #pragma unroll
@@ -71,6 +84,16 @@ extern __shared__ double lds[];
 
 // In-kernel cycle stamps exist only in the diagnostic build (never in libmgx.so): they go to a
 // buffer of their own and no output value depends on them.
+// Causal profiling (diagnostic builds only: -DMGX_DELAY_POINT=n [-DMGX_DELAY=16]): a sleep of MGX_DELAY x 64 clocks at ONE point of the
+// resident launch's iteration; how much of it shows up in the iteration's period says how much of the point lies on the critical path.
+#ifdef MGX_DELAY_POINT
+#ifndef MGX_DELAY
+#define MGX_DELAY 16
+#endif
+#define DELAY_AT(n, cond) do { if (MGX_DELAY_POINT == (n) && (cond)) __builtin_amdgcn_s_sleep(MGX_DELAY); } while (0)
+#else
+#define DELAY_AT(n, cond)
+#endif
 #ifdef MGX_STAMPS
 #define STAMP(var) unsigned long long var = __builtin_readcyclecounter()
 #define STAMP_ADD(acc, a, b) acc += (b) - (a)
@@ -112,10 +135,10 @@ __device__ __forceinline__ int xcd_local_index(int block, int n) {
 }
 
 // straight copies between a robot's blob in HBM and its LDS image, 16 bytes per lane
-__device__ __forceinline__ void copy_words(double *dst, const double *src, int n, int tid) {
+__device__ __forceinline__ void copy_words(double *dst, const double *src, int n, int tid, int nt = SWEEP_BLOCK) {
     const double2 *s2 = reinterpret_cast<const double2 *>(src);
     double2 *d2 = reinterpret_cast<double2 *>(dst);
-    for (int t = tid; t < (n >> 1); t += SWEEP_BLOCK) d2[t] = s2[t];
+    for (int t = tid; t < (n >> 1); t += nt) d2[t] = s2[t];
     if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
 }
 
@@ -123,16 +146,16 @@ __device__ __forceinline__ void copy_words(double *dst, const double *src, int n
 // waits for each 16 bytes before asking for the next costs one memory round trip per iteration, and
 // staging is a handful of such loops.  N (f64 words) is a compile-time constant: the loops unroll into
 // independent loads held in registers.
-template <int N>
+template <int N, int NT = SWEEP_BLOCK>
 struct StageRegs {
-    static constexpr int N2 = N / 2, ITERS = (N2 + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+    static constexpr int N2 = N / 2, ITERS = (N2 + NT - 1) / NT;
     double2 v[ITERS];
     double last;
     __device__ __forceinline__ void load(const double *src, int tid) {
         const double2 *s2 = reinterpret_cast<const double2 *>(src);
 #pragma unroll
         for (int it = 0; it < ITERS; it++) {
-            const int t = tid + it * SWEEP_BLOCK;
+            const int t = tid + it * NT;
             v[it] = (t < N2) ? s2[t] : make_double2(0.0, 0.0);
         }
         last = ((N & 1) && tid == 0) ? src[N - 1] : 0.0;
@@ -141,7 +164,7 @@ struct StageRegs {
         double2 *d2 = reinterpret_cast<double2 *>(dst);
 #pragma unroll
         for (int it = 0; it < ITERS; it++) {
-            const int t = tid + it * SWEEP_BLOCK;
+            const int t = tid + it * NT;
             if (t < N2) d2[t] = v[it];
         }
         if ((N & 1) && tid == 0) dst[N - 1] = last;
@@ -248,12 +271,24 @@ __device__ __forceinline__ void quad_transpose4(unsigned (&x)[4], int lane) {
 // SHARD (resident launches of a sharded world): the snapshot records of ghost robots arrive INSIDE the launch — their owners'
 // ranks store them into this rank's peer-mapped ghost area and this rank's boundary robots store theirs into the peers'.
 template <int KT, int IRM, bool PERSIST, bool SHARD = false>
-__global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int robot0, uint32_t ext_mask, uint32_t int_mask,
+__global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_sweep(DevWorld w, int robot0, uint32_t ext_mask, uint32_t int_mask,
                                                              int n_int, int snap_out, uint32_t hints, const SegPlan plan) {
     constexpr bool HAS_IR = IRM != IR_NONE, STAGE_IR = IRM == IR_STAGED;
+    constexpr int NW = sweep_waves<KT, PERSIST>(), NT = 64 * NW;  // waves / threads of a workgroup
+    constexpr int ROLE_DF = NW == 4 ? 2 : ROLE_DYN, ROLE_UF = NW == 4 ? 3 : ROLE_UV;  // who computes the dynamic / the unary factors' messages
     static_assert(!PERSIST || IRM == IR_STAGED, "resident schedule launches exist for worlds with staged inter-robot messages");
     static_assert(!SHARD || PERSIST, "ghost records arrive in-launch only in resident schedule launches");
     const int nseg = PERSIST ? plan.n : 1;
+    // The plan's per-segment bytes, read as DWORDS of the kernel's arguments: a byte indexed by the segment counter is fetched by a
+    // VECTOR load, and the wait for a vector load waits for every write-through store the wave has in flight as well (one counter) —
+    // `plan.n_int[k + 1]` right behind the publication made the publishing wave sit out the drain of its own stores.
+    static_assert(MAX_SEGS % 4 == 0 && offsetof(SegPlan, ext) % 4 == 0 && offsetof(SegPlan, n_int) % 4 == 0, "SegPlan bytes are read as dwords");
+    auto plan_ext = [&](int k) __attribute__((always_inline)) {
+        return (reinterpret_cast<const uint32_t *>(plan.ext)[k >> 2] >> (8 * (k & 3))) & 0xffu;
+    };
+    auto plan_n_int = [&](int k) __attribute__((always_inline)) {
+        return (int)((reinterpret_cast<const uint32_t *>(plan.n_int)[k >> 2] >> (8 * (k & 3))) & 0xffu);
+    };
     // KT > 0: horizon length fixed at compile time; 0: read from the world (K <= 33); -1: read from the world, any K.
     // BIG: more than 64 dynamic-factor messages / tracking factors per robot (K > 33): some lanes carry two.
     constexpr bool BIG = KT < 0 || KT > 33;
@@ -274,7 +309,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         bool signed_in = false;
         for (;;) {
             int missing = 0;
-            for (unsigned b2 = threadIdx.x; b2 < gridDim.x; b2 += SWEEP_BLOCK)
+            for (unsigned b2 = threadIdx.x; b2 < gridDim.x; b2 += NT)
                 missing |= __hip_atomic_load(&w.census[b2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq ? 1 : 0;
             const bool all = __syncthreads_or(missing) == 0;
             int done = 0;
@@ -345,9 +380,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     int itf = w.iter_factor[r];  // iteration_count.factor (every lane applies the same increments)
 
     // ---- roles ------------------------------------------------------------------------------------
-    const bool is_dyn = role == ROLE_DYN && lane < n_dyn;
-    const bool is_obs = role == ROLE_UV && lane < K - 2;
-    const bool is_trk = role == ROLE_UV && lane >= K - 2 && lane < 2 * (K - 2);
+    const bool is_dyn = role == ROLE_DF && lane < n_dyn;
+    const bool is_obs = role == ROLE_UF && lane < K - 2;
+    const bool is_trk = role == ROLE_UF && lane >= K - 2 && lane < 2 * (K - 2);
     const bool is_var = role == ROLE_UV && lane < K;
     // Horizons of at most 16 variables: the belief finish runs on FOUR lanes per variable (lane (q, i) computes cofactor row q of
     // variable i, variable_finish_quad), and in resident launches the whole variable sweep — inbox sums and finish — stays on the
@@ -355,13 +390,13 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     constexpr bool QUADFIN = KT > 0 && 4 * KT <= 64;
     constexpr bool FUSED = PERSIST && QUADFIN;
     const int sum_t = FUSED ? (role == ROLE_UV ? lane : 4 * K) : tid;        // (variable, row) this thread sums: t = rr * K + i
-    const int sum_step = FUSED ? 4 * K : SWEEP_BLOCK;
+    const int sum_step = FUSED ? 4 * K : NT;
     // which variable sweep of this launch is the robot's last one (its belief goes out)
-    bool plan_int = false, plan_ext = false;  // PERSIST: some segment has internal iterations / an external iteration
+    bool plan_int = false, plan_has_ext = false;  // PERSIST: some segment has internal iterations / an external iteration
     if (PERSIST)
-        for (int k = 0; k < nseg; k++) { plan_int = plan_int || plan.n_int[k] > 0; plan_ext = plan_ext || plan.ext[k] != 0; }
+        for (int k = 0; k < nseg; k++) { plan_int = plan_int || plan_n_int(k) > 0; plan_has_ext = plan_has_ext || plan_ext(k) != 0; }
     const bool has_int_var = PERSIST ? (plan_int && !idle) : ((int_mask & PH_INT_VARIABLE) && n_int > 0 && !idle);
-    const bool any_sweep = has_int_var || ((PERSIST ? plan_ext : (ext_mask & PH_EXT_VARIABLE) != 0) && radio);
+    const bool any_sweep = has_int_var || ((PERSIST ? plan_has_ext : (ext_mask & PH_EXT_VARIABLE) != 0) && radio);
     // a later launch of the same call rewrites this robot's belief image: this one's copy is never read
     const bool bel_dead = ((hints & HINT_LATER_EXT_VARIABLE) && radio) || ((hints & HINT_LATER_INT_VARIABLE) && !idle);
 
@@ -496,10 +531,10 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     if (w.upd) {
 #pragma unroll
         for (int c = 0; c < 4; c++) u_rec[c] = w.upd[(size_t)r * 4 + c];
-        if (lane < 20) u_bel = blob[L.bel() + lane * K + (role == 0 ? K - 1 : 0)];
+        if (lane < 20 && role < 2) u_bel = blob[L.bel() + lane * K + (role == 0 ? K - 1 : 0)];
     }
     // messages that this launch's external factor sweep recomputes before anyone reads them are not fetched
-    const bool recompute = (PERSIST ? plan.ext[0] != 0 : (ext_mask & PH_EXT_FACTOR) != 0) && radio && ir_on;
+    const bool recompute = (PERSIST ? plan_ext(0) != 0 : (ext_mask & PH_EXT_FACTOR) != 0) && radio && ir_on;
     double r_ir[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     bool r_ir_on = false;
 
@@ -529,15 +564,15 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     {
         const double *src = w.snap[w.cur] + (size_t)v0 * SNAP_W;
         if constexpr (KT > 0) {
-            StageRegs<20 * KT> r_prior;
-            StageRegs<BlobLayout(KT).inout_words() - 16 * KT> r_io;
-            constexpr int IT = (SNAP_W * KT + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+            StageRegs<20 * KT, NT> r_prior;
+            StageRegs<BlobLayout(KT).inout_words() - 16 * KT, NT> r_io;
+            constexpr int IT = (SNAP_W * KT + NT - 1) / NT;
             double r_snap[IT];
             r_prior.load(blob + L.prior(), tid);
             r_io.load(blob + L.mu(), tid);
 #pragma unroll
             for (int it = 0; it < IT; it++) {
-                const int t = tid + it * SWEEP_BLOCK;
+                const int t = tid + it * NT;
                 r_snap[it] = (t < SNAP_W * K) ? src[t] : 0.0;
             }
             chain_second_link();
@@ -546,17 +581,17 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             r_io.store(s_mu, tid);
 #pragma unroll
             for (int it = 0; it < IT; it++) {
-                const int t = tid + it * SWEEP_BLOCK;
+                const int t = tid + it * NT;
                 if (t < SNAP_W * K) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = r_snap[it];
             }
         } else {
-            copy_words(s_prior, blob + L.prior(), 20 * K, tid);
+            copy_words(s_prior, blob + L.prior(), 20 * K, tid, NT);
             chain_second_link();
             if (census && BIG && tid == 0) early_decision = __hip_atomic_load(w.decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            copy_words(s_mu, blob + L.mu(), L.inout_words() - 16 * K, tid);
-            for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = src[t];
+            copy_words(s_mu, blob + L.mu(), L.inout_words() - 16 * K, tid, NT);
+            for (int t = tid; t < SNAP_W * K; t += NT) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = src[t];
         }
-        for (int t = tid; t < K; t += SWEEP_BLOCK) s_covset[t] = 0;
+        for (int t = tid; t < K; t += NT) s_covset[t] = 0;
         if (STAGE_IR && tid < IR_STRIDE) s_ir[ne * IR_STRIDE + tid] = 0.0;  // the all-zero message behind the last edge
         if (tid < K) {
             s_epoch[tid] = r_epoch;
@@ -571,7 +606,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #pragma unroll
                 for (int c = 0; c < 6; c++) s_ir[my_j * IR_STRIDE + c] = r_ir[c];
             }
-            for (int q = tid + SWEEP_BLOCK; q < ne; q += SWEEP_BLOCK) {  // robots with more edges than threads
+            for (int q = tid + NT; q < ne; q += NT) {  // robots with more edges than threads
                 const int j = edge_of_lane(q);
                 if (recompute && w.ir_gate[ie0 + j] == 1) continue;
                 const size_t e = (size_t)(ie0 + j);
@@ -634,7 +669,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     if (w.upd) {
         const uint32_t what = (uint32_t)u_rec[3];
         const int i = role == 0 ? K - 1 : 0;
-        if (role == 0 ? (what & 1u) : (what & 2u)) {
+        if (role < 2 && (role == 0 ? (what & 1u) : (what & 2u))) {
             double m[4];
             if (role == 0) {
                 const double ex = s_mu[0 * K + i], ey = s_mu[1 * K + i];         // estimated position (:2242)
@@ -698,7 +733,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         __syncthreads();
     }
     if (PERSIST) {  // columns no sweep recomputes (disabled kinds, tracking in front of its gate) must be equal in both
-        for (int t = tid; t < 20 * E1; t += SWEEP_BLOCK) s_sh[t] = s_fv[t];
+        for (int t = tid; t < 20 * E1; t += NT) s_sh[t] = s_fv[t];
         __syncthreads();
     }
     uint32_t my_epoch = (sum_t < 4 * K) ? s_epoch[sum_t % K] : 0u;  // deliveries of the variable this thread sums
@@ -811,7 +846,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 return ld16_agent_raw(rs_x, off, buf ? xrec_bytes : 0u);
             };
             const uint32_t want_seq = xrec_seq(plan.flag_base + (unsigned long long)k);
-            for (int j0 = 0; j0 < ne; j0 += SWEEP_BLOCK) {  // rounds of the whole workgroup: every lane takes part in the gather
+            for (int j0 = 0; j0 < ne; j0 += NT) {  // rounds of the whole workgroup: every lane takes part in the gather
                 const int q = j0 + tid;                                        // edge lane
                 const int j = j0 == 0 ? my_j : (q < ne ? edge_of_lane(q) : 0);  // its edge
                 const int e = ie0 + j;
@@ -839,6 +874,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                         if (j0 == 0) TLSTAMP(k - 1, 2);
                         gather_records(fetch_xrec, mine, off_mine, want_seq, grec, grec_deliveries);
                         if (j0 == 0) TLSTAMP(k - 1, 3);
+                        DELAY_AT(4, j0 == 0);
+                        DELAY_AT(6, j0 == 0 && role == ROLE_UV);
+                        DELAY_AT(7, j0 == 0 && role == ROLE_DYN);
                     } else {
                         // written by an earlier launch (segment 0 of a sharded launch reads the ghosts' plain copies, filled by the
                         // exchange in front of the launch)
@@ -918,7 +956,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     for (int c = 0; c < 6; c++) o6[c] = 0.0;
                 }
 #ifdef MGX_STAMPS
-                if (tl && k == 5 && j0 == 0) {  // who runs where, and how many of the wave's factors are inside their safety distance
+                if (tl && k == 5 && j0 == 0 && role < 2) {  // who runs where, and how many of the wave's factors are inside their safety distance
                     const unsigned long long lv = __ballot(live_msg);
                     if (lane == __ffsll((unsigned long long)__ballot(true)) - 1) {
                         tl[60 + role] = (unsigned long long)__popcll(lv);
@@ -965,7 +1003,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     auto variable_sums_from = [&](int t_first, int t_step, double *s_out, bool internal, bool last) __attribute__((always_inline)) {
         for (int t = t_first; t < 4 * K; t += t_step) {
             const int rr = t / K, i = t - rr * K;  // consecutive lanes -> consecutive variables: conflict-free LDS rows
-            uint32_t epoch_reg = (4 * K <= SWEEP_BLOCK) ? my_epoch : s_epoch[i];
+            uint32_t epoch_reg = (4 * K <= NT) ? my_epoch : s_epoch[i];
             const int es[4] = {(i >= 1) ? (K - 1) + (i - 1) : ZCOL, (i <= K - 2) ? i : ZCOL,
                                (i >= 1 && i <= K - 2) ? n_dyn + (i - 1) : ZCOL,
                                (i >= 1 && i <= K - 2) ? n_dyn + (K - 2) + (i - 1) : ZCOL};
@@ -1045,7 +1083,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             for (int c = 0; c < 4; c++) s_out[(4 + rr * 4 + c) * K + i] = acc[1 + c];
             if (internal && rr == 0) {
                 s_epoch[i] = ++epoch_reg;  // register copy when each thread owns one (variable, row)
-                if (4 * K <= SWEEP_BLOCK) my_epoch = epoch_reg;
+                if (4 * K <= NT) my_epoch = epoch_reg;
             }
             if (last && s_out != s_prior) {  // the prior is not needed again in this launch: its LDS image
                                              // carries the belief (eta, lam) to the write-back
@@ -1240,7 +1278,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     auto unary_messages = [&](uint32_t skip, double *s_out, int itf_gate) __attribute__((always_inline)) {
         if (obs_rows) {
             // four lanes per obstacle factor: lane q samples tap q and writes row q of the message
-            if (role == ROLE_UV && lane < 4 * (K - 2) && (w.enable & 4u) && !(skip & 4u)) {
+            if (role == ROLE_UF && lane < 4 * (K - 2) && (w.enable & 4u) && !(skip & 4u)) {
                 const int j = lane >> 2, q = lane & 3, var = j + 1, col = n_dyn + j;
                 double x0[4];
                 const bool pres = s_epoch[var] > 0;
@@ -1292,7 +1330,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         }
         // horizons beyond 33 variables: tracking factors K-2+64 .. 2(K-2)-1 have no lane of their own; lanes
         // 0 .. of the UV wave take them on, with their state in HBM (BIG instantiations only)
-        if (BIG && role == ROLE_UV && lane + 64 >= K - 2 && lane + 64 < 2 * (K - 2) && (w.enable & 8u) && itf_gate >= 10 &&
+        if (BIG && role == ROLE_UF && lane + 64 >= K - 2 && lane + 64 < 2 * (K - 2) && (w.enable & 8u) && itf_gate >= 10 &&
             !(skip & 8u)) {
             const int j2 = lane + 64 - (K - 2), var2 = j2 + 1, col2 = n_dyn + (K - 2) + j2, item2 = r * (K - 2) + j2;
             double x0[4], oe[4], ol[16];
@@ -1396,8 +1434,8 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     int last_int_seg = -1, last_ext_seg = -1;  // PERSIST: last segment with internal iterations / an external iteration
     if (PERSIST)
         for (int k = 0; k < nseg; k++) {
-            if (plan.n_int[k] > 0) last_int_seg = k;
-            if (plan.ext[k]) last_ext_seg = k;
+            if (plan_n_int(k) > 0) last_int_seg = k;
+            if (plan_ext(k)) last_ext_seg = k;
         }
 #ifdef MGX_STAMPS
     unsigned long long c_f = 0, c_fb = 0, c_v = 0, c_vb = 0, t_extf = t_staged, t_extv = t_staged, t_loop0 = t_staged;
@@ -1417,9 +1455,9 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         // address and predicate of the loop body in front of the loop and then spills them around the f64 blocks (64 spilled
         // VGPRs, 244 B of scratch per lane at K = 16); recomputing them per segment is a handful of integer instructions.
         if (PERSIST) asm volatile("" : "+v"(tid), "+v"(lane));
-        const uint32_t ext_k = PERSIST ? (plan.ext[k] ? (PH_EXT_FACTOR | PH_EXT_VARIABLE) : 0u) : ext_mask;
+        const uint32_t ext_k = PERSIST ? (plan_ext(k) ? (PH_EXT_FACTOR | PH_EXT_VARIABLE) : 0u) : ext_mask;
         const uint32_t int_k = PERSIST ? (PH_INT_FACTOR | PH_INT_VARIABLE) : int_mask;
-        const int n_int_k = PERSIST ? (int)plan.n_int[k] : n_int;
+        const int n_int_k = PERSIST ? plan_n_int(k) : n_int;
         const bool last_seg = k == nseg - 1;
         // ======================= external factor sweep ============================================
         PSTAMP(ps0);
@@ -1475,7 +1513,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     QSTAMP(4, qt);
                     if (lane < 4 * K) quad_core(s_snap, s_cov, ok_i, fin_i, mu_i);
                 } else {
-                    if (lane < 4 * K) {
+                    if (role == ROLE_DYN && lane < 4 * K) {
                         variable_sums_from(lane, 4 * K, s_tmp, false, false);
                         QSTAMP(4, qt);
                         double mu_x = s_mu[q * K + i];  // the state before this segment: the UV wave stores after the barrier
@@ -1491,6 +1529,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 QSTAMP(6, qt);
                 __syncthreads();
                 QSTAMP(7, qt);
+                DELAY_AT(5, true);
                 if (role == ROLE_UV && lane < 4 * K) {
                     double mu_fin = mu_i;
                     const int xs = s_xok[i];
@@ -1521,7 +1560,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 if (ir_on && k != last_ext_seg) {
                     have_xmu = true;
                 } else if (ir_on) {  // the launch's last external iteration: the response means go to HBM (robot.rs:1842-1858)
-                    for (int q = tid; q < ne; q += SWEEP_BLOCK) {
+                    for (int q = tid; q < ne; q += NT) {
                         const int e = ie0 + (q == tid ? my_j : edge_of_lane(q));
                         int dst;
                         if (q == tid) {
@@ -1551,16 +1590,17 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                     // the response means stay in LDS for the next segment's factor sweep (same wave: these writes follow the
                     // finish's reads of the eta sums they overwrite)
                     if (keep_means && lane < 4 * K) s_xmu[lane] = s_mu[lane] - 0.0;
-                    if (prefired) unary_messages(0u, s_sh, itf);
-                } else if (prefired && is_dyn && (w.enable & 1u)) {
-                    dynamic_messages(s_sh);
                 }
+                // (the unary factors linearise at the means of the last INTERNAL sweep, which this external one does not touch:
+                // with four waves they run beside it)
+                if (prefired && (NW == 4 || role == ROLE_UV)) unary_messages(0u, s_sh, itf);
+                if (prefired && is_dyn && (w.enable & 1u)) dynamic_messages(s_sh);
                 QSTAMP(6, qt);
                 if (keep_means) {
                     have_xmu = true;
                 } else if (ir_on) {  // the launch's last external iteration: the means go to HBM (robot.rs:1842-1858)
                     __syncthreads();
-                    for (int q = tid; q < ne; q += SWEEP_BLOCK) {
+                    for (int q = tid; q < ne; q += NT) {
                         const int e = ie0 + (q == tid ? my_j : edge_of_lane(q));
                         int dst;
                         if (q == tid) {
@@ -1615,7 +1655,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 // linearisation point; eta / lam of the target side never reach the kept message).
                 // Plain stores of LDS values: nothing in this launch but the storing thread itself reads them
                 // (the means are next written after the barrier that ends the coming factor sweep / by nobody).
-                for (int q = tid; q < ne; q += SWEEP_BLOCK) {
+                for (int q = tid; q < ne; q += NT) {
                     const int e = ie0 + (q == tid ? my_j : edge_of_lane(q));
                     int dst;
                     if (q == tid && (do_extf || PERSIST)) {  // gate and constants of the thread's first edge are in registers
@@ -1638,7 +1678,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
 #endif
         // ======================= internal iterations ==============================================
         if (PERSIST && !FUSED && early && !((ext_k & PH_EXT_VARIABLE) && radio)) {  // no external variable sweep ran: adopt here
-            adopt_early(tid, SWEEP_BLOCK);
+            adopt_early(tid, NT);
             __syncthreads();
         }
         if (PERSIST && early) prefired = true;
@@ -1652,7 +1692,10 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
                 if (is_dyn && (w.enable & 1u) && !(it == 0 && (skip0 & 1u))) dynamic_messages(s_fv);
                 // UV wave: first the belief of the previous sweep (mean, covariance) that the unary
                 // factors linearise at — same wave, so its LDS writes precede their LDS reads
-                if (pending) finish(s_snap, true);
+                if (pending) {
+                    finish(s_snap, true);
+                    if (NW == 4) __syncthreads();  // four waves: the unary factors' wave reads the means the UV wave has just completed
+                }
                 pending = false;
                 unary_messages(it == 0 ? skip0 : 0u, s_fv, itf);
                 itf += 1;
@@ -1682,50 +1725,55 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             if (census_says_abort(v)) return;
         }
         // ======================= end of a segment of a resident schedule launch ====================
-        // The snapshot records of this robot (what its variables last sent to their own factors: all that another
-        // robot's inter-robot factors read) go out for the external iteration that opens the next segment: into the
-        // buffer nobody reads during this segment, write-through, every wave drained, then the progress word.
+        // What this robot's variables last sent to their own factors — all that another robot's inter-robot factors read — goes out
+        // for the external iteration that opens the next segment (exchange records, below).
         PSTAMP(ps4);
-        // ONE wave does all of it (the one that completes the means), so it may signal for itself after its own drain.
         if (PERSIST && !last_seg) {
             QSTAMP(9, qt);
+            if (role == ROLE_UV && pending) finish(s_snap, true);
+            // four waves: the means are complete (here, or in the merge of the side-by-side sweeps above) — the unary factors' wave
+            // goes on to the sweep computed ahead, the dynamic factors' wave with it, the chain waves to publication and gather
+            if (NW == 4) __syncthreads();
+            // The robot's EXCHANGE RECORDS (mgx_dev.h) for the external iteration that opens the next segment, into the parity nobody
+            // reads during this segment: item t = chunk t / K of variable t % K, at byte 16 t of the robot's block — a wave's stores are
+            // one contiguous kilobyte per instruction, and its LDS reads (three payload dwords out of two neighbouring f64 rows of the
+            // snapshot image) run along the variables, conflict-free.  Fire and forget: a chunk validates itself, so nothing is drained
+            // and no word follows the stores on the consumers' critical path.  (The (eta, lam) chunks 0 .. 12 are final before the
+            // means and could go out from the other wave meanwhile: measured 2.5 % SLOWER on the two-wave kernel, where that wave's
+            // factor sweep is as long as this one's publication and unary sweep together — experiments/README.md.)
+            const int ob = (w.cur + k + 1) & 1;
+            const unsigned long long next_count = plan.flag_base + (unsigned long long)k + 1ull;
+            auto chunk_of = [&](int t, uint32_t seq) __attribute__((always_inline)) {
+                const int ch = t / K, i = t - ch * K, da = (3 * ch) >> 1;
+                v4u32 v;
+#ifdef MGX_XREC_CHECKSUM
+                if (ch == XREC_CHUNKS - 1) {  // the xor of the variable's 45 payload dwords, and who published them
+                    unsigned x = s_epoch[i];
+                    for (int n = 0; n < 22; n++) { const double f = s_snap[n * K + i]; x ^= (unsigned)__double2loint(f) ^ (unsigned)__double2hiint(f); }
+                    v.x = x; v.y = (unsigned)(r * 64 + i); v.z = 0u; v.w = seq;
+                    return v;
+                }
+#endif
+                const double A = s_snap[da * K + i], B = s_snap[(da + 1) * K + i];
+                v.x = (ch & 1) ? (unsigned)__double2hiint(A) : (unsigned)__double2loint(A);
+                v.y = (ch & 1) ? (unsigned)__double2loint(B) : (unsigned)__double2hiint(A);
+                v.z = (ch & 1) ? (unsigned)__double2hiint(B) : (unsigned)__double2loint(B);
+                if (3 * ch + 2 == XREC_EPOCH_DWORD) v.z = s_epoch[i];
+                v.w = seq;
+                return v;
+            };
+            const unsigned xbase = (unsigned)v0 * (unsigned)XREC_BYTES;
             if (role == ROLE_UV) {
-                if (pending) finish(s_snap, true);
                 QSTAMP(10, qt);
                 __builtin_amdgcn_wave_barrier();  // the wave's LDS writes (means) precede its LDS reads below
+                DELAY_AT(1, true);
                 TLSTAMP(k, 0);
-                // The robot's EXCHANGE RECORDS (mgx_dev.h) for the external iteration that opens the next segment, into the parity
-                // nobody reads during this segment: item t = chunk t / K of variable t % K, at byte 16 t of the robot's block — the
-                // wave's stores are one contiguous kilobyte per instruction, and its LDS reads (three payload dwords out of two
-                // neighbouring f64 rows of the snapshot image) run along the variables, conflict-free.  Fire and forget: a chunk
-                // validates itself, so nothing is drained and no word follows the stores on the consumers' critical path.
-                const int ob = (w.cur + k + 1) & 1;
-                const unsigned long long next_count = plan.flag_base + (unsigned long long)k + 1ull;
-                auto chunk_of = [&](int t, uint32_t seq) __attribute__((always_inline)) {
-                    const int ch = t / K, i = t - ch * K, da = (3 * ch) >> 1;
-                    v4u32 v;
-#ifdef MGX_XREC_CHECKSUM
-                    if (ch == XREC_CHUNKS - 1) {  // the xor of the variable's 45 payload dwords, and who published them
-                        unsigned x = s_epoch[i];
-                        for (int n = 0; n < 22; n++) { const double f = s_snap[n * K + i]; x ^= (unsigned)__double2loint(f) ^ (unsigned)__double2hiint(f); }
-                        v.x = x; v.y = (unsigned)(r * 64 + i); v.z = 0u; v.w = seq;
-                        return v;
-                    }
-#endif
-                    const double A = s_snap[da * K + i], B = s_snap[(da + 1) * K + i];
-                    v.x = (ch & 1) ? (unsigned)__double2hiint(A) : (unsigned)__double2loint(A);
-                    v.y = (ch & 1) ? (unsigned)__double2loint(B) : (unsigned)__double2hiint(A);
-                    v.z = (ch & 1) ? (unsigned)__double2hiint(B) : (unsigned)__double2loint(B);
-                    if (3 * ch + 2 == XREC_EPOCH_DWORD) v.z = s_epoch[i];
-                    v.w = seq;
-                    return v;
-                };
                 {
-                    const unsigned base = (unsigned)v0 * (unsigned)XREC_BYTES;
                     const uint32_t seq = xrec_seq(next_count);
-                    for (int t = lane; t < XREC_CHUNKS * K; t += 64) st16_agent_raw(rs_x, base + 16u * (unsigned)t, ob ? xrec_bytes : 0u, chunk_of(t, seq));
+                    for (int t = lane; t < XREC_CHUNKS * K; t += 64) st16_agent_raw(rs_x, xbase + 16u * (unsigned)t, ob ? xrec_bytes : 0u, chunk_of(t, seq));
                 }
                 QSTAMP(11, qt);
+                DELAY_AT(2, true);
                 TLSTAMP(k, 1);
                 // "through with segment k's gather": for the one-sided readers' sake only (wait_for_peers)
                 if (lane == 0) __hip_atomic_store(&w.sweep_flag[r], next_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1752,10 +1800,11 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
             // the factor sweep that opens the next segment's internal iterations, while the records travel: the DYN wave
             // starts at once (a dynamic factor reads no mean), the UV wave after its publish.  The tracking factors' gate
             // (factorgraph.rs:701) counts the external factor sweep that the reference runs in between.
-            early = plan.n_int[k + 1] > 0 && !idle && skip0 == 0u;
+            early = plan_n_int(k + 1) > 0 && !idle && skip0 == 0u;
+            DELAY_AT(3, role == ROLE_DYN);
             if (early) {
                 if (is_dyn && (w.enable & 1u)) dynamic_messages(s_sh);
-                unary_messages(0u, s_sh, itf + ((plan.ext[k + 1] && radio) ? 1 : 0));
+                unary_messages(0u, s_sh, itf + ((plan_ext(k + 1) && radio) ? 1 : 0));
             }
             QSTAMP(13, qt);
         }
@@ -1772,13 +1821,13 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
         // (eta, lam) image, three quarters of the robot's output.
         if (role == ROLE_UV) {
             if (pending) finish(s_snap, true);
-        } else {
+        } else if (role == ROLE_DYN) {
             copy_words_wave(blob + L.fv(), s_fv, 20 * E1, lane);
             if (any_sweep && !bel_dead) copy_words_wave(blob + L.bel(), s_prior, 20 * K, lane);
         }
         __syncthreads();
 #ifdef MGX_STAMPS
-        if (w.dbg && lane == 0) {  // per wave: cycles in factor phase, its barrier, variable phase, its barrier
+        if (w.dbg && lane == 0 && role < 2) {  // per wave: cycles in factor phase, its barrier, variable phase, its barrier
             unsigned long long *d = w.dbg + ((size_t)blockIdx.x * 2 + role) * 8;
             d[0] = c_f; d[1] = c_fb; d[2] = c_v; d[3] = c_vb; d[4] = __builtin_readcyclecounter() - t_loop0;
             d[5] = __builtin_amdgcn_s_memrealtime() - rt0;  // 100 MHz ticks over the same span
@@ -1804,14 +1853,14 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     }
 
     // ---- write back: straight copies of the LDS images ----------------------------------------------
-    for (int t = tid; t < 16 * K; t += SWEEP_BLOCK)  // covariance of the variables that recomputed it
+    for (int t = tid; t < 16 * K; t += NT)  // covariance of the variables that recomputed it
         if (s_covset[t % K]) blob[L.cov() + t] = s_cov[t];
-    copy_words(blob + L.mu(), s_mu, 4 * K, tid);
-    copy_words(blob + L.valid(), (const double *)s_valid, K, tid);
+    copy_words(blob + L.mu(), s_mu, 4 * K, tid, NT);
+    copy_words(blob + L.valid(), (const double *)s_valid, K, tid, NT);
     if (snap_out >= 0) {
         double *dst = w.snap[snap_out] + (size_t)v0 * SNAP_W;
-        for (int t = tid; t < SNAP_W * K; t += SWEEP_BLOCK) dst[t] = s_snap[(t % SNAP_W) * K + (t / SNAP_W)];
-        for (int t = tid; t < K; t += SWEEP_BLOCK) w.snap_epoch[snap_out][v0 + t] = s_epoch[t];
+        for (int t = tid; t < SNAP_W * K; t += NT) dst[t] = s_snap[(t % SNAP_W) * K + (t / SNAP_W)];
+        for (int t = tid; t < K; t += NT) w.snap_epoch[snap_out][v0 + t] = s_epoch[t];
     }
     if (is_trk) {
         w.trk_record[trk_item] = trk_rec;
@@ -1821,7 +1870,7 @@ __global__ void __launch_bounds__(SWEEP_BLOCK, 2) k_robot_sweep(DevWorld w, int 
     }
     if (tid == 0) w.iter_factor[r] = itf;
 #ifdef MGX_STAMPS
-    if (w.dbg && lane == 0) w.dbg[((size_t)blockIdx.x * 2 + role) * 8 + 7] = __builtin_readcyclecounter() - t_k0;  // whole kernel
+    if (w.dbg && lane == 0 && role < 2) w.dbg[((size_t)blockIdx.x * 2 + role) * 8 + 7] = __builtin_readcyclecounter() - t_k0;  // whole kernel
 #endif
 }
 

@@ -96,7 +96,7 @@ static int resident_capacity_k(const DevWorld &w) {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_robot_sweep<KT, IR_STAGED, true, SHARDED>, SWEEP_BLOCK, staged) != hipSuccess)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_robot_sweep<KT, IR_STAGED, true, SHARDED>, sweep_threads<KT, true>(), staged) != hipSuccess)
         return 0;
     return per_cu * cus;
 }
@@ -112,9 +112,9 @@ static hipError_t resident_launch_k(const DevWorld &w, int n_robots, const SegPl
         uint32_t ext_mask = 0u, int_mask = 0u, hints = 0u;
         void *args[] = {&wa, &robot0, &ext_mask, &int_mask, &n_int, &snap_out, &hints, &pa};
         return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&k_robot_sweep<KT, IR_STAGED, true, SHARDED>), dim3(grid),
-                                          dim3(SWEEP_BLOCK), args, (unsigned int)staged, stream);
+                                          dim3(sweep_threads<KT, true>()), args, (unsigned int)staged, stream);
     }
-    hipLaunchKernelGGL((k_robot_sweep<KT, IR_STAGED, true, SHARDED>), dim3(grid), dim3(SWEEP_BLOCK), staged, stream, w, 0, 0u, 0u, 0,
+    hipLaunchKernelGGL((k_robot_sweep<KT, IR_STAGED, true, SHARDED>), dim3(grid), dim3(sweep_threads<KT, true>()), staged, stream, w, 0, 0u, 0u, 0,
                        -1, 0u, plan);
     return hipGetLastError();
 }

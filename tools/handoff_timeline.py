@@ -18,7 +18,7 @@ import __graft_entry__ as ge  # noqa: E402
 out = os.environ.get("MGX_STAMPS_LIB") or os.path.join(ROOT, "gpurun_out", "libmgx_stamps.so")
 if not os.environ.get("MGX_STAMPS_LIB"):
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    ge.build_library(out, ["-ffp-contract=off"], extra_defines=["-DMGX_STAMPS"])
+    ge.build_library(out, ["-ffp-contract=off"], extra_defines=["-DMGX_STAMPS"] + os.environ.get("MGX_STAMPS_DEFINES", "").split())
 hostlib.LIB_PATH = out
 hostlib._libs.clear()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000

@@ -19,12 +19,13 @@ import __graft_entry__ as _ge  # noqa: E402
 if os.environ.get("MGX_STAMPS_LIB"):  # a prebuilt -DMGX_STAMPS library (experiments)
     out = os.environ["MGX_STAMPS_LIB"]
 else:
-    _ge.build_library(out, ["-ffp-contract=off"], extra_defines=["-DMGX_STAMPS"])
+    _ge.build_library(out, ["-ffp-contract=off"], extra_defines=["-DMGX_STAMPS"] + os.environ.get("MGX_STAMPS_DEFINES", "").split())
 hostlib.LIB_PATH = out
 hostlib._libs.clear()
 n_iter = 10
+N = int(os.environ.get("MGX_STAMPS_N", "1000"))  # robots
 for name, kw in (("config2", dict(interrobot=False)), ("config3", dict(interrobot=True))):
-    sc = S.grid_scenario(1000, 16, **kw)
+    sc = S.grid_scenario(N, 16, **kw)
     w = World(sc["params"])
     S.populate(w, sc)
     steps = [1] * n_iter if name == "config2" else sc["steps"]
@@ -33,11 +34,11 @@ for name, kw in (("config2", dict(interrobot=False)), ("config3", dict(interrobo
     w.synchronize()
     L = hostlib.lib()
     L.mgx_debug_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32]
-    buf = (C.c_ulonglong * (1004 * 48))()
+    buf = (C.c_ulonglong * ((N + 4) * 48))()
     n = L.mgx_debug_read_stamps(w._w, buf, len(buf))
     allw = np.array(buf[:n], dtype=np.uint64)
-    raw = allw[:1004 * 16].reshape(-1, 2, 8)
-    sub = allw[1004 * 16:1004 * 48].reshape(-1, 2, 16).astype(np.float64)
+    raw = allw[:(N + 4) * 16].reshape(-1, 2, 8)
+    sub = allw[(N + 4) * 16:(N + 4) * 48].reshape(-1, 2, 16).astype(np.float64)
     if name == "config3" and os.environ.get("MGX_PERSISTENT", "1") != "0":  # resident launch: cycles per stage over the 10 iterations
         a = raw.astype(np.float64)
         a = a[a[:, 0, 7] > 0]
@@ -47,7 +48,7 @@ for name, kw in (("config2", dict(interrobot=False)), ("config3", dict(interrobo
                   f"finish+publish {pb:.0f}  staging {stg:.0f}  whole kernel {whole:.0f}  (wait max {a[:, role, 0].max():.0f} min {a[:, role, 0].min():.0f})")
             names = ["poll", "poll barrier", "ext factor edges", "its barrier", "ext var sums", "barrier", "ext finish | adopt", "barrier", "response means",
                      "(internal)", "int finish", "publish stores", "drain", "early factor sweep", "records there (from sweep start)", "-"]
-            m = sub[:1000, role, :].mean(axis=0) / 10.0
+            m = sub[:N, role, :].mean(axis=0) / 10.0
             print("   per iteration: " + "  ".join(f"{nm} {v:.0f}" for nm, v in zip(names, m) if nm != "-"))
         continue
     ext_f, ext_v = (raw[:, :, 0] >> np.uint64(32)).astype(np.float64), (raw[:, :, 1] >> np.uint64(32)).astype(np.float64)
