@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--deadline", type=float, default=150.0,
                     help="N > 1 only: seconds a phase with collectives may take before the run is abandoned (non-zero exit)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--sustained-seconds", type=float, default=2.0,
+                    help="length of the sustained run of the headline workload behind the repetitions (0: skip)")
     ap.add_argument("--fma", action="store_true", help="use the FMA-contracting build (not the product)")
     ap.add_argument("--no-resident", action="store_true", help="N > 1: keep the direct transport on its push / wait kernels (no resident launches)")
     ap.add_argument("--role", default="main", choices=["main", "direct-child", "rccl-child"],
@@ -108,6 +110,34 @@ def timed(torch, dist, iterate, steps_one_tick, a, multi, red_dev="cuda", sync=N
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         walls, devs = [float(x) for x in t[0]], [float(x) for x in t[1]]
     return walls, devs
+
+
+def sustained(torch, dist, iterate, steps_one_tick, seconds, ms_per_step, multi, red_dev="cuda", sync=None, units_per_step=1.0):
+    """The headline workload for `seconds` of wall clock in ONE timed block (the repetitions above are a fraction of a
+    millisecond each: clocks, caches and the host's launch queue in a steady state are a different regime).  The number of
+    steps is fixed in advance from the measured step time — the same on every rank — and the block is bracketed like every
+    other: barrier + synchronize on both sides, MAX over ranks."""
+    sync = sync or torch.cuda.synchronize
+    n = max(len(steps_one_tick), int(seconds / max(ms_per_step * 1e-3, 1e-9)))
+    n -= n % len(steps_one_tick)
+    if multi:
+        t = torch.tensor([n], dtype=torch.int64, device=red_dev)
+        dist.broadcast(t, src=0)
+        n = int(t[0])
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    run_steps(iterate, n, steps_one_tick)
+    if multi:
+        dist.barrier()
+    sync()
+    wall = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([wall], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t[0])
+    return {"seconds": round(wall, 3), "steps": n, "value": round(units_per_step * n / wall, 2), "ms_per_step": wall / n * 1e3,
+            "what": "one timed block of the headline workload, barrier + synchronize on both sides, MAX over ranks"}
 
 
 def summary(walls, devs, steps, units_per_step=1.0):
@@ -421,10 +451,38 @@ def scenario_run(World, name="Junction Twoway", sim_seconds=30.0):
                     "spawner, topology pass, prior updates, GBP schedule, waypoint logic (Python host loop included)"}
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` with no launcher around it: this process becomes the launcher.  It starts the N ranks as fresh
+    CHILD processes — before anything here has touched the GPU (torch is not even imported): a process that has initialised the
+    GPU must never be replaced or forked — gives each its RANK / LOCAL_RANK / WORLD_SIZE and a rendezvous on 127.0.0.1, relays
+    rank 0's JSON line and exits with the worst exit code.  The ranks themselves take the same path as under torch.distributed.run."""
+    import socket
+    with socket.socket() as sk:  # a free port for the rendezvous (+ room above it for the probes' own rendezvous, see run_children)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    if port > 65000:
+        port -= 2000
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(a.gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MGX_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode(errors="replace"))
+    sys.stdout.flush()
+    sys.exit(max(abs(rc) for rc in rcs))
+
+
 def main():
     a = parse()
     if a.role in ("direct-child", "rccl-child"):
         return transport_child(a)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -432,8 +490,7 @@ def main():
     multi = world_size > 1
     if a.gpus != world_size:
         if rank == 0:
-            print(f"bench.py: --gpus {a.gpus} needs {a.gpus} processes (torch.distributed.run --nproc-per-node {a.gpus}); "
-                  f"found WORLD_SIZE={world_size}", file=sys.stderr)
+            print(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world_size} processes", file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the engine has no CPU path", file=sys.stderr)
@@ -470,6 +527,27 @@ def main():
         "timing": "median of `repeats` repetitions of exactly `steps` steps, each between barrier + synchronize, MAX over ranks "
                   "per repetition, after `warmup` steps and `preheat_ms` of untimed work",
     }
+
+    # who ran: what torch.distributed saw, each rank's device, the collective library — so that "RCCL saw N ranks on N
+    # different GPUs" can be checked from the line
+    try:
+        prop = torch.cuda.get_device_properties(device_index)
+        me = {"rank": rank, "device_index": device_index, "name": prop.name, "uuid": str(getattr(prop, "uuid", "")),
+              "pci_bus_id": getattr(prop, "pci_bus_id", None)}
+    except Exception as e:  # noqa: BLE001
+        me = {"rank": rank, "device_index": device_index, "error": f"{type(e).__name__}: {e}"}
+    ranks_seen = [me]
+    if multi:
+        ranks_seen = [None] * world_size
+        dist.all_gather_object(ranks_seen, me)
+    try:
+        rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        rccl = None
+    line["ranks"] = {"world_size_seen_by_torch_distributed": dist.get_world_size() if multi else 1, "backend": backend if multi else None,
+                     "rccl_version": rccl, "distinct_devices": len({(r or {}).get("uuid") or (r or {}).get("device_index") for r in ranks_seen}),
+                     "devices": ranks_seen, "started_by": "bench.py itself (child processes)" if os.environ.get("MGX_BENCH_SELF_LAUNCHED") else
+                     ("a launcher (WORLD_SIZE in the environment)" if multi else "one process")}
 
     # Every phase below contains collectives at N > 1 (barriers, reductions, the halo exchange): the run carries a
     # deadline (see _Deadline) that ends it with a non-zero exit code instead of hanging.
@@ -544,6 +622,10 @@ def main():
     sw.iterate(sc2["steps"])
     resident = sw.world.last_launch_count() == 1  # the engine ran the 10-step schedule as ONE resident launch
     r2 = summary(walls, devs, a.steps, units_per_step=world_size)
+    sustained_head = None
+    if a.sustained_seconds > 0:
+        sustained_head = sustained(torch, dist, sw.iterate, sc2["steps"], a.sustained_seconds, r2["ms_per_step"], multi, red_dev,
+                                   units_per_step=world_size)
     by_transport = {("one GPU, no exchange" if not multi else "collective"): round(r2["value"], 2)}
     transport = "none (one GPU)" if not multi else "collective (torch.distributed all_to_all_single over RCCL, host-driven)"
     sw.synchronize()
@@ -596,6 +678,27 @@ def main():
                     ri = summary(walls_i, devs_i, a.steps, units_per_step=world_size)
                     in_engine = {"transport": got, "result": ri, "launches_per_tick": sw_in.world.last_launch_count(),
                                  "resident_stats": [int(x) for x in sw_in.world.resident_stats()]}
+                    try:
+                        if a.sustained_seconds > 0:
+                            in_engine["sustained"] = sustained(torch, dist, sw_in.iterate, sc2["steps"], a.sustained_seconds, ri["ms_per_step"],
+                                                               True, red_dev, sync=sw_in.synchronize, units_per_step=world_size)
+                            in_engine["resident_stats"] = [int(x) for x in sw_in.world.resident_stats()]
+                        if got == "direct+resident":
+                            # the same wiring with resident launches switched off on every rank: what the exchange costs WITHOUT the
+                            # in-launch hand-off (the scaling curve's other half)
+                            sw_in.world.set_resident_launches(False)
+                            walls_s, devs_s = timed(torch, dist, sw_in.iterate, sc2["steps"], a, True, red_dev, sync=sw_in.synchronize)
+                            sw_in.iterate(sc2["steps"])
+                            sw_in.synchronize()
+                            rs = summary(walls_s, devs_s, a.steps, units_per_step=world_size)
+                            in_engine["launch_per_segment"] = {
+                                "value": round(rs["value"], 2), "ms_per_step": rs["ms_per_step"], "device_ms_per_step": rs["device_ms_per_step"],
+                                "launches_per_tick": sw_in.world.last_launch_count(),
+                                "what": "the same sharded workload and direct wiring with mgx_set_resident_launches(world, 0) on every rank: push / "
+                                        "wait kernels around one launch per segment"}
+                            sw_in.world.set_resident_launches(True)
+                    except Exception as e:  # noqa: BLE001
+                        in_engine["sustained_error"] = f"{type(e).__name__}: {e}"
                     by_transport[got + " (in the bench process)"] = round(ri["value"], 2)
                     if rank == 0:  # (resident launches so far, declined by the ranks' agreement, back-off left)
                         line["in_engine_resident_stats"] = in_engine["resident_stats"]
@@ -611,6 +714,20 @@ def main():
     if in_engine is not None:
         head = in_engine["result"]
         resident = in_engine["launches_per_tick"] == 1
+        sustained_head = in_engine.get("sustained", None)
+        if "launch_per_segment" in in_engine:
+            line["launch_per_segment"] = in_engine["launch_per_segment"]
+        line["resident_stats"] = {"launches": in_engine["resident_stats"][0], "declined": in_engine["resident_stats"][1],
+                                  "backoff_left": in_engine["resident_stats"][2] if len(in_engine["resident_stats"]) > 2 else None}
+    elif not multi:
+        try:
+            st = [int(x) for x in sw.world.resident_stats()]
+            line["resident_stats"] = {"launches": st[0], "declined": st[1], "backoff_left": st[2] if len(st) > 2 else None}
+        except Exception:  # noqa: BLE001
+            pass
+    if sustained_head is not None:
+        line["sustained"] = sustained_head
+    if in_engine is not None:
         transport = {"direct+resident": "direct+resident: ONE resident launch per schedule and rank; boundary robots store their snapshot records "
                                         "and progress words into the other ranks' peer-mapped ghost areas from inside it (xGMI, system-scope "
                                         "stores), no exchange kernel, no collective, no host work between the iterations",

@@ -141,3 +141,31 @@ def test_bench_two_rank_control_flow_dry_run():
     assert d["transport"].startswith("direct+resident"), d.get("in_engine_in_process", d["transport"])
     assert d["value"] == d["by_transport"]["direct+resident (in the bench process)"]
     assert "resident" in d["roofline"]["kernel"]
+
+
+def test_bench_bare_launch_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (no WORLD_SIZE in the environment): bench.py starts its two ranks
+    itself, as fresh child processes of a parent that never touches the GPU, and relays rank 0's line — the driver's N = 1 command
+    is a bare `python3 bench.py --gpus 1 ...`, and the first multi-GPU run must not end in a usage error.  Dry-run mode for a
+    one-GPU box (both ranks on cuda:0, gloo); the line says who ran, carries a sustained figure, the resident launches'
+    statistics and the launch-per-segment figure of the same wiring."""
+    import json
+    bench = os.path.join(os.path.dirname(HERE), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MGX_BENCH_BACKEND="gloo", MGX_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", MGX_HALO_TIMEOUT_MS="20000",
+               MGX_RESIDENT_CENSUS_SHARDED_US="500000")
+    cmd = [sys.executable, bench, "--gpus", "2", "--steps", "40", "--warmup", "10", "--robots-per-gpu", "144", "--horizon", "10",
+           "--deadline", "150", "--repeats", "3", "--sustained-seconds", "0.5", "--no-configs1"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert "error" not in d and d["n_gpus"] == 2 and d["value"] > 0
+    assert d["ranks"]["world_size_seen_by_torch_distributed"] == 2 and len(d["ranks"]["devices"]) == 2
+    assert d["ranks"]["started_by"].startswith("bench.py itself")
+    assert {x["rank"] for x in d["ranks"]["devices"]} == {0, 1}
+    assert d["transport"].startswith("direct+resident"), d.get("in_engine_in_process", d["transport"])
+    assert d["sustained"]["value"] > 0 and d["sustained"]["seconds"] >= 0.4
+    assert d["resident_stats"]["launches"] > 0
+    assert d["launch_per_segment"]["value"] > 0 and d["launch_per_segment"]["launches_per_tick"] > 1
