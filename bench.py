@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s peak, 
 # = half the guide's 157.3 TFLOP/s FP32 vector figure; as an issue rate: one f64 VALU wave-instruction per SIMD per 4 clocks
 F64_VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4.0
 SCHEDULE_LEN = 10
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 
 
 def parse():
@@ -259,6 +259,11 @@ def roofline(kernel, alg_bytes_per_launch, launches, dev_seconds, prof_key, iter
     b = max(cands, key=lambda c: c[1])
     out.update({"bound": b[0], "achieved": b[2], "peak": b[3], "unit": b[4], "frac": round(b[1] / avg, 4)})
     out["traffic_source"] = p.get("source", f"profiles/{PROFILE_TAG}_*: rocprofv3 --pmc, separate passes") + (f" — {prof_note}" if prof_note else "")
+    # counters per launch are duration-independent; the profile box's own duration and clock are quoted beside THIS run's, so that a
+    # reader sees "counters from box A at X GHz, clock of this run from box B" instead of finding the two durations disagree
+    out["profile_box"] = {"kernel_trace_avg_us": p.get("kernel_trace_avg_us"), "shader_clock_ghz": p.get("shader_clock_ghz"),
+                          "counter_pass_avg_us": p.get("counter_pass_avg_us"),
+                          "note": "the box the counters were collected on (profiles/); `avg_launch_us` above is this run's own, live"}
     out["note"] = ("frac = max(HBM time of the measured traffic at 8 TB/s, issue time of the measured f64 VALU wave-instructions) / live launch "
                    "duration; the rest of the launch is latency (dependent phases of one workgroup, hand-offs between neighbours)")
     return out

@@ -279,6 +279,36 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     static_assert(!PERSIST || IRM == IR_STAGED, "resident schedule launches exist for worlds with staged inter-robot messages");
     static_assert(!SHARD || PERSIST, "ghost records arrive in-launch only in resident schedule launches");
     const int nseg = PERSIST ? plan.n : 1;
+    // Fields of the world that only COLD paths read (the residency census and its decider, give-up paths of the waits, the ranks'
+    // agreement, the push records of boundary robots): fetched from the kernel's argument block where they are used, through a
+    // pointer the compiler cannot see through — read as `w.field` they are loaded once at the top and held in scalar registers for
+    // the whole kernel, and the sharded instantiation had more of those than spill lanes (the rest went to scratch).
+    struct ArgBlock {  // the kernel's arguments as they lie in its argument block
+        DevWorld w; int robot0; uint32_t ext_mask, int_mask; int n_int, snap_out; uint32_t hints; SegPlan plan;
+    };
+    // (where the block is: the pointer the kernel is entered with, parked in the first 16 bytes of LDS by thread 0 in front of the
+    // staging barrier — held in registers for the whole kernel it was one more pair to spill)
+    auto cold_args = [&]() __attribute__((always_inline)) -> const ArgBlock & {
+        unsigned long long a = PERSIST ? *reinterpret_cast<const unsigned long long *>(lds) : (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+        if (PERSIST) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a & 0xffffffffull));
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+            a = ((unsigned long long)hi << 32) | lo;
+        }
+        const ArgBlock *p = reinterpret_cast<const ArgBlock *>(a);
+        asm volatile("" : "+s"(p));
+        return *p;
+    };
+    auto cold_args_at_entry = [&]() __attribute__((always_inline)) -> const ArgBlock & {  // (in front of the staging barrier)
+        const ArgBlock *p = reinterpret_cast<const ArgBlock *>((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());
+        asm volatile("" : "+s"(p));
+        return *p;
+    };
+    if (PERSIST && threadIdx.x == 0) *reinterpret_cast<unsigned long long *>(lds) = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    auto cold = [&]() __attribute__((always_inline)) -> const DevWorld & { return cold_args().w; };
+    auto cold0 = [&]() __attribute__((always_inline)) -> const DevWorld & { return cold_args_at_entry().w; };
+    auto cold_plan0 = [&]() __attribute__((always_inline)) -> const SegPlan & { return cold_args_at_entry().plan; };
+    auto cold_plan = [&]() __attribute__((always_inline)) -> const SegPlan & { return cold_args().plan; };
     // The plan's per-segment bytes, read as DWORDS of the kernel's arguments: a byte indexed by the segment counter is fetched by a
     // VECTOR load, and the wait for a vector load waits for every write-through store the wave has in flight as well (one counter) —
     // `plan.n_int[k + 1]` right behind the publication made the publishing wave sit out the drain of its own stores.
@@ -296,7 +326,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     // resident launches: "this workgroup has started" (SegPlan: residency census) — a word of its own, a plain write-through
     // store: nothing contended is outstanding when the staging loads are waited for
     const bool census = PERSIST && plan.launch_seq != 0ull;
-    if (census && threadIdx.x == 0) __hip_atomic_store(&w.census[blockIdx.x], plan.launch_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (census && threadIdx.x == 0) __hip_atomic_store(&cold0().census[blockIdx.x], plan.launch_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ... and the launch's LAST workgroup owns no robot: it is the decider.  Dispatched behind every robot's workgroup, it
     // finds every word signed within a microsecond of the launch's start when the whole grid is on the device — while the
     // robots' workgroups are still staging — and says go; if they are not all signed within the bound it says abort.  Either
@@ -305,35 +335,35 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         const unsigned long long seq = plan.launch_seq;
         const long long t0 = wall_clock64();
         // sharded worlds: this rank's answer is the RANKS' answer (SegPlan::agree_seq) — complete here means signed in there
-        const bool ranks = SHARD && plan.agree_seq != 0ull;
+        const bool ranks = SHARD && cold_plan0().agree_seq != 0ull;
         bool signed_in = false;
         for (;;) {
             int missing = 0;
             for (unsigned b2 = threadIdx.x; b2 < gridDim.x; b2 += NT)
-                missing |= __hip_atomic_load(&w.census[b2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq ? 1 : 0;
+                missing |= __hip_atomic_load(&cold0().census[b2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq ? 1 : 0;
             const bool all = __syncthreads_or(missing) == 0;
             int done = 0;
             if (threadIdx.x == 0) {
-                unsigned long long v = __hip_atomic_load(w.decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool late = wall_clock64() - t0 > plan.census_ticks;
+                unsigned long long v = __hip_atomic_load(cold0().decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool late = wall_clock64() - t0 > cold_plan0().census_ticks;
                 unsigned want;
                 if (!ranks) {
                     want = all ? RESIDENT_GO : (late ? RESIDENT_ABORT : 0u);
                 } else if (all && !signed_in) {
-                    want = agree_on_launch(w.agree, plan.agree_seq, (unsigned)w.n_ranks, AGREE_SIGN_IN);
+                    want = agree_on_launch(cold0().agree, cold_plan0().agree_seq, (unsigned)cold0().n_ranks, AGREE_SIGN_IN);
                     signed_in = true;
                 } else {
-                    want = agree_on_launch(w.agree, plan.agree_seq, (unsigned)w.n_ranks, late ? AGREE_ABORT : AGREE_LOOK);
+                    want = agree_on_launch(cold0().agree, cold_plan0().agree_seq, (unsigned)cold0().n_ranks, late ? AGREE_ABORT : AGREE_LOOK);
                 }
                 if (want == AGREE_LOST) {  // the other ranks are more schedules ahead than the word remembers: this world has parted
-                    __hip_atomic_store(w.sweep_err, plan.agree_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // from theirs (reported)
+                    __hip_atomic_store(cold0().sweep_err, cold_plan0().agree_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // from theirs (reported)
                     want = RESIDENT_ABORT;
                 }
                 if ((v >> 2) == seq) {
                     done = 1;  // a workgroup that gave up on this one has decided
                 } else if (want) {
-                    if (__hip_atomic_compare_exchange_strong(w.decision, &v, seq * 4ull + want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                        __hip_atomic_store(w.decision_host, seq * 4ull + want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (__hip_atomic_compare_exchange_strong(cold0().decision, &v, seq * 4ull + want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        __hip_atomic_store(cold0().decision_host, seq * 4ull + want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     done = 1;  // (lost the exchange: somebody else's decision stands)
                 }
             }
@@ -343,14 +373,15 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         }
         return;
     }
-    const int r = robot0 + xcd_local_index(blockIdx.x, census ? gridDim.x - 1 : gridDim.x);
+    // (the workgroup's robot: the same in every lane, and said so — what is derived from it stays out of the vector registers)
+    const int r = __builtin_amdgcn_readfirstlane(robot0 + xcd_local_index(blockIdx.x, census ? gridDim.x - 1 : gridDim.x));
     int tid = threadIdx.x;  // not const: resident launches make them opaque once per segment, see the segment loop
     const int role = tid >> 6;
     int lane = tid & 63;
     const int K = KT > 0 ? KT : w.K, E = 4 * K - 6, E1 = E + 1;
     const BlobLayout L(K);
     const int ZCOL = E;  // all-zero message column (absent edges)
-    double *s_snap = lds;                                 // [24][K] variable -> own-factor snapshots
+    double *s_snap = lds + (PERSIST ? 2 : 0);             // [24][K] variable -> own-factor snapshots (resident: behind the parked argument pointer)
     double *s_prior = s_snap + SNAP_W * K;                // [20][K] prior eta, lam (belief after the last sweep)
     double *s_tmp = s_prior + 20 * K;                     // [20][K] scratch sums (external sweep)
     double *s_io = s_tmp + 20 * K;                        // image of the blob's in/out region:
@@ -465,7 +496,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         const int c = q / (K - 1);
         return (q - c * (K - 1)) * n_in + c;
     };
-    const int my_j = (HAS_IR && tid < ne) ? edge_of_lane(tid) : 0;  // the thread's first edge
+    int my_j = (HAS_IR && tid < ne) ? edge_of_lane(tid) : 0;  // the thread's first edge (not const: opaque per segment, see the segment loop)
     if (HAS_IR && tid < ne) pf_gate = w.ir_gate[ie0 + my_j];
     if (do_extf && tid < ne) {
         MGX_EDGE_LOAD(pf_er, &w.ir_rec[ie0 + my_j]);
@@ -576,7 +607,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                 r_snap[it] = (t < SNAP_W * K) ? src[t] : 0.0;
             }
             chain_second_link();
-            if (census && BIG && tid == 0) early_decision = __hip_atomic_load(w.decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (census && BIG && tid == 0) early_decision = __hip_atomic_load(cold().decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             r_prior.store(s_prior, tid);
             r_io.store(s_mu, tid);
 #pragma unroll
@@ -587,7 +618,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         } else {
             copy_words(s_prior, blob + L.prior(), 20 * K, tid, NT);
             chain_second_link();
-            if (census && BIG && tid == 0) early_decision = __hip_atomic_load(w.decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (census && BIG && tid == 0) early_decision = __hip_atomic_load(cold().decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             copy_words(s_mu, blob + L.mu(), L.inout_words() - 16 * K, tid, NT);
             for (int t = tid; t < SNAP_W * K; t += NT) s_snap[(t % SNAP_W) * K + (t / SNAP_W)] = src[t];
         }
@@ -636,22 +667,22 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     auto census_says_abort = [&](unsigned long long v) __attribute__((always_inline)) {
         int abort_launch = 0;
         if (tid == 0) {
-            const unsigned long long seq = plan.launch_seq;
+            const unsigned long long seq = cold_plan().launch_seq;
             const long long t0 = wall_clock64();
             while ((v >> 2) != seq) {
                 __builtin_amdgcn_s_sleep(1);
-                v = __hip_atomic_load(w.decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((v >> 2) != seq && wall_clock64() - t0 > 4 * plan.census_ticks) {
+                v = __hip_atomic_load(cold().decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 2) != seq && wall_clock64() - t0 > 4 * cold_plan().census_ticks) {
                     // (sharded worlds: only if the ranks' word says abort too — with this vote it does unless every rank,
                     // hence this one's decider, has signed in: then the decider is alive and about to say so here)
-                    if (SHARD && plan.agree_seq != 0ull) {
-                        const unsigned a = agree_on_launch(w.agree, plan.agree_seq, (unsigned)w.n_ranks, AGREE_ABORT);
+                    if (SHARD && cold_plan().agree_seq != 0ull) {
+                        const unsigned a = agree_on_launch(cold().agree, cold_plan().agree_seq, (unsigned)cold().n_ranks, AGREE_ABORT);
                         if (a == RESIDENT_GO) continue;
-                        if (a == AGREE_LOST) __hip_atomic_store(w.sweep_err, plan.agree_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (a == AGREE_LOST) __hip_atomic_store(cold().sweep_err, cold_plan().agree_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
-                    if (__hip_atomic_compare_exchange_strong(w.decision, &v, seq * 4ull + RESIDENT_ABORT, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                    if (__hip_atomic_compare_exchange_strong(cold().decision, &v, seq * 4ull + RESIDENT_ABORT, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_AGENT)) {
-                        __hip_atomic_store(w.decision_host, seq * 4ull + RESIDENT_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(cold().decision_host, seq * 4ull + RESIDENT_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         v = seq * 4ull + RESIDENT_ABORT;
                     }
                 }
@@ -786,10 +817,10 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
 #endif
             if (spins == 0u) t0 = wall_clock64();
             if ((spins & 31u) == 31u) {
-                bool stop = __hip_atomic_load(w.sweep_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
-                if (!stop && wall_clock64() - t0 > plan.timeout_ticks) {
-                    __hip_atomic_store(w.sweep_abort, (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(w.sweep_err, (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                bool stop = __hip_atomic_load(cold().sweep_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+                if (!stop && wall_clock64() - t0 > cold_plan().timeout_ticks) {
+                    __hip_atomic_store(cold().sweep_abort, (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cold().sweep_err, (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     stop = true;
                 }
                 if (__ballot(stop) != 0ull) break;  // (the launch ends with wrong beliefs; the host reports it)
@@ -814,7 +845,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             const unsigned o = off_mine & 0x7fffffffu, rob = o / ((unsigned)K * (unsigned)XREC_BYTES);
             const unsigned want_id = rob * 64u + (o - rob * (unsigned)K * (unsigned)XREC_BYTES) / 16u;  // robot * 64 + variable
             if (x != R[15].x || R[15].y != want_id)
-                __hip_atomic_store(w.sweep_err, 0xBAD0000000000000ull | ((unsigned long long)(R[15].y & 0xfffffu) << 28) | ((unsigned long long)(want_id & 0xfffffu) << 8) | (seq & 0xffu),
+                __hip_atomic_store(cold().sweep_err, 0xBAD0000000000000ull | ((unsigned long long)(R[15].y & 0xfffffu) << 28) | ((unsigned long long)(want_id & 0xfffffu) << 8) | (seq & 0xffu),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
 #endif
@@ -1275,6 +1306,13 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     // tracking factors.  Reads the snapshot means and delivery counts, writes its own message columns.
     // skip: kinds whose sweep k_thaw has already computed (first sweep after mgx_set_enabled only).
     const SdfView sdf = make_sdf_view(w.sdf, w.sdf_w, w.sdf_h, w.world_w, w.world_h);
+    // (the tracking factors' switch padding, opaque where it is used: `pad * 0.01` hoisted in front of the segment loop was a pair of
+    // registers held — and in the sharded instantiation spilled to scratch — for a path most worlds never take)
+    auto trk_pad_here = [&]() __attribute__((always_inline)) {
+        double p_ = w.trk_pad;
+        asm volatile("" : "+v"(p_));
+        return p_;
+    };
     auto unary_messages = [&](uint32_t skip, double *s_out, int itf_gate) __attribute__((always_inline)) {
         if (obs_rows) {
             // four lanes per obstacle factor: lane q samples tap q and writes row q of the message
@@ -1316,7 +1354,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
 #pragma unroll
             for (int c = 0; c < 4; c++) x0[c] = s_snap[(20 + c) * K + uvar];
             const int p0 = w.path_ptr[r], np = w.path_ptr[r + 1] - p0;
-            if (!tracking_update(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, trk_rec,
+            if (!tracking_update(w.path_xy + 2 * (size_t)p0, np, trk_pad_here(), w.trk_attr, w.inv_s2_trk, x0, trk_rec,
                                   trk_lp, trk_lv, oe, ol)) {
 #pragma unroll
                 for (int c = 0; c < 4; c++) oe[c] = 0.0;
@@ -1340,7 +1378,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             float lp2[2] = {w.trk_last_pos[item2], w.trk_last_pos[(size_t)w.NT + item2]};
             double lv2 = w.trk_last_val[item2];
             const int p0 = w.path_ptr[r], np = w.path_ptr[r + 1] - p0;
-            if (!tracking_update(w.path_xy + 2 * (size_t)p0, np, w.trk_pad, w.trk_attr, w.inv_s2_trk, x0, rec2, lp2, lv2, oe, ol)) {
+            if (!tracking_update(w.path_xy + 2 * (size_t)p0, np, trk_pad_here(), w.trk_attr, w.inv_s2_trk, x0, rec2, lp2, lv2, oe, ol)) {
 #pragma unroll
                 for (int c = 0; c < 4; c++) oe[c] = 0.0;
 #pragma unroll
@@ -1381,7 +1419,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     // ghosts_only (sharded worlds, see the end of a segment): look at the peers on other ranks only
     auto progress_of = [&](int pr) __attribute__((always_inline)) {
         if (SHARD && pr >= w.R_local)  // a ghost: its owner's rank stores the word into this rank's ghost area
-            return __hip_atomic_load(&w.gflag[pr - w.R_local], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return __hip_atomic_load(&cold().gflag[pr - w.R_local], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return __hip_atomic_load(&w.sweep_flag[pr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto wait_for_progress = [&](unsigned long long want, bool ghosts_only) __attribute__((always_inline)) {
@@ -1399,10 +1437,13 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                 while (progress_of(pr) < want) {
                     __builtin_amdgcn_s_sleep(4);
                     if ((++spins & 31u) == 0u) {
-                        if (__hip_atomic_load(w.sweep_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
-                        if (wall_clock64() - t0 > plan.timeout_ticks) {
-                            __hip_atomic_store(w.sweep_abort, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(w.sweep_err, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (__hip_atomic_load(cold().sweep_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+                        if (wall_clock64() - t0 > cold_plan().timeout_ticks) {
+                            // (what is reported: the launch's first segment count — any non-zero word stops the waiters; `want`
+                            // itself kept alive into this path was one more register pair to spill)
+                            const unsigned long long word = cold_plan().flag_base + 1ull;
+                            __hip_atomic_store(cold().sweep_abort, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(cold().sweep_err, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             break;
                         }
                     }
@@ -1413,9 +1454,9 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     auto wait_for_peers = [&](int k) __attribute__((always_inline)) { wait_for_progress(plan.flag_base + (unsigned long long)k, false); };
     // sharded worlds: the ranks that hold this robot as a ghost
     int xp0 = 0, xp1 = 0;
-    if (SHARD && role == ROLE_UV) {
-        xp0 = w.xp_ptr[r];
-        xp1 = w.xp_ptr[r + 1];
+    if (SHARD && role == ROLE_UV) {  // (wave-uniform, and told so: the push records are then fetched by scalar loads, not into registers)
+        xp0 = __builtin_amdgcn_readfirstlane(cold().xp_ptr[r]);
+        xp1 = __builtin_amdgcn_readfirstlane(cold().xp_ptr[r + 1]);
     }
 
     bool prefired = false;  // both waves already ran the factor sweep of internal iteration 0
@@ -1454,7 +1495,9 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         // Nothing derived from the thread index stays live across segments: left alone, the compiler hoists every per-thread
         // address and predicate of the loop body in front of the loop and then spills them around the f64 blocks (64 spilled
         // VGPRs, 244 B of scratch per lane at K = 16); recomputing them per segment is a handful of integer instructions.
-        if (PERSIST) asm volatile("" : "+v"(tid), "+v"(lane));
+        // (... nor from the per-thread indices made of it in front of the loop: a kept copy of `&w.ir_bmu[c * NI + ie0 + my_j]` is two
+        // registers per row, and the sharded instantiation spilled four of those to scratch)
+        if (PERSIST) asm volatile("" : "+v"(tid), "+v"(lane), "+v"(my_j), "+v"(pf_dst));
         const uint32_t ext_k = PERSIST ? (plan_ext(k) ? (PH_EXT_FACTOR | PH_EXT_VARIABLE) : 0u) : ext_mask;
         const uint32_t int_k = PERSIST ? (PH_INT_FACTOR | PH_INT_VARIABLE) : int_mask;
         const int n_int_k = PERSIST ? plan_n_int(k) : n_int;
@@ -1721,7 +1764,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         }
         // segment 0 of a resident launch is through: go or abort (see the residency census above) before anything is published
         if (census && !CENSUS_EARLY && k == 0) {
-            const unsigned long long v = tid == 0 ? __hip_atomic_load(w.decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            const unsigned long long v = tid == 0 ? __hip_atomic_load(cold().decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
             if (census_says_abort(v)) return;
         }
         // ======================= end of a segment of a resident schedule launch ====================
@@ -1786,8 +1829,9 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                     // at the end of their launch, below); in later segments their records of the segment in between have.
                     if (k == 0) wait_for_progress(plan.flag_base, true);
                     for (int t = xp0; t < xp1; t++) {
-                        const XPushRec xr = w.xp_rec[t];
-                        const __amdgpu_buffer_rsrc_t rs_peer = uniform_rsrc(xr.xrec[ob], (unsigned)K * (unsigned)XREC_BYTES);
+                        const XPushRec xr = cold().xp_rec[t];
+                        // (no indexing of the record by the parity: a copy that is indexed at run time lives in scratch)
+                        const __amdgpu_buffer_rsrc_t rs_peer = uniform_rsrc(ob ? xr.xrec[1] : xr.xrec[0], (unsigned)K * (unsigned)XREC_BYTES);
                         const uint32_t seq = xrec_seq(next_count + xr.flag_delta);
                         for (int t2 = lane; t2 < XREC_CHUNKS * K; t2 += 64) st16_system_raw(rs_peer, 16u * (unsigned)t2, chunk_of(t2, seq));
                         if (lane == 0)
@@ -1846,7 +1890,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     if (PERSIST) snap_out = (w.cur + nseg) & 1;  // where the records of the schedule's last sweep go (the host follows)
     if (SHARD && role == ROLE_UV && lane == 0) {  // "through with this launch's reads of your records": see the end of a segment
         for (int t = xp0; t < xp1; t++) {
-            const XPushRec xr = w.xp_rec[t];
+            const XPushRec xr = cold().xp_rec[t];
             __hip_atomic_store(reinterpret_cast<unsigned long long *>(xr.flag), plan.flag_base + xr.flag_delta + (unsigned long long)nseg,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }

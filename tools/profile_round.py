@@ -28,6 +28,20 @@ def per_kernel(d, counter):
     return {k: sum(v[len(v) // 5:]) / len(v[len(v) // 5:]) for k, v in acc.items()}
 
 
+def pass_durations(d):
+    """mean dispatch duration (us) per instantiation as the COUNTER pass itself saw it (first fifth dropped)"""
+    acc = collections.defaultdict(dict)
+    rs = [r for r in rows(d, "*counter_collection.csv") if "k_robot_sweep" in r["Kernel_Name"] and "Start_Timestamp" in r and "End_Timestamp" in r]
+    for r in rs:
+        acc[r["Kernel_Name"].split("k_robot_sweep")[1].split(">")[0] + ">"][r["Dispatch_Id"]] = (int(r["Start_Timestamp"]), int(r["End_Timestamp"]))
+    out = {}
+    for k, dd in acc.items():
+        v = [(e - s0) / 1e3 for s0, e in sorted(dd.values())]
+        v = v[len(v) // 5:]
+        out[k] = sum(v) / len(v)
+    return out
+
+
 def durations(d):
     acc = collections.defaultdict(list)
     tr = [r for r in rows(d, "*kernel_trace.csv") if "k_robot_sweep" in r["Kernel_Name"]]
@@ -44,9 +58,11 @@ def kernel_digest():
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     g = os.path.join(ROOT, "gpurun_out", tag)
-    prof = os.path.join(ROOT, "profiles")
+    # (on the GPU box: write beside the raw traces — tools/profile_round.sh then drops those, which are far beyond what comes
+    # back from a gpurun call — and copy gpurun_out/<tag>_profiles/* into profiles/ afterwards)
+    prof = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
     out = [f"# rocprofv3 summary — {tag}", "",
            "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-extras` "
@@ -73,12 +89,18 @@ def main():
                           "MI355X_MICROARCH.md (HBM section) gfx950 FETCH_SIZE counts half the bytes of wide 16-B-per-lane streaming reads, so "
                           "bench.py doubles the reads (an upper bound here: part of the staging uses 8-B loads)."}
     keys = {"<16, 0, false, false>": ("config1", ""), "<16, 2, true, false>": ("config2_resident", ""), "<16, 2, false, false>": ("config2", "_np")}
-    out += ["", "## PMC per dispatch (separate passes)", "", "| instantiation | FETCH_SIZE KiB | WRITE_SIZE KiB | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU x4 / SQ_BUSY_CYCLES x4 | SQ_WAIT_ANY / SQ_WAVE_CYCLES |", "|---|---|---|---|---|---|"]
+    out += ["", "## PMC per dispatch (separate passes)", "",
+            "Shader clock = GRBM_GUI_ACTIVE per dispatch / that dispatch's duration in the same pass: the clock THIS box ran the kernel at "
+            "(durations of other boxes, e.g. the driver's, relate to these counters through it).", "",
+            "| instantiation | FETCH_SIZE KiB | WRITE_SIZE KiB | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES | SQ_WAIT_ANY / SQ_WAVE_CYCLES | kernel trace avg us | shader clock GHz | us in the counter passes (FETCH / WRITE / SQ / GRBM) |", "|---|---|---|---|---|---|---|---|---|"]
     for inst, (key, suf) in keys.items():
         f = per_kernel(g + "_pmc_FETCH_SIZE" + suf, "FETCH_SIZE").get(inst)
         w = per_kernel(g + "_pmc_WRITE_SIZE" + suf, "WRITE_SIZE").get(inst)
         sq = {c: per_kernel(g + "_pmc_SQ_INSTS_VALU" + suf, c).get(inst) for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY")}
         d_us = (dur.get(inst + (" (MGX_PERSISTENT=0)" if suf else "")) or (None, 0))[0]
+        gui = per_kernel(g + "_pmc_GRBM_GUI_ACTIVE" + suf, "GRBM_GUI_ACTIVE").get(inst)
+        pd = [pass_durations(g + "_pmc_" + nm + suf).get(inst) for nm in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")]
+        clock = gui / (pd[3] * 1e3) if gui and pd[3] else None  # cycles / ns = GHz
         if f is None or w is None:
             continue
         ent = {"fetch_kib": round(f, 1), "write_kib": round(w, 1), "source": f"profiles/{tag}_summary.md (rocprofv3 --pmc, separate passes)"}
@@ -93,9 +115,13 @@ def main():
                 ent["wait_pct"] = round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"] * 100.0, 1)
         if d_us:
             ent["kernel_trace_avg_us"] = round(d_us, 2)
+        if clock:
+            ent["shader_clock_ghz"] = round(clock, 3)
+        ent["counter_pass_avg_us"] = [round(x, 2) if x else None for x in pd]
         traffic[key] = ent
         out.append(f"| k_robot_sweep{inst} | {f:.1f} | {w:.1f} | {sq['SQ_INSTS_VALU'] or 0:.4g} | VALU active {busy or 0:.1f} % of wave-cycles | "
-                   f"{(sq['SQ_WAIT_ANY'] or 0) / (sq['SQ_WAVE_CYCLES'] or 1) * 100:.0f} % waiting |")
+                   f"{(sq['SQ_WAIT_ANY'] or 0) / (sq['SQ_WAVE_CYCLES'] or 1) * 100:.0f} % waiting | {d_us or 0:.2f} | {clock or 0:.2f} | "
+                   + " / ".join(f"{x:.1f}" if x else "-" for x in pd) + " |")
     # the K = 32 instantiations (tools/bench_configs.py under the same three counter passes)
     cdur = durations(g + "_cfg")
     if cdur:

@@ -6,11 +6,11 @@
 # Everything lands under gpurun_out/<tag>_*; tools/profile_round.py turns it into profiles/<tag>_*.
 # (the profiled program comes right after `--`: no env / shell hop between rocprofv3 and python3)
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 part=${2:-ab}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-B="python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-extras"
+B="python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-extras --sustained-seconds 0"
 out=gpurun_out/${tag}
 SQ="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 if [[ $part == *a* ]]; then
@@ -19,7 +19,8 @@ if [[ $part == *a* ]]; then
   # the driver's own command line (bench.py's defaults otherwise): the per-dispatch durations behind the round's bench line
   rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_kt_driver -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > ${out}_kt_driver.json 2> ${out}_kt_driver.err || exit 1
   echo "driver command done"
-  for pass in "FETCH_SIZE" "WRITE_SIZE" "$SQ"; do
+  # (GRBM_GUI_ACTIVE: shader-clock cycles per dispatch — with the dispatch's duration the clock the box ran at)
+  for pass in "FETCH_SIZE" "WRITE_SIZE" "$SQ" "GRBM_GUI_ACTIVE"; do
     name=$(echo $pass | cut -d' ' -f1)
     rocprofv3 --pmc $pass --kernel-trace --output-format csv -d ${out}_pmc_${name} -- $B > ${out}_pmc_${name}.json 2> ${out}_pmc_${name}.err || exit 1
     export MGX_PERSISTENT=0
@@ -40,3 +41,8 @@ if [[ $part == *b* ]]; then
   done
   echo "configs done"
 fi
+# the raw traces are tens of megabytes per pass: what travels back is the summary made HERE
+python3 tools/profile_round.py ${tag} gpurun_out/${tag}_profiles > gpurun_out/${tag}_profile_summary.log 2>&1 || exit 1
+rm -rf ${out}_kt ${out}_kt_np ${out}_kt_driver ${out}_pmc_* ${out}_cfg ${out}_cfg_pmc_*
+echo "summary written to gpurun_out/${tag}_profiles"
+
