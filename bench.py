@@ -140,6 +140,25 @@ def sustained(torch, dist, iterate, steps_one_tick, seconds, ms_per_step, multi,
             "what": "one timed block of the headline workload, barrier + synchronize on both sides, MAX over ranks"}
 
 
+def settle_resident(sw, ref, steps_one_tick, agree, max_ticks=40):
+    """Ticks in front of the verification until the ranks' resident launches run: the very first launches of a process load code
+    objects and the ranks' hosts reach them tens of milliseconds apart — the ranks' agreement then declines (by design) and the
+    engines back off for a number of external iterations, in which nothing resident is even tried.  Judging the transport by
+    those ticks would switch it off on every real node.  `ref` (the host-driven twin, if any) runs the same ticks.
+    Returns (ticks run, declined launches during them)."""
+    n = 0
+    while n < max_ticks:
+        sw.iterate(steps_one_tick)
+        if ref is not None:
+            ref.iterate(steps_one_tick)
+        sw.synchronize()
+        n += 1
+        st = sw.world.resident_stats()
+        if n >= 2 and agree(int(st[2]) == 0 and sw.world.last_launch_count() == 1):
+            break
+    return n, int(sw.world.resident_stats()[1])
+
+
 def summary(walls, devs, steps, units_per_step=1.0):
     """median repetition -> throughput; spread of the repetitions beside it"""
     w, d = statistics.median(walls), statistics.median(devs)
@@ -328,6 +347,7 @@ def transport_child(a):
             # unpack): the in-engine transport has to leave bit-identical beliefs
             ref = sharded.ShardedWorld(sc2, rank, world_size, lambda p: World(p, stream=stream, fma=a.fma),
                                        comm=sharded.TorchDistComm(stage_through_host=True))
+            settled, declined0 = (settle_resident(sw, ref, sc2["steps"], agree) if got == "direct+resident" else (0, 0))
             for _ in range(2):
                 sw.iterate(sc2["steps"])
                 ref.iterate(sc2["steps"])
@@ -337,8 +357,9 @@ def transport_child(a):
             verified = agree(same)
             del ref
             # resident launches the ranks could not agree on (a rank late, crowded out, the agreement word out of reach) cost
-            # a wait each before they fall back: if the two ticks above saw any, the measurement is the plain direct transport's
-            if got == "direct+resident" and not agree(sw.world.resident_stats()[1] == 0):
+            # a wait each before they fall back: if the two ticks above (behind the settling ticks) saw any, the measurement is the
+            # plain direct transport's
+            if got == "direct+resident" and not agree(sw.world.resident_stats()[1] == declined0):
                 sw.world.set_resident_launches(False)
                 got = "direct"
                 declined_note = "resident launches were declined by the ranks' agreement during verification: switched off"
@@ -364,6 +385,8 @@ def transport_child(a):
                                "RCCL inside the engine: grouped ncclSend / ncclRecv per external iteration on the launch stream, "
                                "one C call per tick",
                    "ghost_robots_this_rank": len(sw.plan.ghosts)}
+            if a.role == "direct-child":
+                out["settling_ticks"], out["declined_while_settling"] = settled, declined0
             if got.startswith("direct"):
                 st = sw.world.resident_stats()
                 out["resident_launches"], out["resident_declined"] = int(st[0]), int(st[1])
@@ -653,8 +676,12 @@ def main():
             if agree(not err and got is not None and got.startswith("direct")):
                 import numpy as np
                 verified = False
+                settled, declined0 = 0, 0
                 try:
                     ref = sharded.ShardedWorld(sc2, rank, world_size, lambda p: World(p, stream=stream, fma=a.fma), comm=comm)
+                    settled, declined0 = (settle_resident(sw_in, ref, sc2["steps"], agree) if got == "direct+resident" else (0, 0))
+                    if rank == 0:
+                        line["in_engine_settling"] = {"ticks": settled, "declined_while_settling": declined0}
                     for _ in range(2):  # the same two ticks with the exchange driven from the host: bit-identical beliefs
                         sw_in.iterate(sc2["steps"])
                         ref.iterate(sc2["steps"])
@@ -666,7 +693,7 @@ def main():
                     err, same = f"{type(e).__name__}: {e}", False
                 verified = agree(same)
                 walls_i = devs_i = None
-                if verified and got == "direct+resident" and not agree(sw_in.world.resident_stats()[1] == 0):
+                if verified and got == "direct+resident" and not agree(sw_in.world.resident_stats()[1] == declined0):
                     # (see the probe: declined launches cost a wait each — measure the plain direct transport instead)
                     sw_in.world.set_resident_launches(False)
                     got = "direct"
