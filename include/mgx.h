@@ -422,6 +422,23 @@ int mgx_halo_direct_connect(mgx_world *w, uint32_t n_peers, const uint32_t *send
 int mgx_halo_direct_exchange(mgx_world *w, uint32_t what);
 int mgx_halo_direct_status(mgx_world *w, uint64_t *exchanges, uint64_t *failed_exchange);
 int mgx_halo_direct_disconnect(mgx_world *w);
+/* The same exchange for a world whose exchange lists CHANGE (one that follows its topology: connections across ranks come and
+ * go with robot.rs:1386-1586, mgx_update_topology + mgx_halo_plan_from_connections), wired once:
+ *   mgx_halo_direct_setup_slots: the receive area has `slot_capacity` record slots per parity — one per ghost robot of this rank,
+ *      slot = the robot's place among the rank's ghosts in device order (mgx_halo_ghost_slots; capacity >= their number, room for
+ *      robots that join) — and EVERY other rank is a source (n_sources = ranks - 1), with or without records in an exchange:
+ *      a rank that sends nothing still publishes the exchange number, a rank that receives nothing still waits for all of them
+ *      (that wait is its flow control: nobody gets two exchanges ahead of anybody).
+ *   mgx_halo_direct_connect_slots: after every change of the lists, (re)aims the pushes — peers in the order of the send list's
+ *      segments (one per other rank, possibly empty), and for every entry of the send list the slot of that robot in its
+ *      consumer's area.  Exchange numbers go on across calls. */
+int mgx_halo_direct_setup_slots(mgx_world *w, uint32_t n_sources, uint32_t slot_capacity, void **recv_base, void **flag_base);
+int mgx_halo_ghost_slots(mgx_world *w, uint32_t n, const int32_t *robots, int32_t *slots);
+/* the exchange lists as they stand (robot ids, by peer rank in the order of mgx_halo_plan_from_connections' counts) */
+int mgx_halo_get_lists(mgx_world *w, int32_t *send_robots, uint32_t send_capacity, int32_t *recv_robots, uint32_t recv_capacity,
+                       uint32_t *n_send, uint32_t *n_recv);
+int mgx_halo_direct_connect_slots(mgx_world *w, uint32_t n_peers, const uint32_t *send_first, void *const *peer_recv_base,
+                                  const uint64_t *peer_slot_capacity, const uint32_t *entry_slot, void *const *peer_flag_slot);
 
 /* ---- resident schedule launches on sharded worlds ----------------------------------------------------------------------
  * (replaces, like the exchanges above, the serial external phase and routing of robot.rs:1803-1859 and

@@ -418,10 +418,12 @@ __global__ void __launch_bounds__(256) k_halo_push(DevWorld w, int n, const int3
 // waits for that announcement only, so the whole launch follows ONE decision: either every ghost record of the
 // exchange is unpacked or none is, and once an exchange has failed no later one unpacks anything (the error words
 // are never cleared: the world's beliefs are no longer trusted, mgx_synchronize / mgx_read_* / the next sweep say so).
+// by_slot: the record of ghost robot g sits in slot (g's place among this rank's ghosts) of the receive area, not at its place in the
+// receive list (mgx_halo_direct_setup_slots: a wiring that outlives the lists)
 __global__ void __launch_bounds__(256) k_halo_wait_unpack(DevWorld w, int n, const int32_t *ghosts, const double *recv, int n_sources,
                                                           const unsigned long long *flags, unsigned long long seq,
                                                           unsigned long long *err, long long timeout_ticks, unsigned long long *ready,
-                                                          unsigned long long *host_err) {
+                                                          unsigned long long *host_err, int by_slot) {
     if (blockIdx.x == 0) {
         for (int j = threadIdx.x; j < n_sources; j += blockDim.x) {
             const long long t0 = wall_clock64();
@@ -446,7 +448,8 @@ __global__ void __launch_bounds__(256) k_halo_wait_unpack(DevWorld w, int n, con
     if (t >= n * words) return;
     const int rr = t / words, q = t % words;
     const int v0 = ghosts[rr] * w.K;
-    const double val = __hip_atomic_load(&recv[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const size_t at = by_slot ? (size_t)(ghosts[rr] - w.R_local) * (size_t)words + (size_t)q : (size_t)t;
+    const double val = __hip_atomic_load(&recv[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (q < SNAP_W * w.K)
         w.snap[w.cur][(size_t)v0 * SNAP_W + q] = val;
     else
@@ -726,19 +729,20 @@ hipError_t launch_update_priors(const DevWorld &w, int n, const int32_t *robots,
     return hipGetLastError();
 }
 hipError_t launch_halo_push(const DevWorld &w, int n, const int32_t *robots, const unsigned long long *dst, int n_peers,
-                            const unsigned long long *peer_flags, unsigned long long seq, unsigned int *done, hipStream_t stream) {
-    if (n <= 0) return hipSuccess;
-    const int total = n * (SNAP_W + 1) * w.K;
+                            const unsigned long long *peer_flags, unsigned long long seq, unsigned int *done, hipStream_t stream, bool always) {
+    if (n <= 0 && !always) return hipSuccess;  // (always: a rank with nothing to send still tells every peer the exchange's number)
+    const int total = std::max(n, 0) * (SNAP_W + 1) * w.K + (n <= 0 ? 1 : 0);
     hipLaunchKernelGGL(k_halo_push, dim3((total + 255) / 256), dim3(256), 0, stream, w, n, robots, dst, n_peers, peer_flags, seq, done);
     return hipGetLastError();
 }
 hipError_t launch_halo_wait_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *recv, int n_sources,
                                    const unsigned long long *flags, unsigned long long seq, unsigned long long *err,
-                                   long long timeout_ticks, unsigned long long *ready, unsigned long long *host_err, hipStream_t stream) {
-    if (n <= 0) return hipSuccess;
-    const int total = n * (SNAP_W + 1) * w.K;
-    hipLaunchKernelGGL(k_halo_wait_unpack, dim3((total + 255) / 256), dim3(256), 0, stream, w, n, ghosts, recv, n_sources, flags, seq,
-                       err, timeout_ticks, ready, host_err);
+                                   long long timeout_ticks, unsigned long long *ready, unsigned long long *host_err, hipStream_t stream,
+                                   bool by_slot) {
+    if (n <= 0 && !by_slot) return hipSuccess;  // (slots: a rank that receives nothing still waits for every peer — that is its flow control)
+    const int total = std::max(n, 0) * (SNAP_W + 1) * w.K + (n <= 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_halo_wait_unpack, dim3((total + 255) / 256), dim3(256), 0, stream, w, std::max(n, 0), ghosts, recv, n_sources, flags, seq,
+                       err, timeout_ticks, ready, host_err, by_slot ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t launch_gather_variable_means(const DevWorld &w, int var, double *out, hipStream_t stream) {

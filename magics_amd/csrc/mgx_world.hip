@@ -64,10 +64,11 @@ hipError_t launch_var_tables(int R, int K, const int32_t *in_ptr, const int32_t 
                              hipStream_t stream);
 hipError_t launch_edge_gates(int n, const IrEdgeRec *recs, const uint8_t *antenna, const uint8_t *idle, uint8_t *gate, hipStream_t stream);
 hipError_t launch_halo_push(const DevWorld &w, int n, const int32_t *robots, const unsigned long long *dst, int n_peers,
-                            const unsigned long long *peer_flags, unsigned long long seq, unsigned int *done, hipStream_t stream);
+                            const unsigned long long *peer_flags, unsigned long long seq, unsigned int *done, hipStream_t stream, bool always);
 hipError_t launch_halo_wait_unpack(const DevWorld &w, int n, const int32_t *ghosts, const double *recv, int n_sources,
                                    const unsigned long long *flags, unsigned long long seq, unsigned long long *err,
-                                   long long timeout_ticks, unsigned long long *ready, unsigned long long *host_err, hipStream_t stream);
+                                   long long timeout_ticks, unsigned long long *ready, unsigned long long *host_err, hipStream_t stream,
+                                   bool by_slot);
 // mgx_topology.hip
 int env_red_plane(const mgx_env_desc *d, uint32_t resolution, float expansion, float blur_percent, bool with_blur, hipStream_t s,
                   std::vector<uint8_t> &red, uint32_t &W, uint32_t &H);  // mgx_env.hip
@@ -525,6 +526,10 @@ struct mgx_world {
         size_t recv_words = 0;
         int n_sources = 0, n_peers = 0;
         bool connected = false;
+        // a wiring that survives changes of the exchange lists (mgx_halo_direct_setup_slots): one record slot per ghost robot —
+        // slot = the robot's place among this rank's ghosts — instead of one per entry of the receive list
+        bool by_slot = false;
+        size_t slot_cap = 0;
         unsigned long long seq = 0, push_seq = 0;  // exchanges waited for / pushed
         long long timeout_ticks = 500000000ll;  // 5 s of the 100 MHz wall clock
         DevBuf<unsigned long long> dst[2], peer_flags, ready;  // ready: the exchange workgroup 0 of the wait kernel has announced
@@ -3272,6 +3277,18 @@ int mgx_halo_plan_from_connections(mgx_world *w, const int32_t *rank_of, uint32_
     return MGX_OK;
 }
 
+// the exchange lists as they stand (robot ids; send list by consumer rank, receive list by producer rank — the order of the counts
+// mgx_halo_plan_from_connections returned): n_send / n_recv receive the lengths, the arrays are filled up to their capacities
+int mgx_halo_get_lists(mgx_world *w, int32_t *send_robots, uint32_t send_capacity, int32_t *recv_robots, uint32_t recv_capacity,
+                       uint32_t *n_send, uint32_t *n_recv) {
+    if (!w || !n_send || !n_recv) return fail(MGX_ERR_INVALID, "null argument");
+    *n_send = (uint32_t)w->halo_send.size();
+    *n_recv = (uint32_t)w->halo_recv.size();
+    if (send_robots) for (size_t i = 0; i < w->halo_send.size() && i < send_capacity; i++) send_robots[i] = w->halo_send[i];
+    if (recv_robots) for (size_t i = 0; i < w->halo_recv.size() && i < recv_capacity; i++) recv_robots[i] = w->halo_recv[i];
+    return MGX_OK;
+}
+
 static int halo_commit(mgx_world *w) {
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     // Changed connections alone (conns_dirty) are left to the next sweep: an exchange does not read the
@@ -3306,7 +3323,7 @@ static int direct_push(mgx_world *w) {
     dh.push_seq += 1;
     const int par = (int)(dh.push_seq & 1ull);
     HIP_TRY(launch_halo_push(w->d, (int)w->halo_send.size(), w->halo_send_dev.p, dh.dst[par].p, dh.n_peers, dh.peer_flags.p, dh.push_seq,
-                             dh.done.p, w->stream));
+                             dh.done.p, w->stream, dh.by_slot));
     return MGX_OK;
 }
 static int direct_wait(mgx_world *w) {
@@ -3318,7 +3335,7 @@ static int direct_wait(mgx_world *w) {
     const int par = (int)(dh.seq & 1ull);
     HIP_TRY(launch_halo_wait_unpack(w->d, (int)w->halo_recv.size(), w->halo_recv_dev.p, dh.recv + (size_t)par * dh.recv_words,
                                     dh.n_sources, dh.flags, dh.seq, dh.flags + dh.n_sources, dh.timeout_ticks, dh.ready.p, w->d.sweep_err,
-                                    w->stream));
+                                    w->stream, dh.by_slot));
     return MGX_OK;
 }
 static int direct_exchange(mgx_world *w) {
@@ -3401,6 +3418,7 @@ int mgx_halo_direct_setup(mgx_world *w, uint32_t n_sources, void **recv_base, vo
     mgx_world::DirectHalo &dh = w->direct;
     HIP_TRY(hipStreamSynchronize(w->stream));
     dh.connected = false;
+    dh.by_slot = false;
     if (dh.recv) { (void)hipFree(dh.recv); dh.recv = nullptr; }
     if (dh.flags) { (void)hipFree(dh.flags); dh.flags = nullptr; }
     dh.recv_words = w->halo_recv.size() * (size_t)mgx_halo_words((uint32_t)w->K);
@@ -3461,6 +3479,98 @@ int mgx_halo_direct_connect(mgx_world *w, uint32_t n_peers, const uint32_t *send
     HIP_TRY(hipStreamSynchronize(w->stream));
     dh.n_peers = (int)n_peers;
     dh.seq = dh.push_seq = 0;
+    dh.connected = true;
+    return MGX_OK;
+}
+
+// The same exchange wired ONCE for a world whose exchange lists change (worlds that follow their topology, include/mgx.h): the
+// receive area holds `slot_capacity` record slots per parity, slot g = the g-th ghost robot of this rank in device order
+// (mgx_halo_ghost_slots), and EVERY other rank is a source — with or without records in a given exchange.
+int mgx_halo_direct_setup_slots(mgx_world *w, uint32_t n_sources, uint32_t slot_capacity, void **recv_base, void **flag_base) {
+    if (!w || !recv_base || !flag_base) return fail(MGX_ERR_INVALID, "null argument");
+    int rc = halo_commit(w);
+    if (rc != MGX_OK) return rc;
+    const size_t NG = (size_t)(w->d.R_total - w->d.R_local);
+    if ((size_t)slot_capacity < NG) return fail(MGX_ERR_INVALID, "%u slots for %zu ghost robots", slot_capacity, NG);
+    mgx_world::DirectHalo &dh = w->direct;
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    dh.connected = false;
+    if (dh.recv) { (void)hipFree(dh.recv); dh.recv = nullptr; }
+    if (dh.flags) { (void)hipFree(dh.flags); dh.flags = nullptr; }
+    dh.by_slot = true;
+    dh.slot_cap = slot_capacity;
+    dh.recv_words = (size_t)slot_capacity * (size_t)mgx_halo_words((uint32_t)w->K);
+    dh.n_sources = (int)n_sources;
+    const size_t rb = std::max<size_t>(2 * dh.recv_words, 1) * sizeof(double), fb = ((size_t)n_sources + 1) * sizeof(unsigned long long);
+    HIP_TRY(hipExtMallocWithFlags((void **)&dh.recv, rb, hipDeviceMallocFinegrained));
+    HIP_TRY(hipExtMallocWithFlags((void **)&dh.flags, fb, hipDeviceMallocFinegrained));
+    HIP_TRY(hipMemsetAsync(dh.recv, 0, rb, w->stream));
+    HIP_TRY(hipMemsetAsync(dh.flags, 0, fb, w->stream));
+    {
+        std::vector<unsigned long long> z(1, 0ull);
+        HIP_TRY(dh.ready.upload(z, w->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    if (w->sweep_err_host) *w->sweep_err_host = 0ull;
+    dh.seq = dh.push_seq = 0;
+    if (const char *ms = getenv("MGX_HALO_TIMEOUT_MS")) {
+        const long long v = atoll(ms);
+        if (v > 0) dh.timeout_ticks = v * 100000ll;
+    }
+    *recv_base = dh.recv;
+    *flag_base = dh.flags;
+    return MGX_OK;
+}
+
+// slot of every listed robot among this rank's ghosts (-1: not a ghost here) — what the robot's owner stores its record into
+int mgx_halo_ghost_slots(mgx_world *w, uint32_t n, const int32_t *robots, int32_t *slots) {
+    if (!w || (n && (!robots || !slots))) return fail(MGX_ERR_INVALID, "null argument");
+    int rc = halo_commit(w);
+    if (rc != MGX_OK) return rc;
+    for (uint32_t i = 0; i < n; i++) {
+        const int32_t g = robots[i];
+        if (g < 0 || (size_t)g >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id %d", g);
+        slots[i] = w->robots[(size_t)g].ghost ? w->dev_of[(size_t)g] - w->d.R_local : -1;
+    }
+    return MGX_OK;
+}
+
+// (Re)aim the pushes after the exchange lists changed (mgx_halo_plan / mgx_halo_plan_from_connections): peers in the order of the
+// send list's segments — every other rank, an empty segment for a rank that takes nothing now — and for every entry of the send
+// list the slot of that robot in its consumer's area.  The exchange numbers go on: both ends keep counting.
+int mgx_halo_direct_connect_slots(mgx_world *w, uint32_t n_peers, const uint32_t *send_first, void *const *peer_recv_base,
+                                  const uint64_t *peer_slot_capacity, const uint32_t *entry_slot, void *const *peer_flag_slot) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    mgx_world::DirectHalo &dh = w->direct;
+    if (!dh.flags || !dh.by_slot) return fail(MGX_ERR_STATE, "mgx_halo_direct_setup_slots first");
+    if (n_peers && (!send_first || !peer_recv_base || !peer_slot_capacity || !peer_flag_slot)) return fail(MGX_ERR_INVALID, "null argument");
+    if ((int)n_peers != dh.n_sources) return fail(MGX_ERR_INVALID, "%u consumers but %d producers: every other rank is both", n_peers, dh.n_sources);
+    int rc = halo_commit(w);
+    if (rc != MGX_OK) return rc;
+    const size_t n_send = w->halo_send.size(), words = (size_t)mgx_halo_words((uint32_t)w->K);
+    if (n_peers && (send_first[0] != 0 || send_first[n_peers] != n_send)) return fail(MGX_ERR_INVALID, "send_first does not cover the send list");
+    if (n_send && !entry_slot) return fail(MGX_ERR_INVALID, "null argument");
+    std::vector<unsigned long long> d0(std::max<size_t>(n_send, 1), 0ull), d1(std::max<size_t>(n_send, 1), 0ull), pf(std::max<size_t>(n_peers, 1), 0ull);
+    for (uint32_t p = 0; p < n_peers; p++) {
+        if (send_first[p + 1] < send_first[p]) return fail(MGX_ERR_INVALID, "send_first is not ascending");
+        if (!peer_recv_base[p] || !peer_flag_slot[p]) return fail(MGX_ERR_INVALID, "peer %u: null address", p);
+        const unsigned long long base = (unsigned long long)(uintptr_t)peer_recv_base[p];
+        for (uint32_t i = send_first[p]; i < send_first[p + 1]; i++) {
+            if ((uint64_t)entry_slot[i] >= peer_slot_capacity[p]) return fail(MGX_ERR_INVALID, "entry %u: slot %u beyond the peer's %llu", i, entry_slot[i], (unsigned long long)peer_slot_capacity[p]);
+            d0[i] = base + (0ull * peer_slot_capacity[p] + entry_slot[i]) * words * sizeof(double);
+            d1[i] = base + (1ull * peer_slot_capacity[p] + entry_slot[i]) * words * sizeof(double);
+        }
+        pf[p] = (unsigned long long)(uintptr_t)peer_flag_slot[p];
+    }
+    HIP_TRY(dh.dst[0].upload(d0, w->stream));
+    HIP_TRY(dh.dst[1].upload(d1, w->stream));
+    HIP_TRY(dh.peer_flags.upload(pf, w->stream));
+    if (!dh.connected) {
+        std::vector<unsigned int> zero(1, 0u);
+        HIP_TRY(dh.done.upload(zero, w->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    dh.n_peers = (int)n_peers;
     dh.connected = true;
     return MGX_OK;
 }

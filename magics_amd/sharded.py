@@ -187,6 +187,11 @@ class ShardedWorld:
         plan, words = self.plan, self.world.halo_words(self.plan.K)
         sc_, rc_ = self.world.halo_plan_from_connections(plan.owner, plan.rank, plan.world_size)
         self.send_counts, self.recv_counts = [c * words for c in sc_], [c * words for c in rc_]
+        self._send_counts_robots = [int(c) for c in sc_]
+        if getattr(self, "_slot_wiring", None) is not None:
+            if len(plan.owner) == self._slot_robots:
+                self._aim_slots()  # the exchange lives in the engine: only the pushes' destinations follow the lists
+            return  # (robots joined: the areas are wired again by whoever drives the ranks — connect_slots / LocalCluster)
         for name, need in (("send_buf", sum(self.send_counts)), ("recv_buf", sum(self.recv_counts))):
             buf = getattr(self, name)
             if buf is None or buf.numel() < max(1, need):
@@ -201,7 +206,10 @@ class ShardedWorld:
         if out[1] or out[2]:
             self.replan()
             if self.comm is not None:
-                self.exchange()
+                if self.direct:
+                    self.world.halo_direct_exchange()  # (in the engine: push, then wait for every peer's)
+                else:
+                    self.exchange()
         return out
 
     # per-tick calls of a driver over global robot ids: every rank runs the same driver (replicated
@@ -291,6 +299,69 @@ class ShardedWorld:
         self.world.halo_direct_connect(first, base, nrec, off, slot)
         self.direct = True
 
+    # -- the direct exchange of a world that FOLLOWS ITS TOPOLOGY: wired once, re-aimed when the lists change -----
+    def direct_setup_slots(self, export_ipc, spare=64):
+        """Allocate a receive area with one record slot per ghost robot (every robot another rank owns: they are all ghosts on a
+        world that follows its topology) + `spare` for robots that join; returns what the peers need: where it is, its capacity
+        and the slot of every robot in it."""
+        assert self.dynamic
+        plan, ws = self.plan, self.plan.world_size
+        n = len(plan.owner)
+        slots = self.world.halo_ghost_slots(np.arange(n, dtype=np.int32))
+        cap = int((slots >= 0).sum()) + int(spare)
+        recv, flags = self.world.halo_direct_setup_slots(ws - 1, cap)
+        sources = [p for p in range(ws) if p != plan.rank]
+        info = dict(rank=plan.rank, capacity=cap, slots=slots, slot={p: j for j, p in enumerate(sources)}, n_robots=n)
+        if export_ipc:
+            info["recv_handle"], info["flags_handle"] = hostlib.ipc_export(recv), hostlib.ipc_export(flags)
+        else:
+            info["recv_ptr"], info["flags_ptr"] = recv, flags
+        return info
+
+    def direct_connect_slots(self, infos):
+        """infos[q]: what rank q published in direct_setup_slots (handles are opened here, once)."""
+        plan = self.plan
+        self._opened = getattr(self, "_opened", [])
+        wiring = {}
+        for q in range(plan.world_size):
+            if q == plan.rank:
+                continue
+            inf = infos[q]
+            if "recv_ptr" in inf:
+                r, f = inf["recv_ptr"], inf["flags_ptr"]
+            else:
+                r, f = hostlib.ipc_open(inf["recv_handle"]), hostlib.ipc_open(inf["flags_handle"])
+                self._opened += [r, f]
+            wiring[q] = dict(recv=r, flag=f + 8 * inf["slot"][plan.rank], capacity=inf["capacity"], slots=np.asarray(inf["slots"]))
+        self._slot_wiring = wiring
+        self._slot_robots = len(plan.owner)
+        self.direct = True
+        self.transport = "direct"
+        self.replan()  # (aims the pushes)
+
+    def _aim_slots(self):
+        """send list -> (peer segments, slot of every entry in its consumer's area): after every change of the lists"""
+        plan, wiring = self.plan, self._slot_wiring
+        if len(plan.owner) != self._slot_robots:
+            raise hostlib.MgxError("robots joined since the direct exchange was wired: wire it again (direct_setup_slots / direct_connect_slots)")
+        peers = [q for q in range(plan.world_size) if q != plan.rank]
+        send = self.world.halo_send_list()
+        first, slot = [0], []
+        k = 0
+        for q, cnt in ((q, self._send_counts_robots[q]) for q in range(plan.world_size)):
+            if q == plan.rank:
+                assert cnt == 0
+                continue
+            for g in send[k:k + cnt]:
+                sl = int(wiring[q]["slots"][g])
+                assert sl >= 0, (g, q)
+                slot.append(sl)
+            k += cnt
+            first.append(k)
+        assert k == len(send)
+        self.world.halo_direct_connect_slots(first, [wiring[q]["recv"] for q in peers], [wiring[q]["capacity"] for q in peers], slot,
+                                             [wiring[q]["flag"] for q in peers])
+
     # -- resident schedule launches: ghost records travel INSIDE the launches ---------------------------
     def resident_setup(self, export_ipc):
         """Allocate this rank's ghost area (after the direct exchange is wired); returns what the peers need to know:
@@ -352,6 +423,7 @@ class ShardedWorld:
         for ptr in getattr(self, "_opened", []) + getattr(self, "_opened_areas", []):
             hostlib.ipc_close(ptr)
         self._opened, self._opened_areas = [], []
+        self._slot_wiring = None
 
     def resident_close(self):
         """The ghost areas only (the direct exchange stays wired).  Call on every rank, after a barrier."""
@@ -557,9 +629,10 @@ def connect(sw, comm, transport="auto", resident=True):
             break
         try:
             if t == "direct":
+                slots = bool(getattr(sw, "dynamic", False))  # a world that follows its topology: one slot per ghost robot
                 info, err = None, None
                 try:
-                    info = sw.direct_setup(export_ipc=True)
+                    info = sw.direct_setup_slots(export_ipc=True) if slots else sw.direct_setup(export_ipc=True)
                 except Exception as e:  # noqa: BLE001
                     err = e
                 infos = comm.all_gather_object(info)
@@ -568,14 +641,17 @@ def connect(sw, comm, transport="auto", resident=True):
                     sw.direct_close()  # the ranks whose set-up succeeded free their areas (nobody has mapped them yet)
                     continue
                 try:
-                    sw.direct_connect({i["rank"]: i for i in infos})
+                    if slots:
+                        sw.direct_connect_slots({i["rank"]: i for i in infos})
+                    else:
+                        sw.direct_connect({i["rank"]: i for i in infos})
                     ok = True
                 except Exception:  # noqa: BLE001
                     ok = False
                 if all_ok(ok):
                     comm.barrier()
                     sw.transport = "direct"
-                    if resident:
+                    if resident and not slots:
                         _connect_resident(sw, comm, all_ok)
                     return sw.transport
                 comm.barrier()
@@ -653,12 +729,16 @@ class LocalCluster:
         a shared stream before the other rank's stores are even enqueued.
         dynamic=True: worlds that follow their topology (see ShardedWorld); the cluster then also
         offers the per-tick calls of magics_amd.driver.Driver over global robot ids."""
-        assert not (direct and dynamic)
+        assert not (resident and dynamic)
         self.ranks = [ShardedWorld(sc, r, world_size, world_factory, comm=None, owner=owner,
                                    tensor_factory=tensor_factory, dynamic=dynamic) for r in range(world_size)]
         self.n_robots, self.K = len(sc["robots"]), sc.get("K")
         self.resident = False
-        if direct and world_size > 1:
+        self.direct_slots = bool(direct and dynamic and world_size > 1)
+        if self.direct_slots:
+            if self.K is not None:
+                self._wire_slots()
+        elif direct and world_size > 1:
             infos = {sw.plan.rank: sw.direct_setup(export_ipc=False) for sw in self.ranks}
             for sw in self.ranks:
                 sw.direct_connect(infos)
@@ -674,7 +754,22 @@ class LocalCluster:
                     self.resident = True
                     self.agree = agree
 
+    def _wire_slots(self):
+        """the direct exchange of a cluster that follows its topology: one record slot per ghost robot, aimed again by every
+        rank's replan (ShardedWorld.direct_setup_slots / direct_connect_slots); wired again when robots join"""
+        for sw in self.ranks:
+            sw.synchronize()
+        infos = {sw.plan.rank: sw.direct_setup_slots(export_ipc=False) for sw in self.ranks}
+        for sw in self.ranks:
+            sw.direct_connect_slots(infos)
+
     def _exchange(self):
+        if self.direct_slots and self.ranks[0].direct:  # in the engines: all pushes before the first wait (one thread drives all ranks)
+            for sw in self.ranks:
+                sw.world.halo_direct_exchange(hostlib.HALO_PUSH)
+            for sw in self.ranks:
+                sw.world.halo_direct_exchange(hostlib.HALO_WAIT)
+            return
         for sw in self.ranks:
             sw.pack()
         for sw in self.ranks:
@@ -736,6 +831,8 @@ class LocalCluster:
         ids = [sw.add_robot(mean0, prior_diag, dt, radius, path=path, owner=owner, order_key=order_key) for sw in self.ranks]
         assert all(i == ids[0] for i in ids)
         self.n_robots, self.K = ids[0] + 1, np.asarray(mean0).shape[0]
+        if self.direct_slots:
+            self._wire_slots()  # (a robot more: every rank's area has a slot more, or the robot a slot in the others')
         return ids[0]
 
     def tick(self, robots, waypoints_xy, time_scale, what, max_speed, delta_t, steps):

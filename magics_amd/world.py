@@ -383,6 +383,36 @@ class World:
         assert a.size == n + 1 and b.size == c.size == d.size == e.size == n
         self._chk(self._L.mgx_halo_direct_connect(self._w, n, a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, e.ctypes.data))
 
+    def halo_direct_setup_slots(self, n_sources, slot_capacity):
+        """a receive area with one record slot per ghost robot (a wiring that outlives the exchange lists)"""
+        recv, flags = C.c_void_p(), C.c_void_p()
+        self._chk(self._L.mgx_halo_direct_setup_slots(self._w, n_sources, slot_capacity, C.byref(recv), C.byref(flags)))
+        return recv.value, flags.value
+
+    def halo_ghost_slots(self, robots):
+        r = np.ascontiguousarray(robots, dtype=np.int32)
+        out = np.zeros(r.size, dtype=np.int32)
+        self._chk(self._L.mgx_halo_ghost_slots(self._w, r.size, r.ctypes.data, out.ctypes.data))
+        return out
+
+    def halo_send_list(self):
+        """robot ids of the send list as it stands (by consumer rank)"""
+        ns, nr = C.c_uint32(), C.c_uint32()
+        self._chk(self._L.mgx_halo_get_lists(self._w, None, 0, None, 0, C.byref(ns), C.byref(nr)))
+        out = np.zeros(max(ns.value, 1), dtype=np.int32)
+        self._chk(self._L.mgx_halo_get_lists(self._w, out.ctypes.data, ns.value, None, 0, C.byref(ns), C.byref(nr)))
+        return [int(x) for x in out[:ns.value]]
+
+    def halo_direct_connect_slots(self, send_first, peer_recv_base, peer_slot_capacity, entry_slot, peer_flag_slot):
+        n = len(peer_recv_base)
+        a = np.ascontiguousarray(send_first, dtype=np.uint32)
+        b = np.ascontiguousarray(peer_recv_base, dtype=np.uint64)
+        c = np.ascontiguousarray(peer_slot_capacity, dtype=np.uint64)
+        d = np.ascontiguousarray(entry_slot, dtype=np.uint32)
+        e = np.ascontiguousarray(peer_flag_slot, dtype=np.uint64)
+        assert a.size == n + 1 and b.size == c.size == e.size == n and d.size == int(a[-1])
+        self._chk(self._L.mgx_halo_direct_connect_slots(self._w, n, a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, e.ctypes.data))
+
     def halo_direct_exchange(self, what=hostlib.HALO_PUSH | hostlib.HALO_WAIT):
         self._chk(self._L.mgx_halo_direct_exchange(self._w, what))
 

@@ -1,7 +1,9 @@
 """One rank of the multi-process dynamic-topology test (tests/test_gpu_sharded_topology_mp.py): every
 rank is its own process on cuda:0 with a sharded world that follows its topology; the control plane
 and the halo all-to-all-v go through gloo (device buffers staged through the host — a dry run of the
-RCCL path).  Every rank runs the same driver.  usage: dynamic_topology_worker.py RANK WORLD_SIZE PORT OUT.npz"""
+RCCL path), or — mode "direct" — the exchange lives in the engines: peer-mapped stores (hipIpc) into one record slot per ghost
+robot, wired once, re-aimed when the lists change.  Every rank runs the same driver.
+usage: dynamic_topology_worker.py RANK WORLD_SIZE PORT OUT.npz [collective|direct]"""
 import os
 import sys
 
@@ -11,6 +13,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, ws, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    mode = sys.argv[5] if len(sys.argv) > 5 else "collective"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(ws))
     import numpy as np
     import torch
@@ -23,14 +26,21 @@ def main():
     sc = S.circle_scenario(n, K, circle_radius=12.0, n_internal=10, n_external=10)
     sc["ir"] = []
     comm = sharded.TorchDistComm(stage_through_host=True)
-    sw = sharded.ShardedWorld(sc, rank, ws, World, comm=comm, owner=np.arange(n) % ws, dynamic=True)
+    stream = torch.cuda.Stream()
+    sw = sharded.ShardedWorld(sc, rank, ws, lambda p: World(p, stream=stream.cuda_stream), comm=comm, owner=np.arange(n) % ws, dynamic=True)
+    if mode == "direct":
+        got = sharded.connect(sw, comm, "direct")
+        assert got == "direct" and sw.direct, got
     drv = Driver(sw, n, K, waypoints=[[tuple(rb["goal"])] for rb in sc["robots"]], radii=[rb["radius"] for rb in sc["robots"]],
                  t0=[rb["t0"] for rb in sc["robots"]], steps=sc["steps"], comms_radius=12.0, target_speed=sc["target_speed"])
     events = [drv.tick() for _ in range(ticks)]
     ids, eta, lam, mu = sw.read_beliefs()
-    np.savez(out, ids=np.array(ids), eta=eta, lam=lam, mu=mu, events=np.array(events), translation=drv.translation,
+    exchanges = sw.world.halo_direct_status() if mode == "direct" else 0  # (raises if one of them timed out)
+    np.savez(out, exchanges=exchanges, ids=np.array(ids), eta=eta, lam=lam, mu=mu, events=np.array(events), translation=drv.translation,
              finished_at=drv.finished_at, next_number=drv.next_number)
     dist.barrier()
+    if mode == "direct":
+        sw.direct_close()
     dist.destroy_process_group()
 
 

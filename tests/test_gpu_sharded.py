@@ -162,17 +162,24 @@ def _circle_driver(w, sc, n, K, **kw):
                   t0=[rb["t0"] for rb in sc["robots"]], steps=sc["steps"], comms_radius=12.0, target_speed=sc["target_speed"], **kw)
 
 
-@pytest.mark.parametrize("world_size", [2, 3])
-def test_sharded_world_follows_its_topology(world_size):
+@pytest.mark.parametrize("world_size,direct", [(2, False), (3, False), (2, True), (3, True)])
+def test_sharded_world_follows_its_topology(world_size, direct):
     """A whole mission on a sharded world that follows its topology: robots cross a circle, connect and
     disconnect across rank boundaries, arrive and despawn.  Every rank replays the connection
     bookkeeping on all positions; exchange lists follow the connections.  Topology events, robot
-    numbers, trajectories and beliefs equal the single-world oracle's, tick by tick."""
+    numbers, trajectories and beliefs equal the single-world oracle's, tick by tick.
+    direct: the exchange lives in the engines (peer-mapped stores into one record slot per ghost robot, wired ONCE and re-aimed
+    whenever the lists change — mgx_halo_direct_setup_slots / _connect_slots): no host-driven all-to-all in any tick."""
     n, K = 9, 10
     sc = S.circle_scenario(n, K, circle_radius=12.0, n_internal=10, n_external=10)
     sc["ir"] = []
     owner = np.arange(n) % world_size  # interleaved ownership: every neighbour pair crosses a rank boundary sooner or later
-    cluster = sharded.LocalCluster(sc, world_size, World, owner=owner, dynamic=True)
+    if direct:
+        make, _streams = _own_stream_factory()
+        cluster = sharded.LocalCluster(sc, world_size, make, owner=owner, dynamic=True, direct=True)
+        assert all(sw.direct and sw.transport == "direct" for sw in cluster.ranks)
+    else:
+        cluster = sharded.LocalCluster(sc, world_size, World, owner=owner, dynamic=True)
     ref = oracle.OracleWorld(sc["params"])
     S.populate(ref, sc)
     dc, dr = _circle_driver(cluster, sc, n, K), _circle_driver(ref, sc, n, K)
@@ -195,6 +202,9 @@ def test_sharded_world_follows_its_topology(world_size):
     assert sum(c for c, _ in events) > n and sum(d for _, d in events) > 0   # connections came and went
     assert len(plans) > 3                                                      # and the exchange lists with them
     assert dc.summary()["messages"] == dr.summary()["messages"]               # MessageCount of every graph, from its owner's rank
+    if direct:
+        for sw in cluster.ranks:
+            assert sw.world.halo_direct_status() > 100  # exchanges inside the engine, none of them timed out
 
 
 def test_sharded_topology_with_comms_failures_and_initial_connections():

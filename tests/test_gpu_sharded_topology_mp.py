@@ -23,12 +23,15 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-def test_two_processes_follow_the_topology(tmp_path):
+@pytest.mark.parametrize("mode", ["collective", "direct"])
+def test_two_processes_follow_the_topology(tmp_path, mode):
+    """mode "direct": the exchange inside the engines (hipIpc-mapped record slots, one per ghost robot, re-aimed after every topology
+    pass that changed the lists) — no host-driven all-to-all in any tick"""
     ws, n, K, ticks = 2, 8, 10, 60
     port = _free_port()
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(ws)]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dynamic_topology_worker.py"), str(r), str(ws), port, outs[r]],
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MGX_HALO_TIMEOUT_MS="20000")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dynamic_topology_worker.py"), str(r), str(ws), port, outs[r], mode],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(ws)]
     logs = []
     try:
@@ -53,6 +56,7 @@ def test_two_processes_follow_the_topology(tmp_path):
     seen = 0
     for o in outs:
         z = np.load(o)
+        assert (int(z["exchanges"]) > ticks) == (mode == "direct")
         assert np.array_equal(z["events"], events) and np.array_equal(z["translation"], drv.translation)
         assert np.array_equal(z["finished_at"], drv.finished_at) and int(z["next_number"]) == drv.next_number
         for j, g in enumerate(z["ids"]):
