@@ -164,6 +164,7 @@ extern "C" {
     pub fn mgx_halo_direct_disconnect(w: *mut mgx_world) -> c_int;
     pub fn mgx_halo_direct_setup_slots(w: *mut mgx_world, n_sources: u32, slot_capacity: u32, recv_base: *mut *mut c_void, flag_base: *mut *mut c_void) -> c_int;
     pub fn mgx_halo_ghost_slots(w: *mut mgx_world, n: u32, robots: *const i32, slots: *mut i32) -> c_int;
+    pub fn mgx_halo_get_lists(w: *mut mgx_world, send_robots: *mut i32, send_capacity: u32, recv_robots: *mut i32, recv_capacity: u32, n_send: *mut u32, n_recv: *mut u32) -> c_int;
     pub fn mgx_halo_direct_connect_slots(w: *mut mgx_world, n_peers: u32, send_first: *const u32, peer_recv_base: *const *mut c_void, peer_slot_capacity: *const u64, entry_slot: *const u32, peer_flag_slot: *const *mut c_void) -> c_int;
     pub fn mgx_halo_resident_setup(w: *mut mgx_world, area_base: *mut *mut c_void, n_ghost_slots: *mut u32, parity: *mut u32, segment_count: *mut u64, recv_slots: *mut i32, eligible: *mut i32) -> c_int;
     pub fn mgx_halo_resident_connect(w: *mut mgx_world, n_targets: u32, robots: *const i32, peer_area_base: *const *mut c_void, peer_ghost_slots: *const u32, peer_slot: *const u32, peer_parity: *const u32, peer_segment_count: *const u64, coordinator_area: *mut c_void, n_ranks: u32) -> c_int;
