@@ -482,6 +482,18 @@ int mgx_halo_resident_connect(mgx_world *w, uint32_t n_targets, const int32_t *r
                               const uint32_t *peer_ghost_slots, const uint32_t *peer_slot, const uint32_t *peer_parity,
                               const uint64_t *peer_segment_count, void *coordinator_area, uint32_t n_ranks);
 int mgx_halo_resident_disconnect(mgx_world *w);
+/* The same for a world whose exchange lists CHANGE (one that follows its topology; with mgx_halo_direct_setup_slots for the
+ * exchanges in front of launches): mgx_halo_resident_setup as above — `eligible` 2 says "everything but inter-robot factors is
+ * there": they may come later, and every schedule is decided where the ranks agree — then ONCE
+ *   mgx_halo_resident_connect_peers: every other rank's area, number of ghost slots, parity and segment count (what translates
+ *      this rank's counts into each peer's is settled here), the coordinator area and the number of ranks as above;
+ * and after every change of the lists, on every rank, with all ranks' launches through (synchronise, barrier):
+ *   mgx_halo_resident_aim: (local robot, index of the peer in connect_peers' order, the robot's ghost slot there) per boundary
+ *      robot and rank that now holds it as a ghost; the progress words of this rank's own ghosts start over at "through with
+ *      everything so far" (a robot that has just become a neighbour across ranks never stored one here). */
+int mgx_halo_resident_connect_peers(mgx_world *w, uint32_t n_peers, void *const *peer_area_base, const uint32_t *peer_ghost_slots,
+                                    const uint32_t *peer_parity, const uint64_t *peer_segment_count, void *coordinator_area, uint32_t n_ranks);
+int mgx_halo_resident_aim(mgx_world *w, uint32_t n_targets, const int32_t *robots, const uint32_t *peer_index, const uint32_t *peer_slot);
 /* What became of the resident launch the last mgx_iterate enqueued (it decides within microseconds of its start whether it goes
  * ahead: residency census, and on sharded worlds the ranks' agreement above).  Waits for that decision.
  *   MGX_RESIDENT_NONE      nothing was pending (the call ran launch by launch, or its outcome has been taken already)

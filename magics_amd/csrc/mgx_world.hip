@@ -543,6 +543,10 @@ struct mgx_world {
         int n_ghosts = 0;
         bool connected = false;
         bool wired = false;  // connect has run and disconnect has not: the peers may hold `area` mapped and store into it
+        // a wiring that outlives the exchange lists (mgx_halo_resident_connect_peers / _aim): what translates this rank's parity and
+        // segment count into each peer's, settled once when the ranks connect
+        struct Peer { unsigned long long base = 0; size_t n_slots = 0; unsigned x = 0; unsigned long long flag_delta = 0; };
+        std::vector<Peer> peers;
         DevBuf<int32_t> xp_ptr;
         DevBuf<XPushRec> xp_rec;
         // the ranks' agreement on every schedule's launches (SegPlan::agree_seq): the word (in rank 0's area), the number of
@@ -3642,9 +3646,9 @@ int mgx_halo_resident_setup(mgx_world *w, void **area_base, uint32_t *n_ghost_sl
     const DevWorld &d = w->d;
     const int NG = d.R_total - d.R_local;
     // can this rank run its schedules as resident launches at all?
-    bool ok = resident_enabled() && d.ir_max_edges > 0 && !w->conns.empty() && (w->p.enable_mask & 2u) &&
-              sweep_lds_bytes(w->K, d.ir_max_edges, true) <= sweep_resident_lds_max();
-    if (ok) {
+    const bool has_factors = d.ir_max_edges > 0 && !w->conns.empty();
+    bool ok = resident_enabled() && (w->p.enable_mask & 2u) && sweep_lds_bytes(w->K, d.ir_max_edges, true) <= sweep_resident_lds_max();
+    if (ok && has_factors) {
         if (w->resident_cap_sharded < 0) w->resident_cap_sharded = sweep_resident_capacity(d, true);
         ok = d.R_local + 1 <= w->resident_cap_sharded;  // (+ the launch's decider workgroup)
     }
@@ -3666,7 +3670,9 @@ int mgx_halo_resident_setup(mgx_world *w, void **area_base, uint32_t *n_ghost_sl
     *n_ghost_slots = (uint32_t)NG;
     *parity = (uint32_t)d.cur;
     *segment_count = w->flag_base;
-    *eligible = ok ? 1 : 0;
+    // 2: everything but inter-robot factors is there — a world that follows its topology may get them later (every schedule is then
+    // decided where the ranks agree: a rank that cannot run one as a resident launch says so there)
+    *eligible = ok ? (has_factors ? 1 : 2) : 0;
     return MGX_OK;
 }
 
@@ -3722,12 +3728,93 @@ int mgx_halo_resident_connect(mgx_world *w, uint32_t n_targets, const int32_t *r
     return MGX_OK;
 }
 
+// The same wiring for a world whose exchange lists change (one that follows its topology): the peers ONCE — every other rank's
+// ghost area, its number of ghost slots, its buffer parity and segment count as ITS setup returned them — and, after every change of
+// the lists, which local robot's records go into which slot of which peer (mgx_halo_resident_aim).
+int mgx_halo_resident_connect_peers(mgx_world *w, uint32_t n_peers, void *const *peer_area_base, const uint32_t *peer_ghost_slots,
+                                    const uint32_t *peer_parity, const uint64_t *peer_segment_count, void *coordinator_area, uint32_t n_ranks) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    if (n_ranks > 0x3fffu) return fail(MGX_ERR_INVALID, "at most %u ranks", 0x3fffu);
+    if (n_peers && (!peer_area_base || !peer_ghost_slots || !peer_parity || !peer_segment_count)) return fail(MGX_ERR_INVALID, "null argument");
+    mgx_world::ResidentHalo &xr = w->xres;
+    if (!xr.area) return fail(MGX_ERR_STATE, "mgx_halo_resident_setup first");
+    if (!w->dev_valid || w->dirty) return fail(MGX_ERR_STATE, "the world's layout changed since mgx_halo_resident_setup");
+    DevWorld &d = w->d;
+    xr.peers.assign(n_peers, mgx_world::ResidentHalo::Peer());
+    for (uint32_t p = 0; p < n_peers; p++) {
+        if (!peer_area_base[p] || peer_parity[p] > 1u) return fail(MGX_ERR_INVALID, "peer %u: bad area / parity", p);
+        xr.peers[p].base = (unsigned long long)(uintptr_t)peer_area_base[p];
+        xr.peers[p].n_slots = peer_ghost_slots[p];
+        xr.peers[p].x = ((unsigned)d.cur ^ peer_parity[p]) & 1u;
+        xr.peers[p].flag_delta = peer_segment_count[p] - w->flag_base;  // modulo 2^64
+    }
+    const GhostAreaLayout Lm((size_t)xr.n_ghosts, (size_t)w->K);
+    for (int p = 0; p < 2; p++) d.gxrec[p] = (const unsigned char *)xr.area + Lm.xrec[p];
+    d.gflag = (const unsigned long long *)((const char *)xr.area + Lm.flag);
+    xr.agree = coordinator_area && n_ranks >= 2 ? (unsigned long long *)((char *)coordinator_area + GhostAreaLayout::agree) : nullptr;
+    xr.n_ranks = xr.agree ? (int)n_ranks : 0;
+    xr.agree_seq = 0;
+    d.agree = xr.agree;
+    d.n_ranks = xr.n_ranks;
+    xr.connected = true;
+    xr.wired = true;
+    return mgx_halo_resident_aim(w, 0, nullptr, nullptr, nullptr);
+}
+
+// n_targets entries (local robot, index of the peer in mgx_halo_resident_connect_peers' order, the robot's ghost slot there).  Call
+// on every rank after a change of the lists, with every rank's launches through (the callers synchronise and meet at a barrier):
+// the progress words of this rank's ghosts start over at "through with everything so far" — a robot that becomes somebody's
+// neighbour across ranks has never stored one here.
+int mgx_halo_resident_aim(mgx_world *w, uint32_t n_targets, const int32_t *robots, const uint32_t *peer_index, const uint32_t *peer_slot) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    if (n_targets && (!robots || !peer_index || !peer_slot)) return fail(MGX_ERR_INVALID, "null argument");
+    mgx_world::ResidentHalo &xr = w->xres;
+    if (!xr.area || !xr.connected) return fail(MGX_ERR_STATE, "mgx_halo_resident_connect_peers first");
+    if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
+    if (!w->dev_valid || w->dirty) return fail(MGX_ERR_STATE, "the world's layout changed since mgx_halo_resident_setup");
+    const DevWorld &d = w->d;
+    const size_t R = (size_t)d.R_local, K = (size_t)w->K;
+    std::vector<std::pair<int, XPushRec>> recs;
+    recs.reserve(n_targets);
+    for (uint32_t t = 0; t < n_targets; t++) {
+        if (robots[t] < 0 || (size_t)robots[t] >= w->robots.size() || w->robots[(size_t)robots[t]].ghost)
+            return fail(MGX_ERR_INVALID, "target %u: robot %d is not a local robot", t, robots[t]);
+        if ((size_t)peer_index[t] >= xr.peers.size()) return fail(MGX_ERR_INVALID, "target %u: peer %u of %zu", t, peer_index[t], xr.peers.size());
+        const mgx_world::ResidentHalo::Peer &pr = xr.peers[(size_t)peer_index[t]];
+        if ((size_t)peer_slot[t] >= pr.n_slots) return fail(MGX_ERR_INVALID, "target %u: slot %u of %zu", t, peer_slot[t], pr.n_slots);
+        const GhostAreaLayout L(pr.n_slots, K);
+        XPushRec r;
+        for (unsigned p = 0; p < 2; p++) r.xrec[p] = pr.base + L.xrec[p ^ pr.x] + (size_t)peer_slot[t] * K * (size_t)XREC_BYTES;
+        r.flag = pr.base + L.flag + (size_t)peer_slot[t] * sizeof(unsigned long long);
+        r.flag_delta = pr.flag_delta;
+        recs.emplace_back(w->dev_of[(size_t)robots[t]], r);
+    }
+    std::stable_sort(recs.begin(), recs.end(), [](const std::pair<int, XPushRec> &a, const std::pair<int, XPushRec> &b) { return a.first < b.first; });
+    std::vector<int32_t> ptr(R + 1, 0);
+    std::vector<XPushRec> flat(std::max<size_t>(recs.size(), 1));
+    for (size_t i = 0; i < recs.size(); i++) { ptr[(size_t)recs[i].first + 1]++; flat[i] = recs[i].second; }
+    for (size_t r = 0; r < R; r++) ptr[r + 1] += ptr[r];
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    HIP_TRY(xr.xp_ptr.upload(ptr, w->stream));
+    HIP_TRY(xr.xp_rec.upload(flat, w->stream));
+    {
+        const GhostAreaLayout Lm((size_t)xr.n_ghosts, K);
+        std::vector<unsigned long long> f((size_t)std::max(xr.n_ghosts, 1), w->flag_base);
+        HIP_TRY(hipMemcpyAsync((char *)xr.area + Lm.flag, f.data(), sizeof(unsigned long long) * f.size(), hipMemcpyHostToDevice, w->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    w->d.xp_ptr = xr.xp_ptr.p;
+    w->d.xp_rec = xr.xp_rec.p;
+    return MGX_OK;
+}
+
 int mgx_halo_resident_disconnect(mgx_world *w) {
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     HIP_TRY(hipStreamSynchronize(w->stream));
     w->xres.connected = false;
     w->xres.wired = false;
+    w->xres.peers.clear();
     w->xres.agree = nullptr;
     w->d.agree = nullptr;
     return MGX_OK;

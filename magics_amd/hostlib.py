@@ -166,6 +166,8 @@ SYMBOLS = {
     "mgx_resident_ready": (C.c_int, [_V, C.c_char_p, C.c_uint32, C.POINTER(C.c_int32)]),
     "mgx_resident_stats": (C.c_int, [_V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "mgx_halo_resident_disconnect": (C.c_int, [_V]),
+    "mgx_halo_resident_connect_peers": (C.c_int, [_V, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "mgx_halo_resident_aim": (C.c_int, [_V, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_ipc_export": (C.c_int, [C.c_void_p, C.c_char_p]),
     "mgx_ipc_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "mgx_ipc_close": (C.c_int, [C.c_void_p]),

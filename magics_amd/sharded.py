@@ -191,6 +191,8 @@ class ShardedWorld:
         if getattr(self, "_slot_wiring", None) is not None:
             if len(plan.owner) == self._slot_robots:
                 self._aim_slots()  # the exchange lives in the engine: only the pushes' destinations follow the lists
+                if getattr(self, "_res_wiring", None) is not None:
+                    self._aim_resident()
             return  # (robots joined: the areas are wired again by whoever drives the ranks — connect_slots / LocalCluster)
         for name, need in (("send_buf", sum(self.send_counts)), ("recv_buf", sum(self.recv_counts))):
             buf = getattr(self, name)
@@ -204,7 +206,12 @@ class ShardedWorld:
         assert self.dynamic
         out = self.world.update_topology(positions_all, radius, next_number, method=method)
         if out[1] or out[2]:
+            if getattr(self, "_res_wiring", None) is not None and self.comm is not None:
+                self.world.synchronize()  # (mgx_halo_resident_aim: with every rank's launches through)
+                self.comm.barrier()
             self.replan()
+            if getattr(self, "_res_wiring", None) is not None and self.comm is not None:
+                self.comm.barrier()
             if self.comm is not None:
                 if self.direct:
                     self.world.halo_direct_exchange()  # (in the engine: push, then wait for every peer's)
@@ -362,6 +369,58 @@ class ShardedWorld:
         self.world.halo_direct_connect_slots(first, [wiring[q]["recv"] for q in peers], [wiring[q]["capacity"] for q in peers], slot,
                                              [wiring[q]["flag"] for q in peers])
 
+    def resident_setup_slots(self, export_ipc):
+        """(a world that follows its topology, behind direct_connect_slots) allocate this rank's ghost area — a slot per ghost
+        robot as it is — and say what the peers need: where, how many slots, parity, segment count, every robot's slot."""
+        assert self.dynamic and getattr(self, "_slot_wiring", None) is not None
+        plan = self.plan
+        area, ng, par, seg, _, ok = self.world.halo_resident_setup(self.world.halo_n_recv())
+        self._own_area = area
+        info = dict(rank=plan.rank, n_ghosts=ng, parity=par, segments=seg, eligible=ok,
+                    slots=self.world.halo_ghost_slots(np.arange(len(plan.owner), dtype=np.int32)))
+        if export_ipc:
+            info["area_handle"] = hostlib.ipc_export(area)
+        else:
+            info["area_ptr"] = area
+        return info
+
+    def resident_connect_peers(self, infos, agree=True):
+        """infos[q]: what rank q published in resident_setup_slots.  Every other rank is a peer, once; which records go where
+        follows the lists (_aim_resident, from replan)."""
+        plan = self.plan
+        peers = [q for q in range(plan.world_size) if q != plan.rank]
+        areas = {}
+        for q in set(peers) | {0}:
+            inf = infos[q]
+            if q == plan.rank:
+                areas[q] = self._own_area
+            elif "area_ptr" in inf:
+                areas[q] = inf["area_ptr"]
+            else:
+                areas[q] = hostlib.ipc_open(inf["area_handle"])
+                self._opened_areas = getattr(self, "_opened_areas", []) + [areas[q]]
+        self.world.halo_resident_connect_peers([areas[q] for q in peers], [infos[q]["n_ghosts"] for q in peers],
+                                               [infos[q]["parity"] for q in peers], [infos[q]["segments"] for q in peers],
+                                               coordinator_area=areas[0] if agree else None, n_ranks=plan.world_size if agree else 0)
+        self._res_wiring = {q: (j, np.asarray(infos[q]["slots"])) for j, q in enumerate(peers)}
+        self.resident = True
+        self.transport = "direct+resident"
+        self._aim_resident()
+
+    def _aim_resident(self):
+        """which local robot's exchange records go into which peer's ghost slot: from the send list as it stands"""
+        plan = self.plan
+        send = self.world.halo_send_list()
+        robots, peer, slot, k = [], [], [], 0
+        for q in range(plan.world_size):
+            cnt = self._send_counts_robots[q]
+            if q != plan.rank:
+                j, slots = self._res_wiring[q]
+                for g in send[k:k + cnt]:
+                    robots.append(self.lid[g]); peer.append(j); slot.append(int(slots[g]))
+            k += cnt
+        self.world.halo_resident_aim(robots, peer, slot)
+
     # -- resident schedule launches: ghost records travel INSIDE the launches ---------------------------
     def resident_setup(self, export_ipc):
         """Allocate this rank's ghost area (after the direct exchange is wired); returns what the peers need to know:
@@ -423,7 +482,7 @@ class ShardedWorld:
         for ptr in getattr(self, "_opened", []) + getattr(self, "_opened_areas", []):
             hostlib.ipc_close(ptr)
         self._opened, self._opened_areas = [], []
-        self._slot_wiring = None
+        self._slot_wiring = self._res_wiring = None
 
     def resident_close(self):
         """The ghost areas only (the direct exchange stays wired).  Call on every rank, after a barrier."""
@@ -575,7 +634,7 @@ def _connect_resident(sw, comm, all_ok):
     except Exception:  # noqa: BLE001
         info = None
     infos = comm.all_gather_object(info)
-    if any(i is None or not i["eligible"] for i in infos):
+    if any(i is None or i["eligible"] != 1 for i in infos):
         return False
     try:
         sw.resident_connect({i["rank"]: i for i in infos})
@@ -589,6 +648,34 @@ def _connect_resident(sw, comm, all_ok):
     if ok:
         sw.world.halo_resident_disconnect()
         sw.resident = False
+    comm.barrier()
+    return False
+
+
+def _connect_resident_slots(sw, comm, all_ok):
+    """The same for a world that follows its topology (behind direct_connect_slots): every other rank is a peer once, the push
+    tables follow the exchange lists (ShardedWorld._aim_resident).  A rank without inter-robot factors yet is welcome (eligible 2):
+    every schedule is decided where the ranks agree."""
+    info = None
+    try:
+        sw.world.sweep(0, 0, 0)
+        info = sw.resident_setup_slots(export_ipc=True)
+    except Exception:  # noqa: BLE001
+        info = None
+    infos = comm.all_gather_object(info)
+    if any(i is None or i["eligible"] < 1 for i in infos):
+        return False
+    try:
+        sw.resident_connect_peers({i["rank"]: i for i in infos})
+        ok = True
+    except Exception:  # noqa: BLE001
+        ok = False
+    if all_ok(ok):
+        comm.barrier()
+        return True
+    if ok:
+        sw.world.halo_resident_disconnect()
+        sw.resident, sw._res_wiring, sw.transport = False, None, "direct"
     comm.barrier()
     return False
 
@@ -651,8 +738,8 @@ def connect(sw, comm, transport="auto", resident=True):
                 if all_ok(ok):
                     comm.barrier()
                     sw.transport = "direct"
-                    if resident and not slots:
-                        _connect_resident(sw, comm, all_ok)
+                    if resident:
+                        (_connect_resident_slots if slots else _connect_resident)(sw, comm, all_ok)
                     return sw.transport
                 comm.barrier()
                 sw.direct_close()
@@ -729,12 +816,13 @@ class LocalCluster:
         a shared stream before the other rank's stores are even enqueued.
         dynamic=True: worlds that follow their topology (see ShardedWorld); the cluster then also
         offers the per-tick calls of magics_amd.driver.Driver over global robot ids."""
-        assert not (resident and dynamic)
         self.ranks = [ShardedWorld(sc, r, world_size, world_factory, comm=None, owner=owner,
                                    tensor_factory=tensor_factory, dynamic=dynamic) for r in range(world_size)]
         self.n_robots, self.K = len(sc["robots"]), sc.get("K")
         self.resident = False
+        self.agree = agree
         self.direct_slots = bool(direct and dynamic and world_size > 1)
+        self._want_resident = bool(resident and self.direct_slots)
         if self.direct_slots:
             if self.K is not None:
                 self._wire_slots()
@@ -748,7 +836,7 @@ class LocalCluster:
                 for sw in self.ranks:
                     sw.world.sweep(0, 0, 0)
                 infos = {sw.plan.rank: sw.resident_setup(export_ipc=False) for sw in self.ranks}
-                if all(i["eligible"] for i in infos.values()):
+                if all(i["eligible"] == 1 for i in infos.values()):
                     for sw in self.ranks:
                         sw.resident_connect(infos, agree=agree)
                     self.resident = True
@@ -759,9 +847,22 @@ class LocalCluster:
         rank's replan (ShardedWorld.direct_setup_slots / direct_connect_slots); wired again when robots join"""
         for sw in self.ranks:
             sw.synchronize()
+        for sw in self.ranks:
+            if getattr(sw, "resident", False):
+                sw.world.halo_resident_disconnect()
+                sw.resident, sw._res_wiring = False, None
+        self.resident = False
         infos = {sw.plan.rank: sw.direct_setup_slots(export_ipc=False) for sw in self.ranks}
         for sw in self.ranks:
             sw.direct_connect_slots(infos)
+        if self._want_resident:
+            for sw in self.ranks:
+                sw.world.sweep(0, 0, 0)
+            infos = {sw.plan.rank: sw.resident_setup_slots(export_ipc=False) for sw in self.ranks}
+            if all(i["eligible"] >= 1 for i in infos.values()):
+                for sw in self.ranks:
+                    sw.resident_connect_peers(infos, agree=self.agree)
+                self.resident = True
 
     def _exchange(self):
         if self.direct_slots and self.ranks[0].direct:  # in the engines: all pushes before the first wait (one thread drives all ranks)
@@ -841,6 +942,9 @@ class LocalCluster:
 
     # -- per-tick calls of a driver, over global robot ids (dynamic clusters) ------------------------------
     def update_topology(self, positions_all, radius, next_number, method=hostlib.NEIGHBOURS_AUTO):
+        if self.resident and self.direct_slots:
+            for sw in self.ranks:
+                sw.synchronize()  # (the aims behind a pass that changed the lists: with every rank's launches through)
         outs = [sw.update_topology(positions_all, radius, next_number, method=method) for sw in self.ranks]
         assert all(o == outs[0] for o in outs), "the replicated bookkeeping diverged"
         if (outs[0][1] or outs[0][2]) and len(self.ranks) > 1:

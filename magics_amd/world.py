@@ -432,7 +432,30 @@ class World:
         area, ng, par, seg, ok = C.c_void_p(), C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_int32()
         slots = np.zeros(max(int(n_recv), 1), dtype=np.int32)
         self._chk(self._L.mgx_halo_resident_setup(self._w, C.byref(area), C.byref(ng), C.byref(par), C.byref(seg), slots.ctypes.data, C.byref(ok)))
-        return area.value, ng.value, par.value, seg.value, slots[:n_recv].tolist(), bool(ok.value)
+        # (eligible: 1 yes; 2 everything but inter-robot factors — a world that follows its topology may get them later; 0 no)
+        return area.value, ng.value, par.value, seg.value, slots[:n_recv].tolist(), int(ok.value)
+
+    def halo_n_recv(self):
+        ns, nr = C.c_uint32(), C.c_uint32()
+        self._chk(self._L.mgx_halo_get_lists(self._w, None, 0, None, 0, C.byref(ns), C.byref(nr)))
+        return nr.value
+
+    def halo_resident_connect_peers(self, peer_area, peer_ghost_slots, peer_parity, peer_segment_count, coordinator_area=None, n_ranks=0):
+        n = len(peer_area)
+        b = np.ascontiguousarray(peer_area, dtype=np.uint64)
+        c = np.ascontiguousarray(peer_ghost_slots, dtype=np.uint32)
+        e = np.ascontiguousarray(peer_parity, dtype=np.uint32)
+        f = np.ascontiguousarray(peer_segment_count, dtype=np.uint64)
+        assert b.size == c.size == e.size == f.size == n
+        self._chk(self._L.mgx_halo_resident_connect_peers(self._w, n, b.ctypes.data, c.ctypes.data, e.ctypes.data, f.ctypes.data,
+                                                          coordinator_area, int(n_ranks)))
+
+    def halo_resident_aim(self, robots, peer_index, peer_slot):
+        a = np.ascontiguousarray(robots, dtype=np.int32)
+        b = np.ascontiguousarray(peer_index, dtype=np.uint32)
+        c = np.ascontiguousarray(peer_slot, dtype=np.uint32)
+        assert a.size == b.size == c.size
+        self._chk(self._L.mgx_halo_resident_aim(self._w, a.size, a.ctypes.data, b.ctypes.data, c.ctypes.data))
 
     def halo_resident_connect(self, robots, peer_area, peer_ghost_slots, peer_slot, peer_parity, peer_segment_count,
                               coordinator_area=None, n_ranks=0):

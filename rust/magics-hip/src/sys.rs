@@ -169,6 +169,8 @@ extern "C" {
     pub fn mgx_halo_resident_setup(w: *mut mgx_world, area_base: *mut *mut c_void, n_ghost_slots: *mut u32, parity: *mut u32, segment_count: *mut u64, recv_slots: *mut i32, eligible: *mut i32) -> c_int;
     pub fn mgx_halo_resident_connect(w: *mut mgx_world, n_targets: u32, robots: *const i32, peer_area_base: *const *mut c_void, peer_ghost_slots: *const u32, peer_slot: *const u32, peer_parity: *const u32, peer_segment_count: *const u64, coordinator_area: *mut c_void, n_ranks: u32) -> c_int;
     pub fn mgx_halo_resident_disconnect(w: *mut mgx_world) -> c_int;
+    pub fn mgx_halo_resident_connect_peers(w: *mut mgx_world, n_peers: u32, peer_area_base: *const *mut c_void, peer_ghost_slots: *const u32, peer_parity: *const u32, peer_segment_count: *const u64, coordinator_area: *mut c_void, n_ranks: u32) -> c_int;
+    pub fn mgx_halo_resident_aim(w: *mut mgx_world, n_targets: u32, robots: *const i32, peer_index: *const u32, peer_slot: *const u32) -> c_int;
     pub fn mgx_resident_outcome(w: *mut mgx_world, outcome: *mut i32) -> c_int;
     pub fn mgx_resident_ready(w: *mut mgx_world, steps: *const u8, n: u32, ready: *mut i32) -> c_int;
     pub fn mgx_resident_stats(w: *mut mgx_world, launches: *mut u64, declined: *mut u64, backoff: *mut u32) -> c_int;

@@ -3,7 +3,7 @@ rank is its own process on cuda:0 with a sharded world that follows its topology
 and the halo all-to-all-v go through gloo (device buffers staged through the host — a dry run of the
 RCCL path), or — mode "direct" — the exchange lives in the engines: peer-mapped stores (hipIpc) into one record slot per ghost
 robot, wired once, re-aimed when the lists change.  Every rank runs the same driver.
-usage: dynamic_topology_worker.py RANK WORLD_SIZE PORT OUT.npz [collective|direct]"""
+usage: dynamic_topology_worker.py RANK WORLD_SIZE PORT OUT.npz [collective|direct|direct+resident]"""
 import os
 import sys
 
@@ -28,18 +28,20 @@ def main():
     comm = sharded.TorchDistComm(stage_through_host=True)
     stream = torch.cuda.Stream()
     sw = sharded.ShardedWorld(sc, rank, ws, lambda p: World(p, stream=stream.cuda_stream), comm=comm, owner=np.arange(n) % ws, dynamic=True)
-    if mode == "direct":
-        got = sharded.connect(sw, comm, "direct")
-        assert got == "direct" and sw.direct, got
+    if mode.startswith("direct"):
+        os.environ.setdefault("MGX_RESIDENT_CENSUS_SHARDED_US", "500000")  # (two processes share the one GPU of a test box)
+        got = sharded.connect(sw, comm, "direct", resident=mode == "direct+resident")
+        assert got == mode and sw.direct, got
     drv = Driver(sw, n, K, waypoints=[[tuple(rb["goal"])] for rb in sc["robots"]], radii=[rb["radius"] for rb in sc["robots"]],
                  t0=[rb["t0"] for rb in sc["robots"]], steps=sc["steps"], comms_radius=12.0, target_speed=sc["target_speed"])
     events = [drv.tick() for _ in range(ticks)]
     ids, eta, lam, mu = sw.read_beliefs()
-    exchanges = sw.world.halo_direct_status() if mode == "direct" else 0  # (raises if one of them timed out)
-    np.savez(out, exchanges=exchanges, ids=np.array(ids), eta=eta, lam=lam, mu=mu, events=np.array(events), translation=drv.translation,
+    exchanges = sw.world.halo_direct_status() if mode.startswith("direct") else 0  # (raises if one of them timed out)
+    resident = [int(x) for x in sw.world.resident_stats()] if mode == "direct+resident" else [0, 0, 0]
+    np.savez(out, exchanges=exchanges, resident=np.array(resident), ids=np.array(ids), eta=eta, lam=lam, mu=mu, events=np.array(events), translation=drv.translation,
              finished_at=drv.finished_at, next_number=drv.next_number)
     dist.barrier()
-    if mode == "direct":
+    if mode.startswith("direct"):
         sw.direct_close()
     dist.destroy_process_group()
 

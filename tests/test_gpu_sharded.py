@@ -162,22 +162,25 @@ def _circle_driver(w, sc, n, K, **kw):
                   t0=[rb["t0"] for rb in sc["robots"]], steps=sc["steps"], comms_radius=12.0, target_speed=sc["target_speed"], **kw)
 
 
-@pytest.mark.parametrize("world_size,direct", [(2, False), (3, False), (2, True), (3, True)])
+@pytest.mark.parametrize("world_size,direct", [(2, False), (3, False), (2, True), (3, True), (2, "resident"), (3, "resident")])
 def test_sharded_world_follows_its_topology(world_size, direct):
     """A whole mission on a sharded world that follows its topology: robots cross a circle, connect and
     disconnect across rank boundaries, arrive and despawn.  Every rank replays the connection
     bookkeeping on all positions; exchange lists follow the connections.  Topology events, robot
     numbers, trajectories and beliefs equal the single-world oracle's, tick by tick.
     direct: the exchange lives in the engines (peer-mapped stores into one record slot per ghost robot, wired ONCE and re-aimed
-    whenever the lists change — mgx_halo_direct_setup_slots / _connect_slots): no host-driven all-to-all in any tick."""
+    whenever the lists change — mgx_halo_direct_setup_slots / _connect_slots): no host-driven all-to-all in any tick.
+    "resident": on top of that the ghosts' exchange records travel INSIDE one resident launch per schedule and rank, the push
+    tables re-aimed with the lists (mgx_halo_resident_connect_peers / _aim)."""
     n, K = 9, 10
     sc = S.circle_scenario(n, K, circle_radius=12.0, n_internal=10, n_external=10)
     sc["ir"] = []
     owner = np.arange(n) % world_size  # interleaved ownership: every neighbour pair crosses a rank boundary sooner or later
     if direct:
         make, _streams = _own_stream_factory()
-        cluster = sharded.LocalCluster(sc, world_size, make, owner=owner, dynamic=True, direct=True)
-        assert all(sw.direct and sw.transport == "direct" for sw in cluster.ranks)
+        cluster = sharded.LocalCluster(sc, world_size, make, owner=owner, dynamic=True, direct=True, resident=direct == "resident")
+        assert all(sw.direct and sw.transport == ("direct+resident" if direct == "resident" else "direct") for sw in cluster.ranks)
+        assert cluster.resident == (direct == "resident")
     else:
         cluster = sharded.LocalCluster(sc, world_size, World, owner=owner, dynamic=True)
     ref = oracle.OracleWorld(sc["params"])
@@ -204,7 +207,11 @@ def test_sharded_world_follows_its_topology(world_size, direct):
     assert dc.summary()["messages"] == dr.summary()["messages"]               # MessageCount of every graph, from its owner's rank
     if direct:
         for sw in cluster.ranks:
-            assert sw.world.halo_direct_status() > 100  # exchanges inside the engine, none of them timed out
+            assert sw.world.halo_direct_status() > (20 if direct == "resident" else 100)  # exchanges inside the engine, none timed out
+    if direct == "resident":
+        st = [tuple(int(x) for x in sw.world.resident_stats()) for sw in cluster.ranks]
+        print("resident launches / declined / back-off left per rank:", st, "schedules declined by the cluster:", getattr(cluster, "declined", 0))
+        assert all(x[0] > 50 for x in st), st  # most ticks ran as ONE launch per rank (robots that are alone on their rank vote no)
 
 
 def test_sharded_topology_with_comms_failures_and_initial_connections():

@@ -23,10 +23,12 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-@pytest.mark.parametrize("mode", ["collective", "direct"])
+@pytest.mark.parametrize("mode", ["collective", "direct", "direct+resident"])
 def test_two_processes_follow_the_topology(tmp_path, mode):
     """mode "direct": the exchange inside the engines (hipIpc-mapped record slots, one per ghost robot, re-aimed after every topology
-    pass that changed the lists) — no host-driven all-to-all in any tick"""
+    pass that changed the lists) — no host-driven all-to-all in any tick; "direct+resident": and the ghosts' exchange records inside
+    ONE resident launch per schedule and rank (`len(ghosts) < n_robots - n_local` in what is exchanged: only robots connected across
+    the ranks travel; every rank still holds a record of every robot — the replicated bookkeeping)"""
     ws, n, K, ticks = 2, 8, 10, 60
     port = _free_port()
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(ws)]
@@ -56,7 +58,9 @@ def test_two_processes_follow_the_topology(tmp_path, mode):
     seen = 0
     for o in outs:
         z = np.load(o)
-        assert (int(z["exchanges"]) > ticks) == (mode == "direct")
+        assert (int(z["exchanges"]) > (10 if mode == "direct+resident" else ticks)) == mode.startswith("direct")
+        if mode == "direct+resident":
+            assert int(z["resident"][0]) > ticks // 2, z["resident"]  # most schedules ran as ONE launch on this rank
         assert np.array_equal(z["events"], events) and np.array_equal(z["translation"], drv.translation)
         assert np.array_equal(z["finished_at"], drv.finished_at) and int(z["next_number"]) == drv.next_number
         for j, g in enumerate(z["ids"]):
