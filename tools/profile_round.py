@@ -90,9 +90,12 @@ def main():
                           "bench.py doubles the reads (an upper bound here: part of the staging uses 8-B loads)."}
     keys = {"<16, 0, false, false>": ("config1", ""), "<16, 2, true, false>": ("config2_resident", ""), "<16, 2, false, false>": ("config2", "_np")}
     out += ["", "## PMC per dispatch (separate passes)", "",
-            "Shader clock = GRBM_GUI_ACTIVE per dispatch / that dispatch's duration in the same pass: the clock THIS box ran the kernel at "
-            "(durations of other boxes, e.g. the driver's, relate to these counters through it).", "",
-            "| instantiation | FETCH_SIZE KiB | WRITE_SIZE KiB | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES | SQ_WAIT_ANY / SQ_WAVE_CYCLES | kernel trace avg us | shader clock GHz | us in the counter passes (FETCH / WRITE / SQ / GRBM) |", "|---|---|---|---|---|---|---|---|---|"]
+            "GRBM_GUI_ACTIVE is summed over the 8 XCDs and its window opens a few microseconds before a dispatch's start stamp and closes "
+            "after its end stamp, so the clock THIS box ran at is the SLOPE between two instantiations of one pass, "
+            "(cycles_A - cycles_B) / 8 / (duration_A - duration_B): see the line under the table (durations of other boxes, e.g. the "
+            "driver's, relate to these counters through it).", "",
+            "| instantiation | FETCH_SIZE KiB | WRITE_SIZE KiB | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES | SQ_WAIT_ANY / SQ_WAVE_CYCLES | kernel trace avg us | GRBM_GUI_ACTIVE / 8, k cycles | us in the counter passes (FETCH / WRITE / SQ / GRBM) |", "|---|---|---|---|---|---|---|---|---|"]
+    clock_pts = []
     for inst, (key, suf) in keys.items():
         f = per_kernel(g + "_pmc_FETCH_SIZE" + suf, "FETCH_SIZE").get(inst)
         w = per_kernel(g + "_pmc_WRITE_SIZE" + suf, "WRITE_SIZE").get(inst)
@@ -100,7 +103,9 @@ def main():
         d_us = (dur.get(inst + (" (MGX_PERSISTENT=0)" if suf else "")) or (None, 0))[0]
         gui = per_kernel(g + "_pmc_GRBM_GUI_ACTIVE" + suf, "GRBM_GUI_ACTIVE").get(inst)
         pd = [pass_durations(g + "_pmc_" + nm + suf).get(inst) for nm in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")]
-        clock = gui / (pd[3] * 1e3) if gui and pd[3] else None  # cycles / ns = GHz
+        clock = None
+        if gui and pd[3]:
+            clock_pts.append((suf, pd[3], gui / 8.0))  # (pass, us, cycles per XCD)
         if f is None or w is None:
             continue
         ent = {"fetch_kib": round(f, 1), "write_kib": round(w, 1), "source": f"profiles/{tag}_summary.md (rocprofv3 --pmc, separate passes)"}
@@ -115,13 +120,23 @@ def main():
                 ent["wait_pct"] = round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"] * 100.0, 1)
         if d_us:
             ent["kernel_trace_avg_us"] = round(d_us, 2)
-        if clock:
-            ent["shader_clock_ghz"] = round(clock, 3)
+        if gui:
+            ent["gui_active_cycles_per_xcd"] = round(gui / 8.0)
         ent["counter_pass_avg_us"] = [round(x, 2) if x else None for x in pd]
         traffic[key] = ent
         out.append(f"| k_robot_sweep{inst} | {f:.1f} | {w:.1f} | {sq['SQ_INSTS_VALU'] or 0:.4g} | VALU active {busy or 0:.1f} % of wave-cycles | "
-                   f"{(sq['SQ_WAIT_ANY'] or 0) / (sq['SQ_WAVE_CYCLES'] or 1) * 100:.0f} % waiting | {d_us or 0:.2f} | {clock or 0:.2f} | "
+                   f"{(sq['SQ_WAIT_ANY'] or 0) / (sq['SQ_WAVE_CYCLES'] or 1) * 100:.0f} % waiting | {d_us or 0:.2f} | {(gui or 0) / 8e3:.1f} | "
                    + " / ".join(f"{x:.1f}" if x else "-" for x in pd) + " |")
+    same = [pt for pt in clock_pts if pt[0] == ""]
+    if len(same) >= 2:
+        a, b = max(same, key=lambda t: t[1]), min(same, key=lambda t: t[1])
+        ghz = (a[2] - b[2]) / ((a[1] - b[1]) * 1e3)
+        window = b[2] / (ghz * 1e3) - b[1]
+        for key in ("config1", "config2_resident"):
+            if key in traffic:
+                traffic[key]["shader_clock_ghz"] = round(ghz, 3)
+        out += ["", f"Shader clock of this box during the sweep kernels: **{ghz:.2f} GHz** (slope between the {a[1]:.1f} us and the {b[1]:.1f} us "
+                    f"instantiation of the GRBM pass; the counter's window is {window:.1f} us wider than a dispatch's start / end stamps)."]
     # the K = 32 instantiations (tools/bench_configs.py under the same three counter passes)
     cdur = durations(g + "_cfg")
     if cdur:
