@@ -373,6 +373,24 @@ int mgx_shard_plan_get(const mgx_shard_plan *plan, int32_t *local, int32_t *ghos
 int mgx_halo_pack(mgx_world *w, void *dev_buf);
 int mgx_halo_unpack(mgx_world *w, const void *dev_buf);
 
+/* ---- migration: a robot changes its owning rank (worlds that follow their topology) --------------------------------------
+ * The reference has ONE world and no notion of ownership (robot.rs queries run over every entity); a sharded world that
+ * follows its topology re-balances by moving a robot's graph between ranks.  Everything that exists on the owner's rank
+ * only travels in one flat, self-describing record: the graph's numeric state (priors, beliefs, factor -> variable
+ * messages, snapshot records and delivery counts, tracking records, iteration count, path, frozen inboxes), the totals of
+ * its MessageCount, and the state of every InterRobotFactor attached to its variables (kept at the target's rank).  The
+ * replicated bookkeeping (connection sets, node slots, robot numbers, flags, the connections' counters) stays where it is.
+ * Protocol, on every rank at the same point BETWEEN ticks (after the sweeps that followed the last mgx_update_topology):
+ *   old owner:  mgx_robot_export (bytes first with buf = NULL, then the record), mgx_robot_release
+ *   new owner:  mgx_robot_import with the record (refused with MGX_ERR_STATE when its connections differ from this
+ *               rank's bookkeeping: the ranks' topology passes are out of step)
+ *   every rank: the new rank table to mgx_halo_plan_from_connections, and the in-engine transports wired again (device
+ *               indices change: locals first) — as after mgx_robot_add.
+ * Results stay bit-identical to the unsharded world's (tests/test_gpu_sharded.py::test_robots_migrate_between_ranks). */
+int mgx_robot_export(mgx_world *w, int32_t robot, void *buf, uint64_t capacity, uint64_t *bytes);
+int mgx_robot_import(mgx_world *w, int32_t robot, const void *buf, uint64_t bytes);
+int mgx_robot_release(mgx_world *w, int32_t robot);
+
 /* ---- halo exchange through RCCL inside the library -------------------------------------------
  * pack -> grouped ncclSend / ncclRecv with every peer (the all-to-all-v of boundary snapshots over
  * xGMI) -> unpack, enqueued on the world's stream in front of every world-wide launch

@@ -3293,6 +3293,201 @@ int mgx_halo_get_lists(mgx_world *w, int32_t *send_robots, uint32_t send_capacit
     return MGX_OK;
 }
 
+// ---- migration: a robot changes its owning rank (worlds that follow their topology) --------------------------------------
+// Everything that exists on the owner's rank ONLY travels in one flat record: the graph's numeric state (priors, beliefs,
+// factor -> variable messages, snapshot records and delivery counts, tracking records, iteration count, the path, the
+// frozen inboxes of switched-off kinds), the totals of its own MessageCount, and the state of every inter-robot factor
+// attached to its variables (kept at the TARGET's rank).  The replicated bookkeeping — connection sets, node slots, robot
+// numbers, flags, the connections' counters — is the same on every rank already and stays where it is.
+}  // extern "C" (the record's writer and reader are templates)
+namespace {
+struct MigWriter {
+    std::vector<uint8_t> b;
+    template <class T> void pod(const T &v) { const uint8_t *p = reinterpret_cast<const uint8_t *>(&v); b.insert(b.end(), p, p + sizeof(T)); }
+    template <class T> void vec(const std::vector<T> &v) {
+        pod((uint64_t)v.size());
+        const uint8_t *p = reinterpret_cast<const uint8_t *>(v.data());
+        b.insert(b.end(), p, p + sizeof(T) * v.size());
+        while (b.size() & 7) b.push_back(0);
+    }
+};
+struct MigReader {
+    const uint8_t *p, *end;
+    bool ok = true;
+    template <class T> void pod(T &v) {
+        if (!ok || (size_t)(end - p) < sizeof(T)) { ok = false; return; }
+        memcpy(&v, p, sizeof(T));
+        p += sizeof(T);
+    }
+    template <class T> void vec(std::vector<T> &v, size_t want = (size_t)-1) {
+        uint64_t n = 0;
+        pod(n);
+        if (!ok || n > (uint64_t)(end - p) / sizeof(T) || (want != (size_t)-1 && n != want)) { ok = false; return; }
+        v.resize((size_t)n);
+        if (n) memcpy(v.data(), p, sizeof(T) * (size_t)n);
+        p += ((sizeof(T) * (size_t)n + 7) & ~(size_t)7);
+        if (p > end) ok = false;
+    }
+};
+constexpr uint32_t MIG_MAGIC = 0x4d47584du;  // "MXGM"
+constexpr uint32_t MIG_VERSION = 1;
+}  // namespace
+extern "C" {
+
+// The record of a robot this rank owns (mgx_robot_import takes it on the rank that is to own it).  `bytes` receives the
+// record's size; with buf == NULL or capacity too small nothing is copied (MGX_ERR_INVALID when a buffer was given).
+// The world is brought up to date first: schedules issued so far have run, the tables of the last topology pass are laid
+// out.  Call it BETWEEN ticks — after the sweeps that followed the last topology pass — on every rank at the same point.
+int mgx_robot_export(mgx_world *w, int32_t robot, void *buf, uint64_t capacity, uint64_t *bytes) {
+    if (!w || !bytes || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
+    if (w->robots[(size_t)robot].ghost) return fail(MGX_ERR_INVALID, "robot %d is a ghost here: its owner exports it", robot);
+    int rc = check_device_error(w);
+    if (rc != MGX_OK) return rc;
+    if (w->dev_valid && (w->dirty || w->conns_dirty || w->flags_dirty)) {  // (not valid: the host mirror is the truth already)
+        rc = commit(w);
+        if (rc != MGX_OK) return rc;
+    }
+    rc = pull(w);
+    if (rc != MGX_OK) return rc;
+    flush_counts(w);
+    const Robot &rb = w->robots[(size_t)robot];
+    MigWriter wr;
+    wr.pod(MIG_MAGIC); wr.pod(MIG_VERSION);
+    wr.pod((int32_t)rb.K); wr.pod((int32_t)robot);
+    wr.pod((uint64_t)rb.order_key);
+    wr.pod((int32_t)rb.iter_factor); wr.pod((int32_t)rb.thaw);
+    for (int q = 0; q < 4; q++) wr.pod((uint64_t)rb.cnt[q]);
+    wr.vec(rb.prior_eta); wr.vec(rb.prior_lam); wr.vec(rb.bel_eta); wr.vec(rb.bel_lam); wr.vec(rb.bel_mu); wr.vec(rb.bel_cov);
+    wr.vec(rb.valid); wr.vec(rb.snap); wr.vec(rb.epoch); wr.vec(rb.fv_eta); wr.vec(rb.fv_lam);
+    wr.vec(rb.trk_record); wr.vec(rb.trk_last_pos); wr.vec(rb.trk_last_val); wr.vec(rb.path);
+    wr.vec(rb.frozen); wr.vec(rb.frozen_flag); wr.vec(rb.ir_frozen_snap); wr.vec(rb.ir_frozen_epoch); wr.vec(rb.ir_thaw_epoch);
+    uint32_t n_conn = 0;
+    for (const IrConn &c : w->conns) n_conn += c.other == robot ? 1u : 0u;
+    wr.pod(n_conn); wr.pod((uint32_t)0);
+    for (const IrConn &c : w->conns) {
+        if (c.other != robot) continue;
+        wr.pod((int32_t)c.owner); wr.pod((int32_t)c.node_first);
+        wr.pod((uint64_t)c.first_number);
+        for (const IrEdge &ed : c.edges) {
+            for (double v : ed.fv_eta) wr.pod(v);
+            for (double v : ed.fv_lam) wr.pod(v);
+            for (double v : ed.bmu) wr.pod(v);
+            wr.pod((uint32_t)ed.created); wr.pod((uint32_t)(ed.fresh ? 1 : 0));
+        }
+    }
+    *bytes = (uint64_t)wr.b.size();
+    if (!buf) return MGX_OK;
+    if (capacity < wr.b.size()) return fail(MGX_ERR_INVALID, "the record of robot %d takes %zu bytes, %llu given", robot, wr.b.size(), (unsigned long long)capacity);
+    memcpy(buf, wr.b.data(), wr.b.size());
+    return MGX_OK;
+}
+
+// The robot — a ghost here so far — becomes this rank's: its graph and the factors attached to its variables take the
+// state of the record.  The device state is pulled, the host mirror edited, and the next launch lays the world out again
+// (locals first: device indices change, so every wiring that names them — exchange lists, direct / resident halo — is
+// made again by the launcher, as after mgx_robot_add).  The replicated bookkeeping has to be in step with the exporting
+// rank's: the record names its connections (owner, first robot number, first node slot) and a mismatch is refused.
+int mgx_robot_import(mgx_world *w, int32_t robot, const void *buf, uint64_t bytes) {
+    if (!w || !buf || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
+    if (!w->robots[(size_t)robot].ghost) return fail(MGX_ERR_STATE, "robot %d is owned here already", robot);
+    int rc = check_device_error(w);
+    if (rc != MGX_OK) return rc;
+    if (w->dev_valid && (w->dirty || w->conns_dirty || w->flags_dirty)) {
+        rc = commit(w);
+        if (rc != MGX_OK) return rc;
+    }
+    rc = pull(w);
+    if (rc != MGX_OK) return rc;
+    flush_counts(w);
+    MigReader rd{(const uint8_t *)buf, (const uint8_t *)buf + bytes};
+    uint32_t magic = 0, version = 0, n_conn = 0, pad = 0;
+    int32_t K = 0, id = 0, itf = 0, thaw = 0;
+    uint64_t key = 0, cnt[4] = {0, 0, 0, 0};
+    rd.pod(magic); rd.pod(version); rd.pod(K); rd.pod(id); rd.pod(key); rd.pod(itf); rd.pod(thaw);
+    for (uint64_t &c : cnt) rd.pod(c);
+    if (!rd.ok || magic != MIG_MAGIC || version != MIG_VERSION) return fail(MGX_ERR_INVALID, "not a robot record of this library version");
+    Robot tmp = w->robots[(size_t)robot];  // (edited aside: a record that turns out malformed leaves the world untouched)
+    if (K != tmp.K || id != robot || key != tmp.order_key)
+        return fail(MGX_ERR_STATE, "the record is robot %d (K = %d, order key %llu): not robot %d of this world", id, K, (unsigned long long)key, robot);
+    const size_t Ks = (size_t)K, E = (size_t)(4 * K - 6);
+    rd.vec(tmp.prior_eta, 4 * Ks); rd.vec(tmp.prior_lam, 16 * Ks); rd.vec(tmp.bel_eta, 4 * Ks); rd.vec(tmp.bel_lam, 16 * Ks);
+    rd.vec(tmp.bel_mu, 4 * Ks); rd.vec(tmp.bel_cov, 16 * Ks);
+    rd.vec(tmp.valid, Ks); rd.vec(tmp.snap, 24 * Ks); rd.vec(tmp.epoch, Ks); rd.vec(tmp.fv_eta, 4 * E); rd.vec(tmp.fv_lam, 16 * E);
+    rd.vec(tmp.trk_record, Ks - 2); rd.vec(tmp.trk_last_pos, 2 * (Ks - 2)); rd.vec(tmp.trk_last_val, Ks - 2); rd.vec(tmp.path);
+    rd.vec(tmp.frozen); rd.vec(tmp.frozen_flag); rd.vec(tmp.ir_frozen_snap); rd.vec(tmp.ir_frozen_epoch); rd.vec(tmp.ir_thaw_epoch);
+    rd.pod(n_conn); rd.pod(pad);
+    if (!rd.ok || (tmp.path.size() & 1)) return fail(MGX_ERR_INVALID, "malformed robot record");
+    std::vector<size_t> mine;
+    for (size_t ci = 0; ci < w->conns.size(); ci++)
+        if (w->conns[ci].other == robot) mine.push_back(ci);
+    if (mine.size() != n_conn)
+        return fail(MGX_ERR_STATE, "the record holds %u connections into robot %d, this rank's bookkeeping %zu: the ranks' topology passes are out of step",
+                    n_conn, robot, mine.size());
+    std::vector<std::vector<IrEdge>> edges(mine.size());
+    for (size_t m = 0; m < mine.size(); m++) {
+        const IrConn &c = w->conns[mine[m]];
+        int32_t owner = 0, node_first = 0;
+        uint64_t first_number = 0;
+        rd.pod(owner); rd.pod(node_first); rd.pod(first_number);
+        if (!rd.ok || owner != c.owner || node_first != c.node_first || first_number != c.first_number)
+            return fail(MGX_ERR_STATE, "connection %zu into robot %d differs between the ranks (owner %d / %d): the replicated bookkeeping diverged",
+                        m, robot, owner, c.owner);
+        edges[m].resize(c.edges.size());
+        for (IrEdge &ed : edges[m]) {
+            uint32_t created = 0, fresh = 0;
+            for (double &v : ed.fv_eta) rd.pod(v);
+            for (double &v : ed.fv_lam) rd.pod(v);
+            for (double &v : ed.bmu) rd.pod(v);
+            rd.pod(created); rd.pod(fresh);
+            ed.created = created;
+            ed.fresh = fresh != 0;
+        }
+    }
+    if (!rd.ok || rd.p != rd.end) return fail(MGX_ERR_INVALID, "malformed robot record (length)");
+    tmp.ghost = false;
+    tmp.iter_factor = itf;
+    tmp.thaw = (uint8_t)thaw;
+    for (int q = 0; q < 4; q++) tmp.cnt[q] = cnt[q];
+    w->robots[(size_t)robot] = std::move(tmp);
+    for (size_t m = 0; m < mine.size(); m++) {
+        bool any_fresh = false;
+        for (const IrEdge &ed : edges[m]) any_fresh = any_fresh || ed.fresh;
+        w->conns[mine[m]].edges = std::move(edges[m]);
+        w->conn_hot[mine[m]].has_fresh = any_fresh ? 1 : 0;
+    }
+    w->sets.ghost[(size_t)robot] = 0;
+    w->dirty = true;
+    w->dev_valid = false;  // the host mirror is the truth now (mgx_reset_variables does the same)
+    w->conns_dirty = true;
+    w->flags_dirty = true;
+    return MGX_OK;
+}
+
+// The other half on the rank that gave the robot away (after mgx_robot_export): it stays in this world as a ghost — its
+// records arrive by the exchange from now on, the factors attached to its variables are its new owner's.
+int mgx_robot_release(mgx_world *w, int32_t robot) {
+    if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
+    if (w->robots[(size_t)robot].ghost) return fail(MGX_ERR_STATE, "robot %d is a ghost here already", robot);
+    int rc = check_device_error(w);
+    if (rc != MGX_OK) return rc;
+    if (w->dev_valid && (w->dirty || w->conns_dirty || w->flags_dirty)) {
+        rc = commit(w);
+        if (rc != MGX_OK) return rc;
+    }
+    rc = pull(w);
+    if (rc != MGX_OK) return rc;
+    flush_counts(w);
+    Robot &rb = w->robots[(size_t)robot];
+    rb.ghost = true;
+    rb.path.clear();
+    w->sets.ghost[(size_t)robot] = 1;
+    w->dirty = true;
+    w->dev_valid = false;
+    w->conns_dirty = true;
+    w->flags_dirty = true;
+    return MGX_OK;
+}
+
 static int halo_commit(mgx_world *w) {
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     // Changed connections alone (conns_dirty) are left to the next sweep: an exchange does not read the

@@ -156,6 +156,9 @@ SYMBOLS = {
     "mgx_halo_direct_disconnect": (C.c_int, [_V]),
     "mgx_halo_direct_setup_slots": (C.c_int, [_V, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "mgx_halo_ghost_slots": (C.c_int, [_V, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "mgx_robot_export": (C.c_int, [_V, C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "mgx_robot_import": (C.c_int, [_V, C.c_int32, C.c_void_p, C.c_uint64]),
+    "mgx_robot_release": (C.c_int, [_V, C.c_int32]),
     "mgx_halo_get_lists": (C.c_int, [_V, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mgx_halo_direct_connect_slots": (C.c_int, [_V, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_halo_resident_setup": (C.c_int, [_V, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),

@@ -150,6 +150,7 @@ class ShardedWorld:
         self.send_buf = self.recv_buf = None
         self.send_counts = self.recv_counts = [0] * plan.world_size
         self.direct = False
+        self.transport = "collective" if plan.world_size > 1 else "none"  # sharded.connect() moves it to an in-engine one
         self.replan()
 
     def add_robot(self, mean0, prior_diag, dt, radius, path=None, owner=None, order_key=None):
@@ -179,6 +180,54 @@ class ShardedWorld:
 
     def set_environment(self, env):
         self.world.set_environment(env)
+
+    # -- migration: robots change their owning rank (re-balancing a world that follows its topology) -----------
+    def _migrate_out(self, moves):
+        """records of the robots this rank gives away (mgx_robot_export), which become ghosts here (mgx_robot_release)"""
+        out = {g: self.world.robot_export(g) for g, a, _ in moves if a == self.plan.rank}
+        for g in out:
+            self.world.robot_release(g)
+        return out
+
+    def _migrate_in(self, moves, records):
+        plan = self.plan
+        for g, _, b in moves:
+            if b == plan.rank:
+                self.world.robot_import(g, records[g])
+        plan.owner = plan.owner.copy()
+        for g, _, b in moves:
+            plan.owner[g] = b
+        plan.local = [int(g) for g in np.nonzero(plan.owner == plan.rank)[0]]  # (device order of the locals: by id)
+        self._slot_wiring = self._res_wiring = None  # device indices changed: whatever was wired names the old ones
+        self.replan()
+
+    def migrate(self, new_owner):
+        """Re-balance: `new_owner[robot]` = the rank that is to own each robot from now on (the same table on every rank).
+        Collective, BETWEEN ticks (after the sweeps that followed the last topology pass).  A robot's graph state, its
+        counters and the factors attached to its variables travel as one record (include/mgx.h: mgx_robot_export /
+        _import / _release) over the control-plane channel; the replicated bookkeeping stays; exchange lists and in-engine
+        transports are made again.  Returns the number of robots that moved.  The results stay bit-identical to the
+        unsharded world's."""
+        assert self.dynamic
+        plan, comm = self.plan, self.comm
+        new_owner = np.asarray(new_owner)
+        assert new_owner.shape == plan.owner.shape and ((0 <= new_owner) & (new_owner < plan.world_size)).all()
+        moves = [(int(g), int(plan.owner[g]), int(new_owner[g])) for g in np.nonzero(new_owner != plan.owner)[0]]
+        if not moves:
+            return 0
+        in_engine, resident = self.direct and comm is not None, bool(getattr(self, "resident", False))
+        if in_engine:
+            self.synchronize()
+            comm.barrier()  # nobody may still be pushing into an area that is about to be closed
+            self.direct_close()
+        out = self._migrate_out(moves)
+        records = {}
+        for part in ([out] if comm is None else comm.all_gather_object(out)):
+            records.update(part)
+        self._migrate_in(moves, records)
+        if in_engine:
+            connect(self, comm, "direct", resident=resident)
+        return len(moves)
 
     def replan(self):
         """Exchange lists for the connections now held (same result on both ends of every exchange)."""
@@ -935,6 +984,24 @@ class LocalCluster:
         if self.direct_slots:
             self._wire_slots()  # (a robot more: every rank's area has a slot more, or the robot a slot in the others')
         return ids[0]
+
+    def migrate(self, new_owner):
+        """ShardedWorld.migrate for all ranks of the cluster (the records change hands in-process)"""
+        new_owner = np.asarray(new_owner)
+        old = self.ranks[0].plan.owner
+        moves = [(int(g), int(old[g]), int(new_owner[g])) for g in np.nonzero(new_owner != old)[0]]
+        if not moves:
+            return 0
+        for sw in self.ranks:
+            sw.synchronize()
+        records = {}
+        for sw in self.ranks:
+            records.update(sw._migrate_out(moves))
+        for sw in self.ranks:
+            sw._migrate_in(moves, records)
+        if self.direct_slots:
+            self._wire_slots()
+        return len(moves)
 
     def tick(self, robots, waypoints_xy, time_scale, what, max_speed, delta_t, steps):
         self.update_priors(robots, waypoints_xy, time_scale, what, max_speed, delta_t)

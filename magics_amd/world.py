@@ -395,6 +395,21 @@ class World:
         self._chk(self._L.mgx_halo_ghost_slots(self._w, r.size, r.ctypes.data, out.ctypes.data))
         return out
 
+    def robot_export(self, robot):
+        """the record of a robot this rank owns, for the rank that is to own it (mgx_robot_export)"""
+        n = C.c_uint64()
+        self._chk(self._L.mgx_robot_export(self._w, int(robot), None, 0, C.byref(n)))
+        buf = np.zeros(n.value, dtype=np.uint8)
+        self._chk(self._L.mgx_robot_export(self._w, int(robot), buf.ctypes.data, n.value, C.byref(n)))
+        return buf.tobytes()
+
+    def robot_import(self, robot, record):
+        buf = np.frombuffer(record, dtype=np.uint8)
+        self._chk(self._L.mgx_robot_import(self._w, int(robot), buf.ctypes.data, buf.size))
+
+    def robot_release(self, robot):
+        self._chk(self._L.mgx_robot_release(self._w, int(robot)))
+
     def halo_send_list(self):
         """robot ids of the send list as it stands (by consumer rank)"""
         ns, nr = C.c_uint32(), C.c_uint32()

@@ -154,6 +154,9 @@ extern "C" {
     pub fn mgx_shard_plan_get(plan: *const mgx_shard_plan, local: *mut i32, ghosts: *mut i32, connections: *mut u32, send_first: *mut u32, send_robots: *mut i32, recv_first: *mut u32, recv_robots: *mut i32) -> c_int;
     pub fn mgx_halo_pack(w: *mut mgx_world, dev_buf: *mut c_void) -> c_int;
     pub fn mgx_halo_unpack(w: *mut mgx_world, dev_buf: *const c_void) -> c_int;
+    pub fn mgx_robot_export(w: *mut mgx_world, robot: i32, buf: *mut c_void, capacity: u64, bytes: *mut u64) -> c_int;
+    pub fn mgx_robot_import(w: *mut mgx_world, robot: i32, buf: *const c_void, bytes: u64) -> c_int;
+    pub fn mgx_robot_release(w: *mut mgx_world, robot: i32) -> c_int;
     pub fn mgx_rccl_unique_id(id: *mut u8) -> c_int;
     pub fn mgx_halo_rccl_connect(w: *mut mgx_world, id: *const u8, n_ranks: u32, rank: u32, n_peers: u32, peer_rank: *const u32, send_first: *const u32, recv_first: *const u32) -> c_int;
     pub fn mgx_halo_rccl_disconnect(w: *mut mgx_world) -> c_int;

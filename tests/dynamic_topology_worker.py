@@ -3,7 +3,9 @@ rank is its own process on cuda:0 with a sharded world that follows its topology
 and the halo all-to-all-v go through gloo (device buffers staged through the host — a dry run of the
 RCCL path), or — mode "direct" — the exchange lives in the engines: peer-mapped stores (hipIpc) into one record slot per ghost
 robot, wired once, re-aimed when the lists change.  Every rank runs the same driver.
-usage: dynamic_topology_worker.py RANK WORLD_SIZE PORT OUT.npz [collective|direct|direct+resident]"""
+A mode with "+migrate" re-balances every ten ticks: the robots are dealt out again in strips of where they are, and the ones whose
+strip changed move to their new rank (ShardedWorld.migrate: records over the control plane, transports wired again).
+usage: dynamic_topology_worker.py RANK WORLD_SIZE PORT OUT.npz [collective|direct|direct+resident][+migrate]"""
 import os
 import sys
 
@@ -14,6 +16,7 @@ sys.path.insert(0, ROOT)
 def main():
     rank, ws, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     mode = sys.argv[5] if len(sys.argv) > 5 else "collective"
+    migrate, mode = mode.endswith("+migrate"), mode.replace("+migrate", "")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(ws))
     import numpy as np
     import torch
@@ -34,11 +37,20 @@ def main():
         assert got == mode and sw.direct, got
     drv = Driver(sw, n, K, waypoints=[[tuple(rb["goal"])] for rb in sc["robots"]], radii=[rb["radius"] for rb in sc["robots"]],
                  t0=[rb["t0"] for rb in sc["robots"]], steps=sc["steps"], comms_radius=12.0, target_speed=sc["target_speed"])
-    events = [drv.tick() for _ in range(ticks)]
+    events, moved = [], 0
+    for tick in range(ticks):
+        events.append(drv.tick())
+        if migrate and tick % 10 == 9:
+            live = np.nonzero(drv.alive)[0]
+            new = sw.plan.owner.copy()
+            if len(live) >= ws:
+                new[live] = sharded.partition_strips(sw.read_variable_means(0)[live, :2], ws)
+            moved += sw.migrate(new)
+            assert sw.transport == mode, sw.transport  # (wired again as it was)
     ids, eta, lam, mu = sw.read_beliefs()
     exchanges = sw.world.halo_direct_status() if mode.startswith("direct") else 0  # (raises if one of them timed out)
     resident = [int(x) for x in sw.world.resident_stats()] if mode == "direct+resident" else [0, 0, 0]
-    np.savez(out, exchanges=exchanges, resident=np.array(resident), ids=np.array(ids), eta=eta, lam=lam, mu=mu, events=np.array(events), translation=drv.translation,
+    np.savez(out, moved=moved, exchanges=exchanges, resident=np.array(resident), ids=np.array(ids), eta=eta, lam=lam, mu=mu, events=np.array(events), translation=drv.translation,
              finished_at=drv.finished_at, next_number=drv.next_number)
     dist.barrier()
     if mode.startswith("direct"):

@@ -214,6 +214,56 @@ def test_sharded_world_follows_its_topology(world_size, direct):
         assert all(x[0] > 50 for x in st), st  # most ticks ran as ONE launch per rank (robots that are alone on their rank vote no)
 
 
+@pytest.mark.parametrize("world_size,direct", [(2, False), (3, False), (3, True), (2, "resident")])
+def test_robots_migrate_between_ranks(world_size, direct):
+    """Re-balancing a sharded world that follows its topology: every ten ticks the robots are dealt out again in strips of
+    where they ARE (mgx_shard_partition on the current positions), and the ones whose strip changed move to their new rank —
+    graph state, counters and the inter-robot factors attached to their variables as one record (mgx_robot_export /
+    _import / _release), the in-engine transports wired again.  Robots crossing a circle swap sides, so every robot moves
+    at least once; events, trajectories, beliefs and MessageCounts stay the single-world oracle's, tick by tick."""
+    n, K = 9, 10
+    sc = S.circle_scenario(n, K, circle_radius=12.0, n_internal=10, n_external=10)
+    sc["ir"] = []
+    if direct:
+        make, _streams = _own_stream_factory()
+        cluster = sharded.LocalCluster(sc, world_size, make, dynamic=True, direct=True, resident=direct == "resident")
+    else:
+        cluster = sharded.LocalCluster(sc, world_size, World, dynamic=True)
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    dc, dr = _circle_driver(cluster, sc, n, K), _circle_driver(ref, sc, n, K)
+    moved, movers = 0, set()
+    for tick in range(400):
+        if not (dc.finished_at < 0).any():
+            break
+        assert dc.tick() == dr.tick(), tick
+        assert np.array_equal(dc.translation, dr.translation) and np.array_equal(dc.finished_at, dr.finished_at), tick
+        if tick % 10 == 9:
+            assert_identical(cluster, ref, what=f"{world_size} ranks, robots migrating, tick {tick + 1}")
+            old = cluster.ranks[0].plan.owner
+            live = np.nonzero(dc.alive)[0]
+            new = old.copy()
+            if len(live) >= world_size:
+                new[live] = sharded.partition_strips(cluster.read_variable_means(0)[live, :2], world_size)
+            movers |= set(int(g) for g in np.nonzero(new != old)[0])
+            moved += cluster.migrate(new)
+            for sw in cluster.ranks:
+                assert np.array_equal(sw.plan.owner, new) and sw.plan.local == [int(g) for g in np.nonzero(new == sw.plan.rank)[0]]
+            assert_identical(cluster, ref, what=f"{world_size} ranks, right after the migration of tick {tick + 1}")
+            for r in live:
+                assert list(cluster.connections(r)) == list(ref.connections(r))
+    assert (dc.finished_at >= 0).all() and np.array_equal(dc.finished_at, dr.finished_at)
+    print(f"{moved} migrations of {len(movers)} robots over {tick} ticks")
+    assert moved >= n // 2 and len(movers) >= n // 2
+    assert dc.summary()["messages"] == dr.summary()["messages"]  # the counters travelled with the graphs
+    if direct:
+        for sw in cluster.ranks:
+            sw.world.halo_direct_status()  # raises if an exchange timed out
+    if direct == "resident":
+        st = [tuple(int(x) for x in sw.world.resident_stats()) for sw in cluster.ranks]
+        print("resident launches / declined / back-off left per rank:", st)
+
+
 def test_sharded_topology_with_comms_failures_and_initial_connections():
     n, K, world_size = 10, 10, 2
     sc = S.circle_scenario(n, K, circle_radius=10.0, n_internal=10, n_external=10)   # comes with its initial connections

@@ -23,12 +23,14 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-@pytest.mark.parametrize("mode", ["collective", "direct", "direct+resident"])
+@pytest.mark.parametrize("mode", ["collective", "direct", "direct+resident", "collective+migrate", "direct+resident+migrate"])
 def test_two_processes_follow_the_topology(tmp_path, mode):
     """mode "direct": the exchange inside the engines (hipIpc-mapped record slots, one per ghost robot, re-aimed after every topology
     pass that changed the lists) — no host-driven all-to-all in any tick; "direct+resident": and the ghosts' exchange records inside
     ONE resident launch per schedule and rank (`len(ghosts) < n_robots - n_local` in what is exchanged: only robots connected across
-    the ranks travel; every rank still holds a record of every robot — the replicated bookkeeping)"""
+    the ranks travel; every rank still holds a record of every robot — the replicated bookkeeping);
+    "+migrate": every ten ticks the robots are dealt out again by where they are and change ranks (ShardedWorld.migrate: the records
+    over the control plane, the hipIpc areas closed and wired again) — results unchanged"""
     ws, n, K, ticks = 2, 8, 10, 60
     port = _free_port()
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(ws)]
@@ -56,10 +58,14 @@ def test_two_processes_follow_the_topology(tmp_path, mode):
     eta_r, lam_r, mu_r = ref.read_beliefs()
     assert events[:, 0].sum() > 0
     seen = 0
+    migrate, mode = mode.endswith("+migrate"), mode.replace("+migrate", "")
     for o in outs:
         z = np.load(o)
-        assert (int(z["exchanges"]) > (10 if mode == "direct+resident" else ticks)) == mode.startswith("direct")
-        if mode == "direct+resident":
+        if migrate:
+            assert int(z["moved"]) >= n // 2, int(z["moved"])  # (the exchange and launch counts start over with every re-wiring)
+        else:
+            assert (int(z["exchanges"]) > (10 if mode == "direct+resident" else ticks)) == mode.startswith("direct")
+        if mode == "direct+resident" and not migrate:
             assert int(z["resident"][0]) > ticks // 2, z["resident"]  # most schedules ran as ONE launch on this rank
         assert np.array_equal(z["events"], events) and np.array_equal(z["translation"], drv.translation)
         assert np.array_equal(z["finished_at"], drv.finished_at) and int(z["next_number"]) == drv.next_number
