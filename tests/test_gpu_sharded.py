@@ -264,6 +264,45 @@ def test_robots_migrate_between_ranks(world_size, direct):
         print("resident launches / declined / back-off left per rank:", st)
 
 
+def test_migration_carries_frozen_inboxes_flags_and_fresh_factors():
+    """What else lives on the owner's rank only: the inboxes factor kinds froze with when they were switched off
+    (mgx_set_enabled), the records inter-robot factors kept, the first-update marks of kinds that came back — and factors
+    created by the topology pass of the very tick before.  Robots change ranks in every one of these states, with radios
+    failing at random; beliefs, connections and MessageCounts stay the single-world oracle's."""
+    n, K, world_size = 10, 10, 3
+    sc = S.circle_scenario(n, K, circle_radius=10.0, n_internal=10, n_external=10)   # comes with its initial connections
+    assert sc["ir"]
+    cluster = sharded.LocalCluster(sc, world_size, World, dynamic=True)
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    rng = np.random.default_rng(5)
+    draws = rng.random((80, n)) > 0.2
+
+    def failures(tick, k):
+        return draws[tick, :k]
+    dc, dr = (_circle_driver(w, sc, n, K, failure_draws=failures, despawn_when_finished=False) for w in (cluster, ref))
+    dc.next_number = dr.next_number = 1 + (K - 1) * len(sc["ir"])
+    full = sc["params"]["enable_mask"] if isinstance(sc["params"], dict) and "enable_mask" in sc["params"] else 7
+    masks = {8: full & ~2, 16: full, 24: full & ~1, 30: full & ~4, 36: full, 44: full & ~2, 50: full}  # tick -> kinds enabled from then on
+    moved = 0
+    for tick in range(64):
+        if tick in masks:
+            for w in (cluster, ref):
+                w.set_enabled(masks[tick])
+        assert dc.tick() == dr.tick(), tick
+        if tick % 4 == 3:  # every fourth tick a third of the robots moves one rank on: in every state the script goes through
+            new = cluster.ranks[0].plan.owner.copy()
+            sel = np.arange(n) % 3 == (tick // 4) % 3
+            new[sel] = (new[sel] + 1) % world_size
+            moved += cluster.migrate(new)
+            assert_identical(cluster, ref, what=f"migration in state {tick}")
+    assert moved > 40
+    assert_identical(cluster, ref, what="3 ranks, kinds switched, radios failing, robots migrating")
+    for r in range(n):
+        assert list(cluster.connections(r)) == list(ref.connections(r))
+    assert dc.summary()["messages"] == dr.summary()["messages"]
+
+
 def test_sharded_topology_with_comms_failures_and_initial_connections():
     n, K, world_size = 10, 10, 2
     sc = S.circle_scenario(n, K, circle_radius=10.0, n_internal=10, n_external=10)   # comes with its initial connections
