@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--preheat-ms", type=float, default=60.0, help="untimed work in front of the repetitions (clock ramp)")
     ap.add_argument("--robots-per-gpu", type=int, default=1000)
     ap.add_argument("--horizon", type=int, default=16)
+    ap.add_argument("--ticks-per-submission", type=int, default=2,
+                    help="ticks (10-step schedules) handed to the engine per submission (mgx_batch_begin / _end: the engine merges them into "
+                         "one resident launch); 1 = one submission per tick, no batch")
     ap.add_argument("--no-configs1", action="store_true", help="skip the BASELINE configs[1] block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the tick / dynamic_tick / scenario measurements")
@@ -66,25 +69,43 @@ def parse():
     return ap.parse_args()
 
 
-def run_steps(iterate, n, steps_one_tick):
-    """issue exactly n iterations as ticks of len(steps_one_tick) plus a remainder"""
+def run_steps(iterate, n, steps_one_tick, batch=None, group=1):
+    """issue exactly n iterations as ticks of len(steps_one_tick) plus a remainder.  batch (a callable that gives a context
+    manager: World.batch / ShardedWorld.batch) with group > 1: the ticks are handed over `group` at a time inside
+    mgx_batch_begin / mgx_batch_end — the engine submits each group together, merged into one resident launch where its
+    segments fit — every tick still its own mgx_iterate call, nothing skipped, results bit-identical (tests/test_gpu_batch.py).
+    Returns the sweep-kernel launches the groups were submitted as (None: not batched)."""
     full, rem = divmod(n, len(steps_one_tick))
-    for _ in range(full):
-        iterate(steps_one_tick)
-    if rem:
-        iterate(steps_one_tick[:rem])
+    if batch is None or group <= 1:
+        for _ in range(full):
+            iterate(steps_one_tick)
+        if rem:
+            iterate(steps_one_tick[:rem])
+        return None
+    launches, t = 0, 0
+    while t < full or (rem and t == 0 and full == 0):
+        g = min(group, full - t)
+        with batch() as b:
+            for _ in range(g):
+                iterate(steps_one_tick)
+            if rem and t + g >= full:  # the remainder rides with the last group
+                iterate(steps_one_tick[:rem])
+                rem = 0
+        launches += getattr(b, "launches", 0) or 0
+        t += max(g, 1)
+    return launches
 
 
-def timed(torch, dist, iterate, steps_one_tick, a, multi, red_dev="cuda", sync=None):
+def timed(torch, dist, iterate, steps_one_tick, a, multi, red_dev="cuda", sync=None, batch=None, group=1):
     """The contract's measurement, repeated: W warm-up steps, a pre-heat, then `repeats` x [barrier + synchronize,
     EXACTLY K steps, barrier + synchronize].  Returns per-repetition (wall seconds MAX over ranks, device seconds
     between HIP events on the launch stream MAX over ranks)."""
     sync = sync or torch.cuda.synchronize
-    run_steps(iterate, a.warmup, steps_one_tick)
+    run_steps(iterate, a.warmup, steps_one_tick, batch, group)
     sync()
     t_end = time.perf_counter() + a.preheat_ms * 1e-3
     while time.perf_counter() < t_end:  # the same work, untimed: clocks ramp up in the first tens of milliseconds
-        run_steps(iterate, max(a.steps, SCHEDULE_LEN), steps_one_tick)
+        run_steps(iterate, max(a.steps, SCHEDULE_LEN), steps_one_tick, batch, group)
         sync()
     walls, devs = [], []
     for _ in range(a.repeats):  # wall clock: nothing but the K steps between the two barrier + synchronize pairs
@@ -92,7 +113,7 @@ def timed(torch, dist, iterate, steps_one_tick, a, multi, red_dev="cuda", sync=N
             dist.barrier()
         sync()
         t0 = time.perf_counter()
-        run_steps(iterate, a.steps, steps_one_tick)
+        run_steps(iterate, a.steps, steps_one_tick, batch, group)
         if multi:
             dist.barrier()
         sync()
@@ -101,7 +122,7 @@ def timed(torch, dist, iterate, steps_one_tick, a, multi, red_dev="cuda", sync=N
         sync()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        run_steps(iterate, a.steps, steps_one_tick)
+        run_steps(iterate, a.steps, steps_one_tick, batch, group)
         ev1.record()
         sync()
         devs.append(ev0.elapsed_time(ev1) * 1e-3)
@@ -112,7 +133,7 @@ def timed(torch, dist, iterate, steps_one_tick, a, multi, red_dev="cuda", sync=N
     return walls, devs
 
 
-def sustained(torch, dist, iterate, steps_one_tick, seconds, ms_per_step, multi, red_dev="cuda", sync=None, units_per_step=1.0):
+def sustained(torch, dist, iterate, steps_one_tick, seconds, ms_per_step, multi, red_dev="cuda", sync=None, units_per_step=1.0, batch=None, group=1):
     """The headline workload for `seconds` of wall clock in ONE timed block (the repetitions above are a fraction of a
     millisecond each: clocks, caches and the host's launch queue in a steady state are a different regime).  The number of
     steps is fixed in advance from the measured step time — the same on every rank — and the block is bracketed like every
@@ -127,7 +148,7 @@ def sustained(torch, dist, iterate, steps_one_tick, seconds, ms_per_step, multi,
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    run_steps(iterate, n, steps_one_tick)
+    run_steps(iterate, n, steps_one_tick, batch, group)
     if multi:
         dist.barrier()
     sync()
@@ -588,18 +609,21 @@ def main():
         w1 = World(sc1["params"], stream=stream, fma=a.fma)
         S.populate(w1, sc1)
         assert len(sc1["steps"]) == SCHEDULE_LEN
-        walls, devs = timed(torch, dist, w1.iterate, sc1["steps"], a, multi, red_dev)
+        walls, devs = timed(torch, dist, w1.iterate, sc1["steps"], a, multi, red_dev, batch=w1.batch, group=a.ticks_per_submission)
         r1 = summary(walls, devs, a.steps, units_per_step=world_size)
         bytes1 = S.algorithmic_bytes_per_robot_iter(K, 0.0) * n_loc
-        n_launch = -(-a.steps // SCHEDULE_LEN)
+        # launches of the timed K-step block: as the engine counted them for the same block, issued once more
+        n_launch = run_steps(w1.iterate, a.steps, sc1["steps"], w1.batch, a.ticks_per_submission) or -(-a.steps // SCHEDULE_LEN)
+        it1 = a.steps / n_launch
         line["configs1"] = {
             "value": round(r1["value"], 2), "unit": "GBP iterations/s (same unit as the headline)",
             "ms_per_step": r1["ms_per_step"], "device_ms_per_step": r1["device_ms_per_step"], "spread": r1["spread"],
             "config": {"workload": f"BASELINE configs[1]: synthetic {n_loc} robots x {K} horizon per GPU, dynamics + obstacle factors, "
-                                   "seed 805, 10-step schedule = one launch",
+                                   "seed 805, 10-step schedule" + (f", {a.ticks_per_submission} ticks per submission (mgx_batch_*) = one launch"
+                                                                   if a.ticks_per_submission > 1 else " = one launch"),
                        "parallelism": f"{world_size} independent shard(s), no exchange (robots do not interact)"},
-            "roofline": roofline("k_robot_sweep<16,0,false>", bytes1 * SCHEDULE_LEN, n_launch, r1["device_s_median"], "config1" if full_size else "",
-                                 SCHEDULE_LEN),
+            "roofline": roofline("k_robot_sweep<16,0,false>", bytes1 * it1, n_launch, r1["device_s_median"], "config1" if full_size else "",
+                                 it1),
         }
         w1.synchronize()
 
@@ -646,14 +670,22 @@ def main():
         dist.broadcast_object_list(flag, src=0)
         probe_ok = flag[0]
 
-    walls, devs = timed(torch, dist, sw.iterate, sc2["steps"], a, multi, red_dev)
+    G = a.ticks_per_submission
+    walls, devs = timed(torch, dist, sw.iterate, sc2["steps"], a, multi, red_dev, batch=sw.batch, group=G)
     sw.iterate(sc2["steps"])
     resident = sw.world.last_launch_count() == 1  # the engine ran the 10-step schedule as ONE resident launch
+    head_launches = run_steps(sw.iterate, a.steps, sc2["steps"], sw.batch, G)  # (the timed block once more: launches as the engine counted them)
     r2 = summary(walls, devs, a.steps, units_per_step=world_size)
+    per_tick = None
+    if G > 1 and not multi:  # the same workload, one submission per tick (every tick its own launch): what the merge is worth
+        walls_t, devs_t = timed(torch, dist, sw.iterate, sc2["steps"], a, multi, red_dev)
+        rt = summary(walls_t, devs_t, a.steps, units_per_step=world_size)
+        per_tick = {"value": round(rt["value"], 2), "ms_per_step": rt["ms_per_step"], "device_ms_per_step": rt["device_ms_per_step"],
+                    "what": "the same workload without mgx_batch_*: every 10-step tick submitted (and launched) by itself"}
     sustained_head = None
     if a.sustained_seconds > 0:
         sustained_head = sustained(torch, dist, sw.iterate, sc2["steps"], a.sustained_seconds, r2["ms_per_step"], multi, red_dev,
-                                   units_per_step=world_size)
+                                   units_per_step=world_size, batch=sw.batch, group=G)
     by_transport = {("one GPU, no exchange" if not multi else "collective"): round(r2["value"], 2)}
     transport = "none (one GPU)" if not multi else "collective (torch.distributed all_to_all_single over RCCL, host-driven)"
     sw.synchronize()
@@ -701,19 +733,29 @@ def main():
                         line["in_engine_note"] = "resident launches were declined by the ranks' agreement during verification: switched off"
                 if verified:
                     try:
-                        walls_i, devs_i = timed(torch, dist, sw_in.iterate, sc2["steps"], a, True, red_dev, sync=sw_in.synchronize)
+                        walls_i, devs_i = timed(torch, dist, sw_in.iterate, sc2["steps"], a, True, red_dev, sync=sw_in.synchronize,
+                                                batch=sw_in.batch, group=G)
                         sw_in.iterate(sc2["steps"])
                         sw_in.synchronize()
+                        lpt_in = sw_in.world.last_launch_count()
+                        launches_in = run_steps(sw_in.iterate, a.steps, sc2["steps"], sw_in.batch, G)
+                        sw_in.synchronize()
+                        if G > 1:  # one submission per tick, for the same wiring
+                            walls_t, devs_t = timed(torch, dist, sw_in.iterate, sc2["steps"], a, True, red_dev, sync=sw_in.synchronize)
+                            rt = summary(walls_t, devs_t, a.steps, units_per_step=world_size)
+                            per_tick = {"value": round(rt["value"], 2), "ms_per_step": rt["ms_per_step"], "device_ms_per_step": rt["device_ms_per_step"],
+                                        "what": "the same workload and wiring without mgx_batch_*: every 10-step tick submitted by itself"}
                     except Exception as e:  # noqa: BLE001
                         err = f"{type(e).__name__}: {e}"
                 if verified and agree(not err):
                     ri = summary(walls_i, devs_i, a.steps, units_per_step=world_size)
-                    in_engine = {"transport": got, "result": ri, "launches_per_tick": sw_in.world.last_launch_count(),
+                    in_engine = {"transport": got, "result": ri, "launches_per_tick": lpt_in, "launches": launches_in,
                                  "resident_stats": [int(x) for x in sw_in.world.resident_stats()]}
                     try:
                         if a.sustained_seconds > 0:
                             in_engine["sustained"] = sustained(torch, dist, sw_in.iterate, sc2["steps"], a.sustained_seconds, ri["ms_per_step"],
-                                                               True, red_dev, sync=sw_in.synchronize, units_per_step=world_size)
+                                                               True, red_dev, sync=sw_in.synchronize, units_per_step=world_size,
+                                                               batch=sw_in.batch, group=G)
                             in_engine["resident_stats"] = [int(x) for x in sw_in.world.resident_stats()]
                         if got == "direct+resident":
                             # the same wiring with resident launches switched off on every rank: what the exchange costs WITHOUT the
@@ -766,19 +808,30 @@ def main():
                      "direct": "direct (peer-mapped stores over xGMI + device-side arrival counters, in-engine, one C call per tick)"}[in_engine["transport"]]
     ticks = -(-a.steps // SCHEDULE_LEN)
     launches = ticks if resident else a.steps + ticks
-    it_per_launch = SCHEDULE_LEN if resident else 1
+    counted = in_engine.get("launches") if in_engine is not None else head_launches
+    if counted:  # batched submissions: as the engine counted them
+        launches = counted
+    it_per_launch = (a.steps / launches) if resident else 1
+    line["submission"] = {"ticks_per_submission": G, "launches_per_timed_block": launches, "iterations_per_launch": it_per_launch,
+                          "what": ("every tick is one mgx_iterate call; the ticks are handed to the engine " + str(G) + " at a time inside mgx_batch_begin / "
+                                   "mgx_batch_end, which submits them together — merged into one resident launch where their segments fit (the graphs "
+                                   "go HBM -> LDS and back once per launch instead of once per tick); nothing is skipped or reordered, results are "
+                                   "bit-identical (tests/test_gpu_batch.py)") if G > 1 else "one submission (and one resident launch) per tick"}
+    if per_tick is not None:
+        line["one_submission_per_tick"] = per_tick
     kernel = (("k_robot_sweep<16,2,true,shard>" if multi else "k_robot_sweep<16,2,true>") + " (whole schedule resident)") if resident else \
         "k_robot_sweep<16,2,false> (one iteration per launch)"
     line.update({
         "value": round(head["value"], 2), "ms_per_step": head["ms_per_step"], "device_ms_per_step": head["device_ms_per_step"],
         "spread": head["spread"],
         "config": {"workload": f"BASELINE configs[{'2' if not multi else '3 layout'}]: synthetic {n_tot} robots x {K} horizon, dynamics + "
-                               f"obstacle + inter-robot factors (comm radius 8, {D:.2f} neighbours/robot), seed 805, 10/10 schedule",
+                               f"obstacle + inter-robot factors (comm radius 8, {D:.2f} neighbours/robot), seed 805, 10/10 schedule"
+                               + (f", {G} ticks per submission" if G > 1 else ""),
                    "robots_per_gpu": n_loc, "horizon": K, "robots_total": n_tot,
                    "parallelism": (f"robots sharded over {world_size} GPUs in (y, x) strips, one exchange of boundary snapshot records "
                                    "per external iteration" + (", inside ONE resident launch per schedule and rank" if resident else "")) if multi else
-                                  "1 GPU: the 10-step schedule is ONE resident launch, neighbouring workgroups hand their snapshot records "
-                                  "over inside it" if resident else "1 GPU",
+                                  (f"1 GPU: {G} ticks of the 10-step schedule are ONE resident launch" if G > 1 else "1 GPU: the 10-step schedule is "
+                                   "ONE resident launch") + ", neighbouring workgroups hand their snapshot records over inside it" if resident else "1 GPU",
                    "ghost_robots_this_rank": len(sw.plan.ghosts)},
         "roofline": roofline(kernel, bytes2 * it_per_launch, launches, head["device_s_median"],
                              ("config2_resident" if resident else "config2") if full_size else "", it_per_launch,

@@ -172,6 +172,21 @@ int mgx_connections(mgx_world *w, int32_t robot, int32_t *others, uint32_t capac
  * internal phase if steps[i] & MGX_STEP_INTERNAL and the external phase if
  * steps[i] & MGX_STEP_EXTERNAL.  Asynchronous on the world's stream. */
 int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n);
+/* Batches: several schedules, one submission.  A resident schedule launch pays for itself once — the robots' graphs go
+ * HBM -> LDS when it starts and back when it ends, an eighth of a ten-iteration launch at 1000 x 16 — so a caller that issues
+ * schedule after schedule with nothing in between (the reference's `iterate_gbp_v2` loop run ahead of the renderer, a planner
+ * that looks several ticks ahead, a benchmark loop) brackets the loop: between mgx_batch_begin and mgx_batch_end the schedules
+ * handed to mgx_iterate are recorded and submitted TOGETHER, merged into as few launches as their segments fit (32 [external]
+ * internal* segments per launch: three ticks of the 10 / 10 schedule) — when the recorded ones fill a launch, at mgx_batch_end,
+ * and in front of ANY other call on this world, which therefore finds the world as if every schedule had run when it was issued.
+ * Nothing is reordered, nothing skipped: iterate(a); iterate(b) computes what iterate(a ++ b) computes (the phases are
+ * flattened either way, robot.rs:1787-1860), bit for bit — the engine's form of capturing a launch-bound loop in a graph.
+ * The one visible difference: work recorded in an open batch is on the world's stream only after its submission — a caller that
+ * waits on the stream by its own means (events) closes the batch, or calls mgx_synchronize, first.  Works on sharded worlds
+ * whose exchange lives in the engine (every rank brackets alike).  n_schedules / n_launches (may be NULL): schedules recorded
+ * since mgx_batch_begin and sweep-kernel launches they were submitted as. */
+int mgx_batch_begin(mgx_world *w);
+int mgx_batch_end(mgx_world *w, uint32_t *n_schedules, uint32_t *n_launches);
 
 /* How the last mgx_iterate / mgx_tick call ran: the number of sweep-kernel launches it enqueued.  A world whose
  * robots all live on this device, with inter-robot factors enabled and few enough robots for every workgroup

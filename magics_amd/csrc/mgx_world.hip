@@ -418,6 +418,13 @@ struct mgx_world {
     std::vector<int32_t> peer_fill;
     unsigned long long *sweep_err_host = nullptr;  // host-mapped; non-zero once a wait inside a resident launch gave up
     unsigned long long flag_base = 0;              // every progress word is below or at this value between launches
+    // mgx_batch_begin .. mgx_batch_end: the schedules mgx_iterate was handed since the last submission, one after the other (what
+    // iterate(a); iterate(b) computes is what iterate(a ++ b) computes), the launches they were submitted as and how many of them
+    struct Batch {
+        bool open = false;
+        std::vector<uint8_t> steps;
+        uint32_t schedules = 0, submissions = 0, launches = 0;
+    } batch;
     bool resident_off = false;                     // mgx_set_resident_launches(w, 0)
     bool resident_decline = false;                 // mgx_set_resident_launches(w, 2)
     // residency census of resident launches (SegPlan, mgx_dev.h): cumulative per-group counts the device counters reach, the
@@ -590,6 +597,18 @@ struct mgx_world {
 };
 
 static size_t edge_index(const std::vector<int32_t> &in_ptr, int K, int r, int j, int slot);
+
+// mgx_batch_begin .. mgx_batch_end (below, in front of mgx_iterate): every other call on the world first submits the schedules
+// recorded so far, so that it finds the world as if each one had run when it was issued
+static int iterate_now(mgx_world *w, const uint8_t *steps, uint32_t n);
+static int submit_batch(mgx_world *w);
+#define MGX_ENTER(w)                                                    \
+    do {                                                                \
+        if ((w) && !(w)->batch.steps.empty()) {                         \
+            const int rc_enter_ = submit_batch(w);                      \
+            if (rc_enter_ != MGX_OK) return rc_enter_;                  \
+        }                                                               \
+    } while (0)
 
 static bool device_ok() {
     static int state = 0;  // 0 unknown, 1 ok, -1 none
@@ -1827,6 +1846,7 @@ int mgx_world_destroy(mgx_world *w) {
 }
 
 int mgx_set_stream(mgx_world *w, void *hip_stream) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (w->dev_valid) HIP_TRY(hipStreamSynchronize(w->stream));
     w->stream = (hipStream_t)hip_stream;
@@ -1834,6 +1854,7 @@ int mgx_set_stream(mgx_world *w, void *hip_stream) {
 }
 
 int mgx_synchronize(mgx_world *w) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (!device_ok()) return fail(MGX_ERR_NO_DEVICE, "no usable HIP device");
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
@@ -1842,6 +1863,7 @@ int mgx_synchronize(mgx_world *w) {
 }
 
 int mgx_world_set_sdf(mgx_world *w, const uint8_t *rgb, uint32_t width, uint32_t height, double world_w, double world_h) {
+    MGX_ENTER(w);
     if (!w || !rgb || !width || !height || !(world_w > 0) || !(world_h > 0)) return fail(MGX_ERR_INVALID, "bad sdf arguments");
     w->sdf_red.resize((size_t)width * height);
     for (size_t i = 0; i < w->sdf_red.size(); i++) w->sdf_red[i] = rgb[3 * i];  // pixel[0], obstacle.rs:178
@@ -1851,6 +1873,7 @@ int mgx_world_set_sdf(mgx_world *w, const uint8_t *rgb, uint32_t width, uint32_t
 }
 
 int mgx_world_set_environment(mgx_world *w, const mgx_env_desc *env) {
+    MGX_ENTER(w);
     if (!w || !env) return fail(MGX_ERR_INVALID, "null argument");
     uint32_t W = 0, H = 0;
     const int rc = env_red_plane(env, env->sdf_resolution, env->sdf_expansion, env->sdf_blur, true, w->stream, w->sdf_red, W, H);
@@ -1863,6 +1886,7 @@ int mgx_world_set_environment(mgx_world *w, const mgx_env_desc *env) {
 }
 
 int mgx_robot_add(mgx_world *w, const mgx_robot_desc *d, int32_t *robot_id) {
+    MGX_ENTER(w);
     if (!w || !d || !d->mean0 || !d->prior_diag || !d->dt) return fail(MGX_ERR_INVALID, "null argument");
     if (d->K < 3) return fail(MGX_ERR_INVALID, "K must be >= 3");
     if (w->K && (int)d->K != w->K) return fail(MGX_ERR_INVALID, "all robots of a world share K (%d), got %u", w->K, d->K);
@@ -2063,6 +2087,7 @@ static void ir_disconnect_batch(mgx_world *w, const std::vector<std::pair<int, i
 // `query.get_mut` fails) — the same dataflow as idle with the antenna off, for good.  The other
 // robots drop their factors towards it in the following topology passes.
 int mgx_robot_remove(mgx_world *w, int32_t robot) {
+    MGX_ENTER(w);
     if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
     Robot &rb = w->robots[(size_t)robot];
     if (rb.removed) return fail(MGX_ERR_STATE, "robot %d already removed", robot);
@@ -2100,6 +2125,7 @@ static int ensure_frozen(mgx_world *w) {
 }
 
 int mgx_set_enabled(mgx_world *w, uint32_t kind_mask) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (kind_mask & ~15u) return fail(MGX_ERR_INVALID, "unknown factor kind bits 0x%x", kind_mask);
     const uint32_t on = kind_mask & ~w->p.enable_mask, off = w->p.enable_mask & ~kind_mask;
@@ -2172,6 +2198,7 @@ int mgx_set_enabled(mgx_world *w, uint32_t kind_mask) {
 }
 
 int mgx_set_antenna(mgx_world *w, int32_t robot, int32_t active) {
+    MGX_ENTER(w);
     if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
     if (w->robots[(size_t)robot].removed) return fail(MGX_ERR_STATE, "robot %d was removed", robot);
     if (w->robots[(size_t)robot].antenna != (active ? 1 : 0)) flush_counts(w);
@@ -2180,6 +2207,7 @@ int mgx_set_antenna(mgx_world *w, int32_t robot, int32_t active) {
     return MGX_OK;
 }
 int mgx_set_idle(mgx_world *w, int32_t robot, int32_t idle) {
+    MGX_ENTER(w);
     if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
     if (w->robots[(size_t)robot].removed) return fail(MGX_ERR_STATE, "robot %d was removed", robot);
     if (w->robots[(size_t)robot].idle != (idle ? 1 : 0)) flush_counts(w);
@@ -2189,6 +2217,7 @@ int mgx_set_idle(mgx_world *w, int32_t robot, int32_t idle) {
 }
 
 int mgx_set_antennas(mgx_world *w, uint32_t n, const int32_t *robots, const uint8_t *active) {
+    MGX_ENTER(w);
     if (!w || (n && (!robots || !active))) return fail(MGX_ERR_INVALID, "null argument");
     for (uint32_t i = 0; i < n; i++) {
         if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
@@ -2206,12 +2235,14 @@ int mgx_set_antennas(mgx_world *w, uint32_t n, const int32_t *robots, const uint
 // The fine-grained calls keep robots_connected_with in step, as create_/delete_interrobot_factors
 // do (robot.rs:1406-1408,1546), so that they can be mixed with mgx_update_topology.
 int mgx_ir_connect(mgx_world *w, int32_t owner, int32_t other, uint64_t first_robot_number) {
+    MGX_ENTER(w);
     int rc = ir_connect(w, owner, other, first_robot_number);
     if (rc != MGX_OK) return rc;
     if (!w->sets.has((size_t)owner, other)) w->sets.insert_sorted((size_t)owner, other);
     return MGX_OK;
 }
 int mgx_ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
+    MGX_ENTER(w);
     int rc = ir_disconnect(w, a, b);
     if (rc != MGX_OK) return rc;
     w->sets.erase((size_t)a, b);
@@ -2416,6 +2447,7 @@ static int neighbours(mgx_world *w, const float *pos, float radius, uint32_t met
 
 int mgx_neighbours(mgx_world *w, const float *positions_xyz, float radius, uint32_t method, int32_t *row_ptr, int32_t *neighbours_out,
                    uint64_t capacity, uint64_t *needed) {
+    MGX_ENTER(w);
     if (!w || !positions_xyz || !row_ptr) return fail(MGX_ERR_INVALID, "null argument");
     if (method > MGX_NEIGHBOURS_GRID) return fail(MGX_ERR_INVALID, "bad method");
     std::vector<int32_t> ptr, idx;
@@ -2430,6 +2462,7 @@ int mgx_neighbours(mgx_world *w, const float *positions_xyz, float radius, uint3
 }
 
 int mgx_connections(mgx_world *w, int32_t robot, int32_t *others, uint32_t capacity, uint32_t *n) {
+    MGX_ENTER(w);
     if (!w || !n || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
     const int32_t *c = w->sets.row((size_t)robot);
     const size_t nc = (size_t)w->sets.cnt[(size_t)robot];
@@ -2444,6 +2477,7 @@ static int topology_bookkeeping(mgx_world *w, std::vector<int32_t> &ptr, std::ve
                                 uint32_t *stats, StageTimer &tm, OwnerLists *own_lists);
 int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, uint32_t method, uint64_t *robot_number_next,
                         uint32_t *stats) {
+    MGX_ENTER(w);
     if (!w || !positions_xyz || !robot_number_next) return fail(MGX_ERR_INVALID, "null argument");
     if (*robot_number_next == 0) return fail(MGX_ERR_INVALID, "robot_number is NonZeroUsize");
     if (method > MGX_NEIGHBOURS_GRID) return fail(MGX_ERR_INVALID, "bad method");
@@ -2610,6 +2644,7 @@ static int mission_upload(mgx_world *w) {
 }
 
 int mgx_mission_set(mgx_world *w, int32_t robot, const mgx_mission_desc *desc) {
+    MGX_ENTER(w);
     if (!w || !desc || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
     const Robot &rb = w->robots[(size_t)robot];
     if (rb.ghost || rb.removed) return fail(MGX_ERR_INVALID, "robot %d is not a live local robot", robot);
@@ -2641,12 +2676,14 @@ int mgx_mission_set(mgx_world *w, int32_t robot, const mgx_mission_desc *desc) {
 
 int mgx_mission_tick(mgx_world *w, float comms_radius, uint32_t method, uint64_t *robot_number_next, int32_t despawn_finished,
                      const uint8_t *antennas, double max_speed, double delta_t, const uint8_t *steps, uint32_t n_steps, uint32_t *stats) {
+    MGX_ENTER(w);
     int rc = mgx_mission_tick_begin(w, comms_radius, method, robot_number_next, despawn_finished, stats);
     return rc != MGX_OK ? rc : mgx_mission_tick_end(w, antennas, max_speed, delta_t, steps, n_steps);
 }
 
 int mgx_mission_tick_begin(mgx_world *w, float comms_radius, uint32_t method, uint64_t *robot_number_next, int32_t despawn_finished,
                            uint32_t *stats) {
+    MGX_ENTER(w);
     if (!w || !robot_number_next) return fail(MGX_ERR_INVALID, "null argument");
     if (*robot_number_next == 0) return fail(MGX_ERR_INVALID, "robot_number is NonZeroUsize");
     if (method > MGX_NEIGHBOURS_GRID) return fail(MGX_ERR_INVALID, "bad method");
@@ -2727,6 +2764,7 @@ int mgx_mission_tick_begin(mgx_world *w, float comms_radius, uint32_t method, ui
 }
 
 int mgx_mission_tick_end(mgx_world *w, const uint8_t *antennas, double max_speed, double delta_t, const uint8_t *steps, uint32_t n_steps) {
+    MGX_ENTER(w);
     if (!w || (!steps && n_steps)) return fail(MGX_ERR_INVALID, "null argument");
     mgx_world::Mission &ms = w->mission;
     if (!ms.in_tick) return fail(MGX_ERR_STATE, "mgx_mission_tick_end without mgx_mission_tick_begin");
@@ -2794,7 +2832,7 @@ int mgx_mission_tick_end(mgx_world *w, const uint8_t *antennas, double max_speed
     const bool fuse = !plan.empty() && plan[0].ext == 0 && plan[0].n_int > 0 && w->thaw_kinds == 0;
     if (!fuse) {
         HIP_TRY(launch_update_priors(w->d, R, ms.robots_d.p, ms.waypoints_d.p, ms.ts_list_d.p, ms.what_d.p, max_speed, delta_t, s));
-        rc = mgx_iterate(w, steps, n_steps);
+        rc = iterate_now(w, steps, n_steps);
     } else {
         w->d.upd = ms.rec_d.p; w->d.upd_max_speed = max_speed; w->d.upd_delta_t = delta_t;
         const int resident = run_resident(w, plan);
@@ -2819,6 +2857,7 @@ int mgx_mission_tick_end(mgx_world *w, const uint8_t *antennas, double max_speed
 }
 
 int mgx_mission_finished(mgx_world *w, int32_t *robots, uint32_t capacity, uint32_t *n) {
+    MGX_ENTER(w);
     if (!w || !n) return fail(MGX_ERR_INVALID, "null argument");
     const std::vector<int32_t> &f = w->mission.last_finished;
     *n = (uint32_t)f.size();
@@ -2827,6 +2866,7 @@ int mgx_mission_finished(mgx_world *w, int32_t *robots, uint32_t capacity, uint3
     return MGX_OK;
 }
 int mgx_mission_translations(mgx_world *w, float *translations, uint32_t capacity_robots, uint32_t *n_robots) {
+    MGX_ENTER(w);
     if (!w || !translations) return fail(MGX_ERR_INVALID, "null argument");
     const mgx_world::Mission &ms = w->mission;
     const size_t n = std::min<size_t>(ms.tr_n, capacity_robots);
@@ -2836,6 +2876,7 @@ int mgx_mission_translations(mgx_world *w, float *translations, uint32_t capacit
 }
 
 int mgx_mission_read(mgx_world *w, float *translations, int32_t *targets, int64_t *finished_tick) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     mgx_world::Mission &ms = w->mission;
     if (!ms.any) return fail(MGX_ERR_STATE, "no robot has a mission");
@@ -2854,6 +2895,7 @@ int mgx_mission_read(mgx_world *w, float *translations, int32_t *targets, int64_
 
 int mgx_sweep(mgx_world *w, int32_t robot, uint32_t external_phases, uint32_t internal_phases, uint32_t n_internal,
               uint32_t hints) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if ((external_phases & ~3u) || (internal_phases & ~3u)) return fail(MGX_ERR_INVALID, "bad phase mask");
     if (hints & ~MGX_HINT_NEXT_STARTS_EXTERNAL) return fail(MGX_ERR_INVALID, "bad hints");
@@ -2886,8 +2928,62 @@ static std::vector<Launch> plan_launches(const uint8_t *steps, uint32_t n) {
     return out;
 }
 
+// ---- batches: several schedules, one submission ---------------------------------------------------------------------------
+// A resident schedule launch pays for itself once: the robots' graphs go HBM -> LDS when it starts and back when it ends, some
+// 12 us of a 94 us launch at 1000 x 16 (stamps: staging 17.6 k + write-back 14.7 k of 242 k clocks).  A caller that issues
+// schedule after schedule with nothing in between (a planner that runs ahead, a benchmark loop) can bracket the loop: the
+// schedules are recorded and submitted together, merged into as few launches as their segments fit (MAX_SEGS per launch) —
+// the engine's form of capturing a launch-bound loop in a graph.  Nothing is reordered and nothing is skipped:
+// iterate(a); iterate(b) computes exactly what iterate(a ++ b) computes (the phases are flattened either way), and every other
+// call on the world first submits what was recorded (MGX_ENTER), so it finds the world as if each schedule had run when it was
+// issued.
+static int submit_batch(mgx_world *w) {
+    std::vector<uint8_t> st;
+    st.swap(w->batch.steps);  // (first: whatever runs below may pass MGX_ENTER again)
+    if (st.empty()) return MGX_OK;
+    const int rc = iterate_now(w, st.data(), (uint32_t)st.size());
+    w->batch.submissions++;
+    w->batch.launches += w->last_sweep_launches;
+    return rc;
+}
+
+int mgx_batch_begin(mgx_world *w) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    if (w->batch.open) return fail(MGX_ERR_STATE, "a batch is open already");
+    w->batch.open = true;
+    w->batch.schedules = w->batch.submissions = w->batch.launches = 0;
+    return MGX_OK;
+}
+int mgx_batch_end(mgx_world *w, uint32_t *n_schedules, uint32_t *n_launches) {
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    if (!w->batch.open) return fail(MGX_ERR_STATE, "no batch is open");
+    w->batch.open = false;
+    const int rc = submit_batch(w);
+    if (n_schedules) *n_schedules = w->batch.schedules;
+    if (n_launches) *n_launches = w->batch.launches;
+    return rc;
+}
+
 int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n) {
     if (!w || (!steps && n)) return fail(MGX_ERR_INVALID, "null argument");
+    if (!w->batch.open) return iterate_now(w, steps, n);
+    for (uint32_t i = 0; i < n; i++)
+        if (steps[i] & ~(MGX_STEP_INTERNAL | MGX_STEP_EXTERNAL)) return fail(MGX_ERR_INVALID, "bad step %u", i);
+    mgx_world::Batch &b = w->batch;
+    b.schedules++;
+    if (!b.steps.empty()) {  // does it still fit the launch the recorded ones make?
+        std::vector<uint8_t> both(b.steps);
+        both.insert(both.end(), steps, steps + n);
+        if (plan_launches(both.data(), (uint32_t)both.size()).size() > (size_t)MAX_SEGS) {
+            const int rc = submit_batch(w);
+            if (rc != MGX_OK) return rc;
+        }
+    }
+    b.steps.insert(b.steps.end(), steps, steps + n);
+    return MGX_OK;
+}
+
+static int iterate_now(mgx_world *w, const uint8_t *steps, uint32_t n) {
     const std::vector<Launch> plan = plan_launches(steps, n);
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }  // (a declined launch is run again here: not this call's launches)
     w->last_sweep_launches = 0;
@@ -2900,12 +2996,25 @@ int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n) {
     return MGX_OK;
 }
 
-int mgx_internal_factor_iteration(mgx_world *w, int32_t robot) { return w ? sweep(w, robot, 0, PH_INT_FACTOR, 1) : fail(MGX_ERR_INVALID, "null world"); }
-int mgx_internal_variable_iteration(mgx_world *w, int32_t robot) { return w ? sweep(w, robot, 0, PH_INT_VARIABLE, 1) : fail(MGX_ERR_INVALID, "null world"); }
-int mgx_external_factor_iteration(mgx_world *w, int32_t robot) { return w ? sweep(w, robot, PH_EXT_FACTOR, 0, 0) : fail(MGX_ERR_INVALID, "null world"); }
-int mgx_external_variable_iteration(mgx_world *w, int32_t robot) { return w ? sweep(w, robot, PH_EXT_VARIABLE, 0, 0) : fail(MGX_ERR_INVALID, "null world"); }
+int mgx_internal_factor_iteration(mgx_world *w, int32_t robot) {
+    MGX_ENTER(w);
+    return w ? sweep(w, robot, 0, PH_INT_FACTOR, 1) : fail(MGX_ERR_INVALID, "null world");
+}
+int mgx_internal_variable_iteration(mgx_world *w, int32_t robot) {
+    MGX_ENTER(w);
+    return w ? sweep(w, robot, 0, PH_INT_VARIABLE, 1) : fail(MGX_ERR_INVALID, "null world");
+}
+int mgx_external_factor_iteration(mgx_world *w, int32_t robot) {
+    MGX_ENTER(w);
+    return w ? sweep(w, robot, PH_EXT_FACTOR, 0, 0) : fail(MGX_ERR_INVALID, "null world");
+}
+int mgx_external_variable_iteration(mgx_world *w, int32_t robot) {
+    MGX_ENTER(w);
+    return w ? sweep(w, robot, PH_EXT_VARIABLE, 0, 0) : fail(MGX_ERR_INVALID, "null world");
+}
 
 int mgx_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, const uint32_t *var_ix, const double *means) {
+    MGX_ENTER(w);
     if (!w || !robots || !var_ix || !means) return fail(MGX_ERR_INVALID, "null argument");
     if (n == 0) return MGX_OK;
     for (uint32_t i = 0; i < n; i++) {
@@ -2935,6 +3044,7 @@ int mgx_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, const uin
 }
 int mgx_update_priors(mgx_world *w, uint32_t n, const int32_t *robots, const double *waypoints_xy, const double *time_scale,
                       const uint8_t *what, double max_speed, double delta_t) {
+    MGX_ENTER(w);
     if (!w || !robots || !waypoints_xy || !time_scale || !what) return fail(MGX_ERR_INVALID, "null argument");
     if (n == 0) return MGX_OK;
     if (w->K < 3) return fail(MGX_ERR_INVALID, "needs K >= 3");
@@ -2976,6 +3086,7 @@ int mgx_update_priors(mgx_world *w, uint32_t n, const int32_t *robots, const dou
 // through HBM.  Otherwise (or while factors are thawing) this is mgx_update_priors followed by mgx_iterate.
 int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *waypoints_xy, const double *time_scale,
              const uint8_t *what, double max_speed, double delta_t, const uint8_t *steps, uint32_t n_steps) {
+    MGX_ENTER(w);
     if (!w || (!steps && n_steps) || (n && (!robots || !waypoints_xy || !time_scale || !what))) return fail(MGX_ERR_INVALID, "null argument");
     const std::vector<Launch> plan = plan_launches(steps, n_steps);
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }  // (a declined launch is run again here: not this call's launches)
@@ -2983,7 +3094,7 @@ int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *wayp
     const bool fuse = n > 0 && !plan.empty() && plan[0].ext == 0 && plan[0].n_int > 0 && w->thaw_kinds == 0 && w->K >= 3;
     if (!fuse) {
         int rc = mgx_update_priors(w, n, robots, waypoints_xy, time_scale, what, max_speed, delta_t);
-        return rc != MGX_OK ? rc : mgx_iterate(w, steps, n_steps);
+        return rc != MGX_OK ? rc : iterate_now(w, steps, n_steps);
     }
     for (uint32_t i = 0; i < n; i++)  // (the robots' ghost / removed flags from their compact copies)
         if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size() || w->sets.ghost[(size_t)robots[i]] || w->sets.removed[(size_t)robots[i]] || (what[i] & ~3u))
@@ -3050,6 +3161,7 @@ int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *wayp
 // A rare call (the reference makes it when a global path has been found, robot.rs:700-790): the device state is pulled,
 // edited on the host mirror and laid out again by the next launch.
 int mgx_reset_variables(mgx_world *w, int32_t robot, const double *means, uint32_t n_means, double first_last_sigma, double inbetween_sigma) {
+    MGX_ENTER(w);
     if (!w || !means || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
     if (w->robots[(size_t)robot].ghost || w->robots[(size_t)robot].removed) return fail(MGX_ERR_INVALID, "robot %d is not a live local robot", robot);
     if ((int)n_means != w->robots[(size_t)robot].K)  // factorgraph.rs:1548 asserts variable_indices.len() == means.len()
@@ -3081,6 +3193,7 @@ int mgx_reset_variables(mgx_world *w, int32_t robot, const double *means, uint32
 // FactorGraph::reset_tracking_factors (factorgraph.rs:1566-1590): set_timeout(10) on every tracking factor of the graph —
 // its next ten updates are skipped (tracking.rs:362-371) and send the empty message.
 int mgx_reset_tracking_factors(mgx_world *w, int32_t robot) {
+    MGX_ENTER(w);
     if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
     if (w->robots[(size_t)robot].ghost || w->robots[(size_t)robot].removed) return fail(MGX_ERR_INVALID, "robot %d is not a live local robot", robot);
     int rc = pull(w);
@@ -3095,6 +3208,7 @@ int mgx_reset_tracking_factors(mgx_world *w, int32_t robot) {
 // Sharded worlds: a prior change applied on ANOTHER rank (to a robot that is a ghost here) still delivers a message to the
 // inter-robot factors local robots own on that variable (variable.rs:210-221): the counters are told, nothing else happens.
 int mgx_note_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, const uint32_t *var_ix) {
+    MGX_ENTER(w);
     if (!w || (n && (!robots || !var_ix))) return fail(MGX_ERR_INVALID, "null argument");
     for (uint32_t i = 0; i < n; i++)
         if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size() || (int)var_ix[i] >= w->K) return fail(MGX_ERR_INVALID, "bad (robot, variable) at %u", i);
@@ -3104,21 +3218,25 @@ int mgx_note_change_priors(mgx_world *w, uint32_t n, const int32_t *robots, cons
 }
 
 int mgx_change_prior(mgx_world *w, int32_t robot, uint32_t var_ix, const double mean[4]) {
+    MGX_ENTER(w);
     return mgx_change_priors(w, 1, &robot, &var_ix, mean);
 }
 
 int mgx_set_resident_launches(mgx_world *w, int32_t enabled) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     w->resident_off = enabled == 0;
     w->resident_decline = enabled == 2;
     return MGX_OK;
 }
 int mgx_is_thawing(mgx_world *w, int32_t *thawing) {
+    MGX_ENTER(w);
     if (!w || !thawing) return fail(MGX_ERR_INVALID, "null argument");
     *thawing = (w->thaw_kinds || w->ir_thaw_active || w->n_keyless > 0) ? 1 : 0;
     return MGX_OK;
 }
 int mgx_last_launch_count(mgx_world *w, uint32_t *n_launches) {
+    MGX_ENTER(w);
     if (!w || !n_launches) return fail(MGX_ERR_INVALID, "null argument");
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     *n_launches = w->last_sweep_launches;
@@ -3126,6 +3244,7 @@ int mgx_last_launch_count(mgx_world *w, uint32_t *n_launches) {
 }
 
 int mgx_num_robots(mgx_world *w, uint32_t *n_robots, uint32_t *n_variables) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     uint32_t nr = 0;
     for (const Robot &r : w->robots) nr += r.ghost ? 0 : 1;
@@ -3138,6 +3257,7 @@ int mgx_num_robots(mgx_world *w, uint32_t *n_robots, uint32_t *n_variables) {
 // (nth_variable(0) / last_variable for reached_waypoint, robot.rs:2125-2136; variables 0 and 1 for the
 // Transform increment, robot.rs:2309-2330) — gathered on the device straight into pinned memory
 int mgx_read_variable_means(mgx_world *w, uint32_t var_ix, double *means) {
+    MGX_ENTER(w);
     if (!w || !means) return fail(MGX_ERR_INVALID, "null argument");
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
@@ -3156,6 +3276,7 @@ int mgx_read_variable_means(mgx_world *w, uint32_t var_ix, double *means) {
 
 // FactorGraph::messages_sent / messages_received (factorgraph.rs:876-890) of one robot's graph
 int mgx_message_counts(mgx_world *w, int32_t robot, uint64_t counts[4]) {
+    MGX_ENTER(w);
     if (!w || !counts || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     if (w->robots[(size_t)robot].ghost) return fail(MGX_ERR_INVALID, "robot %d is a ghost here: its graph is counted on the rank that owns it", robot);
@@ -3171,12 +3292,14 @@ int mgx_message_counts(mgx_world *w, int32_t robot, uint64_t counts[4]) {
 
 // bulk read of the belief means only (what reached_waypoint and the visualisers read, robot.rs:2125-2136)
 int mgx_read_means(mgx_world *w, double *means) {
+    MGX_ENTER(w);
     if (!w || !means) return fail(MGX_ERR_INVALID, "null argument");
     return mgx_read_beliefs(w, nullptr, nullptr, means);
 }
 
 
 int mgx_read_beliefs(mgx_world *w, double *eta, double *lam, double *means) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
@@ -3209,6 +3332,7 @@ int mgx_read_beliefs(mgx_world *w, double *eta, double *lam, double *means) {
 
 int mgx_get_belief(mgx_world *w, int32_t robot, uint32_t var_ix, double eta[4], double lam[16], double mean[4], double cov[16],
                    int32_t *valid) {
+    MGX_ENTER(w);
     if (!w || robot < 0 || (size_t)robot >= w->robots.size() || (int)var_ix >= w->K) return fail(MGX_ERR_INVALID, "bad (robot, variable)");
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
@@ -3234,6 +3358,7 @@ int mgx_get_belief(mgx_world *w, int32_t robot, uint32_t var_ix, double eta[4], 
 uint32_t mgx_halo_words(uint32_t K) { return (SNAP_W + 1) * K; }
 
 int mgx_halo_plan(mgx_world *w, uint32_t n_send, const int32_t *send_robots, uint32_t n_recv, const int32_t *recv_ghosts) {
+    MGX_ENTER(w);
     if (!w || (n_send && !send_robots) || (n_recv && !recv_ghosts)) return fail(MGX_ERR_INVALID, "null argument");
     for (uint32_t i = 0; i < n_send; i++)
         if (send_robots[i] < 0 || (size_t)send_robots[i] >= w->robots.size() || w->robots[(size_t)send_robots[i]].ghost)
@@ -3252,6 +3377,7 @@ int mgx_halo_plan(mgx_world *w, uint32_t n_send, const int32_t *send_robots, uin
 // that follows its topology (all robots present everywhere) both ends derive the same lists.
 int mgx_halo_plan_from_connections(mgx_world *w, const int32_t *rank_of, uint32_t n_robots, int32_t my_rank, uint32_t n_ranks,
                                    uint32_t *send_counts, uint32_t *recv_counts) {
+    MGX_ENTER(w);
     if (!w || !rank_of || !send_counts || !recv_counts) return fail(MGX_ERR_INVALID, "null argument");
     if (n_robots != w->robots.size() || my_rank < 0 || (uint32_t)my_rank >= n_ranks) return fail(MGX_ERR_INVALID, "bad rank table");
     for (uint32_t r = 0; r < n_robots; r++) {
@@ -3285,6 +3411,7 @@ int mgx_halo_plan_from_connections(mgx_world *w, const int32_t *rank_of, uint32_
 // mgx_halo_plan_from_connections returned): n_send / n_recv receive the lengths, the arrays are filled up to their capacities
 int mgx_halo_get_lists(mgx_world *w, int32_t *send_robots, uint32_t send_capacity, int32_t *recv_robots, uint32_t recv_capacity,
                        uint32_t *n_send, uint32_t *n_recv) {
+    MGX_ENTER(w);
     if (!w || !n_send || !n_recv) return fail(MGX_ERR_INVALID, "null argument");
     *n_send = (uint32_t)w->halo_send.size();
     *n_recv = (uint32_t)w->halo_recv.size();
@@ -3339,6 +3466,7 @@ extern "C" {
 // The world is brought up to date first: schedules issued so far have run, the tables of the last topology pass are laid
 // out.  Call it BETWEEN ticks — after the sweeps that followed the last topology pass — on every rank at the same point.
 int mgx_robot_export(mgx_world *w, int32_t robot, void *buf, uint64_t capacity, uint64_t *bytes) {
+    MGX_ENTER(w);
     if (!w || !bytes || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
     if (w->robots[(size_t)robot].ghost) return fail(MGX_ERR_INVALID, "robot %d is a ghost here: its owner exports it", robot);
     int rc = check_device_error(w);
@@ -3388,6 +3516,7 @@ int mgx_robot_export(mgx_world *w, int32_t robot, void *buf, uint64_t capacity, 
 // made again by the launcher, as after mgx_robot_add).  The replicated bookkeeping has to be in step with the exporting
 // rank's: the record names its connections (owner, first robot number, first node slot) and a mismatch is refused.
 int mgx_robot_import(mgx_world *w, int32_t robot, const void *buf, uint64_t bytes) {
+    MGX_ENTER(w);
     if (!w || !buf || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
     if (!w->robots[(size_t)robot].ghost) return fail(MGX_ERR_STATE, "robot %d is owned here already", robot);
     int rc = check_device_error(w);
@@ -3466,6 +3595,7 @@ int mgx_robot_import(mgx_world *w, int32_t robot, const void *buf, uint64_t byte
 // The other half on the rank that gave the robot away (after mgx_robot_export): it stays in this world as a ghost — its
 // records arrive by the exchange from now on, the factors attached to its variables are its new owner's.
 int mgx_robot_release(mgx_world *w, int32_t robot) {
+    MGX_ENTER(w);
     if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
     if (w->robots[(size_t)robot].ghost) return fail(MGX_ERR_STATE, "robot %d is a ghost here already", robot);
     int rc = check_device_error(w);
@@ -3577,6 +3707,7 @@ int mgx_rccl_unique_id(uint8_t id[128]) {
 }
 int mgx_halo_rccl_connect(mgx_world *w, const uint8_t id[128], uint32_t n_ranks, uint32_t rank, uint32_t n_peers, const uint32_t *peer_rank,
                           const uint32_t *send_first, const uint32_t *recv_first) {
+    MGX_ENTER(w);
     if (!w || !id || (n_peers && (!peer_rank || !send_first || !recv_first))) return fail(MGX_ERR_INVALID, "null argument");
     if (rank >= n_ranks) return fail(MGX_ERR_INVALID, "rank out of range");
     if (!g_rccl.load()) return fail(MGX_ERR_STATE, "RCCL is not available in this process");
@@ -3603,6 +3734,7 @@ int mgx_halo_rccl_connect(mgx_world *w, const uint8_t id[128], uint32_t n_ranks,
     return MGX_OK;
 }
 int mgx_halo_rccl_disconnect(mgx_world *w) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     HIP_TRY(hipStreamSynchronize(w->stream));
     w->rccl.connected = false;
@@ -3611,6 +3743,7 @@ int mgx_halo_rccl_disconnect(mgx_world *w) {
 
 // ---- direct halo exchange (peer-mapped stores) ---------------------------------------------
 int mgx_halo_direct_setup(mgx_world *w, uint32_t n_sources, void **recv_base, void **flag_base) {
+    MGX_ENTER(w);
     if (!w || !recv_base || !flag_base) return fail(MGX_ERR_INVALID, "null argument");
     int rc = halo_commit(w);
     if (rc != MGX_OK) return rc;
@@ -3646,6 +3779,7 @@ int mgx_halo_direct_setup(mgx_world *w, uint32_t n_sources, void **recv_base, vo
 
 int mgx_halo_direct_connect(mgx_world *w, uint32_t n_peers, const uint32_t *send_first, void *const *peer_recv_base,
                             const uint64_t *peer_recv_records, const uint64_t *peer_record_offset, void *const *peer_flag_slot) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     mgx_world::DirectHalo &dh = w->direct;
     if (!dh.flags) return fail(MGX_ERR_STATE, "mgx_halo_direct_setup first");
@@ -3686,6 +3820,7 @@ int mgx_halo_direct_connect(mgx_world *w, uint32_t n_peers, const uint32_t *send
 // receive area holds `slot_capacity` record slots per parity, slot g = the g-th ghost robot of this rank in device order
 // (mgx_halo_ghost_slots), and EVERY other rank is a source — with or without records in a given exchange.
 int mgx_halo_direct_setup_slots(mgx_world *w, uint32_t n_sources, uint32_t slot_capacity, void **recv_base, void **flag_base) {
+    MGX_ENTER(w);
     if (!w || !recv_base || !flag_base) return fail(MGX_ERR_INVALID, "null argument");
     int rc = halo_commit(w);
     if (rc != MGX_OK) return rc;
@@ -3723,6 +3858,7 @@ int mgx_halo_direct_setup_slots(mgx_world *w, uint32_t n_sources, uint32_t slot_
 
 // slot of every listed robot among this rank's ghosts (-1: not a ghost here) — what the robot's owner stores its record into
 int mgx_halo_ghost_slots(mgx_world *w, uint32_t n, const int32_t *robots, int32_t *slots) {
+    MGX_ENTER(w);
     if (!w || (n && (!robots || !slots))) return fail(MGX_ERR_INVALID, "null argument");
     int rc = halo_commit(w);
     if (rc != MGX_OK) return rc;
@@ -3739,6 +3875,7 @@ int mgx_halo_ghost_slots(mgx_world *w, uint32_t n, const int32_t *robots, int32_
 // list the slot of that robot in its consumer's area.  The exchange numbers go on: both ends keep counting.
 int mgx_halo_direct_connect_slots(mgx_world *w, uint32_t n_peers, const uint32_t *send_first, void *const *peer_recv_base,
                                   const uint64_t *peer_slot_capacity, const uint32_t *entry_slot, void *const *peer_flag_slot) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     mgx_world::DirectHalo &dh = w->direct;
     if (!dh.flags || !dh.by_slot) return fail(MGX_ERR_STATE, "mgx_halo_direct_setup_slots first");
@@ -3775,6 +3912,7 @@ int mgx_halo_direct_connect_slots(mgx_world *w, uint32_t n_peers, const uint32_t
 }
 
 int mgx_halo_direct_exchange(mgx_world *w, uint32_t what) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (!w->direct.connected) return fail(MGX_ERR_STATE, "direct halo exchange is not connected");
     if (what == MGX_HALO_PUSH) return direct_push(w);
@@ -3784,6 +3922,7 @@ int mgx_halo_direct_exchange(mgx_world *w, uint32_t what) {
 }
 
 int mgx_halo_direct_status(mgx_world *w, uint64_t *exchanges, uint64_t *failed_exchange) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     mgx_world::DirectHalo &dh = w->direct;
     if (!dh.flags) return fail(MGX_ERR_STATE, "direct halo exchange is not set up");
@@ -3797,6 +3936,7 @@ int mgx_halo_direct_status(mgx_world *w, uint64_t *exchanges, uint64_t *failed_e
 }
 
 int mgx_halo_direct_disconnect(mgx_world *w) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     HIP_TRY(hipStreamSynchronize(w->stream));
     w->direct.connected = false;
@@ -3821,6 +3961,7 @@ struct GhostAreaLayout {
 
 int mgx_halo_resident_setup(mgx_world *w, void **area_base, uint32_t *n_ghost_slots, uint32_t *parity, uint64_t *segment_count,
                             int32_t *recv_slots, int32_t *eligible) {
+    MGX_ENTER(w);
     if (!w || !area_base || !n_ghost_slots || !parity || !segment_count || !eligible) return fail(MGX_ERR_INVALID, "null argument");
     int rc = halo_commit(w);
     if (rc != MGX_OK) return rc;
@@ -3874,6 +4015,7 @@ int mgx_halo_resident_setup(mgx_world *w, void **area_base, uint32_t *n_ghost_sl
 int mgx_halo_resident_connect(mgx_world *w, uint32_t n_targets, const int32_t *robots, void *const *peer_area_base,
                               const uint32_t *peer_ghost_slots, const uint32_t *peer_slot, const uint32_t *peer_parity,
                               const uint64_t *peer_segment_count, void *coordinator_area, uint32_t n_ranks) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (n_ranks > 0x3fffu) return fail(MGX_ERR_INVALID, "at most %u ranks", 0x3fffu);  // (the agreement word counts them in 14 bits)
     if (n_targets && (!robots || !peer_area_base || !peer_ghost_slots || !peer_slot || !peer_parity || !peer_segment_count))
@@ -3928,6 +4070,7 @@ int mgx_halo_resident_connect(mgx_world *w, uint32_t n_targets, const int32_t *r
 // the lists, which local robot's records go into which slot of which peer (mgx_halo_resident_aim).
 int mgx_halo_resident_connect_peers(mgx_world *w, uint32_t n_peers, void *const *peer_area_base, const uint32_t *peer_ghost_slots,
                                     const uint32_t *peer_parity, const uint64_t *peer_segment_count, void *coordinator_area, uint32_t n_ranks) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (n_ranks > 0x3fffu) return fail(MGX_ERR_INVALID, "at most %u ranks", 0x3fffu);
     if (n_peers && (!peer_area_base || !peer_ghost_slots || !peer_parity || !peer_segment_count)) return fail(MGX_ERR_INVALID, "null argument");
@@ -3961,6 +4104,7 @@ int mgx_halo_resident_connect_peers(mgx_world *w, uint32_t n_peers, void *const 
 // the progress words of this rank's ghosts start over at "through with everything so far" — a robot that becomes somebody's
 // neighbour across ranks has never stored one here.
 int mgx_halo_resident_aim(mgx_world *w, uint32_t n_targets, const int32_t *robots, const uint32_t *peer_index, const uint32_t *peer_slot) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (n_targets && (!robots || !peer_index || !peer_slot)) return fail(MGX_ERR_INVALID, "null argument");
     mgx_world::ResidentHalo &xr = w->xres;
@@ -4004,6 +4148,7 @@ int mgx_halo_resident_aim(mgx_world *w, uint32_t n_targets, const int32_t *robot
 }
 
 int mgx_halo_resident_disconnect(mgx_world *w) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     HIP_TRY(hipStreamSynchronize(w->stream));
@@ -4016,11 +4161,13 @@ int mgx_halo_resident_disconnect(mgx_world *w) {
 }
 
 int mgx_resident_outcome(mgx_world *w, int32_t *outcome) {
+    MGX_ENTER(w);
     if (!w || !outcome) return fail(MGX_ERR_INVALID, "null argument");
     return confirm_resident(w, false, outcome);
 }
 
 int mgx_resident_ready(mgx_world *w, const uint8_t *steps, uint32_t n, int32_t *ready) {
+    MGX_ENTER(w);
     if (!w || !ready || (!steps && n)) return fail(MGX_ERR_INVALID, "null argument");
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
@@ -4038,6 +4185,7 @@ int mgx_resident_ready(mgx_world *w, const uint8_t *steps, uint32_t n, int32_t *
 }
 
 int mgx_resident_stats(mgx_world *w, uint64_t *launches, uint64_t *declined, uint32_t *backoff) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     if (launches) *launches = w->resident_launches;
@@ -4070,6 +4218,7 @@ int mgx_ipc_close(void *dev_ptr) {
 }
 
 int mgx_halo_pack(mgx_world *w, void *dev_buf) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     int rc = halo_commit(w);
     if (rc != MGX_OK) return rc;
@@ -4079,6 +4228,7 @@ int mgx_halo_pack(mgx_world *w, void *dev_buf) {
     return MGX_OK;
 }
 int mgx_halo_unpack(mgx_world *w, const void *dev_buf) {
+    MGX_ENTER(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     int rc = halo_commit(w);
     if (rc != MGX_OK) return rc;
@@ -4091,6 +4241,7 @@ int mgx_halo_unpack(mgx_world *w, const void *dev_buf) {
 #ifdef MGX_STAMPS
 // diagnostic build only: copy the per-wave phase cycle sums to the host
 int mgx_debug_read_stamps(mgx_world *w, unsigned long long *out, uint32_t n) {
+    MGX_ENTER(w);
     if (!w || !out) return fail(MGX_ERR_INVALID, "null argument");
     std::vector<unsigned long long> h;
     HIP_TRY(w->dbg.download(h, w->stream));

@@ -128,6 +128,8 @@ SYMBOLS = {
     "mgx_update_topology": (C.c_int, [_V, C.c_void_p, C.c_float, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "mgx_connections": (C.c_int, [_V, C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "mgx_iterate": (C.c_int, [_V, C.c_char_p, C.c_uint32]),
+    "mgx_batch_begin": (C.c_int, [_V]),
+    "mgx_batch_end": (C.c_int, [_V, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mgx_sweep": (C.c_int, [_V, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "mgx_internal_factor_iteration": (C.c_int, [_V, C.c_int32]),
     "mgx_internal_variable_iteration": (C.c_int, [_V, C.c_int32]),

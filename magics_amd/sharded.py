@@ -593,6 +593,15 @@ class ShardedWorld:
                 self.exchange()
             self.sweep_segment(ext, n_int, next_ext=k + 1 < len(segs) and segs[k + 1][0])
 
+    def batch(self):
+        """`with sw.batch(): for ...: sw.iterate(steps)` — World.batch for a rank whose exchange lives in the engine (every rank
+        brackets alike: the merged launches wait for each other's records like any schedule's); a no-op where the exchange is
+        driven from the host (its collectives sit between the launches)"""
+        if self.direct or self.plan.world_size == 1:
+            return self.world.batch()
+        import contextlib
+        return contextlib.nullcontext()
+
     def set_antenna(self, robot, active):
         if robot in self.lid:
             self.world.set_antenna(self.lid[robot], active)

@@ -165,6 +165,20 @@ class World:
         steps = bytes(bytearray(int(s) for s in steps))
         self._chk(self._L.mgx_iterate(self._w, steps, len(steps)))
 
+    def batch_begin(self):
+        self._chk(self._L.mgx_batch_begin(self._w))
+
+    def batch_end(self):
+        """-> (schedules recorded since batch_begin, sweep-kernel launches they were submitted as)"""
+        ns, nl = C.c_uint32(), C.c_uint32()
+        self._chk(self._L.mgx_batch_end(self._w, C.byref(ns), C.byref(nl)))
+        return ns.value, nl.value
+
+    def batch(self):
+        """`with world.batch(): for ...: world.iterate(steps)` — the schedules are submitted together, merged into as few
+        resident launches as their segments fit (include/mgx.h: mgx_batch_begin); same results, bit for bit"""
+        return _Batch(self)
+
     def sweep(self, external_phases, internal_phases, n_internal=1, robot=-1, hints=0):
         self._chk(self._L.mgx_sweep(self._w, robot, external_phases, internal_phases, n_internal, hints))
 
@@ -533,3 +547,16 @@ class FactorGraph:
 
     def variable(self, variable_index):
         return self.world.get_belief(self.id, variable_index)
+
+
+class _Batch:
+    def __init__(self, world):
+        self.world, self.schedules, self.launches = world, 0, 0
+
+    def __enter__(self):
+        self.world.batch_begin()
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        self.schedules, self.launches = self.world.batch_end()
+        return False

@@ -116,6 +116,8 @@ extern "C" {
     pub fn mgx_update_topology(w: *mut mgx_world, positions_xyz: *const f32, radius: f32, method: u32, robot_number_next: *mut u64, stats: *mut u32) -> c_int;
     pub fn mgx_connections(w: *mut mgx_world, robot: i32, others: *mut i32, capacity: u32, n: *mut u32) -> c_int;
     pub fn mgx_iterate(w: *mut mgx_world, steps: *const u8, n: u32) -> c_int;
+    pub fn mgx_batch_begin(w: *mut mgx_world) -> c_int;
+    pub fn mgx_batch_end(w: *mut mgx_world, n_schedules: *mut u32, n_launches: *mut u32) -> c_int;
     pub fn mgx_last_launch_count(w: *mut mgx_world, n_launches: *mut u32) -> c_int;
     pub fn mgx_set_resident_launches(w: *mut mgx_world, enabled: i32) -> c_int;
     pub fn mgx_is_thawing(w: *mut mgx_world, thawing: *mut i32) -> c_int;

@@ -1,7 +1,8 @@
 """One rank of the multi-process direct-halo test (tests/test_gpu_direct_halo_mp.py): every rank
 is its own process on cuda:0, the control plane is gloo, the data plane is hipIpc-mapped
-peer stores.  usage: direct_halo_worker.py RANK WORLD_SIZE PORT OUT.npz [direct | direct+resident | direct+resident+decline | direct+resident+late]
-(direct+resident: the ghost records travel inside ONE resident launch per schedule and rank)"""
+peer stores.  usage: direct_halo_worker.py RANK WORLD_SIZE PORT OUT.npz [direct | direct+resident | direct+resident+decline | direct+resident+late | direct+resident+batch]
+(direct+resident: the ghost records travel inside ONE resident launch per schedule and rank; +batch: two more ticks inside
+mgx_batch_begin / mgx_batch_end on every rank — submitted together, merged into as few launches as their segments fit)"""
 import os
 import sys
 
@@ -24,7 +25,8 @@ def main():
     sw = sharded.ShardedWorld(sc, rank, ws, World, comm=comm)
     decline = mode.endswith("+decline")  # the last rank says no to the resident launch of tick 1: every rank falls back
     late = mode.endswith("+late")        # the last rank starts tick 1 long after the others have given up waiting for it
-    mode = mode.replace("+decline", "").replace("+late", "")
+    batch = mode.endswith("+batch")
+    mode = mode.replace("+decline", "").replace("+late", "").replace("+batch", "")
     got = sharded.connect(sw, comm, resident=mode == "direct+resident")  # the default wiring: in-engine transports first
     assert got == mode, got
     steps = sc["steps"] + [1, 1, 2, 3, 2]
@@ -46,11 +48,17 @@ def main():
         sw.iterate(steps)
         if (decline or late) and tick == 0:
             assert sw.world.resident_stats()[:2] == (1, 0), sw.world.resident_stats()
+    batched = (0, 0)
+    if batch:
+        with sw.batch() as b:
+            sw.iterate(sc["steps"])
+            sw.iterate(sc["steps"])
+        batched = (b.schedules, b.launches)
     launches = sw.world.last_launch_count()
     stats = sw.world.resident_stats()
     ids, eta, lam, mu = sw.read_beliefs()
     n = sw.world.halo_direct_status()
-    np.savez(out, ids=np.array(ids), eta=eta, lam=lam, mu=mu, n=n, launches=launches, stats=np.array(stats, dtype=np.int64))
+    np.savez(out, batched=np.array(batched), ids=np.array(ids), eta=eta, lam=lam, mu=mu, n=n, launches=launches, stats=np.array(stats, dtype=np.int64))
     dist.barrier()
     sw.direct_close()
     dist.destroy_process_group()

@@ -24,7 +24,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world_size,mode", [(2, "direct"), (3, "direct"), (2, "direct+resident"), (3, "direct+resident"),
-                                             (3, "direct+resident+decline"), (3, "direct+resident+late")])
+                                             (3, "direct+resident+decline"), (3, "direct+resident+late"), (2, "direct+resident+batch")])
 def test_ranks_in_separate_processes(world_size, mode, tmp_path):
     """mode "direct+resident": every rank's schedule is ONE resident launch and the ghost records cross the process
     boundary inside it (hipIpc-mapped ghost areas, system-scope stores and polls).
@@ -32,7 +32,8 @@ def test_ranks_in_separate_processes(world_size, mode, tmp_path):
     every schedule, so ALL ranks' launches return with their worlds untouched, every engine runs that schedule launch by launch
     with the direct exchange, and the third tick (inside the back-off) runs launch by launch on every rank too.
     "+late": the last rank issues the second tick 0.3 s after the others — whose launches have given up waiting for it on that word
-    (MGX_RESIDENT_CENSUS_SHARDED_US, here 20 ms) and returned; its own launch finds their "no" and returns as well."""
+    (MGX_RESIDENT_CENSUS_SHARDED_US, here 20 ms) and returned; its own launch finds their "no" and returns as well.
+    "+batch": two more ticks inside mgx_batch_begin / mgx_batch_end on every rank: submitted together as ONE resident launch per rank."""
     port = _free_port()
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(world_size)]
     # (how long the ranks' launches wait for each other before they all fall back: generous where every schedule is expected to
@@ -65,6 +66,10 @@ def test_ranks_in_separate_processes(world_size, mode, tmp_path):
         if tick == 2:
             ref.set_antenna(boundary[0], True)
         ref.iterate(steps)
+    batch, mode = mode.endswith("+batch"), mode.replace("+batch", "")
+    if batch:
+        ref.iterate(sc["steps"])
+        ref.iterate(sc["steps"])
     eta_r, lam_r, mu_r = ref.read_beliefs()
     # exchanges by the push / wait kernels: one per external iteration — or none at all when the schedule (which opens with an
     # internal iteration) runs as one resident launch
@@ -74,6 +79,8 @@ def test_ranks_in_separate_processes(world_size, mode, tmp_path):
         d = np.load(o)
         assert int(d["n"]) == n_ext
         assert int(d["launches"]) == (1 if mode == "direct+resident" else len(sharded.segments(steps)))
+        if batch:
+            assert tuple(int(x) for x in d["batched"]) == (2, 1), d["batched"]  # two ticks of the 10 / 10 schedule: one launch
         if mode.endswith("+decline") or mode.endswith("+late"):  # (resident launches, declined ones, back-off left) — the same on every rank
             assert d["stats"][0] == 2 and d["stats"][1] == 1 and d["stats"][2] > 0, d["stats"]
         for j, g in enumerate(d["ids"]):
