@@ -281,6 +281,11 @@ def roofline(kernel, alg_bytes_per_launch, launches, dev_seconds, prof_key, iter
     if not p:
         out["note"] = "no physical roofline: " + why
         return out
+    ipd = p.get("iterations_per_dispatch") or (1 if prof_key == "config2" else SCHEDULE_LEN)  # (files from before the field: one tick per dispatch)
+    if abs(ipd - iterations_per_launch) > 0.5:
+        out["note"] = (f"no physical roofline: the counters in profiles/ are per dispatch of {ipd} iterations, this run's "
+                       f"launches hold {iterations_per_launch} (other --steps / --ticks-per-submission than the profiled command)")
+        return out
     traffic = int((2 * p["fetch_kib"] + p["write_kib"]) * 1024)
     t_hbm = traffic / (HBM_PEAK_GBS * 1e9)
     hbm = {"bytes_per_launch": traffic, "gbs": round(traffic / avg / 1e9, 1), "peak_gbs": HBM_PEAK_GBS, "frac": round(t_hbm / avg, 4),
@@ -677,8 +682,9 @@ def main():
     head_launches = run_steps(sw.iterate, a.steps, sc2["steps"], sw.batch, G)  # (the timed block once more: launches as the engine counted them)
     r2 = summary(walls, devs, a.steps, units_per_step=world_size)
     per_tick = None
-    if G > 1 and not multi:  # the same workload, one submission per tick (every tick its own launch): what the merge is worth
-        walls_t, devs_t = timed(torch, dist, sw.iterate, sc2["steps"], a, multi, red_dev)
+    a_warm = argparse.Namespace(**{**vars(a), "preheat_ms": 0.0})  # (clocks are up: a second timed pass needs no pre-heat of its own)
+    if G > 1 and not multi and not a.no_extras:  # the same workload, one submission per tick (every tick its own launch): what the merge is worth
+        walls_t, devs_t = timed(torch, dist, sw.iterate, sc2["steps"], a_warm, multi, red_dev)
         rt = summary(walls_t, devs_t, a.steps, units_per_step=world_size)
         per_tick = {"value": round(rt["value"], 2), "ms_per_step": rt["ms_per_step"], "device_ms_per_step": rt["device_ms_per_step"],
                     "what": "the same workload without mgx_batch_*: every 10-step tick submitted (and launched) by itself"}
@@ -741,7 +747,7 @@ def main():
                         launches_in = run_steps(sw_in.iterate, a.steps, sc2["steps"], sw_in.batch, G)
                         sw_in.synchronize()
                         if G > 1:  # one submission per tick, for the same wiring
-                            walls_t, devs_t = timed(torch, dist, sw_in.iterate, sc2["steps"], a, True, red_dev, sync=sw_in.synchronize)
+                            walls_t, devs_t = timed(torch, dist, sw_in.iterate, sc2["steps"], a_warm, True, red_dev, sync=sw_in.synchronize)
                             rt = summary(walls_t, devs_t, a.steps, units_per_step=world_size)
                             per_tick = {"value": round(rt["value"], 2), "ms_per_step": rt["ms_per_step"], "device_ms_per_step": rt["device_ms_per_step"],
                                         "what": "the same workload and wiring without mgx_batch_*: every 10-step tick submitted by itself"}

@@ -65,10 +65,11 @@ def main():
     prof = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
     out = [f"# rocprofv3 summary — {tag}", "",
-           "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-extras` "
-           "(tools/profile_round.sh; MI355X).  `<16, 0, false, false>`: configs[1], 10 iterations per dispatch; `<16, 2, true, false>`: configs[2], "
-           "the 10-step schedule as ONE resident dispatch; `<16, 2, false, false>` (second run, `MGX_PERSISTENT=0`): configs[2], one iteration per "
-           "dispatch (template arguments: horizon, inter-robot message mode, resident, sharded).", ""]
+           "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 40 --no-cpu-baseline --no-extras` "
+           "(tools/profile_round.sh; MI355X).  bench.py hands its 10-step ticks to the engine two at a time (mgx_batch_begin / mgx_batch_end), like "
+           "the driver's `--steps 20`: `<16, 0, false, false>`: configs[1], 20 iterations per dispatch; `<16, 2, true, false>`: configs[2], "
+           "two ticks of the 10-step schedule as ONE resident dispatch (20 iterations); `<16, 2, false, false>` (second run, `MGX_PERSISTENT=0`): "
+           "configs[2], one iteration per dispatch (template arguments: horizon, inter-robot message mode, resident, sharded).", ""]
     for sub, name in (("_kt", "kernel_stats"), ("_kt_np", "kernel_stats_launch_per_iteration"), ("_cfg", "configs_kernel_stats")):
         f = glob.glob(os.path.join(g + sub, "**", "*kernel_stats.csv"), recursive=True)
         if f:
@@ -96,6 +97,14 @@ def main():
             "driver's, relate to these counters through it).", "",
             "| instantiation | FETCH_SIZE KiB | WRITE_SIZE KiB | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES | SQ_WAIT_ANY / SQ_WAVE_CYCLES | kernel trace avg us | GRBM_GUI_ACTIVE / 8, k cycles | us in the counter passes (FETCH / WRITE / SQ / GRBM) |", "|---|---|---|---|---|---|---|---|---|"]
     clock_pts = []
+    # iterations per dispatch: what the profiled bench run itself reported (its JSON line)
+    iters = {"config2": 1}
+    try:
+        ln = json.loads([x for x in open(g + "_kt.json").read().splitlines() if x.startswith("{")][-1])
+        iters["config2_resident"] = ln["roofline"]["iterations_per_launch"]
+        iters["config1"] = ln["configs1"]["roofline"]["iterations_per_launch"]
+    except Exception as e:  # noqa: BLE001
+        print("iterations per dispatch: not found in", g + "_kt.json", e)
     for inst, (key, suf) in keys.items():
         f = per_kernel(g + "_pmc_FETCH_SIZE" + suf, "FETCH_SIZE").get(inst)
         w = per_kernel(g + "_pmc_WRITE_SIZE" + suf, "WRITE_SIZE").get(inst)
@@ -108,7 +117,8 @@ def main():
             clock_pts.append((suf, pd[3], gui / 8.0))  # (pass, us, cycles per XCD)
         if f is None or w is None:
             continue
-        ent = {"fetch_kib": round(f, 1), "write_kib": round(w, 1), "source": f"profiles/{tag}_summary.md (rocprofv3 --pmc, separate passes)"}
+        ent = {"fetch_kib": round(f, 1), "write_kib": round(w, 1), "source": f"profiles/{tag}_summary.md (rocprofv3 --pmc, separate passes)",
+               "iterations_per_dispatch": iters.get(key)}
         busy = None
         if sq["SQ_INSTS_VALU"]:
             ent["valu_wave_instr"] = round(sq["SQ_INSTS_VALU"])

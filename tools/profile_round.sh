@@ -10,7 +10,9 @@ tag=${1:-r04}
 part=${2:-ab}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-B="python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-extras --sustained-seconds 0"
+# (200 steps = 20 ticks, handed to the engine two at a time like the driver's 20 steps: every dispatch of the timed blocks holds 20
+# iterations; 40 warm-up steps for the same reason)
+B="python3 bench.py --steps 200 --warmup 40 --no-cpu-baseline --no-extras --sustained-seconds 0"
 out=gpurun_out/${tag}
 SQ="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 if [[ $part == *a* ]]; then
