@@ -176,6 +176,17 @@ public:
         for (size_t i = 0; i < sched.size(); i++) steps[i] = (uint8_t)((sched[i].internal ? MGX_STEP_INTERNAL : 0) | (sched[i].external ? MGX_STEP_EXTERNAL : 0));
         check(mgx_iterate(w_, steps.data(), (uint32_t)steps.size()));
     }
+    /// several iterate_gbp_v2 calls, one submission (mgx_batch_begin / mgx_batch_end): `{ auto b = world.batch(); for (...) world.iterate_gbp_v2(s); }`
+    struct Batch {
+        mgx_world *w;
+        uint32_t schedules = 0, launches = 0;
+        explicit Batch(mgx_world *world) : w(world) { check(mgx_batch_begin(w)); }
+        Batch(const Batch &) = delete;
+        Batch &operator=(const Batch &) = delete;
+        void end() { if (w) { mgx_world *x = w; w = nullptr; check(mgx_batch_end(x, &schedules, &launches)); } }
+        ~Batch() { if (w) (void)mgx_batch_end(w, nullptr, nullptr); }
+    };
+    Batch batch() { return Batch(w_); }
     // update_prior_of_horizon_state + update_prior_of_current_state_v3 (robot.rs:2182-2338)
     void update_priors(const std::vector<int32_t> &robots, const std::vector<std::array<double, 2>> &next_waypoints,
                        const std::vector<double> &time_scale, double max_speed, double delta_t) {

@@ -95,6 +95,18 @@ impl World {
     pub fn iterate(&self, steps: &[u8]) -> Result<(), MgxError> {
         check(unsafe { sys::mgx_iterate(self.raw, steps.as_ptr(), steps.len() as u32) })
     }
+    /// Several `iterate` calls, one submission (`mgx_batch_begin` / `mgx_batch_end`): the schedules issued inside `f` are recorded and
+    /// submitted together, merged into as few resident launches as their segments fit; same results, bit for bit.
+    /// Returns (schedules recorded, sweep-kernel launches they were submitted as).
+    pub fn batch<F: FnOnce(&Self) -> Result<(), MgxError>>(&self, f: F) -> Result<(u32, u32), MgxError> {
+        check(unsafe { sys::mgx_batch_begin(self.raw) })?;
+        let r = f(self);
+        let (mut schedules, mut launches) = (0u32, 0u32);
+        let e = check(unsafe { sys::mgx_batch_end(self.raw, &mut schedules, &mut launches) });
+        r?;
+        e?;
+        Ok((schedules, launches))
+    }
     /// How the last `iterate` / `tick` ran: sweep-kernel launches (1 = the whole schedule as one resident launch).
     pub fn last_launch_count(&self) -> Result<u32, MgxError> {
         let mut n = 0u32;
