@@ -26,7 +26,10 @@ def _scenario(K, n, seed, tracking=False):
 
 @pytest.mark.parametrize("K,n,seed", [(5, 7, 1), (8, 9, 2), (10, 12, 3), (12, 10, 4), (13, 6, 5), (16, 14, 6), (19, 5, 7),
                                       (21, 8, 8), (32, 6, 9)])
-def test_random_script(K, n, seed):
+@pytest.mark.parametrize("batched", [False, True])
+def test_random_script(K, n, seed, batched):
+    """batched: the engine's whole script runs inside ONE open batch (mgx_batch_begin): consecutive schedules merge into one
+    submission, every other call first submits what was recorded — the results must not know the difference"""
     sc = _scenario(K, n, seed, tracking=(seed % 3 == 0))
     # ragged topology: drop a random third of the directed connections, isolate robot 0 entirely
     rng = np.random.default_rng(seed)
@@ -60,11 +63,16 @@ def test_random_script(K, n, seed):
             script.append(lambda w: w.update_priors(**tick))
         steps = [int(x) for x in rng.integers(1, 4, size=int(rng.integers(1, 6)))]
         script.append(lambda w, steps=steps: w.iterate(steps))
+    if batched:
+        eng.batch_begin()
     for k, f in enumerate(script):
         f(eng)
         f(ref)
         if k % 5 == 4:
             assert_identical(eng, ref, what=f"K={K} n={n} seed={seed} after op {k}")
+    if batched:
+        schedules, _ = eng.batch_end()
+        assert schedules == 14
     assert_identical(eng, ref, what=f"K={K} n={n} seed={seed} final")
 
 
@@ -92,7 +100,8 @@ def test_all_schedule_kinds_full_tick_lengths():
 
 
 @pytest.mark.parametrize("K,n,seed", [(10, 14, 11), (12, 9, 12), (16, 20, 13), (21, 7, 14), (8, 10, 15)])
-def test_random_script_with_dynamic_topology(K, n, seed):
+@pytest.mark.parametrize("batched", [False, True])
+def test_random_script_with_dynamic_topology(K, n, seed, batched):
     """The same idea with the topology systems in the mix: robots wander (positions are the caller's
     Transform inputs), whole update_robot_neighbours / delete / create passes run between sweeps
     (in-place edge-table rebuilds on the device), robots despawn, antennas are rewritten in bulk;
@@ -105,6 +114,8 @@ def test_random_script_with_dynamic_topology(K, n, seed):
     alive = np.ones(n, dtype=bool)
     nxt = {id(eng): 1, id(ref): 1}
     tick = S.tick_inputs(sc)
+    if batched:
+        eng.batch_begin()
     for step in range(24):
         op = int(rng.integers(0, 7))
         if op <= 2:
@@ -139,4 +150,6 @@ def test_random_script_with_dynamic_topology(K, n, seed):
             assert [eng.connections(r) for r in range(n)] == [ref.connections(r) for r in range(n)]
             assert [eng.message_counts(r) for r in range(n)] == [ref.message_counts(r) for r in range(n)], step
             assert_identical(eng, ref, what=f"dynamic K={K} n={n} seed={seed} step {step}")
+    if batched:
+        assert eng.batch_end()[0] == 24
     assert_identical(eng, ref, what=f"dynamic K={K} n={n} seed={seed} final")

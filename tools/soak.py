@@ -43,13 +43,13 @@ while time.time() - t0 < budget:
     n = 5 + (seed * 7) % 14
     with contextlib.redirect_stdout(io.StringIO()):
         try:
-            test_random_script(K, n, seed)
+            test_random_script(K, n, seed, batched=bool(seed & 1))  # (every other script inside one open batch)
             runs["static"] += 1
         except LeftTheFiniteDomain:
             runs["diverged"] += 1
         if K in (8, 10, 12, 16, 21):
             try:
-                test_random_script_with_dynamic_topology(K, n + 3, seed + 1)
+                test_random_script_with_dynamic_topology(K, n + 3, seed + 1, batched=bool(seed & 2))
                 runs["dynamic"] += 1
             except LeftTheFiniteDomain:
                 runs["diverged"] += 1
