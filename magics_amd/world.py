@@ -162,8 +162,14 @@ class World:
 
     # -- hot path ----------------------------------------------------------------------------
     def iterate(self, steps):
-        steps = bytes(bytearray(int(s) for s in steps))
-        self._chk(self._L.mgx_iterate(self._w, steps, len(steps)))
+        # (a tick's schedule is issued over and over: its byte string is made once — building it costs more host time than the call)
+        key = steps if isinstance(steps, (bytes, tuple)) else tuple(steps)
+        b = _STEP_BYTES.get(key)
+        if b is None:
+            if len(_STEP_BYTES) > 256:
+                _STEP_BYTES.clear()
+            b = _STEP_BYTES[key] = bytes(bytearray(int(s) for s in steps))
+        self._chk(self._L.mgx_iterate(self._w, b, len(b)))
 
     def batch_begin(self):
         self._chk(self._L.mgx_batch_begin(self._w))
@@ -547,6 +553,9 @@ class FactorGraph:
 
     def variable(self, variable_index):
         return self.world.get_belief(self.id, variable_index)
+
+
+_STEP_BYTES = {}
 
 
 class _Batch:

@@ -176,3 +176,7 @@ def test_bench_bare_launch_starts_its_own_ranks():
     assert d["sustained"]["value"] > 0 and d["sustained"]["seconds"] >= 0.4
     assert d["resident_stats"]["launches"] > 0
     assert d["launch_per_segment"]["value"] > 0 and d["launch_per_segment"]["launches_per_tick"] > 1
+    # the ticks are handed to the engines two at a time (mgx_batch_*): ONE resident launch of 20 iterations per rank and submission
+    assert d["submission"]["ticks_per_submission"] == 2 and d["submission"]["iterations_per_launch"] == 20, d["submission"]
+    assert d["one_submission_per_tick"]["value"] > 0
+    print("2 ranks on one GPU:", d["value"], "it/s batched,", d["one_submission_per_tick"]["value"], "one submission per tick")
