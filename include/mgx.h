@@ -173,7 +173,7 @@ int mgx_connections(mgx_world *w, int32_t robot, int32_t *others, uint32_t capac
  * steps[i] & MGX_STEP_EXTERNAL.  Asynchronous on the world's stream. */
 int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n);
 /* Batches: several schedules, one submission.  A resident schedule launch pays for itself once — the robots' graphs go
- * HBM -> LDS when it starts and back when it ends, an eighth of a ten-iteration launch at 1000 x 16 — so a caller that issues
+ * HBM -> LDS when it starts and back when it ends, a sixth of a ten-iteration launch at 1000 x 16 — so a caller that issues
  * schedule after schedule with nothing in between (the reference's `iterate_gbp_v2` loop run ahead of the renderer, a planner
  * that looks several ticks ahead, a benchmark loop) brackets the loop: between mgx_batch_begin and mgx_batch_end the schedules
  * handed to mgx_iterate are recorded and submitted TOGETHER, merged into as few launches as their segments fit (32 [external]
