@@ -188,10 +188,13 @@ def summary(walls, devs, steps, units_per_step=1.0):
             "spread": {"repeats": len(walls), "ms_per_step_min": min(walls) / steps * 1e3, "ms_per_step_max": max(walls) / steps * 1e3}}
 
 
-def cpu_baseline(sc, seconds):
+def cpu_baseline(sc, seconds, check=None):
     """The oracle (a from-scratch port of the reference's CPU path, oracle/gbp_oracle.c) timed on
     this box's host cores on the same workload, bounded to ~`seconds` of CPU work.  Robots run in
-    parallel across threads for the internal sweeps, external phase serial (robot.rs:1789-1859)."""
+    parallel across threads for the internal sweeps, external phase serial (robot.rs:1789-1859).
+    check = (ticks, beliefs): the beliefs (eta, lam, mean) a FRESH engine world held after `ticks` ticks of the schedule issued
+    exactly as the timed block issues them; a fresh oracle world runs the same ticks (outside every timed region) and the
+    result — identical bit for bit or not — is returned under "parity" (BASELINE.md §3)."""
     import oracle
     from magics_amd import scenarios as S
     try:
@@ -223,7 +226,25 @@ def cpu_baseline(sc, seconds):
         res[threads] = (n / el, n)
         w.close()
     best = max(res, key=lambda t: res[t][0])
+    parity = None
+    if check is not None:
+        import numpy as np
+        ticks, got = check
+        w = oracle.OracleWorld(sc["params"], threads=best, lib_path=lib_path)
+        S.populate(w, sc)
+        for _ in range(ticks):
+            w.iterate(sc["steps"])
+        want = w.read_beliefs()
+        w.close()
+        same = [bool(np.array_equal(x, y)) for x, y in zip(got, want)]
+        parity = {"checked": True, "identical": all(same), "finite": bool(all(np.isfinite(x).all() for x in got)),
+                  "steps": ticks * len(sc["steps"]), "entries": int(sum(x.size for x in got)),
+                  "max_abs_diff": float(max(np.nanmax(np.abs(x - y)) for x, y in zip(got, want))),
+                  "what": f"a fresh world ran the timed block's exact submission ({ticks} tick(s) of the {len(sc['steps'])}-step schedule, "
+                          "batched as in the timed block) and a fresh CPU oracle the same steps, outside the timed region: belief eta, lam "
+                          "and mean of every variable compared bit for bit"}
     return {
+        "parity": parity,
         "value": round(res[best][0], 2), "unit": "GBP iterations/s", "cores": best, "kind": "port",
         "sample": f"{sc['name']}: {res[best][1]} iterations on {best} of {avail} available host threads (robots parallel in "
                   f"internal sweeps, external phase serial), -O3 -march={'native' if lib_path else 'x86-64-v3'}; "
@@ -924,11 +945,30 @@ def main():
 
     # ---- CPU baseline: rank 0, N = 1 only ---------------------------------------------------------------------------
     if rank == 0 and not multi and not a.no_cpu_baseline:
-        cb = cpu_baseline(sc2, a.cpu_seconds)
+        # parity of the exact path the headline ran: a fresh world, the timed block's submission, read back
+        check = None
+        try:
+            w_par = World(sc2["params"], stream=stream, fma=a.fma)
+            S.populate(w_par, sc2)
+            n_par = min(a.steps, 20 * SCHEDULE_LEN)  # (the whole timed block, up to 200 steps: the oracle runs ~25 steps a second)
+            par_launches = run_steps(w_par.iterate, n_par, sc2["steps"], w_par.batch, G)
+            if n_par % SCHEDULE_LEN == 0:
+                check = (n_par // SCHEDULE_LEN, w_par.read_beliefs())
+            del w_par
+        except Exception as e:  # noqa: BLE001
+            line["parity"] = {"checked": False, "error": f"{type(e).__name__}: {e}"}
+        cb = cpu_baseline(sc2, a.cpu_seconds, check=check)
+        par = cb.pop("parity", None)
+        if par is not None:
+            par["engine_launches"] = par_launches
+            line["parity"] = par
+        elif "parity" not in line:
+            line["parity"] = {"checked": False, "why": "--steps is not a whole number of ticks"}
         line["cpu_baseline"] = cb
         line["speedup_vs_cpu_baseline"] = round(line["value"] / cb["value"], 1)
         if sc1 is not None:
             cb1 = cpu_baseline(sc1, a.cpu_seconds)
+            cb1.pop("parity", None)
             line["configs1"]["cpu_baseline"] = cb1
             line["configs1"]["speedup_vs_cpu_baseline"] = round(line["configs1"]["value"] / cb1["value"], 1)
 

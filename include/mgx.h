@@ -401,6 +401,8 @@ int mgx_halo_unpack(mgx_world *w, const void *dev_buf);
  *               rank's bookkeeping: the ranks' topology passes are out of step)
  *   every rank: the new rank table to mgx_halo_plan_from_connections, and the in-engine transports wired again (device
  *               indices change: locals first) — as after mgx_robot_add.
+ * What does NOT travel: device-side missions (mgx_mission_*: routes, next waypoints, Transforms, completion ticks are state of
+ * unsharded worlds, device index == robot id).  Export, import and release of a robot that has one are refused (MGX_ERR_STATE).
  * Results stay bit-identical to the unsharded world's (tests/test_gpu_sharded.py::test_robots_migrate_between_ranks). */
 int mgx_robot_export(mgx_world *w, int32_t robot, void *buf, uint64_t capacity, uint64_t *bytes);
 int mgx_robot_import(mgx_world *w, int32_t robot, const void *buf, uint64_t bytes);

@@ -83,6 +83,15 @@ constexpr int XREC_CHUNKS = 15;
 #endif
 constexpr int XREC_PAYLOAD_DWORDS = 45, XREC_BYTES = 16 * XREC_CHUNKS, XREC_EPOCH_DWORD = 44;  // XREC_BYTES: per variable
 __host__ __device__ constexpr uint32_t xrec_seq(unsigned long long count) { return 0x80000000u | (uint32_t)(count & 0x7fffffffull); }
+// Records that cross GPUs (a boundary robot's chunks stored into another rank's ghost area over xGMI) do not lean on the 16 bytes
+// arriving as one write — that is measured inside one GPU (experiments/handoff/atomicity.hip) and unobserved across the fabric: their
+// sequence word is stored XORed with a mix of the chunk's three payload dwords, and the consumer undoes the mix with the payload
+// it READ.  A chunk seen half-written (new word over old payload, or the reverse) does not validate — it is simply asked for again,
+// like a chunk that has not arrived — except when the stale dwords mix to the same value as the new ones (2^-32 for unrelated
+// data; identical data is no error).  Memory that was only ever zeroed: mix(0, 0, 0) = 0, no top bit, never valid.
+__host__ __device__ constexpr uint32_t xrec_mix(uint32_t a, uint32_t b, uint32_t c) {
+    return a ^ ((b << 11) | (b >> 21)) ^ ((c << 22) | (c >> 10));
+}
 
 // Resident schedule launches of a SHARDED world: where the exchange records of a local robot that another rank holds as a ghost
 // go at the end of a segment — addresses inside that rank's ghost area (peer-mapped, fine-grained), indexed by THIS rank's

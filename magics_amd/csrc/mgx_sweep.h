@@ -801,11 +801,17 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
 #pragma unroll
             for (int ch = 0; ch < XREC_CHUNKS; ch++) R[ch] = fetch(off_mine + (unsigned)ch * cstride);
         }
+        // (ghost records crossed the fabric: their sequence word carries a mix of the payload it arrived with, mgx_dev.h)
+        const bool remote = SHARD && (off_mine & GHOST_BIT) != 0u;
+        auto word_of = [&](const v4u32 &c) __attribute__((always_inline)) {
+            if constexpr (SHARD) return remote ? (c.w ^ xrec_mix(c.x, c.y, c.z)) : c.w;
+            return c.w;
+        };
         long long t0 = 0;
         for (unsigned spins = 0;; spins++) {
             bool missing = false;
 #pragma unroll
-            for (int ch = 0; ch < XREC_CHUNKS; ch++) missing = missing || R[ch].w != seq;
+            for (int ch = 0; ch < XREC_CHUNKS; ch++) missing = missing || word_of(R[ch]) != seq;
             missing = missing && mine;
             if (__ballot(missing) == 0ull) break;
             // (a waiting workgroup's re-requests load the memory pipeline of its CU, which the workgroups beside it — the ones it
@@ -828,7 +834,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             if (missing) {
 #pragma unroll
                 for (int ch = 0; ch < XREC_CHUNKS; ch++)
-                    if (R[ch].w != seq) R[ch] = fetch(off_mine + (unsigned)ch * cstride);
+                    if (word_of(R[ch]) != seq) R[ch] = fetch(off_mine + (unsigned)ch * cstride);
             }
         }
         auto D = [&](int n) __attribute__((always_inline)) { return R[n / 3][n % 3]; };  // payload dword n
@@ -1833,7 +1839,11 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                         // (no indexing of the record by the parity: a copy that is indexed at run time lives in scratch)
                         const __amdgpu_buffer_rsrc_t rs_peer = uniform_rsrc(ob ? xr.xrec[1] : xr.xrec[0], (unsigned)K * (unsigned)XREC_BYTES);
                         const uint32_t seq = xrec_seq(next_count + xr.flag_delta);
-                        for (int t2 = lane; t2 < XREC_CHUNKS * K; t2 += 64) st16_system_raw(rs_peer, 16u * (unsigned)t2, chunk_of(t2, seq));
+                        for (int t2 = lane; t2 < XREC_CHUNKS * K; t2 += 64) {
+                            v4u32 c = chunk_of(t2, seq);
+                            c.w ^= xrec_mix(c.x, c.y, c.z);  // (across the fabric: the word vouches for the payload it travels with)
+                            st16_system_raw(rs_peer, 16u * (unsigned)t2, c);
+                        }
                         if (lane == 0)
                             __hip_atomic_store(reinterpret_cast<unsigned long long *>(xr.flag), next_count + xr.flag_delta, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_SYSTEM);

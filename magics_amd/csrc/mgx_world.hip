@@ -537,6 +537,11 @@ struct mgx_world {
         // slot = the robot's place among this rank's ghosts — instead of one per entry of the receive list
         bool by_slot = false;
         size_t slot_cap = 0;
+        // ... whose push destinations (dst[], one per entry of the send list, in the consumers' slot numbering) are only as good as
+        // the lists and the device layout they were made for: any change of either (mgx_halo_plan*, a robot added or released)
+        // takes the aim away until mgx_halo_direct_connect_slots has run again — an exchange in between is refused, not run
+        // against tables of another length
+        bool aimed = false;
         unsigned long long seq = 0, push_seq = 0;  // exchanges waited for / pushed
         long long timeout_ticks = 500000000ll;  // 5 s of the 100 MHz wall clock
         DevBuf<unsigned long long> dst[2], peer_flags, ready;  // ready: the exchange workgroup 0 of the wait kernel has announced
@@ -1390,6 +1395,7 @@ static int commit(mgx_world *w) {
     w->flag_base = 0;
     w->resident_cap = w->resident_cap_sharded = -1;
     w->xres.connected = false;  // ghost slots and progress words belonged to the old layout: the ranks wire them again
+    w->direct.aimed = false;    // ... and a slot-wired direct exchange names device indices and slots of the old layout
     d.gxrec[0] = d.gxrec[1] = nullptr; d.gflag = nullptr; d.xp_ptr = nullptr; d.xp_rec = nullptr;
     w->xres.agree = nullptr; d.agree = nullptr; d.n_ranks = 0;
     if (!w->sweep_err_host) {  // the word device code reports a wait that gave up in (resident launches, direct halo waits)
@@ -2966,11 +2972,14 @@ int mgx_batch_end(mgx_world *w, uint32_t *n_schedules, uint32_t *n_launches) {
 
 int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n) {
     if (!w || (!steps && n)) return fail(MGX_ERR_INVALID, "null argument");
-    if (!w->batch.open) return iterate_now(w, steps, n);
+    // (the same checks inside and outside a batch: a call that would fail when it runs fails when it is issued)
     for (uint32_t i = 0; i < n; i++)
         if (steps[i] & ~(MGX_STEP_INTERNAL | MGX_STEP_EXTERNAL)) return fail(MGX_ERR_INVALID, "bad step %u", i);
+    if (!w->batch.open) return iterate_now(w, steps, n);
+    if (w->robots.empty()) return fail(MGX_ERR_STATE, "world has no robots");
+    int rc0 = check_device_error(w);
+    if (rc0 != MGX_OK) return rc0;
     mgx_world::Batch &b = w->batch;
-    b.schedules++;
     if (!b.steps.empty()) {  // does it still fit the launch the recorded ones make?
         std::vector<uint8_t> both(b.steps);
         both.insert(both.end(), steps, steps + n);
@@ -2980,6 +2989,7 @@ int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n) {
         }
     }
     b.steps.insert(b.steps.end(), steps, steps + n);
+    b.schedules++;  // (recorded: a schedule whose predecessors' submission failed above is not counted)
     return MGX_OK;
 }
 
@@ -3369,6 +3379,7 @@ int mgx_halo_plan(mgx_world *w, uint32_t n_send, const int32_t *send_robots, uin
     w->halo_send.assign(send_robots, send_robots + n_send);
     w->halo_recv.assign(recv_ghosts, recv_ghosts + n_recv);
     w->halo_dirty = true;
+    w->direct.aimed = false;
     return MGX_OK;
 }
 
@@ -3404,6 +3415,7 @@ int mgx_halo_plan_from_connections(mgx_world *w, const int32_t *rank_of, uint32_
         w->halo_recv.insert(w->halo_recv.end(), recv[p].begin(), recv[p].end());
     }
     w->halo_dirty = true;
+    w->direct.aimed = false;
     return MGX_OK;
 }
 
@@ -3469,6 +3481,9 @@ int mgx_robot_export(mgx_world *w, int32_t robot, void *buf, uint64_t capacity, 
     MGX_ENTER(w);
     if (!w || !bytes || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
     if (w->robots[(size_t)robot].ghost) return fail(MGX_ERR_INVALID, "robot %d is a ghost here: its owner exports it", robot);
+    if ((size_t)robot < w->mission.has.size() && w->mission.has[(size_t)robot])
+        return fail(MGX_ERR_STATE, "robot %d has a mission on this device (mgx_mission_set): missions do not migrate — routes, next waypoints "
+                                   "and Transforms are state of unsharded worlds (include/mgx.h)", robot);
     int rc = check_device_error(w);
     if (rc != MGX_OK) return rc;
     if (w->dev_valid && (w->dirty || w->conns_dirty || w->flags_dirty)) {  // (not valid: the host mirror is the truth already)
@@ -3519,6 +3534,9 @@ int mgx_robot_import(mgx_world *w, int32_t robot, const void *buf, uint64_t byte
     MGX_ENTER(w);
     if (!w || !buf || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad argument");
     if (!w->robots[(size_t)robot].ghost) return fail(MGX_ERR_STATE, "robot %d is owned here already", robot);
+    if ((size_t)robot < w->mission.has.size() && w->mission.has[(size_t)robot])
+        return fail(MGX_ERR_STATE, "robot %d has a mission on this device (mgx_mission_set): missions do not migrate — routes, next waypoints "
+                                   "and Transforms are state of unsharded worlds (include/mgx.h)", robot);
     int rc = check_device_error(w);
     if (rc != MGX_OK) return rc;
     if (w->dev_valid && (w->dirty || w->conns_dirty || w->flags_dirty)) {
@@ -3598,6 +3616,9 @@ int mgx_robot_release(mgx_world *w, int32_t robot) {
     MGX_ENTER(w);
     if (!w || robot < 0 || (size_t)robot >= w->robots.size()) return fail(MGX_ERR_INVALID, "bad robot id");
     if (w->robots[(size_t)robot].ghost) return fail(MGX_ERR_STATE, "robot %d is a ghost here already", robot);
+    if ((size_t)robot < w->mission.has.size() && w->mission.has[(size_t)robot])
+        return fail(MGX_ERR_STATE, "robot %d has a mission on this device (mgx_mission_set): missions do not migrate — routes, next waypoints "
+                                   "and Transforms are state of unsharded worlds (include/mgx.h)", robot);
     int rc = check_device_error(w);
     if (rc != MGX_OK) return rc;
     if (w->dev_valid && (w->dirty || w->conns_dirty || w->flags_dirty)) {
@@ -3642,12 +3663,27 @@ static int halo_commit(mgx_world *w) {
 
 }  // extern "C" (helpers below have C++ linkage)
 
+// A slot-wired exchange (mgx_halo_direct_setup_slots) is only as good as its last aim: the push walks dst[] by the send list's
+// length and the wait indexes the receive area by ghost number, so lists or a layout newer than the aim — or more ghosts than
+// slots — are an error here, not a store to wherever the old tables point.
+static int direct_slots_ok(mgx_world *w) {
+    const mgx_world::DirectHalo &dh = w->direct;
+    if (!dh.by_slot) return MGX_OK;
+    const size_t NG = (size_t)(w->d.R_total - w->d.R_local);
+    if (NG > dh.slot_cap)
+        return fail(MGX_ERR_STATE, "%zu ghost robots but the direct exchange was wired with %zu slots: wire it again (mgx_halo_direct_setup_slots)", NG, dh.slot_cap);
+    if (!dh.aimed)
+        return fail(MGX_ERR_STATE, "the exchange lists or the device layout changed since the direct exchange was aimed: "
+                                   "mgx_halo_direct_connect_slots again (robots joined: mgx_halo_direct_setup_slots on every rank first)");
+    return MGX_OK;
+}
 // push: this rank's boundary records go to the consumers (exchange number push_seq + 1);
 // wait: the ghosts are filled once every producer has published exchange seq + 1.
 static int direct_push(mgx_world *w) {
     int rc = halo_commit(w);
     if (rc != MGX_OK) return rc;
     mgx_world::DirectHalo &dh = w->direct;
+    if ((rc = direct_slots_ok(w)) != MGX_OK) return rc;
     if (dh.push_seq != dh.seq) return fail(MGX_ERR_STATE, "exchange %llu is already pushed and not yet waited for", dh.push_seq);
     dh.push_seq += 1;
     const int par = (int)(dh.push_seq & 1ull);
@@ -3659,6 +3695,7 @@ static int direct_wait(mgx_world *w) {
     int rc = halo_commit(w);
     if (rc != MGX_OK) return rc;
     mgx_world::DirectHalo &dh = w->direct;
+    if ((rc = direct_slots_ok(w)) != MGX_OK) return rc;
     if (dh.push_seq != dh.seq + 1) return fail(MGX_ERR_STATE, "nothing pushed for exchange %llu", dh.seq + 1);
     dh.seq += 1;
     const int par = (int)(dh.seq & 1ull);
@@ -3751,6 +3788,7 @@ int mgx_halo_direct_setup(mgx_world *w, uint32_t n_sources, void **recv_base, vo
     HIP_TRY(hipStreamSynchronize(w->stream));
     dh.connected = false;
     dh.by_slot = false;
+    dh.aimed = false;
     if (dh.recv) { (void)hipFree(dh.recv); dh.recv = nullptr; }
     if (dh.flags) { (void)hipFree(dh.flags); dh.flags = nullptr; }
     dh.recv_words = w->halo_recv.size() * (size_t)mgx_halo_words((uint32_t)w->K);
@@ -3832,6 +3870,7 @@ int mgx_halo_direct_setup_slots(mgx_world *w, uint32_t n_sources, uint32_t slot_
     if (dh.recv) { (void)hipFree(dh.recv); dh.recv = nullptr; }
     if (dh.flags) { (void)hipFree(dh.flags); dh.flags = nullptr; }
     dh.by_slot = true;
+    dh.aimed = false;
     dh.slot_cap = slot_capacity;
     dh.recv_words = (size_t)slot_capacity * (size_t)mgx_halo_words((uint32_t)w->K);
     dh.n_sources = (int)n_sources;
@@ -3884,6 +3923,9 @@ int mgx_halo_direct_connect_slots(mgx_world *w, uint32_t n_peers, const uint32_t
     int rc = halo_commit(w);
     if (rc != MGX_OK) return rc;
     const size_t n_send = w->halo_send.size(), words = (size_t)mgx_halo_words((uint32_t)w->K);
+    if ((size_t)(w->d.R_total - w->d.R_local) > dh.slot_cap)
+        return fail(MGX_ERR_STATE, "%d ghost robots but the receive area has %zu slots: mgx_halo_direct_setup_slots again (on every rank)",
+                    w->d.R_total - w->d.R_local, dh.slot_cap);
     if (n_peers && (send_first[0] != 0 || send_first[n_peers] != n_send)) return fail(MGX_ERR_INVALID, "send_first does not cover the send list");
     if (n_send && !entry_slot) return fail(MGX_ERR_INVALID, "null argument");
     std::vector<unsigned long long> d0(std::max<size_t>(n_send, 1), 0ull), d1(std::max<size_t>(n_send, 1), 0ull), pf(std::max<size_t>(n_peers, 1), 0ull);
@@ -3908,6 +3950,7 @@ int mgx_halo_direct_connect_slots(mgx_world *w, uint32_t n_peers, const uint32_t
     HIP_TRY(hipStreamSynchronize(w->stream));
     dh.n_peers = (int)n_peers;
     dh.connected = true;
+    dh.aimed = true;
     return MGX_OK;
 }
 

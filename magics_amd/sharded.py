@@ -69,7 +69,9 @@ class ShardPlan:
         else:
             self.owner = np.zeros(0, dtype=np.int64)  # an empty world: robots join later (ShardedWorld.add_robot)
         assert len(self.owner) == n
-        ir = sc["ir"]
+        # (connections made after the robots' first ticks on their own — sc["ir_late"], scenarios.junction_scenario — are planned
+        # for from the start: their ghosts exist, and exchange records, before the factors do)
+        ir = list(sc["ir"]) + list(sc.get("ir_late") or [])
         p = hostlib.shard_plan(self.owner, [c[0] for c in ir], [c[1] for c in ir], rank, world_size)
         self.local = [int(r) for r in p["local"]]
         self.ghosts = [int(g) for g in p["ghosts"]]
@@ -108,7 +110,8 @@ class ShardedWorld:
                                       order_key=rb["order_key"])
         # ghosts: the owners of the connections evaluated here (their records arrive by the exchange) and — bookkeeping only,
         # for the MessageCount of the local graphs — the targets of connections local robots own towards other ranks
-        out_targets = sorted({b for a, b, _ in sc["ir"] if plan.owner[a] == rank and plan.owner[b] != rank} - set(plan.ghosts))
+        ir_all = list(sc["ir"]) + list(sc.get("ir_late") or [])
+        out_targets = sorted({b for a, b, _ in ir_all if plan.owner[a] == rank and plan.owner[b] != rank} - set(plan.ghosts))
         for g in list(plan.ghosts) + out_targets:
             rb = sc["robots"][g]
             self.lid[g] = w.add_robot(rb["mean0"], rb["prior_diag"], rb["dt"], rb["radius"], path=None,
@@ -130,6 +133,31 @@ class ShardedWorld:
 
         self.direct = False
         self.transport = "collective" if plan.world_size > 1 else "none"  # sharded.connect() moves it to an in-engine one
+        self.late_pending = bool(sc.get("ir_late"))
+        if self.late_pending and (comm is not None or plan.world_size == 1):
+            self.connect_late()  # (the ranks of a LocalCluster are ticked and connected by the cluster, in lockstep)
+
+    def connect_late(self, ticked=False):
+        """scenarios.populate's second half on a sharded world: the robots run sc["connect_after_ticks"] driver ticks on their own
+        (every rank at the same time — the exchanges of those ticks carry the ghosts' records although nothing reads them yet),
+        one more exchange so that every ghost's delivery counts are its owner's current ones (a factor created now remembers
+        them, robot.rs:1549-1585), then create_interrobot_factors for the pairs of sc["ir_late"] this rank takes part in.
+        ticked=True: the caller has run the ticks and the exchange (LocalCluster)."""
+        from . import scenarios
+        sc, plan, rank = self.sc, self.plan, self.plan.rank
+        if not self.late_pending:
+            return
+        if not ticked:
+            tick = scenarios.tick_inputs(sc)
+            steps = tick.pop("steps", None) or sc["steps"]
+            for _ in range(sc["connect_after_ticks"]):
+                self.update_priors(**tick)
+                self.iterate(steps)
+            self.exchange()
+        for a, b, n0 in sc["ir_late"]:
+            if plan.owner[b] == rank or plan.owner[a] == rank:
+                self.world.ir_connect(self.lid[a], self.lid[b], n0)
+        self.late_pending = False
 
     # -- a world that follows its topology ---------------------------------------------------------------
     def _init_dynamic(self, sc, tensor_factory):
@@ -176,6 +204,16 @@ class ShardedWorld:
         plan.K = np.asarray(mean0).shape[0]
         self.lid[g] = g
         self.replan()
+        if getattr(self, "_slot_wiring", None) is not None and self.comm is not None:
+            # A multi-process world whose exchange lives in the engines: the robot needs a slot in every other rank's receive
+            # (and ghost) area and the push tables name the old lists and device indices — the engine refuses an exchange until
+            # mgx_halo_direct_connect_slots has run again.  Collective, like the call itself: nobody may still be pushing into an
+            # area that is about to be closed.  (The ranks of a LocalCluster are wired again by the cluster.)
+            resident = bool(getattr(self, "resident", False))
+            self.synchronize()
+            self.comm.barrier()
+            self.direct_close()
+            connect(self, self.comm, "direct", resident=resident)
         return g
 
     def set_environment(self, env):
@@ -242,7 +280,9 @@ class ShardedWorld:
                 self._aim_slots()  # the exchange lives in the engine: only the pushes' destinations follow the lists
                 if getattr(self, "_res_wiring", None) is not None:
                     self._aim_resident()
-            return  # (robots joined: the areas are wired again by whoever drives the ranks — connect_slots / LocalCluster)
+            # robots joined: the areas are wired again by whoever drives the ranks (add_robot over a communicator, LocalCluster);
+            # until then the engine refuses every exchange over the old tables (MGX_ERR_STATE), it does not run them
+            return
         for name, need in (("send_buf", sum(self.send_counts)), ("recv_buf", sum(self.recv_counts))):
             buf = getattr(self, name)
             if buf is None or buf.numel() < max(1, need):
@@ -879,6 +919,18 @@ class LocalCluster:
         self.n_robots, self.K = len(sc["robots"]), sc.get("K")
         self.resident = False
         self.agree = agree
+        if sc.get("ir_late") and not dynamic:
+            # robots that iterate on their own before they meet (ShardedWorld.connect_late): the ticks in lockstep over the
+            # collective transport, the factors, THEN the in-engine transports are wired (for the exchange lists as they end up)
+            from . import scenarios
+            self.direct_slots, self._want_resident = False, False
+            tick = scenarios.tick_inputs(sc)
+            for _ in range(sc["connect_after_ticks"]):
+                self.tick(steps=sc["steps"], **tick)
+            if world_size > 1:
+                self._exchange()
+            for sw in self.ranks:
+                sw.connect_late(ticked=True)
         self.direct_slots = bool(direct and dynamic and world_size > 1)
         self._want_resident = bool(resident and self.direct_slots)
         if self.direct_slots:

@@ -5,7 +5,9 @@ RCCL path), or — mode "direct" — the exchange lives in the engines: peer-map
 robot, wired once, re-aimed when the lists change.  Every rank runs the same driver.
 A mode with "+migrate" re-balances every ten ticks: the robots are dealt out again in strips of where they are, and the ones whose
 strip changed move to their new rank (ShardedWorld.migrate: records over the control plane, transports wired again).
-usage: dynamic_topology_worker.py RANK WORLD_SIZE PORT OUT.npz [collective|direct|direct+resident][+migrate]"""
+A mode with "+spawn" builds and WIRES the world with the first n - 2 robots and lets the last two join afterwards (ShardedWorld.add_robot,
+collective): every rank's receive areas need a slot more and the push tables name the old lists — the transports are wired again.
+usage: dynamic_topology_worker.py RANK WORLD_SIZE PORT OUT.npz [collective|direct|direct+resident][+migrate|+spawn]"""
 import os
 import sys
 
@@ -16,7 +18,8 @@ sys.path.insert(0, ROOT)
 def main():
     rank, ws, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     mode = sys.argv[5] if len(sys.argv) > 5 else "collective"
-    migrate, mode = mode.endswith("+migrate"), mode.replace("+migrate", "")
+    migrate, spawn = "+migrate" in mode, "+spawn" in mode
+    mode = mode.replace("+migrate", "").replace("+spawn", "")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(ws))
     import numpy as np
     import torch
@@ -30,11 +33,17 @@ def main():
     sc["ir"] = []
     comm = sharded.TorchDistComm(stage_through_host=True)
     stream = torch.cuda.Stream()
-    sw = sharded.ShardedWorld(sc, rank, ws, lambda p: World(p, stream=stream.cuda_stream), comm=comm, owner=np.arange(n) % ws, dynamic=True)
+    n0 = n - 2 if spawn else n
+    sc0 = dict(sc, robots=sc["robots"][:n0])
+    sw = sharded.ShardedWorld(sc0, rank, ws, lambda p: World(p, stream=stream.cuda_stream), comm=comm, owner=np.arange(n0) % ws, dynamic=True)
     if mode.startswith("direct"):
         os.environ.setdefault("MGX_RESIDENT_CENSUS_SHARDED_US", "500000")  # (two processes share the one GPU of a test box)
         got = sharded.connect(sw, comm, "direct", resident=mode == "direct+resident")
         assert got == mode and sw.direct, got
+    for g in range(n0, n):  # robots that join a world whose exchange is wired already
+        rb = sc["robots"][g]
+        assert sw.add_robot(rb["mean0"], rb["prior_diag"], rb["dt"], rb["radius"], path=rb["path"], owner=g % ws, order_key=rb["order_key"]) == g
+        assert sw.transport == mode and (sw.direct or mode == "collective"), sw.transport  # (wired again as it was)
     drv = Driver(sw, n, K, waypoints=[[tuple(rb["goal"])] for rb in sc["robots"]], radii=[rb["radius"] for rb in sc["robots"]],
                  t0=[rb["t0"] for rb in sc["robots"]], steps=sc["steps"], comms_radius=12.0, target_speed=sc["target_speed"])
     events, moved = [], 0

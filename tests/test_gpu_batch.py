@@ -77,3 +77,26 @@ def test_batches_on_worlds_that_run_launch_by_launch():
     for _ in range(4):
         ref.iterate(sc["steps"])
     assert_identical(eng, ref, what="batched ticks, launch per segment")
+
+
+@pytest.mark.parametrize("ticks_per_batch", [2, 3])
+def test_batched_ticks_at_the_headline_size(ticks_per_batch):
+    """BASELINE configs[2] at full size — 1000 x 16 + inter-robot factors, every one of the 1000 workgroups resident — with the
+    submission bench.py times: `ticks_per_batch` ticks of the 10 / 10 schedule inside one mgx_batch_begin / _end, merged into ONE
+    resident launch (the last [external] and the next tick's first internal iteration fused into one segment).  Twice in a row,
+    so that the second batch starts from what the first one wrote back; bit-identical to the oracle running tick after tick."""
+    import oracle
+    sc = S.grid_scenario(1000, 16, interrobot=True)
+    from magics_amd import World
+    eng, ref = World(sc["params"]), oracle.OracleWorld(sc["params"], threads=16)
+    assert S.populate(eng, sc) == S.populate(ref, sc)
+    for rep in range(2):
+        with eng.batch() as b:
+            for _ in range(ticks_per_batch):
+                eng.iterate(sc["steps"])
+        assert (b.schedules, b.launches) == (ticks_per_batch, 1), (b.schedules, b.launches)
+        assert eng.last_launch_count() == 1
+        for _ in range(ticks_per_batch):
+            ref.iterate(sc["steps"])
+        assert_identical(eng, ref, what=f"1000 x 16 + ir, {ticks_per_batch} ticks in one resident launch, batch {rep}")
+    assert all(np.isfinite(x).all() for x in eng.read_beliefs())

@@ -124,6 +124,29 @@ def test_config4_full_size_junction_tiles():
     assert not np.array_equal(off.read_beliefs()[2], eng.read_beliefs()[2], equal_nan=True)
 
 
+def test_config4_full_size_sharded_8_ways():
+    """BASELINE configs[4] in its own layout — "4000 robots x 32 horizon ... 8 x MI355X" — in the regime it is quoted on: 4000 x 32
+    lanes on the 20 x 20 crossroads, dynamic + obstacle + inter-robot + tracking factors, the robots hooked up after their first
+    tick (sc["ir_late"]), sharded 8 ways.  The eight ranks run inside one process on the one GPU of the box (one rank's 500
+    workgroups of 75 KB LDS are resident together, eight ranks' are not — the in-launch hand-off of this shape is covered at 2 x
+    200 robots in test_gpu_sharded.py): bit-identical to the single-world oracle, every belief finite, two ticks."""
+    sc = S.junction_scenario(4000, 32, tiles=20)
+    assert len(sc["robots"]) == 4000 and sc["K"] == 32 and sc["params"]["enable_mask"] == 15
+    assert len(sc["ir_late"]) > 4000 and not sc["ir"] and sc["connect_after_ticks"] == 1
+    cluster = sharded.LocalCluster(sc, 8, World)
+    owners = cluster.ranks[0].plan.owner
+    assert len(cluster.ranks) == 8 and sorted(np.bincount(owners)) == [500] * 8
+    assert all(sw.plan.ghosts for sw in cluster.ranks) and not any(sw.late_pending for sw in cluster.ranks)
+    ref = oracle.OracleWorld(sc["params"], threads=ORACLE_THREADS)
+    S.populate(ref, sc)
+    tick = S.tick_inputs(sc)
+    for t in range(2):
+        cluster.tick(steps=sc["steps"], **tick)
+        ref.tick(steps=sc["steps"], **tick)
+        assert_identical(cluster, ref, what=f"configs[4] 4000 x 32 junction, connected after the first tick, 8 ranks, tick {t}")
+        assert all(np.isfinite(x).all() for x in cluster.read_beliefs())
+
+
 def test_config4_everything_at_once_leaves_the_finite_range_identically():
     """the robustness variant: inter-robot AND tracking factors on robots that have never iterated — the reference's arithmetic
     itself goes through 1e+100 to inf / NaN within a tick; engine and oracle agree wherever the oracle holds a number"""

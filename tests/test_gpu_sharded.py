@@ -156,6 +156,38 @@ def test_sharded_junction_scenario_rasterises_on_every_rank():
         assert_identical(cluster, ref, what=f"junction tiles on 3 ranks, tick {tick}")
 
 
+@pytest.mark.parametrize("world_size,mode,shape", [(3, "collective", (60, 12, 2)), (2, "direct", (60, 12, 2)), (2, "resident", (60, 12, 2)),
+                                                   (2, "resident", (400, 32, 6))])
+def test_sharded_junction_robots_meet_after_their_first_tick(world_size, mode, shape):
+    """BASELINE configs[4] in the regime it is quoted on, sharded (scenarios.junction_scenario, connect_after_ticks = 1): the robots
+    run one driver tick on their own, THEN create_interrobot_factors hooks them up (sc["ir_late"]).  A sharded world plans its
+    ghosts and exchange lists for those pairs from the start, every rank ticks at the same time, the ghosts' delivery counts a new
+    factor remembers (robot.rs:1549-1585) are their owners' — beliefs of the single-world oracle bit for bit, every one finite,
+    over the collective transport, the direct one, and with the ghost records inside one resident launch per rank and tick (also
+    at configs[4]'s own horizon: 2 x 200 robots x 32 variables, 75 KB of LDS per workgroup)."""
+    n, K, tiles = shape
+    sc = S.junction_scenario(n, K, tiles=tiles)
+    assert sc["ir_late"] and not sc["ir"] and sc["connect_after_ticks"] == 1
+    make, kw = World, {}
+    if mode != "collective":
+        make, _streams = _own_stream_factory()
+        kw = dict(direct=True, resident=mode == "resident")
+    cluster = sharded.LocalCluster(sc, world_size, make, **kw)
+    assert any(sw.plan.ghosts for sw in cluster.ranks) and not any(sw.late_pending for sw in cluster.ranks)
+    if mode == "resident":
+        assert cluster.resident
+    ref = oracle.OracleWorld(sc["params"])
+    S.populate(ref, sc)
+    tick = S.tick_inputs(sc)
+    for t in range(3):
+        cluster.tick(steps=sc["steps"], **tick)
+        ref.tick(steps=sc["steps"], **tick)
+        assert_identical(cluster, ref, what=f"junction, connected after the first tick, {world_size} ranks ({mode}), tick {t}")
+        if mode == "resident" and t > 0:
+            assert all(sw.world.last_launch_count() == 1 for sw in cluster.ranks) or getattr(cluster, "declined", 0)
+    assert all(np.isfinite(x).all() for x in cluster.read_beliefs())
+
+
 def _circle_driver(w, sc, n, K, **kw):
     from magics_amd.driver import Driver
     return Driver(w, n, K, waypoints=[[tuple(rb["goal"])] for rb in sc["robots"]], radii=[rb["radius"] for rb in sc["robots"]],

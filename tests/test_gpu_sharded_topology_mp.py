@@ -23,14 +23,17 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-@pytest.mark.parametrize("mode", ["collective", "direct", "direct+resident", "collective+migrate", "direct+resident+migrate"])
+@pytest.mark.parametrize("mode", ["collective", "direct", "direct+resident", "collective+migrate", "direct+resident+migrate", "direct+spawn",
+                                  "direct+resident+spawn"])
 def test_two_processes_follow_the_topology(tmp_path, mode):
     """mode "direct": the exchange inside the engines (hipIpc-mapped record slots, one per ghost robot, re-aimed after every topology
     pass that changed the lists) — no host-driven all-to-all in any tick; "direct+resident": and the ghosts' exchange records inside
     ONE resident launch per schedule and rank (`len(ghosts) < n_robots - n_local` in what is exchanged: only robots connected across
     the ranks travel; every rank still holds a record of every robot — the replicated bookkeeping);
     "+migrate": every ten ticks the robots are dealt out again by where they are and change ranks (ShardedWorld.migrate: the records
-    over the control plane, the hipIpc areas closed and wired again) — results unchanged"""
+    over the control plane, the hipIpc areas closed and wired again) — results unchanged;
+    "+spawn": two of the robots join AFTER the in-engine transports were wired (ShardedWorld.add_robot: a slot more in every receive
+    area, push tables for the new lists — wired again collectively; the engine refuses an exchange over stale tables)"""
     ws, n, K, ticks = 2, 8, 10, 60
     port = _free_port()
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(ws)]
@@ -58,7 +61,7 @@ def test_two_processes_follow_the_topology(tmp_path, mode):
     eta_r, lam_r, mu_r = ref.read_beliefs()
     assert events[:, 0].sum() > 0
     seen = 0
-    migrate, mode = mode.endswith("+migrate"), mode.replace("+migrate", "")
+    migrate, mode = mode.endswith("+migrate"), mode.replace("+migrate", "").replace("+spawn", "")
     for o in outs:
         z = np.load(o)
         if migrate:

@@ -267,3 +267,20 @@ def test_shard_plan_rejects_bad_input():
         hostlib.shard_plan([0, 1], [0], [7], 0, 2)          # connection names a robot that does not exist
     with pytest.raises(hostlib.MgxError):
         hostlib.shard_plan([0, 1], [0], [1], 2, 2)          # rank out of range
+
+
+def test_connections_made_after_the_first_tick_are_planned_from_the_start():
+    """sc["ir_late"] (scenarios.junction_scenario, connect_after_ticks = 1): the ghosts and the exchange lists of a sharded
+    world are those of the connections as they END UP, the factors come with ShardedWorld.connect_late()"""
+    sc = _scenario()
+    late = dict(sc, ir=[], ir_late=sc["ir"], connect_after_ticks=1)
+    for r in range(3):
+        a, b = sharded.ShardPlan(sc, r, 3), sharded.ShardPlan(late, r, 3)
+        assert (a.ghosts, a.send_lists, a.recv_lists, a.connections) == (b.ghosts, b.send_lists, b.recv_lists, b.connections)
+        assert a.ghosts
+    ranks = [sharded.ShardedWorld(late, r, 3, FakeWorld, tensor_factory=lambda n: None) for r in range(3)]
+    assert all(sw.late_pending and not sw.world.conns for sw in ranks)  # (in-process ranks: the cluster ticks them in lockstep first)
+    for sw in ranks:
+        sw.connect_late(ticked=True)
+    want = [sharded.ShardedWorld(sc, r, 3, FakeWorld, tensor_factory=lambda n: None) for r in range(3)]
+    assert all(not sw.late_pending and sw.world.conns == w0.world.conns and sw.world.conns for sw, w0 in zip(ranks, want))
