@@ -194,6 +194,29 @@ int mgx_batch_end(mgx_world *w, uint32_t *n_schedules, uint32_t *n_launches);
  * neighbours inside it); otherwise one launch per [external iteration] internal* segment.  MGX_PERSISTENT=0 in
  * the environment forces the latter.  Diagnostic (bench.py prices its roofline per launch with it). */
 int mgx_last_launch_count(mgx_world *w, uint32_t *n_launches);
+
+/* LINGERING resident launches — schedules issued back to back ride in ONE launch.  The reference's driver runs iterate_gbp_v2
+ * tick after tick (robot.rs:85-108, a .chain() in FixedUpdate) with nothing in between but the two prior updates that mgx_tick
+ * folds into the launch; a resident launch that ended with its schedule would write every graph back to HBM only for the next
+ * one to stage it again (a sixth of a 10-iteration tick at 1000 x 16).  So on an unsharded world a resident launch does not end
+ * with its schedule: the robots' workgroups keep their graphs in LDS and wait — at most `microseconds` — for the next mgx_iterate
+ * / mgx_tick, which is POSTED into the running launch (a host-mapped box: plan, prior-update records) instead of
+ * launched: mgx_last_launch_count reports 1 for it all the same (one submission).  Every other call on the world first ends the
+ * launch (it writes back; the call finds the world as after any launch), so nothing observable changes — results are
+ * bit-identical, tests/test_gpu_linger.py — except:
+ *   * work the CALLER puts on the world's stream behind mgx_iterate / mgx_tick by its own means (events, other kernels) starts
+ *     only when the launch has ended: call mgx_flush (ends it, no wait) or mgx_synchronize first;
+ *   * a caller that stops issuing schedules without another call leaves the launch waiting out its bound (default 300 us,
+ *     MGX_LINGER_US; MGX_LINGER=0 or mgx_set_linger(w, 0): launches end with their schedule).  Every wait inside the launch is
+ *     bounded: a host that dies leaves no spinning GPU.
+ * A posted schedule the launch did not take any more (it ended first) is run as a launch of its own — nothing lost, nothing
+ * twice.  Launches linger only where the calling pattern promises schedules to come (two lingering launches in a row that ended
+ * without a post switch it off until schedules are issued back to back again).
+ * mgx_linger_stats: launches that lingered, schedules posted into them, posts taken back and re-run, launches that ended by
+ * themselves (waited out their bound) while the host was about to post. */
+int mgx_flush(mgx_world *w);
+int mgx_set_linger(mgx_world *w, int32_t microseconds /* < 0: default (environment) */);
+int mgx_linger_stats(mgx_world *w, uint64_t *launches, uint64_t *posts, uint64_t *reruns, uint64_t *ended_by_device);
 /* Per-world switch for the above (default: on): 0 keeps every schedule of THIS world on the launch-per-segment path — what
  * MGX_PERSISTENT=0 does for the whole process.  For measuring one against the other; results are identical either way.
  * On a sharded world with resident launches agreed on (mgx_halo_resident_connect) every rank has to switch alike.

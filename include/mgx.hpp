@@ -162,6 +162,9 @@ public:
         check(mgx_last_launch_count(w_, &n));
         return n;
     }
+    /// everything issued so far is enqueued: a lingering launch is told to end (no wait); how long launches linger (us, 0: never)
+    void flush() { check(mgx_flush(w_)); }
+    void set_linger(int32_t microseconds) { check(mgx_set_linger(w_, microseconds)); }
     /// FactorGraph::change_factor_enabled (factorgraph.rs:1529-1539) for every graph: MGX_FACTOR_* bits
     void change_factor_enabled(uint32_t kind_mask) { check(mgx_set_enabled(w_, kind_mask)); }
     std::pair<uint32_t, uint32_t> update_topology(const std::vector<std::array<float, 3>> &translations, float comms_radius,

@@ -249,6 +249,42 @@ constexpr uint32_t PH_INT_VARIABLE = 8u;  // internal_variable_iteration
 // stores + one progress word) and, in front of an external iteration, waits only for the robots it shares
 // inter-robot factors with.  Needs every workgroup of the launch co-resident (checked on the host).
 constexpr int MAX_SEGS = 32;
+
+// LINGERING resident launches (unsharded worlds).  A resident launch costs its iterations plus a fixed part — the graphs HBM -> LDS
+// when it starts and back when it ends, the dispatch, the census — that the NEXT launch of a driver's tick loop pays straight
+// again (robot.rs:85-108 runs iterate_gbp_v2 tick after tick with nothing in between but the two prior updates, which mgx_tick
+// folds into the launch).  So a launch does not end with its plan: the robots' workgroups keep their graphs in LDS and wait — a
+// bounded time — for the host to POST the next plan, or for the word to leave.
+//   * The host writes a post (plan + the tick's prior-update records) into one of two slots of a host-mapped box and raises
+//     `posted`; numbers are the world's launch numbers (monotonic, every post and every fresh launch takes one).
+//   * The launch's extra workgroup (the census' decider, kept alive) is the only poller of the box: it turns `posted` into the
+//     launch's device-side GO WORD (2 S: plan S may be run; 2 S + 1: the launch ends behind plan S) by compare-and-swap, reports
+//     what the robots have picked up (`consumed`, for the slots' reuse) and what was `taken`, and turns the word odd on the host's
+//     request (`close_req`: every other entry point of the C ABI asks for it first).
+//   * A robot's workgroup that has finished plan S polls the go word (device memory); 2 S + 2 or more: it reads plan S + 1 and its
+//     prior updates from the box and goes on where it stands — parities and sequence numbers of the exchange records run on over
+//     the plans (the first segment of a posted plan continues the last segment of the plan before: posts open with an internal
+//     iteration); exactly 2 S + 1: it writes back and returns, as every launch does.  A workgroup that has waited `linger_ticks`
+//     raises the word to 2 S + 1 itself (atomic max: whoever moves first decides for all) — a host that died or went elsewhere
+//     leaves no spinning GPU.
+// A post the launch never took (the word went odd first) is run by the host as a fresh launch: nothing is lost, nothing twice.
+struct LingerPlan {  // one posted plan as the device reads it (dwords; host-mapped memory)
+    uint32_t n, has_upd;                            // segments; 1: the tick's prior updates ride along (upd records in the slot's block)
+    uint32_t ext[MAX_SEGS / 4], n_int[MAX_SEGS / 4];  // SegPlan's bytes
+    double upd_max_speed, upd_delta_t;
+    unsigned long long number;                      // the post's number (checked: a slot that holds another post is reported)
+};
+constexpr int LINGER_PLAN_DWORDS = (int)(sizeof(LingerPlan) / 4);
+struct LingerBox {  // host-mapped
+    unsigned long long posted;     // host -> device: number of the newest post
+    unsigned long long close_req;  // host -> device: the launch numbered at most this is asked to end
+    unsigned long long taken;      // device -> host: newest post the go word covers
+    unsigned long long consumed;   // device -> host: every robot has picked up the plan of this number (its slot may be written again)
+    unsigned long long closed;     // device -> host: the go word as it stands once it is odd (2 S + 1: the launch ended behind plan S)
+    unsigned long long pad[3];
+    LingerPlan plan[2];            // slot = number & 1; the prior-update records follow the box: double upd[2][4 * R_cap]
+};
+
 struct SegPlan {
     int32_t n;                     // segments in this launch
     uint8_t ext[MAX_SEGS];         // 1: the segment opens with an external iteration (factor + variable sweep)
@@ -269,6 +305,13 @@ struct SegPlan {
     // turns the word to go, a rank that has waited census_ticks for the others — or whose own workgroups are not all there —
     // turns it to abort, both by compare-and-swap, so that every rank reads the same answer.
     unsigned long long agree_seq;
+    // lingering (above): wall-clock ticks a robot's workgroup waits for the next post before it ends the launch (0: the launch
+    // ends with its plan), the box, its prior-update records and the go word.  launch_seq is the number of the launch's own plan.
+    long long linger_ticks;
+    const LingerBox *linger_box;       // host-mapped
+    const double *linger_upd;          // host-mapped [2][4 * linger_upd_stride / 4 ...]: slot s at linger_upd + s * linger_upd_stride
+    unsigned long long linger_upd_stride;
+    unsigned long long *linger_go;     // device memory
 };
 constexpr unsigned RESIDENT_GO = 1u, RESIDENT_ABORT = 2u;
 

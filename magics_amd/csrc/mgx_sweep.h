@@ -278,7 +278,11 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     constexpr int ROLE_DF = NW == 4 ? 2 : ROLE_DYN, ROLE_UF = NW == 4 ? 3 : ROLE_UV;  // who computes the dynamic / the unary factors' messages
     static_assert(!PERSIST || IRM == IR_STAGED, "resident schedule launches exist for worlds with staged inter-robot messages");
     static_assert(!SHARD || PERSIST, "ghost records arrive in-launch only in resident schedule launches");
-    const int nseg = PERSIST ? plan.n : 1;
+    // LINGER: the launch may go on with plans the host posts while it runs (mgx_dev.h, "lingering resident launches"): the plan in
+    // force lives in LDS (s_plan: the launch's own from the kernel's arguments, later ones from the host-mapped box), and the
+    // segment counter that parities and sequence numbers derive from runs on over the plans (kbase)
+    constexpr bool LINGER = PERSIST && !SHARD;
+    int nseg = PERSIST ? plan.n : 1;
     // Fields of the world that only COLD paths read (the residency census and its decider, give-up paths of the waits, the ranks'
     // agreement, the push records of boundary robots): fetched from the kernel's argument block where they are used, through a
     // pointer the compiler cannot see through — read as `w.field` they are loaded once at the top and held in scalar registers for
@@ -313,12 +317,37 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     // VECTOR load, and the wait for a vector load waits for every write-through store the wave has in flight as well (one counter) —
     // `plan.n_int[k + 1]` right behind the publication made the publishing wave sit out the drain of its own stores.
     static_assert(MAX_SEGS % 4 == 0 && offsetof(SegPlan, ext) % 4 == 0 && offsetof(SegPlan, n_int) % 4 == 0, "SegPlan bytes are read as dwords");
+    // (LINGER: the bytes of the plan in force, from its LDS copy — a wave-uniform value, and told so)
+    uint32_t *s_plan = reinterpret_cast<uint32_t *>(lds + 2);  // [LINGER_PLAN_DWORDS] (PERSIST only), behind the parked argument pointer
+    double *s_urec = lds + 2 + LINGER_PLAN_DWORDS / 2;          // [4] a posted plan's prior-update record of this robot
+    // [8] what is derived from the plan in force, kept HERE and fetched at the top of every segment (wave-uniform values that would
+    // otherwise sit in scalar registers — and their spill lanes — for the whole launch): segments, last segment with internal
+    // iterations / with an external iteration, flags (1: some internal variable sweep runs on this robot, 2: some variable sweep), the
+    // launch-wide index of the plan's segment 0, plans run before this one
+    int32_t *s_ps = reinterpret_cast<int32_t *>(lds + 2 + LINGER_PLAN_DWORDS / 2 + 4);
+    static_assert(LINGER_PLAN_DWORDS % 2 == 0 && 2 + LINGER_PLAN_DWORDS / 2 + 4 + 4 <= 22, "the resident kernels' LDS prefix is 22 f64");
+    auto ps_word = [&](int i) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(s_ps[i]); };
+    auto plan_dword = [&](int i) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)s_plan[i]); };
     auto plan_ext = [&](int k) __attribute__((always_inline)) {
+        if constexpr (LINGER) return (plan_dword(2 + (k >> 2)) >> (8 * (k & 3))) & 0xffu;
         return (reinterpret_cast<const uint32_t *>(plan.ext)[k >> 2] >> (8 * (k & 3))) & 0xffu;
     };
     auto plan_n_int = [&](int k) __attribute__((always_inline)) {
+        if constexpr (LINGER) return (int)((plan_dword(2 + MAX_SEGS / 4 + (k >> 2)) >> (8 * (k & 3))) & 0xffu);
         return (int)((reinterpret_cast<const uint32_t *>(plan.n_int)[k >> 2] >> (8 * (k & 3))) & 0xffu);
     };
+    if (LINGER && threadIdx.x == 0) {  // the launch's own plan, as a posted one would arrive (read behind the staging barrier)
+        s_plan[0] = (uint32_t)plan.n;
+        s_plan[1] = w.upd ? 1u : 0u;
+#pragma unroll
+        for (int i = 0; i < MAX_SEGS / 4; i++) {
+            s_plan[2 + i] = reinterpret_cast<const uint32_t *>(plan.ext)[i];
+            s_plan[2 + MAX_SEGS / 4 + i] = reinterpret_cast<const uint32_t *>(plan.n_int)[i];
+        }
+        double *pd = reinterpret_cast<double *>(s_plan + 2 + MAX_SEGS / 2);
+        pd[0] = w.upd_max_speed;
+        pd[1] = w.upd_delta_t;
+    }
     // KT > 0: horizon length fixed at compile time; 0: read from the world (K <= 33); -1: read from the world, any K.
     // BIG: more than 64 dynamic-factor messages / tracking factors per robot (K > 33): some lanes carry two.
     constexpr bool BIG = KT < 0 || KT > 33;
@@ -371,6 +400,56 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             __builtin_amdgcn_s_sleep(1);
             if (ranks) __builtin_amdgcn_s_sleep(8);  // (the word is another rank's memory)
         }
+        if constexpr (LINGER) {
+            // A LINGERING launch (mgx_dev.h): this workgroup stays as the launch's postman — the only poller of the host-mapped box.
+            // Every round: how far the robots' workgroups have come (their census words hold the number of the plan they picked up
+            // last: `consumed` tells the host which slot it may write again), then one move on the go word at most — a new post
+            // raises it (2 S: plan S may be run), the host's request to end turns it odd behind everything posted (2 S + 1); a
+            // robot's workgroup that waited out its bound has turned it odd itself.  Every move is a compare-and-swap from the
+            // value just read, so the word is decided once for everybody.  Ends when the word is odd: no bound of its own is
+            // needed — the robots' waits are all bounded, and the last of them ends the launch.
+            int lingers = 0;
+            if (threadIdx.x == 0) {
+                const unsigned long long v = __hip_atomic_load(cold0().decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lingers = ((v >> 2) == seq && (v & 3ull) == RESIDENT_GO && cold_plan0().linger_ticks > 0) ? 1 : 0;
+                if (lingers) __hip_atomic_fetch_max(cold_plan0().linger_go, 2ull * seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (__syncthreads_or(lingers)) {
+                unsigned long long consumed = seq;  // (every thread keeps the same count: it moves on the barriers' verdicts)
+                for (;;) {
+                    int lag = 0;
+                    for (unsigned b2 = threadIdx.x; b2 + 1 < gridDim.x; b2 += NT)
+                        lag |= __hip_atomic_load(&cold0().census[b2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < consumed + 1ull ? 1 : 0;
+                    const bool all = __syncthreads_or(lag) == 0;
+                    if (all) consumed += 1ull;
+                    int over = 0;
+                    if (threadIdx.x == 0) {
+                        LingerBox *box = const_cast<LingerBox *>(cold_plan0().linger_box);
+                        unsigned long long *go = cold_plan0().linger_go;
+                        if (all) __hip_atomic_store(&box->consumed, consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        unsigned long long g = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!(g & 1ull)) {
+                            const unsigned long long posted = __hip_atomic_load(&box->posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            const unsigned long long creq = __hip_atomic_load(&box->close_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            if (posted > (g >> 1)) {
+                                if (__hip_atomic_compare_exchange_strong(go, &g, 2ull * posted, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                                    __hip_atomic_store(&box->taken, posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    g = 2ull * posted;
+                                }  // (lost: a robot's workgroup has ended the launch — g holds the odd word now)
+                            } else if (creq >= seq) {
+                                if (__hip_atomic_compare_exchange_strong(go, &g, g + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) g += 1ull;
+                            }
+                        }
+                        if (g & 1ull) {
+                            __hip_atomic_store(&box->closed, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            over = 1;
+                        }
+                    }
+                    if (__syncthreads_or(over)) break;
+                    __builtin_amdgcn_s_sleep(12);
+                }
+            }
+        }
         return;
     }
     // (the workgroup's robot: the same in every lane, and said so — what is derived from it stays out of the vector registers)
@@ -381,7 +460,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     const int K = KT > 0 ? KT : w.K, E = 4 * K - 6, E1 = E + 1;
     const BlobLayout L(K);
     const int ZCOL = E;  // all-zero message column (absent edges)
-    double *s_snap = lds + (PERSIST ? 2 : 0);             // [24][K] variable -> own-factor snapshots (resident: behind the parked argument pointer)
+    double *s_snap = lds + (PERSIST ? 22 : 0);            // [24][K] variable -> own-factor snapshots (resident: behind the parked argument pointer and the plan)
     double *s_prior = s_snap + SNAP_W * K;                // [20][K] prior eta, lam (belief after the last sweep)
     double *s_tmp = s_prior + 20 * K;                     // [20][K] scratch sums (external sweep)
     double *s_io = s_tmp + 20 * K;                        // image of the blob's in/out region:
@@ -422,12 +501,10 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     constexpr bool FUSED = PERSIST && QUADFIN;
     const int sum_t = FUSED ? (role == ROLE_UV ? lane : 4 * K) : tid;        // (variable, row) this thread sums: t = rr * K + i
     const int sum_step = FUSED ? 4 * K : NT;
-    // which variable sweep of this launch is the robot's last one (its belief goes out)
-    bool plan_int = false, plan_has_ext = false;  // PERSIST: some segment has internal iterations / an external iteration
-    if (PERSIST)
-        for (int k = 0; k < nseg; k++) { plan_int = plan_int || plan_n_int(k) > 0; plan_has_ext = plan_has_ext || plan_ext(k) != 0; }
-    const bool has_int_var = PERSIST ? (plan_int && !idle) : ((int_mask & PH_INT_VARIABLE) && n_int > 0 && !idle);
-    const bool any_sweep = has_int_var || ((PERSIST ? plan_has_ext : (ext_mask & PH_EXT_VARIABLE) != 0) && radio);
+    // which variable sweep of this launch is the robot's last one (its belief goes out); resident launches: per plan, set where a
+    // plan begins (below, behind the staging barrier)
+    bool has_int_var = !PERSIST && (int_mask & PH_INT_VARIABLE) && n_int > 0 && !idle;
+    bool any_sweep = !PERSIST && (has_int_var || ((ext_mask & PH_EXT_VARIABLE) != 0 && radio));
     // a later launch of the same call rewrites this robot's belief image: this one's copy is never read
     const bool bel_dead = ((hints & HINT_LATER_EXT_VARIABLE) && radio) || ((hints & HINT_LATER_INT_VARIABLE) && !idle);
 
@@ -565,7 +642,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         if (lane < 20 && role < 2) u_bel = blob[L.bel() + lane * K + (role == 0 ? K - 1 : 0)];
     }
     // messages that this launch's external factor sweep recomputes before anyone reads them are not fetched
-    const bool recompute = (PERSIST ? plan_ext(0) != 0 : (ext_mask & PH_EXT_FACTOR) != 0) && radio && ir_on;
+    const bool recompute = (PERSIST ? plan.ext[0] != 0 : (ext_mask & PH_EXT_FACTOR) != 0) && radio && ir_on;
     double r_ir[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     bool r_ir_on = false;
 
@@ -692,82 +769,12 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         return __syncthreads_or(abort_launch) != 0;
     };
     if (census && CENSUS_EARLY && census_says_abort(early_decision)) return;  // nothing has been written: the world is as it was
-    // ---- mgx_tick: update_prior_of_horizon_state (wave 0, variable K-1) and update_prior_of_current_state_v3
-    // (wave 1, variable 0) on the staged image, each ending in change_prior of that variable
-    // (robot.rs:2182-2338, variable.rs:203-230; same arithmetic as k_update_priors / apply_change_prior).  For
-    // K >= 3 the two touch disjoint state, and nobody else reads this robot's snapshot in a launch without an
-    // external factor sweep, so the change needs no other synchronisation than the barrier below.
-    if (w.upd) {
-        const uint32_t what = (uint32_t)u_rec[3];
-        const int i = role == 0 ? K - 1 : 0;
-        if (role < 2 && (role == 0 ? (what & 1u) : (what & 2u))) {
-            double m[4];
-            if (role == 0) {
-                const double ex = s_mu[0 * K + i], ey = s_mu[1 * K + i];         // estimated position (:2242)
-                double hx = u_rec[0] - ex, hy = u_rec[1] - ey;                    // horizon2waypoint
-                const double dist = std::sqrt(hx * hx + hy * hy);                 // euclidean_norm
-                double nx = hx, ny = hy;                                           // .normalized(): unchanged if |.| is 0 / inf
-                if (!(dist == 0.0 || std::isinf(dist))) { nx = hx / dist; ny = hy / dist; }
-                const double sp = (w.upd_max_speed < dist || dist != dist) ? w.upd_max_speed : dist;  // Float::min(max_speed, dist)
-                const double vx = sp * nx, vy = sp * ny;                           // new_velocity
-                m[0] = ex + vx * w.upd_delta_t; m[1] = ey + vy * w.upd_delta_t; m[2] = vx; m[3] = vy;  // (:2253-2256)
-            } else {
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const double m0 = s_mu[c * K + 0], m1 = s_mu[c * K + 1];
-                    m[c] = m0 + u_rec[2] * (m1 - m0);                              // (:2309-2316)
-                }
-            }
-            __builtin_amdgcn_wave_barrier();  // every lane has read the means before lanes 4..7 overwrite them
-            if (lane < 4) {  // prior eta = prior lam . mean (:204), in LDS and in the blob (the sweep never writes priors back)
-                double pl[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) pl[c] = s_prior[(4 + lane * 4 + c) * K + i];
-                const double pe = ((pl[0] * m[0] + pl[1] * m[1]) + pl[2] * m[2]) + pl[3] * m[3];
-                s_prior[lane * K + i] = pe;
-                blob[L.prior() + lane * K + i] = pe;
-            } else if (lane < 8) {  // belief mean (:206) and the mean of the message the variable sends (:210-221)
-                const double mc = lane == 4 ? m[0] : (lane == 5 ? m[1] : (lane == 6 ? m[2] : m[3]));
-                s_mu[(lane - 4) * K + i] = mc;
-                s_snap[(20 + lane - 4) * K + i] = mc;
-            } else if (lane == 8) {
-                s_epoch[i] += 1;
-            }
-            if (lane < 20) s_snap[lane * K + i] = u_bel;  // (stale eta, stale lam) of that message
-            // every inbox message of the variable becomes empty (:224-227)
-            const int es[4] = {(i >= 1) ? (K - 1) + (i - 1) : -1, (i <= K - 2) ? i : -1,
-                               (i >= 1 && i <= K - 2) ? n_dyn + (i - 1) : -1, (i >= 1 && i <= K - 2) ? n_dyn + (K - 2) + (i - 1) : -1};
-            for (int t = lane; t < 80; t += 64) {
-                const int col = es[t & 3];
-                if (col >= 0) s_fv[(t >> 2) * E1 + col] = 0.0;
-            }
-            if (HAS_IR) {  // foreign inter-robot factors attached to the variable: their message goes, they get the new mean
-                const int x0 = w.ir_var_ptr[v0 + i], x1 = w.ir_var_ptr[v0 + i + 1];
-                for (int e = x0 + lane; e < x1; e += 64) {
-                    if (w.enable & 2u) {
-#pragma unroll
-                        for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = m[c];
-                    }
-                    w.ir_fv_eta[0 * (size_t)w.NI + e] = 0.0;
-                    w.ir_fv_eta[1 * (size_t)w.NI + e] = 0.0;
-                    w.ir_fv_lam[0 * (size_t)w.NI + e] = 0.0;
-                    w.ir_fv_lam[1 * (size_t)w.NI + e] = 0.0;
-                    w.ir_fv_lam[4 * (size_t)w.NI + e] = 0.0;
-                    w.ir_fv_lam[5 * (size_t)w.NI + e] = 0.0;
-                    if (STAGE_IR) {
-#pragma unroll
-                        for (int c = 0; c < 6; c++) s_ir[(e - ie0) * IR_STRIDE + c] = 0.0;
-                    }
-                }
-            }
-        }
+    if (LINGER && w.upd) {  // mgx_tick's prior updates of the launch's own plan: parked where a posted plan's would be (see where a plan begins)
+        if (tid < 4) s_urec[tid] = tid == 0 ? u_rec[0] : (tid == 1 ? u_rec[1] : (tid == 2 ? u_rec[2] : u_rec[3]));
+        if (lane < 20 && role < 2) s_tmp[4 * K + role * 20 + lane] = u_bel;
         __syncthreads();
     }
-    if (PERSIST) {  // columns no sweep recomputes (disabled kinds, tracking in front of its gate) must be equal in both
-        for (int t = tid; t < 20 * E1; t += NT) s_sh[t] = s_fv[t];
-        __syncthreads();
-    }
-    uint32_t my_epoch = (sum_t < 4 * K) ? s_epoch[sum_t % K] : 0u;  // deliveries of the variable this thread sums
+    uint32_t my_epoch = 0u;  // deliveries of the variable this thread sums (set where a plan begins)
     STAMP(t_staged);
 
     // ======================= external factor sweep (pull form) ================================
@@ -870,8 +877,8 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
 #else
 #define TLSTAMP(kk, what)
 #endif
-    auto external_factor_sweep = [&](int k, bool store_fv) __attribute__((always_inline)) {
-        const int buf = PERSIST ? ((w.cur + k) & 1) : w.cur;  // snapshot buffer the owners' records are read from
+    auto external_factor_sweep = [&](int k, int kg, bool store_fv) __attribute__((always_inline)) {  // k: segment of the plan in force, kg: of the launch
+        const int buf = PERSIST ? ((w.cur + kg) & 1) : w.cur;  // snapshot buffer the owners' records are read from
 #ifdef MGX_STAMPS
         t_edges0 = __builtin_readcyclecounter();
 #endif
@@ -882,7 +889,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                 }
                 return ld16_agent_raw(rs_x, off, buf ? xrec_bytes : 0u);
             };
-            const uint32_t want_seq = xrec_seq(plan.flag_base + (unsigned long long)k);
+            const uint32_t want_seq = xrec_seq(plan.flag_base + (unsigned long long)kg);
             for (int j0 = 0; j0 < ne; j0 += NT) {  // rounds of the whole workgroup: every lane takes part in the gather
                 const int q = j0 + tid;                                        // edge lane
                 const int j = j0 == 0 ? my_j : (q < ne ? edge_of_lane(q) : 0);  // its edge
@@ -1478,12 +1485,13 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             s_fv[c * E1 + e] = s_sh[c * E1 + e];
         }
     };
-    int last_int_seg = -1, last_ext_seg = -1;  // PERSIST: last segment with internal iterations / an external iteration
-    if (PERSIST)
-        for (int k = 0; k < nseg; k++) {
-            if (plan_n_int(k) > 0) last_int_seg = k;
-            if (plan_ext(k)) last_ext_seg = k;
-        }
+    int last_int_seg = -1, last_ext_seg = -1;  // PERSIST: last segment with internal iterations / an external iteration (of the plan in force)
+    // LINGER: plans run so far, and the launch-wide index of the current plan's segment 0 — buffer parities, sequence numbers and
+    // progress counts derive from kbase + k, so that they run on over the plans exactly as over the segments of one plan (the
+    // first segment of a posted plan has no external iteration: it CONTINUES the last segment of the plan before — same index)
+    int plans_done = 0, kbase = 0;
+    bool upd_now = w.upd != nullptr;  // the plan that begins carries mgx_tick's prior updates (u_rec, u_bel)
+    const bool lingers = LINGER && census && plan.linger_ticks > 0;
 #ifdef MGX_STAMPS
     unsigned long long c_f = 0, c_fb = 0, c_v = 0, c_vb = 0, t_extf = t_staged, t_extv = t_staged, t_loop0 = t_staged;
     unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
@@ -1498,6 +1506,121 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
 #define QBEGIN(v)
 #endif
     for (int k = 0; k < nseg; k++) {
+        if (k == 0) {  // ======================= a plan begins: the launch's own, or (LINGER) one the host posted into the running launch
+            // ---- mgx_tick: update_prior_of_horizon_state (wave 0, variable K-1) and update_prior_of_current_state_v3
+            // (wave 1, variable 0) on the staged image, each ending in change_prior of that variable
+            // (robot.rs:2182-2338, variable.rs:203-230; same arithmetic as k_update_priors / apply_change_prior).  For
+            // K >= 3 the two touch disjoint state, and nobody else reads this robot's snapshot in a launch without an
+            // external factor sweep, so the change needs no other synchronisation than the barrier below.
+            if (upd_now) {
+                // (LINGER: the record and the stale (eta, lam) entries wait in LDS — the launch's own parked there behind the staging
+                // barrier, a posted plan's at the end of the plan before: nothing of them stays in registers across the segments)
+                if constexpr (LINGER) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) u_rec[c] = s_urec[c];
+                    u_bel = (lane < 20 && role < 2) ? s_tmp[4 * K + role * 20 + lane] : 0.0;
+                }
+                const double upd_max_speed = LINGER ? reinterpret_cast<const double *>(s_plan + 2 + MAX_SEGS / 2)[0] : w.upd_max_speed;
+                const double upd_delta_t = LINGER ? reinterpret_cast<const double *>(s_plan + 2 + MAX_SEGS / 2)[1] : w.upd_delta_t;
+                const uint32_t what = (uint32_t)u_rec[3];
+                const int i = role == 0 ? K - 1 : 0;
+                if (role < 2 && (role == 0 ? (what & 1u) : (what & 2u))) {
+                    double m[4];
+                    if (role == 0) {
+                        const double ex = s_mu[0 * K + i], ey = s_mu[1 * K + i];         // estimated position (:2242)
+                        double hx = u_rec[0] - ex, hy = u_rec[1] - ey;                    // horizon2waypoint
+                        const double dist = std::sqrt(hx * hx + hy * hy);                 // euclidean_norm
+                        double nx = hx, ny = hy;                                           // .normalized(): unchanged if |.| is 0 / inf
+                        if (!(dist == 0.0 || std::isinf(dist))) { nx = hx / dist; ny = hy / dist; }
+                        const double sp = (upd_max_speed < dist || dist != dist) ? upd_max_speed : dist;  // Float::min(max_speed, dist)
+                        const double vx = sp * nx, vy = sp * ny;                           // new_velocity
+                        m[0] = ex + vx * upd_delta_t; m[1] = ey + vy * upd_delta_t; m[2] = vx; m[3] = vy;  // (:2253-2256)
+                    } else {
+        #pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const double m0 = s_mu[c * K + 0], m1 = s_mu[c * K + 1];
+                            m[c] = m0 + u_rec[2] * (m1 - m0);                              // (:2309-2316)
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();  // every lane has read the means before lanes 4..7 overwrite them
+                    if (lane < 4) {  // prior eta = prior lam . mean (:204), in LDS and in the blob (the sweep never writes priors back)
+                        double pl[4];
+        #pragma unroll
+                        for (int c = 0; c < 4; c++) pl[c] = s_prior[(4 + lane * 4 + c) * K + i];
+                        const double pe = ((pl[0] * m[0] + pl[1] * m[1]) + pl[2] * m[2]) + pl[3] * m[3];
+                        s_prior[lane * K + i] = pe;
+                        blob[L.prior() + lane * K + i] = pe;
+                    } else if (lane < 8) {  // belief mean (:206) and the mean of the message the variable sends (:210-221)
+                        const double mc = lane == 4 ? m[0] : (lane == 5 ? m[1] : (lane == 6 ? m[2] : m[3]));
+                        s_mu[(lane - 4) * K + i] = mc;
+                        s_snap[(20 + lane - 4) * K + i] = mc;
+                        // (a plan posted into a lingering launch: the response means of the variable's foreign factors live in LDS)
+                        if (PERSIST && have_xmu) s_xmu[(lane - 4) * K + i] = mc;
+                    } else if (lane == 8) {
+                        s_epoch[i] += 1;
+                    }
+                    if (lane < 20) s_snap[lane * K + i] = u_bel;  // (stale eta, stale lam) of that message
+                    // every inbox message of the variable becomes empty (:224-227)
+                    const int es[4] = {(i >= 1) ? (K - 1) + (i - 1) : -1, (i <= K - 2) ? i : -1,
+                                       (i >= 1 && i <= K - 2) ? n_dyn + (i - 1) : -1, (i >= 1 && i <= K - 2) ? n_dyn + (K - 2) + (i - 1) : -1};
+                    for (int t = lane; t < 80; t += 64) {
+                        const int col = es[t & 3];
+                        if (col >= 0) {
+                            s_fv[(t >> 2) * E1 + col] = 0.0;
+                            if (PERSIST) s_sh[(t >> 2) * E1 + col] = 0.0;  // (the shadow block too: the launch's first plan copies it below, a posted one finds it in use)
+                        }
+                    }
+                    if (HAS_IR) {  // foreign inter-robot factors attached to the variable: their message goes, they get the new mean
+                        const int x0 = w.ir_var_ptr[v0 + i], x1 = w.ir_var_ptr[v0 + i + 1];
+                        for (int e = x0 + lane; e < x1; e += 64) {
+                            if (w.enable & 2u) {
+        #pragma unroll
+                                for (int c = 0; c < 4; c++) w.ir_bmu[(size_t)c * w.NI + e] = m[c];
+                            }
+                            w.ir_fv_eta[0 * (size_t)w.NI + e] = 0.0;
+                            w.ir_fv_eta[1 * (size_t)w.NI + e] = 0.0;
+                            w.ir_fv_lam[0 * (size_t)w.NI + e] = 0.0;
+                            w.ir_fv_lam[1 * (size_t)w.NI + e] = 0.0;
+                            w.ir_fv_lam[4 * (size_t)w.NI + e] = 0.0;
+                            w.ir_fv_lam[5 * (size_t)w.NI + e] = 0.0;
+                            if (STAGE_IR) {
+        #pragma unroll
+                                for (int c = 0; c < 6; c++) s_ir[(e - ie0) * IR_STRIDE + c] = 0.0;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (PERSIST && plans_done == 0) {  // columns no sweep recomputes (disabled kinds, tracking in front of its gate) must be equal in both
+                for (int t = tid; t < 20 * E1; t += NT) s_sh[t] = s_fv[t];
+                __syncthreads();
+            }
+            my_epoch = (sum_t < 4 * K) ? s_epoch[sum_t % K] : 0u;
+            if (PERSIST) {
+                if (LINGER) nseg = (int)plan_dword(0);
+                bool plan_int = false, plan_has_ext = false;  // some segment has internal iterations / an external iteration
+                last_int_seg = last_ext_seg = -1;
+                for (int q = 0; q < nseg; q++) {
+                    if (plan_n_int(q) > 0) { plan_int = true; last_int_seg = q; }
+                    if (plan_ext(q)) { plan_has_ext = true; last_ext_seg = q; }
+                }
+                has_int_var = plan_int && !idle;
+                any_sweep = has_int_var || (plan_has_ext && radio);
+                if constexpr (LINGER) {
+                    if (tid == 0) {
+                        s_ps[0] = nseg; s_ps[1] = last_int_seg; s_ps[2] = last_ext_seg; s_ps[3] = (has_int_var ? 1 : 0) | (any_sweep ? 2 : 0);
+                        s_ps[4] = kbase; s_ps[5] = plans_done;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        if constexpr (LINGER) {  // (see s_ps)
+            nseg = ps_word(0); last_int_seg = ps_word(1); last_ext_seg = ps_word(2);
+            kbase = ps_word(4);
+        }
+        const int kg = LINGER ? kbase + k : k;  // the segment's launch-wide index
         // Nothing derived from the thread index stays live across segments: left alone, the compiler hoists every per-thread
         // address and predicate of the loop body in front of the loop and then spills them around the f64 blocks (64 spilled
         // VGPRs, 244 B of scratch per lane at K = 16); recomputing them per segment is a handful of integer instructions.
@@ -1512,7 +1635,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         PSTAMP(ps0);
         QBEGIN(qt);
         if (PERSIST && ext_k && k > 0) {  // k == 0: the launch boundary has published everything
-            wait_for_peers(k);  // (one-sided readers only: nobody, as a rule)
+            wait_for_peers(kg);  // (one-sided readers only: nobody, as a rule)
             QSTAMP(0, qt);
             // The edge lanes read the response means the previous external variable sweep left in LDS: written in front of a
             // barrier when the two variable sweeps ran side by side (the steady state of an alternating schedule: each wave goes
@@ -1522,7 +1645,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         }
         PSTAMP(ps1);
         if (ext_k & PH_EXT_FACTOR) {
-            external_factor_sweep(k, !PERSIST || k == last_ext_seg);
+            external_factor_sweep(k, kg, !PERSIST || k == last_ext_seg);
             QSTAMP(2, qt);
             __syncthreads();
             QSTAMP(3, qt);
@@ -1606,9 +1729,9 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                         }
                     }
                 }
-                if (ir_on && k != last_ext_seg) {
-                    have_xmu = true;
-                } else if (ir_on) {  // the launch's last external iteration: the response means go to HBM (robot.rs:1842-1858)
+                // (a lingering launch keeps them in LDS behind its plan's last external iteration as well: a posted plan goes on from there)
+                if (ir_on && (k != last_ext_seg || lingers)) have_xmu = true;
+                if (ir_on && k == last_ext_seg) {  // the plan's last external iteration: the response means go to HBM (robot.rs:1842-1858)
                     for (int q = tid; q < ne; q += NT) {
                         const int e = ie0 + (q == tid ? my_j : edge_of_lane(q));
                         int dst;
@@ -1631,7 +1754,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                 const bool ext_is_last = last_seg && n_int_k == 0;
                 double *s_sum = ext_is_last ? s_prior : s_tmp;
                 prefired = !early && n_int_k > 0 && !idle && (int_k & PH_INT_FACTOR) && skip0 == 0u;
-                const bool keep_means = ir_on && k != last_ext_seg;
+                const bool keep_means = ir_on && (k != last_ext_seg || lingers);
                 if (role == ROLE_UV) {
                     variable_sums(s_sum, false, false);  // reads the messages of the last internal factor sweep (s_fv)
                     QSTAMP(4, qt);
@@ -1645,9 +1768,8 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                 if (prefired && (NW == 4 || role == ROLE_UV)) unary_messages(0u, s_sh, itf);
                 if (prefired && is_dyn && (w.enable & 1u)) dynamic_messages(s_sh);
                 QSTAMP(6, qt);
-                if (keep_means) {
-                    have_xmu = true;
-                } else if (ir_on) {  // the launch's last external iteration: the means go to HBM (robot.rs:1842-1858)
+                if (keep_means) have_xmu = true;
+                if (ir_on && k == last_ext_seg) {  // the plan's last external iteration: the means go to HBM (robot.rs:1842-1858)
                     __syncthreads();
                     for (int q = tid; q < ne; q += NT) {
                         const int e = ie0 + (q == tid ? my_j : edge_of_lane(q));
@@ -1695,10 +1817,11 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             QSTAMP(6, qt);
             __syncthreads();
             QSTAMP(7, qt);
-            if (PERSIST && radio && ir_on && k != last_ext_seg) {
+            if (PERSIST && radio && ir_on && (k != last_ext_seg || lingers)) {
                 if (tid < 4 * K) s_xmu[tid] = s_mu[tid] - 0.0;  // read after the barrier that opens the next segment's factor sweep
                 have_xmu = true;
-            } else if (radio && ir_on) {
+            }
+            if (radio && ir_on && (!PERSIST || k == last_ext_seg)) {
                 // responses to the foreign factors attached to our variables, routed to their inbox
                 // (robot.rs:1842-1858): only the mean of that inbox entry is ever used (it sets the
                 // linearisation point; eta / lam of the target side never reach the kept message).
@@ -1769,7 +1892,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             }
         }
         // segment 0 of a resident launch is through: go or abort (see the residency census above) before anything is published
-        if (census && !CENSUS_EARLY && k == 0) {
+        if (census && !CENSUS_EARLY && k == 0 && plans_done == 0) {
             const unsigned long long v = tid == 0 ? __hip_atomic_load(cold().decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
             if (census_says_abort(v)) return;
         }
@@ -1790,8 +1913,8 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             // and no word follows the stores on the consumers' critical path.  (The (eta, lam) chunks 0 .. 12 are final before the
             // means and could go out from the other wave meanwhile: measured 2.5 % SLOWER on the two-wave kernel, where that wave's
             // factor sweep is as long as this one's publication and unary sweep together — experiments/README.md.)
-            const int ob = (w.cur + k + 1) & 1;
-            const unsigned long long next_count = plan.flag_base + (unsigned long long)k + 1ull;
+            const int ob = (w.cur + kg + 1) & 1;
+            const unsigned long long next_count = plan.flag_base + (unsigned long long)kg + 1ull;
             auto chunk_of = [&](int t, uint32_t seq) __attribute__((always_inline)) {
                 const int ch = t / K, i = t - ch * K, da = (3 * ch) >> 1;
                 v4u32 v;
@@ -1868,6 +1991,88 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             p_wait += ps1 - ps0; p_extf += ps2 - ps1; p_extv += ps3 - ps2; p_int += ps4 - ps3; p_pub += ps5 - ps4;
         }
 #endif
+        // ======================= end of a plan of a LINGERING launch (mgx_dev.h) ===========================
+        // The graph stays where it is.  What the NEXT plan's start needs of this one's end is put aside first — the belief (eta, lam)
+        // image goes to HBM as the tail would write it (a later plan may not sweep this robot: the image is the prior's place) and
+        // hands the coming prior updates their "stale (eta, lam)" (variable.rs:210-221), the prior is asked for again — then thread 0
+        // waits for the go word: the next plan's number or more -> plan and prior-update record are read from the host-mapped box in
+        // one round trip and the loop goes on at segment 0 of that plan, same launch-wide index; the word odd -> tail and
+        // write-back, as every launch ends.  The wait is bounded (plan.linger_ticks, and the world's abort word ends it at once):
+        // whoever waits it out raises the word itself — an atomic max, so one outcome for all.
+        if constexpr (LINGER) {
+            if (lingers && last_seg) {
+                plans_done = ps_word(5);
+                any_sweep = (ps_word(3) & 2) != 0;
+                if (role == ROLE_UV && pending) finish(s_snap, true);
+                pending = false;
+                __syncthreads();
+                const int iu = role == 0 ? K - 1 : 0;
+                // (parked behind the response means in the scratch sums' block, idle between the plans)
+                if (lane < 20 && role < 2) s_tmp[4 * K + role * 20 + lane] = any_sweep ? s_prior[lane * K + iu] : blob[L.bel() + lane * K + iu];
+                if (role == ROLE_DYN && any_sweep) copy_words_wave(blob + L.bel(), s_prior, 20 * K, lane);
+                StageRegs<(KT > 0 ? 20 * KT : 2), NT> r_prior;
+                if constexpr (KT > 0) r_prior.load(blob + L.prior(), tid);
+                int go_on = 0;
+                if (tid == 0) {
+                    const unsigned long long cur2 = 2ull * (cold_plan().launch_seq + (unsigned long long)plans_done);
+                    unsigned long long *go = cold_plan().linger_go;
+                    unsigned long long v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v <= cur2) {
+                        const long long t0 = wall_clock64();
+                        for (unsigned spins = 1;; spins++) {
+                            if (spins < 8u) __builtin_amdgcn_s_sleep(2);
+                            else __builtin_amdgcn_s_sleep(24);
+                            v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (v > cur2) break;
+                            if ((spins & 7u) == 0u &&
+                                (__hip_atomic_load(cold().sweep_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull ||
+                                 wall_clock64() - t0 > cold_plan().linger_ticks)) {
+                                const unsigned long long old = __hip_atomic_fetch_max(go, cur2 + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                v = old > cur2 + 1ull ? old : cur2 + 1ull;
+                                break;
+                            }
+                        }
+                    }
+                    go_on = v >= cur2 + 2ull ? 1 : 0;
+                }
+                if (!__syncthreads_or(go_on)) break;  // the launch ends behind this plan
+                plans_done += 1;
+                {
+                    const unsigned long long number = cold_plan().launch_seq + (unsigned long long)plans_done;
+                    const unsigned slot = (unsigned)(number & 1ull);
+                    int bad = 0;  // the slot holds another post than the go word promised (every workgroup reads the same slot: all of them leave)
+                    if (tid < LINGER_PLAN_DWORDS) {
+                        const uint32_t *src = reinterpret_cast<const uint32_t *>(&cold_plan().linger_box->plan[slot]);
+                        const uint32_t v = __hip_atomic_load(src + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        s_plan[tid] = v;
+                        if (tid == LINGER_PLAN_DWORDS - 2) bad = v != (uint32_t)(number & 0xffffffffull);
+                        if (tid == LINGER_PLAN_DWORDS - 1) bad = v != (uint32_t)(number >> 32);
+                    } else if (tid < LINGER_PLAN_DWORDS + 4) {
+                        const double *src = cold_plan().linger_upd + (size_t)slot * cold_plan().linger_upd_stride + (size_t)r * 4;
+                        s_urec[tid - LINGER_PLAN_DWORDS] = __hip_atomic_load(src + (tid - LINGER_PLAN_DWORDS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    if (__syncthreads_or(bad)) {  // (nothing of the unread plan is run; the tail writes back what the plan before left; the host reports it)
+                        if (tid == 0) {  // (the word odd, whatever it holds: the postman ends with it)
+                            __hip_atomic_fetch_or(cold_plan().linger_go, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(cold().sweep_err, 0xB0C5000000000000ull | (number & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                        break;
+                    }
+                    if constexpr (KT > 0) r_prior.store(s_prior, tid);
+                    else copy_words(s_prior, blob + L.prior(), 20 * K, tid, NT);
+                    __syncthreads();
+                    // "this workgroup has picked up plan `number`": the slot it was read from may be written again once everybody has
+                    if (tid == 0) __hip_atomic_store(&cold().census[blockIdx.x], number, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                upd_now = plan_dword(1) != 0u;
+                kbase += nseg - 1;  // segment 0 of the plan that begins continues this one (no external iteration in between)
+                k = -1;
+            }
+        }
+    }
+    if constexpr (LINGER) {  // (see s_ps; the staging barrier, or the one where the last plan began, lies behind)
+        nseg = ps_word(0); kbase = ps_word(4);
+        any_sweep = (ps_word(3) & 2) != 0;
     }
     {
         // Tail: the UV wave completes the last variable sweep (mean, covariance) while the DYN wave
@@ -1897,7 +2102,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         }
 #endif
     }
-    if (PERSIST) snap_out = (w.cur + nseg) & 1;  // where the records of the schedule's last sweep go (the host follows)
+    if (PERSIST) snap_out = (w.cur + kbase + nseg) & 1;  // where the records of the launch's last sweep go (the host follows)
     if (SHARD && role == ROLE_UV && lane == 0) {  // "through with this launch's reads of your records": see the end of a segment
         for (int t = xp0; t < xp1; t++) {
             const XPushRec xr = cold().xp_rec[t];

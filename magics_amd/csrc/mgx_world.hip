@@ -369,6 +369,8 @@ struct Incoming {
     int ir_max_edges = 0;
     bool blocks_ok = true;
 };
+struct Launch { uint32_t ext; int n_int; uint32_t hints; };  // one [external iteration] internal* segment of a schedule
+
 struct mgx_world {
     mgx_params p{};
     std::vector<Robot> robots;  // ids = indices; ghosts may interleave on the host, device order below
@@ -446,6 +448,32 @@ struct mgx_world {
         double upd_max_speed = 0.0, upd_delta_t = 0.0;
     } pending;
     int upd_ring_slot = -1;  // mgx_tick -> run_resident: the ring slot d.upd points into
+    const double *upd_host = nullptr;  // ... and the host's view of the same records (null: they live in device memory)
+    // LINGERING resident launches (mgx_dev.h): the host's side of the box.  `open`: a launch that lingers is in flight — every
+    // entry point but mgx_iterate / mgx_tick (and the pure queries) ends it first (MGX_ENTER, commit); those two POST their schedule
+    // into it when it qualifies (run_resident).  At most one post is outstanding without the launch's word for it (`un`): what
+    // is needed to take it back and run it as a launch of its own if the launch ended first.
+    struct Linger {
+        long long ticks = -1;  // wall-clock ticks (100 MHz) a robot's workgroup waits for the next post; -1: not asked yet, 0: off
+        LingerBox *box = nullptr;
+        size_t upd_stride = 0;  // f64 words per slot of prior-update records behind the box
+        DevBuf<unsigned long long> go;
+        bool open = false, hold = false;
+        unsigned long long seq0 = 0;       // number of the open launch's own plan
+        uint32_t taken_in_launch = 0;      // posts the open launch has taken
+        int useless = 0;                   // lingering launches in a row that ended without having taken a post
+        uint32_t streak = 0;               // schedules issued back to back, this one included (no other call on the world in between)
+        struct Post {
+            bool active = false;
+            unsigned long long number = 0;
+            std::vector<Launch> plan;
+            bool has_upd = false;
+            double max_speed = 0.0, delta_t = 0.0;
+            int cur_before = 0;
+            unsigned long long flag_base_before = 0;
+        } un;
+        uint64_t launches = 0, posts = 0, reruns = 0, ended_by_device = 0;
+    } linger;
     int sticky_rc = 0;       // a declined launch whose re-run failed inside a call that cannot report it (flush_counts): every
                              // later sweep, read-back and mgx_synchronize reports it (check_device_error)
     // after a declined launch the schedules skip the resident form for a while: counted in world-wide external iterations that
@@ -607,11 +635,26 @@ static size_t edge_index(const std::vector<int32_t> &in_ptr, int K, int r, int j
 // recorded so far, so that it finds the world as if each one had run when it was issued
 static int iterate_now(mgx_world *w, const uint8_t *steps, uint32_t n);
 static int submit_batch(mgx_world *w);
-#define MGX_ENTER(w)                                                    \
+static int linger_close(mgx_world *w);
+// MGX_ENTER_SCHEDULE: mgx_tick (mgx_iterate has the batch's own logic) and the pure queries — recorded schedules are submitted,
+// a lingering launch stays open.  MGX_ENTER: everything else — it also ends a lingering launch (what the call does would sit
+// behind it in the stream, or read what it has not written back) and breaks the streak of back-to-back schedules.
+#define MGX_ENTER_SCHEDULE(w)                                           \
     do {                                                                \
         if ((w) && !(w)->batch.steps.empty()) {                         \
             const int rc_enter_ = submit_batch(w);                      \
             if (rc_enter_ != MGX_OK) return rc_enter_;                  \
+        }                                                               \
+    } while (0)
+#define MGX_ENTER(w)                                                    \
+    do {                                                                \
+        MGX_ENTER_SCHEDULE(w);                                          \
+        if (w) {                                                        \
+            (w)->linger.streak = 0;                                     \
+            if ((w)->linger.open) {                                     \
+                const int rc_enter_ = linger_close(w);                  \
+                if (rc_enter_ != MGX_OK) return rc_enter_;              \
+            }                                                           \
         }                                                               \
     } while (0)
 
@@ -1190,6 +1233,9 @@ static int retopo(mgx_world *w) {
 static int commit(mgx_world *w) {
     if (!device_ok()) return fail(MGX_ERR_NO_DEVICE, "no usable HIP device (this library has no CPU path)");
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
+    // (whoever comes through here enqueues work or reads state: a lingering launch ends first — unless the caller is on its way
+    // to post a schedule into it)
+    if (w->linger.open && !w->linger.hold) { const int rcl = linger_close(w); if (rcl != MGX_OK) return rcl; }
     if (!w->dirty) {
         if (w->conns_dirty) return retopo(w);
         if (w->flags_dirty) return upload_flags(w);
@@ -1458,6 +1504,7 @@ static int confirm_resident(mgx_world *w, bool rerun, int32_t *outcome) {
     if ((v >> 2) == pd.seq && (v & 3ull) == RESIDENT_ABORT) {
         // nothing happened on the device: take the host's bookkeeping back and run the same schedule launch by launch
         w->resident_aborts++;
+        if (w->linger.open && w->linger.seq0 == pd.seq) w->linger.open = false;  // (its decider left with the verdict: nobody lingers)
         w->resident_backoff_len = std::min(std::max(2 * w->resident_backoff_len, 64), 32768);
         w->resident_backoff = w->resident_backoff_len + (int)pd.segs.size();  // (+ this schedule's own re-run)
         w->d.cur = pd.cur_before;
@@ -1576,7 +1623,6 @@ static int sweep(mgx_world *w, int32_t robot, uint32_t ext_mask, uint32_t int_ma
 }
 
 // ---- resident schedule launches: a whole mgx_iterate / mgx_tick schedule in ONE launch -----------------------
-struct Launch { uint32_t ext; int n_int; uint32_t hints; };
 
 static bool resident_enabled() {  // MGX_PERSISTENT=0 keeps every schedule on the launch-per-segment path
     static int v = -1;
@@ -1686,7 +1732,222 @@ static bool resident_gate(const mgx_world *w, const std::vector<Launch> &plan) {
     if (sharded && plan[0].ext && !w->direct.connected) return false;  // the exchange in front of the launch is the direct one
     return true;
 }
+
+// ---- lingering resident launches: the host's side (mgx_dev.h; the device's side is in mgx_sweep.h) --------------------------
+static int run_resident(mgx_world *w, const std::vector<Launch> &plan);
+static long long linger_ticks(mgx_world *w) {
+    mgx_world::Linger &lg = w->linger;
+    if (lg.ticks < 0) {
+        const char *off = getenv("MGX_LINGER"), *us = getenv("MGX_LINGER_US");
+        long long v = us ? atoll(us) : 300;  // microseconds a workgroup waits for the next schedule before it ends the launch
+        if (off && off[0] == '0') v = 0;
+        lg.ticks = (v > 0 ? std::min<long long>(v, 1000000) : 0) * 100ll;  // 100 MHz wall clock
+    }
+    return lg.ticks;
+}
+static double *linger_upd_slot(mgx_world *w, unsigned long long number) {
+    mgx_world::Linger &lg = w->linger;
+    return reinterpret_cast<double *>(reinterpret_cast<char *>(lg.box) + sizeof(LingerBox)) + (size_t)(number & 1ull) * lg.upd_stride;
+}
+// the box (host-mapped: header, two plan slots, two blocks of prior-update records) and the go word; never while a launch lingers
+static int ensure_linger_box(mgx_world *w) {
+    mgx_world::Linger &lg = w->linger;
+    const size_t stride = ((size_t)4 * (size_t)std::max(w->d.R_local, 1) + 7) & ~(size_t)7;
+    if (!lg.go.p) {
+        std::vector<unsigned long long> z(1, 0ull);
+        HIP_TRY(lg.go.upload(z, w->stream));
+        HIP_TRY(hipStreamSynchronize(w->stream));
+    }
+    if (lg.box && lg.upd_stride >= stride) return MGX_OK;
+    if (lg.box) { (void)hipHostFree(lg.box); lg.box = nullptr; }
+    const size_t grown = stride + stride / 2, bytes = sizeof(LingerBox) + 2 * grown * sizeof(double);
+    HIP_TRY(hipHostMalloc((void **)&lg.box, bytes, hipHostMallocMapped));
+    memset(lg.box, 0, bytes);
+    lg.upd_stride = grown;
+    return MGX_OK;
+}
+// Spins (bounded) until `pred` holds: 0; or until the launch has ended (its go word went odd and the postman said so): 1.
+template <class F>
+static int linger_wait(mgx_world *w, F pred, const char *what) {
+    mgx_world::Linger &lg = w->linger;
+    const double t0 = StageTimer::now();
+    for (unsigned spins = 0;; spins++) {
+        if (pred()) return 0;
+        const unsigned long long c = __atomic_load_n(&lg.box->closed, __ATOMIC_ACQUIRE);
+        if ((c & 1ull) && (c >> 1) >= lg.seq0) return 1;
+        if ((spins & 0xfffffu) == 0xfffffu && StageTimer::now() - t0 > 30e6)
+            return fail(MGX_ERR_STATE, "lingering launch %llu: no answer from the device while waiting for %s (the stream does not advance)", lg.seq0, what);
+    }
+}
+// a post the launch has taken: it runs (or has run) behind everything before it — its launches enter the counters' log
+static void linger_confirm(mgx_world *w) {
+    mgx_world::Linger &lg = w->linger;
+    for (const Launch &l : lg.un.plan) log_launch(w, -1, l.ext, l.n_int ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, l.n_int);
+    lg.un.active = false;
+    lg.posts++;
+    lg.taken_in_launch++;
+}
+// The launch has ended (closed word c = 2 S + 1: behind plan S).  A post it never took is taken back and run as a launch of its
+// own — from the same records, nothing lost and nothing twice.
+static int linger_settle(mgx_world *w) {
+    mgx_world::Linger &lg = w->linger;
+    const unsigned long long c = __atomic_load_n(&lg.box->closed, __ATOMIC_ACQUIRE);
+    lg.open = false;
+    int rc = MGX_OK;
+    if (lg.un.active) {
+        if ((c >> 1) >= lg.un.number) {
+            linger_confirm(w);
+        } else {
+            mgx_world::Linger::Post un = std::move(lg.un);
+            lg.un = mgx_world::Linger::Post{};
+            lg.reruns++;
+            w->d.cur = un.cur_before;
+            w->flag_base = un.flag_base_before;
+            void *hp = nullptr, *dp = nullptr;
+            int slot = -1;
+            if (un.has_upd) {  // (a copy in the pinned ring: the box's slot belongs to the posts of the launch that follows)
+                const size_t bytes = 4 * (size_t)w->d.R_local * sizeof(double);
+                HIP_TRY(w->stage.acquire(bytes, &hp, &slot));
+                memcpy(hp, linger_upd_slot(w, un.number), bytes);
+                HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+            }
+            bool first = true;
+            auto with_upd = [&]() { if (first && un.has_upd) { w->d.upd = (const double *)dp; w->d.upd_max_speed = un.max_speed; w->d.upd_delta_t = un.delta_t; w->upd_ring_slot = slot; } };
+            with_upd();
+            w->upd_host = (const double *)hp;
+            const int resident = run_resident(w, un.plan);
+            w->upd_host = nullptr;
+            w->upd_ring_slot = -1;
+            w->d.upd = nullptr;
+            if (resident < 0) rc = resident;
+            if (resident == 0)
+                for (const Launch &l : un.plan) {
+                    with_upd();
+                    rc = sweep(w, -1, l.ext, l.n_int ? (PH_INT_FACTOR | PH_INT_VARIABLE) : 0, l.n_int, l.hints);
+                    w->d.upd = nullptr;
+                    first = false;
+                    if (rc != MGX_OK) break;
+                }
+            if (slot >= 0) {
+                const hipError_t e = w->stage.release(slot, w->stream);
+                if (rc == MGX_OK && e != hipSuccess) rc = fail(MGX_ERR_HIP, "event record: %s", hipGetErrorString(e));
+            }
+        }
+    }
+    if (lg.taken_in_launch == 0) lg.useless++;
+    else lg.useless = 0;
+    return rc;
+}
+// Ends the lingering launch: the postman turns the go word odd behind everything posted, every workgroup writes back as at the
+// end of any launch.  What follows in the stream finds the world as after a plain launch.
+static int linger_close(mgx_world *w) {
+    mgx_world::Linger &lg = w->linger;
+    if (!lg.open) return MGX_OK;
+    if (w->pending.active) {  // (the launch's census: an aborted launch does not linger)
+        const bool hold = lg.hold;
+        lg.hold = true;
+        const int rc = confirm_resident(w);
+        lg.hold = hold;
+        if (rc != MGX_OK) return rc;
+        if (!lg.open) return MGX_OK;
+    }
+    StageTimer clock("linger");
+    __atomic_store_n(&lg.box->close_req, lg.seq0, __ATOMIC_RELEASE);
+    const int r = linger_wait(w, [] { return false; }, "the launch to end");
+    if (r < 0) return r;
+    clock.lap("closed");
+    return linger_settle(w);
+}
+// On the way to post `plan` into the open launch: 1 = the slot of the next number may be written and posted; 0 = no launch
+// lingers any more (it had ended, or the plan does not qualify and it was ended): the caller launches.
+static bool linger_plan_fits(const std::vector<Launch> &plan) {
+    if (plan.empty() || plan.size() > (size_t)MAX_SEGS || plan[0].ext) return false;  // a post CONTINUES the last segment of the plan before
+    for (const Launch &l : plan)
+        if (l.n_int > 255) return false;
+    return true;
+}
+static int linger_prepare_post(mgx_world *w, const std::vector<Launch> &plan) {
+    mgx_world::Linger &lg = w->linger;
+    if (!lg.open) return 0;
+    if (w->pending.active) {  // the launch's own census first (one launch of run-ahead, as ever)
+        lg.hold = true;
+        const int rc = confirm_resident(w);
+        lg.hold = false;
+        if (rc != MGX_OK) return rc;
+        if (!lg.open) return 0;
+    }
+    const bool fits = linger_plan_fits(plan) && !w->dirty && !w->conns_dirty && !w->flags_dirty && !w->thaw_kinds && !w->ir_thaw_active &&
+                      w->n_keyless == 0 && !w->resident_decline && !w->resident_off && (w->p.enable_mask & 2u) && w->resident_backoff == 0;
+    if (!fits) {
+        const int rc = linger_close(w);
+        return rc != MGX_OK ? rc : 0;
+    }
+    int r = 0;
+    if (lg.un.active) {  // the post before: taken?
+        const unsigned long long n = lg.un.number;
+        r = linger_wait(w, [&] { return __atomic_load_n(&lg.box->taken, __ATOMIC_ACQUIRE) >= n; }, "the last post to be taken");
+        if (r == 0) linger_confirm(w);
+    }
+    if (r == 0) {  // the slot of the coming number held the post two before it: has every workgroup read that one?
+        const unsigned long long P = w->launch_seq + 1ull;
+        if (P >= lg.seq0 + 3ull) r = linger_wait(w, [&] { return __atomic_load_n(&lg.box->consumed, __ATOMIC_ACQUIRE) + 2ull >= P; }, "the robots to pick up the plan two before");
+    }
+    if (r < 0) return r;
+    if (r == 1) {  // the launch ended meanwhile (its workgroups waited out their bound)
+        lg.ended_by_device++;
+        const int rc = linger_settle(w);
+        return rc != MGX_OK ? rc : 0;
+    }
+    return 1;
+}
+// Posts `plan` (prepared: linger_prepare_post returned 1; the prior-update records, if any, are in the coming number's slot).
+static int linger_post(mgx_world *w, const std::vector<Launch> &plan, bool has_upd, double max_speed, double delta_t) {
+    mgx_world::Linger &lg = w->linger;
+    const unsigned long long P = ++w->launch_seq;
+    LingerPlan &lp = lg.box->plan[P & 1ull];
+    lp.n = (uint32_t)plan.size();
+    lp.has_upd = has_upd ? 1u : 0u;
+    uint8_t ext[MAX_SEGS] = {}, n_int[MAX_SEGS] = {};
+    for (size_t k = 0; k < plan.size(); k++) { ext[k] = plan[k].ext ? 1 : 0; n_int[k] = (uint8_t)plan[k].n_int; }
+    memcpy(lp.ext, ext, sizeof ext);
+    memcpy(lp.n_int, n_int, sizeof n_int);
+    lp.upd_max_speed = max_speed;
+    lp.upd_delta_t = delta_t;
+    lp.number = P;
+    lg.un.active = true;
+    lg.un.number = P;
+    lg.un.plan = plan;
+    lg.un.has_upd = has_upd; lg.un.max_speed = max_speed; lg.un.delta_t = delta_t;
+    lg.un.cur_before = w->d.cur;
+    lg.un.flag_base_before = w->flag_base;
+    __atomic_store_n(&lg.box->posted, P, __ATOMIC_RELEASE);
+    // (segment 0 of the post continues the last segment of the plan before: one launch-wide index less than a launch of its own)
+    w->d.cur = (w->d.cur + (int)plan.size() - 1) & 1;
+    w->flag_base += (unsigned long long)plan.size() - 1ull;
+    w->stale_kinds |= ~w->p.enable_mask & 15u;  // disabled factors miss what these sweeps deliver
+    w->last_sweep_launches++;  // (one submission: the schedule runs inside the launch that is there)
+    return MGX_OK;
+}
 static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
+    if (w->linger.open) {
+        // A launch lingers: the schedule is posted into it if it qualifies.  (mgx_tick comes here prepared, its records in the box
+        // already — unless the launch it found had ended and the post taken back became THIS lingering launch: then the tick's
+        // prior updates sit in the pinned ring, and are copied over; records in device memory, mgx_mission_tick_end's, cannot ride
+        // in a post: the launch ends first.)
+        if (w->d.upd && !w->upd_host) {
+            const int rc = linger_close(w);
+            if (rc != MGX_OK) return rc;
+        } else {
+            const int r = linger_prepare_post(w, plan);
+            if (r < 0) return r;
+            if (r == 1) {
+                const bool has_upd = w->d.upd != nullptr;
+                if (has_upd) memcpy(linger_upd_slot(w, w->launch_seq + 1ull), w->upd_host, 4 * (size_t)w->d.R_local * sizeof(double));
+                (void)linger_post(w, plan, has_upd, w->d.upd_max_speed, w->d.upd_delta_t);
+                return 1;
+            }
+        }
+    }
     if (!resident_enabled() || w->resident_off || plan.size() < 2) return 0;
     int rc = commit(w);
     if (rc != MGX_OK) return rc;
@@ -1760,6 +2021,20 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
             sp.census_ticks = sharded ? census_ticks_sharded : census_ticks;
             if (ranks_agree) sp.agree_seq = ++w->xres.agree_seq;
         }
+        // Lingering (mgx_dev.h): the launch that runs the END of the schedule stays for the schedules that follow — when the caller's
+        // pattern promises some (schedules back to back, or no evidence yet that they are not: two lingering launches in a row that
+        // ended without a post switch it off until schedules come back to back again)
+        if (census && can && !sharded && i0 + (size_t)MAX_SEGS >= plan.size() && linger_ticks(w) > 0 &&
+            (w->linger.useless < 2 || w->linger.streak >= 2)) {
+            if ((rc = ensure_linger_box(w)) != MGX_OK) return rc;
+            void *bd = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&bd, w->linger.box, 0));
+            sp.linger_ticks = linger_ticks(w);
+            sp.linger_box = (const LingerBox *)bd;
+            sp.linger_upd = reinterpret_cast<const double *>(reinterpret_cast<const char *>(bd) + sizeof(LingerBox));
+            sp.linger_upd_stride = (unsigned long long)w->linger.upd_stride;
+            sp.linger_go = w->linger.go.p;
+        }
         if (sharded && sp.ext[0]) {  // segment 0 reads the ghosts' plain copies: one direct exchange in front of the launch
             rc = direct_exchange(w);
             if (rc != MGX_OK) return rc;
@@ -1780,6 +2055,14 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
         }
         w->last_sweep_launches++;
         w->resident_launches++;
+        if (sp.linger_ticks > 0) {
+            mgx_world::Linger &lg = w->linger;
+            lg.open = true;
+            lg.seq0 = sp.launch_seq;
+            lg.taken_in_launch = 0;
+            lg.un.active = false;
+            lg.launches++;
+        }
         if (census) {  // what confirm_resident needs to take the launch back and run it again launch by launch
             mgx_world::PendingResident &pd = w->pending;
             pd.active = true;
@@ -1837,7 +2120,10 @@ int mgx_world_create(const mgx_params *params, mgx_world **out) {
 
 int mgx_world_destroy(mgx_world *w) {
     if (!w) return MGX_OK;
+    w->batch.steps.clear();
+    if (w->linger.open) (void)linger_close(w);  // (nobody is left to post: the launch would wait out its bound)
     if (w->dev_valid) (void)hipStreamSynchronize(w->stream);
+    if (w->linger.box) (void)hipHostFree(w->linger.box);
     if (w->rccl.comm && g_rccl.ok) (void)g_rccl.comm_destroy(w->rccl.comm);
     if (w->direct.recv) (void)hipFree(w->direct.recv);
     if (w->direct.flags) (void)hipFree(w->direct.flags);
@@ -1866,6 +2152,32 @@ int mgx_synchronize(mgx_world *w) {
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     HIP_TRY(hipStreamSynchronize(w->stream));
     return check_device_error(w);
+}
+
+// Everything issued so far is ENQUEUED: recorded schedules are submitted and a lingering launch is told to end (it writes back and
+// leaves the stream to what the caller puts behind it) — without waiting for the stream.
+int mgx_flush(mgx_world *w) {
+    MGX_ENTER(w);
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    return MGX_OK;
+}
+int mgx_set_linger(mgx_world *w, int32_t microseconds) {
+    MGX_ENTER(w);
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    w->linger.ticks = -1;
+    if (microseconds >= 0) w->linger.ticks = (long long)std::min(microseconds, 1000000) * 100ll;
+    w->linger.useless = 0;
+    return MGX_OK;
+}
+int mgx_linger_stats(mgx_world *w, uint64_t *launches, uint64_t *posts, uint64_t *reruns, uint64_t *ended_by_device) {
+    MGX_ENTER_SCHEDULE(w);
+    if (!w) return fail(MGX_ERR_INVALID, "null world");
+    const mgx_world::Linger &lg = w->linger;
+    if (launches) *launches = lg.launches;
+    if (posts) *posts = lg.posts + (lg.un.active ? 1u : 0u);
+    if (reruns) *reruns = lg.reruns;
+    if (ended_by_device) *ended_by_device = lg.ended_by_device;
+    return MGX_OK;
 }
 
 int mgx_world_set_sdf(mgx_world *w, const uint8_t *rgb, uint32_t width, uint32_t height, double world_w, double world_h) {
@@ -2995,8 +3307,14 @@ int mgx_iterate(mgx_world *w, const uint8_t *steps, uint32_t n) {
 
 static int iterate_now(mgx_world *w, const uint8_t *steps, uint32_t n) {
     const std::vector<Launch> plan = plan_launches(steps, n);
-    if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }  // (a declined launch is run again here: not this call's launches)
+    if (w->pending.active) {  // (a declined launch is run again here: not this call's launches)
+        w->linger.hold = true;
+        const int rcc = confirm_resident(w);
+        w->linger.hold = false;
+        if (rcc != MGX_OK) return rcc;
+    }
     w->last_sweep_launches = 0;
+    w->linger.streak++;  // (every other entry point resets it: MGX_ENTER)
     const int resident = run_resident(w, plan);
     if (resident != 0) return resident < 0 ? resident : MGX_OK;
     for (const Launch &l : plan) {
@@ -3096,28 +3414,44 @@ int mgx_update_priors(mgx_world *w, uint32_t n, const int32_t *robots, const dou
 // through HBM.  Otherwise (or while factors are thawing) this is mgx_update_priors followed by mgx_iterate.
 int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *waypoints_xy, const double *time_scale,
              const uint8_t *what, double max_speed, double delta_t, const uint8_t *steps, uint32_t n_steps) {
-    MGX_ENTER(w);
+    MGX_ENTER_SCHEDULE(w);
     if (!w || (!steps && n_steps) || (n && (!robots || !waypoints_xy || !time_scale || !what))) return fail(MGX_ERR_INVALID, "null argument");
     const std::vector<Launch> plan = plan_launches(steps, n_steps);
-    if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }  // (a declined launch is run again here: not this call's launches)
+    if (w->pending.active) {  // (a declined launch is run again here: not this call's launches)
+        w->linger.hold = true;
+        const int rcc = confirm_resident(w);
+        w->linger.hold = false;
+        if (rcc != MGX_OK) return rcc;
+    }
     w->last_sweep_launches = 0;
     const bool fuse = n > 0 && !plan.empty() && plan[0].ext == 0 && plan[0].n_int > 0 && w->thaw_kinds == 0 && w->K >= 3;
     if (!fuse) {
-        int rc = mgx_update_priors(w, n, robots, waypoints_xy, time_scale, what, max_speed, delta_t);
+        const int rc = n ? mgx_update_priors(w, n, robots, waypoints_xy, time_scale, what, max_speed, delta_t) : MGX_OK;
         return rc != MGX_OK ? rc : iterate_now(w, steps, n_steps);
     }
     for (uint32_t i = 0; i < n; i++)  // (the robots' ghost / removed flags from their compact copies)
         if (robots[i] < 0 || (size_t)robots[i] >= w->robots.size() || w->sets.ghost[(size_t)robots[i]] || w->sets.removed[(size_t)robots[i]] || (what[i] & ~3u))
             return fail(MGX_ERR_INVALID, "bad entry %u", i);
     StageTimer tmk("tick");
+    w->linger.hold = true;  // (a lingering launch stays: this tick is posted into it if it qualifies)
     int rc = commit(w);
+    w->linger.hold = false;
     tmk.lap("commit (confirm + table rebuild)");
     if (rc != MGX_OK) return rc;
     const size_t RL = (size_t)w->d.R_local;
     void *hp = nullptr, *dp = nullptr;
     int slot = 0;
-    HIP_TRY(w->stage.acquire(4 * RL * sizeof(double), &hp, &slot));
-    double *rec = (double *)hp;
+    // a launch lingers and takes this tick: the records go straight into the coming number's slot of its box (the pinned ring's
+    // slots are guarded by events, and an event behind a launch that lingers does not complete)
+    int posting = 0;
+    if (w->linger.open && (posting = linger_prepare_post(w, plan)) < 0) return posting;
+    double *rec = nullptr;
+    if (posting) {
+        rec = linger_upd_slot(w, w->launch_seq + 1ull);
+    } else {
+        HIP_TRY(w->stage.acquire(4 * RL * sizeof(double), &hp, &slot));
+        rec = (double *)hp;
+    }
     std::fill(rec, rec + 4 * RL, 0.0);
     for (uint32_t i = 0; i < n; i++) {
         double *q = rec + 4 * (size_t)w->dev_of[(size_t)robots[i]];
@@ -3125,13 +3459,21 @@ int mgx_tick(mgx_world *w, uint32_t n, const int32_t *robots, const double *wayp
         if (what[i] & 1u) log_change_prior(w, robots[i], w->K - 1);
         if (what[i] & 2u) log_change_prior(w, robots[i], 0);
     }
+    w->linger.streak++;  // (every other entry point resets it: MGX_ENTER)
+    if (posting) {
+        (void)linger_post(w, plan, true, max_speed, delta_t);
+        tmk.lap("update records + counter log + post");
+        return MGX_OK;
+    }
     HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
     w->stale_kinds |= ~w->p.enable_mask & 15u;
     tmk.lap("update records + counter log");
     {   // the whole tick as one resident launch when the world qualifies: the prior updates ride in it all the same
         w->d.upd = (const double *)dp; w->d.upd_max_speed = max_speed; w->d.upd_delta_t = delta_t;
         w->upd_ring_slot = slot;
+        w->upd_host = rec;
         const int resident = run_resident(w, plan);
+        w->upd_host = nullptr;
         w->upd_ring_slot = -1;
         tmk.lap("resident launch enqueued");
         if (resident != 0) {
@@ -3246,7 +3588,7 @@ int mgx_is_thawing(mgx_world *w, int32_t *thawing) {
     return MGX_OK;
 }
 int mgx_last_launch_count(mgx_world *w, uint32_t *n_launches) {
-    MGX_ENTER(w);
+    MGX_ENTER_SCHEDULE(w);
     if (!w || !n_launches) return fail(MGX_ERR_INVALID, "null argument");
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     *n_launches = w->last_sweep_launches;
@@ -4228,7 +4570,7 @@ int mgx_resident_ready(mgx_world *w, const uint8_t *steps, uint32_t n, int32_t *
 }
 
 int mgx_resident_stats(mgx_world *w, uint64_t *launches, uint64_t *declined, uint32_t *backoff) {
-    MGX_ENTER(w);
+    MGX_ENTER_SCHEDULE(w);
     if (!w) return fail(MGX_ERR_INVALID, "null world");
     if (w->pending.active) { const int rcc = confirm_resident(w); if (rcc != MGX_OK) return rcc; }
     if (launches) *launches = w->resident_launches;

@@ -188,6 +188,9 @@ SYMBOLS = {
     "mgx_mission_read": (C.c_int, [_V, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_num_robots": (C.c_int, [_V, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mgx_last_launch_count": (C.c_int, [_V, C.POINTER(C.c_uint32)]),
+    "mgx_flush": (C.c_int, [_V]),
+    "mgx_set_linger": (C.c_int, [_V, C.c_int32]),
+    "mgx_linger_stats": (C.c_int, [_V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mgx_set_resident_launches": (C.c_int, [_V, C.c_int32]),
     "mgx_is_thawing": (C.c_int, [_V, C.POINTER(C.c_int32)]),
     "mgx_halo_words": (C.c_uint32, [C.c_uint32]),

@@ -68,6 +68,20 @@ class World:
     def synchronize(self):
         self._chk(self._L.mgx_synchronize(self._w))
 
+    def flush(self):
+        """everything issued so far is enqueued: a batch is submitted, a lingering launch told to end — no wait (mgx_flush)"""
+        self._chk(self._L.mgx_flush(self._w))
+
+    def set_linger(self, microseconds):
+        """how long a resident launch waits for the next schedule before it ends (0: never; None: the default) — mgx_set_linger"""
+        self._chk(self._L.mgx_set_linger(self._w, -1 if microseconds is None else int(microseconds)))
+
+    def linger_stats(self):
+        """(launches that lingered, schedules posted into them, posts taken back and re-run, launches that ended by themselves)"""
+        v = [C.c_uint64() for _ in range(4)]
+        self._chk(self._L.mgx_linger_stats(self._w, *[C.byref(x) for x in v]))
+        return tuple(int(x.value) for x in v)
+
     # -- topology --------------------------------------------------------------------------
     def set_sdf(self, rgb, world_w, world_h):
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)

@@ -113,6 +113,14 @@ impl World {
         check(unsafe { sys::mgx_last_launch_count(self.raw, &mut n) })?;
         Ok(n)
     }
+    /// Everything issued so far is enqueued: a lingering launch is told to end, without waiting for the stream.
+    pub fn flush(&self) -> Result<(), MgxError> {
+        check(unsafe { sys::mgx_flush(self.raw) })
+    }
+    /// How long a resident launch waits for the next schedule before it ends (microseconds; 0: never, negative: the default).
+    pub fn set_linger(&self, microseconds: i32) -> Result<(), MgxError> {
+        check(unsafe { sys::mgx_set_linger(self.raw, microseconds) })
+    }
     /// (resident launches so far, those declined before they wrote anything, what is left of the back-off)
     pub fn resident_stats(&self) -> Result<(u64, u64, u32), MgxError> {
         let (mut launches, mut declined, mut backoff) = (0u64, 0u64, 0u32);

@@ -119,6 +119,9 @@ extern "C" {
     pub fn mgx_batch_begin(w: *mut mgx_world) -> c_int;
     pub fn mgx_batch_end(w: *mut mgx_world, n_schedules: *mut u32, n_launches: *mut u32) -> c_int;
     pub fn mgx_last_launch_count(w: *mut mgx_world, n_launches: *mut u32) -> c_int;
+    pub fn mgx_flush(w: *mut mgx_world) -> c_int;
+    pub fn mgx_set_linger(w: *mut mgx_world, microseconds: i32) -> c_int;
+    pub fn mgx_linger_stats(w: *mut mgx_world, launches: *mut u64, posts: *mut u64, reruns: *mut u64, ended_by_device: *mut u64) -> c_int;
     pub fn mgx_set_resident_launches(w: *mut mgx_world, enabled: i32) -> c_int;
     pub fn mgx_is_thawing(w: *mut mgx_world, thawing: *mut i32) -> c_int;
     pub fn mgx_sweep(w: *mut mgx_world, robot: i32, external_phases: u32, internal_phases: u32, n_internal: u32, hints: u32) -> c_int;
