@@ -4546,7 +4546,7 @@ int mgx_halo_resident_disconnect(mgx_world *w) {
 }
 
 int mgx_resident_outcome(mgx_world *w, int32_t *outcome) {
-    MGX_ENTER(w);
+    MGX_ENTER_SCHEDULE(w);  // (a query: a launch that lingers stays — and its verdict is still there to be asked for)
     if (!w || !outcome) return fail(MGX_ERR_INVALID, "null argument");
     return confirm_resident(w, false, outcome);
 }
