@@ -257,12 +257,13 @@ constexpr int MAX_SEGS = 32;
 // bounded time — for the host to POST the next plan, or for the word to leave.
 //   * The host writes a post (plan + the tick's prior-update records) into one of two slots of a host-mapped box and raises
 //     `posted`; numbers are the world's launch numbers (monotonic, every post and every fresh launch takes one).
-//   * The launch's extra workgroup (the census' decider, kept alive) is the only poller of the box: it turns `posted` into the
-//     launch's device-side GO WORD (2 S: plan S may be run; 2 S + 1: the launch ends behind plan S) by compare-and-swap, reports
-//     what the robots have picked up (`consumed`, for the slots' reuse) and what was `taken`, and turns the word odd on the host's
-//     request (`close_req`: every other entry point of the C ABI asks for it first).
+//   * The launch's extra workgroup (the census' decider, kept alive) is the only poller of the box — and its only reader: it copies
+//     a post into the launch's device-side slot (not before every robot has picked up the post two before it, whose slot that was),
+//     turns `posted` into the launch's GO WORD (2 S: plan S may be run; 2 S + 1: the launch ends behind plan S) by compare-and-swap,
+//     says what was `taken` (the host may write that slot of the box again), and turns the word odd on the host's request
+//     (`close_req`: every other entry point of the C ABI asks for it first).
 //   * A robot's workgroup that has finished plan S polls the go word (device memory); 2 S + 2 or more: it reads plan S + 1 and its
-//     prior updates from the box and goes on where it stands — parities and sequence numbers of the exchange records run on over
+//     prior updates from the device-side slot and goes on where it stands — parities and sequence numbers of the exchange records run on over
 //     the plans (the first segment of a posted plan continues the last segment of the plan before: posts open with an internal
 //     iteration); exactly 2 S + 1: it writes back and returns, as every launch does.  A workgroup that has waited `linger_ticks`
 //     raises the word to 2 S + 1 itself (atomic max: whoever moves first decides for all) — a host that died or went elsewhere
@@ -279,7 +280,7 @@ struct LingerBox {  // host-mapped
     unsigned long long posted;     // host -> device: number of the newest post
     unsigned long long close_req;  // host -> device: the launch numbered at most this is asked to end
     unsigned long long taken;      // device -> host: newest post the go word covers
-    unsigned long long consumed;   // device -> host: every robot has picked up the plan of this number (its slot may be written again)
+    unsigned long long reserved;
     unsigned long long closed;     // device -> host: the go word as it stands once it is odd (2 S + 1: the launch ended behind plan S)
     unsigned long long pad[3];
     LingerPlan plan[2];            // slot = number & 1; the prior-update records follow the box: double upd[2][4 * R_cap]
@@ -309,8 +310,10 @@ struct SegPlan {
     // ends with its plan), the box, its prior-update records and the go word.  launch_seq is the number of the launch's own plan.
     long long linger_ticks;
     const LingerBox *linger_box;       // host-mapped
-    const double *linger_upd;          // host-mapped [2][4 * linger_upd_stride / 4 ...]: slot s at linger_upd + s * linger_upd_stride
+    const double *linger_upd;          // host-mapped, behind the box: slot s of prior-update records at linger_upd + s * linger_upd_stride (f64 words)
     unsigned long long linger_upd_stride;
+    unsigned char *linger_dev;         // device memory: slot s at linger_dev + s * linger_dev_stride — the plan (128 bytes), then its records
+    unsigned long long linger_dev_stride;
     unsigned long long *linger_go;     // device memory
 };
 constexpr unsigned RESIDENT_GO = 1u, RESIDENT_ABORT = 2u;

@@ -402,12 +402,12 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         }
         if constexpr (LINGER) {
             // A LINGERING launch (mgx_dev.h): this workgroup stays as the launch's postman — the only poller of the host-mapped box.
-            // Every round: how far the robots' workgroups have come (their census words hold the number of the plan they picked up
-            // last: `consumed` tells the host which slot it may write again), then one move on the go word at most — a new post
-            // raises it (2 S: plan S may be run), the host's request to end turns it odd behind everything posted (2 S + 1); a
-            // robot's workgroup that waited out its bound has turned it odd itself.  Every move is a compare-and-swap from the
-            // value just read, so the word is decided once for everybody.  Ends when the word is odd: no bound of its own is
-            // needed — the robots' waits are all bounded, and the last of them ends the launch.
+            // Every round one look at the box and at most one move on the go word: a new post is COPIED into the launch's device-side
+            // slot (a thousand workgroups reading host memory over PCIe cost more than the tick they saved) and then raises the word
+            // (2 S: plan S may be run); the host's request to end turns it odd behind everything posted (2 S + 1); a robot's
+            // workgroup that waited out its bound has turned it odd itself.  Every move is a compare-and-swap from the value just
+            // read, so the word is decided once for everybody.  Ends when the word is odd: no bound of its own is needed — the
+            // robots' waits are all bounded, and the last of them ends the launch.
             int lingers = 0;
             if (threadIdx.x == 0) {
                 const unsigned long long v = __hip_atomic_load(cold0().decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -415,37 +415,82 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                 if (lingers) __hip_atomic_fetch_max(cold_plan0().linger_go, 2ull * seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (__syncthreads_or(lingers)) {
-                unsigned long long consumed = seq;  // (every thread keeps the same count: it moves on the barriers' verdicts)
+                unsigned long long consumed = seq;  // every robot's workgroup has picked up the plan of this number (every thread keeps the same count)
                 for (;;) {
-                    int lag = 0;
-                    for (unsigned b2 = threadIdx.x; b2 + 1 < gridDim.x; b2 += NT)
-                        lag |= __hip_atomic_load(&cold0().census[b2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < consumed + 1ull ? 1 : 0;
-                    const bool all = __syncthreads_or(lag) == 0;
-                    if (all) consumed += 1ull;
-                    int over = 0;
+                    // one look at the box and the word (thread 0), handed to everybody through LDS
+                    unsigned long long *sh = reinterpret_cast<unsigned long long *>(lds + 32);  // [0] the go word, [1] the newest post
                     if (threadIdx.x == 0) {
-                        LingerBox *box = const_cast<LingerBox *>(cold_plan0().linger_box);
-                        unsigned long long *go = cold_plan0().linger_go;
-                        if (all) __hip_atomic_store(&box->consumed, consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        unsigned long long g = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const LingerBox *box = cold_plan0().linger_box;
+                        unsigned long long g = __hip_atomic_load(cold_plan0().linger_go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (!(g & 1ull)) {
                             const unsigned long long posted = __hip_atomic_load(&box->posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             const unsigned long long creq = __hip_atomic_load(&box->close_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            if (posted > (g >> 1)) {
-                                if (__hip_atomic_compare_exchange_strong(go, &g, 2ull * posted, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                                    __hip_atomic_store(&box->taken, posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                    g = 2ull * posted;
-                                }  // (lost: a robot's workgroup has ended the launch — g holds the odd word now)
-                            } else if (creq >= seq) {
-                                if (__hip_atomic_compare_exchange_strong(go, &g, g + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) g += 1ull;
+                            sh[1] = posted;
+                            if (posted <= (g >> 1) && creq >= seq) {  // asked to end — behind everything posted
+                                if (__hip_atomic_compare_exchange_strong(cold_plan0().linger_go, &g, g + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) g += 1ull;
                             }
                         }
-                        if (g & 1ull) {
-                            __hip_atomic_store(&box->closed, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            over = 1;
+                        if (g & 1ull) __hip_atomic_store(const_cast<unsigned long long *>(&box->closed), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        sh[0] = g;
+                    }
+                    __syncthreads();
+                    const unsigned long long g = sh[0], next = (g >> 1) + 1ull;
+                    const bool pending_post = !(g & 1ull) && sh[1] >= next;
+                    __syncthreads();
+                    if (g & 1ull) break;
+                    if (pending_post) {
+                        // Post `next` goes from the box (host memory: ONE reader, wide loads) into the launch's device-side slot
+                        // next & 1 — which held post next - 2: not before every robot's workgroup has picked that one up (their
+                        // census words hold the number of the plan they picked up last).
+                        bool free_slot = consumed + 2ull >= next;
+                        while (!free_slot) {
+                            int lag = 0;
+                            for (unsigned b2 = threadIdx.x; b2 + 1 < gridDim.x; b2 += NT)
+                                lag |= __hip_atomic_load(&cold0().census[b2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < consumed + 1ull ? 1 : 0;
+                            if (__syncthreads_or(lag)) break;  // (not yet: look at the box and the word again first)
+                            consumed += 1ull;
+                            free_slot = consumed + 2ull >= next;
+                        }
+                        if (free_slot) {
+                            const unsigned slot = (unsigned)(next & 1ull);
+                            const LingerBox *box = cold_plan0().linger_box;
+                            unsigned char *dst = cold_plan0().linger_dev + (size_t)slot * cold_plan0().linger_dev_stride;
+                            const uint32_t *ps = reinterpret_cast<const uint32_t *>(&box->plan[slot]);
+                            uint32_t has_upd = 0u;
+                            if (threadIdx.x < LINGER_PLAN_DWORDS) {
+                                const uint32_t v = __hip_atomic_load(ps + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                __hip_atomic_store(reinterpret_cast<uint32_t *>(dst) + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (threadIdx.x == 1) has_upd = v;
+                            }
+                            if (__syncthreads_or((int)has_upd)) {  // the tick's prior-update records: 32 bytes per robot
+                                const v4u32 *src = reinterpret_cast<const v4u32 *>(cold_plan0().linger_upd + (size_t)slot * cold_plan0().linger_upd_stride);
+                                const unsigned n16 = 2u * (unsigned)(gridDim.x - 1);
+                                const __amdgpu_buffer_rsrc_t rs_d = sc1_rsrc(dst + 128, n16 * 16u);
+                                for (unsigned i0 = 0; i0 < n16; i0 += 4u * NT) {
+                                    v4u32 v[4];
+#pragma unroll
+                                    for (int u = 0; u < 4; u++) {
+                                        const unsigned i = i0 + (unsigned)u * NT + threadIdx.x;
+                                        v[u] = i < n16 ? __builtin_nontemporal_load(src + i) : v4u32{0u, 0u, 0u, 0u};
+                                    }
+#pragma unroll
+                                    for (int u = 0; u < 4; u++) {
+                                        const unsigned i = i0 + (unsigned)u * NT + threadIdx.x;
+                                        if (i < n16) __builtin_amdgcn_raw_buffer_store_b128(v[u], rs_d, (int)(16u * i), 0, 16);
+                                    }
+                                }
+                            }
+                            __threadfence();  // (every storing wave drains; one lane moves the word behind the barrier)
+                            __syncthreads();
+                            if (threadIdx.x == 0) {
+                                unsigned long long e = g;
+                                if (__hip_atomic_compare_exchange_strong(cold_plan0().linger_go, &e, 2ull * next, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                    __hip_atomic_store(const_cast<unsigned long long *>(&box->taken), next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                // (lost: a robot's workgroup has ended the launch — the next look finds the word odd)
+                            }
+                            continue;
                         }
                     }
-                    if (__syncthreads_or(over)) break;
                     __builtin_amdgcn_s_sleep(12);
                 }
             }
@@ -2041,15 +2086,15 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                     const unsigned long long number = cold_plan().launch_seq + (unsigned long long)plans_done;
                     const unsigned slot = (unsigned)(number & 1ull);
                     int bad = 0;  // the slot holds another post than the go word promised (every workgroup reads the same slot: all of them leave)
+                    const unsigned char *dslot = cold_plan().linger_dev + (size_t)slot * cold_plan().linger_dev_stride;  // (device memory: the postman's copy)
                     if (tid < LINGER_PLAN_DWORDS) {
-                        const uint32_t *src = reinterpret_cast<const uint32_t *>(&cold_plan().linger_box->plan[slot]);
-                        const uint32_t v = __hip_atomic_load(src + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        const uint32_t v = __hip_atomic_load(reinterpret_cast<const uint32_t *>(dslot) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         s_plan[tid] = v;
                         if (tid == LINGER_PLAN_DWORDS - 2) bad = v != (uint32_t)(number & 0xffffffffull);
                         if (tid == LINGER_PLAN_DWORDS - 1) bad = v != (uint32_t)(number >> 32);
                     } else if (tid < LINGER_PLAN_DWORDS + 4) {
-                        const double *src = cold_plan().linger_upd + (size_t)slot * cold_plan().linger_upd_stride + (size_t)r * 4;
-                        s_urec[tid - LINGER_PLAN_DWORDS] = __hip_atomic_load(src + (tid - LINGER_PLAN_DWORDS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        const double *src = reinterpret_cast<const double *>(dslot + 128) + (size_t)r * 4;
+                        s_urec[tid - LINGER_PLAN_DWORDS] = __hip_atomic_load(src + (tid - LINGER_PLAN_DWORDS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     if (__syncthreads_or(bad)) {  // (nothing of the unread plan is run; the tail writes back what the plan before left; the host reports it)
                         if (tid == 0) {  // (the word odd, whatever it holds: the postman ends with it)

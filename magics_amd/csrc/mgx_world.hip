@@ -458,6 +458,8 @@ struct mgx_world {
         LingerBox *box = nullptr;
         size_t upd_stride = 0;  // f64 words per slot of prior-update records behind the box
         DevBuf<unsigned long long> go;
+        DevBuf<unsigned char> dev;  // the launch's device-side slots (the postman's copies of the posts): [2][dev_stride]
+        size_t dev_stride = 0;
         bool open = false, hold = false;
         unsigned long long seq0 = 0;       // number of the open launch's own plan
         uint32_t taken_in_launch = 0;      // posts the open launch has taken
@@ -1760,10 +1762,15 @@ static int ensure_linger_box(mgx_world *w) {
     }
     if (lg.box && lg.upd_stride >= stride) return MGX_OK;
     if (lg.box) { (void)hipHostFree(lg.box); lg.box = nullptr; }
-    const size_t grown = stride + stride / 2, bytes = sizeof(LingerBox) + 2 * grown * sizeof(double);
+    const size_t grown = (stride + stride / 2 + 7) & ~(size_t)7, bytes = sizeof(LingerBox) + 2 * grown * sizeof(double);
     HIP_TRY(hipHostMalloc((void **)&lg.box, bytes, hipHostMallocMapped));
     memset(lg.box, 0, bytes);
     lg.upd_stride = grown;
+    lg.dev_stride = 128 + grown * sizeof(double);  // the plan (LingerPlan, padded), then the records
+    static_assert(sizeof(LingerPlan) <= 128, "a device-side slot keeps 128 bytes for the plan");
+    HIP_TRY(lg.dev.reserve(2 * lg.dev_stride));
+    HIP_TRY(hipMemsetAsync(lg.dev.p, 0, 2 * lg.dev_stride, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
     return MGX_OK;
 }
 // Spins (bounded) until `pred` holds: 0; or until the launch has ended (its go word went odd and the postman said so): 1.
@@ -1888,10 +1895,7 @@ static int linger_prepare_post(mgx_world *w, const std::vector<Launch> &plan) {
         r = linger_wait(w, [&] { return __atomic_load_n(&lg.box->taken, __ATOMIC_ACQUIRE) >= n; }, "the last post to be taken");
         if (r == 0) linger_confirm(w);
     }
-    if (r == 0) {  // the slot of the coming number held the post two before it: has every workgroup read that one?
-        const unsigned long long P = w->launch_seq + 1ull;
-        if (P >= lg.seq0 + 3ull) r = linger_wait(w, [&] { return __atomic_load_n(&lg.box->consumed, __ATOMIC_ACQUIRE) + 2ull >= P; }, "the robots to pick up the plan two before");
-    }
+    // (the box's slot of the coming number held the post two before it, which the postman has copied to the device: `taken`)
     if (r < 0) return r;
     if (r == 1) {  // the launch ended meanwhile (its workgroups waited out their bound)
         lg.ended_by_device++;
@@ -2033,6 +2037,8 @@ static int run_resident(mgx_world *w, const std::vector<Launch> &plan) {
             sp.linger_box = (const LingerBox *)bd;
             sp.linger_upd = reinterpret_cast<const double *>(reinterpret_cast<const char *>(bd) + sizeof(LingerBox));
             sp.linger_upd_stride = (unsigned long long)w->linger.upd_stride;
+            sp.linger_dev = w->linger.dev.p;
+            sp.linger_dev_stride = (unsigned long long)w->linger.dev_stride;
             sp.linger_go = w->linger.go.p;
         }
         if (sharded && sp.ext[0]) {  // segment 0 reads the ghosts' plain copies: one direct exchange in front of the launch
