@@ -49,9 +49,9 @@ def parse():
     ap.add_argument("--preheat-ms", type=float, default=60.0, help="untimed work in front of the repetitions (clock ramp)")
     ap.add_argument("--robots-per-gpu", type=int, default=1000)
     ap.add_argument("--horizon", type=int, default=16)
-    ap.add_argument("--ticks-per-submission", type=int, default=2,
-                    help="ticks (10-step schedules) handed to the engine per submission (mgx_batch_begin / _end: the engine merges them into "
-                         "one resident launch); 1 = one submission per tick, no batch")
+    ap.add_argument("--ticks-per-submission", type=int, default=1,
+                    help="1 (default) = the reference's call pattern: one mgx_iterate per tick, nothing bracketed — schedules issued back to "
+                         "back ride in one lingering launch by themselves; > 1: that many ticks handed over inside mgx_batch_begin / _end")
     ap.add_argument("--no-configs1", action="store_true", help="skip the BASELINE configs[1] block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the tick / dynamic_tick / scenario measurements")
@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--deadline", type=float, default=150.0,
                     help="N > 1 only: seconds a phase with collectives may take before the run is abandoned (non-zero exit)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--sustained-seconds", type=float, default=2.0,
+    ap.add_argument("--sustained-seconds", type=float, default=10.0,
                     help="length of the sustained run of the headline workload behind the repetitions (0: skip)")
     ap.add_argument("--fma", action="store_true", help="use the FMA-contracting build (not the product)")
     ap.add_argument("--no-resident", action="store_true", help="N > 1: keep the direct transport on its push / wait kernels (no resident launches)")
@@ -96,11 +96,14 @@ def run_steps(iterate, n, steps_one_tick, batch=None, group=1):
     return launches
 
 
-def timed(torch, dist, iterate, steps_one_tick, a, multi, red_dev="cuda", sync=None, batch=None, group=1):
+def timed(torch, dist, iterate, steps_one_tick, a, multi, red_dev="cuda", sync=None, batch=None, group=1, flush=None):
     """The contract's measurement, repeated: W warm-up steps, a pre-heat, then `repeats` x [barrier + synchronize,
     EXACTLY K steps, barrier + synchronize].  Returns per-repetition (wall seconds MAX over ranks, device seconds
-    between HIP events on the launch stream MAX over ranks)."""
+    between HIP events on the launch stream MAX over ranks).
+    sync: the world's own synchronize (mgx_synchronize: a launch that lingers for the next schedule is told to end first — waiting
+    on the stream by other means would wait out its bound); flush: the same without the wait, in front of the closing event."""
     sync = sync or torch.cuda.synchronize
+    flush = flush or (lambda: None)
     run_steps(iterate, a.warmup, steps_one_tick, batch, group)
     sync()
     t_end = time.perf_counter() + a.preheat_ms * 1e-3
@@ -123,6 +126,7 @@ def timed(torch, dist, iterate, steps_one_tick, a, multi, red_dev="cuda", sync=N
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         run_steps(iterate, a.steps, steps_one_tick, batch, group)
+        flush()
         ev1.record()
         sync()
         devs.append(ev0.elapsed_time(ev1) * 1e-3)
@@ -635,7 +639,8 @@ def main():
         w1 = World(sc1["params"], stream=stream, fma=a.fma)
         S.populate(w1, sc1)
         assert len(sc1["steps"]) == SCHEDULE_LEN
-        walls, devs = timed(torch, dist, w1.iterate, sc1["steps"], a, multi, red_dev, batch=w1.batch, group=a.ticks_per_submission)
+        walls, devs = timed(torch, dist, w1.iterate, sc1["steps"], a, multi, red_dev, sync=w1.synchronize, batch=w1.batch, group=a.ticks_per_submission,
+                            flush=w1.flush)
         r1 = summary(walls, devs, a.steps, units_per_step=world_size)
         bytes1 = S.algorithmic_bytes_per_robot_iter(K, 0.0) * n_loc
         # launches of the timed K-step block: as the engine counted them for the same block, issued once more
@@ -697,22 +702,42 @@ def main():
         probe_ok = flag[0]
 
     G = a.ticks_per_submission
-    walls, devs = timed(torch, dist, sw.iterate, sc2["steps"], a, multi, red_dev, batch=sw.batch, group=G)
+    walls, devs = timed(torch, dist, sw.iterate, sc2["steps"], a, multi, red_dev, sync=sw.synchronize, batch=sw.batch, group=G, flush=sw.flush)
     sw.iterate(sc2["steps"])
-    resident = sw.world.last_launch_count() == 1  # the engine ran the 10-step schedule as ONE resident launch
-    head_launches = run_steps(sw.iterate, a.steps, sc2["steps"], sw.batch, G)  # (the timed block once more: launches as the engine counted them)
+    resident = sw.world.last_launch_count() == 1  # the engine ran the 10-step schedule as ONE resident launch (or posted it into one)
+    sw.synchronize()
+    # the timed block once more, counted: sweep-kernel launches (a schedule POSTED into a lingering launch is no launch)
+    res0 = int(sw.world.resident_stats()[0])
+    head_launches = run_steps(sw.iterate, a.steps, sc2["steps"], sw.batch, G)
+    sw.flush()
+    if resident:
+        head_launches = int(sw.world.resident_stats()[0]) - res0
+    lst = [int(x) for x in sw.world.linger_stats()] if hasattr(sw.world, "linger_stats") else None
     r2 = summary(walls, devs, a.steps, units_per_step=world_size)
-    per_tick = None
+    per_tick, variants = None, {}
     a_warm = argparse.Namespace(**{**vars(a), "preheat_ms": 0.0})  # (clocks are up: a second timed pass needs no pre-heat of its own)
-    if G > 1 and not multi and not a.no_extras:  # the same workload, one submission per tick (every tick its own launch): what the merge is worth
-        walls_t, devs_t = timed(torch, dist, sw.iterate, sc2["steps"], a_warm, multi, red_dev)
+    if G > 1:  # the same workload, one submission per tick — always beside a batched headline
+        walls_t, devs_t = timed(torch, dist, sw.iterate, sc2["steps"], a_warm, multi, red_dev, sync=sw.synchronize, flush=sw.flush)
         rt = summary(walls_t, devs_t, a.steps, units_per_step=world_size)
         per_tick = {"value": round(rt["value"], 2), "ms_per_step": rt["ms_per_step"], "device_ms_per_step": rt["device_ms_per_step"],
-                    "what": "the same workload without mgx_batch_*: every 10-step tick submitted (and launched) by itself"}
+                    "what": "the same workload without mgx_batch_*: every 10-step tick its own mgx_iterate call, nothing bracketed"}
+    elif not multi and not a.no_extras:
+        # what the two ways of keeping the graphs in LDS across ticks are worth, each against the same world: ticks bracketed two at
+        # a time (mgx_batch_*: round 4's headline), and lingering switched off (every tick a launch of its own)
+        walls_t, devs_t = timed(torch, dist, sw.iterate, sc2["steps"], a_warm, multi, red_dev, sync=sw.synchronize, batch=sw.batch, group=2, flush=sw.flush)
+        rt = summary(walls_t, devs_t, a.steps, units_per_step=world_size)
+        variants["two_ticks_per_batch"] = {"value": round(rt["value"], 2), "ms_per_step": rt["ms_per_step"], "device_ms_per_step": rt["device_ms_per_step"],
+                                           "what": "ticks handed over two at a time inside mgx_batch_begin / _end (merged into one launch)"}
+        sw.world.set_linger(0)
+        walls_t, devs_t = timed(torch, dist, sw.iterate, sc2["steps"], a_warm, multi, red_dev, sync=sw.synchronize, flush=sw.flush)
+        rt = summary(walls_t, devs_t, a.steps, units_per_step=world_size)
+        variants["launch_per_tick"] = {"value": round(rt["value"], 2), "ms_per_step": rt["ms_per_step"], "device_ms_per_step": rt["device_ms_per_step"],
+                                       "what": "mgx_set_linger(world, 0): every 10-step tick a resident launch of its own (graphs HBM -> LDS -> HBM per tick)"}
+        sw.world.set_linger(None)
     sustained_head = None
     if a.sustained_seconds > 0:
         sustained_head = sustained(torch, dist, sw.iterate, sc2["steps"], a.sustained_seconds, r2["ms_per_step"], multi, red_dev,
-                                   units_per_step=world_size, batch=sw.batch, group=G)
+                                   sync=sw.synchronize, units_per_step=world_size, batch=sw.batch, group=G)
     by_transport = {("one GPU, no exchange" if not multi else "collective"): round(r2["value"], 2)}
     transport = "none (one GPU)" if not multi else "collective (torch.distributed all_to_all_single over RCCL, host-driven)"
     sw.synchronize()
@@ -843,9 +868,20 @@ def main():
                           "what": ("every tick is one mgx_iterate call; the ticks are handed to the engine " + str(G) + " at a time inside mgx_batch_begin / "
                                    "mgx_batch_end, which submits them together — merged into one resident launch where their segments fit (the graphs "
                                    "go HBM -> LDS and back once per launch instead of once per tick); nothing is skipped or reordered, results are "
-                                   "bit-identical (tests/test_gpu_batch.py)") if G > 1 else "one submission (and one resident launch) per tick"}
+                                   "bit-identical (tests/test_gpu_batch.py)") if G > 1 else
+                                  "the reference's call pattern (robot.rs:85-108): one mgx_iterate call per 10-step tick, nothing bracketed.  Schedules "
+                                  "issued back to back are POSTED into the resident launch that is there (it lingers for them: the graphs stay in LDS "
+                                  "across the calls, include/mgx.h); the timed block's closing synchronisation ends the launch.  Bit-identical "
+                                  "(tests/test_gpu_linger.py)"}
+    if lst is not None and not multi:
+        line["submission"]["linger_stats"] = {"launches_that_lingered": lst[0], "schedules_posted": lst[1], "posts_rerun_as_launches": lst[2],
+                                              "launches_ended_by_device": lst[3]}
     if per_tick is not None:
         line["one_submission_per_tick"] = per_tick
+    elif G == 1:
+        line["one_submission_per_tick"] = {"value": round(head["value"], 2), "what": "the headline itself (ticks_per_submission = 1)"}
+    if variants:
+        line["variants"] = variants
     kernel = (("k_robot_sweep<16,2,true,shard>" if multi else "k_robot_sweep<16,2,true>") + " (whole schedule resident)") if resident else \
         "k_robot_sweep<16,2,false> (one iteration per launch)"
     line.update({
@@ -853,12 +889,13 @@ def main():
         "spread": head["spread"],
         "config": {"workload": f"BASELINE configs[{'2' if not multi else '3 layout'}]: synthetic {n_tot} robots x {K} horizon, dynamics + "
                                f"obstacle + inter-robot factors (comm radius 8, {D:.2f} neighbours/robot), seed 805, 10/10 schedule"
-                               + (f", {G} ticks per submission" if G > 1 else ""),
+                               + (f", {G} ticks per submission" if G > 1 else ", one mgx_iterate call per tick"),
                    "robots_per_gpu": n_loc, "horizon": K, "robots_total": n_tot,
                    "parallelism": (f"robots sharded over {world_size} GPUs in (y, x) strips, one exchange of boundary snapshot records "
                                    "per external iteration" + (", inside ONE resident launch per schedule and rank" if resident else "")) if multi else
-                                  (f"1 GPU: {G} ticks of the 10-step schedule are ONE resident launch" if G > 1 else "1 GPU: the 10-step schedule is "
-                                   "ONE resident launch") + ", neighbouring workgroups hand their snapshot records over inside it" if resident else "1 GPU",
+                                  (f"1 GPU: {G} ticks of the 10-step schedule are ONE resident launch" if G > 1 else "1 GPU: the ticks of a timed block "
+                                   "run in ONE resident launch (the first launches it, the others are posted into it)") +
+                                  ", neighbouring workgroups hand their snapshot records over inside it" if resident else "1 GPU",
                    "ghost_robots_this_rank": len(sw.plan.ghosts)},
         "roofline": roofline(kernel, bytes2 * it_per_launch, launches, head["device_s_median"],
                              ("config2_resident" if resident else "config2") if full_size else "", it_per_launch,
@@ -879,7 +916,7 @@ def main():
             w_seg = World(sc2["params"], stream=stream, fma=a.fma)
             S.populate(w_seg, sc2)
             w_seg.set_resident_launches(False)
-            walls_s, devs_s = timed(torch, dist, w_seg.iterate, sc2["steps"], a, False, red_dev)
+            walls_s, devs_s = timed(torch, dist, w_seg.iterate, sc2["steps"], a, False, red_dev, sync=w_seg.synchronize, flush=w_seg.flush)
             w_seg.iterate(sc2["steps"])
             rs = summary(walls_s, devs_s, a.steps)
             line["launch_per_segment"] = {"value": round(rs["value"], 2), "ms_per_step": rs["ms_per_step"], "device_ms_per_step": rs["device_ms_per_step"],
@@ -895,17 +932,34 @@ def main():
     if not multi and not a.no_extras:
         w = sw.world
         tk = S.tick_inputs(sc2)
-        n_ticks = max(20, a.steps // 10)
-        for _ in range(5):
-            w.tick(steps=sc2["steps"], **tk)
-        w.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n_ticks):
-            w.tick(steps=sc2["steps"], **tk)   # mgx_tick: the prior updates ride in the launch that opens the tick
-        w.synchronize()
-        line["tick"] = {"value": round(n_ticks / (time.perf_counter() - t0), 1), "unit": "driver ticks/s per GPU",
+        n_ticks = max(200, a.steps // 10)
+
+        def ticks_per_s(tick_once, n, reps=5):
+            """the headline's protocol for whole driver ticks: a pre-heat of the same work (the blocks before this one leave the GPU
+            idle for seconds of host work: clocks are down), then `reps` blocks of n ticks between synchronisations, the median"""
+            t_end = time.perf_counter() + a.preheat_ms * 1e-3
+            while time.perf_counter() < t_end:
+                for _ in range(10):
+                    tick_once()
+                w.synchronize()
+            rates = []
+            for _ in range(reps):
+                w.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    tick_once()
+                w.synchronize()
+                rates.append(n / (time.perf_counter() - t0))
+            return statistics.median(rates), min(rates), max(rates)
+        med, lo, hi = ticks_per_s(lambda: w.tick(steps=sc2["steps"], **tk), n_ticks)  # mgx_tick: the prior updates ride in the launch / the post
+        line["tick"] = {"value": round(med, 1), "unit": "driver ticks/s per GPU", "min": round(lo, 1), "max": round(hi, 1), "ticks_per_block": n_ticks,
                         "what": "update_prior_of_horizon_state + update_prior_of_current_state_v3 for all robots, then the 10/10 "
-                                "schedule (inter-robot workload), one mgx_tick call per tick"}
+                                "schedule (inter-robot workload), one mgx_tick call per tick, ticks back to back (robot.rs:85-108); median of 5 "
+                                "blocks after a pre-heat"}
+        w.set_linger(0)
+        med0, _, _ = ticks_per_s(lambda: w.tick(steps=sc2["steps"], **tk), n_ticks, reps=3)
+        w.set_linger(None)
+        line["tick"]["launch_per_tick"] = round(med0, 1)  # mgx_set_linger(world, 0): every tick a launch of its own
         try:
             import numpy as np
             sc3 = S.grid_scenario(n_loc, K, interrobot=True, seed=805)
@@ -952,6 +1006,8 @@ def main():
             S.populate(w_par, sc2)
             n_par = min(a.steps, 20 * SCHEDULE_LEN)  # (the whole timed block, up to 200 steps: the oracle runs ~25 steps a second)
             par_launches = run_steps(w_par.iterate, n_par, sc2["steps"], w_par.batch, G)
+            par_linger = [int(x) for x in w_par.linger_stats()]
+            par_launches = par_launches or int(w_par.resident_stats()[0])
             if n_par % SCHEDULE_LEN == 0:
                 check = (n_par // SCHEDULE_LEN, w_par.read_beliefs())
             del w_par
@@ -961,6 +1017,7 @@ def main():
         par = cb.pop("parity", None)
         if par is not None:
             par["engine_launches"] = par_launches
+            par["engine_linger_stats"] = {"launches_that_lingered": par_linger[0], "schedules_posted": par_linger[1], "posts_rerun_as_launches": par_linger[2]}
             line["parity"] = par
         elif "parity" not in line:
             line["parity"] = {"checked": False, "why": "--steps is not a whole number of ticks"}

@@ -320,13 +320,18 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     // (LINGER: the bytes of the plan in force, from its LDS copy — a wave-uniform value, and told so)
     uint32_t *s_plan = reinterpret_cast<uint32_t *>(lds + 2);  // [LINGER_PLAN_DWORDS] (PERSIST only), behind the parked argument pointer
     double *s_urec = lds + 2 + LINGER_PLAN_DWORDS / 2;          // [4] a posted plan's prior-update record of this robot
-    // [8] what is derived from the plan in force, kept HERE and fetched at the top of every segment (wave-uniform values that would
-    // otherwise sit in scalar registers — and their spill lanes — for the whole launch): segments, last segment with internal
-    // iterations / with an external iteration, flags (1: some internal variable sweep runs on this robot, 2: some variable sweep), the
-    // launch-wide index of the plan's segment 0, plans run before this one
-    int32_t *s_ps = reinterpret_cast<int32_t *>(lds + 2 + LINGER_PLAN_DWORDS / 2 + 4);
-    static_assert(LINGER_PLAN_DWORDS % 2 == 0 && 2 + LINGER_PLAN_DWORDS / 2 + 4 + 4 <= 22, "the resident kernels' LDS prefix is 22 f64");
-    auto ps_word = [&](int i) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(s_ps[i]); };
+    // What is derived from the plan in force, kept HERE and fetched at the top of every segment (wave-uniform values that would
+    // otherwise sit in scalar registers — and their spill lanes — for the whole launch).  Every wave works them out for itself where
+    // a plan begins and keeps a copy of its own (no barrier between writing and reading them):
+    //   s_ps  [4 waves][4]   [0] segments | (last segment with internal iterations + 1) << 8 | (last one with an external iteration
+    //                        + 1) << 16 | flags << 24 (1: some internal variable sweep runs on this robot, 2: some variable sweep);
+    //                        [1] launch-wide index of the plan's segment 0; [2] plans run before this one
+    //   s_seg [4 waves][32]  per segment k: external? | internal iterations << 8 | the same two of segment k + 1 << 16
+    constexpr int PS_WORDS = 4, PREFIX_F64 = 2 + LINGER_PLAN_DWORDS / 2 + 4 + (4 * PS_WORDS + 4 * MAX_SEGS) / 2;
+    static_assert(LINGER_PLAN_DWORDS % 2 == 0 && PREFIX_F64 == 90, "the resident kernels' LDS prefix (mgx_kernels.hip: sweep_lds_bytes)");
+    uint32_t *s_ps = reinterpret_cast<uint32_t *>(lds + 2 + LINGER_PLAN_DWORDS / 2 + 4) + (threadIdx.x >> 6) * PS_WORDS;
+    uint32_t *s_seg = reinterpret_cast<uint32_t *>(lds + 2 + LINGER_PLAN_DWORDS / 2 + 4) + 4 * PS_WORDS + (threadIdx.x >> 6) * MAX_SEGS;
+    auto ps_word = [&](int i) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ps[i]); };
     auto plan_dword = [&](int i) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)s_plan[i]); };
     auto plan_ext = [&](int k) __attribute__((always_inline)) {
         if constexpr (LINGER) return (plan_dword(2 + (k >> 2)) >> (8 * (k & 3))) & 0xffu;
@@ -505,7 +510,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     const int K = KT > 0 ? KT : w.K, E = 4 * K - 6, E1 = E + 1;
     const BlobLayout L(K);
     const int ZCOL = E;  // all-zero message column (absent edges)
-    double *s_snap = lds + (PERSIST ? 22 : 0);            // [24][K] variable -> own-factor snapshots (resident: behind the parked argument pointer and the plan)
+    double *s_snap = lds + (PERSIST ? 90 : 0);            // [24][K] variable -> own-factor snapshots (resident: behind the parked argument pointer and the plan)
     double *s_prior = s_snap + SNAP_W * K;                // [20][K] prior eta, lam (belief after the last sweep)
     double *s_tmp = s_prior + 20 * K;                     // [20][K] scratch sums (external sweep)
     double *s_io = s_tmp + 20 * K;                        // image of the blob's in/out region:
@@ -1642,8 +1647,27 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                 __syncthreads();
             }
             my_epoch = (sum_t < 4 * K) ? s_epoch[sum_t % K] : 0u;
-            if (PERSIST) {
-                if (LINGER) nseg = (int)plan_dword(0);
+            if constexpr (LINGER) {
+                // the plan's bytes, one segment per lane: two ballots say which segments have internal iterations / an external one
+                nseg = (int)plan_dword(0);
+                const int q = lane & (MAX_SEGS - 1), q1 = (q + 1) & (MAX_SEGS - 1);
+                auto byte_of = [&](int base, int i) __attribute__((always_inline)) { return (s_plan[base + (i >> 2)] >> (8 * (i & 3))) & 0xffu; };
+                const uint32_t e_q = byte_of(2, q), n_q = byte_of(2 + MAX_SEGS / 4, q);
+                const uint32_t e_1 = q + 1 < MAX_SEGS ? byte_of(2, q1) : 0u, n_1 = q + 1 < MAX_SEGS ? byte_of(2 + MAX_SEGS / 4, q1) : 0u;
+                const bool in = lane < nseg;
+                const unsigned long long m_int = __ballot(in && n_q > 0u), m_ext = __ballot(in && e_q != 0u);
+                last_int_seg = m_int ? 63 - __clzll((long long)m_int) : -1;
+                last_ext_seg = m_ext ? 63 - __clzll((long long)m_ext) : -1;
+                has_int_var = m_int != 0ull && !idle;
+                any_sweep = has_int_var || (m_ext != 0ull && radio);
+                if (lane < MAX_SEGS) s_seg[lane] = e_q | (n_q << 8) | (e_1 << 16) | (n_1 << 24);
+                if (lane == 0) {
+                    s_ps[0] = (uint32_t)nseg | ((uint32_t)(last_int_seg + 1) << 8) | ((uint32_t)(last_ext_seg + 1) << 16) | ((has_int_var ? 1u : 0u) | (any_sweep ? 2u : 0u)) << 24;
+                    s_ps[1] = (uint32_t)kbase;
+                    s_ps[2] = (uint32_t)plans_done;
+                }
+                __builtin_amdgcn_wave_barrier();  // (the wave's own LDS reads below follow its LDS writes above)
+            } else if (PERSIST) {
                 bool plan_int = false, plan_has_ext = false;  // some segment has internal iterations / an external iteration
                 last_int_seg = last_ext_seg = -1;
                 for (int q = 0; q < nseg; q++) {
@@ -1652,18 +1676,18 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                 }
                 has_int_var = plan_int && !idle;
                 any_sweep = has_int_var || (plan_has_ext && radio);
-                if constexpr (LINGER) {
-                    if (tid == 0) {
-                        s_ps[0] = nseg; s_ps[1] = last_int_seg; s_ps[2] = last_ext_seg; s_ps[3] = (has_int_var ? 1 : 0) | (any_sweep ? 2 : 0);
-                        s_ps[4] = kbase; s_ps[5] = plans_done;
-                    }
-                    __syncthreads();
-                }
             }
         }
-        if constexpr (LINGER) {  // (see s_ps)
-            nseg = ps_word(0); last_int_seg = ps_word(1); last_ext_seg = ps_word(2);
-            kbase = ps_word(4);
+        // this segment's (and the next one's) bytes of the plan, and what is derived from the plan as a whole (see s_ps, s_seg)
+        uint32_t seg_b = 0u;
+        if constexpr (LINGER) {
+            seg_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seg[k]);
+            const uint32_t pk = ps_word(0);
+            kbase = (int)ps_word(1);
+            nseg = (int)(pk & 0xffu); last_int_seg = (int)((pk >> 8) & 0xffu) - 1; last_ext_seg = (int)((pk >> 16) & 0xffu) - 1;
+        } else if (PERSIST) {
+            seg_b = plan_ext(k) | ((uint32_t)plan_n_int(k) << 8);
+            if (k + 1 < nseg) seg_b |= (plan_ext(k + 1) << 16) | ((uint32_t)plan_n_int(k + 1) << 24);
         }
         const int kg = LINGER ? kbase + k : k;  // the segment's launch-wide index
         // Nothing derived from the thread index stays live across segments: left alone, the compiler hoists every per-thread
@@ -1672,9 +1696,9 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         // (... nor from the per-thread indices made of it in front of the loop: a kept copy of `&w.ir_bmu[c * NI + ie0 + my_j]` is two
         // registers per row, and the sharded instantiation spilled four of those to scratch)
         if (PERSIST) asm volatile("" : "+v"(tid), "+v"(lane), "+v"(my_j), "+v"(pf_dst));
-        const uint32_t ext_k = PERSIST ? (plan_ext(k) ? (PH_EXT_FACTOR | PH_EXT_VARIABLE) : 0u) : ext_mask;
+        const uint32_t ext_k = PERSIST ? ((seg_b & 0xffu) ? (PH_EXT_FACTOR | PH_EXT_VARIABLE) : 0u) : ext_mask;
         const uint32_t int_k = PERSIST ? (PH_INT_FACTOR | PH_INT_VARIABLE) : int_mask;
-        const int n_int_k = PERSIST ? plan_n_int(k) : n_int;
+        const int n_int_k = PERSIST ? (int)((seg_b >> 8) & 0xffu) : n_int;
         const bool last_seg = k == nseg - 1;
         // ======================= external factor sweep ============================================
         PSTAMP(ps0);
@@ -2022,11 +2046,11 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             // the factor sweep that opens the next segment's internal iterations, while the records travel: the DYN wave
             // starts at once (a dynamic factor reads no mean), the UV wave after its publish.  The tracking factors' gate
             // (factorgraph.rs:701) counts the external factor sweep that the reference runs in between.
-            early = plan_n_int(k + 1) > 0 && !idle && skip0 == 0u;
+            early = (seg_b >> 24) > 0u && !idle && skip0 == 0u;
             DELAY_AT(3, role == ROLE_DYN);
             if (early) {
                 if (is_dyn && (w.enable & 1u)) dynamic_messages(s_sh);
-                unary_messages(0u, s_sh, itf + ((plan_ext(k + 1) && radio) ? 1 : 0));
+                unary_messages(0u, s_sh, itf + ((((seg_b >> 16) & 0xffu) && radio) ? 1 : 0));
             }
             QSTAMP(13, qt);
         }
@@ -2046,8 +2070,8 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         // whoever waits it out raises the word itself — an atomic max, so one outcome for all.
         if constexpr (LINGER) {
             if (lingers && last_seg) {
-                plans_done = ps_word(5);
-                any_sweep = (ps_word(3) & 2) != 0;
+                plans_done = (int)ps_word(2);
+                any_sweep = ((ps_word(0) >> 24) & 2u) != 0u;
                 if (role == ROLE_UV && pending) finish(s_snap, true);
                 pending = false;
                 __syncthreads();
@@ -2116,8 +2140,8 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         }
     }
     if constexpr (LINGER) {  // (see s_ps; the staging barrier, or the one where the last plan began, lies behind)
-        nseg = ps_word(0); kbase = ps_word(4);
-        any_sweep = (ps_word(3) & 2) != 0;
+        nseg = (int)(ps_word(0) & 0xffu); kbase = (int)ps_word(1);
+        any_sweep = ((ps_word(0) >> 24) & 2u) != 0u;
     }
     {
         // Tail: the UV wave completes the last variable sweep (mean, covariance) while the DYN wave

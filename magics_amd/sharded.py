@@ -685,6 +685,11 @@ class ShardedWorld:
     def synchronize(self):
         self.world.synchronize()
 
+    def flush(self):
+        """everything issued so far is enqueued (World.flush: a lingering launch is told to end, nothing is waited for)"""
+        if hasattr(self.world, "flush"):
+            self.world.flush()
+
 
 def _torch_tensor_factory(n):
     """device buffers of the halo exchange (torch is the allocator / collective plumbing)"""
