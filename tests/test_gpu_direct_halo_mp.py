@@ -162,7 +162,7 @@ def test_bench_bare_launch_starts_its_own_ranks():
     env.update(MGX_BENCH_BACKEND="gloo", MGX_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", MGX_HALO_TIMEOUT_MS="20000",
                MGX_RESIDENT_CENSUS_SHARDED_US="500000")
     cmd = [sys.executable, bench, "--gpus", "2", "--steps", "40", "--warmup", "10", "--robots-per-gpu", "144", "--horizon", "10",
-           "--deadline", "150", "--repeats", "3", "--sustained-seconds", "0.5", "--no-configs1"]
+           "--deadline", "150", "--repeats", "3", "--sustained-seconds", "0.5", "--no-configs1", "--ticks-per-submission", "2"]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
@@ -176,7 +176,8 @@ def test_bench_bare_launch_starts_its_own_ranks():
     assert d["sustained"]["value"] > 0 and d["sustained"]["seconds"] >= 0.4
     assert d["resident_stats"]["launches"] > 0
     assert d["launch_per_segment"]["value"] > 0 and d["launch_per_segment"]["launches_per_tick"] > 1
-    # the ticks are handed to the engines two at a time (mgx_batch_*): ONE resident launch of 20 iterations per rank and submission
+    # (--ticks-per-submission 2; the default is the reference's call pattern, one call per tick — sharded worlds' launches do not
+    # linger) the ticks are handed to the engines two at a time (mgx_batch_*): ONE resident launch of 20 iterations per rank and submission
     assert d["submission"]["ticks_per_submission"] == 2 and d["submission"]["iterations_per_launch"] == 20, d["submission"]
     assert d["one_submission_per_tick"]["value"] > 0
     print("2 ranks on one GPU:", d["value"], "it/s batched,", d["one_submission_per_tick"]["value"], "one submission per tick")
