@@ -330,6 +330,37 @@ int mgx_mission_tick_begin(mgx_world *w, float comms_radius, uint32_t method, ui
 int mgx_mission_tick_end(mgx_world *w, const uint8_t *antennas, double max_speed, double delta_t,
                          const uint8_t *steps, uint32_t n_steps);
 int mgx_mission_finished(mgx_world *w, int32_t *robots, uint32_t capacity, uint32_t *n);
+/* MANY ticks in one call: what a headless run does between two spawns (the reference's FixedUpdate chain tick after tick,
+ * robot.rs:85-108, with update_failed_comms' draws in between) without the caller's interpreter in the loop —
+ *   for each tick:  mgx_mission_tick_begin;  one Bernoulli(failure_rate) draw per robot alive after the tick's despawns, id
+ *                   order, from the caller's WyRand stream (rand 0.8.5 Bernoulli over wyrand 0.2.0, restated in
+ *                   magics_amd/prng.py: one u64 per draw unless failure_rate == 1; wyrand_state NULL: no stream, no draws);
+ *                   mgx_mission_tick_end (the draws as antennas when failure_rate > 0).
+ * Per tick t < ticks_done the caller gets what it would have seen tick by tick: connections created / pairs deleted, the
+ * number of missions completed and, one after the other in `finished`, the robots concerned (ascending within a tick), the
+ * Transform::translation of EVERY robot after the tick's move ([n_ticks][n_robots][3], may be NULL) and the draws
+ * ([n_ticks][n_robots], 1 = on air, may be NULL).  stop_when_all_finished: returns behind the tick that completed the last
+ * mission.  No robot may join during the call.  Identical to the same ticks issued one by one (tests/test_gpu_sim.py). */
+typedef struct mgx_mission_run_desc {
+    uint32_t n_ticks;
+    float comms_radius;
+    uint32_t method;                  /* MGX_NEIGHBOURS_* */
+    int32_t despawn_finished, stop_when_all_finished;
+    uint32_t n_steps;
+    const uint8_t *steps;
+    double max_speed, delta_t, failure_rate;
+    uint64_t *wyrand_state;           /* in / out */
+    uint64_t *robot_number_next;      /* in / out */
+    uint32_t *created, *deleted, *n_finished; /* out [n_ticks] */
+    int32_t *finished;                /* out [finished_capacity] */
+    uint32_t finished_capacity;
+    uint32_t finished_total;          /* out */
+    float *translations;              /* out [n_ticks][n_robots][3] or NULL */
+    uint8_t *antennas;                /* out [n_ticks][n_robots] or NULL */
+    uint32_t ticks_done;              /* out */
+    uint32_t reserved;
+} mgx_mission_run_desc;
+int mgx_mission_run(mgx_world *w, mgx_mission_run_desc *desc);
 /* Transform::translation [n][3] of every robot as of the end of the last tick, WITHOUT synchronising: _end sends them to
  * the host behind its launches, so they are complete once the stream has been synchronised since — which the next
  * mgx_mission_tick_begin does by itself.  (PositionTracker / VelocityTracker samples, planner/tracking.rs:104-218.) */

@@ -3180,6 +3180,76 @@ int mgx_mission_tick_end(mgx_world *w, const uint8_t *antennas, double max_speed
     return rc;
 }
 
+// Many ticks in one call (include/mgx.h): the host loop of a headless run — tick, comms draws, tick — without the caller's
+// interpreter in it.  Nothing new happens on the device: the two halves above, once per tick.
+int mgx_mission_run(mgx_world *w, mgx_mission_run_desc *d) {
+    MGX_ENTER(w);
+    if (!w || !d || !d->robot_number_next || (!d->steps && d->n_steps) || !d->created || !d->deleted || !d->n_finished ||
+        (d->finished_capacity && !d->finished))
+        return fail(MGX_ERR_INVALID, "null argument");
+    if (!(d->failure_rate >= 0.0 && d->failure_rate <= 1.0)) return fail(MGX_ERR_INVALID, "failure_rate is outside [0, 1]");
+    mgx_world::Mission &ms = w->mission;
+    const size_t R = w->robots.size();
+    d->ticks_done = 0;
+    d->finished_total = 0;
+    // rand 0.8.5 Bernoulli over wyrand 0.2.0 (restated in magics_amd/prng.py, which is the checker of this copy): one u64 per
+    // draw unless p == 1
+    const bool always = d->failure_rate == 1.0;
+    const unsigned long long p_int = always ? 0ull : (unsigned long long)(d->failure_rate * 18446744073709551616.0);
+    auto next_u64 = [&]() {
+        unsigned long long &st = *reinterpret_cast<unsigned long long *>(d->wyrand_state);
+        st += 0xA0761D6478BD642Full;
+        const unsigned __int128 t = (unsigned __int128)st * (unsigned __int128)(st ^ 0xE7037ED1A0B428DBull);
+        return (unsigned long long)(t >> 64) ^ (unsigned long long)t;
+    };
+    std::vector<uint8_t> ant(R, 1);
+    int rc = MGX_OK;
+    for (uint32_t t = 0; t < d->n_ticks; t++) {
+        uint32_t st[3] = {0, 0, 0};
+        if ((rc = mgx_mission_tick_begin(w, d->comms_radius, d->method, d->robot_number_next, d->despawn_finished, st)) != MGX_OK) return rc;
+        if (w->robots.size() != R) return fail(MGX_ERR_STATE, "robots joined during mgx_mission_run");
+        // (the tick's synchronisation lies behind: the Transforms the tick before sent to the host are complete)
+        if (t > 0 && d->translations && ms.tr_host) memcpy(d->translations + (size_t)(t - 1) * R * 3, ms.tr_host, sizeof(float) * 3 * R);
+        d->created[t] = st[0];
+        d->deleted[t] = st[1];
+        d->n_finished[t] = st[2];
+        for (int32_t r : ms.last_finished) {
+            if (d->finished_total < d->finished_capacity) d->finished[d->finished_total] = r;
+            d->finished_total++;
+        }
+        // update_failed_comms (robot.rs:1593-1601): one draw per robot alive after this tick's despawns, id order
+        bool any_off = false;
+        if (d->wyrand_state)
+            for (size_t r = 0; r < R; r++) {
+                const Robot &rb = w->robots[r];
+                if (rb.removed || rb.ghost) { ant[r] = 1; continue; }
+                const bool fails = always ? true : next_u64() < p_int;
+                ant[r] = fails ? 0 : 1;
+                any_off = any_off || fails;
+            }
+        if (d->antennas) memcpy(d->antennas + (size_t)t * R, ant.data(), R);
+        (void)any_off;
+        if ((rc = mgx_mission_tick_end(w, (d->wyrand_state && d->failure_rate > 0.0) ? ant.data() : nullptr, d->max_speed, d->delta_t, d->steps,
+                                       d->n_steps)) != MGX_OK)
+            return rc;
+        d->ticks_done = t + 1;
+        if (d->stop_when_all_finished) {
+            bool all = true;
+            for (size_t r = 0; r < R && all; r++) all = !ms.has[r] || ms.finished_tick[r] >= 0;
+            if (all) break;
+        }
+    }
+    if (d->ticks_done && d->translations) {  // the last tick's Transforms: behind its launches
+        if (w->linger.open && (rc = linger_close(w)) != MGX_OK) return rc;
+        if (w->pending.active && (rc = confirm_resident(w)) != MGX_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(w->stream));
+        if (ms.tr_host) memcpy(d->translations + (size_t)(d->ticks_done - 1) * R * 3, ms.tr_host, sizeof(float) * 3 * R);
+        if ((rc = check_device_error(w)) != MGX_OK) return rc;
+    }
+    if (d->finished_total > d->finished_capacity) return fail(MGX_ERR_INVALID, "%u missions completed, room for %u", d->finished_total, d->finished_capacity);
+    return MGX_OK;
+}
+
 int mgx_mission_finished(mgx_world *w, int32_t *robots, uint32_t capacity, uint32_t *n) {
     MGX_ENTER(w);
     if (!w || !n) return fail(MGX_ERR_INVALID, "null argument");

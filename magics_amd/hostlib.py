@@ -182,6 +182,7 @@ SYMBOLS = {
     "mgx_mission_tick": (C.c_int, [_V, C.c_float, C.c_uint32, C.POINTER(C.c_uint64), C.c_int32, C.c_void_p, C.c_double, C.c_double,
                                    C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "mgx_mission_tick_begin": (C.c_int, [_V, C.c_float, C.c_uint32, C.POINTER(C.c_uint64), C.c_int32, C.POINTER(C.c_uint32)]),
+    "mgx_mission_run": (C.c_int, [_V, C.c_void_p]),
     "mgx_mission_tick_end": (C.c_int, [_V, C.c_void_p, C.c_double, C.c_double, C.c_char_p, C.c_uint32]),
     "mgx_mission_finished": (C.c_int, [_V, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "mgx_mission_translations": (C.c_int, [_V, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
@@ -326,6 +327,17 @@ def variable_timesteps(lookahead_horizon, lookahead_multiple):
     if n < 0:
         raise ValueError("bad arguments")
     return list(buf[:n])
+
+
+class MissionRunDesc(C.Structure):
+    """mgx_mission_run_desc (include/mgx.h)"""
+    _fields_ = [("n_ticks", C.c_uint32), ("comms_radius", C.c_float), ("method", C.c_uint32), ("despawn_finished", C.c_int32),
+                ("stop_when_all_finished", C.c_int32), ("n_steps", C.c_uint32), ("steps", C.c_char_p), ("max_speed", C.c_double),
+                ("delta_t", C.c_double), ("failure_rate", C.c_double), ("wyrand_state", C.POINTER(C.c_uint64)),
+                ("robot_number_next", C.POINTER(C.c_uint64)), ("created", C.POINTER(C.c_uint32)), ("deleted", C.POINTER(C.c_uint32)),
+                ("n_finished", C.POINTER(C.c_uint32)), ("finished", C.POINTER(C.c_int32)), ("finished_capacity", C.c_uint32),
+                ("finished_total", C.c_uint32), ("translations", C.POINTER(C.c_float)), ("antennas", C.POINTER(C.c_uint8)),
+                ("ticks_done", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class MissionDesc(C.Structure):

@@ -268,10 +268,67 @@ class Simulation:
         """AllFormationsFinished: every spawner is exhausted and every spawned robot completed its mission."""
         return all(sp.exhausted() for sp in self.spawners) and all(r["completed"] for r in self.robots)
 
-    def run(self, max_ticks=None, max_time=None):
+    # -- many ticks per call (device missions): what lies between two spawns is ONE mgx_mission_run ------------------
+    def _quiet_ticks(self, cap):
+        """how many ticks, the coming one included, pass before a spawner acts again (becomes ready, or runs out): the
+        spawners' timers run ahead on copies"""
+        import copy
+        sps = copy.deepcopy(self.spawners)
+        n = 0
+        while n < cap:
+            was = [sp.exhausted() for sp in sps]
+            for sp in sps:
+                sp.tick(self.dt_ns)
+            if any(sp.ready_to_spawn() for sp in sps) or [sp.exhausted() for sp in sps] != was:
+                break
+            n += 1
+        return n
+
+    def _run_chunk(self, cap):
+        """One frame's Update (the spawners) and then every FixedUpdate up to the next frame in which a spawner acts, in one
+        engine call: identical to tick() that many times — the per-tick bookkeeping (events, completions, trackers,
+        collisions) is replayed from what the call returns per tick."""
+        self._spawn()
+        if not self.robots:
+            self.tick_no += 1
+            return
+        self._flush_trackers(synchronise=True)
+        m = 1 + (self._quiet_ticks(cap - 1) if cap > 1 else 0)
+        for _ in range(m - 1):  # the real spawners live through the same frames (nothing happens in them)
+            for sp in self.spawners:
+                sp.tick(self.dt_ns)
+        out = self.w.mission_run(m, self.comms_radius, self.next_number, self.steps, float(self.max_speed), float(self.dt32),
+                                 despawn_finished=self.despawn, method=self.method, failure_rate=self.failure_rate,
+                                 wyrand_state=self.rng.state, stop_when_all_finished=all(sp.exhausted() for sp in self.spawners))
+        self.next_number, self.rng.state = out["next_number"], out["wyrand_state"]
+        for j in range(out["ticks"]):
+            if out["created"][j] or out["deleted"][j]:
+                self.events.append((self.tick_no, int(out["created"][j]), int(out["deleted"][j])))
+            for rid in out["finished"][j]:
+                r = self.robots[int(rid)]
+                r["target"] = len(r["waypoints"])
+                r["completed"], r["finished_at"] = True, self.elapsed()
+                if self.despawn:
+                    r["alive"] = False
+                    self.entities.free(r["entity"])
+            live = [r for r in self.robots if r["alive"]]
+            moving = [r for r in live if not r["completed"]]
+            tr = out["translations"][j]
+            self._track(moving, tr, (self.tick_no + 1) * self.dt_ns * 1e-9)
+            self._collide(live, tr)
+            self.tick_no += 1
+
+    def run(self, max_ticks=None, max_time=None, chunk=256):
+        """chunk: device missions — up to that many ticks per engine call (mgx_mission_run) where no spawner acts; 1: tick by tick"""
         limit = self.cfg["simulation"]["max-time"] if max_time is None else max_time
         while not self.finished() and self.elapsed() < limit and (max_ticks is None or self.tick_no < max_ticks):
-            self.tick()
+            if self.dev and chunk > 1 and hasattr(self.w, "mission_run"):
+                cap = 0  # ticks the loop's own conditions allow from here
+                while cap < chunk and (self.tick_no + cap) * self.dt_ns * 1e-9 < limit and (max_ticks is None or self.tick_no + cap < max_ticks):
+                    cap += 1
+                self._run_chunk(max(cap, 1))
+            else:
+                self.tick()
         if self.dev:
             self._flush_trackers(synchronise=True)
         return self

@@ -305,6 +305,37 @@ class World:
         self._chk(self._L.mgx_mission_tick_end(self._w, None if ant is None else ant.ctypes.data, float(max_speed), float(delta_t),
                                                bytes(bytearray(steps)), len(steps)))
 
+    def mission_run(self, n_ticks, comms_radius, next_number, steps, max_speed, delta_t, despawn_finished=True, method=hostlib.NEIGHBOURS_AUTO,
+                    failure_rate=0.0, wyrand_state=None, stop_when_all_finished=False, want_translations=True, want_antennas=False):
+        """Up to n_ticks whole driver ticks in ONE call (mgx_mission_run): per tick what mission_tick_begin / _end would have
+        given.  Returns dict(ticks, next_number, wyrand_state, created [t], deleted [t], finished (list of id arrays per tick),
+        translations [t, n, 3] f32, antennas [t, n] u8)."""
+        n, _ = self.num_robots()
+        T = int(n_ticks)
+        d = hostlib.MissionRunDesc()
+        created, deleted, nfin = (np.zeros(T, np.uint32) for _ in range(3))
+        fin = np.zeros(max(n, 1), np.int32)
+        tr = np.zeros((T, n, 3), np.float32) if want_translations else None
+        ant = np.zeros((T, n), np.uint8) if want_antennas else None
+        nn, ws = C.c_uint64(int(next_number)), C.c_uint64(0 if wyrand_state is None else int(wyrand_state))
+        sb = bytes(bytearray(int(x) for x in steps))
+        d.n_ticks, d.comms_radius, d.method, d.despawn_finished = T, float(comms_radius), int(method), 1 if despawn_finished else 0
+        d.stop_when_all_finished, d.n_steps, d.steps = (1 if stop_when_all_finished else 0), len(sb), sb
+        d.max_speed, d.delta_t, d.failure_rate = float(max_speed), float(delta_t), float(failure_rate)
+        d.wyrand_state = None if wyrand_state is None else C.pointer(ws)
+        d.robot_number_next = C.pointer(nn)
+        u32p = C.POINTER(C.c_uint32)
+        d.created, d.deleted, d.n_finished = created.ctypes.data_as(u32p), deleted.ctypes.data_as(u32p), nfin.ctypes.data_as(u32p)
+        d.finished, d.finished_capacity = fin.ctypes.data_as(C.POINTER(C.c_int32)), len(fin)
+        d.translations = None if tr is None else tr.ctypes.data_as(C.POINTER(C.c_float))
+        d.antennas = None if ant is None else ant.ctypes.data_as(C.POINTER(C.c_uint8))
+        self._chk(self._L.mgx_mission_run(self._w, C.addressof(d)))
+        t = int(d.ticks_done)
+        cuts = np.concatenate([[0], np.cumsum(nfin[:t])]).astype(int)
+        return dict(ticks=t, next_number=int(nn.value), wyrand_state=None if wyrand_state is None else int(ws.value), created=created[:t],
+                    deleted=deleted[:t], finished=[fin[cuts[i]:cuts[i + 1]].copy() for i in range(t)],
+                    translations=None if tr is None else tr[:t], antennas=None if ant is None else ant[:t])
+
     def mission_translations(self):
         """Transforms [n, 3] as of the end of the last tick; valid once the stream has been synchronised since (no sync here)."""
         n, _ = self.num_robots()

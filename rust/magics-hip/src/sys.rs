@@ -90,6 +90,33 @@ pub struct mgx_mission_desc {
     pub time_scale: f64,
 }
 
+/// many ticks in one call (include/mgx.h, mgx_mission_run)
+#[repr(C)]
+pub struct mgx_mission_run_desc {
+    pub n_ticks: u32,
+    pub comms_radius: f32,
+    pub method: u32,
+    pub despawn_finished: i32,
+    pub stop_when_all_finished: i32,
+    pub n_steps: u32,
+    pub steps: *const u8,
+    pub max_speed: f64,
+    pub delta_t: f64,
+    pub failure_rate: f64,
+    pub wyrand_state: *mut u64,
+    pub robot_number_next: *mut u64,
+    pub created: *mut u32,
+    pub deleted: *mut u32,
+    pub n_finished: *mut u32,
+    pub finished: *mut i32,
+    pub finished_capacity: u32,
+    pub finished_total: u32,
+    pub translations: *mut f32,
+    pub antennas: *mut u8,
+    pub ticks_done: u32,
+    pub reserved: u32,
+}
+
 /// opaque handles (include/mgx.h)
 #[repr(C)]
 pub struct mgx_mvn { _private: [u8; 0] }
@@ -140,6 +167,7 @@ extern "C" {
     pub fn mgx_mission_tick_begin(w: *mut mgx_world, comms_radius: f32, method: u32, robot_number_next: *mut u64, despawn_finished: i32, stats: *mut u32) -> c_int;
     pub fn mgx_mission_tick_end(w: *mut mgx_world, antennas: *const u8, max_speed: f64, delta_t: f64, steps: *const u8, n_steps: u32) -> c_int;
     pub fn mgx_mission_finished(w: *mut mgx_world, robots: *mut i32, capacity: u32, n: *mut u32) -> c_int;
+    pub fn mgx_mission_run(w: *mut mgx_world, desc: *mut mgx_mission_run_desc) -> c_int;
     pub fn mgx_mission_translations(w: *mut mgx_world, translations: *mut f32, capacity_robots: u32, n_robots: *mut u32) -> c_int;
     pub fn mgx_mission_read(w: *mut mgx_world, translations: *mut f32, targets: *mut i32, finished_tick: *mut i64) -> c_int;
     pub fn mgx_get_belief(w: *mut mgx_world, robot: i32, var_ix: u32, eta: *mut f64, lam: *mut f64, mean: *mut f64, cov: *mut f64, valid: *mut i32) -> c_int;

@@ -141,3 +141,53 @@ def test_robot_robot_collisions_are_counted_like_the_reference():
     assert total > 0 and total == 2 * sum(len(p["aabbs"]) for p in pairs)       # every collision counts for both robots
     assert all(p["robot_a"] < p["robot_b"] and all(a["mins"][0] <= a["maxs"][0] for a in p["aabbs"]) for p in pairs)
     assert ex["goal_areas"] == {} and ex["collisions"]["environment"] == []
+
+
+def _run_chunked(name, ticks, tweak=None, chunk=256):
+    """the engine through Simulation.run — whole stretches between two spawns as ONE mgx_mission_run call — against the oracle
+    tick by tick: same spawns, events, Transforms, beliefs, random stream and export"""
+    sc = _scenario(name)
+    if tweak:
+        tweak(sc)
+    a, b = _pair(sc)
+    calls = []
+    real = a.w.mission_run
+
+    def counted(n, *args, **kw):
+        out = real(n, *args, **kw)
+        calls.append((n, out["ticks"]))
+        return out
+    a.w.mission_run = counted
+    a.run(max_ticks=ticks, chunk=chunk)
+    for _ in range(a.tick_no):
+        b.tick()
+    assert a.tick_no == b.tick_no and len(a.robots) == len(b.robots) and a.rng.state == b.rng.state
+    assert np.array_equal(a.translation, b.translation) and a.events == b.events
+    if a.robots:
+        for x, y in zip(a.w.read_beliefs(), b.w.read_beliefs()):
+            assert np.array_equal(x, y)
+    assert json.dumps(a.export(), sort_keys=True) == json.dumps(b.export(), sort_keys=True)
+    return a, calls
+
+
+def test_many_ticks_per_call_junction_twoway():
+    s, calls = _run_chunked("Junction Twoway", 130)
+    assert len(s.robots) >= 24 and s.events
+    assert max(n for n, _ in calls) >= 15 and len(calls) <= 12, calls  # (twelve staggered spawners: some spawner acts every ~20 ticks)
+
+
+def test_many_ticks_per_call_with_comms_failures_and_despawns():
+    def failing(sc):
+        sc["config"]["robot"]["communication"]["failure-rate"] = 0.3
+    s, calls = _run_chunked("Environment Obstacles Experiment", 70, tweak=failing)
+    assert len(s.robots) == 5
+
+    def short(sc):  # (as test_robots_finish_and_despawn) the far side of the circle within reach: missions complete, robots despawn,
+        f = sc["formation"]["formations"][0]  # and the run ends by itself behind the tick that completed the last one
+        f["robots"] = 6
+        f["initial-position"]["shape"]["radius"] = 12.0
+        f["waypoints"][0]["shape"]["radius"] = 12.0
+        sc["config"]["robot"]["communication"]["failure-rate"] = 0.1
+    s, calls = _run_chunked("Circle Experiment", 400, tweak=short, chunk=64)
+    assert s.finished() and all(r["completed"] and not r["alive"] for r in s.robots) and s.tick_no < 400
+    assert calls[-1][1] <= calls[-1][0]

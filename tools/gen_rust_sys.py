@@ -17,7 +17,7 @@ BEGIN, END = "// BEGIN generated from include/mgx.h (tools/gen_rust_sys.py)", "/
 
 SCALARS = {"int": "c_int", "int32_t": "i32", "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64", "uint8_t": "u8", "double": "f64",
            "float": "f32", "char": "c_char", "void": "c_void"}
-STRUCTS = {"mgx_world", "mgx_params", "mgx_robot_desc", "mgx_env_desc", "mgx_env_obstacle", "mgx_mvn", "mgx_shard_plan", "mgx_mission_desc"}
+STRUCTS = {"mgx_world", "mgx_params", "mgx_robot_desc", "mgx_env_desc", "mgx_env_obstacle", "mgx_mvn", "mgx_shard_plan", "mgx_mission_desc", "mgx_mission_run_desc"}
 RUST_KEYWORDS = {"type", "ref", "in", "fn", "mod", "use", "where", "self", "move", "box", "loop", "match"}
 
 
