@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s peak, 
 # = half the guide's 157.3 TFLOP/s FP32 vector figure; as an issue rate: one f64 VALU wave-instruction per SIMD per 4 clocks
 F64_VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4.0
 SCHEDULE_LEN = 10
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 
 def parse():
@@ -288,54 +288,63 @@ def profiled(key):
 
 
 def roofline(kernel, alg_bytes_per_launch, launches, dev_seconds, prof_key, iterations_per_launch, prof_note=""):
-    """What bounds the dominant kernel, as a FRACTION of a physical peak: the larger of (measured HBM bytes per launch / 8 TB/s)
-    and (measured f64 VALU wave-instructions per launch / one per SIMD per 4 clocks), divided by the live launch duration (HIP
-    events on the launch stream).  The counters come from this round's rocprofv3 --pmc passes of this command (profiles/).
-    `work_rate_contract` keeps SURVEY §8d's figure — algorithmic bytes per launch / launch duration — which is a work rate in the
-    survey's byte model, not a bandwidth: the graphs stay in LDS across the iterations of a launch, so it can exceed the peak."""
+    """SURVEY §8(d)'s figure at the top level — ALGORITHMIC bytes per launch (every live message / belief read and written once
+    per sweep: the survey's per-robot figure x robots x iterations of the launch) / the kernel's live average launch duration (HIP
+    events on the launch stream), against 8 TB/s: `achieved`, `peak`, `frac`.  It exceeds 1 where the graphs stay in LDS across the
+    iterations of a launch: a WORK RATE in the survey's byte model then, not a bandwidth — which is what `physical` is for: what
+    rocprofv3's counters measured for this build of the kernel (profiles/, separate --pmc passes), scaled per iteration to this
+    run's launches:
+      physical.hbm   FETCH_SIZE (doubled per MI355X_MICROARCH.md's gfx950 correction) + WRITE_SIZE against 8 TB/s
+      physical.valu  SQ_INSTS_VALU counts EVERY VALU wave-instruction; SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 the f64 ones;
+                     SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64) the share of a wave's 64 lanes that work; from those the
+                     useful f64 FLOP/s against the 78.6 TFLOP/s vector peak, and the issue time of the instruction mix (an f64
+                     wave-instruction holds its SIMD 4 clocks, any other VALU one 2)."""
     avg = dev_seconds / launches
     ach = alg_bytes_per_launch / avg / 1e9
-    out = {"bound": None, "kernel": kernel, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-           "avg_launch_us": round(avg * 1e6, 3), "iterations_per_launch": iterations_per_launch,
-           "work_rate_contract": {"achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                                  "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                                  "note": "SURVEY §8d algorithmic bytes (every live message / belief read and written once per sweep) / live "
-                                          "launch duration: a work rate in the survey's byte model, not a bandwidth (state stays in LDS across "
-                                          "the iterations of a launch)"}}
+    out = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+           "traffic": None, "avg_launch_us": round(avg * 1e6, 3), "iterations_per_launch": iterations_per_launch,
+           "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+           "note": "SURVEY §8d: algorithmic bytes per launch / live launch duration against the HBM peak.  Above 1 this is a work rate in the "
+                   "survey's byte model, not a bandwidth (the graphs stay in LDS across the iterations of a launch: `traffic` is what HBM "
+                   "really moved); `physical` holds the measured fractions of physical peaks"}
     p, why = profiled(prof_key) if prof_key else (None, "no counter profile for this shape")
     if not p:
-        out["note"] = "no physical roofline: " + why
+        out["physical"] = {"note": "no counters: " + why}
         return out
-    ipd = p.get("iterations_per_dispatch") or (1 if prof_key == "config2" else SCHEDULE_LEN)  # (files from before the field: one tick per dispatch)
-    if abs(ipd - iterations_per_launch) > 0.5:
-        out["note"] = (f"no physical roofline: the counters in profiles/ are per dispatch of {ipd} iterations, this run's "
-                       f"launches hold {iterations_per_launch} (other --steps / --ticks-per-submission than the profiled command)")
-        return out
-    traffic = int((2 * p["fetch_kib"] + p["write_kib"]) * 1024)
+    ipd = float(p.get("iterations_per_dispatch") or (1 if prof_key == "config2" else SCHEDULE_LEN))
+    scale = iterations_per_launch / ipd  # counters are per dispatch of `ipd` iterations: per iteration, times this run's
+    traffic = int((2 * p["fetch_kib"] + p["write_kib"]) * 1024 * scale)
     t_hbm = traffic / (HBM_PEAK_GBS * 1e9)
-    hbm = {"bytes_per_launch": traffic, "gbs": round(traffic / avg / 1e9, 1), "peak_gbs": HBM_PEAK_GBS, "frac": round(t_hbm / avg, 4),
-           "traffic_over_algorithmic": round(traffic / alg_bytes_per_launch, 4)}
     out["traffic"] = traffic
-    out["hbm"] = hbm
-    cands = [("hbm", t_hbm, round(traffic / avg / 1e9, 1), HBM_PEAK_GBS, "GB/s")]
+    phys = {"hbm": {"bytes_per_launch": traffic, "gbs": round(traffic / avg / 1e9, 1), "peak_gbs": HBM_PEAK_GBS, "frac": round(t_hbm / avg, 4),
+                    "traffic_over_algorithmic": round(traffic / alg_bytes_per_launch, 4)}}
     if p.get("valu_wave_instr"):
-        t_valu = p["valu_wave_instr"] / F64_VALU_WAVE_INSTR_PER_S
-        rate = p["valu_wave_instr"] / avg
-        out["valu"] = {"wave_instr_per_launch": p["valu_wave_instr"], "g_wave_instr_per_s": round(rate / 1e9, 2),
-                       "peak_g_wave_instr_per_s": round(F64_VALU_WAVE_INSTR_PER_S / 1e9, 1), "frac": round(t_valu / avg, 4),
-                       "valu_active_pct_of_wave_cycles": p.get("valu_busy_pct"), "wait_pct_of_wave_cycles": p.get("wait_pct"),
-                       "note": "SQ_INSTS_VALU per launch against one f64 VALU wave-instruction per SIMD per 4 clocks (1024 SIMDs x 2.4 GHz)"}
-        cands.append(("valu-f64-issue", t_valu, round(rate / 1e9, 2), round(F64_VALU_WAVE_INSTR_PER_S / 1e9, 1), "G wave-instr/s"))
-    b = max(cands, key=lambda c: c[1])
-    out.update({"bound": b[0], "achieved": b[2], "peak": b[3], "unit": b[4], "frac": round(b[1] / avg, 4)})
-    out["traffic_source"] = p.get("source", f"profiles/{PROFILE_TAG}_*: rocprofv3 --pmc, separate passes") + (f" — {prof_note}" if prof_note else "")
-    # counters per launch are duration-independent; the profile box's own duration and clock are quoted beside THIS run's, so that a
-    # reader sees "counters from box A at X GHz, clock of this run from box B" instead of finding the two durations disagree
-    out["profile_box"] = {"kernel_trace_avg_us": p.get("kernel_trace_avg_us"), "shader_clock_ghz": p.get("shader_clock_ghz"),
-                          "counter_pass_avg_us": p.get("counter_pass_avg_us"),
-                          "note": "the box the counters were collected on (profiles/); `avg_launch_us` above is this run's own, live"}
-    out["note"] = ("frac = max(HBM time of the measured traffic at 8 TB/s, issue time of the measured f64 VALU wave-instructions) / live launch "
-                   "duration; the rest of the launch is latency (dependent phases of one workgroup, hand-offs between neighbours)")
+        n_all = p["valu_wave_instr"] * scale
+        v = {"valu_wave_instr_per_launch": round(n_all), "g_valu_wave_instr_per_s": round(n_all / avg / 1e9, 2),
+             "valu_active_pct_of_wave_cycles": p.get("valu_busy_pct"), "wait_pct_of_wave_cycles": p.get("wait_pct"),
+             "note": "SQ_INSTS_VALU: EVERY VALU wave-instruction (f64 arithmetic, moves, selects, integer address work, lane reads / writes "
+                     "of spilled scalars)"}
+        if p.get("f64_wave_instr"):
+            n64 = p["f64_wave_instr"] * scale
+            occ = p.get("lane_occupancy") or 1.0
+            flops = p.get("f64_flops_per_wave_instr", 1.0) * n64 * 64.0 * occ  # (FMA counts 2)
+            t_issue = (4.0 * n64 + 2.0 * (n_all - n64)) / (1024 * 2.4e9)
+            v.update({"f64_wave_instr_per_launch": round(n64), "f64_frac": round(n64 / n_all, 4), "lane_occupancy": round(occ, 4),
+                      "f64_tflops": round(flops / avg / 1e12, 3), "f64_peak_tflops": 78.6, "f64_frac_of_peak": round(flops / avg / 78.6e12, 4),
+                      "issue_frac": round(t_issue / avg, 4),
+                      "issue_model": "an f64 VALU wave-instruction holds its SIMD 4 clocks, any other VALU wave-instruction 2; 1024 SIMDs x 2.4 GHz"})
+        else:
+            v["issue_frac_if_all_were_f64"] = round(n_all / F64_VALU_WAVE_INSTR_PER_S / avg, 4)
+        phys["valu"] = v
+    phys["source"] = p.get("source", f"profiles/{PROFILE_TAG}_*: rocprofv3 --pmc, separate passes") + (f" — {prof_note}" if prof_note else "")
+    phys["counters_per_dispatch_of_iterations"] = ipd
+    # counters per iteration are duration-independent; the profile box's own duration and clock are quoted beside THIS run's
+    phys["profile_box"] = {"kernel_trace_avg_us": p.get("kernel_trace_avg_us"), "shader_clock_ghz": p.get("shader_clock_ghz"),
+                           "counter_pass_avg_us": p.get("counter_pass_avg_us"),
+                           "note": "the box the counters were collected on (profiles/); `avg_launch_us` above is this run's own, live"}
+    phys["note"] = ("neither HBM nor VALU issue bounds the launch: two waves per SIMD, each waiting on its own dependent chain (LDS round "
+                    "trips, f64 latency, the hand-off between neighbouring workgroups) — see wait_pct_of_wave_cycles")
+    out["physical"] = phys
     return out
 
 
@@ -639,19 +648,18 @@ def main():
         w1 = World(sc1["params"], stream=stream, fma=a.fma)
         S.populate(w1, sc1)
         assert len(sc1["steps"]) == SCHEDULE_LEN
-        walls, devs = timed(torch, dist, w1.iterate, sc1["steps"], a, multi, red_dev, sync=w1.synchronize, batch=w1.batch, group=a.ticks_per_submission,
-                            flush=w1.flush)
+        G1 = max(a.ticks_per_submission, 2)  # (no inter-robot factors: nothing to keep a launch resident for — its ticks are bracketed two at a time)
+        walls, devs = timed(torch, dist, w1.iterate, sc1["steps"], a, multi, red_dev, sync=w1.synchronize, batch=w1.batch, group=G1, flush=w1.flush)
         r1 = summary(walls, devs, a.steps, units_per_step=world_size)
         bytes1 = S.algorithmic_bytes_per_robot_iter(K, 0.0) * n_loc
         # launches of the timed K-step block: as the engine counted them for the same block, issued once more
-        n_launch = run_steps(w1.iterate, a.steps, sc1["steps"], w1.batch, a.ticks_per_submission) or -(-a.steps // SCHEDULE_LEN)
+        n_launch = run_steps(w1.iterate, a.steps, sc1["steps"], w1.batch, G1) or -(-a.steps // SCHEDULE_LEN)
         it1 = a.steps / n_launch
         line["configs1"] = {
             "value": round(r1["value"], 2), "unit": "GBP iterations/s (same unit as the headline)",
             "ms_per_step": r1["ms_per_step"], "device_ms_per_step": r1["device_ms_per_step"], "spread": r1["spread"],
             "config": {"workload": f"BASELINE configs[1]: synthetic {n_loc} robots x {K} horizon per GPU, dynamics + obstacle factors, "
-                                   "seed 805, 10-step schedule" + (f", {a.ticks_per_submission} ticks per submission (mgx_batch_*) = one launch"
-                                                                   if a.ticks_per_submission > 1 else " = one launch"),
+                                   "seed 805, 10-step schedule" + f", {G1} ticks per submission (mgx_batch_*) = one launch",
                        "parallelism": f"{world_size} independent shard(s), no exchange (robots do not interact)"},
             "roofline": roofline("k_robot_sweep<16,0,false>", bytes1 * it1, n_launch, r1["device_s_median"], "config1" if full_size else "",
                                  it1),

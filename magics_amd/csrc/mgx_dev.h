@@ -276,6 +276,11 @@ struct LingerPlan {  // one posted plan as the device reads it (dwords; host-map
     unsigned long long number;                      // the post's number (checked: a slot that holds another post is reported)
 };
 constexpr int LINGER_PLAN_DWORDS = (int)(sizeof(LingerPlan) / 4);
+// The launch's DEVICE-side slots (the postman's copies of the posts) are made of self-validating 16-byte chunks like the exchange
+// records: three payload dwords + xrec_seq(number of the post).  Head: the plan's 24 dwords in 8 chunks; then per robot its
+// prior-update record (4 f64 = 8 dwords) in three chunks.
+constexpr unsigned LINGER_SLOT_HEAD = 128u, LINGER_UPD_BYTES = 48u;
+static_assert(LINGER_PLAN_DWORDS == 24, "eight chunks of three dwords");
 struct LingerBox {  // host-mapped
     unsigned long long posted;     // host -> device: number of the newest post
     unsigned long long close_req;  // host -> device: the launch numbered at most this is asked to end

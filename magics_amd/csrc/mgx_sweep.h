@@ -457,41 +457,58 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                             free_slot = consumed + 2ull >= next;
                         }
                         if (free_slot) {
-                            const unsigned slot = (unsigned)(next & 1ull);
-                            const LingerBox *box = cold_plan0().linger_box;
-                            unsigned char *dst = cold_plan0().linger_dev + (size_t)slot * cold_plan0().linger_dev_stride;
-                            const uint32_t *ps = reinterpret_cast<const uint32_t *>(&box->plan[slot]);
-                            uint32_t has_upd = 0u;
-                            if (threadIdx.x < LINGER_PLAN_DWORDS) {
-                                const uint32_t v = __hip_atomic_load(ps + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                __hip_atomic_store(reinterpret_cast<uint32_t *>(dst) + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (threadIdx.x == 1) has_upd = v;
-                            }
-                            if (__syncthreads_or((int)has_upd)) {  // the tick's prior-update records: 32 bytes per robot
-                                const v4u32 *src = reinterpret_cast<const v4u32 *>(cold_plan0().linger_upd + (size_t)slot * cold_plan0().linger_upd_stride);
-                                const unsigned n16 = 2u * (unsigned)(gridDim.x - 1);
-                                const __amdgpu_buffer_rsrc_t rs_d = sc1_rsrc(dst + 128, n16 * 16u);
-                                for (unsigned i0 = 0; i0 < n16; i0 += 4u * NT) {
-                                    v4u32 v[4];
-#pragma unroll
-                                    for (int u = 0; u < 4; u++) {
-                                        const unsigned i = i0 + (unsigned)u * NT + threadIdx.x;
-                                        v[u] = i < n16 ? __builtin_nontemporal_load(src + i) : v4u32{0u, 0u, 0u, 0u};
-                                    }
-#pragma unroll
-                                    for (int u = 0; u < 4; u++) {
-                                        const unsigned i = i0 + (unsigned)u * NT + threadIdx.x;
-                                        if (i < n16) __builtin_amdgcn_raw_buffer_store_b128(v[u], rs_d, (int)(16u * i), 0, 16);
-                                    }
-                                }
-                            }
-                            __threadfence();  // (every storing wave drains; one lane moves the word behind the barrier)
-                            __syncthreads();
+                            // The word first: 2 next says plan `next` WILL run — from here on no robot's workgroup ends the launch
+                            // behind the plan before (its give-up is an atomic max that finds the word moved on) — then the slot, as
+                            // 16-byte chunks that carry the post's sequence word (mgx_dev.h: a chunk that shows it is complete): the
+                            // robots' workgroups poll the chunks themselves, one round trip, and need no second look at anything.
+                            int won = 0;
                             if (threadIdx.x == 0) {
                                 unsigned long long e = g;
-                                if (__hip_atomic_compare_exchange_strong(cold_plan0().linger_go, &e, 2ull * next, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                                    __hip_atomic_store(const_cast<unsigned long long *>(&box->taken), next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                won = __hip_atomic_compare_exchange_strong(cold_plan0().linger_go, &e, 2ull * next, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
                                 // (lost: a robot's workgroup has ended the launch — the next look finds the word odd)
+                            }
+                            if (__syncthreads_or(won)) {
+                                const unsigned slot = (unsigned)(next & 1ull);
+                                const LingerBox *box = cold_plan0().linger_box;
+                                const unsigned n_rob = (unsigned)(gridDim.x - 1);
+                                unsigned char *dst = cold_plan0().linger_dev + (size_t)slot * cold_plan0().linger_dev_stride;
+                                const __amdgpu_buffer_rsrc_t rs_d = sc1_rsrc(dst, LINGER_SLOT_HEAD + LINGER_UPD_BYTES * n_rob);
+                                const uint32_t seq = xrec_seq(next);
+                                uint32_t has_upd = 0u;
+                                if (threadIdx.x < LINGER_PLAN_DWORDS / 3) {
+                                    const uint32_t *ps = reinterpret_cast<const uint32_t *>(&box->plan[slot]) + 3 * threadIdx.x;
+                                    v4u32 c;
+                                    c.x = __hip_atomic_load(ps + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    c.y = __hip_atomic_load(ps + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    c.z = __hip_atomic_load(ps + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    c.w = seq;
+                                    if (threadIdx.x == 0) has_upd = c.y;
+                                    __builtin_amdgcn_raw_buffer_store_b128(c, rs_d, (int)(16u * threadIdx.x), 0, 16);
+                                }
+                                if (__syncthreads_or((int)has_upd)) {  // the tick's prior-update records: 32 bytes per robot in the box, three chunks here
+                                    const v4u32 *src = reinterpret_cast<const v4u32 *>(cold_plan0().linger_upd + (size_t)slot * cold_plan0().linger_upd_stride);
+                                    for (unsigned i0 = 0; i0 < n_rob; i0 += 2u * NT) {
+                                        v4u32 a[2], b[2];
+#pragma unroll
+                                        for (int u = 0; u < 2; u++) {
+                                            const unsigned i = i0 + (unsigned)u * NT + threadIdx.x;
+                                            a[u] = i < n_rob ? __builtin_nontemporal_load(src + 2 * i) : v4u32{0u, 0u, 0u, 0u};
+                                            b[u] = i < n_rob ? __builtin_nontemporal_load(src + 2 * i + 1) : v4u32{0u, 0u, 0u, 0u};
+                                        }
+#pragma unroll
+                                        for (int u = 0; u < 2; u++) {
+                                            const unsigned i = i0 + (unsigned)u * NT + threadIdx.x;
+                                            if (i < n_rob) {
+                                                const int o = (int)(LINGER_SLOT_HEAD + LINGER_UPD_BYTES * i);
+                                                __builtin_amdgcn_raw_buffer_store_b128(v4u32{a[u].x, a[u].y, a[u].z, seq}, rs_d, o, 0, 16);
+                                                __builtin_amdgcn_raw_buffer_store_b128(v4u32{a[u].w, b[u].x, b[u].y, seq}, rs_d, o + 16, 0, 16);
+                                                __builtin_amdgcn_raw_buffer_store_b128(v4u32{b[u].z, b[u].w, 0u, seq}, rs_d, o + 32, 0, 16);
+                                            }
+                                        }
+                                    }
+                                }
+                                __syncthreads();  // (every thread's loads from the box are back: the host may write that slot again)
+                                if (threadIdx.x == 0) __hip_atomic_store(const_cast<unsigned long long *>(&box->taken), next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             }
                             continue;
                         }
@@ -2081,52 +2098,58 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                 if (role == ROLE_DYN && any_sweep) copy_words_wave(blob + L.bel(), s_prior, 20 * K, lane);
                 StageRegs<(KT > 0 ? 20 * KT : 2), NT> r_prior;
                 if constexpr (KT > 0) r_prior.load(blob + L.prior(), tid);
-                int go_on = 0;
-                if (tid == 0) {
-                    const unsigned long long cur2 = 2ull * (cold_plan().launch_seq + (unsigned long long)plans_done);
+                // Wave 0 polls: lanes 0 .. 7 the chunks of the next plan, 8 .. 10 this robot's prior-update record, lane 11 the go word —
+                // ONE round trip where the post is there already (the rule: the host runs a plan or two ahead).  Chunks complete (their
+                // sequence word is the post's): the plan will run — the postman moved the word before it wrote them.  The word odd at
+                // this plan: the launch ends here.  Neither, and nothing promised (the word still at this plan) for the bound: this
+                // workgroup raises the word itself, an atomic max, and takes what it finds.
+                int *s_verdict = reinterpret_cast<int *>(lds + 1);
+                const unsigned long long number = cold_plan().launch_seq + (unsigned long long)plans_done + 1ull;
+                if (role == 0) {
+                    const unsigned long long cur2 = 2ull * (number - 1ull);
                     unsigned long long *go = cold_plan().linger_go;
-                    unsigned long long v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v <= cur2) {
-                        const long long t0 = wall_clock64();
-                        for (unsigned spins = 1;; spins++) {
-                            if (spins < 8u) __builtin_amdgcn_s_sleep(2);
-                            else __builtin_amdgcn_s_sleep(24);
-                            v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (v > cur2) break;
-                            if ((spins & 7u) == 0u &&
-                                (__hip_atomic_load(cold().sweep_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull ||
-                                 wall_clock64() - t0 > cold_plan().linger_ticks)) {
-                                const unsigned long long old = __hip_atomic_fetch_max(go, cur2 + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                v = old > cur2 + 1ull ? old : cur2 + 1ull;
-                                break;
-                            }
+                    const uint32_t seq = xrec_seq(number);
+                    const unsigned char *dslot = cold_plan().linger_dev + (size_t)(number & 1ull) * cold_plan().linger_dev_stride;
+                    const __amdgpu_buffer_rsrc_t rs_s = sc1_rsrc(dslot, LINGER_SLOT_HEAD + LINGER_UPD_BYTES * (unsigned)w.R_local);
+                    const unsigned my_off = lane < 8 ? 16u * (unsigned)lane : LINGER_SLOT_HEAD + LINGER_UPD_BYTES * (unsigned)r + 16u * (unsigned)(lane < 11 ? lane - 8 : 0);
+                    v4u32 c = v4u32{0u, 0u, 0u, 0u};
+                    unsigned long long gw = 0ull;
+                    int verdict = -1;
+                    long long t0 = 0;
+                    for (unsigned spins = 0; verdict < 0; spins++) {
+                        if (lane < 11) c = ld16_agent_raw(rs_s, my_off);
+                        else if (lane == 11) gw = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long ok = __ballot(lane < 11 && c.w == seq);
+                        const uint32_t has_upd = (uint32_t)__builtin_amdgcn_readlane((int)c.y, 0);
+                        unsigned long long g = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(gw >> 32), 11) << 32) |
+                                               (uint32_t)__builtin_amdgcn_readlane((int)(gw & 0xffffffffull), 11);
+                        if ((ok & 0xffull) == 0xffull && (!has_upd || (ok & 0x700ull) == 0x700ull)) { verdict = 1; break; }
+                        if (g == cur2 + 1ull) { verdict = 0; break; }
+                        if (spins == 0u) t0 = wall_clock64();
+                        if (spins < 8u) __builtin_amdgcn_s_sleep(2);
+                        else __builtin_amdgcn_s_sleep(24);
+                        if ((spins & 7u) == 7u && g <= cur2 &&
+                            (__hip_atomic_load(cold().sweep_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull || wall_clock64() - t0 > cold_plan().linger_ticks)) {
+                            unsigned long long old = 0ull;
+                            if (lane == 11) old = __hip_atomic_fetch_max(go, cur2 + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            g = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(old >> 32), 11) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(old & 0xffffffffull), 11);
+                            if (g <= cur2 + 1ull) { verdict = 0; break; }  // (more: the postman moved first — the chunks are on their way)
                         }
                     }
-                    go_on = v >= cur2 + 2ull ? 1 : 0;
+                    if (verdict == 1) {  // payload: three dwords per chunk
+                        if (lane < 8) { s_plan[3 * lane] = c.x; s_plan[3 * lane + 1] = c.y; s_plan[3 * lane + 2] = c.z; }
+                        else if (lane < 11) {
+                            uint32_t *u = reinterpret_cast<uint32_t *>(s_urec) + 3 * (lane - 8);
+                            u[0] = c.x; u[1] = c.y;
+                            if (lane < 10) u[2] = c.z;
+                        }
+                    }
+                    if (lane == 0) *s_verdict = verdict;
                 }
-                if (!__syncthreads_or(go_on)) break;  // the launch ends behind this plan
+                __syncthreads();
+                if (*s_verdict != 1) break;  // the launch ends behind this plan
                 plans_done += 1;
                 {
-                    const unsigned long long number = cold_plan().launch_seq + (unsigned long long)plans_done;
-                    const unsigned slot = (unsigned)(number & 1ull);
-                    int bad = 0;  // the slot holds another post than the go word promised (every workgroup reads the same slot: all of them leave)
-                    const unsigned char *dslot = cold_plan().linger_dev + (size_t)slot * cold_plan().linger_dev_stride;  // (device memory: the postman's copy)
-                    if (tid < LINGER_PLAN_DWORDS) {
-                        const uint32_t v = __hip_atomic_load(reinterpret_cast<const uint32_t *>(dslot) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        s_plan[tid] = v;
-                        if (tid == LINGER_PLAN_DWORDS - 2) bad = v != (uint32_t)(number & 0xffffffffull);
-                        if (tid == LINGER_PLAN_DWORDS - 1) bad = v != (uint32_t)(number >> 32);
-                    } else if (tid < LINGER_PLAN_DWORDS + 4) {
-                        const double *src = reinterpret_cast<const double *>(dslot + 128) + (size_t)r * 4;
-                        s_urec[tid - LINGER_PLAN_DWORDS] = __hip_atomic_load(src + (tid - LINGER_PLAN_DWORDS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (__syncthreads_or(bad)) {  // (nothing of the unread plan is run; the tail writes back what the plan before left; the host reports it)
-                        if (tid == 0) {  // (the word odd, whatever it holds: the postman ends with it)
-                            __hip_atomic_fetch_or(cold_plan().linger_go, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(cold().sweep_err, 0xB0C5000000000000ull | (number & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        }
-                        break;
-                    }
                     if constexpr (KT > 0) r_prior.store(s_prior, tid);
                     else copy_words(s_prior, blob + L.prior(), 20 * K, tid, NT);
                     __syncthreads();

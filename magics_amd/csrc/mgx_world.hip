@@ -1766,8 +1766,7 @@ static int ensure_linger_box(mgx_world *w) {
     HIP_TRY(hipHostMalloc((void **)&lg.box, bytes, hipHostMallocMapped));
     memset(lg.box, 0, bytes);
     lg.upd_stride = grown;
-    lg.dev_stride = 128 + grown * sizeof(double);  // the plan (LingerPlan, padded), then the records
-    static_assert(sizeof(LingerPlan) <= 128, "a device-side slot keeps 128 bytes for the plan");
+    lg.dev_stride = LINGER_SLOT_HEAD + (size_t)LINGER_UPD_BYTES * (grown / 4);  // the plan's chunks, then three chunks per robot (mgx_dev.h)
     HIP_TRY(lg.dev.reserve(2 * lg.dev_stride));
     HIP_TRY(hipMemsetAsync(lg.dev.p, 0, 2 * lg.dev_stride, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));

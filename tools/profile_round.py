@@ -65,11 +65,12 @@ def main():
     prof = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
     out = [f"# rocprofv3 summary — {tag}", "",
-           "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 40 --no-cpu-baseline --no-extras` "
-           "(tools/profile_round.sh; MI355X).  bench.py hands its 10-step ticks to the engine two at a time (mgx_batch_begin / mgx_batch_end), like "
-           "the driver's `--steps 20`: `<16, 0, false, false>`: configs[1], 20 iterations per dispatch; `<16, 2, true, false>`: configs[2], "
-           "two ticks of the 10-step schedule as ONE resident dispatch (20 iterations); `<16, 2, false, false>` (second run, `MGX_PERSISTENT=0`): "
-           "configs[2], one iteration per dispatch (template arguments: horizon, inter-robot message mode, resident, sharded).", ""]
+           "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 20 --repeats 60 --preheat-ms 20 "
+           "--no-cpu-baseline --no-extras --sustained-seconds 0` (tools/profile_round.sh; MI355X) — the driver's block shape, repeated.  Every tick "
+           "is its own mgx_iterate call: `<16, 2, true, false>`: configs[2], a timed block is ONE resident dispatch of 20 iterations (the first tick "
+           "launches it, the second is posted into the lingering launch, the closing synchronisation ends it); `<16, 0, false, false>`: configs[1] "
+           "(ticks bracketed two at a time, 20 iterations per dispatch); `<16, 2, false, false>` (second run, `MGX_PERSISTENT=0`): configs[2], one "
+           "iteration per dispatch (template arguments: horizon, inter-robot message mode, resident, sharded).", ""]
     for sub, name in (("_kt", "kernel_stats"), ("_kt_np", "kernel_stats_launch_per_iteration"), ("_cfg", "configs_kernel_stats")):
         f = glob.glob(os.path.join(g + sub, "**", "*kernel_stats.csv"), recursive=True)
         if f:
@@ -86,7 +87,7 @@ def main():
     for k, (avg, n) in sorted(dur.items()):
         out.append(f"| k_robot_sweep{k} | {n} | {avg:.2f} |")
     traffic = {"_kernel_digest": kernel_digest(), "_source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, tools/profile_round.sh) on `python3 bench.py "
-                          f"--steps 200 --warmup 50 --no-cpu-baseline --no-extras`, MI355X, round {tag}.  KiB per dispatch as reported; per "
+                          f"--steps 20 --warmup 20 --repeats 60 --no-cpu-baseline --no-extras`, MI355X, round {tag}.  KiB per dispatch as reported; per "
                           "MI355X_MICROARCH.md (HBM section) gfx950 FETCH_SIZE counts half the bytes of wide 16-B-per-lane streaming reads, so "
                           "bench.py doubles the reads (an upper bound here: part of the staging uses 8-B loads)."}
     keys = {"<16, 0, false, false>": ("config1", ""), "<16, 2, true, false>": ("config2_resident", ""), "<16, 2, false, false>": ("config2", "_np")}
@@ -97,6 +98,7 @@ def main():
             "driver's, relate to these counters through it).", "",
             "| instantiation | FETCH_SIZE KiB | WRITE_SIZE KiB | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES | SQ_WAIT_ANY / SQ_WAVE_CYCLES | kernel trace avg us | GRBM_GUI_ACTIVE / 8, k cycles | us in the counter passes (FETCH / WRITE / SQ / GRBM) |", "|---|---|---|---|---|---|---|---|---|"]
     clock_pts = []
+    f64_rows = []
     # iterations per dispatch: what the profiled bench run itself reported (its JSON line)
     iters = {"config2": 1}
     try:
@@ -109,9 +111,13 @@ def main():
         f = per_kernel(g + "_pmc_FETCH_SIZE" + suf, "FETCH_SIZE").get(inst)
         w = per_kernel(g + "_pmc_WRITE_SIZE" + suf, "WRITE_SIZE").get(inst)
         sq = {c: per_kernel(g + "_pmc_SQ_INSTS_VALU" + suf, c).get(inst) for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY")}
+        f64 = {c: per_kernel(g + "_pmc_SQ_INSTS_VALU_ADD_F64" + suf, c).get(inst)
+               for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_THREAD_CYCLES_VALU",
+                         "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_SALU")}
         d_us = (dur.get(inst + (" (MGX_PERSISTENT=0)" if suf else "")) or (None, 0))[0]
         gui = per_kernel(g + "_pmc_GRBM_GUI_ACTIVE" + suf, "GRBM_GUI_ACTIVE").get(inst)
         pd = [pass_durations(g + "_pmc_" + nm + suf).get(inst) for nm in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")]
+        pd_f64 = pass_durations(g + "_pmc_SQ_INSTS_VALU_ADD_F64" + suf).get(inst)
         clock = None
         if gui and pd[3]:
             clock_pts.append((suf, pd[3], gui / 8.0))  # (pass, us, cycles per XCD)
@@ -128,6 +134,22 @@ def main():
                 ent["valu_busy_pct"] = round(busy, 1)
             if sq["SQ_WAIT_ANY"] and sq["SQ_WAVE_CYCLES"]:
                 ent["wait_pct"] = round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"] * 100.0, 1)
+        if f64.get("SQ_INSTS_VALU") and f64.get("SQ_INSTS_VALU_ADD_F64") is not None:
+            n64 = sum(f64[c] or 0.0 for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+            flops_w = (f64["SQ_INSTS_VALU_ADD_F64"] or 0.0) + (f64["SQ_INSTS_VALU_MUL_F64"] or 0.0) + 2.0 * (f64["SQ_INSTS_VALU_FMA_F64"] or 0.0) + \
+                      (f64["SQ_INSTS_VALU_TRANS_F64"] or 0.0)
+            ent["f64_wave_instr"] = round(n64)
+            ent["f64_by_kind"] = {k.replace("SQ_INSTS_VALU_", "").lower(): round(f64[k] or 0.0) for k in
+                                  ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")}
+            ent["f64_flops_per_wave_instr"] = round(flops_w / n64, 4) if n64 else 1.0  # (per lane: an FMA counts 2)
+            ent["valu_wave_instr_f64_pass"] = round(f64["SQ_INSTS_VALU"])
+            ent["salu_instr"] = round(f64["SQ_INSTS_SALU"] or 0.0)
+            if f64.get("SQ_THREAD_CYCLES_VALU") and f64.get("SQ_ACTIVE_INST_VALU"):
+                # rocprofiler's VALUUtilization: the share of a wave's 64 lanes active in the VALU instructions it issues
+                ent["lane_occupancy"] = round(f64["SQ_THREAD_CYCLES_VALU"] / (f64["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
+            f64_rows.append(f"| k_robot_sweep{inst} | {f64['SQ_INSTS_VALU']:.4g} | {n64:.4g} ({n64 / f64['SQ_INSTS_VALU'] * 100:.1f} %) | "
+                            f"{f64['SQ_INSTS_VALU_ADD_F64'] or 0:.4g} / {f64['SQ_INSTS_VALU_MUL_F64'] or 0:.4g} / {f64['SQ_INSTS_VALU_FMA_F64'] or 0:.4g} / "
+                            f"{f64['SQ_INSTS_VALU_TRANS_F64'] or 0:.4g} | {ent.get('lane_occupancy', 0) * 100:.1f} % | {f64['SQ_INSTS_SALU'] or 0:.4g} |")
         if d_us:
             ent["kernel_trace_avg_us"] = round(d_us, 2)
         if gui:
@@ -137,6 +159,11 @@ def main():
         out.append(f"| k_robot_sweep{inst} | {f:.1f} | {w:.1f} | {sq['SQ_INSTS_VALU'] or 0:.4g} | VALU active {busy or 0:.1f} % of wave-cycles | "
                    f"{(sq['SQ_WAIT_ANY'] or 0) / (sq['SQ_WAVE_CYCLES'] or 1) * 100:.0f} % waiting | {d_us or 0:.2f} | {(gui or 0) / 8e3:.1f} | "
                    + " / ".join(f"{x:.1f}" if x else "-" for x in pd) + " |")
+    if f64_rows:
+        out += ["", "### what the VALU instructions are (pass `SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 SQ_THREAD_CYCLES_VALU ...`)", "",
+                "SQ_INSTS_VALU counts EVERY VALU wave-instruction; the f64 arithmetic among them by kind; lane occupancy = SQ_THREAD_CYCLES_VALU / "
+                "(SQ_ACTIVE_INST_VALU x 64), the share of a wave's 64 lanes its VALU instructions keep busy (rocprofiler's VALUUtilization).", "",
+                "| instantiation | SQ_INSTS_VALU | of which f64 | add / mul / fma / trans | lane occupancy | SQ_INSTS_SALU |", "|---|---|---|---|---|---|"] + f64_rows
     same = [pt for pt in clock_pts if pt[0] == ""]
     if len(same) >= 2:
         a, b = max(same, key=lambda t: t[1]), min(same, key=lambda t: t[1])

@@ -10,11 +10,13 @@ tag=${1:-r04}
 part=${2:-ab}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-# (200 steps = 20 ticks, handed to the engine two at a time like the driver's 20 steps: every dispatch of the timed blocks holds 20
-# iterations; 40 warm-up steps for the same reason)
-B="python3 bench.py --steps 200 --warmup 40 --no-cpu-baseline --no-extras --sustained-seconds 0"
+# (the driver's own block shape — 20 steps = 2 ticks, one mgx_iterate call each: the first launches, the second is posted into the
+# lingering launch, the closing synchronisation ends it — repeated often: every dispatch of the timed blocks holds 20 iterations)
+B="python3 bench.py --steps 20 --warmup 20 --repeats 60 --preheat-ms 20 --no-cpu-baseline --no-extras --sustained-seconds 0"
 out=gpurun_out/${tag}
 SQ="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
+# what the VALU instructions ARE (f64 arithmetic by kind) and how many of a wave's 64 lanes they keep busy
+F64="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU"
 if [[ $part == *a* ]]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_kt -- $B > ${out}_kt.json 2> ${out}_kt.err || exit 1
   echo "kernel trace done"
@@ -22,7 +24,7 @@ if [[ $part == *a* ]]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_kt_driver -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > ${out}_kt_driver.json 2> ${out}_kt_driver.err || exit 1
   echo "driver command done"
   # (GRBM_GUI_ACTIVE: shader-clock cycles per dispatch — with the dispatch's duration the clock the box ran at)
-  for pass in "FETCH_SIZE" "WRITE_SIZE" "$SQ" "GRBM_GUI_ACTIVE"; do
+  for pass in "FETCH_SIZE" "WRITE_SIZE" "$SQ" "$F64" "GRBM_GUI_ACTIVE"; do
     name=$(echo $pass | cut -d' ' -f1)
     rocprofv3 --pmc $pass --kernel-trace --output-format csv -d ${out}_pmc_${name} -- $B > ${out}_pmc_${name}.json 2> ${out}_pmc_${name}.err || exit 1
     export MGX_PERSISTENT=0
