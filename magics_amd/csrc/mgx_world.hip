@@ -1795,8 +1795,9 @@ static void linger_confirm(mgx_world *w) {
 }
 // The launch has ended (closed word c = 2 S + 1: behind plan S).  A post it never took is taken back and run as a launch of its
 // own — from the same records, nothing lost and nothing twice.
-static int linger_settle(mgx_world *w) {
+static int linger_settle(mgx_world *w, bool nested = false) {  // nested: on the way to the NEXT schedule (whose launches are counted apart)
     mgx_world::Linger &lg = w->linger;
+    const uint32_t count_before = w->last_sweep_launches;
     const unsigned long long c = __atomic_load_n(&lg.box->closed, __ATOMIC_ACQUIRE);
     lg.open = false;
     int rc = MGX_OK;
@@ -1809,6 +1810,7 @@ static int linger_settle(mgx_world *w) {
             lg.reruns++;
             w->d.cur = un.cur_before;
             w->flag_base = un.flag_base_before;
+            w->last_sweep_launches = 0;  // (how the schedule that was posted ran after all: what mgx_last_launch_count says of it)
             void *hp = nullptr, *dp = nullptr;
             int slot = -1;
             if (un.has_upd) {  // (a copy in the pinned ring: the box's slot belongs to the posts of the launch that follows)
@@ -1840,6 +1842,7 @@ static int linger_settle(mgx_world *w) {
             }
         }
     }
+    if (nested) w->last_sweep_launches = count_before;
     if (lg.taken_in_launch == 0) lg.useless++;
     else lg.useless = 0;
     return rc;
@@ -1876,9 +1879,11 @@ static int linger_prepare_post(mgx_world *w, const std::vector<Launch> &plan) {
     mgx_world::Linger &lg = w->linger;
     if (!lg.open) return 0;
     if (w->pending.active) {  // the launch's own census first (one launch of run-ahead, as ever)
+        const uint32_t count_before = w->last_sweep_launches;  // (a declined launch is run again here: not the coming schedule's launches)
         lg.hold = true;
         const int rc = confirm_resident(w);
         lg.hold = false;
+        w->last_sweep_launches = count_before;
         if (rc != MGX_OK) return rc;
         if (!lg.open) return 0;
     }
@@ -1898,7 +1903,7 @@ static int linger_prepare_post(mgx_world *w, const std::vector<Launch> &plan) {
     if (r < 0) return r;
     if (r == 1) {  // the launch ended meanwhile (its workgroups waited out their bound)
         lg.ended_by_device++;
-        const int rc = linger_settle(w);
+        const int rc = linger_settle(w, true);
         return rc != MGX_OK ? rc : 0;
     }
     return 1;

@@ -48,7 +48,9 @@ def durations(d):
     tr.sort(key=lambda r: int(r["Start_Timestamp"]))
     for r in tr:
         acc[r["Kernel_Name"].split("k_robot_sweep")[1].split(">")[0] + ">"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    return {k: (sum(v[len(v) // 5:]) / len(v[len(v) // 5:]), len(v)) for k, v in acc.items()}
+    # (the MEDIAN beside the mean: under the driver's command one dispatch of the resident kernel is a whole `sustained` block —
+    # seconds of ticks posted into one lingering launch)
+    return {k: (sum(v[len(v) // 5:]) / len(v[len(v) // 5:]), len(v), sorted(v)[len(v) // 2]) for k, v in acc.items()}
 
 
 def kernel_digest():
@@ -83,9 +85,9 @@ def main():
     dur = durations(g + "_kt")
     dur.update({k + " (MGX_PERSISTENT=0)": v for k, v in durations(g + "_kt_np").items()})
     dur.update({k + " (the driver's command: --gpus 1 --steps 20 --warmup 5)": v for k, v in durations(g + "_kt_driver").items()})
-    out += ["## steady-state dispatch durations (kernel trace)", "", "| instantiation | dispatches | avg us |", "|---|---|---|"]
-    for k, (avg, n) in sorted(dur.items()):
-        out.append(f"| k_robot_sweep{k} | {n} | {avg:.2f} |")
+    out += ["## steady-state dispatch durations (kernel trace)", "", "| instantiation | dispatches | avg us | median us |", "|---|---|---|---|"]
+    for k, (avg, n, med) in sorted(dur.items()):
+        out.append(f"| k_robot_sweep{k} | {n} | {avg:.2f} | {med:.2f} |")
     traffic = {"_kernel_digest": kernel_digest(), "_source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, tools/profile_round.sh) on `python3 bench.py "
                           f"--steps 20 --warmup 20 --repeats 60 --no-cpu-baseline --no-extras`, MI355X, round {tag}.  KiB per dispatch as reported; per "
                           "MI355X_MICROARCH.md (HBM section) gfx950 FETCH_SIZE counts half the bytes of wide 16-B-per-lane streaming reads, so "
@@ -181,7 +183,7 @@ def main():
                 "| instantiation | dispatches | avg us | FETCH_SIZE KiB | WRITE_SIZE KiB | SQ_INSTS_VALU | VALU active % of wave-cycles | waiting % |", "|---|---|---|---|---|---|---|---|"]
         cf, cw = per_kernel(g + "_cfg_pmc_FETCH_SIZE", "FETCH_SIZE"), per_kernel(g + "_cfg_pmc_WRITE_SIZE", "WRITE_SIZE")
         csq = {c: per_kernel(g + "_cfg_pmc_SQ_INSTS_VALU", c) for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY")}
-        for inst, (avg, n) in sorted(cdur.items()):
+        for inst, (avg, n, _med) in sorted(cdur.items()):
             wc = csq["SQ_WAVE_CYCLES"].get(inst) or 0
             out.append(f"| k_robot_sweep{inst} | {n} | {avg:.2f} | {cf.get(inst, 0):.1f} | {cw.get(inst, 0):.1f} | {csq['SQ_INSTS_VALU'].get(inst, 0):.4g} | "
                        f"{(csq['SQ_ACTIVE_INST_VALU'].get(inst, 0) / wc * 100) if wc else 0:.1f} | {(csq['SQ_WAIT_ANY'].get(inst, 0) / wc * 100) if wc else 0:.0f} |")
