@@ -371,6 +371,18 @@ struct Incoming {
 };
 struct Launch { uint32_t ext; int n_int; uint32_t hints; };  // one [external iteration] internal* segment of a schedule
 
+// Who points at whom, kept IN STEP with the connection list (ir_connect, ir_disconnect_batch) instead of being derived from it in
+// two passes over every connection whenever a topology pass has changed something: per robot id the connections it is the TARGET
+// of — in the order of its variables' inboxes (owner's order key, then node slot: build_incoming) — and the ones it OWNS (no
+// order).  Entries are indices into the connection list, which closes its holes by moving the last survivors into them: a move
+// rewrites the mover's two entries.  Anything the index is not told about (ir_disconnect, a robot that changes sides) just
+// invalidates it: the next use builds it again from the list.
+struct ConnIndex {
+    bool valid = false;
+    bool interleaved = false;  // node slots of two connections of one owner towards one target interleave (never: reported)
+    std::vector<std::vector<int32_t>> in, out;
+};
+
 struct mgx_world {
     mgx_params p{};
     std::vector<Robot> robots;  // ids = indices; ghosts may interleave on the host, device order below
@@ -496,6 +508,7 @@ struct mgx_world {
         uint8_t has_fresh;  // some edge still carries `fresh` (created since the device tables were last laid out) — kept HERE only
     };
     std::vector<ConnHot> conn_hot;
+    ConnIndex cidx;
     Incoming retopo_tables;               // retopo's host tables and slot records (storage kept from tick to tick)
     std::vector<IrSlotRec> retopo_slots;
     // missions on the device (mgx_mission_*): host copies of what mgx_mission_set gave, the device arrays, the
@@ -1043,6 +1056,97 @@ static size_t edge_index(const std::vector<int32_t> &in_ptr, int K, int r, int j
     const int n_in = in_ptr[(size_t)r + 1] - in_ptr[(size_t)r];
     return (size_t)(K - 1) * (size_t)in_ptr[(size_t)r] + (size_t)j * (size_t)n_in + (size_t)(slot - in_ptr[(size_t)r]);
 }
+// ---- the connection index (ConnIndex) ------------------------------------------------------------------------------------------
+static bool conn_before(const mgx_world *w, int32_t a, int32_t b, bool *interleaved) {  // the inbox order of two connections of one target
+    const mgx_world::ConnHot &ca = w->conn_hot[(size_t)a], &cb = w->conn_hot[(size_t)b];
+    const uint64_t ka = w->sets.keys[(size_t)ca.owner], kb = w->sets.keys[(size_t)cb.owner];
+    if (ka != kb) return ka < kb;
+    if ((ca.node_first < cb.node_first) != (ca.node_last < cb.node_last)) *interleaved = true;
+    return ca.node_first < cb.node_first;
+}
+static void conn_index_add(mgx_world *w, int32_t ci) {
+    ConnIndex &x = w->cidx;
+    const mgx_world::ConnHot &c = w->conn_hot[(size_t)ci];
+    std::vector<int32_t> &lst = x.in[(size_t)c.other];
+    size_t at = lst.size();
+    while (at > 0 && conn_before(w, ci, lst[at - 1], &x.interleaved)) at--;
+    lst.insert(lst.begin() + (long)at, ci);
+    x.out[(size_t)c.owner].push_back(ci);
+}
+static void conn_index_rebuild(mgx_world *w) {
+    ConnIndex &x = w->cidx;
+    const size_t n = w->robots.size();
+    x.in.assign(n, {});
+    x.out.assign(n, {});
+    x.interleaved = false;
+    for (size_t ci = 0; ci < w->conn_hot.size(); ci++) conn_index_add(w, (int32_t)ci);
+    x.valid = true;
+}
+static void conn_index_ensure(mgx_world *w) {
+    if (!w->cidx.valid || w->cidx.in.size() != w->robots.size()) conn_index_rebuild(w);
+}
+static void conn_index_drop(mgx_world *w, int32_t ci) {  // connection ci leaves the list
+    ConnIndex &x = w->cidx;
+    const mgx_world::ConnHot &c = w->conn_hot[(size_t)ci];
+    std::vector<int32_t> &a = x.in[(size_t)c.other], &b = x.out[(size_t)c.owner];
+    a.erase(std::find(a.begin(), a.end(), ci));
+    b.erase(std::find(b.begin(), b.end(), ci));
+}
+static void conn_index_moved(mgx_world *w, int32_t from, int32_t to) {  // connection `from` now sits at `to` (conn_hot[to] holds it already)
+    ConnIndex &x = w->cidx;
+    const mgx_world::ConnHot &c = w->conn_hot[(size_t)to];
+    std::vector<int32_t> &a = x.in[(size_t)c.other], &b = x.out[(size_t)c.owner];
+    *std::find(a.begin(), a.end(), from) = to;
+    *std::find(b.begin(), b.end(), from) = to;
+}
+// build_incoming from the index: O(local robots + their connections), no pass over the whole list, no sorting
+static void build_incoming_indexed(mgx_world *w, int R_local, Incoming &t, bool want_peers) {
+    const int K = w->K;
+    const ConnIndex &x = w->cidx;
+    const uint64_t *key = w->sets.keys.data();
+    const int32_t *dev_of = w->dev_of.data();
+    const mgx_world::ConnHot *conns = w->conn_hot.data();
+    const size_t R = (size_t)R_local;
+    t.in_ptr.assign(R + 1, 0);
+    t.mid.assign((size_t)std::max(R_local, 1), 0);
+    t.blocks_ok = !x.interleaved;
+    t.ir_max_edges = 0;
+    size_t n_in_all = 0, n_peer_all = 0;
+    for (size_t r = 0; r < R; r++) {
+        const size_t id = (size_t)w->robot_of[r];
+        n_in_all += x.in[id].size();
+        n_peer_all += x.in[id].size() + x.out[id].size();
+        t.in_ptr[r + 1] = (int32_t)n_in_all;
+    }
+    t.in_list.resize(n_in_all);
+    t.peers.clear();
+    int32_t *pp = nullptr, *pidx = nullptr;
+    if (want_peers) {
+        t.peers.assign(R + 1 + std::max<size_t>(n_peer_all, 1), 0);
+        pp = t.peers.data();
+        pidx = pp + R + 1;
+    }
+    size_t pw = 0;
+    for (size_t r = 0; r < R; r++) {
+        const size_t id = (size_t)w->robot_of[r];
+        const std::vector<int32_t> &lst = x.in[id];
+        const int n_in = (int)lst.size();
+        if (n_in) memcpy(t.in_list.data() + t.in_ptr[r], lst.data(), sizeof(int32_t) * (size_t)n_in);
+        const uint64_t own_key = key[id];
+        int mid = n_in;  // first connection whose owner has a HIGHER key than the target
+        for (int q = n_in - 1; q >= 0; q--)
+            if (key[(size_t)conns[(size_t)lst[(size_t)q]].owner] > own_key) mid = q;
+        t.mid[r] = mid;
+        t.ir_max_edges = std::max(t.ir_max_edges, n_in * (K - 1));
+        if (pp) {
+            for (int32_t ci : lst) pidx[pw++] = dev_of[(size_t)conns[(size_t)ci].owner];
+            for (int32_t ci : x.out[id]) pidx[pw++] = dev_of[(size_t)conns[(size_t)ci].other];
+            pp[r + 1] = (int32_t)pw;
+        }
+    }
+    if (pp) t.peers.resize(R + 1 + std::max<size_t>(pw, 1));
+}
+
 static void build_incoming(const mgx_world *w, int R_local, Incoming &t, bool want_peers = false) {
     const int K = w->K;
     const uint64_t *key = w->sets.keys.data();  // (compact copies of the robots' order keys and ghost flags: a Robot is a dozen vectors wide)
@@ -1139,7 +1243,27 @@ static int retopo(mgx_world *w) {
     Incoming &t = w->retopo_tables;
     // (a world whose schedules can run as resident launches gets that kernel's peer table from the same passes, in the same block)
     const bool want_peers = (w->d.R_total == w->d.R_local || w->xres.connected) && (w->p.enable_mask & 2u) && w->sweep_flag_buf.p;
-    build_incoming(w, R_local, t, want_peers);
+    conn_index_ensure(w);
+    build_incoming_indexed(w, R_local, t, want_peers);
+    static const bool check_index = getenv("MGX_CHECK_INDEX") != nullptr;
+    if (check_index) {  // (diagnostics: the tables of the index against the two passes over the list they replace)
+        Incoming full;
+        build_incoming(w, R_local, full, want_peers);
+        bool same = full.in_ptr == t.in_ptr && full.in_list == t.in_list && full.mid == t.mid && full.ir_max_edges == t.ir_max_edges &&
+                    full.blocks_ok == t.blocks_ok && full.peers.size() == t.peers.size();
+        if (same && want_peers) {
+            for (size_t r = 0; r < (size_t)R_local && same; r++) {  // (a row's order carries no meaning: compared as multisets)
+                same = full.peers[r + 1] == t.peers[r + 1];
+                if (!same) break;
+                std::vector<int32_t> a(full.peers.begin() + R_local + 1 + full.peers[r], full.peers.begin() + R_local + 1 + full.peers[r + 1]),
+                    b(t.peers.begin() + R_local + 1 + t.peers[r], t.peers.begin() + R_local + 1 + t.peers[r + 1]);
+                std::sort(a.begin(), a.end());
+                std::sort(b.begin(), b.end());
+                same = a == b;
+            }
+        }
+        if (!same) return fail(MGX_ERR_STATE, "internal: the connection index and the connection list disagree (MGX_CHECK_INDEX)");
+    }
     tm.lap("build_incoming");
     if (!t.blocks_ok) return fail(MGX_ERR_STATE, "internal: node slots of two connections interleave");
     const size_t n_slots = t.in_list.size(), NI = n_slots * (size_t)(K - 1), NIs = std::max<size_t>(NI, 1);
@@ -2312,6 +2436,8 @@ static int ir_connect(mgx_world *w, int32_t owner, int32_t other, uint64_t first
     c.node_last = c.node.back();
     w->conn_hot.push_back(mgx_world::ConnHot{c.owner, c.other, c.node_first, c.node_last, c.first_number, -1, 1});
     w->conns.push_back(std::move(c));
+    if (w->cidx.valid && w->cidx.in.size() == w->robots.size()) conn_index_add(w, (int32_t)w->conn_hot.size() - 1);
+    else w->cidx.valid = false;
     w->conns_dirty = true;
     return MGX_OK;
 }
@@ -2331,6 +2457,7 @@ static int ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
         std::vector<int> &fr = w->robots[(size_t)self].free_nodes;
         fr.insert(fr.end(), gone.begin(), gone.end());
     }
+    w->cidx.valid = false;  // (the list closes up: every index behind the holes moves)
     w->conns.erase(std::remove_if(w->conns.begin(), w->conns.end(),
                                   [&](const IrConn &c) { return (c.owner == a && c.other == b) || (c.owner == b && c.other == a); }),
                    w->conns.end());
@@ -2348,44 +2475,30 @@ static int ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
 // Several (a, b) deletions in one sweep over the connections (a topology pass deletes dozens):
 // same effect as ir_disconnect(a, b) for each pair in order.
 // the connections listed by owner (what a batch of deletions looks its pairs up in)
-struct OwnerLists {
-    std::vector<int32_t> out_ptr, out;
-    bool valid = false;
-    void build(const mgx_world *w) {
-        const size_t n = w->robots.size();
-        out_ptr.assign(n + 1, 0);
-        for (const IrConn &c : w->conns) out_ptr[(size_t)c.owner + 1]++;
-        for (size_t r = 0; r < n; r++) out_ptr[r + 1] += out_ptr[r];
-        out.resize(w->conns.size());
-        std::vector<int32_t> fill(out_ptr.begin(), out_ptr.end() - 1);
-        for (size_t ci = 0; ci < w->conns.size(); ci++) out[(size_t)fill[(size_t)w->conns[ci].owner]++] = (int32_t)ci;
-        valid = true;
-    }
-};
-static void ir_disconnect_batch(mgx_world *w, const std::vector<std::pair<int, int>> &pairs, OwnerLists *prebuilt = nullptr) {
+static void ir_disconnect_batch(mgx_world *w, const std::vector<std::pair<int, int>> &pairs) {
     if (pairs.empty()) return;
     StageTimer tm("ir_disconnect_batch");
     flush_counts(w);
     tm.lap("flush_counts");
-    OwnerLists own_lists;
-    if (!prebuilt || !prebuilt->valid) { own_lists.build(w); prebuilt = &own_lists; }
-    const std::vector<int32_t> &out_ptr = prebuilt->out_ptr, &out = prebuilt->out;
+    conn_index_ensure(w);  // (who owns what: the index' `out` lists)
     std::vector<uint8_t> dead(w->conns.size(), 0);
+    std::vector<int32_t> dead_list;
     for (const auto &pr : pairs)
         for (int side = 0; side < 2; side++) {
             const int self = side ? pr.second : pr.first, other = side ? pr.first : pr.second;
             std::vector<int> gone;  // node slots are vacated in ascending index order (factorgraph.rs:380-436)
-            for (int32_t q = out_ptr[(size_t)self]; q < out_ptr[(size_t)self + 1]; q++) {
-                const int32_t ci = out[(size_t)q];
+            for (const int32_t ci : w->cidx.out[(size_t)self]) {
                 const IrConn &c = w->conns[(size_t)ci];
                 if (dead[(size_t)ci] || c.other != other) continue;
                 dead[(size_t)ci] = 1;
+                dead_list.push_back(ci);
                 gone.insert(gone.end(), c.node.begin(), c.node.end());
             }
             std::sort(gone.begin(), gone.end());
             std::vector<int> &fr = w->robots[(size_t)self].free_nodes;
             fr.insert(fr.end(), gone.begin(), gone.end());
         }
+    for (const int32_t ci : dead_list) conn_index_drop(w, ci);
     // the list's order carries no meaning (inbox order comes from order keys and node slots, build_incoming): the last
     // survivors fill the holes
     {
@@ -2396,6 +2509,7 @@ static void ir_disconnect_batch(mgx_world *w, const std::vector<std::pair<int, i
             if (lo >= hi) break;
             w->conns[lo] = std::move(w->conns[hi - 1]);  // dead[lo], alive[hi - 1]
             w->conn_hot[lo] = w->conn_hot[hi - 1];
+            conn_index_moved(w, (int32_t)(hi - 1), (int32_t)lo);
             dead[lo] = 0;
             hi--;
         }
@@ -2802,7 +2916,7 @@ int mgx_connections(mgx_world *w, int32_t robot, int32_t *others, uint32_t capac
 }
 
 static int topology_bookkeeping(mgx_world *w, std::vector<int32_t> &ptr, std::vector<int32_t> &idx, uint64_t *robot_number_next,
-                                uint32_t *stats, StageTimer &tm, OwnerLists *own_lists);
+                                uint32_t *stats, StageTimer &tm);
 int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, uint32_t method, uint64_t *robot_number_next,
                         uint32_t *stats) {
     MGX_ENTER(w);
@@ -2814,35 +2928,24 @@ int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, 
     // update_robot_neighbours (robot.rs:1362-1384).  A small world's search runs BESIDE the GBP schedule of the tick before, on a
     // stream of its own — but it must not get onto the device before that schedule's resident launch has all its workgroups
     // there: enqueued a few microseconds behind the launch, its waves took slots the launch's last workgroups needed, the
-    // residency census said no and the tick ran launch by launch (seen: three of sixty ticks, 0.8 ms each).  So the host
-    // lists the connections by owner first — that needs nothing from the device — and only then, with the launch decided
-    // (microseconds after its start), enqueues the search; the message counters are brought up to date under it (the pass
-    // is about to change who sends to whom).
-    // (owner lists first only if the search has to wait for the launch's decision anyway: otherwise it gets their head start)
-    const bool decided = !w->pending.active || (__atomic_load_n(w->decision_host, __ATOMIC_ACQUIRE) >> 2) >= w->pending.seq;
-    OwnerLists own_lists;
-    if (!decided) {
-        own_lists.build(w);
-        tm.lap("owner lists");
-    }
+    // residency census said no and the tick ran launch by launch (seen: three of sixty ticks, 0.8 ms each).  So the search is
+    // enqueued only with the launch decided (microseconds after its start); the message counters are brought up to date
+    // under it (the pass is about to change who sends to whom).  (Who owns which connection — what the deletions walk —
+    // comes from the connection index, kept in step with the list: round 4 listed the connections by owner here, every tick.)
     mgx_world::PendingSearch ps;
     int rc = neighbours_enqueue(w, positions_xyz, radius, method, ps);  // (waits for the launch to be decided first if it has to)
     if (rc != MGX_OK) return rc;
     tm.lap("search enqueued");
-    if (decided) {
-        own_lists.build(w);
-        tm.lap("owner lists (under the search)");
-    }
     flush_counts(w);
     tm.lap("message counters (under the search)");
     rc = neighbours_collect(w, ps, ptr, idx);
     if (rc != MGX_OK) return rc;
     tm.lap("neighbour search");
-    return topology_bookkeeping(w, ptr, idx, robot_number_next, stats, tm, &own_lists);
+    return topology_bookkeeping(w, ptr, idx, robot_number_next, stats, tm);
 }
 // delete_interrobot_factors + create_interrobot_factors on the search's result (rows per robot id, ascending)
 static int topology_bookkeeping(mgx_world *w, std::vector<int32_t> &ptr, std::vector<int32_t> &idx, uint64_t *robot_number_next,
-                                uint32_t *stats, StageTimer &tm, OwnerLists *own_lists) {
+                                uint32_t *stats, StageTimer &tm) {
     int rc = MGX_OK;
     const int n = (int)w->robots.size();
     uint32_t created = 0, deleted = 0;
@@ -2889,7 +2992,7 @@ static int topology_bookkeeping(mgx_world *w, std::vector<int32_t> &ptr, std::ve
         std::vector<std::pair<int, int>> pairs;
         for (int r = 0; r < n; r++)
             if (victim[(size_t)r] >= 0) pairs.emplace_back(r, victim[(size_t)r]);
-        ir_disconnect_batch(w, pairs, own_lists);
+        ir_disconnect_batch(w, pairs);
         deleted = (uint32_t)pairs.size();
         tm.lap("delete");
     }
@@ -3084,7 +3187,7 @@ int mgx_mission_tick_begin(mgx_world *w, float comms_radius, uint32_t method, ui
         }
     }
     uint32_t st[2] = {0, 0};
-    rc = topology_bookkeeping(w, ptr, idx, robot_number_next, st, tm, nullptr);
+    rc = topology_bookkeeping(w, ptr, idx, robot_number_next, st, tm);
     if (rc != MGX_OK) return rc;
     if (stats) { stats[0] = st[0]; stats[1] = st[1]; stats[2] = n_fin; }
     ms.in_tick = true;
