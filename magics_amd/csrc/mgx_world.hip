@@ -263,6 +263,12 @@ struct IrConn {  // K-1 factors owner -> other
     // update counts as sent / received.
     uint64_t updates_per_sweep = 0;
     int node_first = 0, node_last = 0;  // node[0], node.back(): what orders two connections of one owner in an inbox
+    // Everything `cnt` counts is a function of what its two robots have run since the counters were last brought up to date
+    // (internal / external variable sweeps, external factor sweeps, prior changes of variables that carry inter-robot factors:
+    // mgx_world::cum) under flags that do not change in between — so a connection is SETTLED (settle_conn) only when somebody
+    // needs its numbers: a read, a switch of flags or kinds, its deletion; the per-tick topology pass no longer walks every
+    // connection for it.  base: the robots' cumulative counts when the connection was settled last.
+    uint64_t base[5] = {0, 0, 0, 0, 0};  // owner's nIv, target's nEv, owner's nEf, owner's / target's prior changes
     std::vector<IrEdge> edges;  // index i-1 for variable i
     std::vector<int> node;      // node slot of each factor in the owner's graph
     // Factors created while their kind is switched off drop the two messages that would have filled their inbox
@@ -509,6 +515,10 @@ struct mgx_world {
     };
     std::vector<ConnHot> conn_hot;
     ConnIndex cidx;
+    // per robot, cumulative since the world began: internal variable sweeps run, external variable sweeps, external factor sweeps,
+    // prior changes of variables that carry inter-robot factors — what the connections' counters are settled against (IrConn::base)
+    struct Cum { std::vector<uint64_t> nIv, nEv, nEf, on_ir; } cum;
+    bool conns_unsettled = false;  // some flush since the last full one left the connections' counters behind (lazy)
     Incoming retopo_tables;               // retopo's host tables and slot records (storage kept from tick to tick)
     std::vector<IrSlotRec> retopo_slots;
     // missions on the device (mgx_mission_*): host copies of what mgx_mission_set gave, the device arrays, the
@@ -645,6 +655,8 @@ struct mgx_world {
 };
 
 static size_t edge_index(const std::vector<int32_t> &in_ptr, int K, int r, int j, int slot);
+static void flush_counts(mgx_world *w, bool lazy = false);
+static void conn_index_ensure(mgx_world *w);
 
 // mgx_batch_begin .. mgx_batch_end (below, in front of mgx_iterate): every other call on the world first submits the schedules
 // recorded so far, so that it finds the world as if each one had run when it was issued
@@ -872,21 +884,55 @@ static int pull(mgx_world *w) {
 // launches are only logged, and the counters are brought up to date whenever one of those inputs
 // is about to change or a count is asked for.
 
-static void flush_counts(mgx_world *w) {
+// A connection's counters brought up to date against its robots' cumulative counts (IrConn::base; the flags and the enabled kinds
+// have not changed since it was settled last: whoever changes them settles everything first — flush_counts in full).
+static void settle_conn(mgx_world *w, IrConn &c) {
+    const size_t o = (size_t)c.owner, t = (size_t)c.other;
+    const mgx_world::Cum &cu = w->cum;
+    const uint64_t now[5] = {cu.nIv[o], cu.nEv[t], cu.nEf[o], cu.on_ir[o], cu.on_ir[t]};
+    uint64_t d[5];
+    for (int q = 0; q < 5; q++) { d[q] = now[q] - c.base[q]; c.base[q] = now[q]; }
+    if (!(w->p.enable_mask & 2u)) return;
+    const uint64_t K1 = (uint64_t)(w->K - 1);
+    const Robot &ra = w->robots[o], &rb = w->robots[t];
+    const bool radio_a = ra.antenna && !ra.idle, radio_b = rb.antenna && !rb.idle;
+    c.cnt[2] += d[3];                          // the owner's own variable delivers to its factor (change_prior)
+    c.cnt[3] += d[4];                          // the foreign variable delivers to it
+    c.cnt[2] += d[0] * K1;                     // own variables' responses (internal sweeps)
+    if (radio_a) c.cnt[3] += d[1] * K1;        // the foreign variables' responses (robot.rs:1842-1858)
+    const uint64_t sent = d[2] * c.updates_per_sweep;  // external factor sweeps: one message per key
+    c.cnt[0] += sent;
+    c.cnt[1] += sent;
+    if (radio_b) w->robots[t].cnt[3] += sent;  // delivered (robot.rs:1813-1831)
+}
+
+// lazy: the robots' own counters and cumulative counts only — the connections stay as they are until somebody needs them settled
+// (the per-tick topology pass: what it deletes it settles itself).  Not while factors still lack inbox keys (their counting
+// replays the log per connection).
+static void flush_counts(mgx_world *w, bool lazy) {
     if (w->pending.active) {  // the launch's entries join the log once it is known to have run
         const int rcc = confirm_resident(w);
         if (rcc != MGX_OK && w->sticky_rc == MGX_OK) w->sticky_rc = rcc;  // (a re-run that failed: reported by whatever runs or reads next)
     }
-    if (w->clog.empty() && w->cp_dirty.empty()) return;
-    const int K = w->K;
     const size_t n = w->robots.size();
+    mgx_world::Cum &cu = w->cum;
+    if (cu.nIv.size() < n) { cu.nIv.resize(n, 0); cu.nEv.resize(n, 0); cu.nEf.resize(n, 0); cu.on_ir.resize(n, 0); }
+    const bool keyless = w->n_keyless > 0;
+    if (keyless) lazy = false;
+    if (w->clog.empty() && w->cp_dirty.empty()) {
+        if (!lazy && w->conns_unsettled) {
+            for (IrConn &c : w->conns) settle_conn(w, c);
+            w->conns_unsettled = false;
+        }
+        return;
+    }
+    const int K = w->K;
     const uint32_t en = w->p.enable_mask;
     const uint64_t dynf = (en & 1u) ? 2ull * (K - 1) : 0, obsf = (en & 4u) ? (uint64_t)(K - 2) : 0, trkf = (en & 8u) ? (uint64_t)(K - 2) : 0;
-    // Three passes: the robots (what each one's sweeps were, from the log), ONE pass over the connections (everything a connection
-    // counts, and what it contributes to its robots — a world with inter-robot factors has eight connections per robot, and
-    // the topology pass brings the counters up to date every tick), the robots again.  What the connection pass needs of a
-    // robot sits in compact arrays: a Robot is a dozen vectors wide.
-    std::vector<uint64_t> own(n, 0), foreign(n, 0), nIv(n, 0), nEf(n, 0), nEv(n, 0), nIfv(n, 0), trkv(n, 0), recv3(n, 0), on_ir;
+    // The robots (what each one's sweeps were, from the log: their own counters, and the cumulative counts the connections are
+    // settled against), then — in full — the connections.  What the passes need of a robot sits in compact arrays: a Robot is a
+    // dozen vectors wide.
+    std::vector<uint64_t> nIv(n, 0), nEf(n, 0), nEv(n, 0), nIfv(n, 0), trkv(n, 0);
     std::vector<uint8_t> flags(n, 0);  // bit 0: on air (antenna and not idle), bit 1: idle
     for (size_t r = 0; r < n; r++) {
         Robot &rb = w->robots[r];
@@ -924,9 +970,7 @@ static void flush_counts(mgx_world *w) {
         trkv[r] = trk;
     }
     // change_prior (variable.rs:203-230): its sends stay in a local counter; the connected factors receive
-    const bool any_cp = !w->cp_dirty.empty();
-    if (any_cp) {
-        on_ir.assign(n, 0);  // per robot: prior changes of variables that carry inter-robot factors (i >= 1)
+    if (!w->cp_dirty.empty()) {
         for (uint32_t key : w->cp_dirty) {
             const size_t r = key / (uint32_t)K;
             const int i = (int)(key % (uint32_t)K);
@@ -935,53 +979,53 @@ static void flush_counts(mgx_world *w) {
             Robot &rb = w->robots[r];
             const uint64_t dyn_here = (uint64_t)((i >= 1) + (i <= K - 2));
             rb.cnt[2] += c * (((en & 1u) ? dyn_here : 0) + ((i >= 1 && i <= K - 2) ? (uint64_t)(((en & 4u) != 0) + ((en & 8u) != 0)) : 0));
-            if (i >= 1) on_ir[r] += c;  // one inter-robot factor per connection hangs on this variable
+            if (i >= 1) cu.on_ir[r] += c;  // one inter-robot factor per connection hangs on this variable
         }
         w->cp_dirty.clear();
     }
-    const bool ir_counts = (en & 2u) != 0, log_any = !w->clog.empty();
-    for (IrConn &c : w->conns) {
-        const size_t o = (size_t)c.owner, t = (size_t)c.other;
-        own[o]++;
-        foreign[t]++;
-        if (!ir_counts) continue;
-        if (any_cp) {
-            c.cnt[2] += on_ir[o];  // the owner's own variable delivers to its factor
-            c.cnt[3] += on_ir[t];  // the foreign variable delivers to it
-        }
-        if (!log_any && !(w->n_keyless > 0 && !c.keys.empty())) continue;
-        const bool radio_a = (flags[o] & 1u) != 0, radio_b = (flags[t] & 1u) != 0;
-        c.cnt[2] += nIv[o] * (uint64_t)(K - 1);               // own variables' responses (internal sweeps)
-        if (radio_a) c.cnt[3] += nEv[t] * (uint64_t)(K - 1);  // the foreign variables' responses (robot.rs:1842-1858)
-        uint64_t to_own = nEf[o] * c.updates_per_sweep, to_foreign = to_own;  // external factor sweeps: one message per key
-        if (w->n_keyless > 0 && !c.keys.empty()) {  // some keys are still missing: replay the log in order until they are all there
-            const bool a_idle = (flags[o] & 2u) != 0;
-            to_own = to_foreign = 0;
-            for (const mgx_world::CountEntry &e : w->clog) {
-                if (e.robot >= 0 && e.robot != c.owner) continue;  // per-robot launches run internal sweeps only
-                for (uint64_t rep = 0; rep < e.times; rep++) {
-                    if (e.robot < 0 && (e.ext & 1u) && radio_a)
-                        for (size_t f = 0; f < c.keys.size(); f++) { to_own += c.uses[f] * (c.keys[f] & 1u); to_foreign += c.uses[f] * ((c.keys[f] >> 1) & 1u); }
-                    if (e.robot < 0 && (e.ext & 2u) && radio_a && radio_b)
-                        for (uint8_t &k : c.keys) k |= 2u;
-                    if ((e.in & 2u) && e.n_int > 0 && !a_idle)
-                        for (uint8_t &k : c.keys) k |= 1u;
+    const bool log_any = !w->clog.empty();
+    if (keyless) {
+        // Some factors still lack inbox keys: what they send follows the log in order, per connection (the connections WITH all
+        // their keys are settled as ever, against the cumulative counts BEFORE this log joins them — their share of it is added here).
+        for (IrConn &c : w->conns) {
+            settle_conn(w, c);  // (prior changes up to now; sweeps up to the last flush)
+            if (!(en & 2u) || !log_any) continue;
+            const size_t o = (size_t)c.owner, t = (size_t)c.other;
+            const bool radio_a = (flags[o] & 1u) != 0, radio_b = (flags[t] & 1u) != 0;
+            c.cnt[2] += nIv[o] * (uint64_t)(K - 1);
+            if (radio_a) c.cnt[3] += nEv[t] * (uint64_t)(K - 1);
+            uint64_t to_own = nEf[o] * c.updates_per_sweep, to_foreign = to_own;
+            if (!c.keys.empty()) {  // some keys are still missing: replay the log in order until they are all there
+                const bool a_idle = (flags[o] & 2u) != 0;
+                to_own = to_foreign = 0;
+                for (const mgx_world::CountEntry &e : w->clog) {
+                    if (e.robot >= 0 && e.robot != c.owner) continue;  // per-robot launches run internal sweeps only
+                    for (uint64_t rep = 0; rep < e.times; rep++) {
+                        if (e.robot < 0 && (e.ext & 1u) && radio_a)
+                            for (size_t f = 0; f < c.keys.size(); f++) { to_own += c.uses[f] * (c.keys[f] & 1u); to_foreign += c.uses[f] * ((c.keys[f] >> 1) & 1u); }
+                        if (e.robot < 0 && (e.ext & 2u) && radio_a && radio_b)
+                            for (uint8_t &k : c.keys) k |= 2u;
+                        if ((e.in & 2u) && e.n_int > 0 && !a_idle)
+                            for (uint8_t &k : c.keys) k |= 1u;
+                    }
                 }
+                bool all = true;
+                for (uint8_t k : c.keys) all = all && k == 3u;
+                if (all) { c.keys.clear(); c.uses.clear(); w->n_keyless--; }
             }
-            bool all = true;
-            for (uint8_t k : c.keys) all = all && k == 3u;
-            if (all) { c.keys.clear(); c.uses.clear(); w->n_keyless--; }
+            c.cnt[0] += to_own;
+            c.cnt[1] += to_foreign;
+            if (radio_b) w->robots[t].cnt[3] += to_foreign;  // delivered (robot.rs:1813-1831)
         }
-        c.cnt[0] += to_own;
-        c.cnt[1] += to_foreign;
-        if (radio_b) recv3[t] += to_foreign;  // delivered (robot.rs:1813-1831)
     }
-    if (log_any)
+    if (log_any) {
+        conn_index_ensure(w);  // (how many connections a robot owns / is the target of: the index' lists)
         for (size_t r = 0; r < n; r++) {
+            cu.nIv[r] += nIv[r]; cu.nEv[r] += nEv[r]; cu.nEf[r] += nEf[r];
             Robot &rb = w->robots[r];
-            rb.cnt[3] += recv3[r];
             if (rb.ghost) continue;
-            const uint64_t s_int = 2ull * (K - 1) + 2ull * (K - 2) + (uint64_t)(K - 1) * own[r], s_ext = (uint64_t)(K - 1) * foreign[r];
+            const uint64_t own = w->cidx.out[r].size(), foreign = w->cidx.in[r].size();
+            const uint64_t s_int = 2ull * (K - 1) + 2ull * (K - 2) + (uint64_t)(K - 1) * own, s_ext = (uint64_t)(K - 1) * foreign;
             // internal factor sweeps: one message per inbox key of every updated factor, received by the variables
             rb.cnt[0] += nIfv[r] * (dynf + obsf) + trkv[r] * trkf;
             rb.cnt[2] += nIfv[r] * (dynf + obsf) + trkv[r] * trkf;
@@ -990,6 +1034,19 @@ static void flush_counts(mgx_world *w) {
             rb.cnt[1] += (nIv[r] + nEv[r]) * s_ext;
             rb.cnt[2] += nIv[r] * (dynf + obsf + trkf);
         }
+    }
+    if (keyless) {  // (their share of this log was added by hand above: the bases move with the cumulative counts)
+        for (IrConn &c : w->conns) {
+            const size_t o = (size_t)c.owner, t = (size_t)c.other;
+            c.base[0] = cu.nIv[o]; c.base[1] = cu.nEv[t]; c.base[2] = cu.nEf[o];
+        }
+        w->conns_unsettled = false;
+    } else if (!lazy) {
+        for (IrConn &c : w->conns) settle_conn(w, c);
+        w->conns_unsettled = false;
+    } else {
+        w->conns_unsettled = true;
+    }
     w->clog.clear();
 }
 static void log_launch(mgx_world *w, int robot, uint32_t ext_mask, uint32_t int_mask, int n_int) {
@@ -1003,7 +1060,6 @@ static void log_launch(mgx_world *w, int robot, uint32_t ext_mask, uint32_t int_
     w->clog.push_back({ext, in, in ? n_int : 0, robot, 1});
     if (w->clog.size() > 4096) flush_counts(w);
 }
-static void flush_counts(mgx_world *w);
 static void log_change_prior(mgx_world *w, int robot, int var) {
     if (w->n_keyless > 0 && var >= 1 && (w->p.enable_mask & 2u)) {  // the delivery fills inbox keys of factors that lack them
         flush_counts(w);                                           // (what was logged so far saw them missing)
@@ -2412,9 +2468,11 @@ static int ir_connect(mgx_world *w, int32_t owner, int32_t other, uint64_t first
     if (first_robot_number == 0) return fail(MGX_ERR_INVALID, "robot_number is NonZeroUsize");
     // no "already connected" check: the reference creates whatever its connection sets ask for, and
     // a pair can legitimately hold two sets of factors (robot.rs:1391-1404, see mgx_update_topology)
-    flush_counts(w);
+    flush_counts(w, true);  // (the robots' counters: what they answer changes with the connection; the other connections' can wait)
     IrConn c;
     c.owner = owner; c.other = other; c.first_number = first_robot_number;
+    c.base[0] = w->cum.nIv[(size_t)owner]; c.base[1] = w->cum.nEv[(size_t)other]; c.base[2] = w->cum.nEf[(size_t)owner];
+    c.base[3] = w->cum.on_ir[(size_t)owner]; c.base[4] = w->cum.on_ir[(size_t)other];
     c.edges.resize((size_t)w->K - 1);
     c.node.resize((size_t)w->K - 1);
     // add_internal_edge + add_external_edge + the other variable's belief into the new factor
@@ -2478,7 +2536,7 @@ static int ir_disconnect(mgx_world *w, int32_t a, int32_t b) {
 static void ir_disconnect_batch(mgx_world *w, const std::vector<std::pair<int, int>> &pairs) {
     if (pairs.empty()) return;
     StageTimer tm("ir_disconnect_batch");
-    flush_counts(w);
+    flush_counts(w, true);
     tm.lap("flush_counts");
     conn_index_ensure(w);  // (who owns what: the index' `out` lists)
     std::vector<uint8_t> dead(w->conns.size(), 0);
@@ -2498,7 +2556,10 @@ static void ir_disconnect_batch(mgx_world *w, const std::vector<std::pair<int, i
             std::vector<int> &fr = w->robots[(size_t)self].free_nodes;
             fr.insert(fr.end(), gone.begin(), gone.end());
         }
-    for (const int32_t ci : dead_list) conn_index_drop(w, ci);
+    for (const int32_t ci : dead_list) {
+        settle_conn(w, w->conns[(size_t)ci]);  // (what it delivered to its target stays in that robot's counters; its own go with it)
+        conn_index_drop(w, ci);
+    }
     // the list's order carries no meaning (inbox order comes from order keys and node slots, build_incoming): the last
     // survivors fill the holes
     {
@@ -2936,7 +2997,7 @@ int mgx_update_topology(mgx_world *w, const float *positions_xyz, float radius, 
     int rc = neighbours_enqueue(w, positions_xyz, radius, method, ps);  // (waits for the launch to be decided first if it has to)
     if (rc != MGX_OK) return rc;
     tm.lap("search enqueued");
-    flush_counts(w);
+    flush_counts(w, true);  // (lazy: the robots' counters and cumulative counts; connections are settled when deleted or read)
     tm.lap("message counters (under the search)");
     rc = neighbours_collect(w, ps, ptr, idx);
     if (rc != MGX_OK) return rc;
