@@ -49,9 +49,10 @@ def parse():
     ap.add_argument("--preheat-ms", type=float, default=60.0, help="untimed work in front of the repetitions (clock ramp)")
     ap.add_argument("--robots-per-gpu", type=int, default=1000)
     ap.add_argument("--horizon", type=int, default=16)
-    ap.add_argument("--ticks-per-submission", type=int, default=1,
-                    help="1 (default) = the reference's call pattern: one mgx_iterate per tick, nothing bracketed — schedules issued back to "
-                         "back ride in one lingering launch by themselves; > 1: that many ticks handed over inside mgx_batch_begin / _end")
+    ap.add_argument("--ticks-per-submission", type=int, default=0,
+                    help="1 = the reference's call pattern: one mgx_iterate per tick, nothing bracketed — schedules issued back to back ride "
+                         "in one lingering launch by themselves (the default at N = 1); > 1: that many ticks handed over inside "
+                         "mgx_batch_begin / _end (the default at N > 1 is 2: the launches of a sharded world do not linger)")
     ap.add_argument("--no-configs1", action="store_true", help="skip the BASELINE configs[1] block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the tick / dynamic_tick / scenario measurements")
@@ -709,7 +710,7 @@ def main():
         dist.broadcast_object_list(flag, src=0)
         probe_ok = flag[0]
 
-    G = a.ticks_per_submission
+    G = a.ticks_per_submission if a.ticks_per_submission > 0 else (2 if multi else 1)
     walls, devs = timed(torch, dist, sw.iterate, sc2["steps"], a, multi, red_dev, sync=sw.synchronize, batch=sw.batch, group=G, flush=sw.flush)
     sw.iterate(sc2["steps"])
     resident = sw.world.last_launch_count() == 1  # the engine ran the 10-step schedule as ONE resident launch (or posted it into one)

@@ -822,6 +822,9 @@ def connect(sw, comm, transport="auto", resident=True):
                 slots = bool(getattr(sw, "dynamic", False))  # a world that follows its topology: one slot per ghost robot
                 info, err = None, None
                 try:
+                    import os
+                    if os.environ.get("MGX_TEST_FAIL_DIRECT_SETUP_RANK") == str(sw.plan.rank):  # (fault injection for the fallback tests)
+                        raise hostlib.MgxError("injected: this rank cannot set up its receive area")
                     info = sw.direct_setup_slots(export_ipc=True) if slots else sw.direct_setup(export_ipc=True)
                 except Exception as e:  # noqa: BLE001
                     err = e
