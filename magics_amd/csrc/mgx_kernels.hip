@@ -633,10 +633,10 @@ __global__ void k_copy_bytes(uint8_t *__restrict__ dst, const uint8_t *__restric
 }
 
 // ---- launch wrappers (called from mgx_world.hip) -------------------------------------------------
-size_t sweep_lds_bytes(int K, int ir_edges, bool resident) {  // resident: + the shadow of the factor -> variable messages + 720 bytes: the parked argument pointer, the plan in force, a posted plan's prior-update record and, per wave, what is derived from the plan (mgx_sweep.h: s_plan, s_urec, s_ps, s_seg)
+size_t sweep_lds_bytes(int K, int ir_edges, bool resident) {  // resident: + the shadow of the factor -> variable messages + 1232 bytes: the parked argument pointer, the plan in force, a posted plan's prior-update record and, per wave, what is derived from the plan (mgx_sweep.h: s_plan, s_urec, s_ps, s_seg)
     const BlobLayout L(K);
     const int io = L.inout_words() + (L.inout_words() & 1);
-    return sizeof(double) * (size_t)((SNAP_W + 20 + 20) * K + io + IR_STRIDE * (ir_edges + 1) + (resident ? 20 * L.E1 + 90 : 0)) +
+    return sizeof(double) * (size_t)((SNAP_W + 20 + 20) * K + io + IR_STRIDE * (ir_edges + 1) + (resident ? 20 * L.E1 + 154 : 0)) +
            4 * (size_t)((resident ? 3 : 2) * ((K + 1) & ~1) + ((3 * (K + 1) + 1) & ~1));
 }
 size_t sweep_lds_bytes(int K, int ir_edges) { return sweep_lds_bytes(K, ir_edges, false); }

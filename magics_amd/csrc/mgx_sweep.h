@@ -282,6 +282,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     // force lives in LDS (s_plan: the launch's own from the kernel's arguments, later ones from the host-mapped box), and the
     // segment counter that parities and sequence numbers derive from runs on over the plans (kbase)
     constexpr bool LINGER = PERSIST && !SHARD;
+    constexpr bool PLDS = PERSIST;  // the plan in force and what is derived from it live in LDS (s_plan, s_ps, s_seg) in every resident kernel
     int nseg = PERSIST ? plan.n : 1;
     // Fields of the world that only COLD paths read (the residency census and its decider, give-up paths of the waits, the ranks'
     // agreement, the push records of boundary robots): fetched from the kernel's argument block where they are used, through a
@@ -323,25 +324,26 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     // What is derived from the plan in force, kept HERE and fetched at the top of every segment (wave-uniform values that would
     // otherwise sit in scalar registers — and their spill lanes — for the whole launch).  Every wave works them out for itself where
     // a plan begins and keeps a copy of its own (no barrier between writing and reading them):
-    //   s_ps  [4 waves][4]   [0] segments | (last segment with internal iterations + 1) << 8 | (last one with an external iteration
-    //                        + 1) << 16 | flags << 24 (1: some internal variable sweep runs on this robot, 2: some variable sweep);
-    //                        [1] launch-wide index of the plan's segment 0; [2] plans run before this one
-    //   s_seg [4 waves][32]  per segment k: external? | internal iterations << 8 | the same two of segment k + 1 << 16
-    constexpr int PS_WORDS = 4, PREFIX_F64 = 2 + LINGER_PLAN_DWORDS / 2 + 4 + (4 * PS_WORDS + 4 * MAX_SEGS) / 2;
-    static_assert(LINGER_PLAN_DWORDS % 2 == 0 && PREFIX_F64 == 90, "the resident kernels' LDS prefix (mgx_kernels.hip: sweep_lds_bytes)");
+    //   s_ps  [4 waves][4]   [0] plans run before the one in force; [1] launch-wide index BEHIND the plan's last segment;
+    //                        [2] flags (1: some internal variable sweep runs on this robot, 2: some variable sweep)
+    //   s_seg [4 waves][32]  per segment k, ONE 8-byte read at its top: { SEG_* bits | internal iterations << 8 | external? of
+    //                        segment k + 1 << 16 | its internal iterations << 24, the segment's launch-wide index }
+    constexpr int PS_WORDS = 4, PREFIX_F64 = 2 + LINGER_PLAN_DWORDS / 2 + 4 + (4 * PS_WORDS + 4 * 2 * MAX_SEGS) / 2;
+    static_assert(LINGER_PLAN_DWORDS % 2 == 0 && PREFIX_F64 == 154, "the resident kernels' LDS prefix (mgx_kernels.hip: sweep_lds_bytes)");
+    constexpr uint32_t SEG_EXT = 1u, SEG_LAST = 2u, SEG_LAST_INT = 4u, SEG_LAST_EXT = 8u, SEG_FIRST_OF_LAUNCH = 16u, SEG_LINGERS = 32u;
     uint32_t *s_ps = reinterpret_cast<uint32_t *>(lds + 2 + LINGER_PLAN_DWORDS / 2 + 4) + (threadIdx.x >> 6) * PS_WORDS;
-    uint32_t *s_seg = reinterpret_cast<uint32_t *>(lds + 2 + LINGER_PLAN_DWORDS / 2 + 4) + 4 * PS_WORDS + (threadIdx.x >> 6) * MAX_SEGS;
+    uint2 *s_seg = reinterpret_cast<uint2 *>(lds + 2 + LINGER_PLAN_DWORDS / 2 + 4 + (4 * PS_WORDS) / 2) + (threadIdx.x >> 6) * MAX_SEGS;
     auto ps_word = [&](int i) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ps[i]); };
     auto plan_dword = [&](int i) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)s_plan[i]); };
     auto plan_ext = [&](int k) __attribute__((always_inline)) {
-        if constexpr (LINGER) return (plan_dword(2 + (k >> 2)) >> (8 * (k & 3))) & 0xffu;
+        if constexpr (PLDS) return (plan_dword(2 + (k >> 2)) >> (8 * (k & 3))) & 0xffu;
         return (reinterpret_cast<const uint32_t *>(plan.ext)[k >> 2] >> (8 * (k & 3))) & 0xffu;
     };
     auto plan_n_int = [&](int k) __attribute__((always_inline)) {
-        if constexpr (LINGER) return (int)((plan_dword(2 + MAX_SEGS / 4 + (k >> 2)) >> (8 * (k & 3))) & 0xffu);
+        if constexpr (PLDS) return (int)((plan_dword(2 + MAX_SEGS / 4 + (k >> 2)) >> (8 * (k & 3))) & 0xffu);
         return (int)((reinterpret_cast<const uint32_t *>(plan.n_int)[k >> 2] >> (8 * (k & 3))) & 0xffu);
     };
-    if (LINGER && threadIdx.x == 0) {  // the launch's own plan, as a posted one would arrive (read behind the staging barrier)
+    if (PLDS && threadIdx.x == 0) {  // the launch's own plan, as a posted one would arrive (read behind the staging barrier)
         s_plan[0] = (uint32_t)plan.n;
         s_plan[1] = w.upd ? 1u : 0u;
 #pragma unroll
@@ -527,7 +529,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     const int K = KT > 0 ? KT : w.K, E = 4 * K - 6, E1 = E + 1;
     const BlobLayout L(K);
     const int ZCOL = E;  // all-zero message column (absent edges)
-    double *s_snap = lds + (PERSIST ? 90 : 0);            // [24][K] variable -> own-factor snapshots (resident: behind the parked argument pointer and the plan)
+    double *s_snap = lds + (PERSIST ? 154 : 0);            // [24][K] variable -> own-factor snapshots (resident: behind the parked argument pointer and the plan)
     double *s_prior = s_snap + SNAP_W * K;                // [20][K] prior eta, lam (belief after the last sweep)
     double *s_tmp = s_prior + 20 * K;                     // [20][K] scratch sums (external sweep)
     double *s_io = s_tmp + 20 * K;                        // image of the blob's in/out region:
@@ -836,7 +838,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         return __syncthreads_or(abort_launch) != 0;
     };
     if (census && CENSUS_EARLY && census_says_abort(early_decision)) return;  // nothing has been written: the world is as it was
-    if (LINGER && w.upd) {  // mgx_tick's prior updates of the launch's own plan: parked where a posted plan's would be (see where a plan begins)
+    if (PLDS && w.upd) {  // mgx_tick's prior updates of the launch's own plan: parked where a posted plan's would be (see where a plan begins)
         if (tid < 4) s_urec[tid] = tid == 0 ? u_rec[0] : (tid == 1 ? u_rec[1] : (tid == 2 ? u_rec[2] : u_rec[3]));
         if (lane < 20 && role < 2) s_tmp[4 * K + role * 20 + lane] = u_bel;
         __syncthreads();
@@ -1556,9 +1558,10 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
     // LINGER: plans run so far, and the launch-wide index of the current plan's segment 0 — buffer parities, sequence numbers and
     // progress counts derive from kbase + k, so that they run on over the plans exactly as over the segments of one plan (the
     // first segment of a posted plan has no external iteration: it CONTINUES the last segment of the plan before — same index)
-    int plans_done = 0, kbase = 0;
-    bool upd_now = w.upd != nullptr;  // the plan that begins carries mgx_tick's prior updates (u_rec, u_bel)
-    const bool lingers = LINGER && census && plan.linger_ticks > 0;
+    // (LINGER: none of it lives in registers across the segments — see s_ps, s_seg)
+    int kbase = 0;
+    if (PLDS && lane == 0) s_ps[0] = 0u;
+    if (PLDS) __builtin_amdgcn_wave_barrier();
 #ifdef MGX_STAMPS
     unsigned long long c_f = 0, c_fb = 0, c_v = 0, c_vb = 0, t_extf = t_staged, t_extv = t_staged, t_loop0 = t_staged;
     unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
@@ -1572,8 +1575,10 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
 #define QSTAMP(i, since)
 #define QBEGIN(v)
 #endif
-    for (int k = 0; k < nseg; k++) {
+    for (int k = 0; PLDS || k < nseg; k++) {
         if (k == 0) {  // ======================= a plan begins: the launch's own, or (LINGER) one the host posted into the running launch
+            const int plans_done = PLDS ? (int)ps_word(0) : 0;
+            const bool upd_now = PLDS ? plan_dword(1) != 0u : w.upd != nullptr;  // the plan carries mgx_tick's prior updates (u_rec, u_bel)
             // ---- mgx_tick: update_prior_of_horizon_state (wave 0, variable K-1) and update_prior_of_current_state_v3
             // (wave 1, variable 0) on the staged image, each ending in change_prior of that variable
             // (robot.rs:2182-2338, variable.rs:203-230; same arithmetic as k_update_priors / apply_change_prior).  For
@@ -1582,13 +1587,13 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             if (upd_now) {
                 // (LINGER: the record and the stale (eta, lam) entries wait in LDS — the launch's own parked there behind the staging
                 // barrier, a posted plan's at the end of the plan before: nothing of them stays in registers across the segments)
-                if constexpr (LINGER) {
+                if constexpr (PLDS) {
 #pragma unroll
                     for (int c = 0; c < 4; c++) u_rec[c] = s_urec[c];
                     u_bel = (lane < 20 && role < 2) ? s_tmp[4 * K + role * 20 + lane] : 0.0;
                 }
-                const double upd_max_speed = LINGER ? reinterpret_cast<const double *>(s_plan + 2 + MAX_SEGS / 2)[0] : w.upd_max_speed;
-                const double upd_delta_t = LINGER ? reinterpret_cast<const double *>(s_plan + 2 + MAX_SEGS / 2)[1] : w.upd_delta_t;
+                const double upd_max_speed = PLDS ? reinterpret_cast<const double *>(s_plan + 2 + MAX_SEGS / 2)[0] : w.upd_max_speed;
+                const double upd_delta_t = PLDS ? reinterpret_cast<const double *>(s_plan + 2 + MAX_SEGS / 2)[1] : w.upd_delta_t;
                 const uint32_t what = (uint32_t)u_rec[3];
                 const int i = role == 0 ? K - 1 : 0;
                 if (role < 2 && (role == 0 ? (what & 1u) : (what & 2u))) {
@@ -1664,7 +1669,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                 __syncthreads();
             }
             my_epoch = (sum_t < 4 * K) ? s_epoch[sum_t % K] : 0u;
-            if constexpr (LINGER) {
+            if constexpr (PLDS) {
                 // the plan's bytes, one segment per lane: two ballots say which segments have internal iterations / an external one
                 nseg = (int)plan_dword(0);
                 const int q = lane & (MAX_SEGS - 1), q1 = (q + 1) & (MAX_SEGS - 1);
@@ -1677,11 +1682,19 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                 last_ext_seg = m_ext ? 63 - __clzll((long long)m_ext) : -1;
                 has_int_var = m_int != 0ull && !idle;
                 any_sweep = has_int_var || (m_ext != 0ull && radio);
-                if (lane < MAX_SEGS) s_seg[lane] = e_q | (n_q << 8) | (e_1 << 16) | (n_1 << 24);
+                // (segment 0 of a posted plan continues the last segment of the plan before: the launch-wide index does not move)
+                kbase = plans_done ? (int)ps_word(1) - 1 : 0;
+                const bool lingers = LINGER && census && plan.linger_ticks > 0;
+                if (lane < MAX_SEGS) {
+                    const uint32_t bits = (e_q ? SEG_EXT : 0u) | (lane == nseg - 1 ? SEG_LAST : 0u) | (lane == last_int_seg ? SEG_LAST_INT : 0u) |
+                                          (lane == last_ext_seg ? SEG_LAST_EXT : 0u) | ((lane == 0 && plans_done == 0) ? SEG_FIRST_OF_LAUNCH : 0u) |
+                                          (lingers ? SEG_LINGERS : 0u);
+                    s_seg[lane] = uint2{bits | (n_q << 8) | ((e_1 ? 1u : 0u) << 16) | (n_1 << 24), (uint32_t)(kbase + lane)};
+                }
+                __builtin_amdgcn_wave_barrier();  // (ps_word(1) above is read before it is written below)
                 if (lane == 0) {
-                    s_ps[0] = (uint32_t)nseg | ((uint32_t)(last_int_seg + 1) << 8) | ((uint32_t)(last_ext_seg + 1) << 16) | ((has_int_var ? 1u : 0u) | (any_sweep ? 2u : 0u)) << 24;
-                    s_ps[1] = (uint32_t)kbase;
-                    s_ps[2] = (uint32_t)plans_done;
+                    s_ps[1] = (uint32_t)(kbase + nseg);
+                    s_ps[2] = (has_int_var ? 1u : 0u) | (any_sweep ? 2u : 0u);
                 }
                 __builtin_amdgcn_wave_barrier();  // (the wave's own LDS reads below follow its LDS writes above)
             } else if (PERSIST) {
@@ -1697,26 +1710,30 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         }
         // this segment's (and the next one's) bytes of the plan, and what is derived from the plan as a whole (see s_ps, s_seg)
         uint32_t seg_b = 0u;
-        if constexpr (LINGER) {
-            seg_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seg[k]);
-            const uint32_t pk = ps_word(0);
-            kbase = (int)ps_word(1);
-            nseg = (int)(pk & 0xffu); last_int_seg = (int)((pk >> 8) & 0xffu) - 1; last_ext_seg = (int)((pk >> 16) & 0xffu) - 1;
+        int kg = k;  // the segment's launch-wide index
+        if constexpr (PLDS) {
+            // (asked for here and waited for at once: the word of the NEXT segment fetched a segment ahead and turned scalar at its end
+            // measured no better, 7.67 - 7.77 us per iteration against 7.66 - 7.68 — experiments/README.md)
+            const uint2 e = s_seg[k];
+            seg_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
+            kg = __builtin_amdgcn_readfirstlane((int)e.y);
         } else if (PERSIST) {
-            seg_b = plan_ext(k) | ((uint32_t)plan_n_int(k) << 8);
-            if (k + 1 < nseg) seg_b |= (plan_ext(k + 1) << 16) | ((uint32_t)plan_n_int(k + 1) << 24);
+            seg_b = (plan_ext(k) ? SEG_EXT : 0u) | ((uint32_t)plan_n_int(k) << 8) | (k == nseg - 1 ? SEG_LAST : 0u) | (k == last_int_seg ? SEG_LAST_INT : 0u) |
+                    (k == last_ext_seg ? SEG_LAST_EXT : 0u) | (k == 0 ? SEG_FIRST_OF_LAUNCH : 0u);
+            if (k + 1 < nseg) seg_b |= ((plan_ext(k + 1) ? 1u : 0u) << 16) | ((uint32_t)plan_n_int(k + 1) << 24);
         }
-        const int kg = LINGER ? kbase + k : k;  // the segment's launch-wide index
+        const bool is_last_int_seg = (seg_b & SEG_LAST_INT) != 0u, is_last_ext_seg = (seg_b & SEG_LAST_EXT) != 0u;
+        const bool lingers = LINGER && (seg_b & SEG_LINGERS) != 0u;
         // Nothing derived from the thread index stays live across segments: left alone, the compiler hoists every per-thread
         // address and predicate of the loop body in front of the loop and then spills them around the f64 blocks (64 spilled
         // VGPRs, 244 B of scratch per lane at K = 16); recomputing them per segment is a handful of integer instructions.
         // (... nor from the per-thread indices made of it in front of the loop: a kept copy of `&w.ir_bmu[c * NI + ie0 + my_j]` is two
         // registers per row, and the sharded instantiation spilled four of those to scratch)
         if (PERSIST) asm volatile("" : "+v"(tid), "+v"(lane), "+v"(my_j), "+v"(pf_dst));
-        const uint32_t ext_k = PERSIST ? ((seg_b & 0xffu) ? (PH_EXT_FACTOR | PH_EXT_VARIABLE) : 0u) : ext_mask;
+        const uint32_t ext_k = PERSIST ? ((seg_b & SEG_EXT) ? (PH_EXT_FACTOR | PH_EXT_VARIABLE) : 0u) : ext_mask;
         const uint32_t int_k = PERSIST ? (PH_INT_FACTOR | PH_INT_VARIABLE) : int_mask;
         const int n_int_k = PERSIST ? (int)((seg_b >> 8) & 0xffu) : n_int;
-        const bool last_seg = k == nseg - 1;
+        const bool last_seg = PERSIST ? (seg_b & SEG_LAST) != 0u : true;
         // ======================= external factor sweep ============================================
         PSTAMP(ps0);
         QBEGIN(qt);
@@ -1731,7 +1748,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         }
         PSTAMP(ps1);
         if (ext_k & PH_EXT_FACTOR) {
-            external_factor_sweep(k, kg, !PERSIST || k == last_ext_seg);
+            external_factor_sweep(k, kg, !PERSIST || is_last_ext_seg);
             QSTAMP(2, qt);
             __syncthreads();
             QSTAMP(3, qt);
@@ -1757,7 +1774,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             // external sweep's outcome afterwards.  Takes a whole variable sweep off the chain from record to publication.
             par_done = (ext_k & PH_EXT_VARIABLE) && radio && early && n_int_k == 1;
             if (par_done) {
-                const bool is_last = k == last_int_seg && last_seg;
+                const bool is_last = is_last_int_seg && last_seg;
                 const int q = lane / K, i = lane - q * K;  // lanes < 4 K of either wave
                 bool ok_i = false, fin_i = false;
                 double mu_i = 0.0;
@@ -1816,8 +1833,8 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                     }
                 }
                 // (a lingering launch keeps them in LDS behind its plan's last external iteration as well: a posted plan goes on from there)
-                if (ir_on && (k != last_ext_seg || lingers)) have_xmu = true;
-                if (ir_on && k == last_ext_seg) {  // the plan's last external iteration: the response means go to HBM (robot.rs:1842-1858)
+                if (ir_on && (!is_last_ext_seg || lingers)) have_xmu = true;
+                if (ir_on && is_last_ext_seg) {  // the plan's last external iteration: the response means go to HBM (robot.rs:1842-1858)
                     for (int q = tid; q < ne; q += NT) {
                         const int e = ie0 + (q == tid ? my_j : edge_of_lane(q));
                         int dst;
@@ -1840,7 +1857,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                 const bool ext_is_last = last_seg && n_int_k == 0;
                 double *s_sum = ext_is_last ? s_prior : s_tmp;
                 prefired = !early && n_int_k > 0 && !idle && (int_k & PH_INT_FACTOR) && skip0 == 0u;
-                const bool keep_means = ir_on && (k != last_ext_seg || lingers);
+                const bool keep_means = ir_on && (!is_last_ext_seg || lingers);
                 if (role == ROLE_UV) {
                     variable_sums(s_sum, false, false);  // reads the messages of the last internal factor sweep (s_fv)
                     QSTAMP(4, qt);
@@ -1855,7 +1872,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                 if (prefired && is_dyn && (w.enable & 1u)) dynamic_messages(s_sh);
                 QSTAMP(6, qt);
                 if (keep_means) have_xmu = true;
-                if (ir_on && k == last_ext_seg) {  // the plan's last external iteration: the means go to HBM (robot.rs:1842-1858)
+                if (ir_on && is_last_ext_seg) {  // the plan's last external iteration: the means go to HBM (robot.rs:1842-1858)
                     __syncthreads();
                     for (int q = tid; q < ne; q += NT) {
                         const int e = ie0 + (q == tid ? my_j : edge_of_lane(q));
@@ -1903,11 +1920,11 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             QSTAMP(6, qt);
             __syncthreads();
             QSTAMP(7, qt);
-            if (PERSIST && radio && ir_on && (k != last_ext_seg || lingers)) {
+            if (PERSIST && radio && ir_on && (!is_last_ext_seg || lingers)) {
                 if (tid < 4 * K) s_xmu[tid] = s_mu[tid] - 0.0;  // read after the barrier that opens the next segment's factor sweep
                 have_xmu = true;
             }
-            if (radio && ir_on && (!PERSIST || k == last_ext_seg)) {
+            if (radio && ir_on && (!PERSIST || is_last_ext_seg)) {
                 // responses to the foreign factors attached to our variables, routed to their inbox
                 // (robot.rs:1842-1858): only the mean of that inbox entry is ever used (it sets the
                 // linearisation point; eta / lam of the target side never reach the kept message).
@@ -1967,7 +1984,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             if (int_k & PH_INT_VARIABLE) {
                 // the robot's last sweep of the launch leaves its sums in the belief image as well (a robot that is
                 // off the air runs no external sweep: its last one is the last internal iteration of the schedule)
-                const bool is_last = it == n_int_k - 1 && (!PERSIST || (k == last_int_seg && (last_seg || !radio)));
+                const bool is_last = it == n_int_k - 1 && (!PERSIST || (is_last_int_seg && (last_seg || !radio)));
                 variable_sums(s_snap, true, is_last);
                 pending = true;
                 STAMP(t4);
@@ -1978,7 +1995,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             }
         }
         // segment 0 of a resident launch is through: go or abort (see the residency census above) before anything is published
-        if (census && !CENSUS_EARLY && k == 0 && plans_done == 0) {
+        if (census && !CENSUS_EARLY && (seg_b & SEG_FIRST_OF_LAUNCH)) {
             const unsigned long long v = tid == 0 ? __hip_atomic_load(cold().decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
             if (census_says_abort(v)) return;
         }
@@ -2067,7 +2084,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             DELAY_AT(3, role == ROLE_DYN);
             if (early) {
                 if (is_dyn && (w.enable & 1u)) dynamic_messages(s_sh);
-                unary_messages(0u, s_sh, itf + ((((seg_b >> 16) & 0xffu) && radio) ? 1 : 0));
+                unary_messages(0u, s_sh, itf + ((((seg_b >> 16) & 1u) && radio) ? 1 : 0));
             }
             QSTAMP(13, qt);
         }
@@ -2085,10 +2102,13 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         // one round trip and the loop goes on at segment 0 of that plan, same launch-wide index; the word odd -> tail and
         // write-back, as every launch ends.  The wait is bounded (plan.linger_ticks, and the world's abort word ends it at once):
         // whoever waits it out raises the word itself — an atomic max, so one outcome for all.
+        if constexpr (PLDS) {
+            if (last_seg && !lingers) break;
+        }
         if constexpr (LINGER) {
-            if (lingers && last_seg) {
-                plans_done = (int)ps_word(2);
-                any_sweep = ((ps_word(0) >> 24) & 2u) != 0u;
+            if (last_seg) {
+                const int plans_done = (int)ps_word(0);
+                any_sweep = (ps_word(2) & 2u) != 0u;
                 if (role == ROLE_UV && pending) finish(s_snap, true);
                 pending = false;
                 __syncthreads();
@@ -2148,7 +2168,7 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                 }
                 __syncthreads();
                 if (*s_verdict != 1) break;  // the launch ends behind this plan
-                plans_done += 1;
+                if (lane == 0) s_ps[0] = (uint32_t)(plans_done + 1);  // (every wave's own copy)
                 {
                     if constexpr (KT > 0) r_prior.store(s_prior, tid);
                     else copy_words(s_prior, blob + L.prior(), 20 * K, tid, NT);
@@ -2156,15 +2176,14 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                     // "this workgroup has picked up plan `number`": the slot it was read from may be written again once everybody has
                     if (tid == 0) __hip_atomic_store(&cold().census[blockIdx.x], number, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                upd_now = plan_dword(1) != 0u;
-                kbase += nseg - 1;  // segment 0 of the plan that begins continues this one (no external iteration in between)
-                k = -1;
+                k = -1;  // (the plan that begins: see the top of the loop)
             }
         }
     }
-    if constexpr (LINGER) {  // (see s_ps; the staging barrier, or the one where the last plan began, lies behind)
-        nseg = (int)(ps_word(0) & 0xffu); kbase = (int)ps_word(1);
-        any_sweep = ((ps_word(0) >> 24) & 2u) != 0u;
+    int total_segs = nseg;  // segments the launch ran (parities, sequence numbers and progress counts moved on by as many)
+    if constexpr (PLDS) {  // (see s_ps; the staging barrier, or the one where the last plan began, lies behind)
+        total_segs = (int)ps_word(1);
+        any_sweep = (ps_word(2) & 2u) != 0u;
     }
     {
         // Tail: the UV wave completes the last variable sweep (mean, covariance) while the DYN wave
@@ -2194,11 +2213,11 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         }
 #endif
     }
-    if (PERSIST) snap_out = (w.cur + kbase + nseg) & 1;  // where the records of the launch's last sweep go (the host follows)
+    if (PERSIST) snap_out = (w.cur + total_segs) & 1;  // where the records of the launch's last sweep go (the host follows)
     if (SHARD && role == ROLE_UV && lane == 0) {  // "through with this launch's reads of your records": see the end of a segment
         for (int t = xp0; t < xp1; t++) {
             const XPushRec xr = cold().xp_rec[t];
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(xr.flag), plan.flag_base + xr.flag_delta + (unsigned long long)nseg,
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(xr.flag), plan.flag_base + xr.flag_delta + (unsigned long long)total_segs,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
