@@ -192,14 +192,16 @@ __global__ void __launch_bounds__(GRID_BLOCK) k_grid_rows(const float *__restric
     extern __shared__ float lds_pos[];
     const int npad = (n + 3) & ~3;
     float *X = lds_pos, *Y = lds_pos + npad, *Z = lds_pos + 2 * npad;
-    int32_t *CX = reinterpret_cast<int32_t *>(lds_pos + 3 * npad);  // [n] cell of every robot (x, z); INT_MIN for the non-finite ones
-    int32_t *CZ = CX + npad;
-    int32_t *start = CZ + npad;          // [GRID_M + 1]
-    int32_t *fill = start + GRID_M + 1;  // [GRID_M] counts, then cursors
-    int32_t *members = fill + GRID_M;    // [n]
-    int32_t *special = members + npad;   // [n]
-    int32_t *part = special + npad;      // [GRID_BLOCK]
-    int32_t *hit = part + GRID_BLOCK;    // [GRID_BLOCK][REG] the hits of this workgroup's robots as they are found
+    // Small on purpose (26.8 KB for 1000 robots): a workgroup of this kernel has to fit the LDS a resident schedule launch leaves
+    // in one of its holes — 160 KB less three workgroups of up to 40 KB, in 1280-byte granules: a 38424-byte workgroup beside three
+    // others left no room for the 44904 bytes this kernel once took, and the search ended with the launch instead of beside it —
+    // so robot numbers (n <= 1024) are 16-bit words, and a robot's cell is computed again from its position where it is asked for.
+    int32_t *fill = reinterpret_cast<int32_t *>(lds_pos + 3 * npad);    // [GRID_M] counts, then cursors
+    int32_t *part = fill + GRID_M;                                      // [GRID_BLOCK]
+    uint16_t *start = reinterpret_cast<uint16_t *>(part + GRID_BLOCK);  // [GRID_M + 2] (the last word pads)
+    uint16_t *members = start + GRID_M + 2;                             // [n]
+    uint16_t *special = members + npad;                                 // [n]
+    uint16_t *hit = special + npad;                                     // [GRID_BLOCK][REG] the hits of this workgroup's robots as they are found
     __shared__ int32_t n_special;
     const int tid = (int)threadIdx.x;
     {   // all positions, 16 bytes at a time (see k_pairs_rows)
@@ -237,13 +239,9 @@ __global__ void __launch_bounds__(GRID_BLOCK) k_grid_rows(const float *__restric
     // counting sort by bucket
     for (int j = tid; j < n; j += GRID_BLOCK) {
         if (finite3(X[j], Y[j], Z[j])) {
-            const int cx = cell_of(X[j], inv_cell), cz = cell_of(Z[j], inv_cell);
-            CX[j] = cx;
-            CZ[j] = cz;
-            atomicAdd(&fill[bucket_of(cx, cz, GRID_M - 1)], 1);
+            atomicAdd(&fill[bucket_of(cell_of(X[j], inv_cell), cell_of(Z[j], inv_cell), GRID_M - 1)], 1);
         } else {
-            CX[j] = CZ[j] = (int32_t)0x80000000;  // (no cell of a finite robot: cell_of clamps to +-2^30)
-            special[atomicAdd(&n_special, 1)] = j;
+            special[atomicAdd(&n_special, 1)] = (uint16_t)j;
         }
     }
     __syncthreads();
@@ -263,17 +261,17 @@ __global__ void __launch_bounds__(GRID_BLOCK) k_grid_rows(const float *__restric
         int32_t run = part[tid] - sum;
 #pragma unroll
         for (int q = 0; q < PER; q++) {
-            start[tid * PER + q] = run;
+            start[tid * PER + q] = (uint16_t)run;
             run += fill[tid * PER + q];
             fill[tid * PER + q] = 0;
         }
-        if (tid == GRID_BLOCK - 1) start[GRID_M] = run;
+        if (tid == GRID_BLOCK - 1) start[GRID_M] = (uint16_t)run;
     }
     __syncthreads();
     for (int j = tid; j < n; j += GRID_BLOCK)
-        if (CX[j] != (int32_t)0x80000000) {
-            const uint32_t b = bucket_of(CX[j], CZ[j], GRID_M - 1);
-            members[start[b] + atomicAdd(&fill[b], 1)] = j;
+        if (finite3(X[j], Y[j], Z[j])) {
+            const uint32_t b = bucket_of(cell_of(X[j], inv_cell), cell_of(Z[j], inv_cell), GRID_M - 1);
+            members[(int)start[b] + atomicAdd(&fill[b], 1)] = (uint16_t)j;
         }
     __syncthreads();
     // two lanes per robot: lane h looks at cells h, h + 2, ... of the nine (and lane 1 at the non-finite robots)
@@ -292,18 +290,19 @@ __global__ void __launch_bounds__(GRID_BLOCK) k_grid_rows(const float *__restric
             }
         cnt[i] = m;
     }
-    int32_t *mine = hit + tid * REG;  // (a lane's own REG words)
+    uint16_t *mine = hit + tid * REG;  // (a lane's own REG words)
     if (live && !wild) {
-        const int cx = CX[i], cz = CZ[i];
+        const int cx = cell_of(ax, inv_cell), cz = cell_of(az, inv_cell);
         for (int c = h; c < 9; c += 2) {
             const int tx = cx + c / 3 - 1, tz = cz + c % 3 - 1;
             const uint32_t b = bucket_of(tx, tz, GRID_M - 1);
-            const int q1 = start[b + 1];
-            for (int q = start[b]; q < q1; q++) {
-                const int j = members[q];
-                // its TRUE cell is the one being looked at, it is not the robot itself, and it is in range
-                if (CX[j] == tx && CZ[j] == tz && j != i && in_comms_range_sq(ax, ay, az, X[j], Y[j], Z[j], s_max)) {
-                    if (m < REG) mine[m] = j;
+            const int q1 = (int)start[b + 1];
+            for (int q = (int)start[b]; q < q1; q++) {
+                const int j = (int)members[q];
+                const float bx = X[j], bz = Z[j];
+                // it is in range, it is not the robot itself, and its TRUE cell is the one being looked at (members are finite)
+                if (j != i && in_comms_range_sq(ax, ay, az, bx, Y[j], bz, s_max) && cell_of(bx, inv_cell) == tx && cell_of(bz, inv_cell) == tz) {
+                    if (m < REG) mine[m] = (uint16_t)j;
                     m++;
                 }
             }
@@ -311,9 +310,9 @@ __global__ void __launch_bounds__(GRID_BLOCK) k_grid_rows(const float *__restric
         if (h == 1) {
             const int ns = n_special;
             for (int q = 0; q < ns; q++) {
-                const int j = special[q];
+                const int j = (int)special[q];
                 if (in_comms_range_sq(ax, ay, az, X[j], Y[j], Z[j], s_max)) {  // (j != i: this robot is finite)
-                    if (m < REG) mine[m] = j;
+                    if (m < REG) mine[m] = (uint16_t)j;
                     m++;
                 }
             }
@@ -327,10 +326,10 @@ __global__ void __launch_bounds__(GRID_BLOCK) k_grid_rows(const float *__restric
     cnt[i] = m;
     if (m > cap || m > REG) return;  // the host repeats the search with more room: nobody reads this row
     // the row in ascending order: the hits came in bucket order — into registers, an odd-even transposition sort, out
-    const int32_t *theirs = mine + REG;
+    const uint16_t *theirs = mine + REG;
     int32_t keep[REG];
 #pragma unroll
-    for (int p = 0; p < REG; p++) keep[p] = p < m0 ? mine[p] : (p < m ? theirs[p - m0] : 0x7fffffff);
+    for (int p = 0; p < REG; p++) keep[p] = p < m0 ? (int32_t)mine[p] : (p < m ? (int32_t)theirs[p - m0] : 0x7fffffff);
 #pragma unroll
     for (int round = 0; round < REG; round++) {
 #pragma unroll
@@ -369,6 +368,12 @@ __global__ void __launch_bounds__(64) k_stage_positions(const float *__restrict_
     const int t = blockIdx.x * 64 + threadIdx.x;
     if (t < n3) dst[t] = src[t];
 }
+// LDS of one workgroup of the grid search (k_grid_rows) for n robots and rows of up to `cap` entries; its workgroups: one per 64 robots
+static size_t neighbours_rows_lds(int n, int32_t cap) {
+    const size_t npad = (size_t)((n + 3) & ~3);
+    return sizeof(float) * 3 * npad + sizeof(int32_t) * ((size_t)GRID_M + GRID_BLOCK) +
+           sizeof(uint16_t) * ((size_t)GRID_M + 2 + 2 * npad + (size_t)GRID_BLOCK * (cap <= 16 ? 16 : 32));
+}
 hipError_t neighbours_rows(const float *pos, int n, float radius, int32_t cap, int32_t *cnt, int32_t *rows, hipStream_t s, float *stage) {
     if (n <= 0) return hipSuccess;
     if (stage) {
@@ -380,10 +385,9 @@ hipError_t neighbours_rows(const float *pos, int n, float radius, int32_t cap, i
     const float s_max = squared_threshold(radius);
     if (n <= GRID_M && cap <= 32 && std::isfinite(radius) && radius > 0.f) {  // the grid in LDS (a usable radius, room for the rows in registers)
         const double inv_cell = 1.0 / ((double)radius * 1.001);
-        auto lds_grid = [&](size_t reg) { return lds + sizeof(int32_t) * ((size_t)GRID_M + 1 + GRID_M + 4 * npad + GRID_BLOCK + GRID_BLOCK * reg); };
         const dim3 grid((unsigned)((n + GRID_ROBOTS - 1) / GRID_ROBOTS));
-        if (cap <= 16) hipLaunchKernelGGL(k_grid_rows<16>, grid, dim3(GRID_BLOCK), lds_grid(16), s, pos, n, s_max, inv_cell, cap, cnt, rows);
-        else hipLaunchKernelGGL(k_grid_rows<32>, grid, dim3(GRID_BLOCK), lds_grid(32), s, pos, n, s_max, inv_cell, cap, cnt, rows);
+        if (cap <= 16) hipLaunchKernelGGL(k_grid_rows<16>, grid, dim3(GRID_BLOCK), neighbours_rows_lds(n, 16), s, pos, n, s_max, inv_cell, cap, cnt, rows);
+        else hipLaunchKernelGGL(k_grid_rows<32>, grid, dim3(GRID_BLOCK), neighbours_rows_lds(n, 32), s, pos, n, s_max, inv_cell, cap, cnt, rows);
         return hipGetLastError();
     }
     if (n > 512 && n <= 1024)

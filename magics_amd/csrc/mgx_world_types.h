@@ -78,14 +78,30 @@ hipError_t neighbours_rows(const float *pos, int n, float radius, int32_t cap, i
 using namespace mgx;
 
 static thread_local std::string g_err;
-// MGX_TIMING=1: host-side stage times of the topology pass and the table rebuild on stderr (diagnostic)
+// MGX_TIMING=1: host-side stage times of the topology pass and the table rebuild on stderr (diagnostic); MGX_TIMING=2: the same
+// times kept in memory and summed up per stage when the process ends (printing every lap shifts the very phases being looked at)
 struct StageTimer {
-    bool on;
+    struct Sum { const char *what, *stage; double total = 0.0; long n = 0; };
+    struct Book {
+        std::vector<Sum> rows;
+        ~Book() { for (const Sum &r : rows) fprintf(stderr, "[mgx timing] %s: %s n=%ld mean %.1f us\n", r.what, r.stage, r.n, r.total / (double)std::max(r.n, 1L)); }
+        void add(const char *what, const char *stage, double dt) {
+            for (Sum &r : rows) if (r.what == what && r.stage == stage) { if (++r.n > 0) r.total += dt; return; }
+            rows.push_back(Sum{what, stage, 0.0, -7});  // (the first eight of every stage size tables and warm caches: not counted)
+        }
+    };
+    int on;
     double t0;
     const char *what;
     static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
-    explicit StageTimer(const char *w) : what(w) { static const bool e = getenv("MGX_TIMING") != nullptr; on = e; t0 = on ? now() : 0.0; }
-    void lap(const char *stage) { if (on) { const double t = now(); fprintf(stderr, "[mgx timing] %s: %s %.1f us\n", what, stage, t - t0); t0 = t; } }
+    explicit StageTimer(const char *w) : what(w) { static const int e = [] { const char *v = getenv("MGX_TIMING"); return v ? (v[0] == '2' ? 2 : 1) : 0; }(); on = e; t0 = on ? now() : 0.0; }
+    void lap(const char *stage) {
+        if (!on) return;
+        const double t = now();
+        if (on == 2) { static Book book; book.add(what, stage, t - t0); }
+        else fprintf(stderr, "[mgx timing] %s: %s %.1f us\n", what, stage, t - t0);
+        t0 = on == 2 ? now() : t;
+    }
 };
 static int fail(int code, const char *fmt, ...) {
     char buf[512];
