@@ -49,7 +49,7 @@ struct IrEdgeRec {
 };
 
 // One incoming connection of a local robot (K-1 factors, one per variable 1..K-1): what the device
-// needs to lay out that robot's edges when the topology changes (k_edge_rebuild).
+// needs to lay out that robot's edges when the topology changes (k_retopo_robots).
 struct IrSlotRec {
     int32_t tgt_robot;      // local device index of the target robot
     int32_t src_robot;      // device index of the owner
@@ -57,6 +57,14 @@ struct IrSlotRec {
     int32_t flags;          // bit 0: the target has the higher order key (slot order of the factor)
     double d_safe;          // interrobot.rs:64
     uint64_t first_number;  // robot_number of the factor on variable 1 (robot.rs:1527)
+};
+// what the host sends for a topology change (k_retopo_robots): device-visible pointers into ONE pinned block
+struct RetopoBlock {
+    const int32_t *in_ptr;    // [R + 1] slot ranges of the new layout
+    const int32_t *mid;       // [R] first slot whose owner has the HIGHER graph key, relative to the robot's range
+    const int32_t *chg_off;   // [R] where the robot's slot records start in `recs`; -1: its incoming list did not change
+    const int32_t *peers;     // [R + 1 row pointers | entries] the resident kernel's peer table, or null
+    const IrSlotRec *recs;    // slot records of the robots whose list changed (old_slot: position in the robot's OLD list, -1 = created now)
 };
 
 // EXCHANGE RECORDS of resident schedule launches — the hand-off between neighbouring robots' workgroups (and, on sharded worlds,

@@ -531,79 +531,90 @@ __global__ void k_mission_prepare(DevWorld w, DevMission m, int n, const uint8_t
 // In-place topology change.  A robot's incoming connections are kept as one sorted list of SLOTS;
 // every connection hangs one factor on each of the target's variables 1..K-1, so the edges of
 // variable i of robot r are  (K-1) * in_ptr[r] + (i-1) * n_in(r) + q,  q = position in the list.
-// k_edge_rebuild lays out the new edge arrays from the new slot list (one thread per factor):
-// a surviving connection (old_slot >= 0) carries its message (the six live numbers), response mean
-// and creation epoch over from the arrays being replaced; a new one starts empty, created at the
-// owner variable's current delivery count, with the target variable's current belief mean as the
-// response it has seen (robot.rs:1549-1585).  The constant record of every edge is derived here too.
+// k_retopo_robots lays out the new edge arrays from the old ones, one 64-lane workgroup per robot: a surviving connection carries
+// its message (the six live numbers), response mean and creation epoch over from the arrays being replaced; a new one starts
+// empty, created at the owner variable's current delivery count, with the target variable's current belief mean as the response
+// it has seen (robot.rs:1549-1585).  The constant record of every edge is derived here too.
+// What the host sends are DIFFERENCES (RetopoBlock, one pinned block read over the host link): the new slot ranges and key
+// splits of all robots (two words each), the peer table, and slot records ONLY for the robots whose incoming list changed —
+// a robot whose list did not change (chg_off < 0) keeps its slot records (slots_old, on the device since the last pass) and
+// its edges just move by the shift of its range.  The same workgroup writes the robot's part of everything derived: the
+// device copy of the slot ranges (the next pass's "old" ones), the per-variable tables, its peer row, the slot records of the
+// new layout.  ONE launch, no copies, no synchronisation.
 // gate (may be null): the edge's gate byte — its owner is on air — written along (the flags themselves have not changed)
-__global__ void k_edge_rebuild(DevWorld w, int n_slots, const IrSlotRec *__restrict__ slots, const int32_t *__restrict__ in_new,
-                               const int32_t *__restrict__ in_old, int stride_new, IrEdgeRec *__restrict__ recs,
-                               double *__restrict__ fv_eta, double *__restrict__ fv_lam, double *__restrict__ bmu,
-                               uint8_t *__restrict__ gate) {
-    const int K1 = w.K - 1;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_slots * K1) return;
-    const int g = t / K1, j = t - g * K1;
-    const IrSlotRec sl = slots[g];
-    const int r = sl.tgt_robot;
-    const int n_in = in_new[r + 1] - in_new[r];
-    const int e = K1 * in_new[r] + j * n_in + (g - in_new[r]);
-    const size_t sn = (size_t)stride_new, so = (size_t)w.NI;
-    IrEdgeRec rec;
-    rec.src_var = sl.src_robot * w.K + j + 1;
-    rec.src_robot = sl.src_robot;
-    rec.dst = (int32_t)(j + 1) | ((sl.flags & 1) ? (1 << 16) : 0);
-    rec.d_safe = sl.d_safe;
-    rec.offset = (double)1e-6f * (double)(sl.first_number + (unsigned long long)j);  // interrobot.rs:52,75
-    if (sl.old_slot >= 0) {
-        const int n_old = in_old[r + 1] - in_old[r];
-        const int o = K1 * in_old[r] + j * n_old + (sl.old_slot - in_old[r]);
-        fv_eta[0 * sn + e] = w.ir_fv_eta[0 * so + o];
-        fv_eta[1 * sn + e] = w.ir_fv_eta[1 * so + o];
-        fv_lam[0 * sn + e] = w.ir_fv_lam[0 * so + o];
-        fv_lam[1 * sn + e] = w.ir_fv_lam[1 * so + o];
-        fv_lam[4 * sn + e] = w.ir_fv_lam[4 * so + o];
-        fv_lam[5 * sn + e] = w.ir_fv_lam[5 * so + o];
-#pragma unroll
-        for (int c = 0; c < 4; c++) bmu[c * sn + e] = w.ir_bmu[c * so + o];
-        rec.created = w.ir_rec[o].created;
-    } else {
-        fv_eta[0 * sn + e] = 0.0;
-        fv_eta[1 * sn + e] = 0.0;
-        fv_lam[0 * sn + e] = 0.0;
-        fv_lam[1 * sn + e] = 0.0;
-        fv_lam[4 * sn + e] = 0.0;
-        fv_lam[5 * sn + e] = 0.0;
-        const BlobLayout L(w.K);
-#pragma unroll
-        for (int c = 0; c < 4; c++)  // the target's belief goes into the new factor — which drops it while its kind is off
-            bmu[c * sn + e] = (w.enable & 2u) ? w.blob[(size_t)r * w.BS + L.mu() + c * w.K + (j + 1)] : 0.0;
-        rec.created = w.snap_epoch[w.cur][rec.src_var];
+__global__ void __launch_bounds__(64) k_retopo_robots(DevWorld w, RetopoBlock b, const int32_t *__restrict__ in_old, const IrSlotRec *__restrict__ slots_old,
+                                                      int32_t *__restrict__ in_dst, IrSlotRec *__restrict__ slots_new, int32_t *__restrict__ peers_dst,
+                                                      int32_t *__restrict__ var_ptr, int32_t *__restrict__ var_mid, int stride_new,
+                                                      IrEdgeRec *__restrict__ recs, double *__restrict__ fv_eta, double *__restrict__ fv_lam,
+                                                      double *__restrict__ bmu, uint8_t *__restrict__ gate) {
+    const int r = blockIdx.x, lane = threadIdx.x, R = w.R_local, K = w.K, K1 = K - 1;
+    // the robot's six words of the block: one trip over the host link for all of them (lanes 0..5), handed round by shuffles
+    int word = 0;
+    if (lane < 2) word = b.in_ptr[r + lane];
+    else if (lane == 2) word = b.mid[r];
+    else if (lane == 3) word = b.chg_off[r];
+    else if (lane < 6 && b.peers) word = b.peers[r + lane - 4];
+    const int in0 = __shfl(word, 0, 64), in1 = __shfl(word, 1, 64), mid = __shfl(word, 2, 64), off = __shfl(word, 3, 64);
+    const int pp0 = __shfl(word, 4, 64), pp1 = __shfl(word, 5, 64);
+    const int n_new = in1 - in0, base_new = K1 * in0;
+    const int o0 = in_old[r], n_old = in_old[r + 1] - o0, base_old = K1 * o0;
+    if (lane == 0) {
+        in_dst[r] = in0;
+        if (r == R - 1) { in_dst[R] = in1; var_ptr[R * K] = K1 * in1; }
+        if (peers_dst) { peers_dst[r] = pp0; if (r == R - 1) peers_dst[R] = pp1; }
     }
-    recs[e] = rec;
-    if (gate) gate[e] = (w.antenna[rec.src_robot] && !w.idle[rec.src_robot]) ? 1 : 0;
-}
-// The host's tables of a topology change — slot records, per-robot slot ranges, the lower / higher key split — travel in ONE pinned
-// block; this kernel takes them apart into their device arrays (16 bytes per thread, the block read once over the host link)
-// and derives the per-variable tables (k_var_tables) from the block itself in the same launch: one launch instead of three
-// copies and one launch on the host's critical path (a world that follows its topology pays for every call, every tick).
-__global__ void k_retopo_unpack(const uint4 *__restrict__ src, int n16_slots, int n16_ptr, int n16_mid, int n16_peers, uint4 *__restrict__ slots,
-                                uint4 *__restrict__ in_ptr_dst, uint4 *__restrict__ mid_dst, uint4 *__restrict__ peers_dst, int R, int K,
-                                int32_t *__restrict__ var_ptr, int32_t *__restrict__ var_mid) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n16_slots) slots[t] = src[t];
-    else if (t < n16_slots + n16_ptr) in_ptr_dst[t - n16_slots] = src[t];
-    else if (t < n16_slots + n16_ptr + n16_mid) mid_dst[t - n16_slots - n16_ptr] = src[t];
-    else if (t < n16_slots + n16_ptr + n16_mid + n16_peers) peers_dst[t - n16_slots - n16_ptr - n16_mid] = src[t];  // (the resident kernel's peer table)
-    if (t > R * K) return;
-    const int32_t *in_ptr = reinterpret_cast<const int32_t *>(src + n16_slots), *in_mid = reinterpret_cast<const int32_t *>(src + n16_slots + n16_ptr);
-    if (t == R * K) { var_ptr[t] = (K - 1) * in_ptr[R]; return; }
-    const int r = t / K, i = t - r * K;
-    const int n_in = in_ptr[r + 1] - in_ptr[r], base = (K - 1) * in_ptr[r];
-    const int p = (i == 0) ? base : base + (i - 1) * n_in;  // variable 0 carries no inter-robot factor
-    var_ptr[t] = p;
-    var_mid[t] = (i == 0) ? p : p + in_mid[r];
+    for (int i = lane; i < K; i += 64) {
+        const int p = (i == 0) ? base_new : base_new + (i - 1) * n_new;  // variable 0 carries no inter-robot factor
+        var_ptr[r * K + i] = p;
+        var_mid[r * K + i] = (i == 0) ? p : p + mid;
+    }
+    if (peers_dst)
+        for (int q = pp0 + lane; q < pp1; q += 64) peers_dst[R + 1 + q] = b.peers[R + 1 + q];
+    const size_t sn = (size_t)stride_new, so = (size_t)w.NI;
+    for (int t = lane; t < n_new * K1; t += 64) {
+        const int j = t / n_new, q = t - j * n_new;
+        IrSlotRec sl;
+        int oq;
+        if (off < 0) { sl = slots_old[o0 + q]; oq = q; }  // (its list did not change: n_old == n_new)
+        else { sl = b.recs[off + q]; oq = sl.old_slot; }  // (old_slot: its position in the robot's list being replaced, -1 = created now)
+        const int e = base_new + j * n_new + q;
+        IrEdgeRec rec;
+        rec.src_var = sl.src_robot * K + j + 1;
+        rec.src_robot = sl.src_robot;
+        rec.dst = (int32_t)(j + 1) | ((sl.flags & 1) ? (1 << 16) : 0);
+        rec.d_safe = sl.d_safe;
+        rec.offset = (double)1e-6f * (double)(sl.first_number + (unsigned long long)j);  // interrobot.rs:52,75
+        if (oq >= 0) {
+            const int o = base_old + j * n_old + oq;
+            fv_eta[0 * sn + e] = w.ir_fv_eta[0 * so + o];
+            fv_eta[1 * sn + e] = w.ir_fv_eta[1 * so + o];
+            fv_lam[0 * sn + e] = w.ir_fv_lam[0 * so + o];
+            fv_lam[1 * sn + e] = w.ir_fv_lam[1 * so + o];
+            fv_lam[4 * sn + e] = w.ir_fv_lam[4 * so + o];
+            fv_lam[5 * sn + e] = w.ir_fv_lam[5 * so + o];
+#pragma unroll
+            for (int c = 0; c < 4; c++) bmu[c * sn + e] = w.ir_bmu[c * so + o];
+            rec.created = w.ir_rec[o].created;
+        } else {
+            fv_eta[0 * sn + e] = 0.0;
+            fv_eta[1 * sn + e] = 0.0;
+            fv_lam[0 * sn + e] = 0.0;
+            fv_lam[1 * sn + e] = 0.0;
+            fv_lam[4 * sn + e] = 0.0;
+            fv_lam[5 * sn + e] = 0.0;
+            const BlobLayout L(K);
+#pragma unroll
+            for (int c = 0; c < 4; c++)  // the target's belief goes into the new factor — which drops it while its kind is off
+                bmu[c * sn + e] = (w.enable & 2u) ? w.blob[(size_t)r * w.BS + L.mu() + c * K + (j + 1)] : 0.0;
+            rec.created = w.snap_epoch[w.cur][rec.src_var];
+        }
+        recs[e] = rec;
+        if (gate) gate[e] = (w.antenna[rec.src_robot] && !w.idle[rec.src_robot]) ? 1 : 0;
+        if (j == 0) {
+            sl.old_slot = q;
+            slots_new[in0 + q] = sl;
+        }
+    }
 }
 // CSR over variables (and the lower-key / higher-key split) from the per-robot slot lists
 __global__ void k_var_tables(int R, int K, const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_mid,
@@ -767,21 +778,12 @@ hipError_t launch_mission_prepare(const DevWorld &w, const DevMission &m, int n,
                        time_scale, what);
     return hipGetLastError();
 }
-hipError_t launch_edge_rebuild(const DevWorld &w, int n_slots, const IrSlotRec *slots, const int32_t *in_new, const int32_t *in_old,
-                               int stride_new, IrEdgeRec *recs, double *fv_eta, double *fv_lam, double *bmu, uint8_t *gate, hipStream_t stream) {
-    const int total = n_slots * (w.K - 1);
-    if (total <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_edge_rebuild, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, n_slots, slots, in_new, in_old,
-                       stride_new, recs, fv_eta, fv_lam, bmu, gate);
-    return hipGetLastError();
-}
-// src: [slots | in_ptr | mid | peers], every part padded to 16 bytes (device-visible pinned memory)
-hipError_t launch_retopo_unpack(const void *src, size_t b_slots, size_t b_ptr, size_t b_mid, size_t b_peers, void *slots, void *in_ptr, void *mid,
-                                void *peers, int R, int K, int32_t *var_ptr, int32_t *var_mid, hipStream_t stream) {
-    const int n16 = (int)((b_slots + b_ptr + b_mid + b_peers) / 16), need = std::max(n16, R * K + 1);
-    hipLaunchKernelGGL(k_retopo_unpack, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, stream, (const uint4 *)src, (int)(b_slots / 16),
-                       (int)(b_ptr / 16), (int)(b_mid / 16), (int)(b_peers / 16), (uint4 *)slots, (uint4 *)in_ptr, (uint4 *)mid, (uint4 *)peers, R,
-                       K, var_ptr, var_mid);
+hipError_t launch_retopo_robots(const DevWorld &w, const RetopoBlock &b, const int32_t *in_old, const IrSlotRec *slots_old, int32_t *in_dst,
+                                IrSlotRec *slots_new, int32_t *peers_dst, int32_t *var_ptr, int32_t *var_mid, int stride_new, IrEdgeRec *recs,
+                                double *fv_eta, double *fv_lam, double *bmu, uint8_t *gate, hipStream_t stream) {
+    if (w.R_local <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_retopo_robots, dim3((unsigned)w.R_local), dim3(64), 0, stream, w, b, in_old, slots_old, in_dst, slots_new, peers_dst, var_ptr,
+                       var_mid, stride_new, recs, fv_eta, fv_lam, bmu, gate);
     return hipGetLastError();
 }
 hipError_t launch_var_tables(int R, int K, const int32_t *in_ptr, const int32_t *in_mid, int32_t *var_ptr, int32_t *var_mid,

@@ -50,10 +50,9 @@ hipError_t launch_mission_reached(const DevWorld &w, const DevMission &m, int n,
 hipError_t launch_mission_positions(const DevMission &m, int n, const int32_t *alive, float *out, hipStream_t stream);
 hipError_t launch_mission_prepare(const DevWorld &w, const DevMission &m, int n, const uint8_t *moving, double *rec, int32_t *robots,
                                   double *waypoints, double *time_scale, uint8_t *what, hipStream_t stream);
-hipError_t launch_retopo_unpack(const void *src, size_t b_slots, size_t b_ptr, size_t b_mid, size_t b_peers, void *slots, void *in_ptr, void *mid,
-                                void *peers, int R, int K, int32_t *var_ptr, int32_t *var_mid, hipStream_t stream);
-hipError_t launch_edge_rebuild(const DevWorld &w, int n_slots, const IrSlotRec *slots, const int32_t *in_new, const int32_t *in_old,
-                               int stride_new, IrEdgeRec *recs, double *fv_eta, double *fv_lam, double *bmu, uint8_t *gate, hipStream_t stream);
+hipError_t launch_retopo_robots(const DevWorld &w, const RetopoBlock &b, const int32_t *in_old, const IrSlotRec *slots_old, int32_t *in_dst,
+                                IrSlotRec *slots_new, int32_t *peers_dst, int32_t *var_ptr, int32_t *var_mid, int stride_new, IrEdgeRec *recs,
+                                double *fv_eta, double *fv_lam, double *bmu, uint8_t *gate, hipStream_t stream);
 hipError_t launch_var_tables(int R, int K, const int32_t *in_ptr, const int32_t *in_mid, int32_t *var_ptr, int32_t *var_mid,
                              hipStream_t stream);
 hipError_t launch_edge_gates(int n, const IrEdgeRec *recs, const uint8_t *antenna, const uint8_t *idle, uint8_t *gate, hipStream_t stream);
@@ -433,7 +432,7 @@ struct mgx_world {
     DevBuf<double> ir_fv_eta_b, ir_fv_lam_b, ir_bmu_b;  // second set: the edge tables are rebuilt out of place
     DevBuf<IrEdgeRec> ir_rec_b;
     DevBuf<int32_t> in_ptr_dev, in_ptr_dev_b, in_mid_dev;  // per-robot slot ranges (current / being built), split index
-    DevBuf<IrSlotRec> slot_recs;
+    DevBuf<IrSlotRec> slot_recs, slot_recs_b;  // slot records of the layout on the device (current / being built): what a robot whose incoming list did not change keeps
     std::vector<int32_t> dev_in_ptr;  // [R_local + 1] incoming-slot ranges of the tables now on the device
     DevBuf<int32_t> trk_record, path_ptr, iter_factor, ir_var_ptr, ir_var_mid;
     DevBuf<uint32_t> epoch0, epoch1;
@@ -520,7 +519,7 @@ struct mgx_world {
     struct ConnHot {
         int32_t owner, other, node_first, node_last;
         uint64_t first_number;
-        int32_t dev_slot;   // slot of this connection in its target's incoming list on the device (-1: not there) — kept HERE only
+        int32_t dev_q;      // position of this connection in its target's incoming list ON THE DEVICE (-1: not there; its slot is dev_in_ptr[target] + dev_q) — kept HERE only
         uint8_t has_fresh;  // some edge still carries `fresh` (created since the device tables were last laid out) — kept HERE only
     };
     std::vector<ConnHot> conn_hot;
@@ -529,8 +528,38 @@ struct mgx_world {
     // prior changes of variables that carry inter-robot factors — what the connections' counters are settled against (IrConn::base)
     struct Cum { std::vector<uint64_t> nIv, nEv, nEf, on_ir; } cum;
     bool conns_unsettled = false;  // some flush since the last full one left the connections' counters behind (lazy)
-    Incoming retopo_tables;               // retopo's host tables and slot records (storage kept from tick to tick)
-    std::vector<IrSlotRec> retopo_slots;
+    std::vector<uint8_t> scratch_dead;    // ir_disconnect_batch's scratch
+    std::vector<int32_t> scratch_dead_list;
+    std::vector<int> scratch_gone;
+    Incoming retopo_tables;               // scratch of the full table builds (MGX_CHECK_INDEX, ensure_resident_tables)
+    // retopo as DIFFERENCES (a world that follows its topology changes a few dozen of its thousands of connections per tick): which
+    // robots' incoming lists / peer lists changed since the device tables were laid out (marked where the connection index is
+    // edited), and what stays from tick to tick — the lower / higher key split and the peer row of every local robot.  `all`: every
+    // robot counts as changed (after commit(), after the index was rebuilt from the list, before the first retopo).
+    struct RetopoInc {
+        bool all = true;
+        std::vector<uint8_t> in_mark, peer_mark;     // [robot ids]
+        std::vector<int32_t> in_changed, peer_changed;  // the ids marked
+        std::vector<int32_t> mid;                    // [R_local]
+        std::vector<int32_t> peer_cnt, peer_rows;    // [R_local], [R_local][pcap]: owners of incoming, targets of outgoing connections (device indices)
+        int pcap = 0;
+        std::vector<int32_t> in_ptr, chg_off, peers;  // per-retopo scratch (storage kept)
+        std::vector<IrSlotRec> recs;
+        void mark_in(int32_t id) {
+            if ((size_t)id >= in_mark.size()) in_mark.resize((size_t)id + 1, 0);
+            if (!in_mark[(size_t)id]) { in_mark[(size_t)id] = 1; in_changed.push_back(id); }
+        }
+        void mark_peer(int32_t id) {
+            if ((size_t)id >= peer_mark.size()) peer_mark.resize((size_t)id + 1, 0);
+            if (!peer_mark[(size_t)id]) { peer_mark[(size_t)id] = 1; peer_changed.push_back(id); }
+        }
+        void clear_marks() {
+            for (int32_t id : in_changed) in_mark[(size_t)id] = 0;
+            for (int32_t id : peer_changed) peer_mark[(size_t)id] = 0;
+            in_changed.clear();
+            peer_changed.clear();
+        }
+    } rinc;
     // missions on the device (mgx_mission_*): host copies of what mgx_mission_set gave, the device arrays, the
     // host-mapped event list of robots that reached their last waypoint, and the tick counter
     struct Mission {
@@ -665,6 +694,11 @@ struct mgx_world {
 };
 
 static size_t edge_index(const std::vector<int32_t> &in_ptr, int K, int r, int j, int slot);
+// slot of connection ci in the tables ON THE DEVICE (-1: not there — created since they were laid out, or its target is another rank's)
+static inline int32_t dev_slot_of(const mgx_world *w, size_t ci) {
+    const mgx_world::ConnHot &h = w->conn_hot[ci];
+    return h.dev_q < 0 ? -1 : w->dev_in_ptr[(size_t)w->dev_of[(size_t)h.other]] + h.dev_q;
+}
 static void flush_counts(mgx_world *w, bool lazy = false);
 static void conn_index_ensure(mgx_world *w);
 

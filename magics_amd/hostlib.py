@@ -139,8 +139,7 @@ SYMBOLS = {
     "mgx_change_priors": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), c_double_p]),
     "mgx_update_priors": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), c_double_p, c_double_p, C.POINTER(C.c_uint8), C.c_double,
                           C.c_double]),
-    "mgx_tick": (C.c_int, [_V, C.c_uint32, C.POINTER(C.c_int32), c_double_p, c_double_p, C.POINTER(C.c_uint8), C.c_double, C.c_double,
-                 C.c_char_p, C.c_uint32]),
+    "mgx_tick": (C.c_int, [_V, C.c_uint32, _V, _V, _V, _V, C.c_double, C.c_double, C.c_char_p, C.c_uint32]),  # (the four arrays as addresses: world.py _arg)
     "mgx_get_belief": (C.c_int, [_V, C.c_int32, C.c_uint32, c_double_p, c_double_p, c_double_p, c_double_p,
                                  C.POINTER(C.c_int32)]),
     "mgx_read_beliefs": (C.c_int, [_V, c_double_p, c_double_p, c_double_p]),
