@@ -58,13 +58,18 @@ struct IrSlotRec {
     double d_safe;          // interrobot.rs:64
     uint64_t first_number;  // robot_number of the factor on variable 1 (robot.rs:1527)
 };
-// what the host sends for a topology change (k_retopo_robots): device-visible pointers into ONE pinned block
+// What the host sends for a topology change (k_retopo_robots): ONE pinned block, read over the host link in as few transactions
+// as its layout allows — a 16-byte header per robot (robot r reads its own and its successor's: one 32-byte read), and, for the
+// robots whose lists changed, their slot records with their peer row right behind (one contiguous piece each).
+struct RetopoHeader {
+    int32_t in0;   // first slot of the robot in the new layout (the successor's in0 ends its range; entry R closes the last one)
+    int32_t pp0;   // first entry of its row in the new peer table
+    int32_t mid;   // first slot whose owner has the HIGHER graph key, relative to the robot's range
+    int32_t off;   // where its piece starts in `data`, in 16-byte units; -1: neither its incoming list nor its peers changed
+};
 struct RetopoBlock {
-    const int32_t *in_ptr;    // [R + 1] slot ranges of the new layout
-    const int32_t *mid;       // [R] first slot whose owner has the HIGHER graph key, relative to the robot's range
-    const int32_t *chg_off;   // [R] where the robot's slot records start in `recs`; -1: its incoming list did not change
-    const int32_t *peers;     // [R + 1 row pointers | entries] the resident kernel's peer table, or null
-    const IrSlotRec *recs;    // slot records of the robots whose list changed (old_slot: position in the robot's OLD list, -1 = created now)
+    const RetopoHeader *hdr;  // [R + 1]
+    const uint4 *data;        // per changed robot: n_in slot records (IrSlotRec, old_slot: position in the robot's OLD list, -1 = created now), then its peer row (int32, padded to 16 bytes)
 };
 
 // EXCHANGE RECORDS of resident schedule launches — the hand-off between neighbouring robots' workgroups (and, on sharded worlds,

@@ -535,29 +535,28 @@ __global__ void k_mission_prepare(DevWorld w, DevMission m, int n, const uint8_t
 // its message (the six live numbers), response mean and creation epoch over from the arrays being replaced; a new one starts
 // empty, created at the owner variable's current delivery count, with the target variable's current belief mean as the response
 // it has seen (robot.rs:1549-1585).  The constant record of every edge is derived here too.
-// What the host sends are DIFFERENCES (RetopoBlock, one pinned block read over the host link): the new slot ranges and key
-// splits of all robots (two words each), the peer table, and slot records ONLY for the robots whose incoming list changed —
-// a robot whose list did not change (chg_off < 0) keeps its slot records (slots_old, on the device since the last pass) and
-// its edges just move by the shift of its range.  The same workgroup writes the robot's part of everything derived: the
-// device copy of the slot ranges (the next pass's "old" ones), the per-variable tables, its peer row, the slot records of the
-// new layout.  ONE launch, no copies, no synchronisation.
+// What the host sends are DIFFERENCES (RetopoBlock, one pinned block read over the host link): a 16-byte header per robot — its
+// slot range, key split and peer-row start in the new layout — and slot records and peer rows ONLY for the robots whose lists
+// changed; everybody else (header.off < 0) keeps the slot records and the peer row the device holds since the last pass
+// (slots_old, peers_old) and its edges just move by the shift of its range.  The same workgroup writes the robot's part of
+// everything derived: the device copy of the slot ranges (the next pass's "old" ones), the per-variable tables, its peer row,
+// the slot records of the new layout.  ONE launch, no copies, no synchronisation; about two reads over the host link per robot
+// (the kernel's time is their number, not their bytes: four scattered words per robot were 19 us for a thousand robots).
 // gate (may be null): the edge's gate byte — its owner is on air — written along (the flags themselves have not changed)
 __global__ void __launch_bounds__(64) k_retopo_robots(DevWorld w, RetopoBlock b, const int32_t *__restrict__ in_old, const IrSlotRec *__restrict__ slots_old,
-                                                      int32_t *__restrict__ in_dst, IrSlotRec *__restrict__ slots_new, int32_t *__restrict__ peers_dst,
-                                                      int32_t *__restrict__ var_ptr, int32_t *__restrict__ var_mid, int stride_new,
-                                                      IrEdgeRec *__restrict__ recs, double *__restrict__ fv_eta, double *__restrict__ fv_lam,
+                                                      const int32_t *__restrict__ peers_old, int32_t *__restrict__ in_dst, IrSlotRec *__restrict__ slots_new,
+                                                      int32_t *__restrict__ peers_dst, int32_t *__restrict__ var_ptr, int32_t *__restrict__ var_mid,
+                                                      int stride_new, IrEdgeRec *__restrict__ recs, double *__restrict__ fv_eta, double *__restrict__ fv_lam,
                                                       double *__restrict__ bmu, uint8_t *__restrict__ gate) {
     const int r = blockIdx.x, lane = threadIdx.x, R = w.R_local, K = w.K, K1 = K - 1;
-    // the robot's six words of the block: one trip over the host link for all of them (lanes 0..5), handed round by shuffles
-    int word = 0;
-    if (lane < 2) word = b.in_ptr[r + lane];
-    else if (lane == 2) word = b.mid[r];
-    else if (lane == 3) word = b.chg_off[r];
-    else if (lane < 6 && b.peers) word = b.peers[r + lane - 4];
-    const int in0 = __shfl(word, 0, 64), in1 = __shfl(word, 1, 64), mid = __shfl(word, 2, 64), off = __shfl(word, 3, 64);
-    const int pp0 = __shfl(word, 4, 64), pp1 = __shfl(word, 5, 64);
+    // the robot's header and its successor's: 32 bytes, one read over the host link (lanes 0 and 1), handed round by shuffles
+    int4 h = {0, 0, 0, 0};
+    if (lane < 2) h = *reinterpret_cast<const int4 *>(&b.hdr[r + lane]);
+    const int in0 = __shfl(h.x, 0, 64), pp0 = __shfl(h.y, 0, 64), mid = __shfl(h.z, 0, 64), off = __shfl(h.w, 0, 64);
+    const int in1 = __shfl(h.x, 1, 64), pp1 = __shfl(h.y, 1, 64);
     const int n_new = in1 - in0, base_new = K1 * in0;
     const int o0 = in_old[r], n_old = in_old[r + 1] - o0, base_old = K1 * o0;
+    const IrSlotRec *mine = off < 0 ? slots_old + o0 : reinterpret_cast<const IrSlotRec *>(b.data + off);  // (its list did not change: n_old == n_new, same positions)
     if (lane == 0) {
         in_dst[r] = in0;
         if (r == R - 1) { in_dst[R] = in1; var_ptr[R * K] = K1 * in1; }
@@ -568,15 +567,15 @@ __global__ void __launch_bounds__(64) k_retopo_robots(DevWorld w, RetopoBlock b,
         var_ptr[r * K + i] = p;
         var_mid[r * K + i] = (i == 0) ? p : p + mid;
     }
-    if (peers_dst)
-        for (int q = pp0 + lane; q < pp1; q += 64) peers_dst[R + 1 + q] = b.peers[R + 1 + q];
+    if (peers_dst) {  // (a row's length is the same in both tables when the robot's lists did not change)
+        const int32_t *row = off < 0 ? peers_old + R + 1 + peers_old[r] : reinterpret_cast<const int32_t *>(b.data + off + 2 * n_new);
+        for (int q = lane; q < pp1 - pp0; q += 64) peers_dst[R + 1 + pp0 + q] = row[q];
+    }
     const size_t sn = (size_t)stride_new, so = (size_t)w.NI;
     for (int t = lane; t < n_new * K1; t += 64) {
         const int j = t / n_new, q = t - j * n_new;
-        IrSlotRec sl;
-        int oq;
-        if (off < 0) { sl = slots_old[o0 + q]; oq = q; }  // (its list did not change: n_old == n_new)
-        else { sl = b.recs[off + q]; oq = sl.old_slot; }  // (old_slot: its position in the robot's list being replaced, -1 = created now)
+        IrSlotRec sl = mine[q];
+        const int oq = sl.old_slot;  // (its position in the robot's list being replaced — its own, where nothing changed; -1 = created now)
         const int e = base_new + j * n_new + q;
         IrEdgeRec rec;
         rec.src_var = sl.src_robot * K + j + 1;
@@ -778,12 +777,12 @@ hipError_t launch_mission_prepare(const DevWorld &w, const DevMission &m, int n,
                        time_scale, what);
     return hipGetLastError();
 }
-hipError_t launch_retopo_robots(const DevWorld &w, const RetopoBlock &b, const int32_t *in_old, const IrSlotRec *slots_old, int32_t *in_dst,
-                                IrSlotRec *slots_new, int32_t *peers_dst, int32_t *var_ptr, int32_t *var_mid, int stride_new, IrEdgeRec *recs,
-                                double *fv_eta, double *fv_lam, double *bmu, uint8_t *gate, hipStream_t stream) {
+hipError_t launch_retopo_robots(const DevWorld &w, const RetopoBlock &b, const int32_t *in_old, const IrSlotRec *slots_old, const int32_t *peers_old,
+                                int32_t *in_dst, IrSlotRec *slots_new, int32_t *peers_dst, int32_t *var_ptr, int32_t *var_mid, int stride_new,
+                                IrEdgeRec *recs, double *fv_eta, double *fv_lam, double *bmu, uint8_t *gate, hipStream_t stream) {
     if (w.R_local <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_retopo_robots, dim3((unsigned)w.R_local), dim3(64), 0, stream, w, b, in_old, slots_old, in_dst, slots_new, peers_dst, var_ptr,
-                       var_mid, stride_new, recs, fv_eta, fv_lam, bmu, gate);
+    hipLaunchKernelGGL(k_retopo_robots, dim3((unsigned)w.R_local), dim3(64), 0, stream, w, b, in_old, slots_old, peers_old, in_dst, slots_new, peers_dst,
+                       var_ptr, var_mid, stride_new, recs, fv_eta, fv_lam, bmu, gate);
     return hipGetLastError();
 }
 hipError_t launch_var_tables(int R, int K, const int32_t *in_ptr, const int32_t *in_mid, int32_t *var_ptr, int32_t *var_mid,

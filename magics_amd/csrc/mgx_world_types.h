@@ -50,9 +50,9 @@ hipError_t launch_mission_reached(const DevWorld &w, const DevMission &m, int n,
 hipError_t launch_mission_positions(const DevMission &m, int n, const int32_t *alive, float *out, hipStream_t stream);
 hipError_t launch_mission_prepare(const DevWorld &w, const DevMission &m, int n, const uint8_t *moving, double *rec, int32_t *robots,
                                   double *waypoints, double *time_scale, uint8_t *what, hipStream_t stream);
-hipError_t launch_retopo_robots(const DevWorld &w, const RetopoBlock &b, const int32_t *in_old, const IrSlotRec *slots_old, int32_t *in_dst,
-                                IrSlotRec *slots_new, int32_t *peers_dst, int32_t *var_ptr, int32_t *var_mid, int stride_new, IrEdgeRec *recs,
-                                double *fv_eta, double *fv_lam, double *bmu, uint8_t *gate, hipStream_t stream);
+hipError_t launch_retopo_robots(const DevWorld &w, const RetopoBlock &b, const int32_t *in_old, const IrSlotRec *slots_old, const int32_t *peers_old,
+                                int32_t *in_dst, IrSlotRec *slots_new, int32_t *peers_dst, int32_t *var_ptr, int32_t *var_mid, int stride_new,
+                                IrEdgeRec *recs, double *fv_eta, double *fv_lam, double *bmu, uint8_t *gate, hipStream_t stream);
 hipError_t launch_var_tables(int R, int K, const int32_t *in_ptr, const int32_t *in_mid, int32_t *var_ptr, int32_t *var_mid,
                              hipStream_t stream);
 hipError_t launch_edge_gates(int n, const IrEdgeRec *recs, const uint8_t *antenna, const uint8_t *idle, uint8_t *gate, hipStream_t stream);
@@ -442,7 +442,7 @@ struct mgx_world {
     // resident schedule launches (SegPlan, mgx_dev.h): progress words, peer lists, the abort / error words
     DevBuf<unsigned long long> sweep_flag_buf, sweep_abort_buf;
     DevBuf<unsigned char> xrec_buf;  // exchange records of the local robots' variables, two parities (mgx_dev.h)
-    DevBuf<int32_t> peer_ptr_dev;  // [R + 1 row pointers | entries]
+    DevBuf<int32_t> peer_ptr_dev, peer_ptr_dev_b;  // [R + 1 row pointers | entries] (current / being built by a topology change)
     size_t peer_idx_off = 0;
     std::vector<int32_t> peer_fill;
     unsigned long long *sweep_err_host = nullptr;  // host-mapped; non-zero once a wait inside a resident launch gave up
@@ -534,17 +534,15 @@ struct mgx_world {
     Incoming retopo_tables;               // scratch of the full table builds (MGX_CHECK_INDEX, ensure_resident_tables)
     // retopo as DIFFERENCES (a world that follows its topology changes a few dozen of its thousands of connections per tick): which
     // robots' incoming lists / peer lists changed since the device tables were laid out (marked where the connection index is
-    // edited), and what stays from tick to tick — the lower / higher key split and the peer row of every local robot.  `all`: every
+    // edited), and what stays from tick to tick on the host — the lower / higher key split of every local robot.  `all`: every
     // robot counts as changed (after commit(), after the index was rebuilt from the list, before the first retopo).
     struct RetopoInc {
         bool all = true;
         std::vector<uint8_t> in_mark, peer_mark;     // [robot ids]
         std::vector<int32_t> in_changed, peer_changed;  // the ids marked
-        std::vector<int32_t> mid;                    // [R_local]
-        std::vector<int32_t> peer_cnt, peer_rows;    // [R_local], [R_local][pcap]: owners of incoming, targets of outgoing connections (device indices)
-        int pcap = 0;
-        std::vector<int32_t> in_ptr, chg_off, peers;  // per-retopo scratch (storage kept)
-        std::vector<IrSlotRec> recs;
+        std::vector<int32_t> mid;                    // [R_local] the lower / higher key split of every robot's list on the device
+        std::vector<int32_t> in_ptr;                 // per-retopo scratch (storage kept)
+        std::vector<uint8_t> mark;                   // [R_local] this pass sends the robot's piece
         void mark_in(int32_t id) {
             if ((size_t)id >= in_mark.size()) in_mark.resize((size_t)id + 1, 0);
             if (!in_mark[(size_t)id]) { in_mark[(size_t)id] = 1; in_changed.push_back(id); }
