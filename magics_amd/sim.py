@@ -39,6 +39,7 @@ class Simulation:
         path, and the checker of the other one: tests/test_gpu_sim.py)."""
         self.dev = hasattr(world, "mission_tick_begin") if device_missions is None else bool(device_missions)
         self._pending_track = None
+        self._trk_log = []  # what _track noted since _tracks last ran
         self.name = scenario.get("name", "")
         self.cfg, self.env, self.formations = scenario["config"], scenario["environment"], scenario["formation"]["formations"]
         self.w = world
@@ -150,19 +151,32 @@ class Simulation:
     # PositionTracker / VelocityTracker (planner/tracking.rs:104-122,189-218; 100 ms timers, spawner.rs:620-621):
     # FixedUpdate systems over Changed<Transform>, i.e. the robots that moved this tick; sampled after the move
     def _track(self, moving, translation, now):
-        for r in moving:
-            r["trk_elapsed"] += self.dt_ns
-            if r["trk_elapsed"] < 100_000_000:
-                continue
-            r["trk_elapsed"] %= 100_000_000
-            pos = translation[r["id"]].copy()
-            r["positions"].append([float(pos[0]), float(pos[2])])
-            if r["trk_prev"] is not None:
-                dt = now - r["trk_prev"][1]
-                v = (pos - r["trk_prev"][0]) / F(dt)
-                r["velocities"].append({"velocity": [float(v[0]), float(v[1]), float(v[2])], "timestamp": now,
-                                        "measured_over": {"secs": int(dt), "nanos": int(round((dt - int(dt)) * 1e9))}})
-            r["trk_prev"] = (pos, now)
+        """track_robots (export.rs / tracking: a sample of every moving robot's Transform every 100 ms of simulated time).  The tick
+        only NOTES what the samples are taken from — the moving robots' ids and their rows of the Transforms; the per-robot lists
+        the export holds (positions, velocities with their measuring spans) are made from the notes when somebody reads them
+        (_tracks): a dictionary per robot per tick was a fifth of a scenario's wall time."""
+        if moving:
+            ids = np.fromiter((r["id"] for r in moving), dtype=np.int64, count=len(moving))
+            self._trk_log.append((ids, np.asarray(translation)[ids].copy(), now))
+
+    def _tracks(self):
+        """bring every robot's positions / velocities up to the last tick noted by _track"""
+        log, self._trk_log = self._trk_log, []
+        for ids, rows, now in log:
+            for k, rid in enumerate(ids):
+                r = self.robots[int(rid)]
+                r["trk_elapsed"] += self.dt_ns
+                if r["trk_elapsed"] < 100_000_000:
+                    continue
+                r["trk_elapsed"] %= 100_000_000
+                pos = rows[k]
+                r["positions"].append([float(pos[0]), float(pos[2])])
+                if r["trk_prev"] is not None:
+                    dt = now - r["trk_prev"][1]
+                    v = (pos - r["trk_prev"][0]) / F(dt)
+                    r["velocities"].append({"velocity": [float(v[0]), float(v[1]), float(v[2])], "timestamp": now,
+                                            "measured_over": {"secs": int(dt), "nanos": int(round((dt - int(dt)) * 1e9))}})
+                r["trk_prev"] = (pos, now)
 
     # update_robot_robot_collisions (planner/collisions.rs:72-140, FixedUpdate): every pair of live robots, bounding
     # spheres of their Ball(radius) at the Transform's (x, z) — parry2d 0.13 BoundingSphere::intersects, restated from its
@@ -272,8 +286,7 @@ class Simulation:
     def _quiet_ticks(self, cap):
         """how many ticks, the coming one included, pass before a spawner acts again (becomes ready, or runs out): the
         spawners' timers run ahead on copies"""
-        import copy
-        sps = copy.deepcopy(self.spawners)
+        sps = [sp.clone() for sp in self.spawners]
         n = 0
         while n < cap:
             was = [sp.exhausted() for sp in sps]
@@ -337,6 +350,7 @@ class Simulation:
     def export(self):
         if self.dev:
             self._flush_trackers(synchronise=True)
+        self._tracks()
         sch = self.cfg["gbp"]["iteration-schedule"]
         robots = {}
         for r in self.robots:

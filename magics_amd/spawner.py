@@ -175,6 +175,13 @@ class FormationSpawner:  # spawner.rs:221-312
             if self.timer.just_finished():
                 self.state = self.FINISHED if self.timer.exhausted() else self.READY
 
+    def clone(self):
+        """a copy whose timers run independently (all state is scalars; the formation itself is not copied)"""
+        import copy
+        c = copy.copy(self)
+        c.timer = copy.copy(self.timer)
+        return c
+
     def ready_to_spawn(self):
         return self.state == self.READY
 
