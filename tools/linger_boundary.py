@@ -8,16 +8,19 @@ from magics_amd import World, scenarios as S
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 sc = S.grid_scenario(n, 16, interrobot=True)
 w = World(sc["params"]); S.populate(w, sc)
-res = {}
-for mult in (1, 2, 3, 1, 2, 3):
-    steps = sc["steps"] * mult
-    reps = 600 // mult
-    for _ in range(30): w.iterate(steps)
-    w.synchronize(); t0 = time.perf_counter()
-    for _ in range(reps): w.iterate(steps)
-    w.synchronize(); dt = (time.perf_counter() - t0) / reps * 1e6
-    res[mult] = min(res.get(mult, 1e9), dt)
-c = (res[3] - res[1]) / 20.0
-b = res[1] - 10 * c
-print(os.environ.get("MGX_LIB", "product"), "linger", os.environ.get("MGX_LINGER", "default"), {k: round(v, 2) for k, v in res.items()},
-      "us/iteration %.3f  us/boundary %.2f" % (c, b), w.linger_stats() if hasattr(w._L, "mgx_linger_stats") else None)
+tk = S.tick_inputs(sc)
+for mode in ("iterate", "tick"):  # (tick: the same schedules with the prior updates of all robots riding in every post)
+    res = {}
+    for mult in (1, 2, 3, 1, 2, 3):
+        steps = bytes(sc["steps"] * mult)
+        call = (lambda: w.iterate(steps)) if mode == "iterate" else (lambda: w.tick(steps=steps, **tk))
+        reps = 600 // mult
+        for _ in range(30): call()
+        w.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps): call()
+        w.synchronize(); dt = (time.perf_counter() - t0) / reps * 1e6
+        res[mult] = min(res.get(mult, 1e9), dt)
+    c = (res[3] - res[1]) / 20.0
+    b = res[1] - 10 * c
+    print(os.environ.get("MGX_LIB", "product"), "linger", os.environ.get("MGX_LINGER", "default"), mode, {k: round(v, 2) for k, v in res.items()},
+          "us/iteration %.3f  us/boundary %.2f" % (c, b), w.linger_stats() if hasattr(w._L, "mgx_linger_stats") else None)
