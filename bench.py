@@ -981,24 +981,30 @@ def main():
             nxt, _, _ = wd.update_topology(base, 8.0, 1)
             wd.iterate(sc3["steps"])
             wd.synchronize()
-            n_dyn, made, gone = 60, 0, 0
+            n_dyn, n_blocks, n_warm, made, gone = 60, 3, 30, 0, 0
             # (the robots' positions of every tick are this measurement's INPUT: drawn before the clock starts, like every other
-            # synthetic input of the bench; five untimed ticks first — the first one sizes tables and asks for the launch's capacity)
-            poss = [base + rng.normal(0, 0.15, size=base.shape).astype(np.float32) for _ in range(n_dyn + 5)]
-            for pos in poss[:5]:
+            # synthetic input of the bench; untimed ticks first — the first one sizes tables and asks for the launch's capacity, and
+            # the GPU has idled through seconds of host work: the `tick` figure's protocol, a pre-heat and the median of the blocks)
+            poss = [base + rng.normal(0, 0.15, size=base.shape).astype(np.float32) for _ in range(n_warm + n_blocks * n_dyn)]
+            for pos in poss[:n_warm]:
                 nxt, _, _ = wd.update_topology(pos, 8.0, nxt)
                 wd.tick(steps=sc3["steps"], **tk3)
-            wd.synchronize()
-            t0 = time.perf_counter()
-            for pos in poss[5:]:
-                nxt, c, d = wd.update_topology(pos, 8.0, nxt)
-                wd.tick(steps=sc3["steps"], **tk3)
-                made, gone = made + c, gone + d
-            wd.synchronize()
-            line["dynamic_tick"] = {"value": round(n_dyn / (time.perf_counter() - t0), 1), "unit": "driver ticks/s per GPU",
+            rates = []
+            for b in range(n_blocks):
+                wd.synchronize()
+                t0 = time.perf_counter()
+                for pos in poss[n_warm + b * n_dyn:n_warm + (b + 1) * n_dyn]:
+                    nxt, c, d = wd.update_topology(pos, 8.0, nxt)
+                    wd.tick(steps=sc3["steps"], **tk3)
+                    made, gone = made + c, gone + d
+                wd.synchronize()
+                rates.append(n_dyn / (time.perf_counter() - t0))
+            n_all = n_blocks * n_dyn
+            line["dynamic_tick"] = {"value": round(statistics.median(rates), 1), "unit": "driver ticks/s per GPU", "min": round(min(rates), 1),
+                                    "max": round(max(rates), 1), "ticks_per_block": n_dyn,
                                     "what": f"{n_loc} robots x {K}: comms-range search + factor create/delete (on average "
-                                            f"{made / n_dyn:.0f} connections created, {gone / n_dyn:.0f} pairs deleted per tick) + prior "
-                                            "updates + 10 GBP iterations with inter-robot factors"}
+                                            f"{made / n_all:.0f} connections created, {gone / n_all:.0f} pairs deleted per tick) + prior "
+                                            f"updates + 10 GBP iterations with inter-robot factors; median of {n_blocks} blocks after {n_warm} untimed ticks"}
         except Exception as e:  # noqa: BLE001
             line["dynamic_tick"] = {"error": f"{type(e).__name__}: {e}"}
         try:
