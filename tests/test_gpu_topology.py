@@ -298,3 +298,16 @@ def test_one_pass_search_grows_its_rows():
         for method in (hostlib.NEIGHBOURS_AUTO, PAIRS, GRID):
             assert same_csr(eng.neighbours(pos, radius, method), want), (radius, method)
     assert int(np.diff(want[0]).max()) < n
+
+
+def test_topology_differences_are_cross_checked():
+    """Topology changes reach the device as differences (retopo, k_retopo_robots: slot records and peer rows only of the robots
+    whose lists changed).  In a process of its own with MGX_CHECK_INDEX on from the start, every block that goes out is compared
+    with tables built from the whole connection list, and the world — churn, a robot removed on the way, ticks and plain schedules
+    mixed, a read-back in between — stays the oracle's bit for bit (tests/topology_check_worker.py)."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "topology_check_worker.py"), "180", "24"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "OK 180 robots" in out, out[-3000:]
