@@ -873,16 +873,22 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
         const unsigned cstride = 16u * (unsigned)K;
 #pragma unroll
         for (int ch = 0; ch < XREC_CHUNKS; ch++) R[ch] = v4u32{0u, 0u, 0u, 0u};
+        // (ghost records crossed the fabric: their sequence word carries a mix of the payload it arrived with, mgx_dev.h — undone
+        // ONCE, where a chunk is fetched, and only in waves that gather a ghost record at all: fifteen mixes per look of every lane
+        // of every robot were 0.7 us of a sharded world's iteration)
+        const bool remote = SHARD && (off_mine & GHOST_BIT) != 0u;
+        const bool any_remote = SHARD && __ballot(remote) != 0ull;
         if (mine) {
 #pragma unroll
             for (int ch = 0; ch < XREC_CHUNKS; ch++) R[ch] = fetch(off_mine + (unsigned)ch * cstride);
         }
-        // (ghost records crossed the fabric: their sequence word carries a mix of the payload it arrived with, mgx_dev.h)
-        const bool remote = SHARD && (off_mine & GHOST_BIT) != 0u;
-        auto word_of = [&](const v4u32 &c) __attribute__((always_inline)) {
-            if constexpr (SHARD) return remote ? (c.w ^ xrec_mix(c.x, c.y, c.z)) : c.w;
-            return c.w;
-        };
+        if constexpr (SHARD) {  // (behind ALL the fetches: a mix between two of them would wait for the first before asking for the second)
+            if (any_remote) {
+#pragma unroll
+                for (int ch = 0; ch < XREC_CHUNKS; ch++) R[ch].w ^= remote ? xrec_mix(R[ch].x, R[ch].y, R[ch].z) : 0u;
+            }
+        }
+        auto word_of = [&](const v4u32 &c) __attribute__((always_inline)) { return c.w; };
         long long t0 = 0;
         for (unsigned spins = 0;; spins++) {
             bool missing = false;
@@ -908,9 +914,17 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                 if (__ballot(stop) != 0ull) break;  // (the launch ends with wrong beliefs; the host reports it)
             }
             if (missing) {
+                unsigned again = 0u;  // the chunks asked for again
 #pragma unroll
                 for (int ch = 0; ch < XREC_CHUNKS; ch++)
-                    if (word_of(R[ch]) != seq) R[ch] = fetch(off_mine + (unsigned)ch * cstride);
+                    if (word_of(R[ch]) != seq) { again |= 1u << ch; R[ch] = fetch(off_mine + (unsigned)ch * cstride); }
+                if constexpr (SHARD) {
+                    if (remote) {
+#pragma unroll
+                        for (int ch = 0; ch < XREC_CHUNKS; ch++)
+                            if ((again >> ch) & 1u) R[ch].w ^= xrec_mix(R[ch].x, R[ch].y, R[ch].z);
+                    }
+                }
             }
         }
         auto D = [&](int n) __attribute__((always_inline)) { return R[n / 3][n % 3]; };  // payload dword n
