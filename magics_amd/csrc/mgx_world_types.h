@@ -299,6 +299,18 @@ struct ConnSets {
     std::vector<uint8_t> ghost;   // the robots' ghost flags and radii, compact like the keys (fixed when a robot is added): the
     std::vector<double> radius;   // per-tick passes over all connections read them instead of the robots themselves
     std::vector<uint8_t> removed; // ... and Robot::removed (mgx_robot_remove)
+    // ids ascending == order keys ascending?  (the rule: robots get their keys in the order they are added.)  Looked at once per
+    // robot count: the per-tick merges then compare ids instead of looking two keys up per comparison.
+    size_t mono_n = 0;
+    bool mono = true;
+    bool monotone() {
+        if (mono_n != keys.size()) {
+            mono = true;
+            for (size_t r = 1; r < keys.size() && mono; r++) mono = keys[r - 1] < keys[r];
+            mono_n = keys.size();
+        }
+        return mono;
+    }
     void ensure(size_t n) {
         if (cnt.size() < n) { cnt.resize(n, 0); ids.resize(n * (size_t)cap, 0); }
     }
@@ -531,6 +543,8 @@ struct mgx_world {
     std::vector<uint8_t> scratch_dead;    // ir_disconnect_batch's scratch
     std::vector<int32_t> scratch_dead_list;
     std::vector<int> scratch_gone;
+    std::vector<int> scratch_victim;      // topology_bookkeeping's scratch
+    std::vector<std::pair<int, int>> scratch_fresh;
     Incoming retopo_tables;               // scratch of the full table builds (MGX_CHECK_INDEX, ensure_resident_tables)
     // retopo as DIFFERENCES (a world that follows its topology changes a few dozen of its thousands of connections per tick): which
     // robots' incoming lists / peer lists changed since the device tables were laid out (marked where the connection index is
