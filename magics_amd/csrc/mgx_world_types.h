@@ -544,6 +544,10 @@ struct mgx_world {
     std::vector<int32_t> scratch_dead_list;
     std::vector<int> scratch_gone;
     std::vector<int> scratch_victim;      // topology_bookkeeping's scratch
+    // storage of deleted connections' edge and node lists, handed to the connections created next (a topology pass deletes and
+    // creates dozens per tick: 3 KB from the allocator and back for each was a third of the pass's bookkeeping)
+    std::vector<std::vector<IrEdge>> pool_edges;
+    std::vector<std::vector<int>> pool_nodes;
     std::vector<std::pair<int, int>> scratch_fresh;
     Incoming retopo_tables;               // scratch of the full table builds (MGX_CHECK_INDEX, ensure_resident_tables)
     // retopo as DIFFERENCES (a world that follows its topology changes a few dozen of its thousands of connections per tick): which
