@@ -531,7 +531,7 @@ __global__ void k_mission_prepare(DevWorld w, DevMission m, int n, const uint8_t
 // In-place topology change.  A robot's incoming connections are kept as one sorted list of SLOTS;
 // every connection hangs one factor on each of the target's variables 1..K-1, so the edges of
 // variable i of robot r are  (K-1) * in_ptr[r] + (i-1) * n_in(r) + q,  q = position in the list.
-// k_retopo_robots lays out the new edge arrays from the old ones, one 64-lane workgroup per robot: a surviving connection carries
+// k_retopo_robots lays out the new edge arrays from the old ones, one workgroup of two waves per robot: a surviving connection carries
 // its message (the six live numbers), response mean and creation epoch over from the arrays being replaced; a new one starts
 // empty, created at the owner variable's current delivery count, with the target variable's current belief mean as the response
 // it has seen (robot.rs:1549-1585).  The constant record of every edge is derived here too.
@@ -543,17 +543,19 @@ __global__ void k_mission_prepare(DevWorld w, DevMission m, int n, const uint8_t
 // the slot records of the new layout.  ONE launch, no copies, no synchronisation; about two reads over the host link per robot
 // (the kernel's time is their number, not their bytes: four scattered words per robot were 19 us for a thousand robots).
 // gate (may be null): the edge's gate byte — its owner is on air — written along (the flags themselves have not changed)
-__global__ void __launch_bounds__(64) k_retopo_robots(DevWorld w, RetopoBlock b, const int32_t *__restrict__ in_old, const IrSlotRec *__restrict__ slots_old,
+constexpr int RETOPO_THREADS = 128;  // two waves per robot: a robot's hundred-odd edges are ONE round of dependent loads instead of two
+__global__ void __launch_bounds__(RETOPO_THREADS) k_retopo_robots(DevWorld w, RetopoBlock b, const int32_t *__restrict__ in_old, const IrSlotRec *__restrict__ slots_old,
                                                       const int32_t *__restrict__ peers_old, int32_t *__restrict__ in_dst, IrSlotRec *__restrict__ slots_new,
                                                       int32_t *__restrict__ peers_dst, int32_t *__restrict__ var_ptr, int32_t *__restrict__ var_mid,
                                                       int stride_new, IrEdgeRec *__restrict__ recs, double *__restrict__ fv_eta, double *__restrict__ fv_lam,
                                                       double *__restrict__ bmu, uint8_t *__restrict__ gate) {
     const int r = blockIdx.x, lane = threadIdx.x, R = w.R_local, K = w.K, K1 = K - 1;
-    // the robot's header and its successor's: 32 bytes, one read over the host link (lanes 0 and 1), handed round by shuffles
-    int4 h = {0, 0, 0, 0};
-    if (lane < 2) h = *reinterpret_cast<const int4 *>(&b.hdr[r + lane]);
-    const int in0 = __shfl(h.x, 0, 64), pp0 = __shfl(h.y, 0, 64), mid = __shfl(h.z, 0, 64), off = __shfl(h.w, 0, 64);
-    const int in1 = __shfl(h.x, 1, 64), pp1 = __shfl(h.y, 1, 64);
+    // the robot's header and its successor's: 32 bytes, one read over the host link (threads 0 and 1), handed round through LDS
+    __shared__ int4 s_h[2];
+    if (lane < 2) s_h[lane] = *reinterpret_cast<const int4 *>(&b.hdr[r + lane]);
+    __syncthreads();
+    const int in0 = s_h[0].x, pp0 = s_h[0].y, mid = s_h[0].z, off = s_h[0].w;
+    const int in1 = s_h[1].x, pp1 = s_h[1].y;
     const int n_new = in1 - in0, base_new = K1 * in0;
     const int o0 = in_old[r], n_old = in_old[r + 1] - o0, base_old = K1 * o0;
     const IrSlotRec *mine = off < 0 ? slots_old + o0 : reinterpret_cast<const IrSlotRec *>(b.data + off);  // (its list did not change: n_old == n_new, same positions)
@@ -562,17 +564,17 @@ __global__ void __launch_bounds__(64) k_retopo_robots(DevWorld w, RetopoBlock b,
         if (r == R - 1) { in_dst[R] = in1; var_ptr[R * K] = K1 * in1; }
         if (peers_dst) { peers_dst[r] = pp0; if (r == R - 1) peers_dst[R] = pp1; }
     }
-    for (int i = lane; i < K; i += 64) {
+    for (int i = lane; i < K; i += RETOPO_THREADS) {
         const int p = (i == 0) ? base_new : base_new + (i - 1) * n_new;  // variable 0 carries no inter-robot factor
         var_ptr[r * K + i] = p;
         var_mid[r * K + i] = (i == 0) ? p : p + mid;
     }
     if (peers_dst) {  // (a row's length is the same in both tables when the robot's lists did not change)
         const int32_t *row = off < 0 ? peers_old + R + 1 + peers_old[r] : reinterpret_cast<const int32_t *>(b.data + off + 2 * n_new);
-        for (int q = lane; q < pp1 - pp0; q += 64) peers_dst[R + 1 + pp0 + q] = row[q];
+        for (int q = lane; q < pp1 - pp0; q += RETOPO_THREADS) peers_dst[R + 1 + pp0 + q] = row[q];
     }
     const size_t sn = (size_t)stride_new, so = (size_t)w.NI;
-    for (int t = lane; t < n_new * K1; t += 64) {
+    for (int t = lane; t < n_new * K1; t += RETOPO_THREADS) {
         const int j = t / n_new, q = t - j * n_new;
         IrSlotRec sl = mine[q];
         const int oq = sl.old_slot;  // (its position in the robot's list being replaced — its own, where nothing changed; -1 = created now)
@@ -781,7 +783,7 @@ hipError_t launch_retopo_robots(const DevWorld &w, const RetopoBlock &b, const i
                                 int32_t *in_dst, IrSlotRec *slots_new, int32_t *peers_dst, int32_t *var_ptr, int32_t *var_mid, int stride_new,
                                 IrEdgeRec *recs, double *fv_eta, double *fv_lam, double *bmu, uint8_t *gate, hipStream_t stream) {
     if (w.R_local <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_retopo_robots, dim3((unsigned)w.R_local), dim3(64), 0, stream, w, b, in_old, slots_old, peers_old, in_dst, slots_new, peers_dst,
+    hipLaunchKernelGGL(k_retopo_robots, dim3((unsigned)w.R_local), dim3(RETOPO_THREADS), 0, stream, w, b, in_old, slots_old, peers_old, in_dst, slots_new, peers_dst,
                        var_ptr, var_mid, stride_new, recs, fv_eta, fv_lam, bmu, gate);
     return hipGetLastError();
 }
