@@ -186,9 +186,12 @@ __global__ void __launch_bounds__(ROWS_BLOCK) k_pairs_rows(const float *__restri
 // robot) and writes the row; more than `cap`
 // hits are counted only (the host then repeats the search with more room — beyond 32 per row with the all-pairs kernel).
 constexpr int GRID_BLOCK = 128, GRID_ROBOTS = GRID_BLOCK / 2, GRID_M = 1024;
+constexpr int NEIGHBOURS_PREV_STRIDE = 33;  // words per robot of the kept rows: count, then up to 32 entries
+constexpr int32_t NEIGHBOURS_CHANGED = 1 << 30;  // in a robot's count: its row is not the one of the search before
 template <int REG>
 __global__ void __launch_bounds__(GRID_BLOCK) k_grid_rows(const float *__restrict__ pos, int n, float s_max, double inv_cell, int32_t cap,
-                                                          int32_t *__restrict__ cnt, int32_t *__restrict__ rows) {
+                                                          int32_t *__restrict__ cnt, int32_t *__restrict__ rows, int32_t *__restrict__ prev,
+                                                          int prev_valid) {
     extern __shared__ float lds_pos[];
     const int npad = (n + 3) & ~3;
     float *X = lds_pos, *Y = lds_pos + npad, *Z = lds_pos + 2 * npad;
@@ -281,6 +284,17 @@ __global__ void __launch_bounds__(GRID_BLOCK) k_grid_rows(const float *__restric
     const float ax = X[ii], ay = Y[ii], az = Z[ii];
     int32_t *row = rows + (size_t)ii * (size_t)cap;
     const bool wild = !finite3(ax, ay, az);
+    // prev (may be null): the row this robot got in the search before — its connection set, when that search's pass went through
+    // (the host says so: prev_valid).  Asked for here, compared at the end: a robot whose row did not change needs nothing from
+    // the host's pass (no NEIGHBOURS_CHANGED in its count), and a world that follows its topology changes a fifth of its rows per tick.
+    int32_t *pr = prev ? prev + (size_t)ii * NEIGHBOURS_PREV_STRIDE : nullptr;
+    int32_t pv[REG];
+    int pc = -1;
+    if (pr && live && !wild && h == 0) {
+        pc = pr[0];
+#pragma unroll
+        for (int p = 0; p < REG; p++) pv[p] = pr[1 + p];
+    }
     int m = 0;
     if (live && wild && h == 0) {  // compared with everybody, ascending by construction
         for (int j = 0; j < n; j++)
@@ -288,7 +302,8 @@ __global__ void __launch_bounds__(GRID_BLOCK) k_grid_rows(const float *__restric
                 if (m < cap) row[m] = j;
                 m++;
             }
-        cnt[i] = m;
+        cnt[i] = pr ? (m | NEIGHBOURS_CHANGED) : m;
+        if (pr) pr[0] = -1;  // (no row kept for it: changed, this time and the next)
     }
     uint16_t *mine = hit + tid * REG;  // (a lane's own REG words)
     if (live && !wild) {
@@ -323,8 +338,11 @@ __global__ void __launch_bounds__(GRID_BLOCK) k_grid_rows(const float *__restric
     if (!live || wild || h == 1) return;
     const int m0 = m, m1 = m_other;
     m = m0 + m1;
-    cnt[i] = m;
-    if (m > cap || m > REG) return;  // the host repeats the search with more room: nobody reads this row
+    if (m > cap || m > REG) {  // the host repeats the search with more room: nobody reads this row
+        cnt[i] = pr ? (m | NEIGHBOURS_CHANGED) : m;
+        if (pr) pr[0] = -1;
+        return;
+    }
     // the row in ascending order: the hits came in bucket order — into registers, an odd-even transposition sort, out
     const uint16_t *theirs = mine + REG;
     int32_t keep[REG];
@@ -343,6 +361,16 @@ __global__ void __launch_bounds__(GRID_BLOCK) k_grid_rows(const float *__restric
 #pragma unroll
     for (int p = 0; p < REG; p++)
         if (p < m) row[p] = keep[p];
+    if (pr) {
+        bool same = prev_valid != 0 && pc == m;
+#pragma unroll
+        for (int p = 0; p < REG; p++)
+            if (p < m) { same = same && pv[p] == keep[p]; pr[1 + p] = keep[p]; }
+        pr[0] = m;
+        cnt[i] = same ? m : (m | NEIGHBOURS_CHANGED);  // (the flag rides in the count: no write of its own over the host link)
+    } else {
+        cnt[i] = m;
+    }
 }
 
 // the largest f32 s with RN_f32(sqrt(s)) <= radius (see in_comms_range_sq); NaN radius -> NaN (everybody in range), radius < 0 ->
@@ -374,7 +402,12 @@ static size_t neighbours_rows_lds(int n, int32_t cap) {
     return sizeof(float) * 3 * npad + sizeof(int32_t) * ((size_t)GRID_M + GRID_BLOCK) +
            sizeof(uint16_t) * ((size_t)GRID_M + 2 + 2 * npad + (size_t)GRID_BLOCK * (cap <= 16 ? 16 : 32));
 }
-hipError_t neighbours_rows(const float *pos, int n, float radius, int32_t cap, int32_t *cnt, int32_t *rows, hipStream_t s, float *stage) {
+int neighbours_prev_stride() { return NEIGHBOURS_PREV_STRIDE; }
+int32_t neighbours_changed_bit() { return NEIGHBOURS_CHANGED; }
+// prev / prev_valid (may be null / 0): see k_grid_rows; *flagged says whether the kernel that ran marks the counts of changed rows
+hipError_t neighbours_rows(const float *pos, int n, float radius, int32_t cap, int32_t *cnt, int32_t *rows, hipStream_t s, float *stage,
+                           int32_t *prev, int prev_valid, bool *flagged) {
+    if (flagged) *flagged = false;
     if (n <= 0) return hipSuccess;
     if (stage) {
         hipLaunchKernelGGL(k_stage_positions, dim3((unsigned)((3 * n + 63) / 64)), dim3(64), 0, s, pos, stage, 3 * n);
@@ -386,8 +419,10 @@ hipError_t neighbours_rows(const float *pos, int n, float radius, int32_t cap, i
     if (n <= GRID_M && cap <= 32 && std::isfinite(radius) && radius > 0.f) {  // the grid in LDS (a usable radius, room for the rows in registers)
         const double inv_cell = 1.0 / ((double)radius * 1.001);
         const dim3 grid((unsigned)((n + GRID_ROBOTS - 1) / GRID_ROBOTS));
-        if (cap <= 16) hipLaunchKernelGGL(k_grid_rows<16>, grid, dim3(GRID_BLOCK), neighbours_rows_lds(n, 16), s, pos, n, s_max, inv_cell, cap, cnt, rows);
-        else hipLaunchKernelGGL(k_grid_rows<32>, grid, dim3(GRID_BLOCK), neighbours_rows_lds(n, 32), s, pos, n, s_max, inv_cell, cap, cnt, rows);
+        if (!flagged) prev = nullptr;  // (a caller that does not ask cannot read flagged counts)
+        if (cap <= 16) hipLaunchKernelGGL(k_grid_rows<16>, grid, dim3(GRID_BLOCK), neighbours_rows_lds(n, 16), s, pos, n, s_max, inv_cell, cap, cnt, rows, prev, prev_valid);
+        else hipLaunchKernelGGL(k_grid_rows<32>, grid, dim3(GRID_BLOCK), neighbours_rows_lds(n, 32), s, pos, n, s_max, inv_cell, cap, cnt, rows, prev, prev_valid);
+        if (flagged) *flagged = prev != nullptr;
         return hipGetLastError();
     }
     if (n > 512 && n <= 1024)

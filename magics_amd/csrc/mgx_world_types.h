@@ -71,7 +71,10 @@ hipError_t neighbours_count(const float *pos, int n, float radius, bool grid, ui
 hipError_t neighbours_fill(const float *pos, int n, float radius, bool grid, uint32_t M, const int32_t *bucket_ptr,
                            const int32_t *members, const int32_t *special, const int32_t *n_special, const int32_t *ptr,
                            int32_t *idx, int32_t cap, hipStream_t s);
-hipError_t neighbours_rows(const float *pos, int n, float radius, int32_t cap, int32_t *cnt, int32_t *rows, hipStream_t s, float *stage);
+hipError_t neighbours_rows(const float *pos, int n, float radius, int32_t cap, int32_t *cnt, int32_t *rows, hipStream_t s, float *stage,
+                           int32_t *prev = nullptr, int prev_valid = 0, bool *flagged = nullptr);
+int neighbours_prev_stride();
+int32_t neighbours_changed_bit();
 }  // namespace mgx
 
 using namespace mgx;
@@ -544,6 +547,7 @@ struct mgx_world {
     std::vector<int32_t> scratch_dead_list;
     std::vector<int> scratch_gone;
     std::vector<int> scratch_victim;      // topology_bookkeeping's scratch
+    std::vector<uint8_t> scratch_chg;     // neighbours_collect: the rows-changed flags taken out of the counts
     // storage of deleted connections' edge and node lists, handed to the connections created next (a topology pass deletes and
     // creates dozens per tick: 3 KB from the allocator and back for each was a third of the pass's bookkeeping)
     std::vector<std::vector<IrEdge>> pool_edges;
@@ -617,6 +621,7 @@ struct mgx_world {
         int n = 0, n_all = 0;
         std::vector<int> alive;
         size_t guess = 0, off_ptr = 0, off_idx = 0;
+        bool has_chg = false;  // rows mode: the counts carry "this robot's row changed" (see nb_prev)
         float radius = 0.f;
         uint32_t method = 0, M = 0;
     } mission_search;  // the coming tick's search, enqueued by mgx_mission_tick_end
@@ -688,6 +693,12 @@ struct mgx_world {
     DevBuf<int32_t> nb_cnt, nb_bucket_cnt, nb_bucket_ptr, nb_cursor, nb_members, nb_special, nb_nspecial, nb_ptr, nb_idx;
     size_t nb_last_total = 0;  // rows of the last search: sizes the speculative second pass of the next one
     int nb_row_cap = 16;       // one-pass searches: capacity of a row (grown to what the largest row needed)
+    // The rows of the last topology pass's search, kept on the device: after a pass a robot's connection set IS its row, so the
+    // next search can say which robots' rows changed (k_grid_rows) and the host's pass looks at those only.  nb_prev_valid: the
+    // kept rows are the sets — false whenever the sets were touched by anything but a pass that compared against them.
+    DevBuf<int32_t> nb_prev;
+    bool nb_prev_valid = false;
+    size_t nb_prev_n = 0;
     hipStream_t search_stream = nullptr, nb_last_stream = nullptr;  // searches over host-supplied positions run beside the world's stream
     bool nb_last_stream_set = false;
     // pinned host memory the search's positions go up from and its rows come back into: copies to and from pageable memory
