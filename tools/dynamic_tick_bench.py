@@ -18,6 +18,7 @@ tk = S.tick_inputs(sc)
 nxt, _, _ = w.update_topology(base, 8.0, 1)
 w.iterate(sc["steps"]); w.synchronize()
 out = []
+per_tick = []
 for b in range(blocks):
     poss = [base + rng.normal(0, 0.15, size=base.shape).astype(np.float32) for _ in range(n_dyn + 5)]
     for pos in poss[:5]:
@@ -27,10 +28,13 @@ for b in range(blocks):
     t0 = time.perf_counter()
     for pos in poss[5:]:
         a = time.perf_counter(); nxt, c, d = w.update_topology(pos, 8.0, nxt); m = time.perf_counter()
-        w.tick(steps=sc["steps"], **tk); t_tick += time.perf_counter() - m; t_top += m - a
+        w.tick(steps=sc["steps"], **tk); e = time.perf_counter(); t_tick += e - m; t_top += m - a
+        per_tick.append((e - a) * 1e6)
     w.synchronize()
     dt = time.perf_counter() - t0
     out.append(f"{n_dyn / dt:.0f}/s (topology {t_top / n_dyn * 1e6:.0f} us, tick {t_tick / n_dyn * 1e6:.0f} us)")
+pt = np.array(per_tick)
+print(f"per tick: median {np.median(pt):.0f} us, 90 % {np.percentile(pt, 90):.0f}, max {pt.max():.0f}; ticks over twice the median: {int((pt > 2 * np.median(pt)).sum())} of {len(pt)}")
 st = w.linger_stats() if hasattr(w._L, "mgx_linger_stats") else None
 print("resident launches / declined / back-off left", w.resident_stats(), end=" | ")
 print(os.environ.get("MGX_LIB", "product"), "linger", os.environ.get("MGX_LINGER", "default"), "|", " | ".join(out), "| linger stats", st)
