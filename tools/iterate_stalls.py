@@ -25,7 +25,7 @@ w.synchronize()
 total = time.perf_counter() - t[0]
 d = np.diff(t) * 1e6
 med = float(np.median(d))
-big = np.nonzero(d > 10 * med)[0]
+big = np.nonzero(d > float(os.environ.get("MGX_STALL_FACTOR", "10")) * med)[0]
 print(f"{mode}: {calls} calls in {total * 1e3:.1f} ms = {total / calls / 10 * 1e6:.2f} us per iteration; median call {med:.1f} us; "
       f"{len(big)} calls over {10 * med:.0f} us, {d[big].sum() / 1e3:.1f} ms in all; without them {(total * 1e6 - d[big].sum() + len(big) * med) / calls / 10:.2f} us per iteration")
 for i in big[:12]:
