@@ -2123,15 +2123,8 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
             if (last_seg) {
                 const int plans_done = (int)ps_word(0);
                 any_sweep = (ps_word(2) & 2u) != 0u;
-                if (role == ROLE_UV && pending) finish(s_snap, true);
-                pending = false;
-                __syncthreads();
-                const int iu = role == 0 ? K - 1 : 0;
-                // (parked behind the response means in the scratch sums' block, idle between the plans)
-                if (lane < 20 && role < 2) s_tmp[4 * K + role * 20 + lane] = any_sweep ? s_prior[lane * K + iu] : blob[L.bel() + lane * K + iu];
-                if (role == ROLE_DYN && any_sweep) copy_words_wave(blob + L.bel(), s_prior, 20 * K, lane);
-                StageRegs<(KT > 0 ? 20 * KT : 2), NT> r_prior;
-                if constexpr (KT > 0) r_prior.load(blob + L.prior(), tid);
+                // (the wave that polls is the one with nothing left to do in this plan: the other one's last variable sweep — its means,
+                // covariances — runs while the poll's round trip is under way)
                 // Wave 0 polls: lanes 0 .. 7 the chunks of the next plan, 8 .. 10 this robot's prior-update record, lane 11 the go word —
                 // ONE round trip where the post is there already (the rule: the host runs a plan or two ahead).  Chunks complete (their
                 // sequence word is the post's): the plan will run — the postman moved the word before it wrote them.  The word odd at
@@ -2180,6 +2173,15 @@ __global__ void __launch_bounds__((sweep_threads<KT, PERSIST>()), 2) k_robot_swe
                     }
                     if (lane == 0) *s_verdict = verdict;
                 }
+                if (role == ROLE_UV && pending) finish(s_snap, true);
+                pending = false;
+                __syncthreads();
+                const int iu = role == 0 ? K - 1 : 0;
+                // (parked behind the response means in the scratch sums' block, idle between the plans)
+                if (lane < 20 && role < 2) s_tmp[4 * K + role * 20 + lane] = any_sweep ? s_prior[lane * K + iu] : blob[L.bel() + lane * K + iu];
+                if (role == ROLE_DYN && any_sweep) copy_words_wave(blob + L.bel(), s_prior, 20 * K, lane);
+                StageRegs<(KT > 0 ? 20 * KT : 2), NT> r_prior;
+                if constexpr (KT > 0) r_prior.load(blob + L.prior(), tid);
                 __syncthreads();
                 if (*s_verdict != 1) break;  // the launch ends behind this plan
                 if (lane == 0) s_ps[0] = (uint32_t)(plans_done + 1);  // (every wave's own copy)
