@@ -87,3 +87,26 @@ def test_counts_follow_topology_changes_and_removal():
         if tick % 5 == 4:
             same_counts(eng, ref, n, f"tick {tick}")
     assert_identical(eng, ref, what="topology + removal with counts")
+
+
+def test_counts_over_a_log_that_fills():
+    """A driver that iterates without reading: the engine's launch log takes three entries per schedule and is flushed when it
+    holds four thousand — summed once per class of robots (on air / silent / idle), a robot walking it only while its tracking
+    gate is closed (mgx_world_counters.inc).  1500 schedules of a small world with tracking factors, one robot silent and one
+    idle from the start, a robot idle until half way: counters and beliefs equal the oracle's at the end."""
+    n = 6
+    sc = S.grid_scenario(n, 10, interrobot=True, tracking=True, pitch=2.5, comm_radius=5.0)
+    eng, ref = make_pair(sc)
+    for w in (eng, ref):
+        w.set_antenna(1, False)  # silent: internal sweeps only
+        w.set_idle(4, True)      # idle: nothing
+        w.set_idle(2, True)      # ... until half way (its tracking gate opens in the SECOND log)
+        w.iterate([1, 2, 3])     # (the gate of the others: still closed when the long run begins)
+    steps = sc["steps"]
+    for w in (eng, ref):
+        for i in range(1500):
+            if i == 1400:
+                w.set_idle(2, False)
+            w.iterate(steps)
+    same_counts(eng, ref, n, "1500 schedules")
+    assert_identical(eng, ref, what="1500 schedules, nothing read in between")
